@@ -1,0 +1,104 @@
+"""ctypes binding of libic3rollout.so (include/ic3_rollout.h).  No fallback: import errors are fatal."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libic3rollout.so")
+
+ENV_PP, ENV_TJ = 1, 2
+PP_MODES = {"mixed": 0, "cooperative": 1, "competitive": 2}
+TJ_DIFFICULTY = {"easy": 0, "medium": 1, "hard": 2}
+
+
+class PPCfg(C.Structure):
+    _fields_ = [("E", C.c_int32), ("N", C.c_int32), ("nprey", C.c_int32), ("dim", C.c_int32), ("vision", C.c_int32),
+                ("mode", C.c_int32), ("stay", C.c_int32), ("moving_prey", C.c_int32), ("seed", C.c_uint32),
+                ("env_id_offset", C.c_uint32)]
+
+
+class TJCfg(C.Structure):
+    _fields_ = [("E", C.c_int32), ("N", C.c_int32), ("dim", C.c_int32), ("vision", C.c_int32),
+                ("difficulty", C.c_int32), ("vocab_type", C.c_int32), ("add_rate_min", C.c_double),
+                ("add_rate_max", C.c_double), ("curr_start", C.c_double), ("curr_end", C.c_double),
+                ("seed", C.c_uint32), ("env_id_offset", C.c_uint32)]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "E", "N", "obs_dim", "vocab", "naction", "window", "npath",
+                                         "narrival", "max_route_len", "grid_h", "grid_w", "state_words")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("success_sum", C.c_double), ("add_rate", C.c_double), ("episodes", C.c_int64),
+                ("live_env_steps", C.c_int64)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "ic3_version": (C.c_int, []),
+    "ic3_last_error": (C.c_char_p, []),
+    "ic3_pp_create": (C.c_int, [C.POINTER(PPCfg), C.c_int, C.POINTER(C.c_void_p)]),
+    "ic3_tj_create": (C.c_int, [C.POINTER(TJCfg), C.c_int, C.POINTER(C.c_void_p)]),
+    "ic3_env_destroy": (C.c_int, [C.c_void_p]),
+    "ic3_env_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
+    "ic3_env_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ic3_env_step": (C.c_int, [C.c_void_p] * 7 + [C.c_void_p]),
+    "ic3_env_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ic3_env_check": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ic3_env_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ic3_env_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ic3_env_state_field": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ic3_tj_get_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ic3_tj_build_tables": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t]),
+    "ic3_tj_get_add_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ic3_env_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    "ic3_comm_masked_mean": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "ic3_sample_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                     C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+class IC3Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libic3rollout.so (built by __graft_entry__.build() / `make -C ic3net_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise IC3Error("%s is missing: build it with `make -C ic3net_amd/csrc` (hipcc, gfx950). "
+                           "There is no CPU fallback." % SO_PATH)
+        l = C.CDLL(SO_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, exc=IC3Error):
+    if rc < 0:
+        msg = lib().ic3_last_error().decode("utf-8", "replace")
+        if rc == -38:
+            raise NotImplementedError(msg)
+        if rc == -22 and exc is IC3Error:
+            raise ValueError(msg)
+        raise exc(msg)
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

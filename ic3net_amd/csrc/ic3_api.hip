@@ -1,0 +1,377 @@
+// ic3_api.hip — C ABI entry points of libic3rollout.so (declared in include/ic3_rollout.h).
+#include <cstring>
+#include <new>
+
+#include "ic3_common.hpp"
+
+namespace ic3 {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+// stats: sum over envs of a per-env int32 flag (success / has_failed) + live step counter
+__global__ __launch_bounds__(256) void stats_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ tstep,
+                                                    double* __restrict__ out, int E, int invert)
+{
+    __shared__ double sh[2][4];
+    double a = 0.0, b = 0.0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        const int f = flag[e];
+        a += (double)(invert ? 1 - f : f);
+        b += (double)tstep[e];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o);
+        b += __shfl_down(b, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sh[0][wave] = a;
+        sh[1][wave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+        atomicAdd(&out[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    }
+}
+
+int env_stats(ic3_env* env, ic3_stats* out, hipStream_t s)
+{
+    IC3_HIP(hipMemsetAsync(env->d_stats, 0, 2 * sizeof(double), s));
+    const int E = env->dims.E;
+    int blocks = (E + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const bool pp = env->kind == IC3_ENV_PP;
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, s, env->f(pp ? "success" : "has_failed"), env->f("t"),
+                       env->d_stats, E, pp ? 0 : 1);
+    IC3_HIP(hipGetLastError());
+    double h[2];
+    IC3_HIP(hipMemcpyAsync(h, env->d_stats, sizeof(h), hipMemcpyDeviceToHost, s));
+    IC3_HIP(hipStreamSynchronize(s));
+    out->success_sum = h[0];
+    out->live_env_steps = (int64_t)h[1];
+    out->add_rate = pp ? 0.0 : env->add_rate;
+    out->episodes = env->resets * (int64_t)E;
+    return 0;
+}
+
+static void add_field(ic3_env* env, const char* name, int64_t count)
+{
+    int64_t off = env->fields.empty() ? 0 : env->fields.back().off + env->fields.back().count;
+    env->fields.push_back({ name, off, count });
+}
+
+static int finish_create(ic3_env* env, int device)
+{
+    env->device = device;
+    int64_t words = env->fields.back().off + env->fields.back().count;
+    env->dims.state_words = (int32_t)words;
+    IC3_HIP(hipSetDevice(device));
+    IC3_HIP(hipMalloc(&env->state, (size_t)words * sizeof(int32_t)));
+    IC3_HIP(hipMemset(env->state, 0, (size_t)words * sizeof(int32_t)));
+    // episode counters start at -1 so that the first reset plays episode 0
+    {
+        int64_t off = 0, cnt = 0;
+        for (auto& f : env->fields)
+            if (!strcmp(f.name, "episode")) { off = f.off; cnt = f.count; }
+        IC3_HIP(hipMemset(env->state + off, 0xff, (size_t)cnt * sizeof(int32_t)));
+    }
+    IC3_HIP(hipMalloc(&env->d_err, sizeof(int32_t)));
+    IC3_HIP(hipMemset(env->d_err, 0, sizeof(int32_t)));
+    IC3_HIP(hipMalloc(&env->d_stats, 2 * sizeof(double)));
+    return 0;
+}
+
+}  // namespace ic3
+
+int32_t* ic3_env::f(const char* name) const
+{
+    for (const auto& fl : fields)
+        if (!strcmp(fl.name, name)) return state + fl.off;
+    return nullptr;
+}
+
+using namespace ic3;
+
+extern "C" {
+
+int ic3_version(void) { return IC3_VERSION; }
+const char* ic3_last_error(void) { return g_err.c_str(); }
+
+int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out)
+{
+    if (!cfg || !out) return fail(-22, "ic3_pp_create: null argument");
+    if (cfg->moving_prey) return fail(-38, "moving_prey: NotImplementedError (predator_prey_env.py:84-85)");
+    if (cfg->E <= 0 || cfg->N <= 0 || cfg->N > 64 || cfg->dim <= 0 || cfg->vision < 0)
+        return fail(-22, "ic3_pp_create: need E>0, 0<N<=64, dim>0, vision>=0");
+    if (cfg->nprey != 1) return fail(-22, "ic3_pp_create: only nenemies=1 works in the reference (predator_prey_env.py:258)");
+    if (cfg->N + cfg->nprey > cfg->dim * cfg->dim) return fail(-22, "ic3_pp_create: more entities than cells");
+    if (cfg->mode < 0 || cfg->mode > 2)
+        return fail(-22, "Incorrect mode, Available modes: [cooperative|competitive|mixed]");
+    ic3_env* env = new (std::nothrow) ic3_env();
+    if (!env) return fail(-12, "out of memory");
+    env->kind = IC3_ENV_PP;
+    env->pp = *cfg;
+    ic3_dims& d = env->dims;
+    d.kind = IC3_ENV_PP;
+    d.E = cfg->E;
+    d.N = cfg->N;
+    d.window = 2 * cfg->vision + 1;
+    d.vocab = cfg->dim * cfg->dim + 4;               // predator_prey_env.py:103
+    d.obs_dim = d.window * d.window * d.vocab;       // :107 (only the product is used, env_wrappers.py:31)
+    d.naction = cfg->stay ? 5 : 4;                   // :90-93
+    d.grid_h = d.grid_w = cfg->dim;
+    const int64_t E = cfg->E, N = cfg->N, T = cfg->N + cfg->nprey;
+    add_field(env, "loc_r", E * T);
+    add_field(env, "loc_c", E * T);
+    add_field(env, "reached", E * N);
+    add_field(env, "over", E);
+    add_field(env, "success", E);
+    add_field(env, "episode", E);
+    add_field(env, "t", E);
+    int rc = finish_create(env, device);
+    if (rc) { ic3_env_destroy(env); return rc; }
+    *out = env;
+    return 0;
+}
+
+int ic3_tj_create(const ic3_tj_cfg* cfg, int device, ic3_env** out)
+{
+    if (!cfg || !out) return fail(-22, "ic3_tj_create: null argument");
+    if (cfg->vocab_type != 0) return fail(-38, "vocab_type 'scalar' is not implemented (SURVEY 8(f) f3)");
+    if (cfg->E <= 0 || cfg->N <= 0 || cfg->N > 64 || cfg->vision < 0)
+        return fail(-22, "ic3_tj_create: need E>0, 0<N<=64, vision>=0");
+    ic3_env* env = new (std::nothrow) ic3_env();
+    if (!env) return fail(-12, "out of memory");
+    env->kind = IC3_ENV_TJ;
+    env->tj = *cfg;
+    int h, w, base, npath, narrival, rpa;
+    std::string err;
+    int rc = tj_build_tables(cfg->dim, cfg->vision, cfg->difficulty, &h, &w, &base, &npath, &narrival, &rpa, env->h_grid,
+                             env->h_route_off, env->h_route_rc, err);
+    if (rc) { delete env; return fail(rc, err); }
+    ic3_dims& d = env->dims;
+    d.kind = IC3_ENV_TJ;
+    d.E = cfg->E;
+    d.N = cfg->N;
+    d.window = 2 * cfg->vision + 1;
+    d.vocab = base + 3;                                  // traffic_junction_env.py:134
+    d.obs_dim = 2 + d.window * d.window * d.vocab;       // Tuple(Discrete, Discrete, MultiBinary) env_wrappers.py:21-29
+    d.naction = 2;                                       // :108
+    d.npath = npath;
+    d.narrival = narrival;
+    d.grid_h = h;
+    d.grid_w = w;
+    d.max_route_len = 0;
+    for (int p = 0; p < npath; ++p) {
+        const int len = env->h_route_off[p + 1] - env->h_route_off[p];
+        if (len > d.max_route_len) d.max_route_len = len;
+    }
+    env->exact_rate = env->add_rate = cfg->add_rate_min;  // :103
+    env->epoch_last_update = 0;                           // :104
+    const int64_t E = cfg->E, N = cfg->N;
+    for (const char* nm : { "alive", "wait", "loc_r", "loc_c", "last_act", "route_loc", "route_id", "is_completed" })
+        add_field(env, nm, E * N);
+    for (const char* nm : { "cars_in_sys", "has_failed", "over", "episode", "t" }) add_field(env, nm, E);
+    rc = finish_create(env, device);
+    if (rc) { ic3_env_destroy(env); return rc; }
+    std::vector<int32_t> packed(env->h_route_rc.size() / 2);
+    for (size_t i = 0; i < packed.size(); ++i) packed[i] = (env->h_route_rc[2 * i] << 16) | env->h_route_rc[2 * i + 1];
+    hipError_t e1 = hipMalloc(&env->d_grid, env->h_grid.size() * 4);
+    hipError_t e2 = hipMalloc(&env->d_route_off, env->h_route_off.size() * 4);
+    hipError_t e3 = hipMalloc(&env->d_route_rc, packed.size() * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { ic3_env_destroy(env); return fail(-12, "hipMalloc failed"); }
+    (void)hipMemcpy(env->d_grid, env->h_grid.data(), env->h_grid.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(env->d_route_off, env->h_route_off.data(), env->h_route_off.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(env->d_route_rc, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+    *out = env;
+    return 0;
+}
+
+int ic3_env_destroy(ic3_env* env)
+{
+    if (!env) return 0;
+    (void)hipFree(env->state);
+    (void)hipFree(env->d_err);
+    (void)hipFree(env->d_stats);
+    (void)hipFree(env->d_grid);
+    (void)hipFree(env->d_route_off);
+    (void)hipFree(env->d_route_rc);
+    delete env;
+    return 0;
+}
+
+int ic3_env_dims(const ic3_env* env, ic3_dims* out)
+{
+    if (!env || !out) return fail(-22, "ic3_env_dims: null argument");
+    *out = env->dims;
+    return 0;
+}
+
+// traffic_junction_env.py:196-200 gating + :620-626 curriculum (host-side scalars; every env of the
+// handle sees the same epoch sequence, so they share one add_rate exactly like N reference instances).
+static double py_float_floordiv(double vx, double wx)
+{
+    double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0 && ((wx < 0) != (mod < 0))) div -= 1.0;
+    if (div == 0.0) return copysign(0.0, vx / wx);
+    double fl = floor(div);
+    if (div - fl > 0.5) fl += 1.0;
+    return fl;
+}
+
+int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
+{
+    if (!env) return fail(-22, "ic3_env_reset: null handle");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (env->kind == IC3_ENV_PP) {
+        rc = pp_reset(env, s);
+    } else {
+        const ic3_tj_cfg& c = env->tj;
+        const double epoch_range = c.curr_end - c.curr_start, rate_range = c.add_rate_max - c.add_rate_min;
+        if (epoch >= 0 && epoch_range > 0 && rate_range > 0 && (double)epoch > env->epoch_last_update) {
+            if (c.curr_start <= (double)epoch && (double)epoch < c.curr_end) {
+                const double step = rate_range / epoch_range;
+                env->exact_rate = env->exact_rate + step;
+                env->add_rate = 0.01 * py_float_floordiv(env->exact_rate, 0.01);  // Python float `//`, quirk Q16
+            }
+            env->epoch_last_update = (double)epoch;
+        }
+        rc = tj_reset(env, s);
+    }
+    if (rc) return rc;
+    env->resets += 1;
+    if (obs) return ic3_env_observe(env, obs, stream);
+    return 0;
+}
+
+int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream)
+{
+    if (!env || !obs) return fail(-22, "ic3_env_observe: null argument");
+    return env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
+}
+
+int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,
+                 int32_t* is_completed, ic3_stream stream)
+{
+    if (!env || !actions || !reward || !done) return fail(-22, "ic3_env_step: null argument");
+    if (env->resets == 0) return fail(-22, "ic3_env_step: reset() has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = env->kind == IC3_ENV_PP ? pp_step(env, actions, reward, done, alive, is_completed, s)
+                                     : tj_step(env, actions, reward, done, alive, is_completed, s);
+    if (rc) return rc;
+    if (obs) return ic3_env_observe(env, obs, stream);
+    return 0;
+}
+
+int ic3_env_check(ic3_env* env, ic3_stream stream)
+{
+    if (!env) return fail(-22, "ic3_env_check: null handle");
+    int32_t h = 0;
+    IC3_HIP(hipMemcpyAsync(&h, env->d_err, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    IC3_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (h) {
+        IC3_HIP(hipMemsetAsync(env->d_err, 0, sizeof(int32_t), (hipStream_t)stream));
+        return fail(-22, "Actions should be in the range [0,naction).");
+    }
+    return 0;
+}
+
+int ic3_env_get_state(const ic3_env* env, int32_t* host_out, size_t bytes, ic3_stream stream)
+{
+    if (!env || !host_out) return fail(-22, "ic3_env_get_state: null argument");
+    if (bytes != (size_t)env->dims.state_words * 4) return fail(-22, "ic3_env_get_state: size mismatch");
+    IC3_HIP(hipMemcpyAsync(host_out, env->state, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    IC3_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int ic3_env_set_state(ic3_env* env, const int32_t* host_in, size_t bytes, ic3_stream stream)
+{
+    if (!env || !host_in) return fail(-22, "ic3_env_set_state: null argument");
+    if (bytes != (size_t)env->dims.state_words * 4) return fail(-22, "ic3_env_set_state: size mismatch");
+    IC3_HIP(hipMemcpyAsync(env->state, host_in, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    IC3_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (env->resets == 0) env->resets = 1;
+    return 0;
+}
+
+int ic3_env_state_field(const ic3_env* env, const char* name, int64_t* offset_words, int64_t* count_words)
+{
+    if (!env || !name) return fail(-22, "ic3_env_state_field: null argument");
+    for (const auto& f : env->fields)
+        if (!strcmp(f.name, name)) {
+            if (offset_words) *offset_words = f.off;
+            if (count_words) *count_words = f.count;
+            return 0;
+        }
+    return fail(-2, std::string("no such state field: ") + name);
+}
+
+int ic3_tj_get_tables(const ic3_env* env, int32_t* grid, int32_t* route_off, int32_t* route_rc, size_t rc_capacity_words)
+{
+    if (!env || env->kind != IC3_ENV_TJ) return fail(-22, "ic3_tj_get_tables: not a Traffic-Junction handle");
+    if (grid) memcpy(grid, env->h_grid.data(), env->h_grid.size() * 4);
+    if (route_off) memcpy(route_off, env->h_route_off.data(), env->h_route_off.size() * 4);
+    if (route_rc) {
+        if (rc_capacity_words < env->h_route_rc.size()) return fail(-22, "ic3_tj_get_tables: route_rc buffer too small");
+        memcpy(route_rc, env->h_route_rc.data(), env->h_route_rc.size() * 4);
+    }
+    return (int)env->h_route_rc.size();  // words needed for route_rc
+}
+
+int ic3_tj_build_tables(int dim, int vision, int difficulty, ic3_dims* dims_out, int32_t* grid, int32_t* route_off,
+                        int32_t* route_rc, size_t rc_capacity_words)
+{
+    int h, w, base, npath, narrival, rpa;
+    std::vector<int32_t> g, off, rc;
+    std::string err;
+    int r = tj_build_tables(dim, vision, difficulty, &h, &w, &base, &npath, &narrival, &rpa, g, off, rc, err);
+    if (r) return fail(r, err);
+    if (dims_out) {
+        memset(dims_out, 0, sizeof(*dims_out));
+        dims_out->kind = IC3_ENV_TJ;
+        dims_out->window = 2 * vision + 1;
+        dims_out->vocab = base + 3;
+        dims_out->obs_dim = 2 + dims_out->window * dims_out->window * dims_out->vocab;
+        dims_out->naction = 2;
+        dims_out->npath = npath;
+        dims_out->narrival = narrival;
+        dims_out->grid_h = h;
+        dims_out->grid_w = w;
+        for (int p = 0; p < npath; ++p)
+            if (off[p + 1] - off[p] > dims_out->max_route_len) dims_out->max_route_len = off[p + 1] - off[p];
+    }
+    if (grid) memcpy(grid, g.data(), g.size() * 4);
+    if (route_off) memcpy(route_off, off.data(), off.size() * 4);
+    if (route_rc) {
+        if (rc_capacity_words < rc.size()) return fail(-22, "ic3_tj_build_tables: route_rc buffer too small");
+        memcpy(route_rc, rc.data(), rc.size() * 4);
+    }
+    return (int)rc.size();
+}
+
+int ic3_tj_get_add_rate(const ic3_env* env, double* add_rate, double* exact_rate)
+{
+    if (!env || env->kind != IC3_ENV_TJ) return fail(-22, "ic3_tj_get_add_rate: not a Traffic-Junction handle");
+    if (add_rate) *add_rate = env->add_rate;
+    if (exact_rate) *exact_rate = env->exact_rate;
+    return 0;
+}
+
+int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream)
+{
+    if (!env || !host_out) return fail(-22, "ic3_env_stats: null argument");
+    return env_stats(env, host_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// ic3_common.hpp — shared declarations of libic3rollout (MI355X / gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ic3_rollout.h"
+
+namespace ic3 {
+
+// Random stream contract: x24 = Philox4x32-10((draw, t, episode, domain), (seed, env_gid))[0] >> 8
+enum : uint32_t { DOMAIN_PP_RESET = 1, DOMAIN_TJ_ADD = 2, DOMAIN_SAMPLE = 3, DOMAIN_BENCH = 4 };
+
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+__host__ __device__ inline uint32_t philox_x24(uint32_t seed, uint32_t env_gid, uint32_t domain, uint32_t episode,
+                                               uint32_t t, uint32_t draw)
+{
+    uint32_t c0 = draw, c1 = t, c2 = episode, c3 = domain, k0 = seed, k1 = env_gid;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0 >> 8;
+}
+
+// floor(u * n) with u = x24 / 2^24, exact in integers
+__host__ __device__ inline uint32_t scale24(uint32_t x24, uint32_t n) { return (uint32_t)(((uint64_t)x24 * n) >> 24); }
+
+struct Field {
+    const char* name;
+    int64_t off;    // int32 words from state base
+    int64_t count;  // int32 words
+};
+
+// smallest power of two >= n (n <= 64): lanes per environment in the per-agent kernels
+inline int group_lanes(int n)
+{
+    int g = 1;
+    while (g < n) g <<= 1;
+    return g;
+}
+
+}  // namespace ic3
+
+struct ic3_env {
+    int kind = 0;
+    int device = 0;
+    ic3_dims dims{};
+    ic3_pp_cfg pp{};
+    ic3_tj_cfg tj{};
+    int32_t* state = nullptr;  // device, dims.state_words int32
+    std::vector<ic3::Field> fields;
+    int32_t* d_err = nullptr;  // sticky bad-action flag
+    double* d_stats = nullptr; // small device scratch for ic3_env_stats
+    int64_t resets = 0;
+    // Traffic-Junction constant tables (device + host copies)
+    int32_t* d_grid = nullptr;       // [h*w] road ids
+    int32_t* d_route_off = nullptr;  // [npath+1]
+    int32_t* d_route_rc = nullptr;   // [total] packed (row << 16 | col)
+    std::vector<int32_t> h_grid, h_route_off, h_route_rc;  // h_route_rc: (row, col) pairs
+    // curriculum scalars (traffic_junction_env.py:103-104)
+    double exact_rate = 0, add_rate = 0, epoch_last_update = 0;
+
+    int32_t* f(const char* name) const;
+};
+
+namespace ic3 {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define IC3_HIP(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            return ic3::fail(-5 /*EIO*/, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+// pp_kernels.hip
+int pp_reset(ic3_env* env, hipStream_t s);
+int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
+            hipStream_t s);
+int pp_observe(ic3_env* env, float* obs, hipStream_t s);
+// tj_kernels.hip
+int tj_reset(ic3_env* env, hipStream_t s);
+int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
+            hipStream_t s);
+int tj_observe(ic3_env* env, float* obs, hipStream_t s);
+// tj_tables.cpp (host)
+int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
+                    int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,
+                    std::vector<int32_t>& route_rc, std::string& err);
+// stats
+int env_stats(ic3_env* env, ic3_stats* out, hipStream_t s);
+
+}  // namespace ic3

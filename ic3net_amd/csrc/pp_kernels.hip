@@ -1,0 +1,278 @@
+// pp_kernels.hip — Predator-Prey: reset / step / observation assembly for E environments (gfx950).
+//
+// Reference semantics: /root/reference/ic3net-envs/ic3net_envs/predator_prey_env.py (cited "PP:line").
+// State is struct-of-arrays in HBM, one int32 array per field, env-major ([e][n]) so that the lane
+// mapping (env, agent) -> consecutive lanes reads/writes consecutive words.
+#include "ic3_common.hpp"
+
+namespace ic3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: one global_store_dwordx4
+
+// ------------------------------------------------------------------------------------------------
+// reset: PP:146-168 + _get_cordinates PP:173-175 (np.random.choice(dim*dim, N+nprey, replace=False))
+// = sequential rejection sampling of distinct cells on the injected stream.  One lane per env (the
+// draw sequence is inherently serial; runs once per episode).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pp_reset_kernel(int32_t* __restrict__ loc_r, int32_t* __restrict__ loc_c,
+                                                       int32_t* __restrict__ reached, int32_t* __restrict__ over,
+                                                       int32_t* __restrict__ success, int32_t* __restrict__ episode,
+                                                       int32_t* __restrict__ tstep, int E, int N, int nprey, int dim,
+                                                       uint32_t seed, uint32_t gid0)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int total = N + nprey;
+    const uint32_t ncell = (uint32_t)(dim * dim);
+    const uint32_t ep = (uint32_t)(episode[e] + 1);
+    int32_t* r = loc_r + (size_t)e * total;
+    int32_t* c = loc_c + (size_t)e * total;
+    int n = 0;
+    uint32_t d = 0;
+    while (n < total) {
+        const uint32_t k = scale24(philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_PP_RESET, ep, 0u, d), ncell);
+        ++d;
+        const int kr = (int)(k / (uint32_t)dim), kc = (int)(k % (uint32_t)dim);
+        bool dup = false;
+        for (int j = 0; j < n; ++j) dup |= (r[j] == kr) & (c[j] == kc);  // own earlier writes (same thread)
+        if (!dup) {
+            r[n] = kr;
+            c[n] = kc;
+            ++n;
+        }
+    }
+    for (int i = 0; i < N; ++i) reached[(size_t)e * N + i] = 0;  // PP:155
+    over[e] = 0;                                                  // PP:154
+    success[e] = 0;
+    episode[e] = (int32_t)ep;
+    tstep[e] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// step: PP:112-144 = _take_action for every predator (PP:212-252), then _get_reward (PP:254-290).
+// G = pow2 >= N lanes per env; the per-env reductions (predators on prey, all reached) are wave
+// ballots restricted to the env's lane group.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool padded_outside(int pr, int pc, int v, int dim)
+{
+    return pr < v || pr >= v + dim || pc < v || pc >= v + dim;  // np.pad(grid, vision, OUTSIDE_CLASS) PP:184
+}
+
+__global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_r, int32_t* __restrict__ loc_c,
+                                                      int32_t* __restrict__ reached, int32_t* __restrict__ over,
+                                                      int32_t* __restrict__ success, int32_t* __restrict__ tstep,
+                                                      const int32_t* __restrict__ actions, float* __restrict__ reward,
+                                                      int32_t* __restrict__ done, int32_t* __restrict__ alive_out,
+                                                      int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E,
+                                                      int N, int nprey, int dim, int v, int mode, int naction, int G)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid / G, n = tid - e * G;
+    const bool valid = (e < E) && (n < N);
+    const int total = N + nprey;
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
+
+    int r = 0, c = 0, pr = -1, pc = -1, rch = 0, act = 4, was_over = 1;
+    if (valid) {
+        const size_t li = (size_t)e * total + n;
+        r = loc_r[li];
+        c = loc_c[li];
+        pr = loc_r[(size_t)e * total + N];  // prey 0 only: (N,2)==(1,2) broadcast, quirk Q7 PP:258
+        pc = loc_c[(size_t)e * total + N];
+        rch = reached[(size_t)e * N + n];
+        act = actions[(size_t)e * N + n];
+        was_over = over[e];
+        if (act > naction) atomicOr(err, 1);  // PP:137 (<=, quirk Q2)
+    }
+    const bool live = valid && !was_over;
+    if (live && rch != 1 && act != 5) {  // frozen PP:221-222; (sic) STAY guard PP:224-226
+        if (act == 0) {                  // UP PP:229-232
+            int qr = r + v - 1;
+            qr = qr < 0 ? 0 : qr;
+            if (!padded_outside(qr, c + v, v, dim)) r = (r - 1 > 0) ? r - 1 : 0;
+        } else if (act == 1) {           // RIGHT PP:235-239 (padded index clamped to dim-1, sic)
+            int qc = c + v + 1;
+            qc = qc > dim - 1 ? dim - 1 : qc;
+            if (!padded_outside(r + v, qc, v, dim)) c = (c + 1 < dim - 1) ? c + 1 : dim - 1;
+        } else if (act == 2) {           // DOWN PP:242-246
+            int qr = r + v + 1;
+            qr = qr > dim - 1 ? dim - 1 : qr;
+            if (!padded_outside(qr, c + v, v, dim)) r = (r + 1 < dim - 1) ? r + 1 : dim - 1;
+        } else if (act == 3) {           // LEFT PP:249-252
+            int qc = c + v - 1;
+            qc = qc < 0 ? 0 : qc;
+            if (!padded_outside(r + v, qc, v, dim)) c = (c - 1 > 0) ? c - 1 : 0;
+        }
+    }
+    const bool on = live && (r == pr) && (c == pc);
+    const int n_on = __popcll(__ballot(on) & gmask);
+    const int rch_new = (rch == 1 || on) ? 1 : 0;  // PP:271
+    const int n_reached = __popcll(__ballot(live && rch_new) & gmask);
+    if (!valid) return;
+    float rew = 0.0f;
+    if (live) {
+        double rd = -0.05;  // TIMESTEP_PENALTY PP:256
+        if (on) {
+            if (mode == IC3_PP_COOPERATIVE) rd = 0.05 * (double)n_on;        // PP:262
+            else if (mode == IC3_PP_COMPETITIVE) rd = 0.05 / (double)n_on;   // PP:265
+            else rd = 0.0;                                                   // PP:267
+        }
+        rew = (float)rd;
+        const size_t li = (size_t)e * total + n;
+        loc_r[li] = r;
+        loc_c[li] = c;
+        reached[(size_t)e * N + n] = rch_new;
+    }
+    reward[(size_t)e * N + n] = rew;
+    if (alive_out) alive_out[(size_t)e * N + n] = 1;
+    if (comp_out) comp_out[(size_t)e * N + n] = 0;
+    if (n == 0) {
+        int ov = was_over;
+        if (live) {
+            ov = (n_reached == N && mode == IC3_PP_MIXED) ? 1 : 0;                 // PP:273-274
+            if (mode != IC3_PP_COMPETITIVE) success[e] = (n_on == N) ? 1 : 0;      // PP:284-288
+            over[e] = ov;
+            tstep[e] += 1;
+        }
+        done[e] = ov;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation assembly: PP:188-210 (+ one-hot base grid PP:177-186, flatten env_wrappers.py:88-100).
+// The reference copies a (dim+2v)^2 x vocab int64 one-hot grid per step and slices windows; here each
+// workgroup owns one env (its N rows are contiguous: N*obs_dim floats), stages the N+nprey positions
+// and the per-window-cell descriptors in LDS, and streams the rows out exactly once with 16-byte
+// stores.  This is the HBM-write-bound kernel the roofline is quoted on: algorithmic bytes per env =
+// N * obs_dim * 4.
+//   row a, window cell s = dy*W+dx, channel ch:  obs[a][s*vocab + ch] =
+//       (ch == id(s))            id = r*dim+c inside the grid, OUTSIDE_CLASS = dim*dim+1 otherwise
+//     + (ch == PREY_CLASS)  * #prey on the cell       (counts, quirk Q3)
+//     + (ch == PREDATOR_CLASS) * #predators on the cell
+// ------------------------------------------------------------------------------------------------
+template <bool VEC4>
+__global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
+                                                     const int32_t* __restrict__ loc_c, float* __restrict__ obs,
+                                                     int N, int nprey, int dim, int v)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x;
+    const int total = N + nprey, W = 2 * v + 1, nseg = N * W * W;
+    const int vocab = dim * dim + 4, OUTSIDE = dim * dim + 1;
+    int32_t* sr = smem;              // [total]
+    int32_t* sc = sr + total;        // [total]
+    int2* tab = reinterpret_cast<int2*>(smem + ((2 * total + 3) & ~3));  // [nseg] (one-hot channel, npred | nprey<<16)
+
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        sr[i] = loc_r[(size_t)e * total + i];
+        sc[i] = loc_c[(size_t)e * total + i];
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
+        const int a = s / (W * W), w = s - a * (W * W);
+        const int dy = w / W, dx = w - dy * W;
+        const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
+        const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
+        int npred = 0, npr = 0;
+        for (int p = 0; p < N; ++p) npred += (sr[p] == gr) & (sc[p] == gc);             // PP:191-192
+        for (int p = N; p < total; ++p) npr += (sr[p] == gr) & (sc[p] == gc);           // PP:194-195
+        tab[s] = make_int2(id, npred | (npr << 16));
+    }
+    __syncthreads();
+
+    if constexpr (VEC4) {
+        // vocab % 4 == 0: a 16-byte store never straddles a window cell; the three special channels
+        // (OUTSIDE, PREY, PREDATOR = vocab-3, -2, -1) share the cell's last float4.
+        const int segq = vocab >> 2;
+        const int Q = nseg * segq;
+        f32x4* out = reinterpret_cast<f32x4*>(obs + (size_t)e * nseg * vocab);
+        int seg = threadIdx.x / segq, q = threadIdx.x - seg * segq;
+        const int dseg = 256 / segq, dq = 256 - dseg * segq;
+        for (int g = threadIdx.x; g < Q; g += 256) {
+            const int2 t = tab[seg];
+            f32x4 z = { 0.f, 0.f, 0.f, 0.f };
+            if ((t.x >> 2) == q) {
+                const int j = t.x & 3;
+                z.x = (j == 0) ? 1.f : 0.f;
+                z.y = (j == 1) ? 1.f : 0.f;
+                z.z = (j == 2) ? 1.f : 0.f;
+                z.w = (j == 3) ? 1.f : 0.f;
+            }
+            if (q == segq - 1) {
+                z.z += (float)(t.y >> 16);
+                z.w += (float)(t.y & 0xffff);
+            }
+            __builtin_nontemporal_store(z, out + g);
+            seg += dseg;
+            q += dq;
+            if (q >= segq) {
+                q -= segq;
+                ++seg;
+            }
+        }
+    } else {
+        const int total_f = nseg * vocab;
+        float* out = obs + (size_t)e * total_f;
+        int seg = threadIdx.x / vocab, ch = threadIdx.x - seg * vocab;
+        const int dseg = 256 / vocab, dch = 256 - dseg * vocab;
+        for (int g = threadIdx.x; g < total_f; g += 256) {
+            const int2 t = tab[seg];
+            float z = (ch == t.x) ? 1.f : 0.f;
+            if (ch == vocab - 2) z += (float)(t.y >> 16);
+            if (ch == vocab - 1) z += (float)(t.y & 0xffff);
+            out[g] = z;
+            seg += dseg;
+            ch += dch;
+            if (ch >= vocab) {
+                ch -= vocab;
+                ++seg;
+            }
+        }
+    }
+}
+
+int pp_reset(ic3_env* env, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int blocks = (c.E + 255) / 256;
+    hipLaunchKernelGGL(pp_reset_kernel, dim3(blocks), dim3(256), 0, s, env->f("loc_r"), env->f("loc_c"),
+                       env->f("reached"), env->f("over"), env->f("success"), env->f("episode"), env->f("t"), c.E, c.N,
+                       c.nprey, c.dim, c.seed, c.env_id_offset);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
+            hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int G = group_lanes(c.N);
+    const long long threads = (long long)c.E * G;
+    const int blocks = (int)((threads + 255) / 256);
+    hipLaunchKernelGGL(pp_step_kernel, dim3(blocks), dim3(256), 0, s, env->f("loc_r"), env->f("loc_c"),
+                       env->f("reached"), env->f("over"), env->f("success"), env->f("t"), actions, reward, done, alive,
+                       is_completed, env->d_err, c.E, c.N, c.nprey, c.dim, c.vision, c.mode, c.stay ? 5 : 4, G);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+int pp_observe(ic3_env* env, float* obs, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
+    const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
+    const int vocab = c.dim * c.dim + 4;
+    if ((vocab & 3) == 0 && vocab / 4 <= 256 * 64) {
+        hipLaunchKernelGGL(pp_obs_kernel<true>, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"), obs,
+                           c.N, c.nprey, c.dim, c.vision);
+    } else {
+        hipLaunchKernelGGL(pp_obs_kernel<false>, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"), obs,
+                           c.N, c.nprey, c.dim, c.vision);
+    }
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ic3

@@ -1,0 +1,278 @@
+// tj_kernels.hip — Traffic-Junction: reset / step / observation assembly for E environments (gfx950).
+//
+// Reference semantics: /root/reference/ic3net-envs/ic3net_envs/traffic_junction_env.py (cited "TJ:line").
+// One lane group (G = pow2 >= max(N, 8) lanes, inside one wavefront) per environment; the order-dependent
+// `_add_cars` loop runs as <= 8 uniform iterations with ballot-ranked dead-slot selection, the O(N^2)
+// collision test as N lane broadcasts.
+#include "ic3_common.hpp"
+
+namespace ic3 {
+
+__global__ __launch_bounds__(256) void tj_reset_kernel(int32_t* __restrict__ alive, int32_t* __restrict__ wait,
+                                                       int32_t* __restrict__ loc_r, int32_t* __restrict__ loc_c,
+                                                       int32_t* __restrict__ last_act, int32_t* __restrict__ route_loc,
+                                                       int32_t* __restrict__ route_id, int32_t* __restrict__ completed,
+                                                       int32_t* __restrict__ cars, int32_t* __restrict__ failed,
+                                                       int32_t* __restrict__ over, int32_t* __restrict__ episode,
+                                                       int32_t* __restrict__ tstep, int E, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E * N) {
+        alive[i] = 0;       // TJ:171
+        wait[i] = 0;        // TJ:172
+        loc_r[i] = 0;       // TJ:187
+        loc_c[i] = 0;
+        last_act[i] = 0;    // TJ:188
+        route_loc[i] = -1;  // TJ:190
+        route_id[i] = -1;   // TJ:178
+        completed[i] = 0;
+    }
+    if (i < E) {
+        cars[i] = 0;    // TJ:173
+        failed[i] = 0;  // TJ:169
+        over[i] = 0;    // TJ:168
+        episode[i] += 1;
+        tstep[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void tj_step_kernel(
+    int32_t* __restrict__ alive_s, int32_t* __restrict__ wait_s, int32_t* __restrict__ loc_r, int32_t* __restrict__ loc_c,
+    int32_t* __restrict__ last_act_s, int32_t* __restrict__ route_loc_s, int32_t* __restrict__ route_id_s,
+    int32_t* __restrict__ completed_s, int32_t* __restrict__ cars_s, int32_t* __restrict__ failed_s,
+    const int32_t* __restrict__ over_s, const int32_t* __restrict__ episode_s, int32_t* __restrict__ tstep_s,
+    const int32_t* __restrict__ route_off, const int32_t* __restrict__ route_rc, const int32_t* __restrict__ actions,
+    float* __restrict__ reward, int32_t* __restrict__ done, int32_t* __restrict__ alive_out,
+    int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E, int N, int G, int narrival, int rpa, int32_t thr,
+    uint32_t seed, uint32_t gid0)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid / G, n = tid - e * G;
+    const bool env_ok = e < E;
+    const bool valid = env_ok && n < N;
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
+    const size_t i = (size_t)e * N + n;
+
+    int alive = 0, wait = 0, r = 0, c = 0, last_act = 0, rloc = -1, rid = -1, completed = 0, act = 1;
+    uint32_t ep = 0, t = 0;
+    if (env_ok) {
+        ep = (uint32_t)episode_s[e];
+        t = (uint32_t)tstep_s[e];
+    }
+    if (valid) {
+        alive = alive_s[i];
+        wait = wait_s[i];
+        r = loc_r[i];
+        c = loc_c[i];
+        last_act = last_act_s[i];
+        rloc = route_loc_s[i];
+        rid = route_id_s[i];
+        act = actions[i];
+        if (act > 2) atomicOr(err, 1);  // TJ:228 (naction = 2, <=, quirk Q2)
+    }
+    // ---- _take_action TJ:540-581 ----
+    if (valid && alive) {
+        wait += 1;                      // TJ:546
+        if (act == 1) {
+            last_act = 1;               // TJ:549-551
+        } else if (act == 0) {
+            rloc += 1;                  // TJ:556
+            const int o = route_off[rid], len = route_off[rid + 1] - o;
+            if (rloc == len) {          // TJ:560-568 reached the end of its route
+                alive = 0;
+                wait = 0;
+                r = c = 0;
+                completed = 1;
+            } else {
+                const int rc = route_rc[o + rloc];  // TJ:575-578
+                r = rc >> 16;
+                c = rc & 0xffff;
+                last_act = 0;           // TJ:581
+            }
+        }
+    }
+    // ---- _add_cars TJ:369-393: lane j of the group pre-draws arrival point j's three uniforms ----
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
+    if (env_ok && n < narrival) {
+        x0 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 0u);
+        x1 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 1u);
+        x2 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 2u);
+    }
+    for (int a = 0; a < narrival; ++a) {
+        const unsigned long long am = __ballot(valid && alive) & gmask;
+        const unsigned long long dm = __ballot(valid && !alive) & gmask;
+        const int cars = __popcll(am), nd = __popcll(dm);
+        const uint32_t u0 = (uint32_t)__shfl((int)x0, gbase + a);
+        const uint32_t u1 = (uint32_t)__shfl((int)x1, gbase + a);
+        const uint32_t u2 = (uint32_t)__shfl((int)x2, gbase + a);
+        const bool add = (cars < N) && ((int32_t)u0 <= thr);              // TJ:371-372, 375
+        if (add && valid && !alive) {
+            const int k = (int)scale24(u1, (uint32_t)nd);                 // _choose_dead TJ:614-618: k-th dead slot
+            const int rank = __popcll(dm & ((1ull << lane) - 1ull));
+            if (rank == k) {
+                alive = 1;                                                // TJ:380
+                rid = (int)scale24(u2, (uint32_t)rpa) + a * rpa;          // TJ:383-385
+                rloc = 0;                                                 // TJ:389
+                const int rc = route_rc[route_off[rid]];                  // TJ:390
+                r = rc >> 16;
+                c = rc & 0xffff;
+            }
+        }
+    }
+    const int cars_now = __popcll(__ballot(valid && alive) & gmask);     // == cars_in_sys (TJ:393,561)
+    // ---- _get_reward TJ:585-595: crash iff another car (alive or parked dead) shares a non-(0,0) cell ----
+    const int packed = valid ? ((r << 16) | c) : -1;
+    bool same = false;
+    for (int j = 0; j < N; ++j) {
+        const int pj = __shfl(packed, gbase + j);
+        same |= (j != n) && (pj == packed);
+    }
+    const bool crash = valid && same && (packed != 0);                   // l.any(): loc != (0,0), quirk Q10
+    const bool any_crash = (__ballot(crash) & gmask) != 0ull;
+    if (!valid) return;
+    double rd = -0.01 * (double)wait;                                     // TJ:586
+    if (crash) rd += -10.0;                                               // TJ:591
+    rd = (double)alive * rd;                                              // TJ:594
+    reward[i] = (float)rd;
+    alive_s[i] = alive;
+    wait_s[i] = wait;
+    loc_r[i] = r;
+    loc_c[i] = c;
+    last_act_s[i] = last_act;
+    route_loc_s[i] = rloc;
+    route_id_s[i] = rid;
+    completed_s[i] = completed;
+    if (alive_out) alive_out[i] = alive;                                  // info['alive_mask'] TJ:244
+    if (comp_out) comp_out[i] = completed;                                // info['is_completed'] TJ:247
+    if (n == 0) {
+        cars_s[e] = cars_now;
+        if (any_crash) failed_s[e] = 1;                                   // TJ:592
+        tstep_s[e] = (int32_t)t + 1;
+        done[e] = over_s[e];                                              // never set by TJ (quirk Q12)
+    }
+}
+
+// TJ:321-366 _get_obs ('bool' vocab) + env_wrappers.py:88-100: row a = [last_act/(naction-1),
+// route_id/(npath-1), one-hot window], all-zero if the car is dead.  CAR channel counts every car on
+// the cell including dead ones parked at (0,0) (quirk Q8).  Rows are 2+W*W*vocab floats (not 16-byte
+// multiples), so this path uses coalesced dword stores; algorithmic bytes per env = N*obs_dim*4.
+__global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__ alive_s,
+                                                     const int32_t* __restrict__ loc_r, const int32_t* __restrict__ loc_c,
+                                                     const int32_t* __restrict__ last_act_s,
+                                                     const int32_t* __restrict__ route_id_s,
+                                                     const int32_t* __restrict__ grid, float* __restrict__ obs, int N,
+                                                     int h, int w, int v, int vocab, int outside, int car_class, int npath)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x;
+    const int W = 2 * v + 1, WW = W * W, nseg = N * WW, obs_dim = 2 + WW * vocab;
+    int32_t* sr = smem;          // [N]
+    int32_t* sc = sr + N;        // [N]
+    int32_t* sal = sc + N;       // [N]
+    float* s0 = reinterpret_cast<float*>(sal + N);  // [N] last_act scalar
+    float* s1 = s0 + N;                             // [N] route scalar
+    int2* tab = reinterpret_cast<int2*>(smem + ((5 * N + 3) & ~3));  // [nseg] (one-hot channel, #cars)
+    for (int a = threadIdx.x; a < N; a += blockDim.x) {
+        const size_t i = (size_t)e * N + a;
+        sr[a] = loc_r[i];
+        sc[a] = loc_c[i];
+        sal[a] = alive_s[i];
+        s0[a] = (float)((double)last_act_s[i] / 1.0);                       // TJ:338 naction-1 == 1
+        s1[a] = (float)((double)route_id_s[i] / (double)(npath - 1));       // TJ:341
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
+        const int a = s / WW, q = s - a * WW;
+        const int dy = q / W, dx = q - dy * W;
+        const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
+        const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;  // pad_grid TJ:317
+        int ncar = 0;
+        for (int p = 0; p < N; ++p) ncar += (sr[p] == gr) & (sc[p] == gc);                    // TJ:326-327
+        tab[s] = make_int2(id, ncar);
+    }
+    __syncthreads();
+    const int total = N * obs_dim;
+    float* out = obs + (size_t)e * total;
+    const float inv_vocab = 1.0f / (float)vocab;
+    int a = threadIdx.x / obs_dim, off = threadIdx.x - a * obs_dim;
+    const int da = 256 / obs_dim, doff = 256 - da * obs_dim;
+    for (int g = threadIdx.x; g < total; g += 256) {
+        float z = 0.0f;
+        if (sal[a]) {  // TJ:352-356
+            if (off == 0) z = s0[a];
+            else if (off == 1) z = s1[a];
+            else {
+                const int k = off - 2;
+                const int seg = (int)(((float)k + 0.5f) * inv_vocab);  // exact for k < 2^20
+                const int ch = k - seg * vocab;
+                const int2 t = tab[a * WW + seg];
+                z = (ch == t.x) ? 1.0f : 0.0f;
+                if (ch == car_class) z += (float)t.y;
+            }
+        }
+        out[g] = z;
+        a += da;
+        off += doff;
+        if (off >= obs_dim) {
+            off -= obs_dim;
+            ++a;
+        }
+    }
+}
+
+int tj_reset(ic3_env* env, hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const int n = c.E * c.N;
+    hipLaunchKernelGGL(tj_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, env->f("alive"), env->f("wait"),
+                       env->f("loc_r"), env->f("loc_c"), env->f("last_act"), env->f("route_loc"), env->f("route_id"),
+                       env->f("is_completed"), env->f("cars_in_sys"), env->f("has_failed"), env->f("over"),
+                       env->f("episode"), env->f("t"), c.E, c.N);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+static int tj_group(int N)
+{
+    const int g = group_lanes(N);
+    return g < 8 ? 8 : g;
+}
+
+int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
+            hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const int G = tj_group(c.N);
+    const long long threads = (long long)c.E * G;
+    // u <= add_rate  <=>  x24 <= floor(add_rate * 2^24)   (exact: power-of-two scaling in fp64)
+    double thr_d = __builtin_floor(env->add_rate * 16777216.0);
+    if (thr_d > 16777216.0) thr_d = 16777216.0;
+    if (thr_d < -1.0) thr_d = -1.0;
+    const int32_t thr = (int32_t)thr_d;
+    const int rpa = env->dims.npath / env->dims.narrival;
+    hipLaunchKernelGGL(tj_step_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, env->f("alive"),
+                       env->f("wait"), env->f("loc_r"), env->f("loc_c"), env->f("last_act"), env->f("route_loc"),
+                       env->f("route_id"), env->f("is_completed"), env->f("cars_in_sys"), env->f("has_failed"),
+                       env->f("over"), env->f("episode"), env->f("t"), env->d_route_off, env->d_route_rc, actions, reward,
+                       done, alive, is_completed, env->d_err, c.E, c.N, G, env->dims.narrival, rpa, thr, c.seed,
+                       c.env_id_offset);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+int tj_observe(ic3_env* env, float* obs, hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const ic3_dims& d = env->dims;
+    const int WW = d.window * d.window;
+    const size_t lds = (size_t)(((5 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
+    hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
+                       env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
+                       d.vocab, d.vocab - 3, d.vocab - 1, d.npath);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ic3

@@ -1,0 +1,297 @@
+"""Batched Predator-Prey / Traffic-Junction environments with the reference's gym-style API.
+
+Mirrors /root/reference/ic3net-envs/ic3net_envs/predator_prey_env.py (PP) and traffic_junction_env.py
+(TJ): `init_args(parser)`, `multi_agent_init(args)`, `reset([epoch])`, `step(action)`,
+`reward_terminal()`, `stat`, `observation_space`, `action_space`, `seed()` — but one object holds
+`args.nenvs` independent environments as struct-of-arrays in HBM, stepped by HIP kernels
+(ic3net_amd/csrc).  Tensors returned are torch CUDA tensors with a leading env dimension:
+obs (E, N, obs_dim) float32, reward (E, N) float32, done (E,) int32,
+info['alive_mask'] / info['is_completed'] (E, N) int32.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, spaces
+from ._lib import check, ptr, stream
+
+
+class _BatchedEnv(object):
+    """Shared plumbing: handle lifetime, output buffers, state dump / injection."""
+
+    def __init__(self):
+        self._h = None
+        self.stat = dict()
+        self.episode_over = False
+
+    # --- handle ---------------------------------------------------------------------------------
+    def _finish_init(self, handle, device):
+        self._h = handle
+        self.device = torch.device('cuda', device)
+        d = _lib.Dims()
+        check(_lib.lib().ic3_env_dims(self._h, C.byref(d)))
+        self.dims = d
+        self.nenvs, self.nagents_env, self.obs_dim = d.E, d.N, d.obs_dim
+        E, N = d.E, d.N
+        with torch.cuda.device(self.device):
+            self._obs = torch.empty((E, N, d.obs_dim), dtype=torch.float32, device=self.device)
+            self._reward = torch.empty((E, N), dtype=torch.float32, device=self.device)
+            self._done = torch.empty((E,), dtype=torch.int32, device=self.device)
+            self._alive = torch.empty((E, N), dtype=torch.int32, device=self.device)
+            self._completed = torch.empty((E, N), dtype=torch.int32, device=self.device)
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.lib().ic3_env_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _require(self):
+        if self._h is None:
+            raise _lib.IC3Error("multi_agent_init(args) has not been called")
+
+    def _actions(self, action):
+        """Accepts the reference's list/ndarray of N ints (E == 1) or an (E, N) tensor/array."""
+        E, N = self.nenvs, self.nagents_env
+        if not torch.is_tensor(action):
+            action = torch.as_tensor(np.asarray(action).squeeze().astype(np.int32))
+        if action.numel() != E * N:
+            raise AssertionError("Action for each agent should be provided.")   # TJ:230
+        return action.to(device=self.device, dtype=torch.int32).reshape(E, N).contiguous()
+
+    # --- parity / debug --------------------------------------------------------------------------
+    def get_state(self):
+        """Full integer state as {field: ndarray} (synchronising)."""
+        self._require()
+        buf = np.empty(self.dims.state_words, np.int32)
+        check(_lib.lib().ic3_env_get_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
+        out = {}
+        for name, shape in self._fields():
+            off, cnt = C.c_int64(), C.c_int64()
+            check(_lib.lib().ic3_env_state_field(self._h, name.encode(), C.byref(off), C.byref(cnt)))
+            out[name] = buf[off.value:off.value + cnt.value].reshape(shape).copy()
+        return out
+
+    def set_state(self, **fields):
+        """Overwrite some state fields (golden initial states); others keep their current values."""
+        self._require()
+        buf = np.empty(self.dims.state_words, np.int32)
+        check(_lib.lib().ic3_env_get_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
+        for name, val in fields.items():
+            off, cnt = C.c_int64(), C.c_int64()
+            check(_lib.lib().ic3_env_state_field(self._h, name.encode(), C.byref(off), C.byref(cnt)))
+            buf[off.value:off.value + cnt.value] = np.asarray(val, np.int32).reshape(-1)
+        check(_lib.lib().ic3_env_set_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
+
+    def check_actions(self):
+        """Synchronising form of the reference's action-range assert (PP:137 / TJ:228)."""
+        rc = _lib.lib().ic3_env_check(self._h, stream())
+        if rc < 0:
+            raise AssertionError(_lib.lib().ic3_last_error().decode())
+
+    def observe(self):
+        self._require()
+        check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
+        return self._obs
+
+    def device_stats(self):
+        s = _lib.Stats()
+        check(_lib.lib().ic3_env_stats(self._h, C.byref(s), stream()))
+        return s
+
+    def seed(self):
+        return
+
+    # --- common reset / step ---------------------------------------------------------------------
+    def _reset(self, epoch):
+        self._require()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().ic3_env_reset(self._h, -1 if epoch is None else int(epoch), ptr(self._obs), stream()))
+        self.stat = dict()
+        self.episode_over = False
+        return self._obs
+
+    def _step(self, action):
+        self._require()
+        a = self._actions(action)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(self._reward), ptr(self._done),
+                                          ptr(self._alive), ptr(self._completed), stream()))
+        return self._obs, self._reward, self._done
+
+    def reward_terminal(self):
+        return torch.zeros_like(self._reward)      # PP:292-293 / TJ:611-612: zeros
+
+
+class PredatorPreyEnv(_BatchedEnv):
+    """predator_prey_env.py:30-339, batched."""
+
+    def __init__(self):
+        super(PredatorPreyEnv, self).__init__()
+        self.__version__ = "0.0.1"
+        self.OUTSIDE_CLASS = 1
+        self.PREY_CLASS = 2
+        self.PREDATOR_CLASS = 3
+        self.TIMESTEP_PENALTY = -0.05
+        self.PREY_REWARD = 0
+        self.POS_PREY_REWARD = 0.05
+
+    def init_args(self, parser):            # PP:55-70 (same flags)
+        env = parser.add_argument_group('Prey Predator task')
+        env.add_argument('--nenemies', type=int, default=1, help="Total number of preys in play")
+        env.add_argument('--dim', type=int, default=5, help="Dimension of box")
+        env.add_argument('--vision', type=int, default=2, help="Vision of predator")
+        env.add_argument('--moving_prey', action="store_true", default=False, help="Whether prey is fixed or moving")
+        env.add_argument('--no_stay', action="store_true", default=False,
+                         help="Whether predators have an action to stay in place")
+        parser.add_argument('--mode', default='mixed', type=str, help='cooperative|competitive|mixed (default: mixed)')
+        env.add_argument('--enemy_comm', action="store_true", default=False, help="Whether prey can communicate.")
+
+    def multi_agent_init(self, args):       # PP:72-110
+        for key in ('dim', 'vision', 'moving_prey', 'mode', 'enemy_comm'):
+            setattr(self, key, getattr(args, key))
+        self.nprey = args.nenemies
+        self.npredator = args.nfriendly
+        self.dims_grid = (self.dim, self.dim)
+        self.stay = not args.no_stay
+        if args.moving_prey:
+            raise NotImplementedError
+        if self.enemy_comm:
+            raise NotImplementedError("enemy_comm is outside the hot-path scope (SURVEY 8(f) f3)")
+        if self.mode not in _lib.PP_MODES:
+            raise RuntimeError("Incorrect mode, Available modes: [cooperative|competitive|mixed]")   # PP:269
+        self.naction = 5 if self.stay else 4
+        self.action_space = spaces.MultiDiscrete([self.naction])
+        self.BASE = self.dim * self.dim
+        self.OUTSIDE_CLASS += self.BASE
+        self.PREY_CLASS += self.BASE
+        self.PREDATOR_CLASS += self.BASE
+        self.vocab_size = 1 + 1 + self.BASE + 1 + 1
+        self.observation_space = spaces.Box(low=0, high=1, shape=(self.vocab_size, 2 * self.vision + 1,
+                                                                   2 * self.vision + 1), dtype=int)
+        device = int(getattr(args, 'device', 0) or 0)
+        cfg = _lib.PPCfg(int(getattr(args, 'nenvs', 1)), self.npredator, self.nprey, self.dim, self.vision,
+                         _lib.PP_MODES[self.mode], int(self.stay), int(bool(args.moving_prey)),
+                         int(getattr(args, 'seed', 0)) & 0xffffffff, int(getattr(args, 'env_id_offset', 0)))
+        h = C.c_void_p()
+        check(_lib.lib().ic3_pp_create(C.byref(cfg), device, C.byref(h)))
+        self._finish_init(h, device)
+
+    def _fields(self):
+        E, N, T = self.nenvs, self.npredator, self.npredator + self.nprey
+        return [("loc_r", (E, T)), ("loc_c", (E, T)), ("reached", (E, N)), ("over", (E,)), ("success", (E,)),
+                ("episode", (E,)), ("t", (E,))]
+
+    def reset(self):                        # PP:146-168
+        return self._reset(None)
+
+    def step(self, action):                 # PP:112-144
+        obs, reward, done = self._step(action)
+        debug = {'alive_mask_device': self._alive}   # PP has no alive_mask in info (trainer.py:78-81 uses ones)
+        return obs, reward, done, debug
+
+
+class TrafficJunctionEnv(_BatchedEnv):
+    """traffic_junction_env.py:34-626, batched ('bool' vocab)."""
+
+    def __init__(self):
+        super(TrafficJunctionEnv, self).__init__()
+        self.__version__ = "0.0.1"
+        self.OUTSIDE_CLASS = 0
+        self.ROAD_CLASS = 1
+        self.CAR_CLASS = 2
+        self.TIMESTEP_PENALTY = -0.01
+        self.CRASH_PENALTY = -10
+
+    def init_args(self, parser):            # TJ:60-77 (same flags)
+        env = parser.add_argument_group('Traffic Junction task')
+        env.add_argument('--dim', type=int, default=5, help="Dimension of box (i.e length of road) ")
+        env.add_argument('--vision', type=int, default=1, help="Vision of car")
+        env.add_argument('--add_rate_min', type=float, default=0.05, help="rate at which to add car (till curr. start)")
+        env.add_argument('--add_rate_max', type=float, default=0.2, help=" max rate at which to add car")
+        env.add_argument('--curr_start', type=float, default=0, help="start making harder after this many epochs [0]")
+        env.add_argument('--curr_end', type=float, default=0, help="when to make the game hardest [0]")
+        env.add_argument('--difficulty', type=str, default='easy', help="Difficulty level, easy|medium|hard")
+        env.add_argument('--vocab_type', type=str, default='bool', help="Type of location vector to use, bool|scalar")
+
+    def multi_agent_init(self, args):       # TJ:80-158
+        for key in ('dim', 'vision', 'add_rate_min', 'add_rate_max', 'curr_start', 'curr_end', 'difficulty',
+                    'vocab_type'):
+            setattr(self, key, getattr(args, key))
+        self.ncar = args.nagents
+        if self.difficulty in ('medium', 'easy'):
+            assert self.dim % 2 == 0, 'Only even dimension supported for now.'
+            assert self.dim >= 4 + self.vision, 'Min dim: 4 + vision'
+        if self.difficulty == 'hard':
+            assert self.dim >= 9, 'Min dim: 9'
+            assert self.dim % 3 == 0, 'Hard version works for multiple of 3. dim. only.'
+        if self.vocab_type != 'bool':
+            raise NotImplementedError("vocab_type 'scalar' is outside the hot-path scope (SURVEY 8(f) f3)")
+        self.naction = 2
+        self.action_space = spaces.Discrete(self.naction)
+        device = int(getattr(args, 'device', 0) or 0)
+        cfg = _lib.TJCfg(int(getattr(args, 'nenvs', 1)), self.ncar, self.dim, self.vision,
+                         _lib.TJ_DIFFICULTY[self.difficulty], 0, float(self.add_rate_min), float(self.add_rate_max),
+                         float(self.curr_start), float(self.curr_end), int(getattr(args, 'seed', 0)) & 0xffffffff,
+                         int(getattr(args, 'env_id_offset', 0)))
+        h = C.c_void_p()
+        check(_lib.lib().ic3_tj_create(C.byref(cfg), device, C.byref(h)), exc=AssertionError)
+        self._finish_init(h, device)
+        d = self.dims
+        self.dims_grid = (d.grid_h, d.grid_w)
+        self.npath = d.npath
+        self.vocab_size = d.vocab
+        self.BASE = d.vocab - 3
+        self.OUTSIDE_CLASS += self.BASE
+        self.CAR_CLASS += self.BASE
+        self.observation_space = spaces.Tuple((spaces.Discrete(self.naction), spaces.Discrete(self.npath),
+                                               spaces.MultiBinary((d.window, d.window, self.vocab_size))))
+
+    def _fields(self):
+        E, N = self.nenvs, self.ncar
+        per_agent = ["alive", "wait", "loc_r", "loc_c", "last_act", "route_loc", "route_id", "is_completed"]
+        per_env = ["cars_in_sys", "has_failed", "over", "episode", "t"]
+        return [(n, (E, N)) for n in per_agent] + [(n, (E,)) for n in per_env]
+
+    @property
+    def add_rate(self):
+        a, b = C.c_double(), C.c_double()
+        check(_lib.lib().ic3_tj_get_add_rate(self._h, C.byref(a), C.byref(b)))
+        return a.value
+
+    def tables(self):
+        """(grid (h,w), route_off (npath+1), route_rc (total,2)) — the init-time tables, host copies."""
+        d = self.dims
+        grid = np.empty((d.grid_h, d.grid_w), np.int32)
+        off = np.empty(d.npath + 1, np.int32)
+        need = check(_lib.lib().ic3_tj_get_tables(self._h, grid.ctypes.data_as(C.c_void_p),
+                                                  off.ctypes.data_as(C.c_void_p), None, 0))
+        rc = np.empty(need, np.int32)
+        check(_lib.lib().ic3_tj_get_tables(self._h, None, None, rc.ctypes.data_as(C.c_void_p), need))
+        return grid, off, rc.reshape(-1, 2)
+
+    def reset(self, epoch=None):            # TJ:160-204
+        return self._reset(epoch)
+
+    def step(self, action):                 # TJ:206-252
+        obs, reward, done = self._step(action)
+        debug = {'alive_mask': self._alive, 'is_completed': self._completed}
+        return obs, reward, done, debug
+
+
+def tj_build_tables(dim, vision, difficulty):
+    """Host-only: the Traffic-Junction init-time tables (traffic_helper.py:5-209, TJ:300-319) as computed by
+    the library's C++ generator.  -> (dims, grid (h,w), route_off, route_rc (total,2)).  Needs no GPU."""
+    d = _lib.Dims()
+    need = _lib.lib().ic3_tj_build_tables(dim, vision, _lib.TJ_DIFFICULTY[difficulty], C.byref(d), None, None, None, 0)
+    check(need, exc=AssertionError)
+    grid = np.empty((d.grid_h, d.grid_w), np.int32)
+    off = np.empty(d.npath + 1, np.int32)
+    rc = np.empty(need, np.int32)
+    check(_lib.lib().ic3_tj_build_tables(dim, vision, _lib.TJ_DIFFICULTY[difficulty], C.byref(d),
+                                         grid.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                         rc.ctypes.data_as(C.c_void_p), need))
+    return d, grid, off, rc.reshape(-1, 2)

@@ -1,0 +1,176 @@
+/*
+ * ic3_rollout.h — C ABI of libic3rollout.so, the MI355X-native batched rollout engine.
+ *
+ * The reference (IC3Net, /root/reference) is pure Python and has no FFI: its "plugin interface" for
+ * this path is the duck-typed gym Env / GymWrapper / policy / Trainer surface.
+ * This header is the boundary a maintainer binds *under* that surface (ctypes stub in
+ * INTEGRATION.md; the build's own binding is ic3net_amd/_lib.py).  Each entry point cites the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *   - return 0 = OK, negative errno-style code on error; ic3_last_error() gives the message.
+ *   - every tensor argument is a DEVICE pointer owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); the library owns only the opaque handle (struct-of-arrays env state + constant
+ *     tables).  No torch types cross this boundary.
+ *   - all work is enqueued asynchronously on the caller's stream (hipStream_t passed as void*);
+ *     no hidden synchronisation except where documented (get/set_state, stats: debug/parity).
+ *   - a handle is bound to one device, one handle per process per GPU, not thread-safe.
+ *   - layouts: per-agent arrays are [E][N] (row = e*N + n, env-major) int32/float32; per-env arrays
+ *     are [E]; observations are [E][N][obs_dim] float32 — exactly the rows the policy's encoder
+ *     GEMM consumes (replaces env_wrappers.py:88-100 `_flatten_obs`).
+ *   - randomness: counter-based Philox4x32-10 keyed by (seed, env_id_offset + e); see DESIGN.md §RNG.
+ */
+#ifndef IC3_ROLLOUT_H
+#define IC3_ROLLOUT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IC3_VERSION 100 /* 0.1.0 */
+
+typedef struct ic3_env ic3_env; /* opaque */
+typedef void* ic3_stream;       /* hipStream_t */
+
+enum { IC3_ENV_PP = 1, IC3_ENV_TJ = 2 };
+enum { IC3_PP_MIXED = 0, IC3_PP_COOPERATIVE = 1, IC3_PP_COMPETITIVE = 2 }; /* --mode, predator_prey_env.py:67,261-269 */
+enum { IC3_TJ_EASY = 0, IC3_TJ_MEDIUM = 1, IC3_TJ_HARD = 2 };             /* --difficulty, traffic_junction_env.py:74 */
+
+/* Predator-Prey config == the args read by PredatorPreyEnv.multi_agent_init (predator_prey_env.py:72-110). */
+typedef struct {
+    int32_t E;             /* number of parallel environments in this handle (new: --nenvs) */
+    int32_t N;             /* args.nfriendly (npredator)      :80 */
+    int32_t nprey;         /* args.nenemies; only 1 supported (reference quirk Q7, :258) */
+    int32_t dim;           /* args.dim                        :81 */
+    int32_t vision;        /* args.vision                     :75 */
+    int32_t mode;          /* IC3_PP_*                        :75,261-269 */
+    int32_t stay;          /* !args.no_stay                   :82,90-93 */
+    int32_t moving_prey;   /* must be 0: -ENOSYS otherwise (NotImplementedError :84-85) */
+    uint32_t seed;         /* Philox key[0] */
+    uint32_t env_id_offset;/* global id of env 0 of this shard (multi-GPU sharding), Philox key[1] = offset+e */
+} ic3_pp_cfg;
+
+/* Traffic-Junction config == the args read by TrafficJunctionEnv.multi_agent_init (traffic_junction_env.py:80-158). */
+typedef struct {
+    int32_t E;
+    int32_t N;             /* args.nagents (ncar)             :88 */
+    int32_t dim;           /* args.dim                        :89 */
+    int32_t vision;        /* args.vision                     :91 */
+    int32_t difficulty;    /* IC3_TJ_*                        :90 */
+    int32_t vocab_type;    /* 0 = 'bool'; 'scalar' (1) -> -ENOSYS */
+    double add_rate_min;   /* :103 */
+    double add_rate_max;
+    double curr_start;
+    double curr_end;
+    uint32_t seed;
+    uint32_t env_id_offset;
+} ic3_tj_cfg;
+
+typedef struct {
+    int32_t kind;          /* IC3_ENV_PP / IC3_ENV_TJ */
+    int32_t E, N;
+    int32_t obs_dim;       /* GymWrapper.observation_dim      env_wrappers.py:15-31 */
+    int32_t vocab;         /* vocab_size                      PP:103 / TJ:134 */
+    int32_t naction;       /* GymWrapper.num_actions          env_wrappers.py:33-40 */
+    int32_t window;        /* 2*vision+1 */
+    int32_t npath;         /* TJ:126 (0 for PP) */
+    int32_t narrival;      /* len(routes) (0 for PP) */
+    int32_t max_route_len; /* (0 for PP) */
+    int32_t grid_h, grid_w;/* TJ self.dims (dim+1 for easy), PP dim */
+    int32_t state_words;   /* int32 words of ic3_env_get_state/set_state */
+} ic3_dims;
+
+typedef struct {
+    double success_sum;    /* PP: sum_e stat['success'] (PP:284-288); TJ: sum_e (1 - has_failed) (TJ:249) */
+    double add_rate;       /* TJ stat['add_rate'] (TJ:250); 0 for PP */
+    int64_t episodes;      /* number of resets so far * E */
+    int64_t live_env_steps;/* env-steps actually simulated (not-yet-done envs) since the last reset */
+} ic3_stats;
+
+int ic3_version(void);
+const char* ic3_last_error(void); /* thread-local, valid until the next call on this thread */
+
+/* gym.make('PredatorPrey-v0') + multi_agent_init(args): data.py:16-21, predator_prey_env.py:72-110 */
+int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out);
+/* gym.make('TrafficJunction-v0') + multi_agent_init(args): data.py:22-27, traffic_junction_env.py:80-158;
+ * builds grid ids and routes on the host (traffic_helper.py:5-209) and uploads them once. */
+int ic3_tj_create(const ic3_tj_cfg* cfg, int device, ic3_env** out);
+int ic3_env_destroy(ic3_env* env);
+int ic3_env_dims(const ic3_env* env, ic3_dims* out);
+
+/* Env.reset([epoch]) for all E envs: predator_prey_env.py:146-168 / traffic_junction_env.py:160-204.
+ * epoch < 0 means "no epoch" (reset() without argument).  obs may be NULL. */
+int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream);
+
+/* Env.step(action) for all E envs: predator_prey_env.py:112-144 / traffic_junction_env.py:206-252.
+ *   actions       [E][N] int32   the env-action head only (GymWrapper.step drops the talk head, env_wrappers.py:76-77)
+ *   obs           [E][N][obs_dim] float32 or NULL
+ *   reward        [E][N] float32 (the reference's float64 reward rounded to fp32)
+ *   done          [E] int32      episode_over after this step
+ *   alive         [E][N] int32 or NULL   info['alive_mask'] (TJ:244); ones for PP
+ *   is_completed  [E][N] int32 or NULL   info['is_completed'] (TJ:247); zeros for PP
+ * Environments whose episode is already over are frozen (the reference raises RuntimeError
+ * "Episode is done", PP:129-130; a batched launch cannot raise per env): reward 0, done 1.
+ * Out-of-range actions (> naction, the reference's assert PP:137 / TJ:228) set a sticky error flag
+ * reported by ic3_env_check(). */
+int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done,
+                 int32_t* alive, int32_t* is_completed, ic3_stream stream);
+
+/* Observation of the current state without stepping (what reset/step return), obs [E][N][obs_dim]. */
+int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream);
+
+/* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
+int ic3_env_check(ic3_env* env, ic3_stream stream);
+
+/* Parity / debug (synchronising, HOST pointers): full integer state.  Field layout by name:
+ *   PP: "loc_r" "loc_c" [E][N+nprey], "reached" [E][N], "over" "success" "episode" "t" [E]
+ *   TJ: "alive" "wait" "loc_r" "loc_c" "last_act" "route_loc" "route_id" "is_completed" [E][N],
+ *       "cars_in_sys" "has_failed" "over" "episode" "t" [E]
+ * ic3_env_state_field gives (offset, count) in int32 words inside the dump. */
+int ic3_env_get_state(const ic3_env* env, int32_t* host_out, size_t bytes, ic3_stream stream);
+int ic3_env_set_state(ic3_env* env, const int32_t* host_in, size_t bytes, ic3_stream stream);
+int ic3_env_state_field(const ic3_env* env, const char* name, int64_t* offset_words, int64_t* count_words);
+
+/* TJ constant tables (host copies, for parity with traffic_helper.get_routes): grid [h*w] road ids,
+ * route_off [npath+1], route_rc [2*route_off[npath]].  Pass NULL to query sizes via ic3_env_dims. */
+int ic3_tj_get_tables(const ic3_env* env, int32_t* grid, int32_t* route_off, int32_t* route_rc, size_t rc_capacity_words);
+
+/* Host-only (no GPU needed): build the TJ tables for (dim, vision, difficulty) — what ic3_tj_create uploads.
+ * Fills dims_out (grid_h/w, vocab, obs_dim, npath, narrival, max_route_len; E/N left 0) and, when non-NULL,
+ * grid / route_off / route_rc.  Returns the number of int32 words route_rc needs, or a negative error
+ * (-EINVAL with the reference's assert text for invalid dims, traffic_junction_env.py:93-100). */
+int ic3_tj_build_tables(int dim, int vision, int difficulty, ic3_dims* dims_out, int32_t* grid, int32_t* route_off,
+                        int32_t* route_rc, size_t rc_capacity_words);
+
+/* TJ curriculum scalar state (traffic_junction_env.py:103-104,196-200,620-626) */
+int ic3_tj_get_add_rate(const ic3_env* env, double* add_rate, double* exact_rate);
+
+/* Reduced episode statistics (synchronising; host struct): env.stat (PP:284-288, TJ:249-250). */
+int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream);
+
+/* CommNetMLP communication block, comm.py:181-205, in closed form per env (SURVEY B.5 i):
+ *   m_j = alive_j * comm_action_j ; out_j = m_j * (sum_i m_i h_i - m_j h_j) [ / (n_alive - 1) if mode_avg && n_alive > 1 ]
+ * n_alive = sum_j alive_j (NOT the talker count, quirk Q23) or N when alive == NULL (quirk Q21).
+ *   h [E][N][H] f32, alive [E][N] int32 or NULL, comm_action [E][N] int32 or NULL (all talk),
+ *   out [E][N][H] f32.  mask_self: 1 = ones-eye comm_mask (default), 0 = comm_mask_zero (out = 0). */
+int ic3_comm_masked_mean(const float* h, const int32_t* alive, const int32_t* comm_action, float* out,
+                         int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream);
+
+/* select_action (action_utils.py:32-36): one multinomial draw per (env, agent) row from exp(logp),
+ * as inverse-CDF on Philox uniforms: counter (head*N+n, t, episode, DOMAIN_SAMPLE), key (seed, env_id_offset+e).
+ *   logp [E][N][A] f32 -> action [E][N] int32, chosen_logp [E][N] f32 or NULL. */
+int ic3_sample_actions(const float* logp, int A, int head, uint32_t seed, uint32_t env_id_offset,
+                       uint32_t episode, uint32_t t, int32_t* action, float* chosen_logp, int E, int N,
+                       ic3_stream stream);
+
+/* Synthetic uniform actions in [0, naction) for env-only benchmarks (DOMAIN_BENCH). */
+int ic3_random_actions(int32_t* action, int naction, uint32_t seed, uint32_t env_id_offset, uint32_t episode,
+                       uint32_t t, int E, int N, ic3_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IC3_ROLLOUT_H */

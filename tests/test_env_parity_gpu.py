@@ -1,0 +1,226 @@
+"""GPU: the HIP env kernels (through the C ABI / ic3net_amd.envs) against
+  (1) golden vectors captured from the reference itself, and
+  (2) the CPU oracle on seeded random trajectories at sizes the oracle finishes in seconds.
+Integer state is compared bit-exact; rewards as float32(reference float64) bit-exact."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load, SparseObs, PP_FIXTURES, TJ_FIXTURES, MODES, DIFFS  # noqa: E402
+
+
+def pp_args(N, dim, vision, mode, E, seed=0, offset=0, no_stay=False):
+    return argparse.Namespace(nfriendly=N, nenemies=1, dim=dim, vision=vision, moving_prey=False, mode=mode,
+                              enemy_comm=False, no_stay=no_stay, nenvs=E, seed=seed, env_id_offset=offset)
+
+
+def tj_args(N, dim, vision, difficulty, E, seed=0, offset=0, add_rate_min=0.05, add_rate_max=0.05, curr_start=0,
+            curr_end=0):
+    return argparse.Namespace(nagents=N, dim=dim, vision=vision, difficulty=difficulty, vocab_type='bool',
+                              add_rate_min=add_rate_min, add_rate_max=add_rate_max, curr_start=curr_start,
+                              curr_end=curr_end, nenvs=E, seed=seed, env_id_offset=offset)
+
+
+def make_pp(*a, **k):
+    from ic3net_amd.envs import PredatorPreyEnv
+    env = PredatorPreyEnv()
+    env.multi_agent_init(pp_args(*a, **k))
+    return env
+
+
+def make_tj(*a, **k):
+    from ic3net_amd.envs import TrafficJunctionEnv
+    env = TrafficJunctionEnv()
+    env.multi_agent_init(tj_args(*a, **k))
+    return env
+
+
+@pytest.mark.parametrize("name", PP_FIXTURES)
+def test_pp_hip_matches_reference_golden(name):
+    fx = load(name)
+    N, dim, vision, mode, T, no_stay = [int(x) for x in fx["cfg"]]
+    nenv, nep = fx["nsteps"].shape
+    sp = SparseObs(fx["obs_coo"], N, int(fx["obs_dim"]))
+    env = make_pp(N, dim, vision, MODES[mode], nenv, seed=int(fx["seed"]), offset=int(fx["env_gid0"]),
+                  no_stay=bool(no_stay))
+    assert env.obs_dim == int(fx["obs_dim"])
+    for ep in range(nep):
+        obs = env.reset().cpu().numpy()
+        st = env.get_state()
+        loc = np.stack([st["loc_r"], st["loc_c"]], -1)
+        np.testing.assert_array_equal(loc, fx["init_loc"][:, ep])
+        for e in range(nenv):
+            np.testing.assert_array_equal(obs[e], sp.dense(e, ep, 0))
+        nsteps = fx["nsteps"][:, ep]
+        last = {}
+        for t in range(int(nsteps.max())):
+            act = np.where((t < nsteps)[:, None], fx["actions"][:, ep, t], 0)
+            live = [e for e in range(nenv) if t < nsteps[e]]
+            obs, rew, done, info = env.step(act)
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            st = env.get_state()
+            loc = np.stack([st["loc_r"], st["loc_c"]], -1)
+            for e in range(nenv):
+                if e in live:
+                    np.testing.assert_array_equal(loc[e], fx["loc"][e, ep, t])
+                    np.testing.assert_array_equal(st["reached"][e], fx["reached"][e, ep, t])
+                    np.testing.assert_array_equal(rew[e], fx["reward"][e, ep, t].astype(np.float32))
+                    assert done[e] == fx["done"][e, ep, t]
+                    if fx["success"][e, ep, t] >= 0:
+                        assert st["success"][e] == fx["success"][e, ep, t]
+                    np.testing.assert_array_equal(obs[e], sp.dense(e, ep, t + 1))
+                    last[e] = (loc[e].copy(), st["reached"][e].copy())
+                else:   # frozen after done (the reference raises RuntimeError here)
+                    assert done[e] == 1 and not rew[e].any()
+                    np.testing.assert_array_equal(loc[e], last[e][0])
+                    np.testing.assert_array_equal(st["reached"][e], last[e][1])
+        env.check_actions()
+
+
+@pytest.mark.parametrize("name", TJ_FIXTURES)
+def test_tj_hip_matches_reference_golden(name):
+    fx = load(name)
+    N, dim, vision, diff, T = [int(x) for x in fx["cfg"]]
+    nenv, nep = fx["epochs"].shape
+    sp = SparseObs(fx["obs_coo"], N, int(fx["obs_dim"]))
+    cur = fx["curriculum"]
+    has_curr = bool(cur[3] > cur[2])
+    kw = dict(add_rate_min=float(fx["add_rate"]), add_rate_max=float(fx["add_rate"]))
+    if has_curr:
+        kw = dict(add_rate_min=cur[0], add_rate_max=cur[1], curr_start=cur[2], curr_end=cur[3])
+    # the curriculum fixture gives every env instance its own epoch sequence -> one handle per env there
+    groups = [[e] for e in range(nenv)] if has_curr else [list(range(nenv))]
+    for grp in groups:
+        env = make_tj(N, dim, vision, DIFFS[diff], len(grp), seed=int(fx["seed"]),
+                      offset=int(fx["env_gid0"]) + grp[0], **kw)
+        assert env.obs_dim == int(fx["obs_dim"])
+        for ep in range(nep):
+            obs = env.reset(int(fx["epochs"][grp[0], ep]))
+            assert not obs.any().item()
+            for t in range(T):
+                obs, rew, done, info = env.step(fx["actions"][grp, ep, t])
+                obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+                st = env.get_state()
+                st["loc"] = np.stack([st["loc_r"], st["loc_c"]], -1)
+                for k in ("alive", "wait", "loc", "last_act", "route_loc", "route_id", "is_completed",
+                          "cars_in_sys", "has_failed"):
+                    np.testing.assert_array_equal(st[k], fx[k][grp, ep, t], err_msg="%s ep=%d t=%d" % (k, ep, t))
+                np.testing.assert_array_equal(info["alive_mask"].cpu().numpy(), fx["alive"][grp, ep, t])
+                np.testing.assert_array_equal(info["is_completed"].cpu().numpy(), fx["is_completed"][grp, ep, t])
+                np.testing.assert_array_equal(rew, fx["reward"][grp, ep, t].astype(np.float32))
+                assert env.add_rate == fx["add_rate_seen"][grp[0], ep, t]
+                assert not done.any().item()
+                for i, e in enumerate(grp):
+                    np.testing.assert_array_equal(obs[i], sp.dense(e, ep, t + 1))
+        env.check_actions()
+
+
+def test_tj_tables_through_handle():
+    fx = load("tj_tables")
+    for key in ("medium_14_v1", "hard_18_v0", "easy_6_v0"):
+        diff, dim, v = key.split("_")
+        env = make_tj(5, int(dim), int(v[1:]), diff, 2)
+        grid, off, rc = env.tables()
+        np.testing.assert_array_equal(grid, fx[key + "_grid"])
+        np.testing.assert_array_equal(off, fx[key + "_off"])
+        np.testing.assert_array_equal(rc, fx[key + "_rc"])
+
+
+@pytest.mark.parametrize("cfg", [(10, 20, 1, "mixed", 96, 40), (3, 5, 0, "cooperative", 200, 20),
+                                 (32, 40, 2, "mixed", 8, 12), (7, 9, 2, "competitive", 64, 25)])
+def test_pp_hip_matches_oracle_random(cfg):
+    import oracle
+    N, dim, vision, mode, E, T = cfg
+    env = make_pp(N, dim, vision, mode, E, seed=77, offset=1000)
+    orcs = [oracle.PPOracle(N, dim, vision, mode, seed=77, env_gid=1000 + e) for e in range(E)]
+    rs = np.random.RandomState(5)
+    for ep in range(2):
+        obs = env.reset().cpu().numpy()
+        for e, o in enumerate(orcs):
+            np.testing.assert_array_equal(obs[e], o.reset())
+        for t in range(T):
+            act = rs.randint(0, 5, size=(E, N))
+            obs, rew, done, _ = env.step(act)
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            st = env.get_state()
+            for e, o in enumerate(orcs):
+                if o.over.value:
+                    assert done[e] == 1
+                    continue
+                oo, orew, od = o.step(act[e])
+                np.testing.assert_array_equal(np.stack([st["loc_r"][e], st["loc_c"][e]], -1), o.loc)
+                np.testing.assert_array_equal(st["reached"][e], o.reached)
+                np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+                assert done[e] == int(od)
+                np.testing.assert_array_equal(obs[e], oo)
+
+
+@pytest.mark.parametrize("cfg", [(10, 14, 1, "medium", 48, 40, 0.3), (20, 18, 0, "hard", 32, 60, 0.1),
+                                 (5, 6, 0, "easy", 128, 20, 0.6), (20, 18, 1, "hard", 8, 30, 1.0)])
+def test_tj_hip_matches_oracle_random(cfg):
+    import oracle
+    N, dim, vision, diff, E, T, rate = cfg
+    env = make_tj(N, dim, vision, diff, E, seed=9, offset=500, add_rate_min=rate, add_rate_max=rate)
+    orcs = [oracle.TJOracle(N, dim, vision, diff, add_rate_min=rate, add_rate_max=rate, seed=9, env_gid=500 + e)
+            for e in range(E)]
+    rs = np.random.RandomState(6)
+    for ep in range(2):
+        env.reset(ep)
+        for o in orcs:
+            o.reset(ep)
+        for t in range(T):
+            act = (rs.rand(E, N) < 0.35).astype(np.int32)
+            obs, rew, done, info = env.step(act)
+            obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+            st = env.get_state()
+            for e, o in enumerate(orcs):
+                oo, orew, _ = o.step(act[e])
+                for k in ("alive", "wait", "last_act", "route_loc", "route_id", "is_completed"):
+                    np.testing.assert_array_equal(st[k][e], getattr(o, k), err_msg=k)
+                np.testing.assert_array_equal(np.stack([st["loc_r"][e], st["loc_c"][e]], -1), o.loc)
+                assert st["cars_in_sys"][e] == o.cars_in_sys.value and st["has_failed"][e] == o.has_failed.value
+                np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+                np.testing.assert_array_equal(obs[e], oo)
+
+
+def test_pp_full_size_properties():
+    """BASELINE config 2 at full size (E=8192): size-independent properties of the obs tensor."""
+    E, N, dim, v = 8192, 10, 20, 1
+    env = make_pp(N, dim, v, "mixed", E, seed=3)
+    obs = env.reset()
+    vocab = dim * dim + 4
+    o = obs.view(E, N, 9, vocab)
+    # exactly one location bit (cell id or OUTSIDE) per window cell
+    assert torch.equal(o[..., :dim * dim + 2].sum(-1), torch.ones(E, N, 9, device=obs.device))
+    # the centre cell holds the agent itself: predator count >= 1; total predator count over the 3x3 window
+    assert (o[:, :, 4, vocab - 1] >= 1).all()
+    st = env.get_state()
+    r, c = torch.as_tensor(st["loc_r"][:, :N]).cuda(), torch.as_tensor(st["loc_c"][:, :N]).cuda()
+    centre_id = (r * dim + c).long()
+    assert torch.equal(o[:, :, 4, :dim * dim].argmax(-1), centre_id)
+    # shard invariance: envs [4096, 8192) of this handle == a second handle with env_id_offset 4096
+    env2 = make_pp(N, dim, v, "mixed", 4096, seed=3, offset=4096)
+    obs2 = env2.reset()
+    assert torch.equal(obs[4096:], obs2)
+
+
+def test_bad_action_flag_and_errors():
+    env = make_pp(3, 5, 0, "mixed", 4)
+    env.reset()
+    env.step(np.full((4, 3), 5))          # 5 is tolerated (<= naction, quirk Q2)
+    env.check_actions()
+    env.step(np.full((4, 3), 6))
+    with pytest.raises(AssertionError):
+        env.check_actions()
+    from ic3net_amd.envs import PredatorPreyEnv
+    bad = PredatorPreyEnv()
+    a = pp_args(3, 5, 0, "mixed", 4)
+    a.moving_prey = True
+    with pytest.raises(NotImplementedError):
+        bad.multi_agent_init(a)
+    with pytest.raises(AssertionError):
+        make_tj(5, 7, 0, "medium", 2)
