@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on its headline config, on N MI355X of one node.
+
+metric   env-steps/sec counted as agents x envs x steps (BASELINE.json) of the rollout hot path
+         Trainer.step_episode = {CommNetMLP forward -> select_action -> env.step (step + obs assembly kernels)},
+         episodes reset inside the timed region every max_steps steps.
+workload configs[1] "Predator-Prey hard": 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent hid 128,
+         8192 parallel envs per GPU (weak scaling: every rank owns 8192 envs, global env ids rank*8192 + e).
+A "step" = one lock-step iteration of the hot loop over all envs of the rank.
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+WORKLOADS = {
+    # name: (env_name, dict of flags)  — BASELINE.json configs
+    "pp_hard": ("predator_prey", dict(nagents=10, dim=20, vision=1, max_steps=80, hid_size=128, ic3net=True,
+                                      recurrent=True, detach_gap=10, mode='mixed')),
+    "pp_easy": ("predator_prey", dict(nagents=3, dim=5, vision=0, max_steps=20, hid_size=128, ic3net=True,
+                                      recurrent=True, detach_gap=10, mode='mixed')),
+    "tj_medium": ("traffic_junction", dict(nagents=10, dim=14, vision=1, max_steps=40, hid_size=128, commnet=True,
+                                           recurrent=True, detach_gap=10, difficulty='medium', add_rate_min=0.05,
+                                           add_rate_max=0.05)),
+    "tj_hard": ("traffic_junction", dict(nagents=20, dim=18, vision=1, max_steps=80, hid_size=128, ic3net=True,
+                                         recurrent=True, detach_gap=10, difficulty='hard', add_rate_min=0.05,
+                                         add_rate_max=0.05)),
+    "pp_scaled": ("predator_prey", dict(nagents=32, dim=40, vision=2, max_steps=80, hid_size=256, ic3net=True,
+                                        recurrent=True, detach_gap=10, mode='mixed')),
+}
+
+
+def make_args(env_name, flags, nenvs, seed, env_id_offset, device):
+    """main.py:22-155 argument handling for the flags the hot path reads."""
+    a = argparse.Namespace(
+        batch_size=500, hid_size=64, recurrent=False, seed=seed, lrate=0.001, env_name=env_name, max_steps=20,
+        display=False, commnet=False, ic3net=False, nagents=1, comm_mode='avg', comm_passes=1, comm_mask_zero=False,
+        mean_ratio=1.0, rnn_type='MLP', detach_gap=10000, comm_init='uniform', hard_attn=False, comm_action_one=False,
+        share_weights=False, nenvs=nenvs, env_id_offset=env_id_offset, device=device, store_states=False)
+    if env_name == 'predator_prey':
+        a.__dict__.update(nenemies=1, dim=5, vision=2, moving_prey=False, no_stay=False, mode='mixed', enemy_comm=False)
+    else:
+        a.__dict__.update(dim=5, vision=1, add_rate_min=0.05, add_rate_max=0.2, curr_start=0, curr_end=0,
+                          difficulty='easy', vocab_type='bool')
+    a.__dict__.update(flags)
+    if a.ic3net:                          # main.py:115-123
+        a.commnet = 1
+        a.hard_attn = 1
+        a.mean_ratio = 0
+        if a.env_name == 'traffic_junction':
+            a.comm_action_one = True
+    a.nfriendly = a.nagents               # main.py:125
+    return a
+
+
+def build_trainer(workload, nenvs, seed, env_id_offset, device):
+    import torch
+    from ic3net_amd import data
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    from ic3net_amd.trainer import Trainer
+    env_name, flags = WORKLOADS[workload]
+    a = make_args(env_name, flags, nenvs, seed, env_id_offset, device)
+    env = data.init(env_name, a, False)
+    a.num_actions = [env.num_actions]     # main.py:134-152
+    a.dim_actions = env.dim_actions
+    a.num_inputs = env.observation_dim
+    if a.hard_attn and a.commnet:
+        a.num_actions = [*a.num_actions, 2]
+        a.dim_actions = env.dim_actions + 1
+    if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
+        a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    torch.manual_seed(seed)               # default PyTorch init, random weights (no checkpoints offline)
+    net = CommNetMLP(a, a.num_inputs).to(torch.device('cuda', device)).float()
+    return Trainer(a, net, env), a
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline leg: the oracle ("port" of the reference's per-env Python/numpy loop), timed on the host
+# cores of this box on a bounded sample of the same workload.  One env object per step call, batch-1
+# fp64 policy calls — the reference's cost structure — in `procs` forked workers (README: nprocesses 16).
+# --------------------------------------------------------------------------------------------------
+def _cpu_worker(job):
+    workload, env_ids, episodes, seed = job
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    import oracle
+    from oracle import policy_ref, philox
+    env_name, f = WORKLOADS[workload]
+    N, H, T = f['nagents'], f['hid_size'], f['max_steps']
+    rs = np.random.RandomState(seed)
+    t0 = time.perf_counter()
+    steps = 0
+    params = None
+    for gid in env_ids:
+        if env_name == 'predator_prey':
+            env = oracle.PPOracle(N, f['dim'], f['vision'], f['mode'], seed=seed, env_gid=gid)
+        else:
+            env = oracle.TJOracle(N, f['dim'], f['vision'], f['difficulty'], add_rate_min=f['add_rate_min'],
+                                  add_rate_max=f['add_rate_max'], seed=seed, env_gid=gid)
+        heads = [env.cfg.naction if env_name == 'predator_prey' else 2] + ([2] if f.get('ic3net') else [])
+        if params is None:
+            k = 1.0 / np.sqrt(H)
+            shp = {'encoder.weight': (H, env.obs_dim), 'encoder.bias': (H,), 'f_module.weight_ih': (4 * H, H),
+                   'f_module.weight_hh': (4 * H, H), 'f_module.bias_ih': (4 * H,), 'f_module.bias_hh': (4 * H,),
+                   'C_modules.0.weight': (H, H), 'C_modules.0.bias': (H,), 'value_head.weight': (1, H),
+                   'value_head.bias': (1,)}
+            for i, A in enumerate(heads):
+                shp['heads.%d.weight' % i] = (A, H)
+                shp['heads.%d.bias' % i] = (A,)
+            params = {n: rs.uniform(-k, k, size=s) for n, s in shp.items()}
+        for ep in range(episodes):
+            obs = env.reset() if env_name == 'predator_prey' else env.reset(ep)
+            hc = (np.zeros((N, H)), np.zeros((N, H)))
+            alive, ca = None, np.zeros(N)
+            for t in range(T):
+                logp, value, hc = policy_ref.forward(params, obs[None].astype(np.float64), hc, alive, ca,
+                                                     recurrent=True, hard_attn=bool(f.get('ic3net')),
+                                                     nheads=len(heads))
+                acts = []
+                for hd, lp in enumerate(logp):
+                    acts.append([oracle.sample_one(lp[0, n].astype(np.float32),
+                                                   philox.x24(seed, gid, philox.DOMAIN_SAMPLE, ep, t, hd * N + n))
+                                 for n in range(N)])
+                obs, rew, done = env.step(np.array(acts[0]))
+                if env_name == 'traffic_junction':
+                    alive = env.alive.astype(np.float64)
+                    ca = np.ones(N)
+                else:
+                    ca = np.array(acts[-1], np.float64)
+                steps += 1
+                if done:
+                    break
+    return steps, time.perf_counter() - t0
+
+
+def cpu_baseline(workload, envs_per_proc=6, episodes=2, seed=0):
+    import multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    import oracle
+    oracle.build()
+    procs = max(1, min(16, os.cpu_count() or 1))        # the reference's nprocesses=16 (README.md:46)
+    jobs = [(workload, list(range(p * envs_per_proc, (p + 1) * envs_per_proc)), episodes, seed) for p in range(procs)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    env_steps = sum(r[0] for r in res)
+    N = WORKLOADS[workload][1]['nagents']
+    return {"value": round(N * env_steps / wall, 1), "unit": "agent-steps/s", "cores": procs, "kind": "port",
+            "sample": "%d procs x %d envs x %d episode(s) of %s, batch-1 fp64 numpy policy + C oracle env, "
+                      "%d env-steps in %.1f s wall" % (procs, envs_per_proc, episodes, workload, env_steps, wall)}
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=160)
+    p.add_argument('--warmup', type=int, default=16)
+    p.add_argument('--workload', default='pp_hard', choices=sorted(WORKLOADS))
+    p.add_argument('--nenvs', type=int, default=8192, help='environments per GPU')
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--graph', type=int, default=int(os.environ.get('IC3_BENCH_GRAPH', '0')))
+    o = p.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == o.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    cpu = None
+    if rank == 0 and world == 1 and not o.no_cpu_baseline:
+        cpu = cpu_baseline(o.workload)            # before CUDA is initialised (fork-safe)
+
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend='nccl')   # RCCL; used only for the timing barrier / max-reduce
+
+    trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
+    T = a.max_steps
+    raw_env = trainer.env.env
+
+    def run(nsteps, t_in_ep):
+        for _ in range(nsteps):
+            if t_in_ep == 0:
+                trainer.begin_episode(0)
+            trainer.step_episode(t_in_ep)
+            t_in_ep += 1
+            if t_in_ep == T:
+                trainer.end_episode()             # stats reduced on device, one host read per episode
+                t_in_ep = 0
+        return t_in_ep
+
+    t_in_ep = run(o.warmup, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    raw_env.obs_timer = []
+    t0 = time.perf_counter()
+    t_in_ep = run(o.steps, t_in_ep)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    obs_ms = [s.elapsed_time(e) for s, e in raw_env.obs_timer]
+    raw_env.obs_timer = None
+    if rank == 0:
+        N = a.nagents
+        E_total = o.nenvs * world
+        value = N * E_total * o.steps / dt
+        obs_bytes = o.nenvs * N * raw_env.obs_dim * 4          # algorithmic bytes of one obs-assembly launch
+        avg_ms = sum(obs_ms) / max(len(obs_ms), 1)
+        achieved = obs_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'obs_traffic.json')
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(o.workload)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (agents x envs x steps), rollout hot path",
+            "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
+            "ms_per_step": round(dt / o.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
+                                   "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
+                       "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world},
+            "roofline": {"kernel": "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": obs_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": len(obs_ms)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -2,6 +2,10 @@
 import ctypes as C
 import os
 
+# torch must load first: it ships its own libamdhip64 (same soname as /opt/rocm's); loading ours first would
+# bind the process to a second HIP runtime that cannot see torch's device allocations.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libic3rollout.so")
 

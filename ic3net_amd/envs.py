@@ -24,6 +24,7 @@ class _BatchedEnv(object):
         self._h = None
         self.stat = dict()
         self.episode_over = False
+        self.obs_timer = None     # set to a list to collect (start, end) HIP events around every obs launch
 
     # --- handle ---------------------------------------------------------------------------------
     def _finish_init(self, handle, device):
@@ -118,8 +119,19 @@ class _BatchedEnv(object):
         self._require()
         a = self._actions(action)
         with torch.cuda.device(self.device):
-            check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(self._reward), ptr(self._done),
-                                          ptr(self._alive), ptr(self._completed), stream()))
+            if self.obs_timer is None:
+                check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(self._reward), ptr(self._done),
+                                              ptr(self._alive), ptr(self._completed), stream()))
+            else:
+                # same two kernels, but with HIP events (on the launch stream) bracketing the obs-assembly launch
+                check(_lib.lib().ic3_env_step(self._h, ptr(a), None, ptr(self._reward), ptr(self._done),
+                                              ptr(self._alive), ptr(self._completed), stream()))
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
+                check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
+                e1.record(torch.cuda.current_stream())
+                self.obs_timer.append((e0, e1))
         return self._obs, self._reward, self._done
 
     def reward_terminal(self):

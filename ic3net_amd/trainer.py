@@ -1,0 +1,172 @@
+"""Trainer mirror — the rollout half of /root/reference/trainer.py (`Transition` :10-11, `get_episode`
+:26-126, `run_batch` :227-242), batched: one call plays E = env.nenvs episodes in lock-step, every
+tensor of a Transition carries a leading env dimension and everything stays on the GPU until the
+per-episode statistics are reduced once at the end.
+
+Differences forced by batching:
+  * an env whose episode ended early (PP 'mixed': all predators on the prey) is frozen by the step kernel;
+    its later transitions are masked through misc['alive_mask'] == 0 and misc['live'] == 0, and do not
+    count in stat['num_steps'] — each env's episode is exactly the reference's episode.
+  * stat values are sums over the E envs (the reference sums the same keys over episodes in merge_stat);
+    run_batch adds E to stats['num_episodes'] per get_episode call.
+  * `state` / `next_state` are only materialised in the Transition when args.store_states is set (the
+    env reuses one (E,N,obs_dim) buffer; PP-hard is 1.19 GB per step at E = 8192).
+"""
+from collections import namedtuple
+from inspect import signature
+
+import numpy as np
+import torch
+from torch import optim
+
+from .action_utils import SampleClock, select_action, translate_action
+from .utils import merge_stat
+
+Transition = namedtuple('Transition', ('state', 'action', 'action_out', 'value', 'episode_mask', 'episode_mini_mask',
+                                       'next_state', 'reward', 'misc'))
+
+
+class Trainer(object):
+    def __init__(self, args, policy_net, env):
+        self.args = args
+        self.policy_net = policy_net
+        self.env = env
+        self.display = False
+        self.last_step = False
+        self.optimizer = optim.RMSprop(policy_net.parameters(), lr=args.lrate, alpha=0.97, eps=1e-6)   # trainer.py:21-22
+        self.params = [p for p in self.policy_net.parameters()]
+        self.clock = SampleClock(getattr(args, 'seed', 0), getattr(args, 'env_id_offset', 0))
+        self.clock.episode = -1
+        self.stats = dict()
+
+    # ------------------------------------------------------------------------------------------
+    def get_episode(self, epoch):
+        """trainer.py:26-126 for E envs in lock-step: begin_episode + max_steps x step_episode + end_episode."""
+        self.begin_episode(epoch)
+        check_every = int(getattr(self.args, 'done_check_every', 0))
+        for t in range(self.args.max_steps):
+            self.step_episode(t)
+            if check_every and (t + 1) % check_every == 0 and not bool(self._live.any().item()):
+                break                                               # trainer.py:107-108 (every env is done)
+        return self.end_episode()
+
+    def begin_episode(self, epoch):
+        args = self.args
+        self._episode = []
+        if 'epoch' in signature(self.env.reset).parameters:        # trainer.py:28-32
+            state = self.env.reset(epoch)
+        else:
+            state = self.env.reset()
+        if self.display and self.last_step:
+            raise NotImplementedError("--display is outside the hot-path scope (SURVEY 8(f) f4)")
+        E, dev = state.shape[0], state.device
+        self._state = state
+        self.clock.episode += 1
+        self._info = dict()
+        self._live = torch.ones(E, dtype=torch.float32, device=dev)     # 1 while the env's episode is running
+        self._steps = torch.zeros(E, dtype=torch.float32, device=dev)
+        self._reward_sum = torch.zeros(args.nagents, dtype=torch.float64, device=dev)
+        self._comm_sum = torch.zeros(args.nagents, dtype=torch.float64, device=dev)
+        self._prev_hid = None
+
+    def step_episode(self, t):
+        """One iteration of the hot loop trainer.py:43-108 for all E envs."""
+        args = self.args
+        state, info, live = self._state, self._info, self._live
+        E, dev = state.shape[0], state.device
+        store = bool(getattr(args, 'store_states', False))
+        self.clock.t = t
+        misc = dict()
+        with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):
+            if t == 0 and args.hard_attn and args.commnet:         # trainer.py:45-46 (quirk Q22)
+                info['comm_action'] = torch.zeros((E, args.nagents), dtype=torch.int32, device=dev)
+            if args.recurrent:                                     # trainer.py:49-60
+                if args.rnn_type == 'LSTM' and t == 0:
+                    self._prev_hid = self.policy_net.init_hidden(batch_size=E)
+                action_out, value, prev_hid = self.policy_net([state, self._prev_hid], info)
+                if (t + 1) % args.detach_gap == 0:
+                    prev_hid = (prev_hid[0].detach(), prev_hid[1].detach())
+                self._prev_hid = prev_hid
+            else:
+                action_out, value = self.policy_net(state, info)
+            action = select_action(args, action_out, self.clock)            # trainer.py:65
+            action, actual = translate_action(args, self.env, action)       # trainer.py:66
+            cur_state = state.clone() if store else None
+            next_state, reward, done, info = self.env.step(actual)          # trainer.py:67
+            info = dict(info)
+            if args.hard_attn and args.commnet:                    # trainer.py:70-75
+                info['comm_action'] = action[-1] if not args.comm_action_one else \
+                    torch.ones((E, args.nagents), dtype=torch.int32, device=dev)
+                self._comm_sum += (info['comm_action'].to(torch.float64) * live.unsqueeze(1).double()).sum(0)
+            if 'alive_mask' in info:                               # trainer.py:78-81
+                alive = info['alive_mask'].to(torch.float32)
+            else:
+                alive = torch.ones_like(reward)
+            misc['alive_mask'] = alive * live.unsqueeze(1)
+            misc['live'] = live
+            reward = reward.clone()
+            self._reward_sum += reward.double().sum(0)             # trainer.py:86 (frozen envs report 0)
+            self._steps += live
+            not_done = ~done.to(torch.bool)
+            done_t = ~not_done if t != args.max_steps - 1 else torch.ones_like(not_done)    # trainer.py:90
+            episode_mask = (~done_t).to(torch.float32).unsqueeze(1).expand(E, args.nagents).contiguous()
+            episode_mini_mask = torch.ones_like(reward)
+            if 'is_completed' in info:                             # trainer.py:98-99 (only when not done, Q26)
+                episode_mini_mask = torch.where(done_t.unsqueeze(1), episode_mini_mask,
+                                                1.0 - info['is_completed'].to(torch.float32))
+            trans = Transition(cur_state, torch.stack(action), action_out, value, episode_mask, episode_mini_mask,
+                               next_state.clone() if store else None, reward, misc)
+            self._episode.append(trans)
+            self._live = live * not_done.to(torch.float32)
+            self._state = next_state
+            self._info = info
+        return trans
+
+    def end_episode(self):
+        args = self.args
+        episode, stat = self._episode, dict()
+        num_steps = float(self._steps.sum().item())
+        stat['num_steps'] = num_steps                              # trainer.py:109-110
+        stat['steps_taken'] = num_steps
+        stat['reward'] = self._reward_sum.cpu().numpy()[:args.nfriendly]
+        if args.hard_attn and args.commnet:
+            stat['comm_action'] = self._comm_sum.cpu().numpy()[:args.nfriendly]
+        if hasattr(self.env, 'reward_terminal'):                   # trainer.py:112-121 (zeros for PP/TJ)
+            rt = self.env.reward_terminal()
+            episode[-1] = episode[-1]._replace(reward=episode[-1].reward + rt)
+            stat['reward'] = stat['reward'] + rt.double().sum(0).cpu().numpy()[:args.nfriendly]
+        if hasattr(self.env, 'get_stat'):                          # trainer.py:124-125
+            merge_stat(self.env.get_stat(), stat)
+        return (episode, stat)
+
+    def run_batch(self, epoch):                                    # trainer.py:227-242
+        batch = []
+        self.stats = dict()
+        self.stats['num_episodes'] = 0
+        nsteps = 0
+        E = self.env.nenvs
+        while nsteps < self.args.batch_size:
+            if self.args.batch_size - nsteps <= self.args.max_steps * E:
+                self.last_step = True
+            episode, episode_stat = self.get_episode(epoch)
+            nsteps += episode_stat['num_steps']
+            merge_stat(episode_stat, self.stats)
+            self.stats['num_episodes'] += E
+            batch += episode
+        self.last_step = False
+        self.stats['num_steps'] = nsteps
+        batch = Transition(*zip(*batch))
+        return batch, self.stats
+
+    # ------------------------------------------------------------------------------------------
+    def compute_grad(self, batch):
+        raise NotImplementedError("compute_grad (trainer.py:128-225) is the 'next' row f1 of SURVEY 8(f)")
+
+    def train_batch(self, epoch):
+        raise NotImplementedError("train_batch (trainer.py:245-256) is the 'next' row f1 of SURVEY 8(f)")
+
+    def state_dict(self):                                          # trainer.py:258-262
+        return self.optimizer.state_dict()
+
+    def load_state_dict(self, state):
+        self.optimizer.load_state_dict(state)

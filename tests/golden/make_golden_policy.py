@@ -1,0 +1,203 @@
+"""Policy-forward (F4) and Trainer-surface (F5) golden vectors from the reference's own CommNetMLP /
+Trainer (fp64), see make_golden.py.  Fixtures hold weights (small configs) or a closed-form weight
+recipe (full-size config), inputs and the reference's outputs."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+import ref_harness as rh
+from oracle import philox
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def closed_form_weights(shapes, scale=0.05):
+    """Deterministic weights from the index alone (both sides regenerate them; no big blobs)."""
+    out = {}
+    for k, name in enumerate(sorted(shapes)):
+        shp = shapes[name]
+        n = int(np.prod(shp))
+        i = np.arange(n, dtype=np.float64)
+        out[name] = (scale * np.sin(0.37 * i + 1.3 * k) * np.cos(0.011 * i * (k + 1))).reshape(shp)
+    return out
+
+
+def policy_case(name, N, obs_dim, H, steps, seed, B=1, closed_form=False, **flags):
+    ref = rh.load_reference()
+    torch.set_default_dtype(torch.float64)
+    a = rh.make_args('predator_prey', nagents=N, hid_size=H, **flags)
+    a.num_inputs = obs_dim
+    heads = [5, 2] if a.hard_attn else [5]
+    a.naction_heads = heads
+    a.continuous = False
+    a.num_actions = heads
+    a.dim_actions = len(heads)
+    if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
+        a.recurrent = True
+        a.rnn_type = 'LSTM'
+    torch.manual_seed(seed)
+    net = ref['comm'].CommNetMLP(a, obs_dim)
+    if closed_form:
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        w = closed_form_weights(shapes)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    rs = np.random.RandomState(seed)
+    xs, alives, cas, outs_logp, outs_val, outs_h, outs_c = [], [], [], [[] for _ in heads], [], [], []
+    hid = net.init_hidden(B) if a.recurrent else None
+    for t in range(steps):
+        # sparse one-hot-like observations (what the envs produce) with a few counts > 1
+        x = np.zeros((B, N, obs_dim))
+        for b in range(B):
+            for n in range(N):
+                idx = rs.choice(obs_dim, size=min(obs_dim, 11), replace=False)
+                x[b, n, idx] = rs.choice([1.0, 1.0, 1.0, 2.0], size=len(idx))
+        info = {}
+        mode = t % 5
+        if mode == 0:
+            alive = None                                    # t=0: no alive_mask key (quirk Q21)
+        else:
+            k = [N, 0, 1, 2, max(N - 1, 0)][mode]
+            alive = np.zeros(N)
+            alive[rs.choice(N, size=k, replace=False)] = 1
+            info['alive_mask'] = alive.copy()
+        ca = (rs.rand(N) < 0.6).astype(np.int64) if t > 0 else np.zeros(N, dtype=np.int64)   # Q22
+        if a.hard_attn:
+            info['comm_action'] = ca
+        xt = torch.from_numpy(x)
+        with torch.no_grad():
+            if a.recurrent:
+                logp, val, hid = net([xt, hid], info)
+            else:
+                logp, val = net(xt, info)
+        xs.append(x)
+        alives.append(np.full(N, -1.0) if alive is None else alive)
+        cas.append(ca)
+        for k in range(len(heads)):
+            outs_logp[k].append(logp[k].numpy())
+        outs_val.append(val.numpy().reshape(B * N, 1))
+        if a.recurrent:
+            outs_h.append(hid[0].numpy())
+            outs_c.append(hid[1].numpy())
+    out = dict(cfg=np.array([N, obs_dim, H, steps, B, int(a.recurrent), a.comm_passes, int(a.comm_mode == 'avg'),
+                             int(a.comm_mask_zero), int(bool(a.hard_attn)), int(a.share_weights), len(heads),
+                             int(closed_form)], np.int32),
+               x=np.array(xs), alive=np.array(alives), comm_action=np.array(cas), value=np.array(outs_val))
+    if closed_form:
+        # inputs are regenerated from the seed by the test (same RandomState sequence) — keep only sparse form
+        nz = np.nonzero(out['x'])
+        out['x_nz'] = np.stack(nz).astype(np.int32)
+        out['x_val'] = out['x'][nz]
+        del out['x']
+    else:
+        for k, v in sd.items():
+            out['w:' + k] = v
+    for k in range(len(heads)):
+        out['logp%d' % k] = np.array(outs_logp[k])
+    if a.recurrent:
+        out['h'] = np.array(outs_h)
+        out['c'] = np.array(outs_c)
+    out['param_names'] = np.array(sorted(sd.keys()))
+    out['param_shapes'] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'params', len(sd), 'steps', steps)
+
+
+def main():
+    policy_case('policy_ic3net_small', 4, 29, 16, 10, 1, ic3net=True, recurrent=True)
+    policy_case('policy_ic3net_b3', 5, 29, 16, 6, 2, B=3, ic3net=True, recurrent=True)
+    policy_case('policy_commnet_rec', 4, 29, 16, 10, 3, commnet=True, recurrent=True)
+    policy_case('policy_commnet_mlp2', 4, 29, 16, 5, 4, commnet=True, comm_passes=2)
+    policy_case('policy_commnet_sum', 4, 29, 16, 5, 5, commnet=True, recurrent=True, comm_mode='sum')
+    policy_case('policy_commnet_maskzero', 4, 29, 16, 5, 6, commnet=True, recurrent=True, comm_mask_zero=True)
+    policy_case('policy_commnet_share', 4, 29, 16, 5, 7, commnet=True, comm_passes=3, share_weights=True)
+    policy_case('policy_commnet_initzeros', 4, 29, 16, 5, 8, commnet=True, recurrent=True, comm_init='zeros')
+    policy_case('policy_pphard_closed', 10, 3636, 128, 80, 9, ic3net=True, recurrent=True, closed_form=True)
+
+
+def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, **flags):
+    """F5: the reference Trainer.get_episode with `select_action` replaced by an action tape and the env RNG
+    injected; one reference episode per (env, episode).  Records per-transition fields + the stat dict."""
+    ref = rh.load_reference()
+    torch.set_default_dtype(torch.float64)
+    a = rh.make_args(env_name, max_steps=T, seed=seed, **flags)
+    env = rh.make_env(env_name, a)
+    rh.finish_args(a, env)
+    torch.manual_seed(seed)
+    net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    tr = ref['trainer'].Trainer(a, net, env)
+    N, nh = a.nagents, len(a.naction_heads)
+    rs = np.random.RandomState(seed)
+    tape = np.zeros((nenv, nep, T, nh, N), np.int64)
+    for h, A in enumerate(a.naction_heads):
+        tape[:, :, :, h] = rs.randint(0, A, size=(nenv, nep, T, N))
+    if env_name == 'traffic_junction':
+        tape[:, :, :, 0] = (rs.rand(nenv, nep, T, N) < 0.3)
+    rec = dict(action=np.zeros((nenv, nep, T, nh, N), np.int32), reward=np.zeros((nenv, nep, T, N)),
+               episode_mask=np.zeros((nenv, nep, T, N)), episode_mini_mask=np.zeros((nenv, nep, T, N)),
+               alive_mask=np.zeros((nenv, nep, T, N)), nsteps=np.zeros((nenv, nep), np.int32))
+    stat_keys = None
+    stats = {}
+    cursor = {}
+    trmod = ref['trainer']
+
+    def taped_select(args, action_out):
+        e, ep, t = cursor['e'], cursor['ep'], cursor['t']
+        cursor['t'] += 1
+        if env_name == 'traffic_junction':
+            ref['rnd'].begin(cursor['st'], philox.DOMAIN_TJ_ADD, ep, t)
+        act = tape[e, ep, t].copy()
+        if greedy and env_name == 'predator_prey' and e == 0:
+            raw = env.env
+            for i in range(N):
+                dr = raw.prey_loc[0][0] - raw.predator_loc[i][0]
+                dc = raw.prey_loc[0][1] - raw.predator_loc[i][1]
+                act[0, i] = (2 if dr > 0 else 0) if dr != 0 else ((1 if dc > 0 else 3) if dc != 0 else 4)
+            tape[e, ep, t] = act
+        return torch.from_numpy(act).view(nh, 1, N, 1)
+    trmod.select_action = taped_select
+    for e in range(nenv):
+        st = philox.Stream(seed, 300 + e)
+        env = rh.make_env(env_name, a)
+        tr.env = env
+        for ep in range(nep):
+            cursor.update(e=e, ep=ep, t=0, st=st)
+            ref['rnd'].begin(st, philox.DOMAIN_PP_RESET, ep, 0)
+            episode, stat = tr.get_episode(ep)
+            n = len(episode)
+            rec['nsteps'][e, ep] = n
+            for t, trn in enumerate(episode):
+                rec['action'][e, ep, t] = np.array([np.asarray(x) for x in trn.action])
+                rec['reward'][e, ep, t] = trn.reward
+                rec['episode_mask'][e, ep, t] = trn.episode_mask
+                rec['episode_mini_mask'][e, ep, t] = trn.episode_mini_mask
+                rec['alive_mask'][e, ep, t] = trn.misc['alive_mask']
+            for k, v in stat.items():
+                stats.setdefault(k, np.zeros((nenv, nep) + np.shape(v)))[e, ep] = v
+    trmod.select_action = ref['action_utils'].select_action
+    out = dict(rec)
+    out['tape'] = tape.astype(np.int32)
+    for k, v in stats.items():
+        out['stat:' + k] = v
+    out['cfg'] = np.array([N, T, nenv, nep, nh, seed], np.int32)
+    out['flags'] = np.array(repr(sorted(flags.items())))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'nsteps', rec['nsteps'].tolist(), 'stat keys', sorted(stats))
+
+
+def trainer_main():
+    trainer_case('trainer_pp_easy', 'predator_prey', 20, 3, 2, 21, greedy=True, nagents=3, dim=5, vision=0,
+                 hid_size=16, ic3net=True, recurrent=True, detach_gap=10)
+    trainer_case('trainer_pp_medium', 'predator_prey', 40, 2, 2, 22, greedy=True, nagents=5, dim=10, vision=1,
+                 hid_size=16, ic3net=True, recurrent=True, detach_gap=10)
+    trainer_case('trainer_tj_easy', 'traffic_junction', 20, 3, 2, 23, nagents=5, dim=6, vision=0, hid_size=16,
+                 ic3net=True, recurrent=True, detach_gap=10, add_rate_min=0.3, add_rate_max=0.3, difficulty='easy')
+    trainer_case('trainer_tj_medium_commnet', 'traffic_junction', 40, 2, 2, 24, nagents=10, dim=14, vision=1,
+                 hid_size=16, commnet=True, recurrent=True, detach_gap=10, add_rate_min=0.2, add_rate_max=0.2,
+                 difficulty='medium')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,54 @@
+"""Shared by CPU/GPU policy tests: rebuild fixture inputs / weights (tests/golden/policy_*.npz)."""
+import argparse
+
+import numpy as np
+
+from golden_util import load
+
+POLICY_FIXTURES = ["policy_ic3net_small", "policy_ic3net_b3", "policy_commnet_rec", "policy_commnet_mlp2",
+                   "policy_commnet_sum", "policy_commnet_maskzero", "policy_commnet_share",
+                   "policy_commnet_initzeros", "policy_pphard_closed"]
+
+
+def closed_form_weights(shapes, scale=0.05):
+    out = {}
+    for k, name in enumerate(sorted(shapes)):
+        shp = shapes[name]
+        n = int(np.prod(shp))
+        i = np.arange(n, dtype=np.float64)
+        out[name] = (scale * np.sin(0.37 * i + 1.3 * k) * np.cos(0.011 * i * (k + 1))).reshape(shp)
+    return out
+
+
+class PolicyCase(object):
+    def __init__(self, name):
+        fx = load(name)
+        (self.N, self.obs_dim, self.H, self.steps, self.B, rec, self.comm_passes, avg, mz, ha, sh, self.nheads,
+         closed) = [int(v) for v in fx["cfg"]]
+        self.recurrent, self.mode_avg, self.mask_zero, self.hard_attn, self.share = bool(rec), bool(avg), bool(mz), \
+            bool(ha), bool(sh)
+        self.fx = fx
+        if closed:
+            shapes = {str(n): eval(str(s)) for n, s in zip(fx["param_names"], fx["param_shapes"])}
+            self.params = closed_form_weights(shapes)
+            x = np.zeros((self.steps, self.B, self.N, self.obs_dim))
+            x[tuple(fx["x_nz"])] = fx["x_val"]
+            self.x = x
+        else:
+            self.params = {k[2:]: fx[k] for k in fx.files if k.startswith("w:")}
+            self.x = fx["x"]
+        self.heads = [5, 2][:self.nheads]
+
+    def alive(self, t):
+        a = self.fx["alive"][t]
+        return None if a[0] < 0 else a
+
+    def comm_action(self, t):
+        return self.fx["comm_action"][t]
+
+    def args(self):
+        return argparse.Namespace(nagents=self.N, hid_size=self.H, comm_passes=self.comm_passes,
+                                  recurrent=self.recurrent, continuous=False, naction_heads=self.heads,
+                                  comm_mask_zero=self.mask_zero, share_weights=self.share, comm_init='uniform',
+                                  hard_attn=self.hard_attn, comm_mode='avg' if self.mode_avg else 'sum',
+                                  rnn_type='LSTM' if self.recurrent else 'MLP', init_std=0.2)

@@ -59,3 +59,19 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(Exception):
         env.multi_agent_init(argparse.Namespace(nfriendly=3, nenemies=1, dim=5, vision=0, moving_prey=False,
                                                 mode='mixed', enemy_comm=False, no_stay=False, nenvs=2, seed=0))
+
+
+def test_policy_state_dict_keys_match_reference():
+    """Checkpoint compatibility surface: same parameter names and shapes as the reference's
+    CommNetMLP.state_dict(), recorded in the policy fixtures."""
+    import torch
+    from policy_util import POLICY_FIXTURES, PolicyCase
+    from ic3net_amd.comm import CommNetMLP
+    for name in POLICY_FIXTURES:
+        pc = PolicyCase(name)
+        net = CommNetMLP(pc.args(), pc.obs_dim)
+        sd = net.state_dict()
+        names = [str(n) for n in pc.fx["param_names"]]
+        shapes = [eval(str(s)) for s in pc.fx["param_shapes"]]
+        assert sorted(sd.keys()) == names, name
+        assert [tuple(sd[n].shape) for n in names] == shapes, name

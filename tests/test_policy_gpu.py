@@ -1,0 +1,139 @@
+"""GPU: the product policy (ic3net_amd.comm.CommNetMLP, fp32, comm_masked_mean HIP op) against outputs of
+the reference's own CommNetMLP (fp64 golden vectors) — tolerance 1e-5 absolute (north_star), over a
+free-running recurrence; plus the two custom ops against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from policy_util import POLICY_FIXTURES, PolicyCase  # noqa: E402
+
+TOL = 1e-5   # north_star: policy forward within 1e-5 (fp32 vs the reference's fp64)
+
+
+def build(pc):
+    from ic3net_amd.comm import CommNetMLP
+    net = CommNetMLP(pc.args(), pc.obs_dim)
+    sd = {k: torch.from_numpy(np.asarray(v)).float() for k, v in pc.params.items()}
+    net.load_state_dict(sd)           # strict: same keys and shapes as the reference's state_dict
+    return net.cuda().float()
+
+
+@pytest.mark.parametrize("name", POLICY_FIXTURES)
+def test_policy_matches_reference(name):
+    pc = PolicyCase(name)
+    fx = pc.fx
+    net = build(pc)
+    hid = net.init_hidden(pc.B) if pc.recurrent else None
+    worst = 0.0
+    with torch.no_grad():
+        for t in range(pc.steps):
+            info = {}
+            if pc.alive(t) is not None:
+                info['alive_mask'] = torch.from_numpy(pc.alive(t)).int().cuda()
+            if pc.hard_attn:
+                info['comm_action'] = torch.from_numpy(pc.comm_action(t)).int().cuda()
+            x = torch.from_numpy(pc.x[t]).float().cuda()
+            if pc.recurrent:
+                logp, val, hid = net([x, hid], info)
+            else:
+                logp, val = net(x, info)
+            for k in range(pc.nheads):
+                worst = max(worst, np.abs(logp[k].cpu().numpy() - fx["logp%d" % k][t]).max())
+            worst = max(worst, np.abs(val.reshape(-1, 1).cpu().numpy() - fx["value"][t]).max())
+            if pc.recurrent:
+                worst = max(worst, np.abs(hid[0].cpu().numpy() - fx["h"][t]).max())
+                worst = max(worst, np.abs(hid[1].cpu().numpy() - fx["c"][t]).max())
+    assert worst < TOL, worst
+
+
+@pytest.mark.parametrize("E,N,H", [(64, 10, 128), (7, 3, 16), (33, 20, 128), (5, 32, 256), (3, 1, 64)])
+def test_comm_masked_mean_vs_oracle(E, N, H):
+    from oracle import policy_ref
+    from ic3net_amd import ops
+    rs = np.random.RandomState(E + N)
+    h = rs.randn(E, N, H).astype(np.float32)
+    alive = (rs.rand(E, N) < 0.7).astype(np.int32)
+    ca = (rs.rand(E, N) < 0.6).astype(np.int32)
+    alive[0] = 0
+    if E > 1:
+        alive[1] = 0
+        alive[1, 0] = 1
+    ht = torch.from_numpy(h).cuda()
+    for avg in (True, False):
+        for use_alive, use_ca in ((True, True), (False, True), (True, False), (False, False)):
+            out = ops.comm_masked_mean(ht, torch.from_numpy(alive).cuda() if use_alive else None,
+                                       torch.from_numpy(ca).cuda() if use_ca else None, avg, True).cpu().numpy()
+            for e in range(E):
+                lit = policy_ref.comm_block(h[e:e + 1].astype(np.float64), alive[e] if use_alive else None,
+                                            ca[e] if use_ca else np.ones(N), avg, False, True)
+                np.testing.assert_allclose(out[e], lit[0], atol=2e-6)
+    z = ops.comm_masked_mean(ht, None, None, True, False)
+    assert not z.any().item()
+
+
+def test_comm_masked_mean_backward():
+    from ic3net_amd import ops
+    torch.manual_seed(0)
+    E, N, H = 6, 5, 32
+    h = torch.randn(E, N, H, device='cuda', requires_grad=True)
+    alive = (torch.rand(E, N, device='cuda') < 0.7).int()
+    ca = (torch.rand(E, N, device='cuda') < 0.7).int()
+    out = ops.comm_masked_mean(h, alive, ca, True, True)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    # dense torch reference of the same linear map
+    m = (alive * ca).float()
+    n_alive = alive.sum(1, keepdim=True).float()
+    scale = torch.where(n_alive > 1, 1.0 / (n_alive - 1).clamp(min=1), torch.ones_like(n_alive))
+    M = m.unsqueeze(2) * m.unsqueeze(1) * (1 - torch.eye(N, device='cuda')) * scale.unsqueeze(2)   # [e, j, i]
+    h2 = h.detach().clone().requires_grad_(True)
+    out2 = torch.einsum('eji,eih->ejh', M, h2)
+    (out2 * w).sum().backward()
+    torch.testing.assert_close(out, out2, atol=1e-5, rtol=0)
+    torch.testing.assert_close(h.grad, h2.grad, atol=1e-5, rtol=0)
+
+
+def test_sample_actions_vs_oracle_and_distribution():
+    import oracle
+    from oracle import philox
+    from ic3net_amd import ops
+    E, N, A = 512, 10, 5
+    rs = np.random.RandomState(1)
+    logits = rs.randn(E, N, A).astype(np.float32) * 1.5
+    logp = torch.log_softmax(torch.from_numpy(logits), -1)
+    act, chosen = ops.sample_actions(logp.cuda(), 1, 42, 7000, 3, 9, want_logp=True)
+    act, chosen = act.cpu().numpy(), chosen.cpu().numpy()
+    lp = logp.numpy()
+    mism = 0
+    for e in range(E):
+        for n in range(N):
+            x = philox.x24(42, 7000 + e, philox.DOMAIN_SAMPLE, 3, 9, 1 * N + n)
+            want = oracle.sample_one(lp[e, n], x)
+            if want != act[e, n]:      # only possible when u sits within an ulp of a cdf edge (expf rounding)
+                mism += 1
+                u = x / 2.0 ** 24
+                cdf = np.cumsum(np.exp(lp[e, n].astype(np.float64)))
+                assert np.abs(cdf - u).min() < 1e-6
+            assert chosen[e, n] == lp[e, n, act[e, n]]
+    assert mism <= 2
+    # distribution: many draws (different t) from one fixed row -> chi^2 against exp(logp)
+    p = np.array([0.05, 0.15, 0.4, 0.3, 0.1], np.float32)
+    row = torch.log(torch.from_numpy(p)).view(1, 1, A).expand(4096, 8, A).contiguous().cuda()
+    counts = np.zeros(A)
+    for t in range(8):
+        a = ops.sample_actions(row, 0, 5, 0, 0, t).cpu().numpy()
+        counts += np.bincount(a.ravel(), minlength=A)
+    n = counts.sum()
+    chi2 = ((counts - n * p) ** 2 / (n * p)).sum()
+    assert chi2 < 30.0, (chi2, counts)     # 4 dof; 30 is far beyond the 1e-5 quantile
+
+
+def test_random_actions_stream():
+    from oracle import philox
+    from ic3net_amd import ops
+    a = ops.random_actions(16, 6, 5, 11, 100, 2, 3).cpu().numpy()
+    for e in range(16):
+        for n in range(6):
+            assert a[e, n] == (philox.x24(11, 100 + e, philox.DOMAIN_BENCH, 2, 3, n) * 5) >> 24

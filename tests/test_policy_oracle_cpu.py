@@ -1,0 +1,53 @@
+"""CPU: the numpy policy oracle (oracle/policy_ref.py, literal N x N x H restatement of comm.py) against
+outputs of the reference's own CommNetMLP (fp64) — free-running recurrence over the fixture's steps."""
+import numpy as np
+import pytest
+
+from oracle import policy_ref
+from policy_util import POLICY_FIXTURES, PolicyCase
+
+
+@pytest.mark.parametrize("name", POLICY_FIXTURES)
+def test_policy_oracle_matches_reference(name):
+    pc = PolicyCase(name)
+    fx = pc.fx
+    hc = (np.zeros((pc.B * pc.N, pc.H)), np.zeros((pc.B * pc.N, pc.H))) if pc.recurrent else None
+    for t in range(pc.steps):
+        logp, value, hc2 = policy_ref.forward(pc.params, pc.x[t], hc, pc.alive(t), pc.comm_action(t),
+                                              recurrent=pc.recurrent, comm_passes=pc.comm_passes,
+                                              comm_mode_avg=pc.mode_avg, comm_mask_zero=pc.mask_zero,
+                                              hard_attn=pc.hard_attn, nheads=pc.nheads)
+        for k in range(pc.nheads):
+            np.testing.assert_allclose(logp[k], fx["logp%d" % k][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(value.reshape(-1, 1), fx["value"][t], rtol=0, atol=1e-12)
+        if pc.recurrent:
+            np.testing.assert_allclose(hc2[0], fx["h"][t], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(hc2[1], fx["c"][t], rtol=0, atol=1e-12)
+            hc = hc2
+
+
+def test_closed_form_comm_equals_literal():
+    """The closed form the HIP op implements (SURVEY B.5 i) against the literal expand/mask chain."""
+    rs = np.random.RandomState(0)
+    for trial in range(50):
+        N, H, B = rs.randint(1, 9), 8, 2
+        h = rs.randn(B, N, H)
+        alive = (rs.rand(N) < 0.7).astype(np.float64)
+        ca = (rs.rand(N) < 0.6).astype(np.float64)
+        for avg in (True, False):
+            lit = policy_ref.comm_block(h, alive, ca, avg, False, True)
+            m = alive * ca
+            S = (m[None, :, None] * h).sum(1, keepdims=True)
+            n_alive = alive.sum()
+            scale = 1.0 / (n_alive - 1) if (avg and n_alive > 1) else 1.0
+            closed = m[None, :, None] * (S - m[None, :, None] * h) * scale
+            np.testing.assert_allclose(closed, lit, atol=1e-13)
+
+
+def test_sampling_oracle_known_answers():
+    import oracle
+    lp = np.log(np.array([0.1, 0.2, 0.3, 0.4], np.float32))
+    # u = x24 / 2^24 against cdf 0.1, 0.3, 0.6
+    for u, want in ((0.0, 0), (0.05, 0), (0.15, 1), (0.299, 1), (0.31, 2), (0.59, 2), (0.61, 3), (0.9999, 3)):
+        assert oracle.sample_one(lp, int(u * 2 ** 24)) == want
+    assert oracle.sample_one(np.log(np.array([1.0], np.float32)), 12345) == 0

@@ -1,0 +1,128 @@
+"""GPU: the batched Trainer.get_episode / run_batch surface against golden vectors recorded from the
+reference's own Trainer.get_episode (action tape + injected env RNG, tests/golden/trainer_*.npz)."""
+import argparse
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load  # noqa: E402
+
+FIXTURES = [("trainer_pp_easy", "predator_prey"), ("trainer_pp_medium", "predator_prey"),
+            ("trainer_tj_easy", "traffic_junction"), ("trainer_tj_medium_commnet", "traffic_junction")]
+
+
+def build_args(env_name, flags, N, T, nenv, seed):
+    a = argparse.Namespace(
+        batch_size=500, hid_size=64, recurrent=False, seed=seed, lrate=0.001, env_name=env_name, max_steps=T,
+        display=False, commnet=False, ic3net=False, nagents=N, comm_mode='avg', comm_passes=1, comm_mask_zero=False,
+        mean_ratio=1.0, rnn_type='MLP', detach_gap=10000, comm_init='uniform', hard_attn=False, comm_action_one=False,
+        share_weights=False, nenvs=nenv, env_id_offset=300, store_states=False)
+    if env_name == 'predator_prey':
+        a.__dict__.update(nenemies=1, dim=5, vision=2, moving_prey=False, no_stay=False, mode='mixed', enemy_comm=False)
+    else:
+        a.__dict__.update(dim=5, vision=1, add_rate_min=0.05, add_rate_max=0.2, curr_start=0, curr_end=0,
+                          difficulty='easy', vocab_type='bool')
+    a.__dict__.update(flags)
+    if a.ic3net:                          # main.py:115-123
+        a.commnet = 1
+        a.hard_attn = 1
+        a.mean_ratio = 0
+        if a.env_name == 'traffic_junction':
+            a.comm_action_one = True
+    a.nfriendly = a.nagents
+    return a
+
+
+@pytest.mark.parametrize("name,env_name", FIXTURES)
+def test_get_episode_matches_reference(name, env_name):
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    fx = load(name)
+    N, T, nenv, nep, nh, seed = [int(x) for x in fx["cfg"]]
+    flags = dict(ast.literal_eval(str(fx["flags"])))
+    a = build_args(env_name, flags, N, T, nenv, seed)
+    env = data.init(env_name, a, False)
+    a.num_actions = [env.num_actions]     # main.py:134-152
+    a.dim_actions = env.dim_actions
+    a.num_inputs = env.observation_dim
+    if a.hard_attn and a.commnet:
+        a.num_actions = [*a.num_actions, 2]
+        a.dim_actions = env.dim_actions + 1
+    if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
+        a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    assert len(a.naction_heads) == nh
+    torch.manual_seed(seed)
+    net = CommNetMLP(a, a.num_inputs).cuda()
+    tr = trmod.Trainer(a, net, env)
+    tape = fx["tape"]                     # (nenv, nep, T, heads, N)
+
+    def taped(args, action_out, clock):
+        assert [tuple(x.shape) for x in action_out] == [(nenv, N, A) for A in a.naction_heads]
+        return torch.from_numpy(tape[:, clock.episode, clock.t]).permute(1, 0, 2).contiguous().int().cuda()
+    orig = trmod.select_action
+    trmod.select_action = taped
+    try:
+        for ep in range(nep):
+            episode, stat = tr.get_episode(ep)
+            nsteps = fx["nsteps"][:, ep]
+            assert len(episode) == T
+            for t, trn in enumerate(episode):
+                assert trn.value.shape == (nenv * N, 1)
+                rew, em, emm = trn.reward.cpu().numpy(), trn.episode_mask.cpu().numpy(), \
+                    trn.episode_mini_mask.cpu().numpy()
+                am, live = trn.misc['alive_mask'].cpu().numpy(), trn.misc['live'].cpu().numpy()
+                act = trn.action.cpu().numpy()
+                for e in range(nenv):
+                    if t < nsteps[e]:
+                        assert live[e] == 1
+                        np.testing.assert_array_equal(act[:, e], fx["action"][e, ep, t])
+                        np.testing.assert_array_equal(rew[e], fx["reward"][e, ep, t].astype(np.float32))
+                        np.testing.assert_array_equal(em[e], fx["episode_mask"][e, ep, t])
+                        np.testing.assert_array_equal(emm[e], fx["episode_mini_mask"][e, ep, t])
+                        np.testing.assert_array_equal(am[e], fx["alive_mask"][e, ep, t])
+                    else:
+                        assert live[e] == 0 and not am[e].any() and not rew[e].any()
+            # stats: the batched episode's stat is the sum of the E reference episodes' stats
+            assert stat['num_steps'] == nsteps.sum() == stat['steps_taken']
+            for k in [f[5:] for f in fx.files if f.startswith("stat:")]:
+                want = fx["stat:" + k][:, ep].sum(0)
+                np.testing.assert_allclose(np.asarray(stat[k], np.float64), want, rtol=1e-5, atol=1e-5, err_msg=k)
+            assert set(stat) == set(f[5:] for f in fx.files if f.startswith("stat:"))
+    finally:
+        trmod.select_action = orig
+
+
+def test_run_batch_surface():
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    a = build_args('predator_prey', dict(nagents=3, dim=5, vision=0, hid_size=32, ic3net=True, recurrent=True,
+                                         detach_gap=10), 3, 20, 16, 1)
+    a.env_id_offset = 0
+    env = data.init('predator_prey', a, False)
+    a.num_actions = [env.num_actions, 2]
+    a.dim_actions = 2
+    a.num_inputs = env.observation_dim
+    a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    net = CommNetMLP(a, a.num_inputs).cuda()
+    tr = trmod.Trainer(a, net, env)
+    a.batch_size = 500
+    batch, stats = tr.run_batch(0)
+    assert stats['num_episodes'] % 16 == 0 and stats['num_steps'] >= 500
+    assert stats['num_steps'] - 500 < 20 * 16                      # overshoot < one batched episode (quirk Q29)
+    assert set(stats) >= {'num_episodes', 'num_steps', 'steps_taken', 'reward', 'comm_action', 'success'}
+    assert isinstance(batch, trmod.Transition) and len(batch.reward) == len(batch.action)
+    assert batch.action[0].shape == (2, 16, 3) and batch.action_out[0][0].shape == (16, 3, 5)
+    # same seeds -> same rollout (counter-based streams)
+    tr2 = trmod.Trainer(a, net, data.init('predator_prey', a, False))
+    batch2, stats2 = tr2.run_batch(0)
+    assert stats2['num_steps'] == stats['num_steps']
+    assert all(torch.equal(x, y) for x, y in zip(batch.action, batch2.action))
+    np.testing.assert_array_equal(stats['reward'], stats2['reward'])
