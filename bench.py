@@ -93,7 +93,7 @@ def build_trainer(workload, nenvs, seed, env_id_offset, device):
 # fp64 policy calls — the reference's cost structure — in `procs` forked workers (README: nprocesses 16).
 # --------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
-    workload, env_ids, episodes, seed = job
+    workload, env_ids, episodes, seed, budget_s = job
     os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     try:
@@ -110,6 +110,8 @@ def _cpu_worker(job):
     steps = 0
     params = None
     for gid in env_ids:
+        if time.perf_counter() - t0 > budget_s:
+            break
         if env_name == 'predator_prey':
             env = oracle.PPOracle(N, f['dim'], f['vision'], f['mode'], seed=seed, env_gid=gid)
         else:
@@ -151,13 +153,15 @@ def _cpu_worker(job):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline(workload, envs_per_proc=6, episodes=2, seed=0):
+def cpu_baseline(workload, envs_per_proc=256, episodes=1, seed=0, budget_s=12.0):
+    """Every worker plays whole episodes on fresh envs until `budget_s` of CPU time is spent (bounded sample)."""
     import multiprocessing as mp
     sys.path.insert(0, ROOT)
     import oracle
     oracle.build()
     procs = max(1, min(16, os.cpu_count() or 1))        # the reference's nprocesses=16 (README.md:46)
-    jobs = [(workload, list(range(p * envs_per_proc, (p + 1) * envs_per_proc)), episodes, seed) for p in range(procs)]
+    jobs = [(workload, list(range(p * envs_per_proc, (p + 1) * envs_per_proc)), episodes, seed, budget_s)
+            for p in range(procs)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(procs) as pool:
         res = pool.map(_cpu_worker, jobs)
@@ -165,8 +169,8 @@ def cpu_baseline(workload, envs_per_proc=6, episodes=2, seed=0):
     env_steps = sum(r[0] for r in res)
     N = WORKLOADS[workload][1]['nagents']
     return {"value": round(N * env_steps / wall, 1), "unit": "agent-steps/s", "cores": procs, "kind": "port",
-            "sample": "%d procs x %d envs x %d episode(s) of %s, batch-1 fp64 numpy policy + C oracle env, "
-                      "%d env-steps in %.1f s wall" % (procs, envs_per_proc, episodes, workload, env_steps, wall)}
+            "sample": "%d procs x whole %s episodes for %.0f s each, batch-1 fp64 numpy policy + C oracle env: "
+                      "%d env-steps in %.1f s wall" % (procs, workload, budget_s, env_steps, wall)}
 
 
 def main():
