@@ -3,6 +3,8 @@
 // Reference semantics: /root/reference/ic3net-envs/ic3net_envs/predator_prey_env.py (cited "PP:line").
 // State is struct-of-arrays in HBM, one int32 array per field, env-major ([e][n]) so that the lane
 // mapping (env, agent) -> consecutive lanes reads/writes consecutive words.
+#include <cstdlib>
+
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
 //     + (ch == PREY_CLASS)  * #prey on the cell       (counts, quirk Q3)
 //     + (ch == PREDATOR_CLASS) * #predators on the cell
 // ------------------------------------------------------------------------------------------------
-template <bool VEC4>
+template <bool VEC4, bool NT, bool ALIGN>
 __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
                                                      const int32_t* __restrict__ loc_c, float* __restrict__ obs,
                                                      int N, int nprey, int dim, int v)
@@ -186,11 +188,17 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
         // vocab % 4 == 0: a 16-byte store never straddles a window cell; the three special channels
         // (OUTSIDE, PREY, PREDATOR = vocab-3, -2, -1) share the cell's last float4.
         const int segq = vocab >> 2;
-        const int Q = nseg * segq;
+        const int Q = nseg * segq;                         // float4s of this env (contiguous rows)
         f32x4* out = reinterpret_cast<f32x4*>(obs + (size_t)e * nseg * vocab);
-        int seg = threadIdx.x / segq, q = threadIdx.x - seg * segq;
+        // An env chunk is Q*16 bytes, in general not a multiple of the 1 KiB a wavefront stores per
+        // instruction: shift the lane->float4 mapping by o = (e*Q) mod 64 so that every wave-store is
+        // 1 KiB-aligned in the global address space (no partial cache lines except at chunk ends).
+        const int o = ALIGN ? (int)(((long long)e * Q) & 63) : 0;
+        int g = (int)threadIdx.x - o;
+        if (g < 0) g += 256;
+        int seg = g / segq, q = g - seg * segq;
         const int dseg = 256 / segq, dq = 256 - dseg * segq;
-        for (int g = threadIdx.x; g < Q; g += 256) {
+        for (; g < Q; g += 256) {
             const int2 t = tab[seg];
             f32x4 z = { 0.f, 0.f, 0.f, 0.f };
             if ((t.x >> 2) == q) {
@@ -204,7 +212,8 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
                 z.z += (float)(t.y >> 16);
                 z.w += (float)(t.y & 0xffff);
             }
-            __builtin_nontemporal_store(z, out + g);
+            if constexpr (NT) __builtin_nontemporal_store(z, out + g);
+            else out[g] = z;
             seg += dseg;
             q += dq;
             if (q >= segq) {
@@ -264,13 +273,22 @@ int pp_observe(ic3_env* env, float* obs, hipStream_t s)
     const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     const int vocab = c.dim * c.dim + 4;
-    if ((vocab & 3) == 0 && vocab / 4 <= 256 * 64) {
-        hipLaunchKernelGGL(pp_obs_kernel<true>, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"), obs,
-                           c.N, c.nprey, c.dim, c.vision);
+    static const int variant = getenv("IC3_OBS_VARIANT") ? atoi(getenv("IC3_OBS_VARIANT")) : 0;  // experiments only
+#define IC3_OBS_LAUNCH(V, NT, AL)                                                                                  \
+    hipLaunchKernelGGL((pp_obs_kernel<V, NT, AL>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"), obs, \
+                       c.N, c.nprey, c.dim, c.vision)
+    if ((vocab & 3) == 0) {
+        switch (variant) {
+            // measured on MI355X, PP-hard E=8192 (profiles/r01/obs_variants.txt): 5.62 / 5.03 / 4.41 / 5.40 TB/s
+            case 1: IC3_OBS_LAUNCH(true, true, true); break;    // nontemporal, aligned
+            case 2: IC3_OBS_LAUNCH(true, true, false); break;   // nontemporal, unaligned (first version)
+            case 3: IC3_OBS_LAUNCH(true, false, false); break;  // plain, unaligned
+            default: IC3_OBS_LAUNCH(true, false, true); break;  // plain stores, 1 KiB-aligned wave stores
+        }
     } else {
-        hipLaunchKernelGGL(pp_obs_kernel<false>, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"), obs,
-                           c.N, c.nprey, c.dim, c.vision);
+        IC3_OBS_LAUNCH(false, false, false);
     }
+#undef IC3_OBS_LAUNCH
     IC3_HIP(hipGetLastError());
     return 0;
 }
