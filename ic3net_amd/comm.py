@@ -51,6 +51,11 @@ class CommNetMLP(nn.Module):
                 self.C_modules[i].weight.data.zero_()
         self.tanh = nn.Tanh()
         self.value_head = nn.Linear(self.hid_size, 1)
+        # Optional fast path for the encoder during rollouts: a callable (weight_t, bias) -> (E,N,H) that evaluates
+        # encoder(current observation) straight from env state (envs.encode, the sparse-gather HIP kernel).  Set by
+        # Trainer when args.sparse_encoder; only used under torch.no_grad() (no backward through the gather yet).
+        self.obs_encoder = None
+        self._wt_cache = (None, None)
 
     # ------------------------------------------------------------------------------------------
     def _mask(self, info, key, batch, device):
@@ -68,9 +73,9 @@ class CommNetMLP(nn.Module):
         n, H = self.nagents, self.hid_size
         if self.args.recurrent:                                   # comm.py:117-122 (no tanh on this branch)
             x, (hidden_state, cell_state) = x
-            x = self.encoder(x)
+            x = self._encode(x)
         else:                                                     # comm.py:127-129
-            x = self.tanh(self.encoder(x))
+            x = self.tanh(self._encode(x))
             hidden_state, cell_state = x, None
         batch = x.size(0)
         alive = self._mask(info, 'alive_mask', batch, x.device)
@@ -91,6 +96,16 @@ class CommNetMLP(nn.Module):
         if self.args.recurrent:
             return action, value_head, (hidden_state.clone(), cell_state.clone())
         return action, value_head
+
+    def _encode(self, x):
+        """self.encoder(x) (comm.py:51,119); during no-grad rollouts optionally via the env's sparse gather."""
+        if self.obs_encoder is not None and not torch.is_grad_enabled() and self.hid_size % 4 == 0:
+            w = self.encoder.weight
+            key = (w._version, w.data_ptr())
+            if self._wt_cache[0] != key:
+                self._wt_cache = (key, w.detach().t().contiguous())
+            return self.obs_encoder(self._wt_cache[1], self.encoder.bias.detach())
+        return self.encoder(x)
 
     def init_hidden(self, batch_size):                            # comm.py:250-253
         p = self.encoder.weight

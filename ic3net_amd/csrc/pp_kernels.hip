@@ -154,19 +154,17 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
 //     + (ch == PREY_CLASS)  * #prey on the cell       (counts, quirk Q3)
 //     + (ch == PREDATOR_CLASS) * #predators on the cell
 // ------------------------------------------------------------------------------------------------
-template <bool VEC4, bool NT, bool ALIGN>
-__global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
-                                                     const int32_t* __restrict__ loc_c, float* __restrict__ obs,
-                                                     int N, int nprey, int dim, int v)
+// Per-env window descriptors in LDS: tab[a*W*W + dy*W + dx] = (one-hot channel, #predators | #prey << 16)
+// for agent a's window cell (dy, dx).  Shared by the obs-assembly and the sparse-encoder kernels.
+__device__ __forceinline__ const int2* pp_build_tab(int32_t* smem, const int32_t* __restrict__ loc_r,
+                                                    const int32_t* __restrict__ loc_c, int e, int N, int nprey,
+                                                    int dim, int v)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
-    const int e = blockIdx.x;
     const int total = N + nprey, W = 2 * v + 1, nseg = N * W * W;
-    const int vocab = dim * dim + 4, OUTSIDE = dim * dim + 1;
+    const int OUTSIDE = dim * dim + 1;
     int32_t* sr = smem;              // [total]
     int32_t* sc = sr + total;        // [total]
-    int2* tab = reinterpret_cast<int2*>(smem + ((2 * total + 3) & ~3));  // [nseg] (one-hot channel, npred | nprey<<16)
-
+    int2* tab = reinterpret_cast<int2*>(smem + ((2 * total + 3) & ~3));  // [nseg]
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         sr[i] = loc_r[(size_t)e * total + i];
         sc[i] = loc_c[(size_t)e * total + i];
@@ -183,6 +181,19 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
         tab[s] = make_int2(id, npred | (npr << 16));
     }
     __syncthreads();
+    return tab;
+}
+
+template <bool VEC4, bool NT, bool ALIGN>
+__global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
+                                                     const int32_t* __restrict__ loc_c, float* __restrict__ obs,
+                                                     int N, int nprey, int dim, int v)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x;
+    const int W = 2 * v + 1, nseg = N * W * W;
+    const int vocab = dim * dim + 4;
+    const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v);
 
     if constexpr (VEC4) {
         // vocab % 4 == 0: a 16-byte store never straddles a window cell; the three special channels
@@ -240,6 +251,51 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse encoder: nn.Linear(obs_dim, H) of comm.py:51,119 applied to the observation WITHOUT reading
+// it back: a row of obs has <= 3 non-zeros per window cell, so  enc[a] = bias + sum_cells ( Wt[cell*vocab+id]
+// + npred * Wt[cell*vocab+PRED] + nprey * Wt[cell*vocab+PREY] )  with Wt = encoder.weight^T ([obs_dim][H]).
+// One workgroup per env; each group of H/4 lanes owns one agent and reads whole 4H-byte rows of Wt (L2
+// resident: obs_dim*H*4 = 1.9 MB for PP-hard).  Replaces a 2*N*obs_dim*H-flop dense fp32 GEMM per env.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restrict__ loc_r,
+                                                        const int32_t* __restrict__ loc_c,
+                                                        const f32x4* __restrict__ Wt, const f32x4* __restrict__ bias,
+                                                        f32x4* __restrict__ out, int N, int nprey, int dim, int v,
+                                                        int H4)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x;
+    const int WW = (2 * v + 1) * (2 * v + 1);
+    const int vocab = dim * dim + 4;
+    const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v);
+    for (int idx = threadIdx.x; idx < N * H4; idx += blockDim.x) {
+        const int a = idx / H4, c4 = idx - a * H4;
+        f32x4 acc = bias[c4];
+        for (int cell = 0; cell < WW; ++cell) {
+            const int2 t = tab[a * WW + cell];
+            const size_t row = (size_t)cell * vocab;
+            acc += Wt[(row + t.x) * H4 + c4];
+            const int npred = t.y & 0xffff, npr = t.y >> 16;
+            if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
+            if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
+        }
+        out[((size_t)e * N + a) * H4 + c4] = acc;
+    }
+}
+
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
+    const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
+    hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
+                       reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
+                       reinterpret_cast<f32x4*>(out), c.N, c.nprey, c.dim, c.vision, H / 4);
+    IC3_HIP(hipGetLastError());
+    return 0;
 }
 
 int pp_reset(ic3_env* env, hipStream_t s)

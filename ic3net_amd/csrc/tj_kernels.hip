@@ -222,6 +222,78 @@ __global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__
     }
 }
 
+// sparse encoder for Traffic-Junction rows (see pp_encode_kernel): enc[a] = bias (dead car: obs row is zero)
+// or bias + last_act*Wt[0] + route_frac*Wt[1] + sum_cells ( Wt[2+cell*vocab+id] + ncar*Wt[2+cell*vocab+CAR] ).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restrict__ alive_s,
+                                                        const int32_t* __restrict__ loc_r, const int32_t* __restrict__ loc_c,
+                                                        const int32_t* __restrict__ last_act_s,
+                                                        const int32_t* __restrict__ route_id_s,
+                                                        const int32_t* __restrict__ grid, const f32x4* __restrict__ Wt,
+                                                        const f32x4* __restrict__ bias, f32x4* __restrict__ out, int N,
+                                                        int h, int w, int v, int vocab, int outside, int car_class,
+                                                        int npath, int H4)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x;
+    const int W = 2 * v + 1, WW = W * W, nseg = N * WW;
+    int32_t* sr = smem;
+    int32_t* sc = sr + N;
+    int32_t* sal = sc + N;
+    float* s0 = reinterpret_cast<float*>(sal + N);
+    float* s1 = s0 + N;
+    int2* tab = reinterpret_cast<int2*>(smem + ((5 * N + 3) & ~3));
+    for (int a = threadIdx.x; a < N; a += blockDim.x) {
+        const size_t i = (size_t)e * N + a;
+        sr[a] = loc_r[i];
+        sc[a] = loc_c[i];
+        sal[a] = alive_s[i];
+        s0[a] = (float)((double)last_act_s[i] / 1.0);
+        s1[a] = (float)((double)route_id_s[i] / (double)(npath - 1));
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
+        const int a = s / WW, q = s - a * WW;
+        const int dy = q / W, dx = q - dy * W;
+        const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
+        const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
+        int ncar = 0;
+        for (int p = 0; p < N; ++p) ncar += (sr[p] == gr) & (sc[p] == gc);
+        tab[s] = make_int2(id, ncar);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < N * H4; idx += blockDim.x) {
+        const int a = idx / H4, c4 = idx - a * H4;
+        f32x4 acc = bias[c4];
+        if (sal[a]) {
+            acc += s0[a] * Wt[c4];
+            acc += s1[a] * Wt[H4 + c4];
+            for (int cell = 0; cell < WW; ++cell) {
+                const int2 t = tab[a * WW + cell];
+                const size_t row = 2 + (size_t)cell * vocab;
+                acc += Wt[(row + t.x) * H4 + c4];
+                if (t.y) acc += (float)t.y * Wt[(row + car_class) * H4 + c4];
+            }
+        }
+        out[((size_t)e * N + a) * H4 + c4] = acc;
+    }
+}
+
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const ic3_dims& d = env->dims;
+    const int WW = d.window * d.window;
+    const size_t lds = (size_t)(((5 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
+    hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
+                       env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
+                       reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), c.N, d.grid_h, d.grid_w,
+                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
 int tj_reset(ic3_env* env, hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;

@@ -98,6 +98,19 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
         return self._obs
 
+    def encode(self, weight_t, bias, out=None):
+        """encoder(obs(current state)) as a sparse gather (ic3_env_encode): weight_t = encoder.weight.t()
+        contiguous (obs_dim, H), bias (H,) -> (E, N, H) float32.  Equals self.observe() @ weight_t + bias."""
+        self._require()
+        H = weight_t.shape[1]
+        if weight_t.shape[0] != self.obs_dim or not weight_t.is_contiguous() or weight_t.dtype != torch.float32:
+            raise ValueError("encode: weight_t must be a contiguous float32 (obs_dim, H) tensor")
+        if out is None:
+            out = torch.empty((self.nenvs, self.nagents_env, H), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), H, stream()))
+        return out
+
     def device_stats(self):
         s = _lib.Stats()
         check(_lib.lib().ic3_env_stats(self._h, C.byref(s), stream()))

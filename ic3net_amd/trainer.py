@@ -38,6 +38,11 @@ class Trainer(object):
         self.clock = SampleClock(getattr(args, 'seed', 0), getattr(args, 'env_id_offset', 0))
         self.clock.episode = -1
         self.stats = dict()
+        # encoder(obs) as a sparse gather from env state (ic3_env_encode) instead of a dense obs_dim x H GEMM;
+        # the dense observation is still assembled by env.step (API contract / store_states).
+        if getattr(args, 'sparse_encoder', True) and hasattr(policy_net, 'obs_encoder') \
+                and hasattr(getattr(env, 'env', None), 'encode'):
+            policy_net.obs_encoder = env.env.encode
 
     # ------------------------------------------------------------------------------------------
     def get_episode(self, epoch):

@@ -122,6 +122,12 @@ int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward
 /* Observation of the current state without stepping (what reset/step return), obs [E][N][obs_dim]. */
 int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream);
 
+/* encoder(obs(state)) without reading the observation back: out[e][n][:] = bias + sum_k obs[e][n][k] * Wt[k][:]
+ * — the nn.Linear(obs_dim, hid) of comm.py:51,119 evaluated as a gather over the few non-zero obs entries
+ * (<= 3 per window cell for PP, 2 + 2 per cell for TJ).  Wt = encoder.weight transposed, [obs_dim][H] row-major,
+ * bias [H], out [E][N][H]; H % 4 == 0.  Mathematically identical to obs @ Wt + bias (fp32 sum order differs). */
+int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, ic3_stream stream);
+
 /* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
 int ic3_env_check(ic3_env* env, ic3_stream stream);
 

@@ -137,3 +137,54 @@ def test_random_actions_stream():
     for e in range(16):
         for n in range(6):
             assert a[e, n] == (philox.x24(11, 100 + e, philox.DOMAIN_BENCH, 2, 3, n) * 5) >> 24
+
+
+@pytest.mark.parametrize("kind,cfg", [("pp", (10, 20, 1, 128, 96)), ("pp", (3, 5, 0, 64, 33)), ("pp", (32, 40, 2, 256, 4)),
+                                      ("tj", (10, 14, 1, "medium", 128, 64)), ("tj", (20, 18, 0, "hard", 128, 32)),
+                                      ("tj", (5, 6, 1, "easy", 32, 17))])
+def test_sparse_encoder_equals_dense(kind, cfg):
+    """ic3_env_encode == observe() @ W^T + b on states reached after some random steps (incl. dead TJ cars)."""
+    from test_env_parity_gpu import make_pp, make_tj
+    torch.manual_seed(0)
+    if kind == "pp":
+        N, dim, v, H, E = cfg
+        env = make_pp(N, dim, v, "mixed", E, seed=1)
+        env.reset()
+        nact = 5
+    else:
+        N, dim, v, diff, H, E = cfg
+        env = make_tj(N, dim, v, diff, E, seed=1, add_rate_min=0.4, add_rate_max=0.4)
+        env.reset(0)
+        nact = 2
+    lin = torch.nn.Linear(env.obs_dim, H).cuda()
+    for t in range(12):
+        env.step(torch.randint(0, nact, (E, N), device='cuda', dtype=torch.int32))
+        if t in (0, 5, 11):
+            obs = env.observe()
+            with torch.no_grad():
+                dense = lin(obs.double().cpu().cuda()) if False else (obs.double() @ lin.weight.double().t() + lin.bias.double())
+                sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
+            torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
+
+
+def test_policy_sparse_encoder_hook_matches_dense():
+    from test_env_parity_gpu import make_pp
+    from policy_util import PolicyCase
+    from ic3net_amd.comm import CommNetMLP
+    import argparse
+    N, dim, v, H, E = 10, 20, 1, 128, 64
+    env = make_pp(N, dim, v, "mixed", E, seed=2)
+    obs = env.reset()
+    a = argparse.Namespace(nagents=N, hid_size=H, comm_passes=1, recurrent=True, continuous=False,
+                           naction_heads=[5, 2], comm_mask_zero=False, share_weights=False, comm_init='uniform',
+                           hard_attn=True, comm_mode='avg', rnn_type='LSTM')
+    torch.manual_seed(1)
+    net = CommNetMLP(a, env.obs_dim).cuda()
+    info = {'comm_action': torch.ones(E, N, dtype=torch.int32, device='cuda')}
+    with torch.no_grad():
+        hid = net.init_hidden(E)
+        d_logp, d_val, d_h = net([obs, hid], info)
+        net.obs_encoder = env.encode
+        s_logp, s_val, s_h = net([obs, hid], info)
+    for x, y in zip(d_logp + [d_val, d_h[0], d_h[1]], s_logp + [s_val, s_h[0], s_h[1]]):
+        torch.testing.assert_close(x, y, atol=2e-6, rtol=0)
