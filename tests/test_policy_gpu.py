@@ -68,7 +68,7 @@ def test_comm_masked_mean_vs_oracle(E, N, H):
             for e in range(E):
                 lit = policy_ref.comm_block(h[e:e + 1].astype(np.float64), alive[e] if use_alive else None,
                                             ca[e] if use_ca else np.ones(N), avg, False, True)
-                np.testing.assert_allclose(out[e], lit[0], rtol=2e-6, atol=2e-6)
+                np.testing.assert_allclose(out[e], lit[0], rtol=1e-5, atol=1e-5)   # unbounded N(0,1) inputs, N up to 32
     z = ops.comm_masked_mean(ht, None, None, True, False)
     assert not z.any().item()
 
