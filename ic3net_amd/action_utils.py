@@ -21,14 +21,18 @@ class SampleClock(object):
         self.seed, self.env_id_offset, self.episode, self.t = seed, env_id_offset, 0, 0
 
 
-def select_action(args, action_out, clock=None):
-    """action_utils.py:32-36.  action_out: list of (E,N,A_k) log-probs -> (heads, E, N) int32."""
+def select_action(args, action_out, clock=None, out=None):
+    """action_utils.py:32-36.  action_out: list of (E,N,A_k) log-probs -> (heads, E, N) int32.
+    `out`: optional preallocated (heads, E, N) int32 tensor the sampling kernels write into."""
     if getattr(args, 'continuous', False):
         raise NotImplementedError
     clock = clock or getattr(args, 'sample_clock', None) or SampleClock(getattr(args, 'seed', 0))
-    acts = [ops.sample_actions(lp, k, clock.seed, clock.env_id_offset, clock.episode, clock.t)
-            for k, lp in enumerate(action_out)]
-    return torch.stack(acts)
+    if out is None:
+        E, N = action_out[0].shape[:2]
+        out = torch.empty((len(action_out), E, N), dtype=torch.int32, device=action_out[0].device)
+    for k, lp in enumerate(action_out):
+        ops.sample_actions(lp, k, clock.seed, clock.env_id_offset, clock.episode, clock.t, out=out[k])
+    return out
 
 
 def translate_action(args, env, action):      # action_utils.py:39-43

@@ -25,6 +25,8 @@ class _BatchedEnv(object):
         self.stat = dict()
         self.episode_over = False
         self.obs_timer = None     # set to a list to collect (start, end) HIP events around every obs launch
+        self.out = None           # optional {'reward','done','alive','is_completed'} output tensors for step()
+        self._last = None
 
     # --- handle ---------------------------------------------------------------------------------
     def _finish_init(self, handle, device):
@@ -131,21 +133,27 @@ class _BatchedEnv(object):
     def _step(self, action):
         self._require()
         a = self._actions(action)
+        # `self.out` lets a caller (the batched Trainer) receive reward / done / alive / is_completed directly in
+        # slices of its own episode buffers instead of the env's per-step buffers (no copies on the hot path).
+        o = self.out or {}
+        reward, done = o.get('reward', self._reward), o.get('done', self._done)
+        alive, completed = o.get('alive', self._alive), o.get('is_completed', self._completed)
         with torch.cuda.device(self.device):
             if self.obs_timer is None:
-                check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(self._reward), ptr(self._done),
-                                              ptr(self._alive), ptr(self._completed), stream()))
+                check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(reward), ptr(done),
+                                              ptr(alive), ptr(completed), stream()))
             else:
                 # same two kernels, but with HIP events (on the launch stream) bracketing the obs-assembly launch
-                check(_lib.lib().ic3_env_step(self._h, ptr(a), None, ptr(self._reward), ptr(self._done),
-                                              ptr(self._alive), ptr(self._completed), stream()))
+                check(_lib.lib().ic3_env_step(self._h, ptr(a), None, ptr(reward), ptr(done),
+                                              ptr(alive), ptr(completed), stream()))
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream())
                 check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
                 e1.record(torch.cuda.current_stream())
                 self.obs_timer.append((e0, e1))
-        return self._obs, self._reward, self._done
+        self._last = (reward, done, alive, completed)
+        return self._obs, reward, done
 
     def reward_terminal(self):
         return torch.zeros_like(self._reward)      # PP:292-293 / TJ:611-612: zeros
@@ -215,7 +223,7 @@ class PredatorPreyEnv(_BatchedEnv):
 
     def step(self, action):                 # PP:112-144
         obs, reward, done = self._step(action)
-        debug = {'alive_mask_device': self._alive}   # PP has no alive_mask in info (trainer.py:78-81 uses ones)
+        debug = {'alive_mask_device': self._last[2]}   # PP has no alive_mask in info (trainer.py:78-81 uses ones)
         return obs, reward, done, debug
 
 
@@ -303,7 +311,7 @@ class TrafficJunctionEnv(_BatchedEnv):
 
     def step(self, action):                 # TJ:206-252
         obs, reward, done = self._step(action)
-        debug = {'alive_mask': self._alive, 'is_completed': self._completed}
+        debug = {'alive_mask': self._last[2], 'is_completed': self._last[3]}
         return obs, reward, done, debug
 
 

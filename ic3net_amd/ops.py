@@ -44,12 +44,12 @@ def comm_masked_mean(h, alive=None, comm_action=None, mode_avg=True, mask_self=T
     return _CommMaskedMean.apply(h, alive, comm_action, mode_avg, mask_self)
 
 
-def sample_actions(logp, head, seed, env_id_offset, episode, t, want_logp=False):
+def sample_actions(logp, head, seed, env_id_offset, episode, t, want_logp=False, out=None):
     """logp (E,N,A) f32 -> action (E,N) int32 [, chosen log-prob (E,N) f32]; action_utils.py:32-36."""
     _need_cuda(logp, "sample_actions")
     E, N, A = logp.shape
     logp = logp.detach().contiguous().float()
-    action = torch.empty((E, N), dtype=torch.int32, device=logp.device)
+    action = out if out is not None else torch.empty((E, N), dtype=torch.int32, device=logp.device)
     chosen = torch.empty((E, N), dtype=torch.float32, device=logp.device) if want_logp else None
     with torch.cuda.device(logp.device):
         check(_lib.lib().ic3_sample_actions(ptr(logp), A, int(head), int(seed) & 0xffffffff, int(env_id_offset),

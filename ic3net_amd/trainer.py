@@ -51,13 +51,13 @@ class Trainer(object):
         check_every = int(getattr(self.args, 'done_check_every', 0))
         for t in range(self.args.max_steps):
             self.step_episode(t)
-            if check_every and (t + 1) % check_every == 0 and not bool(self._live.any().item()):
+            if check_every and (t + 1) % check_every == 0 and \
+                    bool(self._buf['done'][:t + 1].to(torch.bool).any(0).all().item()):
                 break                                               # trainer.py:107-108 (every env is done)
         return self.end_episode()
 
     def begin_episode(self, epoch):
         args = self.args
-        self._episode = []
         if 'epoch' in signature(self.env.reset).parameters:        # trainer.py:28-32
             state = self.env.reset(epoch)
         else:
@@ -65,83 +65,103 @@ class Trainer(object):
         if self.display and self.last_step:
             raise NotImplementedError("--display is outside the hot-path scope (SURVEY 8(f) f4)")
         E, dev = state.shape[0], state.device
+        T, N, nh = args.max_steps, args.nagents, len(args.naction_heads)
         self._state = state
         self.clock.episode += 1
         self._info = dict()
-        self._live = torch.ones(E, dtype=torch.float32, device=dev)     # 1 while the env's episode is running
-        self._steps = torch.zeros(E, dtype=torch.float32, device=dev)
-        self._reward_sum = torch.zeros(args.nagents, dtype=torch.float64, device=dev)
-        self._comm_sum = torch.zeros(args.nagents, dtype=torch.float64, device=dev)
         self._prev_hid = None
+        self._nsteps = 0
+        # Episode buffers [T, ...]: the env / sampling kernels write step t's outputs straight into slice t, so the
+        # hot loop launches no bookkeeping kernels; masks and statistics are derived once in end_episode().
+        z = lambda *shape, dt=torch.int32: torch.empty((T,) + shape, dtype=dt, device=dev)
+        self._buf = dict(action=z(nh, E, N), reward=z(E, N, dt=torch.float32), done=z(E), alive=z(E, N),
+                         is_completed=z(E, N))
+        self._step_out = [(None, None, None, None)] * T          # (state, action_out, value, next_state) per step
+        self._ones_comm = torch.ones((E, N), dtype=torch.int32, device=dev) if args.comm_action_one else None
+        self._zeros_comm = torch.zeros((E, N), dtype=torch.int32, device=dev)
 
     def step_episode(self, t):
         """One iteration of the hot loop trainer.py:43-108 for all E envs."""
         args = self.args
-        state, info, live = self._state, self._info, self._live
-        E, dev = state.shape[0], state.device
+        state, info, buf = self._state, self._info, self._buf
         store = bool(getattr(args, 'store_states', False))
         self.clock.t = t
-        misc = dict()
         with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):
             if t == 0 and args.hard_attn and args.commnet:         # trainer.py:45-46 (quirk Q22)
-                info['comm_action'] = torch.zeros((E, args.nagents), dtype=torch.int32, device=dev)
+                info['comm_action'] = self._zeros_comm
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:
-                    self._prev_hid = self.policy_net.init_hidden(batch_size=E)
+                    self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
                 action_out, value, prev_hid = self.policy_net([state, self._prev_hid], info)
                 if (t + 1) % args.detach_gap == 0:
                     prev_hid = (prev_hid[0].detach(), prev_hid[1].detach())
                 self._prev_hid = prev_hid
             else:
                 action_out, value = self.policy_net(state, info)
-            action = select_action(args, action_out, self.clock)            # trainer.py:65
-            action, actual = translate_action(args, self.env, action)       # trainer.py:66
+            action = select_action(args, action_out, self.clock, out=buf['action'][t])   # trainer.py:65
+            action, actual = translate_action(args, self.env, action)                    # trainer.py:66
             cur_state = state.clone() if store else None
-            next_state, reward, done, info = self.env.step(actual)          # trainer.py:67
+            raw = self.env.env
+            raw.out = dict(reward=buf['reward'][t], done=buf['done'][t], alive=buf['alive'][t],
+                           is_completed=buf['is_completed'][t])
+            try:
+                next_state, reward, done, info = self.env.step(actual)                   # trainer.py:67
+            finally:
+                raw.out = None
             info = dict(info)
-            if args.hard_attn and args.commnet:                    # trainer.py:70-75
-                info['comm_action'] = action[-1] if not args.comm_action_one else \
-                    torch.ones((E, args.nagents), dtype=torch.int32, device=dev)
-                self._comm_sum += (info['comm_action'].to(torch.float64) * live.unsqueeze(1).double()).sum(0)
-            if 'alive_mask' in info:                               # trainer.py:78-81
-                alive = info['alive_mask'].to(torch.float32)
-            else:
-                alive = torch.ones_like(reward)
-            misc['alive_mask'] = alive * live.unsqueeze(1)
-            misc['live'] = live
-            reward = reward.clone()
-            self._reward_sum += reward.double().sum(0)             # trainer.py:86 (frozen envs report 0)
-            self._steps += live
-            not_done = ~done.to(torch.bool)
-            done_t = ~not_done if t != args.max_steps - 1 else torch.ones_like(not_done)    # trainer.py:90
-            episode_mask = (~done_t).to(torch.float32).unsqueeze(1).expand(E, args.nagents).contiguous()
-            episode_mini_mask = torch.ones_like(reward)
-            if 'is_completed' in info:                             # trainer.py:98-99 (only when not done, Q26)
-                episode_mini_mask = torch.where(done_t.unsqueeze(1), episode_mini_mask,
-                                                1.0 - info['is_completed'].to(torch.float32))
-            trans = Transition(cur_state, torch.stack(action), action_out, value, episode_mask, episode_mini_mask,
-                               next_state.clone() if store else None, reward, misc)
-            self._episode.append(trans)
-            self._live = live * not_done.to(torch.float32)
+            if args.hard_attn and args.commnet:                    # trainer.py:70-71 (gate for the NEXT step)
+                info['comm_action'] = action[-1] if not args.comm_action_one else self._ones_comm
+            self._step_out[t] = (cur_state, action_out, value, next_state.clone() if store else None)
             self._state = next_state
             self._info = info
-        return trans
+            self._nsteps = t + 1
 
     def end_episode(self):
+        """Everything get_episode derives per step in the reference (trainer.py:70-105), vectorised over the
+        episode buffers: live / alive / episode masks, per-agent reward and comm-action sums, step counts."""
         args = self.args
-        episode, stat = self._episode, dict()
-        num_steps = float(self._steps.sum().item())
+        n, buf = self._nsteps, self._buf
+        E, N = buf['reward'].shape[1:]
+        dev = buf['reward'].device
+        has_info = self.env.env.dims.kind == 2                     # TJ reports alive_mask / is_completed in info
+        done = buf['done'][:n].to(torch.bool)                      # (n, E) episode_over after step t
+        not_done = (~done).to(torch.float32)
+        live = torch.ones((n, E), dtype=torch.float32, device=dev) # live[t] = env still running when step t starts
+        if n > 1:
+            live[1:] = torch.cumprod(not_done[:-1], dim=0)
+        done_t = done.clone()
+        if n == args.max_steps:
+            done_t[n - 1] = True                                   # trainer.py:90 forced done at the last step
+        reward = buf['reward'][:n]
+        alive = buf['alive'][:n].to(torch.float32) if has_info else torch.ones_like(reward)   # trainer.py:78-81
+        alive_mask = alive * live.unsqueeze(2)
+        episode_mask = (~done_t).to(torch.float32).unsqueeze(2).expand(n, E, N)                # trainer.py:92-96
+        episode_mini_mask = torch.ones_like(reward)
+        if has_info:                                               # trainer.py:98-99 (only when not done, Q26)
+            episode_mini_mask = torch.where(done_t.unsqueeze(2), episode_mini_mask,
+                                            1.0 - buf['is_completed'][:n].to(torch.float32))
+        action = buf['action'][:n]
+        stat = dict()
+        num_steps = float(live.sum().item())
         stat['num_steps'] = num_steps                              # trainer.py:109-110
         stat['steps_taken'] = num_steps
-        stat['reward'] = self._reward_sum.cpu().numpy()[:args.nfriendly]
-        if args.hard_attn and args.commnet:
-            stat['comm_action'] = self._comm_sum.cpu().numpy()[:args.nfriendly]
+        stat['reward'] = reward.double().sum((0, 1)).cpu().numpy()[:args.nfriendly]            # trainer.py:86
+        if args.hard_attn and args.commnet:                        # trainer.py:73
+            gate = torch.ones_like(reward) if args.comm_action_one else action[:, -1].to(torch.float32)
+            stat['comm_action'] = (gate * live.unsqueeze(2)).double().sum((0, 1)).cpu().numpy()[:args.nfriendly]
+        episode = []
+        for t in range(n):
+            cur_state, action_out, value, next_state = self._step_out[t]
+            misc = {'alive_mask': alive_mask[t], 'live': live[t]}
+            episode.append(Transition(cur_state, action[t], action_out, value, episode_mask[t], episode_mini_mask[t],
+                                      next_state, reward[t], misc))
         if hasattr(self.env, 'reward_terminal'):                   # trainer.py:112-121 (zeros for PP/TJ)
             rt = self.env.reward_terminal()
             episode[-1] = episode[-1]._replace(reward=episode[-1].reward + rt)
             stat['reward'] = stat['reward'] + rt.double().sum(0).cpu().numpy()[:args.nfriendly]
         if hasattr(self.env, 'get_stat'):                          # trainer.py:124-125
             merge_stat(self.env.get_stat(), stat)
+        self._live = live[-1] * not_done[-1]
         return (episode, stat)
 
     def run_batch(self, epoch):                                    # trainer.py:227-242
