@@ -224,6 +224,7 @@ def main():
     raw_env.obs_timer = []
     t0 = time.perf_counter()
     t_in_ep = run(o.steps, t_in_ep)
+    host_dt = time.perf_counter() - t0        # host-side enqueue time (diagnostic: host- vs GPU-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -263,6 +264,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": obs_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": len(obs_ms)},
             "cpu_baseline": cpu,
+            "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),
         }
         print(json.dumps(out))
     if world > 1:

@@ -62,9 +62,13 @@ def test_get_episode_matches_reference(name, env_name):
     tr = trmod.Trainer(a, net, env)
     tape = fx["tape"]                     # (nenv, nep, T, heads, N)
 
-    def taped(args, action_out, clock):
+    def taped(args, action_out, clock, out=None):
         assert [tuple(x.shape) for x in action_out] == [(nenv, N, A) for A in a.naction_heads]
-        return torch.from_numpy(tape[:, clock.episode, clock.t]).permute(1, 0, 2).contiguous().int().cuda()
+        act = torch.from_numpy(tape[:, clock.episode, clock.t]).permute(1, 0, 2).contiguous().int().cuda()
+        if out is not None:
+            out.copy_(act)
+            return out
+        return act
     orig = trmod.select_action
     trmod.select_action = taped
     try:
