@@ -48,7 +48,7 @@ EXPORTS = {
     "ic3_env_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ic3_env_step": (C.c_int, [C.c_void_p] * 7 + [C.c_void_p]),
     "ic3_env_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_env_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ic3_env_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ic3_env_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -58,8 +58,11 @@ EXPORTS = {
                                       C.c_size_t]),
     "ic3_tj_get_add_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ic3_env_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
-    "ic3_comm_masked_mean": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
-    "ic3_sample_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+    "ic3_comm_masked_mean": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "ic3_lstm_cell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_policy_heads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_void_p]),
+    "ic3_sample_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_int, C.c_void_p]),

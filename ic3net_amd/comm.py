@@ -71,6 +71,8 @@ class CommNetMLP(nn.Module):
 
     def forward(self, x, info={}):
         n, H = self.nagents, self.hid_size
+        if self._fused_ok(x):
+            return self._forward_fused(x, info)
         if self.args.recurrent:                                   # comm.py:117-122 (no tanh on this branch)
             x, (hidden_state, cell_state) = x
             x = self._encode(x)
@@ -96,6 +98,90 @@ class CommNetMLP(nn.Module):
         if self.args.recurrent:
             return action, value_head, (hidden_state.clone(), cell_state.clone())
         return action, value_head
+
+    # ------------------------------------------------------------------------------------------
+    # Fused rollout path (no autograd): the same math as forward() for the recurrent LSTM policy with one
+    # communication pass, restructured around one persistent [inp | h] buffer XH (R, 2H) so that a step is
+    #   encode -> XH[:, :H]      (sparse gather, bias = encoder.bias + C.bias)          1 kernel
+    #   comm_masked_mean(XH[:, H:])                                                     1 kernel
+    #   XH[:, :H] += comm_sum @ C^T                       (fp32 MFMA GEMM, hipBLASLt)   1 kernel
+    #   gates = XH @ [W_ih | W_hh]^T + (b_ih + b_hh)      (fp32 MFMA GEMM, hipBLASLt)   1 kernel
+    #   lstm_cell: (gates, c) -> c (in place), h' -> XH[:, H:]                          1 kernel
+    #   policy_heads: XH[:, H:] -> [log_softmax heads | value]                          1 kernel
+    # The returned (h, c) are views of internal buffers, valid until the next forward.
+    # ------------------------------------------------------------------------------------------
+    def _fused_ok(self, x):
+        a = self.args
+        if torch.is_grad_enabled() or not getattr(a, 'fused_policy', True):
+            return False
+        if not (a.recurrent and self.comm_passes == 1 and self.hid_size % 4 == 0 and len(self.heads) <= 4):
+            return False
+        if sum(int(o) for o in a.naction_heads) + 1 > 16:
+            return False
+        return isinstance(x, (list, tuple)) and x[0].is_cuda and self.encoder.weight.dtype == torch.float32
+
+    def _fused_cache(self):
+        ps = [self.encoder.weight, self.encoder.bias, self.C_modules[0].weight, self.C_modules[0].bias,
+              self.f_module.weight_ih, self.f_module.weight_hh, self.f_module.bias_ih, self.f_module.bias_hh,
+              self.value_head.weight, self.value_head.bias] + [p for hd in self.heads for p in (hd.weight, hd.bias)]
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        if getattr(self, '_fc_key', None) != key:
+            with torch.no_grad():
+                self._fc = dict(
+                    wt=self.encoder.weight.t().contiguous(),
+                    enc_bias=(self.encoder.bias + self.C_modules[0].bias).contiguous(),    # comm.py:206 bias, Q24
+                    c_wt=self.C_modules[0].weight.t().contiguous(),
+                    w_cat_t=torch.cat([self.f_module.weight_ih, self.f_module.weight_hh], 1).t().contiguous(),
+                    b_cat=(self.f_module.bias_ih + self.f_module.bias_hh).contiguous(),
+                    w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
+                    b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
+            self._fc_key = key
+        return self._fc
+
+    def _forward_fused(self, x, info):
+        n, H = self.nagents, self.hid_size
+        x, (hidden_state, cell_state) = x
+        batch = x.size(0)
+        R = batch * n
+        dev = x.device
+        fc = self._fused_cache()
+        buf = getattr(self, '_fb', None)
+        if buf is None or buf['xh'].shape[0] != R or buf['xh'].device != dev:
+            buf = self._fb = dict(xh=torch.empty((R, 2 * H), dtype=torch.float32, device=dev),
+                                  c=torch.empty((R, H), dtype=torch.float32, device=dev),
+                                  comm=torch.empty((batch, n, H), dtype=torch.float32, device=dev),
+                                  gates=torch.empty((R, 4 * H), dtype=torch.float32, device=dev))
+        xh, c = buf['xh'], buf['c']
+        h_view = xh[:, H:]
+        if hidden_state.data_ptr() != h_view.data_ptr():       # fresh hidden state from the caller (t = 0)
+            h_view.copy_(hidden_state.detach().reshape(R, H))
+        if cell_state.data_ptr() != c.data_ptr():
+            c.copy_(cell_state.detach().reshape(R, H))
+        alive = self._mask(info, 'alive_mask', batch, dev)
+        comm_action = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
+        mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
+        # encoder(x) + C.bias -> XH[:, :H]
+        if self.obs_encoder is not None:
+            self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H])
+        else:
+            enc = buf.get('enc')
+            if enc is None:
+                enc = buf['enc'] = torch.empty((R, H), dtype=torch.float32, device=dev)
+            torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)           # dense encoder GEMM
+            xh[:, :H].copy_(enc)
+        ops._launch(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg, not self.args.comm_mask_zero,
+                    out=buf['comm'])
+        xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                          # inp = enc + C(comm_sum)
+        torch.addmm(fc['b_cat'], xh, fc['w_cat_t'], out=buf['gates'])                  # all four gates
+        ops.lstm_cell_(buf['gates'], c, h_view)
+        out = ops.policy_heads(h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads)
+        OT = out.shape[1]
+        action, off = [], 0
+        for A in self.args.naction_heads:
+            action.append(out.view(batch, n, OT)[:, :, off:off + A])
+            off += A
+        value_head = out[:, off:off + 1]
+        return action, value_head, (h_view, c)
 
     def _encode(self, x):
         """self.encoder(x) (comm.py:51,119); during no-grad rollouts optionally via the env's sparse gather."""

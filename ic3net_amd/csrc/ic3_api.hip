@@ -260,12 +260,13 @@ int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream)
     return env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
 }
 
-int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, ic3_stream stream)
+int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, ic3_stream stream)
 {
     if (!env || !Wt || !bias || !out) return fail(-22, "ic3_env_encode: null argument");
-    if (H <= 0 || (H & 3)) return fail(-22, "ic3_env_encode: H must be a positive multiple of 4");
-    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, out, H, (hipStream_t)stream)
-                                   : tj_encode(env, Wt, bias, out, H, (hipStream_t)stream);
+    if (ldo <= 0) ldo = H;
+    if (H <= 0 || (H & 3) || (ldo & 3) || ldo < H) return fail(-22, "ic3_env_encode: H and ldo must be positive multiples of 4");
+    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream)
+                                   : tj_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream);
 }
 
 int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,

@@ -99,13 +99,13 @@ int pp_reset(ic3_env* env, hipStream_t s);
 int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s);
 int pp_observe(ic3_env* env, float* obs, hipStream_t s);
-int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, hipStream_t s);
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
 // tj_kernels.hip
 int tj_reset(ic3_env* env, hipStream_t s);
 int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s);
 int tj_observe(ic3_env* env, float* obs, hipStream_t s);
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, hipStream_t s);
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
 // tj_tables.cpp (host)
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,

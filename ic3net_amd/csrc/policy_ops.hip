@@ -13,39 +13,157 @@ namespace ic3 {
 //     out_j = m_j * (S - m_j * h_j) * scale,   S = sum_i m_i h_i,   scale = 1/(n_alive-1) if avg && n_alive>1
 // One workgroup per env, one lane per hidden column: h rows are read coalesced (and re-read from L1/L2
 // for the second pass), 2*N*H*4 algorithmic bytes per env.
-__global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __restrict__ h,
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// H4 = H/4 lanes per env (each lane owns 4 hidden columns as one 16-byte access); a 256-thread workgroup holds
+// 256/H4 envs.  h rows may be strided (ldh floats) so the op can read the [inp | h] buffer of the fused LSTM path.
+__global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __restrict__ h, int ldh,
                                                                const int32_t* __restrict__ alive,
                                                                const int32_t* __restrict__ comm_action,
-                                                               float* __restrict__ out, int N, int H, int mode_avg,
-                                                               int mask_self)
+                                                               float* __restrict__ out, int E, int N, int H4,
+                                                               int mode_avg, int mask_self)
+{
+    const int per_block = blockDim.x / H4;
+    const int e = blockIdx.x * per_block + threadIdx.x / H4;
+    const int k = threadIdx.x % H4;
+    if (e >= E || threadIdx.x >= per_block * H4) return;
+    int n_alive = 0;
+    for (int j = 0; j < N; ++j) n_alive += alive ? alive[(size_t)e * N + j] : 1;   // comm.py:102-107, quirk Q21
+    const float scale = (mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;  // comm.py:194-196, Q23
+    f32x4* oe = reinterpret_cast<f32x4*>(out + (size_t)e * N * H4 * 4) + k;
+    if (!mask_self) {  // comm_mask_zero: comm.py:40-41 -> all-zero communication
+        for (int j = 0; j < N; ++j) oe[(size_t)j * H4] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        return;
+    }
+    f32x4 S = { 0.f, 0.f, 0.f, 0.f };
+    for (int i = 0; i < N; ++i) {
+        const int m = (alive ? alive[(size_t)e * N + i] : 1) * (comm_action ? comm_action[(size_t)e * N + i] : 1);
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + i) * ldh + 4 * k);
+        S += (float)m * hv;
+    }
+    for (int j = 0; j < N; ++j) {
+        const float m = (float)((alive ? alive[(size_t)e * N + j] : 1) *
+                                (comm_action ? comm_action[(size_t)e * N + j] : 1));
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + j) * ldh + 4 * k);
+        oe[(size_t)j * H4] = m * (S - m * hv) * scale;
+    }
+}
+
+// scalar fallback for H % 4 != 0
+__global__ __launch_bounds__(256) void comm_masked_mean_scalar_kernel(const float* __restrict__ h, int ldh,
+                                                                      const int32_t* __restrict__ alive,
+                                                                      const int32_t* __restrict__ comm_action,
+                                                                      float* __restrict__ out, int N, int H,
+                                                                      int mode_avg, int mask_self)
 {
     const int e = blockIdx.x;
-    const float* he = h + (size_t)e * N * H;
     float* oe = out + (size_t)e * N * H;
     int n_alive = 0;
-    for (int j = 0; j < N; ++j) n_alive += alive ? alive[(size_t)e * N + j] : 1;  // comm.py:102-107, quirk Q21
-    const float scale = (mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;  // comm.py:194-196, Q23
+    for (int j = 0; j < N; ++j) n_alive += alive ? alive[(size_t)e * N + j] : 1;
+    const float scale = (mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
     for (int k = threadIdx.x; k < H; k += blockDim.x) {
-        if (!mask_self) {  // comm_mask_zero: comm.py:40-41 -> all-zero communication
-            for (int j = 0; j < N; ++j) oe[(size_t)j * H + k] = 0.0f;
-            continue;
-        }
         float S = 0.0f;
         for (int i = 0; i < N; ++i) {
             const int m = (alive ? alive[(size_t)e * N + i] : 1) * (comm_action ? comm_action[(size_t)e * N + i] : 1);
-            S += (float)m * he[(size_t)i * H + k];
+            S += (float)m * h[((size_t)e * N + i) * ldh + k];
         }
         for (int j = 0; j < N; ++j) {
             const float m = (float)((alive ? alive[(size_t)e * N + j] : 1) *
                                     (comm_action ? comm_action[(size_t)e * N + j] : 1));
-            oe[(size_t)j * H + k] = m * (S - m * he[(size_t)j * H + k]) * scale;
+            oe[(size_t)j * H + k] = mask_self ? m * (S - m * h[((size_t)e * N + j) * ldh + k]) * scale : 0.0f;
         }
     }
 }
 
+// torch.nn.LSTMCell pointwise half (comm.py:215, gate order i,f,g,o): gates [R][4H] already hold
+// W_ih x + b_ih + W_hh h + b_hh.  c is updated in place, h' is written with row stride ldh (into the
+// [inp | h] buffer).  HBM-bound: reads 4H+H, writes 2H floats per row.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gates, float* __restrict__ c,
+                                                        float* __restrict__ h_out, int ldh, int R, int H4)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)R * H4) return;
+    const int row = (int)(idx / H4), k = (int)(idx - (long long)row * H4);
+    const f32x4* g = reinterpret_cast<const f32x4*>(gates + (size_t)row * 16 * H4);
+    const f32x4 gi = g[k], gf = g[H4 + k], gg = g[2 * H4 + k], go = g[3 * H4 + k];
+    f32x4* cp = reinterpret_cast<f32x4*>(c + (size_t)row * 4 * H4) + k;
+    const f32x4 c0 = *cp;
+    f32x4 c1, h1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        c1[q] = sigmoidf_(gf[q]) * c0[q] + sigmoidf_(gi[q]) * tanhf(gg[q]);
+        h1[q] = sigmoidf_(go[q]) * tanhf(c1[q]);
+    }
+    *cp = c1;
+    *reinterpret_cast<f32x4*>(h_out + (size_t)row * ldh + 4 * k) = h1;
+}
+
+// Action heads + value head + log_softmax (comm.py:228,239) in one pass over h: out[row][:] =
+// [log_softmax(W_0 h + b_0) | log_softmax(W_1 h + b_1) | ... | w_v h + b_v], OT = sum A_k + 1 <= 16 columns.
+// 8 lanes per row (each lane a strided set of float4 chunks of the row), W staged in LDS, 3-step shuffle reduce.
+#define IC3_MAX_OT 16
+__global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restrict__ h, int ldh,
+                                                           const float* __restrict__ W, const float* __restrict__ b,
+                                                           float* __restrict__ out, int R, int H4, int OT, int nheads,
+                                                           int a0, int a1, int a2, int a3)
+{
+    extern __shared__ __attribute__((aligned(16))) float sW[];  // [OT][4*H4]
+    for (int i = threadIdx.x; i < OT * H4; i += blockDim.x)
+        reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(W)[i];
+    __syncthreads();
+    const int row = blockIdx.x * (blockDim.x / 8) + (threadIdx.x >> 3);
+    const int l8 = threadIdx.x & 7;
+    float acc[IC3_MAX_OT];
+#pragma unroll
+    for (int o = 0; o < IC3_MAX_OT; ++o) acc[o] = 0.0f;
+    if (row < R) {
+        for (int k = l8; k < H4; k += 8) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(h + (size_t)row * ldh + 4 * k);
+#pragma unroll
+            for (int o = 0; o < IC3_MAX_OT; ++o) {
+                if (o < OT) {
+                    const f32x4 w = reinterpret_cast<const f32x4*>(sW)[o * H4 + k];
+                    acc[o] += hv.x * w.x + hv.y * w.y + hv.z * w.z + hv.w * w.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < IC3_MAX_OT; ++o) {
+        acc[o] += __shfl_xor(acc[o], 1);
+        acc[o] += __shfl_xor(acc[o], 2);
+        acc[o] += __shfl_xor(acc[o], 4);
+    }
+    if (row >= R || l8 != 0) return;
+    const int sizes[4] = { a0, a1, a2, a3 };
+    float* orow = out + (size_t)row * OT;
+    int off = 0;
+    for (int hd = 0; hd < nheads; ++hd) {
+        const int A = sizes[hd];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int o = 0; o < IC3_MAX_OT; ++o)
+            if (o >= off && o < off + A) { acc[o] += b[o]; mx = fmaxf(mx, acc[o]); }
+        float sum = 0.0f;
+#pragma unroll
+        for (int o = 0; o < IC3_MAX_OT; ++o)
+            if (o >= off && o < off + A) sum += expf(acc[o] - mx);
+        const float lse = mx + logf(sum);
+#pragma unroll
+        for (int o = 0; o < IC3_MAX_OT; ++o)
+            if (o >= off && o < off + A) orow[o] = acc[o] - lse;
+        off += A;
+    }
+#pragma unroll
+    for (int o = 0; o < IC3_MAX_OT; ++o)
+        if (o == off) orow[o] = acc[o] + b[o];  // value head
+}
+
 // action_utils.py:32-36: torch.multinomial(exp(logp), 1) per row.  Inverse-CDF on the injected uniform:
 // first a with u < sum_{b<=a} exp(logp_b), last action as fallback (fp32, left-to-right).
-__global__ __launch_bounds__(256) void sample_actions_kernel(const float* __restrict__ logp, int A, int head,
+__global__ __launch_bounds__(256) void sample_actions_kernel(const float* __restrict__ logp, int ld, int A, int head,
                                                              uint32_t seed, uint32_t gid0, uint32_t episode, uint32_t t,
                                                              int32_t* __restrict__ action,
                                                              float* __restrict__ chosen_logp, int E, int N)
@@ -55,7 +173,7 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float* __rest
     const int e = row / N, n = row - e * N;
     const uint32_t x = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_SAMPLE, episode, t, (uint32_t)(head * N + n));
     const float u = (float)x * (1.0f / 16777216.0f);
-    const float* lp = logp + (size_t)row * A;
+    const float* lp = logp + (size_t)row * ld;
     float cdf = 0.0f;
     int a = A - 1;
     for (int b = 0; b < A - 1; ++b) {
@@ -81,25 +199,59 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* __restrict
 
 }  // namespace ic3
 
-extern "C" int ic3_comm_masked_mean(const float* h, const int32_t* alive, const int32_t* comm_action, float* out, int E,
-                                    int N, int H, int mode_avg, int mask_self, ic3_stream stream)
+extern "C" int ic3_comm_masked_mean(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, float* out,
+                                    int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream)
 {
     if (!h || !out || E <= 0 || N <= 0 || H <= 0) return ic3::fail(-22, "ic3_comm_masked_mean: bad arguments");
-    const int threads = H >= 256 ? 256 : ((H + 63) / 64) * 64;
-    hipLaunchKernelGGL(ic3::comm_masked_mean_kernel, dim3(E), dim3(threads), 0, (hipStream_t)stream, h, alive,
-                       comm_action, out, N, H, mode_avg, mask_self);
+    if (ldh <= 0) ldh = H;
+    if ((H & 3) == 0 && (ldh & 3) == 0 && H / 4 <= 256) {
+        const int H4 = H / 4, per_block = 256 / H4;
+        hipLaunchKernelGGL(ic3::comm_masked_mean_kernel, dim3((E + per_block - 1) / per_block), dim3(256), 0,
+                           (hipStream_t)stream, h, ldh, alive, comm_action, out, E, N, H4, mode_avg, mask_self);
+    } else {
+        const int threads = H >= 256 ? 256 : ((H + 63) / 64) * 64;
+        hipLaunchKernelGGL(ic3::comm_masked_mean_scalar_kernel, dim3(E), dim3(threads), 0, (hipStream_t)stream, h, ldh,
+                           alive, comm_action, out, N, H, mode_avg, mask_self);
+    }
     IC3_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int ic3_sample_actions(const float* logp, int A, int head, uint32_t seed, uint32_t env_id_offset,
+extern "C" int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream)
+{
+    if (!gates || !c || !h_out || R <= 0 || H <= 0 || (H & 3) || (ldh & 3) || ldh < H)
+        return ic3::fail(-22, "ic3_lstm_cell: bad arguments (H and ldh must be multiples of 4)");
+    const long long n = (long long)R * (H / 4);
+    hipLaunchKernelGGL(ic3::lstm_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                       c, h_out, ldh, R, H / 4);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_policy_heads(const float* h, int ldh, const float* W, const float* b, const int32_t* head_sizes,
+                                int nheads, float* out, int R, int H, ic3_stream stream)
+{
+    if (!h || !W || !b || !head_sizes || !out || R <= 0 || H <= 0 || (H & 3) || (ldh & 3) || nheads < 1 || nheads > 4)
+        return ic3::fail(-22, "ic3_policy_heads: bad arguments (1..4 heads, H % 4 == 0)");
+    int sz[4] = { 0, 0, 0, 0 }, OT = 1;
+    for (int i = 0; i < nheads; ++i) { sz[i] = head_sizes[i]; OT += head_sizes[i]; }
+    if (OT > IC3_MAX_OT) return ic3::fail(-22, "ic3_policy_heads: more than 15 actions in total");
+    const size_t lds = (size_t)OT * H * sizeof(float);
+    hipLaunchKernelGGL(ic3::policy_heads_kernel, dim3((R + 31) / 32), dim3(256), lds, (hipStream_t)stream, h, ldh, W, b,
+                       out, R, H / 4, OT, nheads, sz[0], sz[1], sz[2], sz[3]);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_sample_actions(const float* logp, int ld, int A, int head, uint32_t seed, uint32_t env_id_offset,
                                   uint32_t episode, uint32_t t, int32_t* action, float* chosen_logp, int E, int N,
                                   ic3_stream stream)
 {
     if (!logp || !action || A <= 0 || E <= 0 || N <= 0) return ic3::fail(-22, "ic3_sample_actions: bad arguments");
+    if (ld <= 0) ld = A;
     const int rows = E * N;
-    hipLaunchKernelGGL(ic3::sample_actions_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, logp, A,
-                       head, seed, env_id_offset, episode, t, action, chosen_logp, E, N);
+    hipLaunchKernelGGL(ic3::sample_actions_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, logp, ld,
+                       A, head, seed, env_id_offset, episode, t, action, chosen_logp, E, N);
     IC3_HIP(hipGetLastError());
     return 0;
 }

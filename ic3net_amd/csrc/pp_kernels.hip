@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restrict__ loc_r,
                                                         const int32_t* __restrict__ loc_c,
                                                         const f32x4* __restrict__ Wt, const f32x4* __restrict__ bias,
-                                                        f32x4* __restrict__ out, int N, int nprey, int dim, int v,
-                                                        int H4)
+                                                        f32x4* __restrict__ out, int ldo4, int N, int nprey, int dim,
+                                                        int v, int H4)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -282,18 +282,18 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
             if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
             if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
         }
-        out[((size_t)e * N + a) * H4 + c4] = acc;
+        out[((size_t)e * N + a) * ldo4 + c4] = acc;
     }
 }
 
-int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, hipStream_t s)
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
     const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
                        reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
-                       reinterpret_cast<f32x4*>(out), c.N, c.nprey, c.dim, c.vision, H / 4);
+                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4);
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ last_act_s,
                                                         const int32_t* __restrict__ route_id_s,
                                                         const int32_t* __restrict__ grid, const f32x4* __restrict__ Wt,
-                                                        const f32x4* __restrict__ bias, f32x4* __restrict__ out, int N,
-                                                        int h, int w, int v, int vocab, int outside, int car_class,
-                                                        int npath, int H4)
+                                                        const f32x4* __restrict__ bias, f32x4* __restrict__ out, int ldo4,
+                                                        int N, int h, int w, int v, int vocab, int outside,
+                                                        int car_class, int npath, int H4)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -276,11 +276,11 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
                 if (t.y) acc += (float)t.y * Wt[(row + car_class) * H4 + c4];
             }
         }
-        out[((size_t)e * N + a) * H4 + c4] = acc;
+        out[((size_t)e * N + a) * ldo4 + c4] = acc;
     }
 }
 
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, hipStream_t s)
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
@@ -288,7 +288,7 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
     const size_t lds = (size_t)(((5 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
     hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
-                       reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), c.N, d.grid_h, d.grid_w,
+                       reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, c.N, d.grid_h, d.grid_w,
                        c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4);
     IC3_HIP(hipGetLastError());
     return 0;

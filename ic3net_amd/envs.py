@@ -109,8 +109,9 @@ class _BatchedEnv(object):
             raise ValueError("encode: weight_t must be a contiguous float32 (obs_dim, H) tensor")
         if out is None:
             out = torch.empty((self.nenvs, self.nagents_env, H), dtype=torch.float32, device=self.device)
+        ldo = H if out.dim() == 3 else out.stride(0)     # (E*N, H) column slice of a wider buffer: row stride
         with torch.cuda.device(self.device):
-            check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), H, stream()))
+            check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
         return out
 
     def device_stats(self):

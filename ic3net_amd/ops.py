@@ -24,14 +24,56 @@ class _CommMaskedMean(torch.autograd.Function):
         return _launch(g.contiguous(), ctx.alive, ctx.comm_action, ctx.mode_avg, ctx.mask_self), None, None, None, None
 
 
-def _launch(h, alive, comm_action, mode_avg, mask_self):
+def _rows(t, H):
+    """(tensor usable by the kernels, row stride in floats) for a (..., H) fp32 tensor whose rows are unit-stride
+    and evenly spaced (e.g. a column slice of a wider row-major buffer); anything else is made contiguous."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    flat = t.reshape(-1, H) if t.is_contiguous() else t
+    if flat.dim() == 2 and flat.stride(1) == 1 and flat.stride(0) >= H:
+        return flat, flat.stride(0)
+    if t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) >= H:
+        return t, t.stride(1)
+    t = t.contiguous()
+    return t, H
+
+
+def _launch(h, alive, comm_action, mode_avg, mask_self, out=None):
     _need_cuda(h, "comm_masked_mean")
     E, N, H = h.shape
-    h = h.contiguous().float()
-    out = torch.empty_like(h)
+    hk, ldh = _rows(h, H)
+    if out is None:
+        out = torch.empty((E, N, H), dtype=torch.float32, device=h.device)
     with torch.cuda.device(h.device):
-        check(_lib.lib().ic3_comm_masked_mean(ptr(h), ptr(alive), ptr(comm_action), ptr(out), E, N, H, int(mode_avg),
-                                              int(mask_self), stream()))
+        check(_lib.lib().ic3_comm_masked_mean(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(out), E, N, H,
+                                              int(mode_avg), int(mask_self), stream()))
+    return out
+
+
+def lstm_cell_(gates, c, h_out):
+    """In-place LSTM pointwise step: gates (R,4H) contiguous, c (R,H) contiguous (updated), h_out (R,H) rows
+    with unit column stride (may be a column slice of a wider buffer)."""
+    _need_cuda(gates, "lstm_cell")
+    R, H = c.shape
+    assert gates.is_contiguous() and c.is_contiguous() and h_out.stride(1) == 1
+    with torch.cuda.device(gates.device):
+        check(_lib.lib().ic3_lstm_cell(ptr(gates), ptr(c), ptr(h_out), h_out.stride(0), R, H, stream()))
+    return h_out, c
+
+
+def policy_heads(h, W, b, head_sizes, out=None):
+    """h (R,H) rows (unit column stride), W (OT,H), b (OT,) -> out (R,OT) = [log_softmax heads | value]."""
+    import ctypes as C
+    _need_cuda(h, "policy_heads")
+    R, H = h.shape
+    OT = W.shape[0]
+    assert h.stride(1) == 1 and W.is_contiguous() and OT == sum(head_sizes) + 1
+    if out is None:
+        out = torch.empty((R, OT), dtype=torch.float32, device=h.device)
+    sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
+    with torch.cuda.device(h.device):
+        check(_lib.lib().ic3_policy_heads(ptr(h), h.stride(0), ptr(W), ptr(b), sizes, len(head_sizes), ptr(out), R, H,
+                                          stream()))
     return out
 
 
@@ -48,11 +90,11 @@ def sample_actions(logp, head, seed, env_id_offset, episode, t, want_logp=False,
     """logp (E,N,A) f32 -> action (E,N) int32 [, chosen log-prob (E,N) f32]; action_utils.py:32-36."""
     _need_cuda(logp, "sample_actions")
     E, N, A = logp.shape
-    logp = logp.detach().contiguous().float()
+    logp, ld = _rows(logp.detach(), A)
     action = out if out is not None else torch.empty((E, N), dtype=torch.int32, device=logp.device)
     chosen = torch.empty((E, N), dtype=torch.float32, device=logp.device) if want_logp else None
     with torch.cuda.device(logp.device):
-        check(_lib.lib().ic3_sample_actions(ptr(logp), A, int(head), int(seed) & 0xffffffff, int(env_id_offset),
+        check(_lib.lib().ic3_sample_actions(ptr(logp), ld, A, int(head), int(seed) & 0xffffffff, int(env_id_offset),
                                             int(episode), int(t), ptr(action), ptr(chosen), E, N, stream()))
     return (action, chosen) if want_logp else action
 

@@ -126,7 +126,8 @@ int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream);
  * — the nn.Linear(obs_dim, hid) of comm.py:51,119 evaluated as a gather over the few non-zero obs entries
  * (<= 3 per window cell for PP, 2 + 2 per cell for TJ).  Wt = encoder.weight transposed, [obs_dim][H] row-major,
  * bias [H], out [E][N][H]; H % 4 == 0.  Mathematically identical to obs @ Wt + bias (fp32 sum order differs). */
-int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int H, ic3_stream stream);
+int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo /* out row stride in floats, 0 = H */,
+                   int H, ic3_stream stream);
 
 /* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
 int ic3_env_check(ic3_env* env, ic3_stream stream);
@@ -162,15 +163,27 @@ int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream);
  * n_alive = sum_j alive_j (NOT the talker count, quirk Q23) or N when alive == NULL (quirk Q21).
  *   h [E][N][H] f32, alive [E][N] int32 or NULL, comm_action [E][N] int32 or NULL (all talk),
  *   out [E][N][H] f32.  mask_self: 1 = ones-eye comm_mask (default), 0 = comm_mask_zero (out = 0). */
-int ic3_comm_masked_mean(const float* h, const int32_t* alive, const int32_t* comm_action, float* out,
-                         int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream);
+int ic3_comm_masked_mean(const float* h, int ldh /* h row stride in floats, 0 = H */, const int32_t* alive,
+                         const int32_t* comm_action, float* out, int E, int N, int H, int mode_avg, int mask_self,
+                         ic3_stream stream);
+
+/* Pointwise half of torch.nn.LSTMCell (comm.py:61,215; gate order i,f,g,o): gates [R][4H] already hold
+ * W_ih x + b_ih + W_hh h + b_hh (two fp32 MFMA GEMMs, or one over [x | h]).  c [R][H] is updated in place,
+ * h' is written to h_out with row stride ldh.  H % 4 == 0. */
+int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream);
+
+/* Action heads + value head + log_softmax (comm.py:228,239) in one pass: out[r][:] =
+ * [log_softmax(W_0 h_r + b_0) | ... | log_softmax(W_{k-1} h_r + b_{k-1}) | w_v h_r + b_v], OT = sum A_k + 1 <= 16.
+ * W [OT][H] = rows of heads.k.weight stacked, then value_head.weight; b [OT] likewise; head_sizes is a HOST array. */
+int ic3_policy_heads(const float* h, int ldh, const float* W, const float* b, const int32_t* head_sizes, int nheads,
+                     float* out, int R, int H, ic3_stream stream);
 
 /* select_action (action_utils.py:32-36): one multinomial draw per (env, agent) row from exp(logp),
  * as inverse-CDF on Philox uniforms: counter (head*N+n, t, episode, DOMAIN_SAMPLE), key (seed, env_id_offset+e).
- *   logp [E][N][A] f32 -> action [E][N] int32, chosen_logp [E][N] f32 or NULL. */
-int ic3_sample_actions(const float* logp, int A, int head, uint32_t seed, uint32_t env_id_offset,
-                       uint32_t episode, uint32_t t, int32_t* action, float* chosen_logp, int E, int N,
-                       ic3_stream stream);
+ *   logp [E*N rows][ld] f32 (first A columns of each row) -> action [E][N] int32, chosen_logp [E][N] f32 or NULL. */
+int ic3_sample_actions(const float* logp, int ld /* logp row stride in floats, 0 = A */, int A, int head, uint32_t seed,
+                       uint32_t env_id_offset, uint32_t episode, uint32_t t, int32_t* action, float* chosen_logp,
+                       int E, int N, ic3_stream stream);
 
 /* Synthetic uniform actions in [0, naction) for env-only benchmarks (DOMAIN_BENCH). */
 int ic3_random_actions(int32_t* action, int naction, uint32_t seed, uint32_t env_id_offset, uint32_t episode,

@@ -20,11 +20,15 @@ def build(pc):
     return net.cuda().float()
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", POLICY_FIXTURES)
-def test_policy_matches_reference(name):
+def test_policy_matches_reference(name, fused):
+    """fused=True: the no-grad rollout fast path (one [inp|h] buffer, lstm_cell / policy_heads HIP kernels) where it
+    applies (recurrent, one comm pass); fused=False: the generic torch path + comm_masked_mean op."""
     pc = PolicyCase(name)
     fx = pc.fx
     net = build(pc)
+    net.args.fused_policy = fused
     hid = net.init_hidden(pc.B) if pc.recurrent else None
     worst = 0.0
     with torch.no_grad():
@@ -188,3 +192,31 @@ def test_policy_sparse_encoder_hook_matches_dense():
         s_logp, s_val, s_h = net([obs, hid], info)
     for x, y in zip(d_logp + [d_val, d_h[0], d_h[1]], s_logp + [s_val, s_h[0], s_h[1]]):
         torch.testing.assert_close(x, y, atol=2e-6, rtol=0)
+
+
+def test_lstm_cell_and_heads_kernels_vs_torch():
+    from ic3net_amd import ops
+    torch.manual_seed(3)
+    R, H = 777, 128
+    cell = torch.nn.LSTMCell(H, H).cuda()
+    x, h, c = torch.randn(R, H, device='cuda'), torch.randn(R, H, device='cuda') * 0.5, torch.randn(R, H, device='cuda')
+    with torch.no_grad():
+        h_ref, c_ref = cell(x, (h, c))
+        gates = x @ cell.weight_ih.t() + cell.bias_ih + h @ cell.weight_hh.t() + cell.bias_hh
+        xh = torch.zeros(R, 2 * H, device='cuda')
+        c2 = c.clone()
+        ops.lstm_cell_(gates.contiguous(), c2, xh[:, H:])
+        torch.testing.assert_close(xh[:, H:], h_ref, atol=2e-6, rtol=0)
+        torch.testing.assert_close(c2, c_ref, atol=2e-6, rtol=0)
+        assert not xh[:, :H].any().item()
+        for sizes in ([5, 2], [2], [5, 2, 3, 4], [9]):
+            OT = sum(sizes) + 1
+            W, b = torch.randn(OT, H, device='cuda') * 0.2, torch.randn(OT, device='cuda')
+            out = ops.policy_heads(xh[:, H:], W, b, sizes)
+            z = h_ref @ W.t() + b
+            off = 0
+            for A in sizes:
+                torch.testing.assert_close(out[:, off:off + A], torch.log_softmax(z[:, off:off + A], -1), atol=3e-6,
+                                           rtol=0)
+                off += A
+            torch.testing.assert_close(out[:, off], z[:, off], atol=3e-6, rtol=0)
