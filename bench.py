@@ -47,7 +47,8 @@ def make_args(env_name, flags, nenvs, seed, env_id_offset, device):
         batch_size=500, hid_size=64, recurrent=False, seed=seed, lrate=0.001, env_name=env_name, max_steps=20,
         display=False, commnet=False, ic3net=False, nagents=1, comm_mode='avg', comm_passes=1, comm_mask_zero=False,
         mean_ratio=1.0, rnn_type='MLP', detach_gap=10000, comm_init='uniform', hard_attn=False, comm_action_one=False,
-        share_weights=False, nenvs=nenvs, env_id_offset=env_id_offset, device=device, store_states=False)
+        share_weights=False, nenvs=nenvs, env_id_offset=env_id_offset, device=device, store_states=False,
+        hip_graph=False)
     if env_name == 'predator_prey':
         a.__dict__.update(nenemies=1, dim=5, vision=2, moving_prey=False, no_stay=False, mode='mixed', enemy_comm=False)
     else:
@@ -182,7 +183,8 @@ def main():
     p.add_argument('--nenvs', type=int, default=8192, help='environments per GPU')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--graph', type=int, default=int(os.environ.get('IC3_BENCH_GRAPH', '0')))
+    p.add_argument('--graph', type=int, default=int(os.environ.get('IC3_BENCH_GRAPH', '1')),
+                   help='replay the per-step launch sequence as hipGraphs (Trainer args.hip_graph)')
     o = p.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -202,6 +204,7 @@ def main():
         dist.init_process_group(backend='nccl')   # RCCL; used only for the timing barrier / max-reduce
 
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
+    a.hip_graph = bool(o.graph)
     T = a.max_steps
     raw_env = trainer.env.env
 
@@ -216,6 +219,9 @@ def main():
                 t_in_ep = 0
         return t_in_ep
 
+    raw_env.obs_timer = []                    # event-time the obs launch from the start (graphs are captured in this mode)
+    if o.graph:                               # untimed: one eager episode (warm-up) + one capture episode
+        run(2 * T, 0)
     t_in_ep = run(o.warmup, 0)
     torch.cuda.synchronize()
     if world > 1:

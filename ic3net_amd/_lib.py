@@ -64,6 +64,8 @@ EXPORTS = {
                                    C.c_int, C.c_void_p]),
     "ic3_sample_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_env_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_int, C.c_void_p]),
 }

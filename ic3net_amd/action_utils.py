@@ -17,8 +17,11 @@ def parse_action_args(args):                   # action_utils.py:5-24
 class SampleClock(object):
     """Where on the counter-based stream the next draw sits: (seed, env_id_offset, episode, t)."""
 
-    def __init__(self, seed=0, env_id_offset=0):
+    def __init__(self, seed=0, env_id_offset=0, env=None):
         self.seed, self.env_id_offset, self.episode, self.t = seed, env_id_offset, 0, 0
+        # when set (a batched env object), draws are positioned by the env handle's own device-side
+        # (episode, t) counters — the same stream positions, but hipGraph-capturable
+        self.env = env
 
 
 def select_action(args, action_out, clock=None, out=None):
@@ -31,7 +34,10 @@ def select_action(args, action_out, clock=None, out=None):
         E, N = action_out[0].shape[:2]
         out = torch.empty((len(action_out), E, N), dtype=torch.int32, device=action_out[0].device)
     for k, lp in enumerate(action_out):
-        ops.sample_actions(lp, k, clock.seed, clock.env_id_offset, clock.episode, clock.t, out=out[k])
+        if clock.env is not None:
+            ops.sample_actions_env(clock.env, lp, k, out=out[k])
+        else:
+            ops.sample_actions(lp, k, clock.seed, clock.env_id_offset, clock.episode, clock.t, out=out[k])
     return out
 
 

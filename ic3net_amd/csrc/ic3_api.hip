@@ -86,6 +86,8 @@ static int finish_create(ic3_env* env, int device)
     IC3_HIP(hipMalloc(&env->d_err, sizeof(int32_t)));
     IC3_HIP(hipMemset(env->d_err, 0, sizeof(int32_t)));
     IC3_HIP(hipMalloc(&env->d_stats, 2 * sizeof(double)));
+    IC3_HIP(hipMalloc(&env->d_thr, sizeof(int32_t)));
+    IC3_HIP(hipMemset(env->d_thr, 0, sizeof(int32_t)));
     return 0;
 }
 
@@ -201,6 +203,7 @@ int ic3_env_destroy(ic3_env* env)
     (void)hipFree(env->state);
     (void)hipFree(env->d_err);
     (void)hipFree(env->d_stats);
+    (void)hipFree(env->d_thr);
     (void)hipFree(env->d_grid);
     (void)hipFree(env->d_route_off);
     (void)hipFree(env->d_route_rc);
@@ -280,6 +283,13 @@ int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward
     if (rc) return rc;
     if (obs) return ic3_env_observe(env, obs, stream);
     return 0;
+}
+
+int ic3_env_sample_actions(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action,
+                           float* chosen_logp, ic3_stream stream)
+{
+    if (!env || !logp || !action || A <= 0) return fail(-22, "ic3_env_sample_actions: bad arguments");
+    return sample_actions_env(env, logp, ld, A, head, action, chosen_logp, (hipStream_t)stream);
 }
 
 int ic3_env_check(ic3_env* env, ic3_stream stream)

@@ -70,6 +70,7 @@ struct ic3_env {
     std::vector<ic3::Field> fields;
     int32_t* d_err = nullptr;  // sticky bad-action flag
     double* d_stats = nullptr; // small device scratch for ic3_env_stats
+    int32_t* d_thr = nullptr;  // TJ: floor(add_rate * 2^24), device-resident so captured step graphs stay valid
     int64_t resets = 0;
     // Traffic-Junction constant tables (device + host copies)
     int32_t* d_grid = nullptr;       // [h*w] road ids
@@ -110,6 +111,9 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,
                     std::vector<int32_t>& route_rc, std::string& err);
+// policy_ops.hip
+int sample_actions_env(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action, float* chosen_logp,
+                       hipStream_t s);
 // stats
 int env_stats(ic3_env* env, ic3_stats* out, hipStream_t s);
 

@@ -187,6 +187,48 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(const float* __rest
     if (chosen_logp) chosen_logp[row] = lp[a];
 }
 
+// Same draw, but (episode, t) come from the env handle's device-side counters (episode[e], t[e]) instead of
+// by-value arguments, so a captured step graph stays valid across steps and episodes.
+__global__ __launch_bounds__(256) void sample_actions_env_kernel(const float* __restrict__ logp, int ld, int A, int head,
+                                                                 uint32_t seed, uint32_t gid0,
+                                                                 const int32_t* __restrict__ episode,
+                                                                 const int32_t* __restrict__ tstep,
+                                                                 int32_t* __restrict__ action,
+                                                                 float* __restrict__ chosen_logp, int E, int N)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= E * N) return;
+    const int e = row / N, n = row - e * N;
+    const uint32_t x = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)episode[e], (uint32_t)tstep[e],
+                                  (uint32_t)(head * N + n));
+    const float u = (float)x * (1.0f / 16777216.0f);
+    const float* lp = logp + (size_t)row * ld;
+    float cdf = 0.0f;
+    int a = A - 1;
+    for (int b = 0; b < A - 1; ++b) {
+        cdf += expf(lp[b]);
+        if (u < cdf) {
+            a = b;
+            break;
+        }
+    }
+    action[row] = a;
+    if (chosen_logp) chosen_logp[row] = lp[a];
+}
+
+int sample_actions_env(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action, float* chosen_logp,
+                       hipStream_t s)
+{
+    const int E = env->dims.E, N = env->dims.N, rows = E * N;
+    if (ld <= 0) ld = A;
+    const uint32_t seed = env->kind == IC3_ENV_PP ? env->pp.seed : env->tj.seed;
+    const uint32_t gid0 = env->kind == IC3_ENV_PP ? env->pp.env_id_offset : env->tj.env_id_offset;
+    hipLaunchKernelGGL(sample_actions_env_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, logp, ld, A, head, seed, gid0,
+                       env->f("episode"), env->f("t"), action, chosen_logp, E, N);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* __restrict__ action, int naction, uint32_t seed,
                                                              uint32_t gid0, uint32_t episode, uint32_t t, int E, int N)
 {

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void tj_step_kernel(
     const int32_t* __restrict__ over_s, const int32_t* __restrict__ episode_s, int32_t* __restrict__ tstep_s,
     const int32_t* __restrict__ route_off, const int32_t* __restrict__ route_rc, const int32_t* __restrict__ actions,
     float* __restrict__ reward, int32_t* __restrict__ done, int32_t* __restrict__ alive_out,
-    int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E, int N, int G, int narrival, int rpa, int32_t thr,
-    uint32_t seed, uint32_t gid0)
+    int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E, int N, int G, int narrival, int rpa,
+    const int32_t* __restrict__ thr_p, uint32_t seed, uint32_t gid0)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / G, n = tid - e * G;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void tj_step_kernel(
         }
     }
     // ---- _add_cars TJ:369-393: lane j of the group pre-draws arrival point j's three uniforms ----
+    const int32_t thr = *thr_p;  // floor(add_rate * 2^24): u <= add_rate <=> x24 <= thr (exact)
     uint32_t x0 = 0, x1 = 0, x2 = 0;
     if (env_ok && n < narrival) {
         x0 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 0u);
@@ -294,9 +295,16 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
     return 0;
 }
 
+__global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
+
 int tj_reset(ic3_env* env, hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
+    // u <= add_rate  <=>  x24 <= floor(add_rate * 2^24)   (exact: power-of-two scaling in fp64)
+    double thr_d = __builtin_floor(env->add_rate * 16777216.0);
+    if (thr_d > 16777216.0) thr_d = 16777216.0;
+    if (thr_d < -1.0) thr_d = -1.0;
+    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, env->d_thr, (int32_t)thr_d);
     const int n = c.E * c.N;
     hipLaunchKernelGGL(tj_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, env->f("alive"), env->f("wait"),
                        env->f("loc_r"), env->f("loc_c"), env->f("last_act"), env->f("route_loc"), env->f("route_id"),
@@ -318,17 +326,12 @@ int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, 
     const ic3_tj_cfg& c = env->tj;
     const int G = tj_group(c.N);
     const long long threads = (long long)c.E * G;
-    // u <= add_rate  <=>  x24 <= floor(add_rate * 2^24)   (exact: power-of-two scaling in fp64)
-    double thr_d = __builtin_floor(env->add_rate * 16777216.0);
-    if (thr_d > 16777216.0) thr_d = 16777216.0;
-    if (thr_d < -1.0) thr_d = -1.0;
-    const int32_t thr = (int32_t)thr_d;
     const int rpa = env->dims.npath / env->dims.narrival;
     hipLaunchKernelGGL(tj_step_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, env->f("alive"),
                        env->f("wait"), env->f("loc_r"), env->f("loc_c"), env->f("last_act"), env->f("route_loc"),
                        env->f("route_id"), env->f("is_completed"), env->f("cars_in_sys"), env->f("has_failed"),
                        env->f("over"), env->f("episode"), env->f("t"), env->d_route_off, env->d_route_rc, actions, reward,
-                       done, alive, is_completed, env->d_err, c.E, c.N, G, env->dims.narrival, rpa, thr, c.seed,
+                       done, alive, is_completed, env->d_err, c.E, c.N, G, env->dims.narrival, rpa, env->d_thr, c.seed,
                        c.env_id_offset);
     IC3_HIP(hipGetLastError());
     return 0;

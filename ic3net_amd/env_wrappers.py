@@ -57,10 +57,10 @@ class GymWrapper(object):
     def end_display(self):
         pass
 
-    def step(self, action):                    # env_wrappers.py:73-80
+    def step(self, action, observe=True):      # env_wrappers.py:73-80
         if self.dim_actions == 1:
             action = action[0]
-        obs, r, done, info = self.env.step(action)
+        obs, r, done, info = self.env.step(action, observe) if not observe else self.env.step(action)
         return (self._flatten_obs(obs), r, done, info)
 
     def reward_terminal(self):                 # env_wrappers.py:82-86

@@ -110,8 +110,7 @@ class _BatchedEnv(object):
         if out is None:
             out = torch.empty((self.nenvs, self.nagents_env, H), dtype=torch.float32, device=self.device)
         ldo = H if out.dim() == 3 else out.stride(0)     # (E*N, H) column slice of a wider buffer: row stride
-        with torch.cuda.device(self.device):
-            check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
+        check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
         return out
 
     def device_stats(self):
@@ -131,7 +130,7 @@ class _BatchedEnv(object):
         self.episode_over = False
         return self._obs
 
-    def _step(self, action):
+    def _step(self, action, observe=True):
         self._require()
         a = self._actions(action)
         # `self.out` lets a caller (the batched Trainer) receive reward / done / alive / is_completed directly in
@@ -139,22 +138,28 @@ class _BatchedEnv(object):
         o = self.out or {}
         reward, done = o.get('reward', self._reward), o.get('done', self._done)
         alive, completed = o.get('alive', self._alive), o.get('is_completed', self._completed)
-        with torch.cuda.device(self.device):
-            if self.obs_timer is None:
-                check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(reward), ptr(done),
-                                              ptr(alive), ptr(completed), stream()))
-            else:
-                # same two kernels, but with HIP events (on the launch stream) bracketing the obs-assembly launch
-                check(_lib.lib().ic3_env_step(self._h, ptr(a), None, ptr(reward), ptr(done),
-                                              ptr(alive), ptr(completed), stream()))
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(torch.cuda.current_stream())
-                check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
-                e1.record(torch.cuda.current_stream())
-                self.obs_timer.append((e0, e1))
+        if self.obs_timer is None and observe:
+            check(_lib.lib().ic3_env_step(self._h, ptr(a), ptr(self._obs), ptr(reward), ptr(done),
+                                          ptr(alive), ptr(completed), stream()))
+        else:
+            check(_lib.lib().ic3_env_step(self._h, ptr(a), None, ptr(reward), ptr(done),
+                                          ptr(alive), ptr(completed), stream()))
+            if observe:
+                self.observe_timed()
         self._last = (reward, done, alive, completed)
         return self._obs, reward, done
+
+    def observe_timed(self):
+        """The obs-assembly launch, bracketed by HIP events on the launch stream when `obs_timer` is a list."""
+        if self.obs_timer is None:
+            return self.observe()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
+        e1.record(torch.cuda.current_stream())
+        self.obs_timer.append((e0, e1))
+        return self._obs
 
     def reward_terminal(self):
         return torch.zeros_like(self._reward)      # PP:292-293 / TJ:611-612: zeros
@@ -222,8 +227,8 @@ class PredatorPreyEnv(_BatchedEnv):
     def reset(self):                        # PP:146-168
         return self._reset(None)
 
-    def step(self, action):                 # PP:112-144
-        obs, reward, done = self._step(action)
+    def step(self, action, observe=True):   # PP:112-144
+        obs, reward, done = self._step(action, observe)
         debug = {'alive_mask_device': self._last[2]}   # PP has no alive_mask in info (trainer.py:78-81 uses ones)
         return obs, reward, done, debug
 
@@ -310,8 +315,8 @@ class TrafficJunctionEnv(_BatchedEnv):
     def reset(self, epoch=None):            # TJ:160-204
         return self._reset(epoch)
 
-    def step(self, action):                 # TJ:206-252
-        obs, reward, done = self._step(action)
+    def step(self, action, observe=True):   # TJ:206-252
+        obs, reward, done = self._step(action, observe)
         debug = {'alive_mask': self._last[2], 'is_completed': self._last[3]}
         return obs, reward, done, debug
 

@@ -44,9 +44,8 @@ def _launch(h, alive, comm_action, mode_avg, mask_self, out=None):
     hk, ldh = _rows(h, H)
     if out is None:
         out = torch.empty((E, N, H), dtype=torch.float32, device=h.device)
-    with torch.cuda.device(h.device):
-        check(_lib.lib().ic3_comm_masked_mean(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(out), E, N, H,
-                                              int(mode_avg), int(mask_self), stream()))
+    check(_lib.lib().ic3_comm_masked_mean(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(out), E, N, H,
+                                          int(mode_avg), int(mask_self), stream()))
     return out
 
 
@@ -56,8 +55,7 @@ def lstm_cell_(gates, c, h_out):
     _need_cuda(gates, "lstm_cell")
     R, H = c.shape
     assert gates.is_contiguous() and c.is_contiguous() and h_out.stride(1) == 1
-    with torch.cuda.device(gates.device):
-        check(_lib.lib().ic3_lstm_cell(ptr(gates), ptr(c), ptr(h_out), h_out.stride(0), R, H, stream()))
+    check(_lib.lib().ic3_lstm_cell(ptr(gates), ptr(c), ptr(h_out), h_out.stride(0), R, H, stream()))
     return h_out, c
 
 
@@ -71,9 +69,8 @@ def policy_heads(h, W, b, head_sizes, out=None):
     if out is None:
         out = torch.empty((R, OT), dtype=torch.float32, device=h.device)
     sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
-    with torch.cuda.device(h.device):
-        check(_lib.lib().ic3_policy_heads(ptr(h), h.stride(0), ptr(W), ptr(b), sizes, len(head_sizes), ptr(out), R, H,
-                                          stream()))
+    check(_lib.lib().ic3_policy_heads(ptr(h), h.stride(0), ptr(W), ptr(b), sizes, len(head_sizes), ptr(out), R, H,
+                                      stream()))
     return out
 
 
@@ -93,9 +90,20 @@ def sample_actions(logp, head, seed, env_id_offset, episode, t, want_logp=False,
     logp, ld = _rows(logp.detach(), A)
     action = out if out is not None else torch.empty((E, N), dtype=torch.int32, device=logp.device)
     chosen = torch.empty((E, N), dtype=torch.float32, device=logp.device) if want_logp else None
-    with torch.cuda.device(logp.device):
-        check(_lib.lib().ic3_sample_actions(ptr(logp), ld, A, int(head), int(seed) & 0xffffffff, int(env_id_offset),
-                                            int(episode), int(t), ptr(action), ptr(chosen), E, N, stream()))
+    check(_lib.lib().ic3_sample_actions(ptr(logp), ld, A, int(head), int(seed) & 0xffffffff, int(env_id_offset),
+                                        int(episode), int(t), ptr(action), ptr(chosen), E, N, stream()))
+    return (action, chosen) if want_logp else action
+
+
+def sample_actions_env(env, logp, head, out=None, want_logp=False):
+    """sample_actions with (seed, env_id_offset, episode, t) taken from the env handle's own device-side counters
+    (ic3_env_sample_actions): identical draws, but every launch argument is constant -> hipGraph-capturable."""
+    _need_cuda(logp, "sample_actions_env")
+    E, N, A = logp.shape
+    logp, ld = _rows(logp.detach(), A)
+    action = out if out is not None else torch.empty((E, N), dtype=torch.int32, device=logp.device)
+    chosen = torch.empty((E, N), dtype=torch.float32, device=logp.device) if want_logp else None
+    check(_lib.lib().ic3_env_sample_actions(env._h, ptr(logp), ld, A, int(head), ptr(action), ptr(chosen), stream()))
     return (action, chosen) if want_logp else action
 
 

@@ -37,7 +37,14 @@ class Trainer(object):
         self.params = [p for p in self.policy_net.parameters()]
         self.clock = SampleClock(getattr(args, 'seed', 0), getattr(args, 'env_id_offset', 0))
         self.clock.episode = -1
+        self.clock.env = getattr(env, 'env', None) if hasattr(getattr(env, 'env', None), '_h') else None
         self.stats = dict()
+        # hipGraph capture of the per-step launch sequence (args.hip_graph): one graph per step index t, captured
+        # during the second episode (the first runs eagerly as warm-up) and replayed afterwards.
+        self._graphs = {}
+        self._graph_pool = None
+        self._episodes_played = 0
+        self._static = None
         # encoder(obs) as a sparse gather from env state (ic3_env_encode) instead of a dense obs_dim x H GEMM;
         # the dense observation is still assembled by env.step (API contract / store_states).
         if getattr(args, 'sparse_encoder', True) and hasattr(policy_net, 'obs_encoder') \
@@ -73,15 +80,56 @@ class Trainer(object):
         self._nsteps = 0
         # Episode buffers [T, ...]: the env / sampling kernels write step t's outputs straight into slice t, so the
         # hot loop launches no bookkeeping kernels; masks and statistics are derived once in end_episode().
-        z = lambda *shape, dt=torch.int32: torch.empty((T,) + shape, dtype=dt, device=dev)
-        self._buf = dict(action=z(nh, E, N), reward=z(E, N, dt=torch.float32), done=z(E), alive=z(E, N),
-                         is_completed=z(E, N))
+        # With hipGraph replay the buffers must keep their addresses, so they are allocated once and reused
+        # (a Transition then stays valid until the next begin_episode).
+        if self._static is None or not self._use_graph():
+            z = lambda *shape, dt=torch.int32: torch.empty((T,) + shape, dtype=dt, device=dev)
+            self._static = dict(action=z(nh, E, N), reward=z(E, N, dt=torch.float32), done=z(E), alive=z(E, N),
+                                is_completed=z(E, N),
+                                ones=torch.ones((E, N), dtype=torch.int32, device=dev),
+                                zeros=torch.zeros((E, N), dtype=torch.int32, device=dev))
+        self._buf = self._static
         self._step_out = [(None, None, None, None)] * T          # (state, action_out, value, next_state) per step
-        self._ones_comm = torch.ones((E, N), dtype=torch.int32, device=dev) if args.comm_action_one else None
-        self._zeros_comm = torch.zeros((E, N), dtype=torch.int32, device=dev)
+        self._ones_comm = self._static['ones'] if args.comm_action_one else None
+        self._zeros_comm = self._static['zeros']
+
+    def _use_graph(self):
+        a = self.args
+        return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
+            and not getattr(a, 'rollout_grad', False) and self.clock.env is not None
 
     def step_episode(self, t):
-        """One iteration of the hot loop trainer.py:43-108 for all E envs."""
+        """One iteration of the hot loop trainer.py:43-108 for all E envs (eager, or as a hipGraph replay)."""
+        if not self._use_graph() or self._episodes_played == 0:
+            self._step_body(t, observe=True)
+            return
+        raw = self.env.env
+        g = self._graphs.get(t)
+        if g is None:
+            # capture: the launch sequence of step t (policy kernels, sampling, env step [, obs assembly]) with the
+            # buffers it reads/writes.  The obs launch stays outside the graph while it is being event-timed.
+            in_graph_obs = raw.obs_timer is None
+            saved = (self._state, self._info, self._prev_hid)
+            graph = torch.cuda.CUDAGraph()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(graph, pool=self._graph_pool):
+                self._step_body(t, observe=in_graph_obs)
+            g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
+                                       outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
+            # capture does not execute: fall through to a replay so that step t actually runs
+        if g['obs_inside'] != (raw.obs_timer is None) and g['obs_inside']:
+            # timing was switched on after capture: re-capture without the obs launch
+            del self._graphs[t]
+            return self.step_episode(t)
+        self.clock.t = t
+        g['graph'].replay()
+        if not g['obs_inside']:
+            raw.observe_timed()
+        self._state, self._info, self._prev_hid, self._step_out[t] = g['outputs']
+        self._nsteps = t + 1
+
+    def _step_body(self, t, observe=True):
         args = self.args
         state, info, buf = self._state, self._info, self._buf
         store = bool(getattr(args, 'store_states', False))
@@ -105,7 +153,10 @@ class Trainer(object):
             raw.out = dict(reward=buf['reward'][t], done=buf['done'][t], alive=buf['alive'][t],
                            is_completed=buf['is_completed'][t])
             try:
-                next_state, reward, done, info = self.env.step(actual)                   # trainer.py:67
+                if observe:
+                    next_state, reward, done, info = self.env.step(actual)               # trainer.py:67
+                else:
+                    next_state, reward, done, info = self.env.step(actual, observe=False)
             finally:
                 raw.out = None
             info = dict(info)
@@ -162,6 +213,7 @@ class Trainer(object):
         if hasattr(self.env, 'get_stat'):                          # trainer.py:124-125
             merge_stat(self.env.get_stat(), stat)
         self._live = live[-1] * not_done[-1]
+        self._episodes_played += 1
         return (episode, stat)
 
     def run_batch(self, epoch):                                    # trainer.py:227-242

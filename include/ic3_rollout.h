@@ -185,6 +185,12 @@ int ic3_sample_actions(const float* logp, int ld /* logp row stride in floats, 0
                        uint32_t env_id_offset, uint32_t episode, uint32_t t, int32_t* action, float* chosen_logp,
                        int E, int N, ic3_stream stream);
 
+/* The same draw with (seed, env_id_offset) taken from the handle's config and (episode, t) read from its
+ * device-side per-env counters (the env's own episode / step counters): every argument is constant across
+ * steps, so a hipGraph capture of the rollout step can be replayed for the whole run. */
+int ic3_env_sample_actions(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action,
+                           float* chosen_logp, ic3_stream stream);
+
 /* Synthetic uniform actions in [0, naction) for env-only benchmarks (DOMAIN_BENCH). */
 int ic3_random_actions(int32_t* action, int naction, uint32_t seed, uint32_t env_id_offset, uint32_t episode,
                        uint32_t t, int E, int N, ic3_stream stream);

@@ -130,3 +130,53 @@ def test_run_batch_surface():
     assert stats2['num_steps'] == stats['num_steps']
     assert all(torch.equal(x, y) for x, y in zip(batch.action, batch2.action))
     np.testing.assert_array_equal(stats['reward'], stats2['reward'])
+
+
+@pytest.mark.parametrize("env_name,flags", [
+    ("predator_prey", dict(nagents=5, dim=10, vision=1, hid_size=32, ic3net=True, recurrent=True, detach_gap=10)),
+    ("traffic_junction", dict(nagents=10, dim=14, vision=1, hid_size=32, ic3net=True, recurrent=True, detach_gap=10,
+                              difficulty='medium', add_rate_min=0.2, add_rate_max=0.2)),
+    ("traffic_junction", dict(nagents=5, dim=6, vision=0, hid_size=32, commnet=True, recurrent=True, detach_gap=10,
+                              difficulty='easy', add_rate_min=0.1, add_rate_max=0.3, curr_start=0, curr_end=4)),
+])
+def test_hip_graph_replay_equals_eager(env_name, flags):
+    """args.hip_graph: episode 0 eager, episode 1 captured, episodes 2.. replayed — every episode must be
+    identical to the all-eager run (counter-based streams; the curriculum case changes add_rate between episodes)."""
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+
+    def run(graph):
+        a = build_args(env_name, dict(flags), flags['nagents'], 12, 64, 5)
+        a.env_id_offset = 0
+        a.hip_graph = graph
+        env = data.init(env_name, a, False)
+        a.num_actions = [env.num_actions]
+        a.dim_actions = env.dim_actions
+        a.num_inputs = env.observation_dim
+        if a.hard_attn and a.commnet:
+            a.num_actions = [*a.num_actions, 2]
+            a.dim_actions = env.dim_actions + 1
+        a.recurrent, a.rnn_type = True, 'LSTM'
+        parse_action_args(a)
+        torch.manual_seed(11)
+        net = CommNetMLP(a, a.num_inputs).cuda()
+        tr = trmod.Trainer(a, net, env)
+        out = []
+        for ep in range(5):
+            episode, stat = tr.get_episode(ep)
+            out.append(([t.action.clone() for t in episode], [t.reward.clone() for t in episode],
+                        [t.value.clone() for t in episode], [t.misc['alive_mask'].clone() for t in episode],
+                        {k: np.asarray(v).copy() for k, v in stat.items()}))
+        return out, tr
+
+    eager, _ = run(False)
+    graphed, tr = run(True)
+    assert len(tr._graphs) == 12
+    for ep, (e, g) in enumerate(zip(eager, graphed)):
+        for i in range(4):
+            for x, y in zip(e[i], g[i]):
+                assert torch.equal(x, y), (ep, i)
+        assert set(e[4]) == set(g[4])
+        for k in e[4]:
+            np.testing.assert_array_equal(e[4][k], g[4][k], err_msg=k)
