@@ -327,24 +327,17 @@ int pp_observe(ic3_env* env, float* obs, hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
     const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
-    const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     const int vocab = c.dim * c.dim + 4;
-    static const int variant = getenv("IC3_OBS_VARIANT") ? atoi(getenv("IC3_OBS_VARIANT")) : 0;  // experiments only
-#define IC3_OBS_LAUNCH(V, NT, AL)                                                                                  \
-    hipLaunchKernelGGL((pp_obs_kernel<V, NT, AL>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"), obs, \
-                       c.N, c.nprey, c.dim, c.vision)
+    const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
+    // Geometry/stores chosen by measurement on MI355X (profiles/r01/obs_variants.txt, obs_geometry.txt): one WG per
+    // env with LDS-staged descriptors, plain (not nontemporal) stores, 1 KiB-aligned wave stores.
     if ((vocab & 3) == 0) {
-        switch (variant) {
-            // measured on MI355X, PP-hard E=8192 (profiles/r01/obs_variants.txt): 5.62 / 5.03 / 4.41 / 5.40 TB/s
-            case 1: IC3_OBS_LAUNCH(true, true, true); break;    // nontemporal, aligned
-            case 2: IC3_OBS_LAUNCH(true, true, false); break;   // nontemporal, unaligned (first version)
-            case 3: IC3_OBS_LAUNCH(true, false, false); break;  // plain, unaligned
-            default: IC3_OBS_LAUNCH(true, false, true); break;  // plain stores, 1 KiB-aligned wave stores
-        }
-    } else {
-        IC3_OBS_LAUNCH(false, false, false);
+        hipLaunchKernelGGL((pp_obs_kernel<true, false, true>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
+                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision);
+    } else {   // vocab % 4 != 0 (odd dim): dword stores
+        hipLaunchKernelGGL((pp_obs_kernel<false, false, false>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
+                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision);
     }
-#undef IC3_OBS_LAUNCH
     IC3_HIP(hipGetLastError());
     return 0;
 }
