@@ -25,6 +25,7 @@ def allreduce_stats(stat, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return stat
+    stat = dict(stat)
     keys = sorted(k for k, v in stat.items() if isinstance(v, (int, float, np.ndarray, np.floating, np.integer)))
     flat = np.concatenate([np.atleast_1d(np.asarray(stat[k], np.float64)).ravel() for k in keys])
     dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'

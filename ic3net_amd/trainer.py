@@ -137,6 +137,8 @@ class Trainer(object):
         with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):
             if t == 0 and args.hard_attn and args.commnet:         # trainer.py:45-46 (quirk Q22)
                 info['comm_action'] = self._zeros_comm
+            if torch.is_grad_enabled():
+                state = state.clone()          # the env reuses its obs buffer; autograd keeps the encoder input
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:
                     self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
@@ -237,10 +239,75 @@ class Trainer(object):
 
     # ------------------------------------------------------------------------------------------
     def compute_grad(self, batch):
-        raise NotImplementedError("compute_grad (trainer.py:128-225) is the 'next' row f1 of SURVEY 8(f)")
+        """trainer.py:128-225 over a batch whose transitions carry a leading env dimension.  The time axis is the
+        concatenation of the batched episodes (episode_mask is 0 on every env's last step, so the reversed return
+        scan restarts there exactly as in the reference's episode-after-episode batch); transitions of envs that
+        were already done (misc['live'] == 0) are excluded from every sum, mean and std."""
+        args = self.args
+        stat = dict()
+        n = args.nagents
+        rewards = torch.stack(batch.reward)                                   # (T, E, N)
+        T, E = rewards.shape[0], rewards.shape[1]
+        episode_masks = torch.stack(batch.episode_mask)
+        episode_mini_masks = torch.stack(batch.episode_mini_mask)
+        actions = torch.stack(batch.action).permute(0, 2, 3, 1).long()        # (T, E, N, heads)
+        values = torch.stack([v.reshape(E, n) for v in batch.value])          # (T, E, N), carries the graph
+        nheads = len(batch.action_out[0])
+        log_p_a = [torch.stack([ao[k] for ao in batch.action_out]) for k in range(nheads)]    # (T, E, N, A_k)
+        alive_masks = torch.stack([m['alive_mask'] for m in batch.misc])      # (T, E, N), already x live
+        live = torch.stack([m['live'] for m in batch.misc]).unsqueeze(2).expand(T, E, n)      # (T, E, N)
+
+        coop_returns = torch.empty_like(rewards)
+        ncoop_returns = torch.empty_like(rewards)
+        prev_coop = torch.zeros_like(rewards[0])
+        prev_ncoop = torch.zeros_like(rewards[0])
+        for i in reversed(range(T)):                                          # trainer.py:162-170
+            coop_returns[i] = rewards[i] + args.gamma * prev_coop * episode_masks[i]
+            ncoop_returns[i] = rewards[i] + args.gamma * prev_ncoop * episode_masks[i] * episode_mini_masks[i]
+            prev_coop = coop_returns[i]
+            prev_ncoop = ncoop_returns[i]
+        returns = args.mean_ratio * coop_returns.mean(dim=2, keepdim=True) + (1 - args.mean_ratio) * ncoop_returns
+        advantages = returns - values.detach()                                # trainer.py:173-174
+        if args.normalize_rewards:                                            # trainer.py:176-177 (live entries only)
+            cnt = live.sum()
+            mean = (advantages * live).sum() / cnt
+            var = (((advantages - mean) ** 2) * live).sum() / (cnt - 1)       # torch.std() is unbiased
+            advantages = (advantages - mean) / var.sqrt()
+        per_head = [lp.gather(3, actions[..., k:k + 1]).squeeze(3) for k, lp in enumerate(log_p_a)]   # utils.py:42-53
+        if args.advantages_per_action:                                        # trainer.py:192-194
+            action_loss = sum((-advantages * lp * alive_masks).sum() for lp in per_head)
+        else:
+            action_loss = (-advantages * sum(per_head) * alive_masks).sum()   # trainer.py:196-197
+        stat['action_loss'] = action_loss.item()
+        value_loss = ((values - returns).pow(2) * alive_masks).sum()          # trainer.py:203-206
+        stat['value_loss'] = value_loss.item()
+        loss = action_loss + args.value_coeff * value_loss
+        entropy = 0                                                           # trainer.py:211-218 (no alive mask there)
+        for lp in log_p_a:
+            entropy = entropy - (lp * lp.exp() * live.unsqueeze(3)).sum()
+        stat['entropy'] = entropy.item()
+        if args.entr > 0:
+            loss = loss - args.entr * entropy
+        loss.backward()
+        return stat
 
     def train_batch(self, epoch):
-        raise NotImplementedError("train_batch (trainer.py:245-256) is the 'next' row f1 of SURVEY 8(f)")
+        """trainer.py:245-256 (+ multi_processing.py:74-98 when torch.distributed is initialised: gradients and
+        stats are summed over ranks and divided by the global num_steps)."""
+        from . import sharding
+        prev = getattr(self.args, 'rollout_grad', False)
+        self.args.rollout_grad = True                   # the rollout keeps the autograd graph, like the reference
+        try:
+            batch, stat = self.run_batch(epoch)
+        finally:
+            self.args.rollout_grad = prev
+        self.optimizer.zero_grad()
+        s = self.compute_grad(batch)
+        merge_stat(s, stat)
+        stat = sharding.allreduce_stats(stat)
+        sharding.allreduce_grads(self.params, stat['num_steps'])             # grads /= num_steps (trainer.py:251-253)
+        self.optimizer.step()
+        return stat
 
     def state_dict(self):                                          # trainer.py:258-262
         return self.optimizer.state_dict()

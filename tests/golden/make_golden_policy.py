@@ -187,7 +187,84 @@ def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, **flags):
     print(name, 'nsteps', rec['nsteps'].tolist(), 'stat keys', sorted(stats))
 
 
+def grad_case(name, env_name, T, nenv, nep, seed, **flags):
+    """F5b: the reference run_batch + compute_grad (trainer.py:128-225) over nenv*nep taped episodes played one
+    after the other in ONE batch (what a single reference process does), fp64.  Records the loss terms and every
+    parameter gradient (before the /num_steps of train_batch), plus the weights and the action tape."""
+    ref = rh.load_reference()
+    torch.set_default_dtype(torch.float64)
+    a = rh.make_args(env_name, max_steps=T, seed=seed, **flags)
+    env = rh.make_env(env_name, a)
+    rh.finish_args(a, env)
+    torch.manual_seed(seed)
+    net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    tr = ref['trainer'].Trainer(a, net, env)
+    N, nh = a.nagents, len(a.naction_heads)
+    rs = np.random.RandomState(seed)
+    tape = np.zeros((nenv, nep, T, nh, N), np.int64)
+    for h, A in enumerate(a.naction_heads):
+        tape[:, :, :, h] = rs.randint(0, A, size=(nenv, nep, T, N))
+    if env_name == 'traffic_junction':
+        tape[:, :, :, 0] = (rs.rand(nenv, nep, T, N) < 0.3)
+    cursor = {}
+    trmod = ref['trainer']
+
+    def taped_select(args, action_out):
+        e, ep, t = cursor['e'], cursor['ep'], cursor['t']
+        cursor['t'] += 1
+        if env_name == 'traffic_junction':
+            ref['rnd'].begin(cursor['st'], philox.DOMAIN_TJ_ADD, ep, t)
+        act = tape[e, ep, t].copy()
+        if env_name == 'predator_prey' and e == 0:       # steer env 0 onto the prey: early termination in the batch
+            raw = tr.env.env
+            for i in range(N):
+                dr = raw.prey_loc[0][0] - raw.predator_loc[i][0]
+                dc = raw.prey_loc[0][1] - raw.predator_loc[i][1]
+                act[0, i] = (2 if dr > 0 else 0) if dr != 0 else ((1 if dc > 0 else 3) if dc != 0 else 4)
+            tape[e, ep, t] = act
+        return torch.from_numpy(act).view(nh, 1, N, 1)
+    trmod.select_action = taped_select
+    batch = []
+    stats = dict(num_episodes=0)
+    nsteps = np.zeros((nenv, nep), np.int32)
+    streams = [philox.Stream(seed, 400 + e) for e in range(nenv)]
+    envs = [rh.make_env(env_name, a) for e in range(nenv)]
+    for ep in range(nep):                                # episode-major order == the batched engine's order
+        for e in range(nenv):
+            tr.env = envs[e]
+            cursor.update(e=e, ep=ep, t=0, st=streams[e])
+            ref['rnd'].begin(streams[e], philox.DOMAIN_PP_RESET, ep, 0)
+            episode, stat = tr.get_episode(ep)
+            nsteps[e, ep] = len(episode)
+            ref['utils'].merge_stat(stat, stats)
+            stats['num_episodes'] += 1
+            batch += episode
+    trmod.select_action = ref['action_utils'].select_action
+    stats['num_steps'] = len(batch)
+    batch = trmod.Transition(*zip(*batch))
+    tr.optimizer.zero_grad()
+    s = tr.compute_grad(batch)
+    out = dict(tape=tape.astype(np.int32), nsteps=nsteps, cfg=np.array([N, T, nenv, nep, nh, seed], np.int32),
+               flags=np.array(repr(sorted(flags.items()))), action_loss=s['action_loss'], value_loss=s['value_loss'],
+               entropy=s.get('entropy', 0.0), num_steps=stats['num_steps'])
+    for k, v in net.state_dict().items():
+        out['w:' + k] = v.detach().numpy().copy()
+    for k, p in net.named_parameters():
+        out['g:' + k] = np.zeros(0) if p.grad is None else p.grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'steps', stats['num_steps'], 'losses', s)
+
+
 def trainer_main():
+    grad_case('grad_pp_easy_ic3net', 'predator_prey', 20, 4, 2, 31, nagents=3, dim=5, vision=0, hid_size=16,
+              ic3net=True, recurrent=True, detach_gap=10, entr=0.01, value_coeff=0.01)
+    grad_case('grad_pp_medium_commnet_norm', 'predator_prey', 40, 3, 1, 32, nagents=5, dim=10, vision=1, hid_size=16,
+              commnet=True, recurrent=True, detach_gap=10, normalize_rewards=True, mean_ratio=0.5, gamma=0.95)
+    grad_case('grad_tj_easy_ic3net', 'traffic_junction', 20, 4, 2, 33, nagents=5, dim=6, vision=0, hid_size=16,
+              ic3net=True, recurrent=True, detach_gap=10, add_rate_min=0.3, add_rate_max=0.3, difficulty='easy')
+    grad_case('grad_tj_medium_perhead', 'traffic_junction', 40, 2, 1, 34, nagents=10, dim=14, vision=1, hid_size=16,
+              ic3net=True, recurrent=True, detach_gap=10, add_rate_min=0.2, add_rate_max=0.2, difficulty='medium',
+              advantages_per_action=True, entr=0.001)
     trainer_case('trainer_pp_easy', 'predator_prey', 20, 3, 2, 21, greedy=True, nagents=3, dim=5, vision=0,
                  hid_size=16, ic3net=True, recurrent=True, detach_gap=10)
     trainer_case('trainer_pp_medium', 'predator_prey', 40, 2, 2, 22, greedy=True, nagents=5, dim=10, vision=1,

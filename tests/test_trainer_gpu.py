@@ -20,7 +20,8 @@ def build_args(env_name, flags, N, T, nenv, seed):
         batch_size=500, hid_size=64, recurrent=False, seed=seed, lrate=0.001, env_name=env_name, max_steps=T,
         display=False, commnet=False, ic3net=False, nagents=N, comm_mode='avg', comm_passes=1, comm_mask_zero=False,
         mean_ratio=1.0, rnn_type='MLP', detach_gap=10000, comm_init='uniform', hard_attn=False, comm_action_one=False,
-        share_weights=False, nenvs=nenv, env_id_offset=300, store_states=False)
+        share_weights=False, nenvs=nenv, env_id_offset=300, store_states=False, gamma=1.0, normalize_rewards=False,
+        entr=0, value_coeff=0.01, advantages_per_action=False)
     if env_name == 'predator_prey':
         a.__dict__.update(nenemies=1, dim=5, vision=2, moving_prey=False, no_stay=False, mode='mixed', enemy_comm=False)
     else:
@@ -180,3 +181,89 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
         assert set(e[4]) == set(g[4])
         for k in e[4]:
             np.testing.assert_array_equal(e[4][k], g[4][k], err_msg=k)
+
+
+GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_commnet_norm", "predator_prey"),
+                 ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction")]
+
+
+@pytest.mark.parametrize("name,env_name", GRAD_FIXTURES)
+def test_compute_grad_matches_reference(name, env_name):
+    """run_batch (with grad) + compute_grad against the reference's own trainer.py:128-225 on the same weights,
+    action tape and env draws: losses and every parameter gradient (fp32 on GPU vs the reference's fp64)."""
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    fx = load(name)
+    N, T, nenv, nep, nh, seed = [int(x) for x in fx["cfg"]]
+    flags = dict(ast.literal_eval(str(fx["flags"])))
+    a = build_args(env_name, flags, N, T, nenv, seed)
+    a.env_id_offset = 400
+    env = data.init(env_name, a, False)
+    a.num_actions = [env.num_actions]
+    a.dim_actions = env.dim_actions
+    a.num_inputs = env.observation_dim
+    if a.hard_attn and a.commnet:
+        a.num_actions = [*a.num_actions, 2]
+        a.dim_actions = env.dim_actions + 1
+    if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
+        a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    net = CommNetMLP(a, a.num_inputs)
+    net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
+    net = net.cuda()
+    tr = trmod.Trainer(a, net, env)
+    tape = fx["tape"]
+
+    def taped(args, action_out, clock, out=None):
+        act = torch.from_numpy(tape[:, clock.episode, clock.t]).permute(1, 0, 2).contiguous().int().cuda()
+        out.copy_(act)
+        return out
+    orig = trmod.select_action
+    trmod.select_action = taped
+    try:
+        a.rollout_grad = True
+        a.batch_size = int(fx["num_steps"])          # exactly nep batched episodes
+        batch, stats = tr.run_batch(0)
+        assert stats['num_steps'] == int(fx["num_steps"]) and stats['num_episodes'] == nenv * nep
+        tr.optimizer.zero_grad()
+        s = tr.compute_grad(batch)
+    finally:
+        trmod.select_action = orig
+    for k in ("action_loss", "value_loss", "entropy"):
+        np.testing.assert_allclose(s[k], float(fx[k]), rtol=2e-4, atol=1e-3, err_msg=k)
+    for pname, p in net.named_parameters():
+        g = fx["g:" + pname]
+        if g.size == 0:
+            assert p.grad is None, pname            # unused hidd_encoder (quirk Q18)
+            continue
+        scale = max(np.abs(g).max(), 1e-6)
+        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=3e-4, err_msg=pname)
+
+
+def test_train_batch_updates_parameters():
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    a = build_args('traffic_junction', dict(nagents=5, dim=6, vision=1, hid_size=32, ic3net=True, recurrent=True,
+                                            detach_gap=10, difficulty='easy', add_rate_min=0.3, add_rate_max=0.3), 5, 20,
+                   32, 2)
+    a.env_id_offset = 0
+    env = data.init('traffic_junction', a, False)
+    a.num_actions = [env.num_actions, 2]
+    a.dim_actions = 2
+    a.num_inputs = env.observation_dim
+    a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    torch.manual_seed(0)
+    net = CommNetMLP(a, a.num_inputs).cuda()
+    tr = trmod.Trainer(a, net, env)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    st = tr.train_batch(0)
+    assert set(st) >= {'num_steps', 'num_episodes', 'reward', 'success', 'add_rate', 'action_loss', 'value_loss',
+                       'entropy', 'comm_action'}
+    changed = [k for k, v in net.named_parameters() if not torch.equal(v, before[k])]
+    assert 'encoder.weight' in changed and 'f_module.weight_hh' in changed and 'heads.0.weight' in changed
+    assert not any(k.startswith('hidd_encoder') for k in changed)           # no grad -> untouched (quirk Q18)
+    st2 = tr.train_batch(1)                                                  # a second update runs (graph freed)
+    assert np.isfinite(st2['action_loss'])
