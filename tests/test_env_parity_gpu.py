@@ -224,3 +224,74 @@ def test_bad_action_flag_and_errors():
         bad.multi_agent_init(a)
     with pytest.raises(AssertionError):
         make_tj(5, 7, 0, "medium", 2)
+
+
+def test_reference_style_single_env_calls():
+    """E = 1 drop-in: list-of-arrays actions through GymWrapper like the reference's Trainer passes them."""
+    import argparse as ap
+    from ic3net_amd import data
+    import oracle
+    a = pp_args(3, 5, 1, "mixed", 1, seed=4, offset=17)
+    a.display = False
+    w = data.init('predator_prey', a, False)
+    assert (w.observation_dim, w.num_actions, w.dim_actions) == (9 * 29, 5, 1)
+    o = oracle.PPOracle(3, 5, 1, seed=4, env_gid=17)
+    obs = w.reset(0)
+    assert tuple(obs.shape) == (1, 3, 9 * 29) and np.array_equal(obs[0].cpu().numpy(), o.reset())
+    for t in range(6):
+        act = [np.array([t % 5, (t + 1) % 5, 4]), np.array([0, 1, 0])]        # [env head, talk head]
+        obs, r, done, info = w.step(act)
+        oo, orew, od = o.step(act[0])
+        assert np.array_equal(obs[0].cpu().numpy(), oo) and np.array_equal(r[0].cpu().numpy(), orew.astype(np.float32))
+    assert not w.reward_terminal().any().item()
+    st = w.get_stat()
+    assert st['success'] in (0.0, 1.0)
+    with pytest.raises(AssertionError):
+        w.env.step(np.zeros(4))                                               # wrong number of agents
+
+
+def test_set_state_injection_and_single_agent():
+    import oracle
+    env = make_pp(1, 3, 0, "mixed", 2, seed=0)
+    env.reset()
+    env.set_state(loc_r=[[0, 2], [2, 2]], loc_c=[[0, 2], [1, 2]], reached=[[0], [0]], over=[0, 0])
+    obs, r, d, _ = env.step(np.array([[2], [1]]))          # env 0 moves down (not on prey), env 1 right -> on prey
+    st = env.get_state()
+    assert st["loc_r"].tolist() == [[1, 2], [2, 2]] and st["loc_c"].tolist() == [[0, 2], [2, 2]]
+    assert r.cpu().numpy().tolist() == [[np.float32(-0.05)], [0.0]] and d.cpu().numpy().tolist() == [0, 1]
+    assert st["success"].tolist() == [0, 1]
+
+
+def test_tj_full_size_properties():
+    """BASELINE config 4 per-GPU size (TJ-hard, 20 cars, E=8192): size-independent invariants after 30 steps."""
+    E, N = 8192, 20
+    env = make_tj(N, 18, 1, "hard", E, seed=2, add_rate_min=0.3, add_rate_max=0.3)
+    env.reset(0)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for t in range(30):
+        act = (torch.rand((E, N), device='cuda', generator=g) < 0.3).int()
+        obs, rew, done, info = env.step(act)
+    st = {k: torch.as_tensor(v).cuda() for k, v in env.get_state().items()}
+    assert torch.equal(st["cars_in_sys"], st["alive"].sum(1).int())
+    dead = st["alive"] == 0
+    assert (st["loc_r"][dead] == 0).all() and (st["loc_c"][dead] == 0).all() and (st["wait"][dead] == 0).all()
+    assert not obs[dead].any().item() and not rew[dead].any().item()
+    rows = obs[~dead]
+    win = rows[:, 2:].view(rows.shape[0], 9, -1)
+    assert (win[:, :, :win.shape[2] - 1].sum(-1) == 1).all()
+    assert torch.equal(info["alive_mask"], st["alive"])
+    # crashes cost exactly -10 on top of -0.01*wait
+    w = st["wait"].float()
+    base = -0.01 * w.double()
+    diff = (rew.double() - base.double())[~dead]
+    assert (((diff.abs() < 1e-6) | ((diff + 10).abs() < 1e-5))).all()
+    # shard invariance on the add_cars stream
+    env2 = make_tj(N, 18, 1, "hard", 1024, seed=2, offset=4096, add_rate_min=0.3, add_rate_max=0.3)
+    env2.reset(0)
+    env3 = make_tj(N, 18, 1, "hard", 8192, seed=2, add_rate_min=0.3, add_rate_max=0.3)
+    env3.reset(0)
+    for t in range(5):
+        z = torch.zeros((8192, N), dtype=torch.int32, device='cuda')
+        o3, _, _, _ = env3.step(z)
+        o2, _, _, _ = env2.step(z[:1024])
+    assert torch.equal(o3[4096:5120], o2)
