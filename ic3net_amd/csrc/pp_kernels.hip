@@ -3,8 +3,6 @@
 // Reference semantics: /root/reference/ic3net-envs/ic3net_envs/predator_prey_env.py (cited "PP:line").
 // State is struct-of-arrays in HBM, one int32 array per field, env-major ([e][n]) so that the lane
 // mapping (env, agent) -> consecutive lanes reads/writes consecutive words.
-#include <cstdlib>
-
 #include "ic3_common.hpp"
 
 namespace ic3 {
