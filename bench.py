@@ -185,6 +185,8 @@ def main():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--graph', type=int, default=int(os.environ.get('IC3_BENCH_GRAPH', '1')),
                    help='replay the per-step launch sequence as hipGraphs (Trainer args.hip_graph)')
+    p.add_argument('--no-dense-obs', action='store_true',
+                   help='diagnostic: skip obs assembly (sparse encoder consumes env state directly); NOT the headline config')
     o = p.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -205,6 +207,7 @@ def main():
 
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
     a.hip_graph = bool(o.graph)
+    a.dense_obs = not o.no_dense_obs
     T = a.max_steps
     raw_env = trainer.env.env
 
@@ -249,7 +252,7 @@ def main():
         value = N * E_total * o.steps / dt
         obs_bytes = o.nenvs * N * raw_env.obs_dim * 4          # algorithmic bytes of one obs-assembly launch
         avg_ms = sum(obs_ms) / max(len(obs_ms), 1)
-        achieved = obs_bytes / (avg_ms * 1e-3) / 1e9
+        achieved = obs_bytes / (avg_ms * 1e-3) / 1e9 if obs_ms else 0.0
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'obs_traffic.json')
         if os.path.exists(tf):

@@ -93,6 +93,14 @@ class Trainer(object):
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
 
+    def _dense_obs(self):
+        """args.dense_obs=False skips the obs-assembly launch when nothing consumes the dense observation (sparse
+        encoder active, no store_states, no autograd): env.step(..., obs=NULL) in the C ABI.  Default: assemble it."""
+        a = self.args
+        if getattr(a, 'dense_obs', True) or getattr(a, 'store_states', False) or getattr(a, 'rollout_grad', False):
+            return True
+        return getattr(self.policy_net, 'obs_encoder', None) is None
+
     def _use_graph(self):
         a = self.args
         return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
@@ -101,14 +109,14 @@ class Trainer(object):
     def step_episode(self, t):
         """One iteration of the hot loop trainer.py:43-108 for all E envs (eager, or as a hipGraph replay)."""
         if not self._use_graph() or self._episodes_played == 0:
-            self._step_body(t, observe=True)
+            self._step_body(t, observe=self._dense_obs())
             return
         raw = self.env.env
         g = self._graphs.get(t)
         if g is None:
             # capture: the launch sequence of step t (policy kernels, sampling, env step [, obs assembly]) with the
             # buffers it reads/writes.  The obs launch stays outside the graph while it is being event-timed.
-            in_graph_obs = raw.obs_timer is None
+            in_graph_obs = raw.obs_timer is None and self._dense_obs()
             saved = (self._state, self._info, self._prev_hid)
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
@@ -118,13 +126,13 @@ class Trainer(object):
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
             # capture does not execute: fall through to a replay so that step t actually runs
-        if g['obs_inside'] != (raw.obs_timer is None) and g['obs_inside']:
+        if g['obs_inside'] and raw.obs_timer is not None:
             # timing was switched on after capture: re-capture without the obs launch
             del self._graphs[t]
             return self.step_episode(t)
         self.clock.t = t
         g['graph'].replay()
-        if not g['obs_inside']:
+        if not g['obs_inside'] and self._dense_obs():
             raw.observe_timed()
         self._state, self._info, self._prev_hid, self._step_out[t] = g['outputs']
         self._nsteps = t + 1
