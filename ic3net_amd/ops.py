@@ -59,6 +59,29 @@ def lstm_cell_(gates, c, h_out):
     return h_out, c
 
 
+def lstm_pack_weights(w_ih, w_hh):
+    """[W_ih | W_hh] (4H x 2H) in the packed layout ic3_lstm_fused streams (see csrc/lstm_fused.hip)."""
+    _need_cuda(w_ih, "lstm_pack_weights")
+    H = w_ih.shape[1]
+    wp = torch.empty(4 * H * 2 * H, dtype=torch.float32, device=w_ih.device)
+    check(_lib.lib().ic3_lstm_pack_weights(ptr(w_ih.detach().contiguous().float()), ptr(w_hh.detach().contiguous().float()),
+                                           ptr(wp), H, stream()))
+    return wp
+
+
+LSTM_FUSED_SIZES = (64, 128, 256)
+
+
+def lstm_fused_(xh, wp, bias, c):
+    """Whole LSTMCell on the [inp | h] buffer xh (R, 2H): c updated in place, h' written to xh[:, H:] (hand-written
+    fp32-MFMA kernel, no gates tensor)."""
+    _need_cuda(xh, "lstm_fused")
+    R, H = c.shape
+    assert xh.stride(1) == 1 and xh.shape[1] >= 2 * H and c.is_contiguous()
+    check(_lib.lib().ic3_lstm_fused(ptr(xh), xh.stride(0), ptr(wp), ptr(bias), ptr(c), R, H, stream()))
+    return xh[:, H:2 * H], c
+
+
 def policy_heads(h, W, b, head_sizes, out=None):
     """h (R,H) rows (unit column stride), W (OT,H), b (OT,) -> out (R,OT) = [log_softmax heads | value]."""
     import ctypes as C

@@ -172,6 +172,13 @@ int ic3_comm_masked_mean(const float* h, int ldh /* h row stride in floats, 0 = 
  * h' is written to h_out with row stride ldh.  H % 4 == 0. */
 int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream);
 
+/* The whole LSTMCell in one hand-written fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact f32): gate GEMM over the
+ * [inp | h] buffer XH [R][ldx] (first 2H columns), bias [4H] = b_ih + b_hh, in-register cell epilogue; c [R][H] is
+ * updated in place and h' is written back to XH[:, H:2H] (race-free: one workgroup owns 64 whole rows).  Wp is the
+ * weight matrix [W_ih | W_hh] in the packed layout produced by ic3_lstm_pack_weights (4H*2H floats).  H in {64,128,256}. */
+int ic3_lstm_pack_weights(const float* w_ih, const float* w_hh, float* Wp, int H, ic3_stream stream);
+int ic3_lstm_fused(float* XH, int ldx, const float* Wp, const float* bias, float* c, int R, int H, ic3_stream stream);
+
 /* Action heads + value head + log_softmax (comm.py:228,239) in one pass: out[r][:] =
  * [log_softmax(W_0 h_r + b_0) | ... | log_softmax(W_{k-1} h_r + b_{k-1}) | w_v h_r + b_v], OT = sum A_k + 1 <= 16.
  * W [OT][H] = rows of heads.k.weight stacked, then value_head.weight; b [OT] likewise; head_sizes is a HOST array. */

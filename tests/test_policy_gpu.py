@@ -220,3 +220,25 @@ def test_lstm_cell_and_heads_kernels_vs_torch():
                                            rtol=0)
                 off += A
             torch.testing.assert_close(out[:, off], z[:, off], atol=3e-6, rtol=0)
+
+
+@pytest.mark.parametrize("R,H", [(640, 128), (1000, 128), (77, 64), (300, 256), (64, 128), (1, 128)])
+def test_lstm_fused_mfma_kernel_vs_torch(R, H):
+    """Hand-written fp32-MFMA LSTM kernel (gate GEMM + cell epilogue, in-place h') against torch.nn.LSTMCell;
+    an asymmetric weight matrix catches any row/column or k-order slip in the fragment layouts."""
+    from ic3net_amd import ops
+    torch.manual_seed(R + H)
+    cell = torch.nn.LSTMCell(H, H).cuda()
+    with torch.no_grad():
+        cell.weight_ih.add_(torch.arange(4 * H * H, device='cuda').view(4 * H, H).float() * 1e-6)   # asymmetric
+        x = torch.randn(R, H, device='cuda')
+        h = torch.randn(R, H, device='cuda') * 0.5
+        c = torch.randn(R, H, device='cuda')
+        h_ref, c_ref = cell(x, (h, c))
+        xh = torch.cat([x, h], 1).contiguous()
+        c2 = c.clone()
+        wp = ops.lstm_pack_weights(cell.weight_ih, cell.weight_hh)
+        ops.lstm_fused_(xh, wp, (cell.bias_ih + cell.bias_hh).contiguous(), c2)
+        torch.testing.assert_close(xh[:, H:], h_ref, atol=3e-6, rtol=0)
+        torch.testing.assert_close(c2, c_ref, atol=3e-6, rtol=0)
+        torch.testing.assert_close(xh[:, :H], x, atol=0, rtol=0)            # the input half is untouched
