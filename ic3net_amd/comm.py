@@ -105,9 +105,10 @@ class CommNetMLP(nn.Module):
     #   encode -> XH[:, :H]      (sparse gather, bias = encoder.bias + C.bias)          1 kernel
     #   comm_masked_mean(XH[:, H:])                                                     1 kernel
     #   XH[:, :H] += comm_sum @ C^T                       (fp32 MFMA GEMM, hipBLASLt)   1 kernel
-    #   lstm_fused: gates = XH @ [W_ih | W_hh]^T + b, cell epilogue in registers:       1 kernel
-    #               c in place, h' -> XH[:, H:]   (hand-written fp32 MFMA, H in {64,128,256};
-    #               otherwise hipBLASLt GEMM + lstm_cell kernel)
+    #   gates = XH @ [W_ih | W_hh]^T + (b_ih + b_hh)      (fp32 MFMA GEMM, hipBLASLt)   1 kernel
+    #   lstm_cell: (gates, c) -> c (in place), h' -> XH[:, H:]                          1 kernel
+    #     (args.fused_lstm: both as ONE hand-written fp32-MFMA kernel, csrc/lstm_fused.hip — at parity with the
+    #      library pair on MI355X, so off by default)
     #   policy_heads: XH[:, H:] -> [log_softmax heads | value]                          1 kernel
     # The returned (h, c) are views of internal buffers, valid until the next forward.
     # ------------------------------------------------------------------------------------------
@@ -135,7 +136,7 @@ class CommNetMLP(nn.Module):
                     w_cat_t=torch.cat([self.f_module.weight_ih, self.f_module.weight_hh], 1).t().contiguous(),
                     b_cat=(self.f_module.bias_ih + self.f_module.bias_hh).contiguous(),
                     wp=(ops.lstm_pack_weights(self.f_module.weight_ih, self.f_module.weight_hh)
-                        if self.hid_size in ops.LSTM_FUSED_SIZES else None),
+                        if self.hid_size in ops.LSTM_FUSED_SIZES and getattr(self.args, 'fused_lstm', False) else None),
                     w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
                     b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
             self._fc_key = key
@@ -175,7 +176,7 @@ class CommNetMLP(nn.Module):
         ops._launch(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg, not self.args.comm_mask_zero,
                     out=buf['comm'])
         xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                          # inp = enc + C(comm_sum)
-        if fc['wp'] is not None and getattr(self.args, 'fused_lstm', True):
+        if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
             ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel
         else:
             torch.addmm(fc['b_cat'], xh, fc['w_cat_t'], out=buf['gates'])              # all four gates (hipBLASLt)

@@ -4,6 +4,13 @@
 // The (R x 4H) gate tensor is never materialised (the library-GEMM + pointwise pair wrote and re-read 4H floats
 // per row).  MFMA-bound: 2·R·2H·4H flops at the 157 TFLOP/s fp32-matrix peak.
 //
+// STATUS (round 1, MI355X, R = 81920, H = 128; tools/microbench_lstm.py, profiles/r01/lstm_fused.txt): 245 us =
+// 88 TFLOP/s for the whole cell, vs 199 us hipBLASLt GEMM (108 TFLOP/s) + 44 us lstm_cell kernel = 243 us.
+// The MFMA loop alone runs at the library's rate; the A-tile staging and the epilogue (~45 us) are not hidden
+// because the two co-resident workgroups of a CU run phase-locked.  Parity with the library pair, not faster, so
+// the policy uses it only when args.fused_lstm is set (default: hipBLASLt + ic3_lstm_cell).  Next step would be a
+// persistent, phase-skewed variant (epilogue of one half-workgroup under the MFMA loop of the other).
+//
 // Decomposition (H = 128: 256 threads):
 //   * one workgroup = 64 rows x ALL 4H gate columns: the workgroup is the only reader and the only writer of its
 //     rows of the [inp | h] buffer XH, so h' can be written back in place (XH[:, H:]) once the A tile is in LDS;
@@ -21,7 +28,18 @@ namespace ic3 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Epilogue nonlinearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each): the accurate
+// ocml expf/tanhf cost ~35k VALU cycles per wave and tile here — as much as the tile's MFMA work — and the two
+// co-resident workgroups run in lock-step, so that time is not hidden.  Absolute error <= ~2e-7 on outputs in
+// [-1, 1] (the parity bar is 1e-5); overflow-safe: exp2(+big) = inf -> 1/(1+inf) = 0.
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 template <int H>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_fused_kernel(float* __restrict__ XH, int ldx,
@@ -35,16 +53,29 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_fused_kernel(f
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
-    // ---- stage the A tile: coalesced 16-byte global reads, scalar LDS writes (row stride breaks 16-B alignment) ----
-    for (int idx = threadIdx.x; idx < BM * (K / 4); idx += NT) {
-        const int row = idx / (K / 4), c4 = idx - row * (K / 4);
-        f32x4 v = { 0.f, 0.f, 0.f, 0.f };
-        if (r0 + row < R) v = *reinterpret_cast<const f32x4*>(XH + (size_t)(r0 + row) * ldx + 4 * c4);
-        float* dst = As + row * LDA + 4 * c4;
-        dst[0] = v.x;
-        dst[1] = v.y;
-        dst[2] = v.z;
-        dst[3] = v.w;
+    // ---- stage the A tile: coalesced 16-byte global reads (all issued before the first LDS write), scalar LDS
+    // writes (the 2H+1 row stride breaks 16-byte alignment).  Tiles are full except possibly the last one. ----
+    const bool full = (r0 + BM <= R);   // workgroup-uniform
+    {
+        constexpr int PER = BM * (K / 4) / NT;   // float4s per thread (= 16)
+        f32x4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int row = idx / (K / 4), c4 = idx - row * (K / 4);
+            if (full || r0 + row < R) v[i] = *reinterpret_cast<const f32x4*>(XH + (size_t)(r0 + row) * ldx + 4 * c4);
+            else v[i] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int row = idx / (K / 4), c4 = idx - row * (K / 4);
+            float* dst = As + row * LDA + 4 * c4;
+            dst[0] = v[i].x;
+            dst[1] = v[i].y;
+            dst[2] = v[i].z;
+            dst[3] = v[i].w;
+        }
     }
     __syncthreads();
 
@@ -60,44 +91,77 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_fused_kernel(f
     const f32x4* wp = Wp + ((size_t)(32 * w + li) * 2 + lh);
     constexpr int KB = K / 8;
     constexpr size_t KB_STRIDE = (size_t)4 * H * 2;  // float4s per kb
-    f32x4 bq[4], bn[4];
+    // Two weight-fragment buffers, refilled a full 32-MFMA block (2048 cycles) before they are needed: L2 latency
+    // stays hidden behind the other buffer's MFMAs (no register copies, loop unrolled by two).
+    f32x4 b0[4], b1[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bq[g] = wp[(size_t)g * H * 2];
+    for (int g = 0; g < 4; ++g) {
+        b0[g] = wp[(size_t)g * H * 2];
+        b1[g] = wp[KB_STRIDE + (size_t)g * H * 2];
+    }
     const float* a0p = As + li * LDA + lh;
     const float* a1p = As + (32 + li) * LDA + lh;
-    for (int kb = 0; kb < KB; ++kb) {
-        if (kb + 1 < KB) {
+    auto block = [&](const f32x4 (&bq)[4], int kb) {
+        float a0[4], a1[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bn[g] = wp[(size_t)(kb + 1) * KB_STRIDE + (size_t)g * H * 2];
+        for (int j = 0; j < 4; ++j) {
+            a0[j] = a0p[8 * kb + 2 * j];
+            a1[j] = a1p[8 * kb + 2 * j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a0 = a0p[8 * kb + 2 * j], a1 = a1p[8 * kb + 2 * j];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[g][j], acc[0][g], 0, 0, 0);
-                acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[g][j], acc[1][g], 0, 0, 0);
+                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[g][j], acc[0][g], 0, 0, 0);
+                acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[g][j], acc[1][g], 0, 0, 0);
             }
         }
+    };
+    static_assert(KB % 2 == 0, "K/8 must be even");
+    // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
+    // their first use, which exposes the full L2 latency every block).
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += 2) {
+        block(b0, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < KB) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = bn[g];
+            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        block(b1, kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 3 < KB) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  All 32 old cell values are
+    // loaded up front (one memory latency, not 32); full tiles take a branch-free path. ----
     const int j = 32 * w + li;
     const float bi = bias[j], bf = bias[H + j], bg = bias[2 * H + j], bo = bias[3 * H + j];
+    float cold[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            cold[rt][reg] = (full || row < R) ? c[(size_t)row * H + j] : 0.0f;
+        }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = r0 + 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            if (row < R) {
-                const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
-                const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
-                float* cp = c + (size_t)row * H + j;
-                const float c1 = sigm(gf) * (*cp) + sigm(gi) * tanhf(gg);
-                *cp = c1;
-                XH[(size_t)row * ldx + H + j] = sigm(go) * tanhf(c1);
+            const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
+            const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
+            const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
+            const float h1 = fast_sigmoid(go) * fast_tanh(c1);
+            if (full || row < R) {
+                c[(size_t)row * H + j] = c1;
+                XH[(size_t)row * ldx + H + j] = h1;
             }
         }
     }

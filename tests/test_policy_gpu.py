@@ -20,7 +20,7 @@ def build(pc):
     return net.cuda().float()
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "mfma_lstm"])
 @pytest.mark.parametrize("name", POLICY_FIXTURES)
 def test_policy_matches_reference(name, fused):
     """fused=True: the no-grad rollout fast path (one [inp|h] buffer, lstm_cell / policy_heads HIP kernels) where it
@@ -28,7 +28,10 @@ def test_policy_matches_reference(name, fused):
     pc = PolicyCase(name)
     fx = pc.fx
     net = build(pc)
-    net.args.fused_policy = fused
+    net.args.fused_policy = bool(fused)
+    net.args.fused_lstm = (fused == "mfma_lstm")     # the hand-written fp32-MFMA LSTM kernel inside the fused path
+    if fused == "mfma_lstm" and not (pc.recurrent and pc.comm_passes == 1 and pc.H in (64, 128, 256)):
+        pytest.skip("fused LSTM kernel needs recurrent, one comm pass, H in {64,128,256}")
     hid = net.init_hidden(pc.B) if pc.recurrent else None
     worst = 0.0
     with torch.no_grad():
