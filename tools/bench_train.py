@@ -1,0 +1,32 @@
+"""Throughput of the update path Trainer.train_batch (rollout with autograd + compute_grad + RMSprop), PP-hard."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    updates = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    tr, a = bench.build_trainer('pp_hard', E, 0, 0, 0)
+    a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
+                      batch_size=E * a.max_steps)
+    tr.train_batch(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 0
+    for u in range(updates):
+        st = tr.train_batch(u)
+        steps += st['num_steps']
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("train_batch PP-hard E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
+          "peak mem %.1f GB" % (E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates, steps // updates,
+                                torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
+if __name__ == '__main__':
+    main()
