@@ -1,87 +1,80 @@
-"""GymWrapper mirror (/root/reference/env_wrappers.py:7-107) for the batched envs: the kernels already
-write the flattened (E, N, obs_dim) float32 layout, so `_flatten_obs` is the identity."""
+"""`GymWrapper` for the batched environments — same public surface as the reference adapter
+(/root/reference/env_wrappers.py:7-107: observation_dim, num_actions, dim_actions, action_space, reset, step,
+reward_terminal, get_stat, display, end_display), different job: the reference flattens per-agent tuples / arrays
+into a (1, N, obs_dim) double tensor on every call (`_flatten_obs`, :88-100); here the kernels already write the
+(E, N, obs_dim) float32 layout, so the wrapper only derives the three sizes once and forwards calls.
+"""
 from inspect import signature
 
 import numpy as np
 import torch
 
 
+def _space_sizes(observation_space, action_space):
+    """(obs_dim, num_actions, dim_actions) with the reference's rules:
+      obs_dim   Box -> prod(shape); Tuple -> sum over members of prod(member.shape) if the ACTION space has a
+                `shape` attribute, else 1 per member (sic, env_wrappers.py:21-29, quirk Q17 — harmless because
+                every space class carries `shape`, and prod(()) == 1 for Discrete members);
+      actions   MultiDiscrete -> (nvec[0], len(nvec)); Discrete -> (n, 1)   (env_wrappers.py:33-50)."""
+    members = getattr(observation_space, 'spaces', None)
+    if members is None:
+        obs_dim = int(np.prod(observation_space.shape))
+    else:
+        counted = hasattr(action_space, 'shape')
+        obs_dim = sum(int(np.prod(m.shape)) if counted else 1 for m in members)
+    if hasattr(action_space, 'nvec'):
+        return obs_dim, int(action_space.nvec[0]), action_space.shape[0]
+    if hasattr(action_space, 'n'):
+        return obs_dim, action_space.n, 1
+    return obs_dim, None, None
+
+
 class GymWrapper(object):
     def __init__(self, env):
         self.env = env
+        self._takes_epoch = 'epoch' in signature(env.reset).parameters      # env_wrappers.py:57-61
+        self._obs_dim, self._num_actions, self._dim_actions = _space_sizes(env.observation_space, env.action_space)
 
-    @property
-    def observation_dim(self):                 # env_wrappers.py:15-31 (incl. quirk Q17)
-        if hasattr(self.env.observation_space, 'spaces'):
-            total_obs_dim = 0
-            for space in self.env.observation_space.spaces:
-                if hasattr(self.env.action_space, 'shape'):
-                    total_obs_dim += int(np.prod(space.shape))
-                else:
-                    total_obs_dim += 1
-            return total_obs_dim
-        return int(np.prod(self.env.observation_space.shape))
+    observation_dim = property(lambda self: self._obs_dim)
+    num_actions = property(lambda self: self._num_actions)
+    dim_actions = property(lambda self: self._dim_actions)
+    action_space = property(lambda self: self.env.action_space)
+    nenvs = property(lambda self: self.env.nenvs)
 
-    @property
-    def num_actions(self):                     # env_wrappers.py:33-40
-        if hasattr(self.env.action_space, 'nvec'):
-            return int(self.env.action_space.nvec[0])
-        elif hasattr(self.env.action_space, 'n'):
-            return self.env.action_space.n
-
-    @property
-    def dim_actions(self):                     # env_wrappers.py:42-50
-        if hasattr(self.env.action_space, 'nvec'):
-            return self.env.action_space.shape[0]
-        elif hasattr(self.env.action_space, 'n'):
-            return 1
-
-    @property
-    def action_space(self):
-        return self.env.action_space
-
-    @property
-    def nenvs(self):
-        return self.env.nenvs
-
-    def reset(self, epoch):                    # env_wrappers.py:56-64
-        if 'epoch' in signature(self.env.reset).parameters:
-            obs = self.env.reset(epoch)
-        else:
-            obs = self.env.reset()
+    def reset(self, epoch):
+        obs = self.env.reset(epoch) if self._takes_epoch else self.env.reset()
         return self._flatten_obs(obs)
+
+    def step(self, action, observe=True):
+        """`action` is the list of per-head (E, N) arrays the policy produced; an env with a single action
+        dimension gets head 0 only (the IC3Net talk head is not an env action, env_wrappers.py:76-77)."""
+        env_action = action[0] if self._dim_actions == 1 else action
+        obs, reward, done, info = self.env.step(env_action) if observe else self.env.step(env_action, observe=False)
+        return self._flatten_obs(obs), reward, done, info
+
+    def reward_terminal(self):
+        fn = getattr(self.env, 'reward_terminal', None)
+        return fn() if fn is not None else torch.zeros(1)
+
+    def _flatten_obs(self, obs):
+        return obs.reshape(self.env.nenvs, -1, self._obs_dim)              # already flat: a view, no copy
+
+    def get_stat(self):
+        """env.stat of all E environments, summed (merge_stat sums the same keys over episodes in the reference):
+        PP 'success' (predator_prey_env.py:284-288, absent in competitive mode); TJ 'success' = 1 - has_failed and
+        'add_rate' (traffic_junction_env.py:249-250).  'steps_taken' is dropped like env_wrappers.py:104."""
+        s = self.env.device_stats()
+        stat = {k: v for k, v in self.env.stat.items() if k != 'steps_taken'}
+        if self.env.dims.kind == 1:
+            if self.env.mode != 'competitive':
+                stat['success'] = s.success_sum
+        else:
+            stat['success'] = s.success_sum
+            stat['add_rate'] = s.add_rate * self.env.nenvs
+        return stat
 
     def display(self):
         raise NotImplementedError("rendering is outside the hot-path scope (SURVEY 8(f) f4)")
 
     def end_display(self):
         pass
-
-    def step(self, action, observe=True):      # env_wrappers.py:73-80
-        if self.dim_actions == 1:
-            action = action[0]
-        obs, r, done, info = self.env.step(action, observe) if not observe else self.env.step(action)
-        return (self._flatten_obs(obs), r, done, info)
-
-    def reward_terminal(self):                 # env_wrappers.py:82-86
-        if hasattr(self.env, 'reward_terminal'):
-            return self.env.reward_terminal()
-        return torch.zeros(1)
-
-    def _flatten_obs(self, obs):               # env_wrappers.py:88-100: already (E, N, obs_dim) float32
-        return obs.reshape(self.env.nenvs, -1, self.observation_dim)
-
-    def get_stat(self):                        # env_wrappers.py:102-107
-        """env.stat summed over the E environments of the handle: PP 'success' (PP:284-288), TJ 'success',
-        'add_rate' (TJ:249-250) — the reference sums these per episode in merge_stat."""
-        s = self.env.device_stats()
-        stat = dict(self.env.stat)
-        kind = self.env.dims.kind
-        if kind == 1:
-            if self.env.mode != 'competitive':
-                stat['success'] = s.success_sum
-        else:
-            stat['success'] = s.success_sum
-            stat['add_rate'] = s.add_rate * self.env.nenvs
-        stat.pop('steps_taken', None)
-        return stat
