@@ -224,7 +224,15 @@ def main():
 
     raw_env.obs_timer = []                    # event-time the obs launch from the start (graphs are captured in this mode)
     if o.graph:                               # untimed: one eager episode (warm-up) + one capture episode
-        run(2 * T, 0)
+        try:
+            run(2 * T, 0)
+        except Exception as exc:              # capture trouble on this box: measure the eager path instead of dying
+            sys.stderr.write("bench.py: hipGraph capture failed (%r); falling back to eager launches\n" % (exc,))
+            torch.cuda.synchronize()
+            trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
+            a.hip_graph, a.dense_obs, o.graph = False, not o.no_dense_obs, 0
+            raw_env = trainer.env.env
+            raw_env.obs_timer = []
     t_in_ep = run(o.warmup, 0)
     torch.cuda.synchronize()
     if world > 1:
@@ -267,7 +275,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
-                       "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world},
+                       "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world,
+                       "launch": "hipGraph replay" if o.graph else "eager", "dense_obs": not o.no_dense_obs},
             "roofline": {"kernel": "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
