@@ -295,3 +295,28 @@ def test_tj_full_size_properties():
         o3, _, _, _ = env3.step(z)
         o2, _, _, _ = env2.step(z[:1024])
     assert torch.equal(o3[4096:5120], o2)
+
+
+def test_pp_scaled_full_size_spotcheck():
+    """BASELINE config 5 per-GPU size: 32 agents, dim 40, vision 2, E = 8192 -> a 42 GB observation tensor.
+    Envs at the start, middle and far end of the tensor (64-bit offsets) are compared with the oracle."""
+    import oracle
+    E, N = 8192, 32
+    env = make_pp(N, 40, 2, "mixed", E, seed=5)
+    assert env.obs_dim == 40100
+    obs = env.reset()
+    assert obs.numel() == E * N * 40100
+    picks = (0, 4097, 8191)
+    orcs = {e: oracle.PPOracle(N, 40, 2, "mixed", seed=5, env_gid=e) for e in picks}
+    for e, o in orcs.items():
+        assert np.array_equal(obs[e].cpu().numpy(), o.reset()), e
+    act = torch.randint(0, 5, (E, N), device="cuda", dtype=torch.int32)
+    obs, r, d, _ = env.step(act)
+    for e, o in orcs.items():
+        oo, orew, od = o.step(act[e].cpu().numpy())
+        assert np.array_equal(obs[e].cpu().numpy(), oo) and np.array_equal(r[e].cpu().numpy(), orew.astype(np.float32)), e
+    # one location bit per window cell everywhere (checked on a slice to bound the temporary)
+    o4 = obs[8000:8192].view(192, N, 25, 1604)
+    assert (o4[..., :1602].sum(-1) == 1).all()
+    del obs, env
+    torch.cuda.empty_cache()
