@@ -76,7 +76,7 @@ class Trainer(object):
         self._state = state
         self.clock.episode += 1
         self._info = dict()
-        self._prev_hid = None
+        self._prev_hid = torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)  # trainer.py:41
         self._nsteps = 0
         # Episode buffers [T, ...]: the env / sampling kernels write step t's outputs straight into slice t, so the
         # hot loop launches no bookkeeping kernels; masks and statistics are derived once in end_episode().
@@ -151,8 +151,9 @@ class Trainer(object):
                 if args.rnn_type == 'LSTM' and t == 0:
                     self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
                 action_out, value, prev_hid = self.policy_net([state, self._prev_hid], info)
-                if (t + 1) % args.detach_gap == 0:
-                    prev_hid = (prev_hid[0].detach(), prev_hid[1].detach())
+                if (t + 1) % args.detach_gap == 0:                 # trainer.py:56-60
+                    prev_hid = (prev_hid[0].detach(), prev_hid[1].detach()) if args.rnn_type == 'LSTM' \
+                        else prev_hid.detach()
                 self._prev_hid = prev_hid
             else:
                 action_out, value = self.policy_net(state, info)

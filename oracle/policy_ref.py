@@ -83,3 +83,25 @@ def forward(p, x, hc=None, alive=None, comm_action=None, recurrent=True, comm_pa
     hv = h.reshape(B, N, H)
     logp = [log_softmax(_linear(p, 'heads.%d' % k, hv)) for k in range(nheads)]   # comm.py:239
     return logp, value, ((h, c) if recurrent else h)
+
+
+def mlp_forward(p, x, nheads=1):
+    """models.py:23-34 (MLP): tanh(affine1) -> tanh(affine2(x) + x) -> heads, value."""
+    x1 = np.tanh(_linear(p, 'affine1', x))
+    h = np.tanh(_linear(p, 'affine2', x1) + x1)
+    return [log_softmax(_linear(p, 'heads.%d' % k, h)) for k in range(nheads)], _linear(p, 'value_head', h)
+
+
+def rnn_forward(p, x, prev_hid, lstm=False, nheads=1):
+    """models.py:68-92 (RNN).  lstm: prev_hid = (h, c) each (B*N,H); else prev_hid (B,N,H)."""
+    B, N, _ = x.shape
+    enc = _linear(p, 'affine1', x)
+    H = enc.shape[-1]
+    if lstm:
+        q = {('f_module.' + k[len('lstm_unit.'):]): v for k, v in p.items() if k.startswith('lstm_unit.')}
+        h, c = lstm_cell(q, enc.reshape(B * N, H), prev_hid[0], prev_hid[1])
+        ret, nh = (h, c), h.reshape(B, N, H)
+    else:
+        nh = np.tanh(_linear(p, 'affine2', prev_hid) + enc)
+        ret = nh
+    return [log_softmax(_linear(p, 'heads.%d' % k, nh)) for k in range(nheads)], _linear(p, 'value_head', nh), ret

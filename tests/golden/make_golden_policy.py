@@ -105,7 +105,47 @@ def policy_case(name, N, obs_dim, H, steps, seed, B=1, closed_form=False, **flag
     print(name, 'params', len(sd), 'steps', steps)
 
 
+def baseline_case(name, kind, N, obs_dim, H, steps, seed, B=2, rnn_type='MLP'):
+    """IC / IRIC baselines: the reference's models.MLP / models.RNN (models.py:8-97), free-running."""
+    ref = rh.load_reference()
+    torch.set_default_dtype(torch.float64)
+    a = rh.make_args('predator_prey', nagents=N, hid_size=H, recurrent=(kind == 'rnn'), rnn_type=rnn_type)
+    a.naction_heads, a.continuous, a.num_actions, a.dim_actions = [5], False, [5], 1
+    torch.manual_seed(seed)
+    net = (ref['models'].RNN if kind == 'rnn' else ref['models'].MLP)(a, obs_dim)
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    rs = np.random.RandomState(seed)
+    hid = None
+    if kind == 'rnn':
+        hid = net.init_hidden(B) if rnn_type == 'LSTM' else torch.zeros(B, N, H)
+    xs, logps, vals, hs, cs = [], [], [], [], []
+    for t in range(steps):
+        x = (rs.rand(B, N, obs_dim) < 0.3).astype(np.float64)
+        with torch.no_grad():
+            if kind == 'rnn':
+                logp, v, hid = net([torch.from_numpy(x), hid])
+            else:
+                logp, v = net(torch.from_numpy(x))
+        xs.append(x)
+        logps.append(logp[0].numpy())
+        vals.append(v.numpy())
+        if kind == 'rnn':
+            hs.append((hid[0] if rnn_type == 'LSTM' else hid).numpy())
+            if rnn_type == 'LSTM':
+                cs.append(hid[1].numpy())
+    out = dict(cfg=np.array([N, obs_dim, H, steps, B, int(kind == 'rnn'), int(rnn_type == 'LSTM')], np.int32),
+               x=np.array(xs), logp0=np.array(logps), value=np.array(vals), h=np.array(hs), c=np.array(cs),
+               param_names=np.array(sorted(sd)), param_shapes=np.array([str(tuple(sd[k].shape)) for k in sorted(sd)]))
+    for k, v in sd.items():
+        out['w:' + k] = v
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, sorted(sd))
+
+
 def main():
+    baseline_case('baseline_mlp', 'mlp', 4, 29, 16, 4, 11)
+    baseline_case('baseline_rnn', 'rnn', 4, 29, 16, 8, 12)
+    baseline_case('baseline_rnn_lstm', 'rnn', 4, 29, 16, 8, 13, rnn_type='LSTM')
     policy_case('policy_ic3net_small', 4, 29, 16, 10, 1, ic3net=True, recurrent=True)
     policy_case('policy_ic3net_b3', 5, 29, 16, 6, 2, B=3, ic3net=True, recurrent=True)
     policy_case('policy_commnet_rec', 4, 29, 16, 10, 3, commnet=True, recurrent=True)

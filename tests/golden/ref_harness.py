@@ -110,7 +110,8 @@ def load_reference():
     import action_utils
     import trainer
     import utils
-    _state.update(pp=pp, tj=tj, th=th, comm=comm, env_wrappers=env_wrappers, data=data,
+    import models
+    _state.update(models=models, pp=pp, tj=tj, th=th, comm=comm, env_wrappers=env_wrappers, data=data,
                   action_utils=action_utils, trainer=trainer, utils=utils, rnd=rnd)
     return _state
 

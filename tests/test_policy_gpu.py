@@ -245,3 +245,30 @@ def test_lstm_fused_mfma_kernel_vs_torch(R, H):
         torch.testing.assert_close(xh[:, H:], h_ref, atol=3e-6, rtol=0)
         torch.testing.assert_close(c2, c_ref, atol=3e-6, rtol=0)
         torch.testing.assert_close(xh[:, :H], x, atol=0, rtol=0)            # the input half is untouched
+
+
+@pytest.mark.parametrize("name", ["baseline_mlp", "baseline_rnn", "baseline_rnn_lstm"])
+def test_baseline_models_match_reference(name):
+    import argparse
+    from golden_util import load
+    from ic3net_amd import models
+    fx = load(name)
+    N, obs_dim, H, steps, B, rec, lstm = [int(v) for v in fx["cfg"]]
+    a = argparse.Namespace(nagents=N, hid_size=H, continuous=False, naction_heads=[5], rnn_type='LSTM' if lstm else 'MLP')
+    net = (models.RNN if rec else models.MLP)(a, obs_dim)
+    net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
+    net = net.cuda()
+    hid = None
+    if rec:
+        hid = net.init_hidden(B) if lstm else torch.zeros(B, N, H, device='cuda')
+    with torch.no_grad():
+        for t in range(steps):
+            x = torch.from_numpy(fx["x"][t]).float().cuda()
+            if rec:
+                logp, v, hid = net([x, hid])
+                h = hid[0] if lstm else hid
+                assert np.abs(h.cpu().numpy() - fx["h"][t]).max() < TOL
+            else:
+                logp, v = net(x)
+            assert np.abs(logp[0].cpu().numpy() - fx["logp0"][t]).max() < TOL
+            assert np.abs(v.cpu().numpy() - fx["value"][t]).max() < TOL

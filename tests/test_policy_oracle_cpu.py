@@ -51,3 +51,39 @@ def test_sampling_oracle_known_answers():
     for u, want in ((0.0, 0), (0.05, 0), (0.15, 1), (0.299, 1), (0.31, 2), (0.59, 2), (0.61, 3), (0.9999, 3)):
         assert oracle.sample_one(lp, int(u * 2 ** 24)) == want
     assert oracle.sample_one(np.log(np.array([1.0], np.float32)), 12345) == 0
+
+
+BASELINES = ["baseline_mlp", "baseline_rnn", "baseline_rnn_lstm"]
+
+
+def _baseline(name):
+    from golden_util import load
+    fx = load(name)
+    N, obs_dim, H, steps, B, rec, lstm = [int(v) for v in fx["cfg"]]
+    params = {k[2:]: fx[k] for k in fx.files if k.startswith("w:")}
+    return fx, params, (N, obs_dim, H, steps, B, bool(rec), bool(lstm))
+
+
+@pytest.mark.parametrize("name", BASELINES)
+def test_baseline_oracle_and_state_dict(name):
+    """IC/IRIC baselines (models.py:8-97): numpy oracle vs the reference's outputs; the product modules expose the
+    reference's parameter names/shapes (checked on CPU; their GPU numerics in tests/test_policy_gpu.py)."""
+    import argparse
+    from ic3net_amd import models
+    fx, params, (N, obs_dim, H, steps, B, rec, lstm) = _baseline(name)
+    hid = None
+    if rec:
+        hid = (np.zeros((B * N, H)), np.zeros((B * N, H))) if lstm else np.zeros((B, N, H))
+    for t in range(steps):
+        if rec:
+            logp, v, hid = policy_ref.rnn_forward(params, fx["x"][t], hid, lstm=lstm)
+            np.testing.assert_allclose(hid[0] if lstm else hid, fx["h"][t], atol=1e-12)
+        else:
+            logp, v = policy_ref.mlp_forward(params, fx["x"][t])
+        np.testing.assert_allclose(logp[0], fx["logp0"][t], atol=1e-12)
+        np.testing.assert_allclose(v, fx["value"][t], atol=1e-12)
+    a = argparse.Namespace(nagents=N, hid_size=H, continuous=False, naction_heads=[5], rnn_type='LSTM' if lstm else 'MLP')
+    net = (models.RNN if rec else models.MLP)(a, obs_dim)
+    sd = net.state_dict()
+    assert sorted(sd) == [str(n) for n in fx["param_names"]]
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == [str(s) for s in fx["param_shapes"]]

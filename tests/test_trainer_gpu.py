@@ -267,3 +267,27 @@ def test_train_batch_updates_parameters():
     assert not any(k.startswith('hidd_encoder') for k in changed)           # no grad -> untouched (quirk Q18)
     st2 = tr.train_batch(1)                                                  # a second update runs (graph freed)
     assert np.isfinite(st2['action_loss'])
+
+
+@pytest.mark.parametrize("kind,rnn_type", [("mlp", "MLP"), ("rnn", "MLP"), ("rnn", "LSTM")])
+def test_baseline_policies_through_trainer(kind, rnn_type):
+    """IC / IRIC baselines (no communication) run through the same batched Trainer, incl. one update."""
+    from ic3net_amd import data, models, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    a = build_args('predator_prey', dict(nagents=3, dim=5, vision=1, hid_size=32, recurrent=(kind == "rnn"),
+                                         rnn_type=rnn_type, detach_gap=10, mean_ratio=0.0), 3, 20, 32, 7)
+    a.env_id_offset = 0
+    env = data.init('predator_prey', a, False)
+    a.num_actions, a.dim_actions, a.num_inputs = [env.num_actions], env.dim_actions, env.observation_dim
+    a.continuous = False
+    parse_action_args(a)
+    torch.manual_seed(0)
+    net = (models.RNN if kind == "rnn" else models.MLP)(a, a.num_inputs).cuda()
+    tr = trmod.Trainer(a, net, env)
+    episode, stat = tr.get_episode(0)
+    assert len(episode) == 20 and episode[0].action.shape == (1, 32, 3) and episode[0].value.numel() == 96
+    assert 'comm_action' not in stat and stat['num_steps'] <= 32 * 20
+    before = net.affine1.weight.detach().clone()
+    a.batch_size = 32 * 20
+    st = tr.train_batch(0)
+    assert np.isfinite(st['action_loss']) and not torch.equal(before, net.affine1.weight)
