@@ -202,8 +202,6 @@ def main():
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend='nccl')   # RCCL; used only for the timing barrier / max-reduce
 
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
     a.hip_graph = bool(o.graph)
@@ -236,6 +234,9 @@ def main():
     t_in_ep = run(o.warmup, 0)
     torch.cuda.synchronize()
     if world > 1:
+        # RCCL is used only for the timing barrier / max-reduce (no collective on the rollout path); it is brought
+        # up after the untimed warm-up so that graph capture never runs next to a communicator's helper threads.
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
         dist.barrier()
     torch.cuda.synchronize()
     raw_env.obs_timer = []

@@ -121,7 +121,8 @@ class Trainer(object):
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(graph, pool=self._graph_pool):
+            # thread_local: calls made by other threads (e.g. an RCCL watchdog) must not invalidate the capture
+            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                 self._step_body(t, observe=in_graph_obs)
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
