@@ -236,8 +236,17 @@ def main():
     if world > 1:
         # RCCL is used only for the timing barrier / max-reduce (no collective on the rollout path); it is brought
         # up after the untimed warm-up so that graph capture never runs next to a communicator's helper threads.
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-        dist.barrier()
+        try:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+            dist.barrier()
+            backend = 'nccl'
+        except Exception as exc:                   # timing barrier only: gloo is an acceptable stand-in
+            sys.stderr.write("bench.py: RCCL bring-up failed (%r); using gloo for the timing barrier\n" % (exc,))
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group(backend='gloo')
+            dist.barrier()
+            backend = 'gloo'
     torch.cuda.synchronize()
     raw_env.obs_timer = []
     t0 = time.perf_counter()
@@ -249,7 +258,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
