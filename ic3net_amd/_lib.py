@@ -16,7 +16,8 @@ TJ_DIFFICULTY = {"easy": 0, "medium": 1, "hard": 2}
 
 class PPCfg(C.Structure):
     _fields_ = [("E", C.c_int32), ("N", C.c_int32), ("nprey", C.c_int32), ("dim", C.c_int32), ("vision", C.c_int32),
-                ("mode", C.c_int32), ("stay", C.c_int32), ("moving_prey", C.c_int32), ("seed", C.c_uint32),
+                ("mode", C.c_int32), ("stay", C.c_int32), ("moving_prey", C.c_int32), ("enemy_comm", C.c_int32),
+                ("seed", C.c_uint32),
                 ("env_id_offset", C.c_uint32)]
 
 

@@ -111,8 +111,8 @@ int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out)
 {
     if (!cfg || !out) return fail(-22, "ic3_pp_create: null argument");
     if (cfg->moving_prey) return fail(-38, "moving_prey: NotImplementedError (predator_prey_env.py:84-85)");
-    if (cfg->E <= 0 || cfg->N <= 0 || cfg->N > 64 || cfg->dim <= 0 || cfg->vision < 0)
-        return fail(-22, "ic3_pp_create: need E>0, 0<N<=64, dim>0, vision>=0");
+    if (cfg->E <= 0 || cfg->N <= 0 || cfg->N + (cfg->enemy_comm ? cfg->nprey : 0) > 64 || cfg->dim <= 0 || cfg->vision < 0)
+        return fail(-22, "ic3_pp_create: need E>0, 0<N (+nprey with enemy_comm)<=64, dim>0, vision>=0");
     if (cfg->nprey != 1) return fail(-22, "ic3_pp_create: only nenemies=1 works in the reference (predator_prey_env.py:258)");
     if (cfg->N + cfg->nprey > cfg->dim * cfg->dim) return fail(-22, "ic3_pp_create: more entities than cells");
     if (cfg->mode < 0 || cfg->mode > 2)
@@ -124,7 +124,7 @@ int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out)
     ic3_dims& d = env->dims;
     d.kind = IC3_ENV_PP;
     d.E = cfg->E;
-    d.N = cfg->N;
+    d.N = cfg->N + (cfg->enemy_comm ? cfg->nprey : 0);   // rows seen by the policy (main.py:125-130)
     d.window = 2 * cfg->vision + 1;
     d.vocab = cfg->dim * cfg->dim + 4;               // predator_prey_env.py:103
     d.obs_dim = d.window * d.window * d.vocab;       // :107 (only the product is used, env_wrappers.py:31)

@@ -64,17 +64,26 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
                                                       const int32_t* __restrict__ actions, float* __restrict__ reward,
                                                       int32_t* __restrict__ done, int32_t* __restrict__ alive_out,
                                                       int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E,
-                                                      int N, int nprey, int dim, int v, int mode, int naction, int G)
+                                                      int N, int nprey, int dim, int v, int mode, int naction, int G,
+                                                      int rows)
 {
+    // rows = N, or N + nprey with enemy_comm: the prey then own an action slot (ignored: fixed prey, PP:214-219), a
+    // reward (PP:276-281) and an observation row; lanes n >= N only take part in that.
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / G, n = tid - e * G;
-    const bool valid = (e < E) && (n < N);
+    const bool in_env = (e < E) && (n < rows);
+    const bool valid = in_env && (n < N);
     const int total = N + nprey;
     const int lane = threadIdx.x & 63;
     const int gbase = lane & ~(G - 1);
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
 
     int r = 0, c = 0, pr = -1, pc = -1, rch = 0, act = 4, was_over = 1;
+    if (in_env) {
+        act = actions[(size_t)e * rows + n];
+        was_over = over[e];
+        if (act > naction) atomicOr(err, 1);  // PP:137 (<=, quirk Q2; checked on every entry of `action`)
+    }
     if (valid) {
         const size_t li = (size_t)e * total + n;
         r = loc_r[li];
@@ -82,9 +91,6 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
         pr = loc_r[(size_t)e * total + N];  // prey 0 only: (N,2)==(1,2) broadcast, quirk Q7 PP:258
         pc = loc_c[(size_t)e * total + N];
         rch = reached[(size_t)e * N + n];
-        act = actions[(size_t)e * N + n];
-        was_over = over[e];
-        if (act > naction) atomicOr(err, 1);  // PP:137 (<=, quirk Q2)
     }
     const bool live = valid && !was_over;
     if (live && rch != 1 && act != 5) {  // frozen PP:221-222; (sic) STAY guard PP:224-226
@@ -110,7 +116,13 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
     const int n_on = __popcll(__ballot(on) & gmask);
     const int rch_new = (rch == 1 || on) ? 1 : 0;  // PP:271
     const int n_reached = __popcll(__ballot(live && rch_new) & gmask);
-    if (!valid) return;
+    if (!in_env) return;
+    if (!valid) {   // prey row (enemy_comm): reward 0.05 while no predator is on it, else 0 (PP:276-281)
+        reward[(size_t)e * rows + n] = was_over ? 0.0f : (n_on == 0 ? (float)0.05 : 0.0f);
+        if (alive_out) alive_out[(size_t)e * rows + n] = 1;
+        if (comp_out) comp_out[(size_t)e * rows + n] = 0;
+        return;
+    }
     float rew = 0.0f;
     if (live) {
         double rd = -0.05;  // TIMESTEP_PENALTY PP:256
@@ -125,9 +137,9 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
         loc_c[li] = c;
         reached[(size_t)e * N + n] = rch_new;
     }
-    reward[(size_t)e * N + n] = rew;
-    if (alive_out) alive_out[(size_t)e * N + n] = 1;
-    if (comp_out) comp_out[(size_t)e * N + n] = 0;
+    reward[(size_t)e * rows + n] = rew;
+    if (alive_out) alive_out[(size_t)e * rows + n] = 1;
+    if (comp_out) comp_out[(size_t)e * rows + n] = 0;
     if (n == 0) {
         int ov = was_over;
         if (live) {
@@ -156,9 +168,11 @@ __global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_
 // for agent a's window cell (dy, dx).  Shared by the obs-assembly and the sparse-encoder kernels.
 __device__ __forceinline__ const int2* pp_build_tab(int32_t* smem, const int32_t* __restrict__ loc_r,
                                                     const int32_t* __restrict__ loc_c, int e, int N, int nprey,
-                                                    int dim, int v)
+                                                    int dim, int v, int rows)
 {
-    const int total = N + nprey, W = 2 * v + 1, nseg = N * W * W;
+    // rows = observed agents: the N predators, plus the prey with enemy_comm (PP:203-207); entity a's window is
+    // centred on loc[a] either way (prey positions follow the predators in the loc arrays)
+    const int total = N + nprey, W = 2 * v + 1, nseg = rows * W * W;
     const int OUTSIDE = dim * dim + 1;
     int32_t* sr = smem;              // [total]
     int32_t* sc = sr + total;        // [total]
@@ -185,13 +199,13 @@ __device__ __forceinline__ const int2* pp_build_tab(int32_t* smem, const int32_t
 template <bool VEC4, bool NT, bool ALIGN>
 __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
                                                      const int32_t* __restrict__ loc_c, float* __restrict__ obs,
-                                                     int N, int nprey, int dim, int v)
+                                                     int N, int nprey, int dim, int v, int rows)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
-    const int W = 2 * v + 1, nseg = N * W * W;
+    const int W = 2 * v + 1, nseg = rows * W * W;
     const int vocab = dim * dim + 4;
-    const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v);
+    const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v, rows);
 
     if constexpr (VEC4) {
         // vocab % 4 == 0: a 16-byte store never straddles a window cell; the three special channels
@@ -262,14 +276,14 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ loc_c,
                                                         const f32x4* __restrict__ Wt, const f32x4* __restrict__ bias,
                                                         f32x4* __restrict__ out, int ldo4, int N, int nprey, int dim,
-                                                        int v, int H4)
+                                                        int v, int H4, int rows)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
     const int WW = (2 * v + 1) * (2 * v + 1);
     const int vocab = dim * dim + 4;
-    const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v);
-    for (int idx = threadIdx.x; idx < N * H4; idx += blockDim.x) {
+    const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v, rows);
+    for (int idx = threadIdx.x; idx < rows * H4; idx += blockDim.x) {
         const int a = idx / H4, c4 = idx - a * H4;
         f32x4 acc = bias[c4];
         for (int cell = 0; cell < WW; ++cell) {
@@ -280,18 +294,19 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
             if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
             if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
         }
-        out[((size_t)e * N + a) * ldo4 + c4] = acc;
+        out[((size_t)e * rows + a) * ldo4 + c4] = acc;
     }
 }
 
 int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
-    const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
+    const int rows = env->dims.N;
+    const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = rows * W * W;
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
                        reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
-                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4);
+                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows);
     IC3_HIP(hipGetLastError());
     return 0;
 }
@@ -311,12 +326,13 @@ int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, 
             hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
-    const int G = group_lanes(c.N);
+    const int rows = env->dims.N;
+    const int G = group_lanes(rows);
     const long long threads = (long long)c.E * G;
     const int blocks = (int)((threads + 255) / 256);
     hipLaunchKernelGGL(pp_step_kernel, dim3(blocks), dim3(256), 0, s, env->f("loc_r"), env->f("loc_c"),
                        env->f("reached"), env->f("over"), env->f("success"), env->f("t"), actions, reward, done, alive,
-                       is_completed, env->d_err, c.E, c.N, c.nprey, c.dim, c.vision, c.mode, c.stay ? 5 : 4, G);
+                       is_completed, env->d_err, c.E, c.N, c.nprey, c.dim, c.vision, c.mode, c.stay ? 5 : 4, G, rows);
     IC3_HIP(hipGetLastError());
     return 0;
 }
@@ -324,17 +340,18 @@ int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, 
 int pp_observe(ic3_env* env, float* obs, hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
-    const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = c.N * W * W;
+    const int rows = env->dims.N;
+    const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = rows * W * W;
     const int vocab = c.dim * c.dim + 4;
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     // Geometry/stores chosen by measurement on MI355X (profiles/r01/obs_variants.txt, obs_geometry.txt): one WG per
     // env with LDS-staged descriptors, plain (not nontemporal) stores, 1 KiB-aligned wave stores.
     if ((vocab & 3) == 0) {
         hipLaunchKernelGGL((pp_obs_kernel<true, false, true>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
-                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision);
+                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
     } else {   // vocab % 4 != 0 (odd dim): dword stores
         hipLaunchKernelGGL((pp_obs_kernel<false, false, false>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
-                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision);
+                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
     }
     IC3_HIP(hipGetLastError());
     return 0;

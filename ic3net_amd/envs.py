@@ -198,8 +198,6 @@ class PredatorPreyEnv(_BatchedEnv):
         self.stay = not args.no_stay
         if args.moving_prey:
             raise NotImplementedError
-        if self.enemy_comm:
-            raise NotImplementedError("enemy_comm is outside the hot-path scope (SURVEY 8(f) f3)")
         if self.mode not in _lib.PP_MODES:
             raise RuntimeError("Incorrect mode, Available modes: [cooperative|competitive|mixed]")   # PP:269
         self.naction = 5 if self.stay else 4
@@ -213,7 +211,7 @@ class PredatorPreyEnv(_BatchedEnv):
                                                                    2 * self.vision + 1), dtype=int)
         device = int(getattr(args, 'device', 0) or 0)
         cfg = _lib.PPCfg(int(getattr(args, 'nenvs', 1)), self.npredator, self.nprey, self.dim, self.vision,
-                         _lib.PP_MODES[self.mode], int(self.stay), int(bool(args.moving_prey)),
+                         _lib.PP_MODES[self.mode], int(self.stay), int(bool(args.moving_prey)), int(bool(self.enemy_comm)),
                          int(getattr(args, 'seed', 0)) & 0xffffffff, int(getattr(args, 'env_id_offset', 0)))
         h = C.c_void_p()
         check(_lib.lib().ic3_pp_create(C.byref(cfg), device, C.byref(h)))

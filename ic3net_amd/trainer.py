@@ -208,10 +208,17 @@ class Trainer(object):
         num_steps = float(live.sum().item())
         stat['num_steps'] = num_steps                              # trainer.py:109-110
         stat['steps_taken'] = num_steps
-        stat['reward'] = reward.double().sum((0, 1)).cpu().numpy()[:args.nfriendly]            # trainer.py:86
-        if args.hard_attn and args.commnet:                        # trainer.py:73
+        enemy = bool(getattr(args, 'enemy_comm', False))
+        rsum = reward.double().sum((0, 1)).cpu().numpy()
+        stat['reward'] = rsum[:args.nfriendly]                     # trainer.py:86
+        if enemy:
+            stat['enemy_reward'] = rsum[args.nfriendly:]           # trainer.py:87-88
+        if args.hard_attn and args.commnet:                        # trainer.py:73-75
             gate = torch.ones_like(reward) if args.comm_action_one else action[:, -1].to(torch.float32)
-            stat['comm_action'] = (gate * live.unsqueeze(2)).double().sum((0, 1)).cpu().numpy()[:args.nfriendly]
+            csum = (gate * live.unsqueeze(2)).double().sum((0, 1)).cpu().numpy()
+            stat['comm_action'] = csum[:args.nfriendly]
+            if enemy:
+                stat['enemy_comm'] = csum[args.nfriendly:]
         episode = []
         for t in range(n):
             cur_state, action_out, value, next_state = self._step_out[t]
@@ -221,7 +228,10 @@ class Trainer(object):
         if hasattr(self.env, 'reward_terminal'):                   # trainer.py:112-121 (zeros for PP/TJ)
             rt = self.env.reward_terminal()
             episode[-1] = episode[-1]._replace(reward=episode[-1].reward + rt)
-            stat['reward'] = stat['reward'] + rt.double().sum(0).cpu().numpy()[:args.nfriendly]
+            rts = rt.double().sum(0).cpu().numpy()
+            stat['reward'] = stat['reward'] + rts[:args.nfriendly]
+            if enemy:
+                stat['enemy_reward'] = stat['enemy_reward'] + rts[args.nfriendly:]
         if hasattr(self.env, 'get_stat'):                          # trainer.py:124-125
             merge_stat(self.env.get_stat(), stat)
         self._live = live[-1] * not_done[-1]

@@ -49,6 +49,8 @@ typedef struct {
     int32_t mode;          /* IC3_PP_*                        :75,261-269 */
     int32_t stay;          /* !args.no_stay                   :82,90-93 */
     int32_t moving_prey;   /* must be 0: -ENOSYS otherwise (NotImplementedError :84-85) */
+    int32_t enemy_comm;    /* args.enemy_comm :75: prey rows are appended to obs / reward (:203-207,255,276-281) and the
+                              policy sees N + nprey agents (main.py:125-130); dims.N reports that row count */
     uint32_t seed;         /* Philox key[0] */
     uint32_t env_id_offset;/* global id of env 0 of this shard (multi-GPU sharding), Philox key[1] = offset+e */
 } ic3_pp_cfg;

@@ -32,7 +32,7 @@ def lib():
 
 
 class PPCfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ('N', 'nprey', 'dim', 'vision', 'mode', 'naction')]
+    _fields_ = [(n, C.c_int32) for n in ('N', 'nprey', 'dim', 'vision', 'mode', 'naction', 'enemy_comm')]
 
 
 class TJCfg(C.Structure):
@@ -50,9 +50,10 @@ MODES = {'mixed': 0, 'cooperative': 1, 'competitive': 2}
 class PPOracle(object):
     """One Predator-Prey environment (predator_prey_env.py), state as int32 numpy arrays."""
 
-    def __init__(self, N, dim, vision, mode='mixed', nprey=1, stay=True, seed=0, env_gid=0):
-        self.cfg = PPCfg(N, nprey, dim, vision, MODES[mode], 5 if stay else 4)
+    def __init__(self, N, dim, vision, mode='mixed', nprey=1, stay=True, seed=0, env_gid=0, enemy_comm=False):
+        self.cfg = PPCfg(N, nprey, dim, vision, MODES[mode], 5 if stay else 4, int(enemy_comm))
         self.N, self.nprey, self.dim, self.vision = N, nprey, dim, vision
+        self.rows = N + (nprey if enemy_comm else 0)       # agents the policy sees (main.py:125-130)
         self.vocab = dim * dim + 4
         self.obs_dim = (2 * vision + 1) ** 2 * self.vocab
         self.seed, self.env_gid = seed, env_gid
@@ -75,25 +76,24 @@ class PPOracle(object):
         self.over = C.c_int32(int(over))
 
     def obs(self):
-        out = np.empty((self.N, self.obs_dim), np.float32)
+        out = np.empty((self.rows, self.obs_dim), np.float32)
         lib().orc_pp_obs(C.byref(self.cfg), _p(self.loc), _p(out))
         return out
 
     def step(self, action):
-        """-> obs (N,obs_dim) f32, reward (N,) f64, done bool; raises like the reference."""
+        """-> obs (rows,obs_dim) f32, reward (rows,) f64, done bool; raises like the reference.
+        The reference moves, takes obs, then computes the reward (which freezes) — PP:134-144; obs only reads the
+        positions, which the reward pass does not change, so taking it afterwards is equivalent."""
         action = np.ascontiguousarray(np.asarray(action).reshape(-1), np.int32)
         if self.over.value:
             raise RuntimeError("Episode is done")
-        # the reference moves, takes obs, then computes reward (which freezes) — PP:134-144
-        reward = np.empty(self.N, np.float64)
-        # obs must be taken between move and reward: do the move+reward in C on a copy for obs timing
-        loc_before = self.loc.copy()
-        reached_before = self.reached.copy()
+        if len(action) < self.N:
+            raise AssertionError("Action for each agent should be provided.")
+        reward = np.empty(self.rows, np.float64)
         rc = lib().orc_pp_step(C.byref(self.cfg), _p(action), _p(self.loc), _p(self.reached), _p(reward),
                                C.byref(self.over), C.byref(self.success))
         if rc == -2:
             raise AssertionError("Actions should be in the range [0,naction).")
-        del loc_before, reached_before
         return self.obs(), reward, bool(self.over.value)
 
 

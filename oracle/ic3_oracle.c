@@ -60,6 +60,7 @@ typedef struct {
     int32_t vision;   /* PP:75 */
     int32_t mode;     /* 0 mixed, 1 cooperative, 2 competitive  PP:261-269 */
     int32_t naction;  /* 5, or 4 with --no_stay                 PP:90-93 */
+    int32_t enemy_comm; /* prey rows in obs / reward (PP:203-207,255,276-281); the policy then sees N+nprey agents */
 } orc_pp_cfg;
 
 /* PP:146-168 reset + PP:173-175 _get_cordinates with the injected stream:
@@ -141,6 +142,8 @@ static void pp_get_reward(const orc_pp_cfg* c, const int32_t* loc, int32_t* reac
     int all = 1;
     for (int i = 0; i < N; ++i) all &= (reached[i] == 1);
     if (all && c->mode == 0) *episode_over = 1;                           /* PP:273-274 */
+    if (c->enemy_comm)                                                    /* PP:255,276-281 prey reward */
+        for (int p = 0; p < c->nprey; ++p) reward[N + p] = (n_on == 0) ? 0.05 : 0.0;
     if (c->mode != 2) *success = (n_on == N) ? 1 : 0;                     /* PP:284-288 */
 }
 
@@ -151,7 +154,8 @@ int orc_pp_step(const orc_pp_cfg* c, const int32_t* action, int32_t* loc, int32_
 {
     if (*episode_over) return -1;                                         /* PP:129-130 */
     int bad = 0;
-    for (int i = 0; i < c->N; ++i) {                                      /* PP:134-135 */
+    const int rows = c->N + (c->enemy_comm ? c->nprey : 0);               /* len(action) == args.nagents */
+    for (int i = 0; i < rows; ++i) {                                      /* PP:134-135 (prey actions are ignored) */
         pp_take_action(c, loc, reached, i, action[i]);
         bad |= (action[i] > c->naction);                                  /* PP:137 (<=, Q2) */
     }
@@ -171,8 +175,9 @@ void orc_pp_obs(const orc_pp_cfg* c, const int32_t* loc, float* obs)
     const int N = c->N, v = c->vision, dim = c->dim, W = 2 * v + 1;
     const int base = dim * dim, OUTSIDE = base + 1, PREY = base + 2, PRED = base + 3, vocab = base + 4;
     const int pd = dim + 2 * v;
-    memset(obs, 0, sizeof(float) * (size_t)N * W * W * vocab);
-    for (int a = 0; a < N; ++a) {
+    const int rows = N + (c->enemy_comm ? c->nprey : 0);                  /* PP:203-207 */
+    memset(obs, 0, sizeof(float) * (size_t)rows * W * W * vocab);
+    for (int a = 0; a < rows; ++a) {
         float* row = obs + (size_t)a * W * W * vocab;
         for (int dy = 0; dy < W; ++dy)
             for (int dx = 0; dx < W; ++dx) {

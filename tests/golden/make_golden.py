@@ -35,19 +35,23 @@ def coo(rows, e, ep, t, obs):
 # ------------------------------------------------------------------------------------------------
 # F1: Predator-Prey trajectories
 # ------------------------------------------------------------------------------------------------
-def pp_fixture(name, N, dim, vision, mode, T, nenv=3, nep=2, greedy_env=None, no_stay=False):
+def pp_fixture(name, N, dim, vision, mode, T, nenv=3, nep=2, greedy_env=None, no_stay=False, enemy_comm=False):
+    """N = number of predators (args.nfriendly).  enemy_comm: the policy/env see N+1 agents (main.py:125-130)."""
     ref = rh.load_reference()
     a = rh.make_args('predator_prey', nagents=N, dim=dim, vision=vision, mode=mode, max_steps=T,
-                     no_stay=no_stay)
+                     no_stay=no_stay, enemy_comm=enemy_comm)
+    if enemy_comm:
+        a.nagents += a.nenemies
     env = rh.make_env('predator_prey', a)
+    R = N + (1 if enemy_comm else 0)
     raw = env.env
     rs = np.random.RandomState(zlib.crc32(name.encode()) & 0xffff)
     obs_rows = []
     init_loc = np.zeros((nenv, nep, N + 1, 2), np.int32)
-    actions = np.zeros((nenv, nep, T, N), np.int32)
+    actions = np.zeros((nenv, nep, T, R), np.int32)
     loc = np.zeros((nenv, nep, T, N + 1, 2), np.int32)
     reached = np.zeros((nenv, nep, T, N), np.int32)
-    reward = np.zeros((nenv, nep, T, N), np.float64)
+    reward = np.zeros((nenv, nep, T, R), np.float64)
     done = np.zeros((nenv, nep, T), np.int32)
     success = np.full((nenv, nep, T), -1, np.int32)
     nsteps = np.zeros((nenv, nep), np.int32)
@@ -65,7 +69,7 @@ def pp_fixture(name, N, dim, vision, mode, T, nenv=3, nep=2, greedy_env=None, no
             for t in range(T):
                 if greedy_env is not None and e in greedy_env:
                     # steer towards the prey so that freezing / early termination is exercised
-                    act = np.full(N, 4, np.int64)
+                    act = np.full(R, 4, np.int64)
                     for i in range(N):
                         dr = raw.prey_loc[0][0] - raw.predator_loc[i][0]
                         dc = raw.prey_loc[0][1] - raw.predator_loc[i][1]
@@ -76,7 +80,7 @@ def pp_fixture(name, N, dim, vision, mode, T, nenv=3, nep=2, greedy_env=None, no
                         if rs.rand() < 0.15:
                             act[i] = rs.randint(0, 6)
                 else:
-                    act = rs.randint(0, 6 if not no_stay else 5, size=N)   # includes the tolerated extra value (Q2)
+                    act = rs.randint(0, 6 if not no_stay else 5, size=R)   # includes the tolerated extra value (Q2)
                 actions[e, ep, t] = act
                 o, r, d, info = env.step([act])
                 coo(obs_rows, e, ep, t + 1, o[0].numpy())
@@ -96,6 +100,7 @@ def pp_fixture(name, N, dim, vision, mode, T, nenv=3, nep=2, greedy_env=None, no
                     break
     np.savez_compressed(os.path.join(HERE, name + '.npz'),
                         cfg=np.array([N, dim, vision, {'mixed': 0, 'cooperative': 1, 'competitive': 2}[mode], T, int(no_stay)], np.int32),
+                        enemy_comm=int(enemy_comm),
                         seed=SEED, env_gid0=100, obs_dim=env.observation_dim, init_loc=init_loc, actions=actions,
                         loc=loc, reached=reached, reward=reward, done=done, success=success, nsteps=nsteps,
                         ndraws=ndraws, obs_coo=np.array(obs_rows, np.float64))
@@ -206,6 +211,8 @@ def main():
         pp_fixture('pp_hard_mixed', 10, 20, 1, 'mixed', 80, nenv=2, greedy_env=[1])
         pp_fixture('pp_edge_v2', 4, 6, 2, 'mixed', 30, greedy_env=[0], nenv=3)
         pp_fixture('pp_nostay_v1', 3, 4, 1, 'cooperative', 15, no_stay=True)
+        pp_fixture('pp_enemycomm_mixed', 3, 5, 1, 'mixed', 20, greedy_env=[1], enemy_comm=True)
+        pp_fixture('pp_enemycomm_coop', 4, 6, 0, 'cooperative', 20, greedy_env=[0, 2], enemy_comm=True)
     if 'tjt' in which:
         tj_tables_fixture()
     if 'tj' in which:

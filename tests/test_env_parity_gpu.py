@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 from golden_util import load, SparseObs, PP_FIXTURES, TJ_FIXTURES, MODES, DIFFS  # noqa: E402
 
 
-def pp_args(N, dim, vision, mode, E, seed=0, offset=0, no_stay=False):
+def pp_args(N, dim, vision, mode, E, seed=0, offset=0, no_stay=False, enemy_comm=False):
     return argparse.Namespace(nfriendly=N, nenemies=1, dim=dim, vision=vision, moving_prey=False, mode=mode,
-                              enemy_comm=False, no_stay=no_stay, nenvs=E, seed=seed, env_id_offset=offset)
+                              enemy_comm=enemy_comm, no_stay=no_stay, nenvs=E, seed=seed, env_id_offset=offset)
 
 
 def tj_args(N, dim, vision, difficulty, E, seed=0, offset=0, add_rate_min=0.05, add_rate_max=0.05, curr_start=0,
@@ -44,10 +44,11 @@ def test_pp_hip_matches_reference_golden(name):
     fx = load(name)
     N, dim, vision, mode, T, no_stay = [int(x) for x in fx["cfg"]]
     nenv, nep = fx["nsteps"].shape
-    sp = SparseObs(fx["obs_coo"], N, int(fx["obs_dim"]))
+    ec = bool(int(fx["enemy_comm"]))
+    sp = SparseObs(fx["obs_coo"], N + (1 if ec else 0), int(fx["obs_dim"]))
     env = make_pp(N, dim, vision, MODES[mode], nenv, seed=int(fx["seed"]), offset=int(fx["env_gid0"]),
-                  no_stay=bool(no_stay))
-    assert env.obs_dim == int(fx["obs_dim"])
+                  no_stay=bool(no_stay), enemy_comm=ec)
+    assert env.obs_dim == int(fx["obs_dim"]) and env.nagents_env == N + (1 if ec else 0)
     for ep in range(nep):
         obs = env.reset().cpu().numpy()
         st = env.get_state()
@@ -320,3 +321,29 @@ def test_pp_scaled_full_size_spotcheck():
     assert (o4[..., :1602].sum(-1) == 1).all()
     del obs, env
     torch.cuda.empty_cache()
+
+
+def test_pp_enemy_comm_vs_oracle_random():
+    """enemy_comm (prey rows in obs / reward, N+1 action slots) at a larger size against the oracle."""
+    import oracle
+    N, dim, vision, E, T = 5, 8, 1, 64, 15
+    env = make_pp(N, dim, vision, "cooperative", E, seed=21, offset=50, enemy_comm=True)
+    orcs = [oracle.PPOracle(N, dim, vision, "cooperative", seed=21, env_gid=50 + e, enemy_comm=True) for e in range(E)]
+    obs = env.reset().cpu().numpy()
+    assert obs.shape == (E, N + 1, env.obs_dim)
+    for e, o in enumerate(orcs):
+        np.testing.assert_array_equal(obs[e], o.reset())
+    rs = np.random.RandomState(3)
+    lin = torch.nn.Linear(env.obs_dim, 32).cuda()
+    for t in range(T):
+        act = rs.randint(0, 5, size=(E, N + 1))
+        obs, rew, done, _ = env.step(act)
+        o_np, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for e, o in enumerate(orcs):
+            oo, orew, od = o.step(act[e])
+            np.testing.assert_array_equal(o_np[e], oo)
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+    with torch.no_grad():   # the sparse encoder covers the prey rows too
+        dense = obs.double() @ lin.weight.double().t() + lin.bias.double()
+        sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
+    torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)

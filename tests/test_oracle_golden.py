@@ -39,10 +39,11 @@ def test_pp_oracle_matches_reference(name):
     fx = load(name)
     N, dim, vision, mode, T, no_stay = [int(x) for x in fx["cfg"]]
     nenv, nep = fx["nsteps"].shape
-    sp = SparseObs(fx["obs_coo"], N, int(fx["obs_dim"]))
+    ec = bool(int(fx["enemy_comm"])) if "enemy_comm" in fx.files else False
+    sp = SparseObs(fx["obs_coo"], N + (1 if ec else 0), int(fx["obs_dim"]))
     for e in range(nenv):
         env = oracle.PPOracle(N, dim, vision, MODES[mode], stay=not no_stay, seed=int(fx["seed"]),
-                              env_gid=int(fx["env_gid0"]) + e)
+                              env_gid=int(fx["env_gid0"]) + e, enemy_comm=ec)
         assert env.obs_dim == int(fx["obs_dim"])
         for ep in range(nep):
             obs = env.reset()

@@ -291,3 +291,30 @@ def test_baseline_policies_through_trainer(kind, rnn_type):
     a.batch_size = 32 * 20
     st = tr.train_batch(0)
     assert np.isfinite(st['action_loss']) and not torch.equal(before, net.affine1.weight)
+
+
+def test_enemy_comm_through_trainer():
+    """main.py:125-130: with --enemy_comm the policy sees nagents = nfriendly + nenemies; stats gain
+    enemy_reward / enemy_comm (trainer.py:73-75,87-88)."""
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    a = build_args('predator_prey', dict(nagents=3, dim=5, vision=1, hid_size=32, ic3net=True, recurrent=True,
+                                         detach_gap=10, enemy_comm=True), 3, 20, 16, 9)
+    a.env_id_offset = 0
+    a.nagents += a.nenemies               # main.py:126-128
+    env = data.init('predator_prey', a, False)
+    a.num_actions, a.dim_actions, a.num_inputs = [env.num_actions, 2], 2, env.observation_dim
+    a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    torch.manual_seed(0)
+    net = CommNetMLP(a, a.num_inputs).cuda()
+    tr = trmod.Trainer(a, net, env)
+    episode, stat = tr.get_episode(0)
+    assert episode[0].action.shape == (2, 16, 4) and episode[0].reward.shape == (16, 4)
+    assert stat['reward'].shape == (3,) and stat['enemy_reward'].shape == (1,) and stat['enemy_comm'].shape == (1,)
+    # the prey earns 0.05 per live step without a predator on it, 0 otherwise (predator_prey_env.py:276-281)
+    assert 0.0 <= stat['enemy_reward'][0] <= 0.05 * stat['num_steps'] + 1e-6
+    a.batch_size = 16 * 20
+    st = tr.train_batch(0)
+    assert np.isfinite(st['action_loss'])
