@@ -147,7 +147,7 @@ int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out)
 int ic3_tj_create(const ic3_tj_cfg* cfg, int device, ic3_env** out)
 {
     if (!cfg || !out) return fail(-22, "ic3_tj_create: null argument");
-    if (cfg->vocab_type != 0) return fail(-38, "vocab_type 'scalar' is not implemented (SURVEY 8(f) f3)");
+    if (cfg->vocab_type != 0 && cfg->vocab_type != 1) return fail(-22, "vocab_type must be 0 ('bool') or 1 ('scalar')");
     if (cfg->E <= 0 || cfg->N <= 0 || cfg->N > 64 || cfg->vision < 0)
         return fail(-22, "ic3_tj_create: need E>0, 0<N<=64, vision>=0");
     ic3_env* env = new (std::nothrow) ic3_env();
@@ -156,16 +156,21 @@ int ic3_tj_create(const ic3_tj_cfg* cfg, int device, ic3_env** out)
     env->tj = *cfg;
     int h, w, base, npath, narrival, rpa;
     std::string err;
+    std::vector<int32_t> road;
     int rc = tj_build_tables(cfg->dim, cfg->vision, cfg->difficulty, &h, &w, &base, &npath, &narrival, &rpa, env->h_grid,
-                             env->h_route_off, env->h_route_rc, err);
+                             env->h_route_off, env->h_route_rc, err, &road);
     if (rc) { delete env; return fail(rc, err); }
+    const bool scalar = cfg->vocab_type == 1;
+    if (scalar) env->h_grid = road;   // traffic_junction_env.py:301-307: the grid holds OUTSIDE_CLASS 0 / ROAD_CLASS 1
     ic3_dims& d = env->dims;
     d.kind = IC3_ENV_TJ;
     d.E = cfg->E;
     d.N = cfg->N;
     d.window = 2 * cfg->vision + 1;
-    d.vocab = base + 3;                                  // traffic_junction_env.py:134
-    d.obs_dim = 2 + d.window * d.window * d.vocab;       // Tuple(Discrete, Discrete, MultiBinary) env_wrappers.py:21-29
+    // 'bool': vocab_size = BASE + 3 (:134), obs = Tuple(Discrete, Discrete, MultiBinary)            -> 2 + W*W*vocab
+    // 'scalar': vocab_size = 2 (:141), obs = Tuple(Discrete, Discrete, MultiDiscrete(dims), MultiBinary) -> 4 + W*W*2
+    d.vocab = scalar ? 2 : base + 3;
+    d.obs_dim = (scalar ? 4 : 2) + d.window * d.window * d.vocab;   // env_wrappers.py:21-29
     d.naction = 2;                                       // :108
     d.npath = npath;
     d.narrival = narrival;
@@ -190,7 +195,13 @@ int ic3_tj_create(const ic3_tj_cfg* cfg, int device, ic3_env** out)
     hipError_t e2 = hipMalloc(&env->d_route_off, env->h_route_off.size() * 4);
     hipError_t e3 = hipMalloc(&env->d_route_rc, packed.size() * 4);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { ic3_env_destroy(env); return fail(-12, "hipMalloc failed"); }
-    (void)hipMemcpy(env->d_grid, env->h_grid.data(), env->h_grid.size() * 4, hipMemcpyHostToDevice);
+    {
+        // device copy: road ids ('bool'), or road ? 0 : -1 ('scalar') so that one kernel serves both vocabularies
+        std::vector<int32_t> dev_grid = env->h_grid;
+        if (scalar)
+            for (auto& x : dev_grid) x = x ? 0 : -1;
+        (void)hipMemcpy(env->d_grid, dev_grid.data(), dev_grid.size() * 4, hipMemcpyHostToDevice);
+    }
     (void)hipMemcpy(env->d_route_off, env->h_route_off.data(), env->h_route_off.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(env->d_route_rc, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
     *out = env;

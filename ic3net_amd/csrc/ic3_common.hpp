@@ -110,7 +110,7 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
 // tj_tables.cpp (host)
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,
-                    std::vector<int32_t>& route_rc, std::string& err);
+                    std::vector<int32_t>& route_rc, std::string& err, std::vector<int32_t>* road_out = nullptr);
 // policy_ops.hip
 int sample_actions_env(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action, float* chosen_logp,
                        hipStream_t s);

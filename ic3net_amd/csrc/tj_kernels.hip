@@ -164,17 +164,23 @@ __global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__
                                                      const int32_t* __restrict__ last_act_s,
                                                      const int32_t* __restrict__ route_id_s,
                                                      const int32_t* __restrict__ grid, float* __restrict__ obs, int N,
-                                                     int h, int w, int v, int vocab, int outside, int car_class, int npath)
+                                                     int h, int w, int v, int vocab, int outside, int car_class, int npath,
+                                                     int hdr)
 {
+    // hdr = 2 ('bool' vocab: [last_act, route]) or 4 ('scalar' vocab: + p_norm = (r/(h-1), c/(w-1)), TJ:344,361).
+    // In scalar mode the uploaded grid is (road ? 0 : -1), vocab = 2, car_class = 1, outside = -1, so the one-hot
+    // formula below yields exactly the reference's (road, #cars) pair per window cell (TJ:331-332).
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
-    const int W = 2 * v + 1, WW = W * W, nseg = N * WW, obs_dim = 2 + WW * vocab;
+    const int W = 2 * v + 1, WW = W * W, nseg = N * WW, obs_dim = hdr + WW * vocab;
     int32_t* sr = smem;          // [N]
     int32_t* sc = sr + N;        // [N]
     int32_t* sal = sc + N;       // [N]
     float* s0 = reinterpret_cast<float*>(sal + N);  // [N] last_act scalar
     float* s1 = s0 + N;                             // [N] route scalar
-    int2* tab = reinterpret_cast<int2*>(smem + ((5 * N + 3) & ~3));  // [nseg] (one-hot channel, #cars)
+    float* s2 = s1 + N;                             // [N] r / (h-1)
+    float* s3 = s2 + N;                             // [N] c / (w-1)
+    int2* tab = reinterpret_cast<int2*>(smem + ((7 * N + 3) & ~3));  // [nseg] (one-hot channel, #cars)
     for (int a = threadIdx.x; a < N; a += blockDim.x) {
         const size_t i = (size_t)e * N + a;
         sr[a] = loc_r[i];
@@ -182,6 +188,8 @@ __global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__
         sal[a] = alive_s[i];
         s0[a] = (float)((double)last_act_s[i] / 1.0);                       // TJ:338 naction-1 == 1
         s1[a] = (float)((double)route_id_s[i] / (double)(npath - 1));       // TJ:341
+        s2[a] = (float)((double)sr[a] / (double)(h - 1));                   // TJ:344
+        s3[a] = (float)((double)sc[a] / (double)(w - 1));
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
@@ -204,8 +212,9 @@ __global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__
         if (sal[a]) {  // TJ:352-356
             if (off == 0) z = s0[a];
             else if (off == 1) z = s1[a];
+            else if (off < hdr) z = (off == 2) ? s2[a] : s3[a];
             else {
-                const int k = off - 2;
+                const int k = off - hdr;
                 const int seg = (int)(((float)k + 0.5f) * inv_vocab);  // exact for k < 2^20
                 const int ch = k - seg * vocab;
                 const int2 t = tab[a * WW + seg];
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ grid, const f32x4* __restrict__ Wt,
                                                         const f32x4* __restrict__ bias, f32x4* __restrict__ out, int ldo4,
                                                         int N, int h, int w, int v, int vocab, int outside,
-                                                        int car_class, int npath, int H4)
+                                                        int car_class, int npath, int H4, int hdr)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -244,7 +253,9 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
     int32_t* sal = sc + N;
     float* s0 = reinterpret_cast<float*>(sal + N);
     float* s1 = s0 + N;
-    int2* tab = reinterpret_cast<int2*>(smem + ((5 * N + 3) & ~3));
+    float* s2 = s1 + N;
+    float* s3 = s2 + N;
+    int2* tab = reinterpret_cast<int2*>(smem + ((7 * N + 3) & ~3));
     for (int a = threadIdx.x; a < N; a += blockDim.x) {
         const size_t i = (size_t)e * N + a;
         sr[a] = loc_r[i];
@@ -252,6 +263,8 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
         sal[a] = alive_s[i];
         s0[a] = (float)((double)last_act_s[i] / 1.0);
         s1[a] = (float)((double)route_id_s[i] / (double)(npath - 1));
+        s2[a] = (float)((double)sr[a] / (double)(h - 1));
+        s3[a] = (float)((double)sc[a] / (double)(w - 1));
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
@@ -270,10 +283,14 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
         if (sal[a]) {
             acc += s0[a] * Wt[c4];
             acc += s1[a] * Wt[H4 + c4];
+            if (hdr == 4) {
+                acc += s2[a] * Wt[2 * H4 + c4];
+                acc += s3[a] * Wt[3 * H4 + c4];
+            }
             for (int cell = 0; cell < WW; ++cell) {
                 const int2 t = tab[a * WW + cell];
-                const size_t row = 2 + (size_t)cell * vocab;
-                acc += Wt[(row + t.x) * H4 + c4];
+                const size_t row = hdr + (size_t)cell * vocab;
+                if (t.x >= 0) acc += Wt[(row + t.x) * H4 + c4];          // scalar vocab: -1 = not a road cell
                 if (t.y) acc += (float)t.y * Wt[(row + car_class) * H4 + c4];
             }
         }
@@ -286,11 +303,11 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window;
-    const size_t lds = (size_t)(((5 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
+    const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
     hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
                        reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, c.N, d.grid_h, d.grid_w,
-                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4);
+                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2);
     IC3_HIP(hipGetLastError());
     return 0;
 }
@@ -342,10 +359,10 @@ int tj_observe(ic3_env* env, float* obs, hipStream_t s)
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window;
-    const size_t lds = (size_t)(((5 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
+    const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
     hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
-                       d.vocab, d.vocab - 3, d.vocab - 1, d.npath);
+                       d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -136,7 +136,7 @@ Hop hop(const World& g, Cell cur, int turn, int turn_step, Cell origin, const st
 
 int tj_build_tables(int dim, int vision, int difficulty, int* h_out, int* w_out, int* base_out, int* npath_out,
                     int* narrival_out, int* rpa_out, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,
-                    std::vector<int32_t>& route_rc, std::string& err)
+                    std::vector<int32_t>& route_rc, std::string& err, std::vector<int32_t>* road_out)
 {
     // traffic_junction_env.py:93-100 config asserts
     if (difficulty == IC3_TJ_EASY || difficulty == IC3_TJ_MEDIUM) {
@@ -231,6 +231,7 @@ int tj_build_tables(int dim, int vision, int difficulty, int* h_out, int* w_out,
         }
     }
     if ((int)route_off.size() - 1 != npath) { err = "len(paths) != npath"; return -22; }  // :520
+    if (road_out) road_out->assign(g.road.begin(), g.road.end());   // 0/1 road flags (the 'scalar' vocab grid, TJ:301-307)
     *h_out = h;
     *w_out = w;
     *base_out = base;

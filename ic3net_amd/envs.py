@@ -265,13 +265,14 @@ class TrafficJunctionEnv(_BatchedEnv):
         if self.difficulty == 'hard':
             assert self.dim >= 9, 'Min dim: 9'
             assert self.dim % 3 == 0, 'Hard version works for multiple of 3. dim. only.'
-        if self.vocab_type != 'bool':
-            raise NotImplementedError("vocab_type 'scalar' is outside the hot-path scope (SURVEY 8(f) f3)")
+        if self.vocab_type not in ('bool', 'scalar'):
+            raise ValueError("vocab_type must be bool|scalar")
         self.naction = 2
         self.action_space = spaces.Discrete(self.naction)
         device = int(getattr(args, 'device', 0) or 0)
         cfg = _lib.TJCfg(int(getattr(args, 'nenvs', 1)), self.ncar, self.dim, self.vision,
-                         _lib.TJ_DIFFICULTY[self.difficulty], 0, float(self.add_rate_min), float(self.add_rate_max),
+                         _lib.TJ_DIFFICULTY[self.difficulty], int(self.vocab_type == 'scalar'), float(self.add_rate_min),
+                         float(self.add_rate_max),
                          float(self.curr_start), float(self.curr_end), int(getattr(args, 'seed', 0)) & 0xffffffff,
                          int(getattr(args, 'env_id_offset', 0)))
         h = C.c_void_p()
@@ -281,11 +282,16 @@ class TrafficJunctionEnv(_BatchedEnv):
         self.dims_grid = (d.grid_h, d.grid_w)
         self.npath = d.npath
         self.vocab_size = d.vocab
-        self.BASE = d.vocab - 3
-        self.OUTSIDE_CLASS += self.BASE
-        self.CAR_CLASS += self.BASE
-        self.observation_space = spaces.Tuple((spaces.Discrete(self.naction), spaces.Discrete(self.npath),
-                                               spaces.MultiBinary((d.window, d.window, self.vocab_size))))
+        if self.vocab_type == 'bool':                          # TJ:129-138
+            self.BASE = d.vocab - 3
+            self.OUTSIDE_CLASS += self.BASE
+            self.CAR_CLASS += self.BASE
+            self.observation_space = spaces.Tuple((spaces.Discrete(self.naction), spaces.Discrete(self.npath),
+                                                   spaces.MultiBinary((d.window, d.window, self.vocab_size))))
+        else:                                                  # TJ:139-148
+            self.observation_space = spaces.Tuple((spaces.Discrete(self.naction), spaces.Discrete(self.npath),
+                                                   spaces.MultiDiscrete(self.dims_grid),
+                                                   spaces.MultiBinary((d.window, d.window, self.vocab_size))))
 
     def _fields(self):
         E, N = self.nenvs, self.ncar

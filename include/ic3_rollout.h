@@ -62,7 +62,7 @@ typedef struct {
     int32_t dim;           /* args.dim                        :89 */
     int32_t vision;        /* args.vision                     :91 */
     int32_t difficulty;    /* IC3_TJ_*                        :90 */
-    int32_t vocab_type;    /* 0 = 'bool'; 'scalar' (1) -> -ENOSYS */
+    int32_t vocab_type;    /* 0 = 'bool', 1 = 'scalar' (:76,129-148): obs rows [last_act, route, r/(h-1), c/(w-1), (road, #cars) per cell] */
     double add_rate_min;   /* :103 */
     double add_rate_max;
     double curr_start;

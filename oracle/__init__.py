@@ -37,7 +37,7 @@ class PPCfg(C.Structure):
 
 class TJCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('N', 'h', 'w', 'vision', 'vocab', 'outside', 'car_class', 'npath',
-                                         'narrival', 'routes_per_arrival')]
+                                         'narrival', 'routes_per_arrival', 'scalar')]
 
 
 def _p(a):
@@ -101,16 +101,17 @@ class TJOracle(object):
     """One Traffic-Junction environment (traffic_junction_env.py); tables from oracle.tj_tables."""
 
     def __init__(self, N, dim, vision, difficulty, add_rate_min=0.05, add_rate_max=0.2, curr_start=0,
-                 curr_end=0, seed=0, env_gid=0):
+                 curr_end=0, seed=0, env_gid=0, vocab_type='bool'):
         from . import tj_tables
-        self.tab = tab = tj_tables.build(dim, vision, difficulty)
+        self.tab = tab = tj_tables.build(dim, vision, difficulty, vocab_type)
         self.N, self.vision = N, vision
+        scalar = vocab_type == 'scalar'
         self.cfg = TJCfg(N, tab['h'], tab['w'], vision, tab['vocab'], tab['outside'], tab['car_class'],
-                         tab['npath'], tab['narrival'], tab['routes_per_arrival'])
+                         tab['npath'], tab['narrival'], tab['routes_per_arrival'], int(scalar))
         self.grid = np.ascontiguousarray(tab['grid'], np.int32)
         self.route_off = np.ascontiguousarray(tab['route_off'], np.int32)
         self.route_rc = np.ascontiguousarray(tab['route_rc'], np.int32)
-        self.obs_dim = 2 + (2 * vision + 1) ** 2 * tab['vocab']
+        self.obs_dim = (4 if scalar else 2) + (2 * vision + 1) ** 2 * tab['vocab']
         self.seed, self.env_gid = seed, env_gid
         self.episode = -1
         self.t = 0

@@ -208,6 +208,8 @@ typedef struct {
     int32_t npath;        /* nPr(nroad, 2)                            TJ:126 */
     int32_t narrival;     /* len(self.routes)                         TJ:370 */
     int32_t routes_per_arrival; /* len(routes) for every arrival point TJ:384 */
+    int32_t scalar;       /* vocab_type == 'scalar' (TJ:139-148): grid holds road flags, obs rows are
+                             [last_act, route, r/(h-1), c/(w-1), (road, #cars) per window cell] */
 } orc_tj_cfg;
 
 /* tables: grid[h*w] road ids (TJ:300-319); route_off[npath+1]; route_rc[2*total_cells] (row,col) */
@@ -332,9 +334,37 @@ int orc_tj_step(const orc_tj_cfg* c, const int32_t* grid, const int32_t* route_o
 /* TJ:321-366 _get_obs (vocab_type 'bool') + env_wrappers.py:88-100.
  * Row a: [last_act/(naction-1), route_id/(npath-1), window one-hot (W*W*vocab)], zero if dead.
  * CAR channel counts every car on the cell incl. dead ones parked at (0,0) (Q8). */
+/* TJ:321-366 with vocab_type 'scalar': the one-hot base grid has 3 columns (outside, road, car), CAR += 1 per car
+ * (TJ:326-327), the outside column is dropped (TJ:331-332), p_norm = p / (h-1, w-1) is inserted (TJ:344,361). */
+static void tj_obs_scalar(const orc_tj_cfg* c, const int32_t* grid, const int32_t* alive, const int32_t* loc,
+                          const int32_t* last_act, const int32_t* route_id, float* obs)
+{
+    const int N = c->N, v = c->vision, W = 2 * v + 1;
+    const size_t od = 4 + (size_t)W * W * 2;
+    memset(obs, 0, sizeof(float) * od * (size_t)N);
+    for (int a = 0; a < N; ++a) {
+        if (alive[a] == 0) continue;
+        float* row = obs + od * (size_t)a;
+        row[0] = (float)((double)last_act[a] / 1.0);
+        row[1] = (float)((double)route_id[a] / (double)(c->npath - 1));
+        row[2] = (float)((double)loc[2 * a] / (double)(c->h - 1));
+        row[3] = (float)((double)loc[2 * a + 1] / (double)(c->w - 1));
+        for (int dy = 0; dy < W; ++dy)
+            for (int dx = 0; dx < W; ++dx) {
+                const int gr = loc[2 * a] + dy - v, gc = loc[2 * a + 1] + dx - v;
+                float* cell = row + 4 + (size_t)(dy * W + dx) * 2;
+                const int inside = (gr >= 0 && gr < c->h && gc >= 0 && gc < c->w);
+                cell[0] = (inside && grid[gr * c->w + gc] == 1) ? 1.0f : 0.0f;      /* ROAD_CLASS column */
+                for (int p = 0; p < N; ++p)
+                    if (loc[2 * p] == gr && loc[2 * p + 1] == gc) cell[1] += 1.0f;   /* CAR_CLASS column */
+            }
+    }
+}
+
 void orc_tj_obs(const orc_tj_cfg* c, const int32_t* grid, const int32_t* alive, const int32_t* loc,
                 const int32_t* last_act, const int32_t* route_id, float* obs)
 {
+    if (c->scalar) { tj_obs_scalar(c, grid, alive, loc, last_act, route_id, obs); return; }
     const int N = c->N, v = c->vision, W = 2 * v + 1, vocab = c->vocab;
     const size_t od = 2 + (size_t)W * W * vocab;
     memset(obs, 0, sizeof(float) * od * (size_t)N);

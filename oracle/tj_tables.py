@@ -140,7 +140,7 @@ def walk_routes(h, w, route, difficulty):
     return out
 
 
-def build(dim, vision, difficulty):
+def build(dim, vision, difficulty, vocab_type='bool'):
     h = w = dim
     if difficulty in ('medium', 'easy'):                                         # TJ:93-96
         assert dim % 2 == 0, 'Only even dimension supported for now.'
@@ -161,6 +161,10 @@ def build(dim, vision, difficulty):
                   [np.array([(h // 2, i) for i in range(w)], dtype=np.int64)]]
     else:
         routes = walk_routes(h, w, route, difficulty)
+    if vocab_type == 'scalar':                                                   # TJ:139-148, 300-307
+        vocab, outside, car_class, base = 2, 0, 2, 0                             # classes are not shifted
+        grid = route.copy()                                                      # 0 outside / 1 road (ROAD_CLASS)
+        pad = np.pad(grid, vision, 'constant', constant_values=0)
     flat = [p for r in routes for p in r]
     assert len(flat) == npath                                                    # TJ:520
     off = np.zeros(npath + 1, np.int32)

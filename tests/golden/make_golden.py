@@ -140,12 +140,13 @@ def a_obs_dim(a, env):
 # ------------------------------------------------------------------------------------------------
 # F3: Traffic-Junction trajectories
 # ------------------------------------------------------------------------------------------------
-def tj_fixture(name, N, dim, vision, difficulty, add_rate, T, nenv=2, nep=2, brake_p=0.3, curriculum=None):
+def tj_fixture(name, N, dim, vision, difficulty, add_rate, T, nenv=2, nep=2, brake_p=0.3, curriculum=None,
+               vocab_type='bool'):
     ref = rh.load_reference()
-    kw = dict(add_rate_min=add_rate, add_rate_max=add_rate)
+    kw = dict(add_rate_min=add_rate, add_rate_max=add_rate, vocab_type=vocab_type)
     if curriculum:
         kw = dict(add_rate_min=curriculum[0], add_rate_max=curriculum[1], curr_start=curriculum[2],
-                  curr_end=curriculum[3])
+                  curr_end=curriculum[3], vocab_type=vocab_type)
     a = rh.make_args('traffic_junction', nagents=N, dim=dim, vision=vision, difficulty=difficulty, max_steps=T, **kw)
     env = rh.make_env('traffic_junction', a)
     raw = env.env
@@ -193,6 +194,7 @@ def tj_fixture(name, N, dim, vision, difficulty, add_rate, T, nenv=2, nep=2, bra
     np.savez_compressed(os.path.join(HERE, name + '.npz'),
                         cfg=np.array([N, dim, vision, {'easy': 0, 'medium': 1, 'hard': 2}[difficulty], T], np.int32),
                         add_rate=add_rate, curriculum=np.array(curriculum if curriculum else [0, 0, 0, 0], np.float64),
+                        scalar=int(vocab_type == 'scalar'),
                         epochs=epochs, seed=SEED, env_gid0=200, obs_dim=env.observation_dim, actions=actions,
                         alive=alive, wait=wait, loc=loc, last_act=last_act, route_loc=route_loc, route_id=route_id,
                         is_completed=is_completed, cars_in_sys=cars_in_sys, has_failed=has_failed, reward=reward,
@@ -224,6 +226,9 @@ def main():
         tj_fixture('tj_hard_v1', 20, 18, 1, 'hard', 0.3, 40, nenv=1, brake_p=0.4)
         tj_fixture('tj_hard9_v2', 8, 9, 2, 'hard', 1.0, 25, nenv=1, brake_p=0.5)
         tj_fixture('tj_easy_curr', 5, 6, 0, 'easy', 0.1, 12, nenv=2, nep=6, curriculum=(0.1, 0.3, 2, 12))
+        tj_fixture('tj_scalar_medium_v1', 10, 14, 1, 'medium', 0.3, 30, vocab_type='scalar')
+        tj_fixture('tj_scalar_easy_v0', 5, 6, 0, 'easy', 0.5, 20, vocab_type='scalar', brake_p=0.5)
+        tj_fixture('tj_scalar_hard_v2', 12, 12, 2, 'hard', 0.4, 25, nenv=1, vocab_type='scalar')
     if 'policy' in which:
         import make_golden_policy
         make_golden_policy.main()

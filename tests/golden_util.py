@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PP_FIXTURES = ["pp_easy_mixed", "pp_easy_coop", "pp_easy_comp", "pp_medium_mixed", "pp_hard_mixed", "pp_edge_v2",
                "pp_nostay_v1", "pp_enemycomm_mixed", "pp_enemycomm_coop"]
 TJ_FIXTURES = ["tj_easy_v0", "tj_easy_v1_full", "tj_medium_v0", "tj_medium_v1", "tj_hard_v0", "tj_hard_v1",
-               "tj_hard9_v2", "tj_easy_curr"]
+               "tj_hard9_v2", "tj_easy_curr", "tj_scalar_medium_v1", "tj_scalar_easy_v0", "tj_scalar_hard_v2"]
 MODES = ["mixed", "cooperative", "competitive"]
 DIFFS = ["easy", "medium", "hard"]
 

@@ -19,8 +19,8 @@ def pp_args(N, dim, vision, mode, E, seed=0, offset=0, no_stay=False, enemy_comm
 
 
 def tj_args(N, dim, vision, difficulty, E, seed=0, offset=0, add_rate_min=0.05, add_rate_max=0.05, curr_start=0,
-            curr_end=0):
-    return argparse.Namespace(nagents=N, dim=dim, vision=vision, difficulty=difficulty, vocab_type='bool',
+            curr_end=0, vocab_type='bool'):
+    return argparse.Namespace(nagents=N, dim=dim, vision=vision, difficulty=difficulty, vocab_type=vocab_type,
                               add_rate_min=add_rate_min, add_rate_max=add_rate_max, curr_start=curr_start,
                               curr_end=curr_end, nenvs=E, seed=seed, env_id_offset=offset)
 
@@ -93,6 +93,7 @@ def test_tj_hip_matches_reference_golden(name):
     kw = dict(add_rate_min=float(fx["add_rate"]), add_rate_max=float(fx["add_rate"]))
     if has_curr:
         kw = dict(add_rate_min=cur[0], add_rate_max=cur[1], curr_start=cur[2], curr_end=cur[3])
+    kw["vocab_type"] = 'scalar' if ("scalar" in fx.files and int(fx["scalar"])) else 'bool'
     # the curriculum fixture gives every env instance its own epoch sequence -> one handle per env there
     groups = [[e] for e in range(nenv)] if has_curr else [list(range(nenv))]
     for grp in groups:
@@ -347,3 +348,35 @@ def test_pp_enemy_comm_vs_oracle_random():
         dense = obs.double() @ lin.weight.double().t() + lin.bias.double()
         sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
     torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
+
+
+def test_tj_scalar_vocab_vs_oracle_and_encoder():
+    """vocab_type='scalar' (traffic_junction_env.py:139-148): rows [last_act, route, r/(h-1), c/(w-1), (road, #cars)
+    per window cell]; checked against the oracle on random steps, plus the sparse encoder on those rows."""
+    import oracle
+    N, dim, vision, diff, E, T, rate = 10, 14, 1, "medium", 48, 25, 0.4
+    env = make_tj(N, dim, vision, diff, E, seed=4, offset=70, add_rate_min=rate, add_rate_max=rate, vocab_type='scalar')
+    assert env.obs_dim == 4 + 9 * 2
+    from ic3net_amd.env_wrappers import GymWrapper
+    assert GymWrapper(env).observation_dim == env.obs_dim
+    orcs = [oracle.TJOracle(N, dim, vision, diff, add_rate_min=rate, add_rate_max=rate, seed=4, env_gid=70 + e,
+                            vocab_type='scalar') for e in range(E)]
+    env.reset(0)
+    for o in orcs:
+        o.reset(0)
+    rs = np.random.RandomState(8)
+    lin = torch.nn.Linear(env.obs_dim, 64).cuda()
+    for t in range(T):
+        act = (rs.rand(E, N) < 0.35).astype(np.int32)
+        obs, rew, done, info = env.step(act)
+        o_np = obs.cpu().numpy()
+        for e, o in enumerate(orcs):
+            oo, orew, _ = o.step(act[e])
+            np.testing.assert_array_equal(o_np[e], oo)
+            np.testing.assert_array_equal(rew[e].cpu().numpy(), orew.astype(np.float32))
+    with torch.no_grad():
+        dense = obs.double() @ lin.weight.double().t() + lin.bias.double()
+        sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
+    torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
+    grid, off, rc = env.tables()
+    assert set(np.unique(grid)) == {0, 1}                      # the reference's self.grid holds road flags here

@@ -101,7 +101,7 @@ def test_tj_oracle_matches_reference(name):
         if has_curr:
             kw = dict(add_rate_min=cur[0], add_rate_max=cur[1], curr_start=cur[2], curr_end=cur[3])
         env = oracle.TJOracle(N, dim, vision, DIFFS[diff], seed=int(fx["seed"]), env_gid=int(fx["env_gid0"]) + e,
-                              **kw)
+                              vocab_type='scalar' if ("scalar" in fx.files and int(fx["scalar"])) else 'bool', **kw)
         assert env.obs_dim == int(fx["obs_dim"])
         for ep in range(nep):
             obs = env.reset(int(fx["epochs"][e, ep]))
