@@ -12,7 +12,7 @@ def init(env_name, args, final_init=True):
         raise NotImplementedError("%s is not shipped with / in scope of the hot path (SURVEY §2 rows 13, 17)" % env_name)
     else:
         raise RuntimeError("wrong env name")
-    if getattr(args, 'display', False):
-        raise NotImplementedError("--display (curses rendering) is outside the hot-path scope")
+    # args.display: the reference calls env.init_curses() here (data.py:18-19,24-25); rendering is plain text in
+    # this engine (env.render()), so there is nothing to initialise
     env.multi_agent_init(args)
     return GymWrapper(env)

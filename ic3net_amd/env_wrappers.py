@@ -74,7 +74,8 @@ class GymWrapper(object):
         return stat
 
     def display(self):
-        raise NotImplementedError("rendering is outside the hot-path scope (SURVEY 8(f) f4)")
+        """env_wrappers.py:66-68: render (here: env 0 of the batch as text, from a state readback)."""
+        self.env.render()
 
     def end_display(self):
         pass

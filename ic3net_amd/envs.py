@@ -165,6 +165,10 @@ class _BatchedEnv(object):
         return torch.zeros_like(self._reward)      # PP:292-293 / TJ:611-612: zeros
 
 
+def _grid_to_text(cells):
+    return "\n".join(" ".join(c.center(3) for c in row) for row in cells)
+
+
 class PredatorPreyEnv(_BatchedEnv):
     """predator_prey_env.py:30-339, batched."""
 
@@ -221,6 +225,24 @@ class PredatorPreyEnv(_BatchedEnv):
         E, N, T = self.nenvs, self.npredator, self.npredator + self.nprey
         return [("loc_r", (E, T)), ("loc_c", (E, T)), ("reached", (E, N)), ("over", (E,)), ("success", (E,)),
                 ("episode", (E,)), ("t", (E,))]
+
+    def render(self, mode='human', close=False, env_index=0):
+        """Debug view of ONE env from a state readback (the reference draws the same grid with curses,
+        PP:307-336): 'X' predator, 'P' prey, a leading count when several share a cell, '0' empty."""
+        st = self.get_state()
+        dim, N = self.dim, self.npredator
+        cells = [['0'] * dim for _ in range(dim)]
+        marks = {}
+        for i in range(N + self.nprey):
+            key = (int(st['loc_r'][env_index, i]), int(st['loc_c'][env_index, i]))
+            marks.setdefault(key, []).append('X' if i < N else 'P')
+        for (r, c), m in marks.items():
+            nx, npr = m.count('X'), m.count('P')
+            cells[r][c] = (str(nx) if nx > 1 else '') + ('X' if nx else '') + ('P' if npr else '')
+        text = _grid_to_text(cells)
+        if mode == 'human':
+            print(text + "\n")
+        return text
 
     def reset(self):                        # PP:146-168
         return self._reset(None)
@@ -315,6 +337,30 @@ class TrafficJunctionEnv(_BatchedEnv):
         rc = np.empty(need, np.int32)
         check(_lib.lib().ic3_tj_get_tables(self._h, None, None, rc.ctypes.data_as(C.c_void_p), need))
         return grid, off, rc.reshape(-1, 2)
+
+    def render(self, mode='human', close=False, env_index=0):
+        """Debug view of ONE env (the reference's curses drawing, TJ:254-292, as text): '_' road, '<>' car that last
+        moved, '<b>' car that last braked, a count prefix when cars share a cell (a crash)."""
+        st = self.get_state()
+        grid, _, _ = self.tables()
+        h, w = grid.shape
+        road = (grid != self.OUTSIDE_CLASS) if self.vocab_type == 'bool' else (grid == 1)
+        if self.vocab_type == 'bool' and self.difficulty == 'easy':
+            road = np.zeros_like(road)
+            road[h // 2, :] = True
+            road[:, w // 2] = True                        # quirk Q9: an easy road id equals OUTSIDE_CLASS
+        cells = [['_' if road[r, c] else '' for c in range(w)] for r in range(h)]
+        marks = {}
+        for i in range(self.ncar):
+            if st['alive'][env_index, i]:
+                key = (int(st['loc_r'][env_index, i]), int(st['loc_c'][env_index, i]))
+                marks.setdefault(key, []).append('<b>' if st['last_act'][env_index, i] else '<>')
+        for (r, c), m in marks.items():
+            cells[r][c] = (str(len(m)) if len(m) > 1 else '') + m[0]
+        text = _grid_to_text(cells)
+        if mode == 'human':
+            print(text + "\n")
+        return text
 
     def reset(self, epoch=None):            # TJ:160-204
         return self._reset(epoch)

@@ -69,8 +69,9 @@ class Trainer(object):
             state = self.env.reset(epoch)
         else:
             state = self.env.reset()
-        if self.display and self.last_step:
-            raise NotImplementedError("--display is outside the hot-path scope (SURVEY 8(f) f4)")
+        self._should_display = self.display and self.last_step      # trainer.py:33-36
+        if self._should_display:
+            self.env.display()
         E, dev = state.shape[0], state.device
         T, N, nh = args.max_steps, args.nagents, len(args.naction_heads)
         self._state = state
@@ -104,7 +105,8 @@ class Trainer(object):
     def _use_graph(self):
         a = self.args
         return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
-            and not getattr(a, 'rollout_grad', False) and self.clock.env is not None
+            and not getattr(a, 'rollout_grad', False) and self.clock.env is not None \
+            and not getattr(self, '_should_display', False)
 
     def step_episode(self, t):
         """One iteration of the hot loop trainer.py:43-108 for all E envs (eager, or as a hipGraph replay)."""
@@ -174,6 +176,8 @@ class Trainer(object):
             info = dict(info)
             if args.hard_attn and args.commnet:                    # trainer.py:70-71 (gate for the NEXT step)
                 info['comm_action'] = action[-1] if not args.comm_action_one else self._ones_comm
+            if getattr(self, '_should_display', False):            # trainer.py:101-102
+                self.env.display()
             self._step_out[t] = (cur_state, action_out, value, next_state.clone() if store else None)
             self._state = next_state
             self._info = info

@@ -380,3 +380,17 @@ def test_tj_scalar_vocab_vs_oracle_and_encoder():
     torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
     grid, off, rc = env.tables()
     assert set(np.unique(grid)) == {0, 1}                      # the reference's self.grid holds road flags here
+
+
+def test_render_text_views():
+    env = make_pp(2, 3, 0, "mixed", 2, seed=0)
+    env.reset()
+    env.set_state(loc_r=[[0, 0, 2], [1, 1, 1]], loc_c=[[0, 0, 1], [0, 2, 2]])
+    txt = env.render(mode='ansi', env_index=0).split("\n")
+    assert [c.strip() for c in txt[0].split("  ") if c.strip()][0] == '2X' and 'P' in txt[2]
+    assert 'XP' in env.render(mode='ansi', env_index=1)
+    tj = make_tj(5, 6, 0, "easy", 2, seed=1, add_rate_min=1.0, add_rate_max=1.0)
+    tj.reset(0)
+    tj.step(np.zeros((2, 5), np.int32))
+    t = tj.render(mode='ansi')
+    assert '<>' in t and '_' in t
