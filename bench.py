@@ -187,6 +187,8 @@ def main():
                    help='replay the per-step launch sequence as hipGraphs (Trainer args.hip_graph)')
     p.add_argument('--no-dense-obs', action='store_true',
                    help='diagnostic: skip obs assembly (sparse encoder consumes env state directly); NOT the headline config')
+    p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
+                   help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
     o = p.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -206,6 +208,7 @@ def main():
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
     a.hip_graph = bool(o.graph)
     a.dense_obs = not o.no_dense_obs
+    a.fused_lstm = bool(o.fused_lstm)
     T = a.max_steps
     raw_env = trainer.env.env
 

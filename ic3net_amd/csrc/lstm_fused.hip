@@ -4,12 +4,12 @@
 // The (R x 4H) gate tensor is never materialised (the library-GEMM + pointwise pair wrote and re-read 4H floats
 // per row).  MFMA-bound: 2·R·2H·4H flops at the 157 TFLOP/s fp32-matrix peak.
 //
-// STATUS (round 1, MI355X, R = 81920, H = 128; tools/microbench_lstm.py, profiles/r01/lstm_fused.txt): 245 us =
-// 88 TFLOP/s for the whole cell, vs 199 us hipBLASLt GEMM (108 TFLOP/s) + 44 us lstm_cell kernel = 243 us.
-// The MFMA loop alone runs at the library's rate; the A-tile staging and the epilogue (~45 us) are not hidden
-// because the two co-resident workgroups of a CU run phase-locked.  Parity with the library pair, not faster, so
-// the policy uses it only when args.fused_lstm is set (default: hipBLASLt + ic3_lstm_cell).  Next step would be a
-// persistent, phase-skewed variant (epilogue of one half-workgroup under the MFMA loop of the other).
+// STATUS (round 1, MI355X, R = 81920, H = 128; tools/microbench_lstm.py, profiles/r01/lstm_fused.txt): 223 us =
+// 96 TFLOP/s for the whole cell standalone, vs 199 us hipBLASLt GEMM (108 TFLOP/s) + 44 us lstm_cell = 243 us;
+// inside the rollout graph the library GEMM runs faster (178 us) and the step time is the same with either
+// (0.60-0.61 ms), so the policy uses this kernel only when args.fused_lstm is set.  Without the phase skew below
+// it took 240-245 us: the MFMA loop runs at the library's rate, but the A-tile staging and the epilogue (~45 us)
+// of the two co-resident workgroups coincided instead of hiding under each other's MFMA loops.
 //
 // Decomposition (H = 128: 256 threads):
 //   * one workgroup = 64 rows x ALL 4H gate columns: the workgroup is the only reader and the only writer of its
@@ -45,9 +45,15 @@ template <int H>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_fused_kernel(float* __restrict__ XH, int ldx,
                                                                                const f32x4* __restrict__ Wp,
                                                                                const float* __restrict__ bias,
-                                                                               float* __restrict__ c, int R)
+                                                                               float* __restrict__ c, int R, int skew)
 {
     constexpr int K = 2 * H, LDA = K + 1, BM = 64, NT = 2 * H;  // NT threads = 64 * (H/32) waves
+    // Phase skew: the two workgroups resident on a CU would otherwise run their (memory-bound) staging/epilogue and
+    // their (MFMA-bound) main loops at the same time.  Workgroups 256..511 — observed to be the second residency
+    // slot of each CU in the first dispatch round; an assumption that only affects speed — start `skew` sleeps
+    // late, and every later workgroup inherits the offset of the slot it replaces.
+    if (skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(127);
     extern __shared__ __attribute__((aligned(16))) float As[];  // [BM][LDA]
     const int r0 = blockIdx.x * BM;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -195,6 +201,7 @@ extern "C" int ic3_lstm_pack_weights(const float* w_ih, const float* w_hh, float
 extern "C" int ic3_lstm_fused(float* XH, int ldx, const float* Wp, const float* bias, float* c, int R, int H,
                               ic3_stream stream)
 {
+    const int skew = 6;   // x ~3.4 us (s_sleep 127) ~ 2/3 of a tile; measured 0/2/4/6/8 -> 240/241/229/223/225 us
     if (!XH || !Wp || !bias || !c || R <= 0 || ldx < 2 * H || (ldx & 3))
         return ic3::fail(-22, "ic3_lstm_fused: bad arguments");
     const int blocks = (R + 63) / 64;
@@ -202,9 +209,9 @@ extern "C" int ic3_lstm_fused(float* XH, int ldx, const float* Wp, const float* 
     hipStream_t s = (hipStream_t)stream;
     const ic3::f32x4* wp = reinterpret_cast<const ic3::f32x4*>(Wp);
     if (H == 128) {
-        hipLaunchKernelGGL(ic3::lstm_fused_kernel<128>, dim3(blocks), dim3(256), lds, s, XH, ldx, wp, bias, c, R);
+        hipLaunchKernelGGL(ic3::lstm_fused_kernel<128>, dim3(blocks), dim3(256), lds, s, XH, ldx, wp, bias, c, R, skew);
     } else if (H == 64) {
-        hipLaunchKernelGGL(ic3::lstm_fused_kernel<64>, dim3(blocks), dim3(128), lds, s, XH, ldx, wp, bias, c, R);
+        hipLaunchKernelGGL(ic3::lstm_fused_kernel<64>, dim3(blocks), dim3(128), lds, s, XH, ldx, wp, bias, c, R, skew);
     } else if (H == 256) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -212,7 +219,7 @@ extern "C" int ic3_lstm_fused(float* XH, int ldx, const float* Wp, const float* 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
-        hipLaunchKernelGGL(ic3::lstm_fused_kernel<256>, dim3(blocks), dim3(512), lds, s, XH, ldx, wp, bias, c, R);
+        hipLaunchKernelGGL(ic3::lstm_fused_kernel<256>, dim3(blocks), dim3(512), lds, s, XH, ldx, wp, bias, c, R, skew);
     } else {
         return ic3::fail(-38, "ic3_lstm_fused: H must be 64, 128 or 256 (use ic3_lstm_cell after a library GEMM otherwise)");
     }
