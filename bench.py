@@ -189,6 +189,9 @@ def main():
                    help='diagnostic: skip obs assembly (sparse encoder consumes env state directly); NOT the headline config')
     p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
                    help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
+    p.add_argument('--tune-gemm', type=int, default=int(os.environ.get('IC3_BENCH_TUNE_GEMM', '1')),
+                   help='let PyTorch TunableOp pick the fastest hipBLASLt/rocBLAS solution for the two policy GEMMs '
+                        'during the eager warm-up episode (seconds; nothing is written to disk)')
     o = p.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -205,6 +208,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
 
+    if o.tune_gemm:
+        try:
+            import torch.cuda.tunable as tunable
+            tunable.enable(True)
+            tunable.tuning_enable(True)
+            tunable.write_file_on_exit(False)
+        except Exception as exc:
+            sys.stderr.write("bench.py: TunableOp unavailable (%r); using the default GEMM heuristics\n" % (exc,))
+            o.tune_gemm = 0
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
     a.hip_graph = bool(o.graph)
     a.dense_obs = not o.no_dense_obs
@@ -224,6 +236,11 @@ def main():
         return t_in_ep
 
     raw_env.obs_timer = []                    # event-time the obs launch from the start (graphs are captured in this mode)
+    if o.tune_gemm:                           # untimed: every GEMM shape is met (and tuned) in one eager episode
+        saved_graph, a.hip_graph = a.hip_graph, False
+        run(T, 0)
+        a.hip_graph = saved_graph
+        torch.cuda.tunable.tuning_enable(False)   # keep the selections, stop tuning (never tune inside a capture)
     if o.graph:                               # untimed: one eager episode (warm-up) + one capture episode
         try:
             run(2 * T, 0)
@@ -289,7 +306,8 @@ def main():
             "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
                        "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world,
-                       "launch": "hipGraph replay" if o.graph else "eager", "dense_obs": not o.no_dense_obs},
+                       "launch": "hipGraph replay" if o.graph else "eager", "dense_obs": not o.no_dense_obs,
+                       "gemm": "TunableOp-selected" if o.tune_gemm else "default heuristics"},
             "roofline": {"kernel": "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
