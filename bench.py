@@ -191,7 +191,7 @@ def main():
                    help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
     p.add_argument('--tune-gemm', type=int, default=int(os.environ.get('IC3_BENCH_TUNE_GEMM', '1')),
                    help='let PyTorch TunableOp pick the fastest hipBLASLt/rocBLAS solution for the two policy GEMMs '
-                        'during the eager warm-up episode (seconds; nothing is written to disk)')
+                        'during the eager warm-up episode (seconds; selections are kept in memory)')
     o = p.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -214,6 +214,7 @@ def main():
             tunable.enable(True)
             tunable.tuning_enable(True)
             tunable.write_file_on_exit(False)
+            tunable.set_filename(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ic3_tunableop_%d.csv' % os.getpid()))
         except Exception as exc:
             sys.stderr.write("bench.py: TunableOp unavailable (%r); using the default GEMM heuristics\n" % (exc,))
             o.tune_gemm = 0
