@@ -110,7 +110,8 @@ class CommNetMLP(nn.Module):
     #     (args.fused_lstm: both as ONE hand-written fp32-MFMA kernel, csrc/lstm_fused.hip — at parity with the
     #      library pair on MI355X, so off by default)
     #   policy_heads: XH[:, H:] -> [log_softmax heads | value]                          1 kernel
-    # The returned (h, c) are views of internal buffers, valid until the next forward.
+    # The returned (h, c) are views of internal buffers, valid until the next forward: one rollout at a time per
+    # policy instance in this mode (set args.fused_policy = False to get fresh tensors from the generic path).
     # ------------------------------------------------------------------------------------------
     def _fused_ok(self, x):
         a = self.args
@@ -173,8 +174,8 @@ class CommNetMLP(nn.Module):
                 enc = buf['enc'] = torch.empty((R, H), dtype=torch.float32, device=dev)
             torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)           # dense encoder GEMM
             xh[:, :H].copy_(enc)
-        ops._launch(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg, not self.args.comm_mask_zero,
-                    out=buf['comm'])
+        ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg,
+                                   not self.args.comm_mask_zero, out=buf['comm'])
         xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                          # inp = enc + C(comm_sum)
         if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
             ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel

@@ -17,11 +17,11 @@ class _CommMaskedMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, alive, comm_action, mode_avg, mask_self):
         ctx.alive, ctx.comm_action, ctx.mode_avg, ctx.mask_self = alive, comm_action, mode_avg, mask_self
-        return _launch(h, alive, comm_action, mode_avg, mask_self)
+        return comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self)
 
     @staticmethod
     def backward(ctx, g):
-        return _launch(g.contiguous(), ctx.alive, ctx.comm_action, ctx.mode_avg, ctx.mask_self), None, None, None, None
+        return comm_masked_mean_raw(g.contiguous(), ctx.alive, ctx.comm_action, ctx.mode_avg, ctx.mask_self), None, None, None, None
 
 
 def _rows(t, H):
@@ -38,7 +38,8 @@ def _rows(t, H):
     return t, H
 
 
-def _launch(h, alive, comm_action, mode_avg, mask_self, out=None):
+def comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self, out=None):
+    """The kernel launch without autograd: h (E,N,H) rows may be a strided column slice; `out` (E,N,H) contiguous."""
     _need_cuda(h, "comm_masked_mean")
     E, N, H = h.shape
     hk, ldh = _rows(h, H)
