@@ -200,6 +200,10 @@ class Trainer(object):
         if n == args.max_steps:
             done_t[n - 1] = True                                   # trainer.py:90 forced done at the last step
         reward = buf['reward'][:n]
+        if self._use_graph():
+            # static buffers are rewritten by the next episode's replays: hand out copies (action_out / value of a
+            # Transition stay graph-owned and are valid until the same step of the next episode)
+            reward = reward.clone()
         alive = buf['alive'][:n].to(torch.float32) if has_info else torch.ones_like(reward)   # trainer.py:78-81
         alive_mask = alive * live.unsqueeze(2)
         episode_mask = (~done_t).to(torch.float32).unsqueeze(2).expand(n, E, N)                # trainer.py:92-96
@@ -207,7 +211,7 @@ class Trainer(object):
         if has_info:                                               # trainer.py:98-99 (only when not done, Q26)
             episode_mini_mask = torch.where(done_t.unsqueeze(2), episode_mini_mask,
                                             1.0 - buf['is_completed'][:n].to(torch.float32))
-        action = buf['action'][:n]
+        action = buf['action'][:n].clone() if self._use_graph() else buf['action'][:n]
         stat = dict()
         num_steps = float(live.sum().item())
         stat['num_steps'] = num_steps                              # trainer.py:109-110
