@@ -394,3 +394,41 @@ def test_render_text_views():
     tj.step(np.zeros((2, 5), np.int32))
     t = tj.render(mode='ansi')
     assert '<>' in t and '_' in t
+
+
+def test_max_agents_per_env_vs_oracle():
+    """N = 64 (one env per wavefront, the full 64-bit ballot mask) for PP, and N = 48 cars for TJ-hard."""
+    import oracle
+    E, T = 6, 10
+    env = make_pp(64, 10, 1, "cooperative", E, seed=8, offset=3)
+    orcs = [oracle.PPOracle(64, 10, 1, "cooperative", seed=8, env_gid=3 + e) for e in range(E)]
+    obs = env.reset().cpu().numpy()
+    for e, o in enumerate(orcs):
+        np.testing.assert_array_equal(obs[e], o.reset())
+    rs = np.random.RandomState(1)
+    for t in range(T):
+        act = rs.randint(0, 5, size=(E, 64))
+        obs, rew, done, _ = env.step(act)
+        for e, o in enumerate(orcs):
+            oo, orew, od = o.step(act[e])
+            np.testing.assert_array_equal(obs[e].cpu().numpy(), oo)
+            np.testing.assert_array_equal(rew[e].cpu().numpy(), orew.astype(np.float32))
+    tj = make_tj(48, 18, 1, "hard", E, seed=8, offset=3, add_rate_min=0.9, add_rate_max=0.9)
+    torcs = [oracle.TJOracle(48, 18, 1, "hard", add_rate_min=0.9, add_rate_max=0.9, seed=8, env_gid=3 + e)
+             for e in range(E)]
+    tj.reset(0)
+    for o in torcs:
+        o.reset(0)
+    for t in range(25):
+        act = (rs.rand(E, 48) < 0.5).astype(np.int32)
+        obs, rew, done, info = tj.step(act)
+        st = tj.get_state()
+        for e, o in enumerate(torcs):
+            oo, orew, _ = o.step(act[e])
+            np.testing.assert_array_equal(st["alive"][e], o.alive)
+            np.testing.assert_array_equal(st["route_id"][e], o.route_id)
+            np.testing.assert_array_equal(obs[e].cpu().numpy(), oo)
+            np.testing.assert_array_equal(rew[e].cpu().numpy(), orew.astype(np.float32))
+    from ic3net_amd.envs import PredatorPreyEnv
+    with pytest.raises(ValueError):
+        PredatorPreyEnv().multi_agent_init(pp_args(65, 10, 1, "mixed", 2))       # N > 64 is rejected, not mis-simulated
