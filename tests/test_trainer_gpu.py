@@ -318,3 +318,57 @@ def test_enemy_comm_through_trainer():
     a.batch_size = 16 * 20
     st = tr.train_batch(0)
     assert np.isfinite(st['action_loss'])
+
+
+@pytest.mark.parametrize("workload,E", [("pp_hard", 96), ("tj_hard", 48), ("tj_medium", 64)])
+def test_free_running_graph_rollout_replays_through_oracle(workload, E):
+    """BASELINE shapes (PP-hard / TJ-hard / TJ-medium policies and envs, fewer envs), hipGraph mode: the third episode is
+    a pure graph replay.  Its sampled env actions are replayed through the CPU oracle envs from the same reset: rewards,
+    alive masks, done flags and the episode statistics must agree — and the sampled actions themselves must be the
+    oracle's inverse-CDF draws from the recorded log-probs."""
+    import bench
+    import oracle
+    from oracle import philox
+    tr, a = bench.build_trainer(workload, E, 3, 1000, 0)
+    a.hip_graph = True
+    for ep in range(3):
+        episode, stat = tr.get_episode(ep)
+    env_name, f = bench.WORKLOADS[workload]
+    N, T = a.nagents, a.max_steps
+    act = torch.stack([t.action for t in episode]).cpu().numpy()            # (T, heads, E, N)
+    rew = torch.stack([t.reward for t in episode]).cpu().numpy()
+    alive = torch.stack([t.misc['alive_mask'] for t in episode]).cpu().numpy()
+    live = torch.stack([t.misc['live'] for t in episode]).cpu().numpy()
+    logp0 = torch.stack([t.action_out[0] for t in episode]).cpu().numpy()   # (T, E, N, A)
+    total_reward = np.zeros(N)
+    steps = 0
+    for e in range(E):
+        gid = 1000 + e
+        if env_name == 'predator_prey':
+            o = oracle.PPOracle(N, f['dim'], f['vision'], f['mode'], seed=3, env_gid=gid)
+        else:
+            o = oracle.TJOracle(N, f['dim'], f['vision'], f['difficulty'], add_rate_min=f['add_rate_min'],
+                                add_rate_max=f['add_rate_max'], seed=3, env_gid=gid)
+        for ep in range(3):                                                 # episode counters advance per reset
+            o.reset() if env_name == 'predator_prey' else o.reset(ep)
+        over = False
+        for t in range(T):
+            if over:
+                assert live[t, e] == 0 and not rew[t, e].any()
+                continue
+            assert live[t, e] == 1
+            if e < 8:   # sampling: the device draw equals the oracle's inverse-CDF on the same stream position
+                for n in range(N):
+                    want = oracle.sample_one(logp0[t, e, n], philox.x24(3, gid, philox.DOMAIN_SAMPLE, 2, t, 0 * N + n))
+                    if want != act[t, 0, e, n]:
+                        u = philox.x24(3, gid, philox.DOMAIN_SAMPLE, 2, t, n) / 2.0 ** 24
+                        assert np.abs(np.cumsum(np.exp(logp0[t, e, n].astype(np.float64))) - u).min() < 1e-6
+            oo, orew, od = o.step(act[t, 0, e])
+            np.testing.assert_array_equal(rew[t, e], orew.astype(np.float32))
+            if env_name == 'traffic_junction':
+                np.testing.assert_array_equal(alive[t, e], o.alive.astype(np.float32))
+            total_reward += orew
+            steps += 1
+            over = bool(od)
+    assert stat['num_steps'] == steps
+    np.testing.assert_allclose(stat['reward'], total_reward, rtol=1e-5, atol=1e-4)
