@@ -197,6 +197,8 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if 'IC3_BENCH_DEVICE' in os.environ:      # test hook: several ranks on one GPU (exercises the world>1 control flow)
+        local_rank = int(os.environ['IC3_BENCH_DEVICE'])
     assert world == o.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     cpu = None
