@@ -196,8 +196,8 @@ __device__ __forceinline__ const int2* pp_build_tab(int32_t* smem, const int32_t
     return tab;
 }
 
-template <bool VEC4, bool NT, bool ALIGN>
-__global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
+template <bool VEC4, bool NT, bool ALIGN, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void pp_obs_kernel(const int32_t* __restrict__ loc_r,
                                                      const int32_t* __restrict__ loc_c, float* __restrict__ obs,
                                                      int N, int nprey, int dim, int v, int rows)
 {
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
         // 1 KiB-aligned in the global address space (no partial cache lines except at chunk ends).
         const int o = ALIGN ? (int)(((long long)e * Q) & 63) : 0;
         int g = (int)threadIdx.x - o;
-        if (g < 0) g += 256;
+        if (g < 0) g += THREADS;
         int seg = g / segq, q = g - seg * segq;
-        const int dseg = 256 / segq, dq = 256 - dseg * segq;
-        for (; g < Q; g += 256) {
+        const int dseg = THREADS / segq, dq = THREADS - dseg * segq;
+        for (; g < Q; g += THREADS) {
             const int2 t = tab[seg];
             f32x4 z = { 0.f, 0.f, 0.f, 0.f };
             if ((t.x >> 2) == q) {
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void pp_obs_kernel(const int32_t* __restrict__
         const int total_f = nseg * vocab;
         float* out = obs + (size_t)e * total_f;
         int seg = threadIdx.x / vocab, ch = threadIdx.x - seg * vocab;
-        const int dseg = 256 / vocab, dch = 256 - dseg * vocab;
-        for (int g = threadIdx.x; g < total_f; g += 256) {
+        const int dseg = THREADS / vocab, dch = THREADS - dseg * vocab;
+        for (int g = threadIdx.x; g < total_f; g += THREADS) {
             const int2 t = tab[seg];
             float z = (ch == t.x) ? 1.f : 0.f;
             if (ch == vocab - 2) z += (float)(t.y >> 16);
@@ -345,8 +345,13 @@ int pp_observe(ic3_env* env, float* obs, hipStream_t s)
     const int vocab = c.dim * c.dim + 4;
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     // Geometry/stores chosen by measurement on MI355X (profiles/r01/obs_variants.txt, obs_geometry.txt): one WG per
-    // env with LDS-staged descriptors, plain (not nontemporal) stores, 1 KiB-aligned wave stores.
-    if ((vocab & 3) == 0) {
+    // env with LDS-staged descriptors, plain (not nontemporal) stores, 1 KiB-aligned wave stores; 1024 threads per env
+    // (9 stores per thread for PP-hard) beat 256 (36 per thread) by 4 % — fewer stores per thread is better here.
+    const long long Q = (long long)nseg * (vocab / 4);
+    if ((vocab & 3) == 0 && Q >= 4096) {
+        hipLaunchKernelGGL((pp_obs_kernel<true, false, true, 1024>), dim3(c.E), dim3(1024), lds, s, env->f("loc_r"),
+                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
+    } else if ((vocab & 3) == 0) {
         hipLaunchKernelGGL((pp_obs_kernel<true, false, true>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
                            env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
     } else {   // vocab % 4 != 0 (odd dim): dword stores
