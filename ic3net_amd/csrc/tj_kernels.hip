@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void tj_step_kernel(
 // route_id/(npath-1), one-hot window], all-zero if the car is dead.  CAR channel counts every car on
 // the cell including dead ones parked at (0,0) (quirk Q8).  Rows are 2+W*W*vocab floats (not 16-byte
 // multiples), so this path uses coalesced dword stores; algorithmic bytes per env = N*obs_dim*4.
-__global__ __launch_bounds__(1024) void tj_obs_kernel(const int32_t* __restrict__ alive_s,
+__global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__ alive_s,
                                                      const int32_t* __restrict__ loc_r, const int32_t* __restrict__ loc_c,
                                                      const int32_t* __restrict__ last_act_s,
                                                      const int32_t* __restrict__ route_id_s,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(1024) void tj_obs_kernel(const int32_t* __restrict_
     const int total = N * obs_dim;
     float* out = obs + (size_t)e * total;
     const float inv_vocab = 1.0f / (float)vocab;
-    const int NT = blockDim.x;   // 1024 threads per env for big rows: fewer stores per thread stream faster (see pp_obs)
+    const int NT = blockDim.x;
     int a = threadIdx.x / obs_dim, off = threadIdx.x - a * obs_dim;
     const int da = NT / obs_dim, doff = NT - da * obs_dim;
     for (int g = threadIdx.x; g < total; g += NT) {
@@ -361,8 +361,9 @@ int tj_observe(ic3_env* env, float* obs, hipStream_t s)
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window;
     const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
-    const int threads = (long long)c.N * d.obs_dim >= 16384 ? 1024 : 256;
-    hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(threads), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
+    // 256 threads per env: unlike the float4 PP kernel, this dword-store kernel is slower with 1024 threads inside the
+    // rollout loop (TJ-hard 4.5 vs 5.1 TB/s, measured)
+    hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
                        d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
     IC3_HIP(hipGetLastError());
