@@ -233,6 +233,102 @@ __global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__
     }
 }
 
+// float4 form of tj_obs_kernel for large rows: an env chunk (N*obs_dim floats) is in general neither 16-byte aligned
+// nor a multiple of 16 bytes, so the workgroup writes <= 3 head and <= 3 tail floats with dword stores and the body
+// as float4s whose lane mapping is shifted so that every wave store is 1 KiB-aligned in the global address space;
+// each of a float4's four elements is evaluated on its own (it may sit in another row / window cell).
+__global__ __launch_bounds__(1024) void tj_obs_vec4_kernel(const int32_t* __restrict__ alive_s,
+                                                           const int32_t* __restrict__ loc_r,
+                                                           const int32_t* __restrict__ loc_c,
+                                                           const int32_t* __restrict__ last_act_s,
+                                                           const int32_t* __restrict__ route_id_s,
+                                                           const int32_t* __restrict__ grid, float* __restrict__ obs,
+                                                           int N, int h, int w, int v, int vocab, int outside,
+                                                           int car_class, int npath, int hdr)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x, NT = blockDim.x;
+    const int W = 2 * v + 1, WW = W * W, nseg = N * WW, obs_dim = hdr + WW * vocab;
+    int32_t* sr = smem;
+    int32_t* sc = sr + N;
+    int32_t* sal = sc + N;
+    float* s0 = reinterpret_cast<float*>(sal + N);
+    float* s1 = s0 + N;
+    float* s2 = s1 + N;
+    float* s3 = s2 + N;
+    int2* tab = reinterpret_cast<int2*>(smem + ((7 * N + 3) & ~3));
+    for (int a = threadIdx.x; a < N; a += NT) {
+        const size_t i = (size_t)e * N + a;
+        sr[a] = loc_r[i];
+        sc[a] = loc_c[i];
+        sal[a] = alive_s[i];
+        s0[a] = (float)((double)last_act_s[i] / 1.0);
+        s1[a] = (float)((double)route_id_s[i] / (double)(npath - 1));
+        s2[a] = (float)((double)sr[a] / (double)(h - 1));
+        s3[a] = (float)((double)sc[a] / (double)(w - 1));
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nseg; s += NT) {
+        const int a = s / WW, q = s - a * WW;
+        const int dy = q / W, dx = q - dy * W;
+        const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
+        const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
+        int ncar = 0;
+        for (int p = 0; p < N; ++p) ncar += (sr[p] == gr) & (sc[p] == gc);
+        tab[s] = make_int2(id, ncar);
+    }
+    __syncthreads();
+    const float inv_vocab = 1.0f / (float)vocab;
+    auto value = [&](int a, int off) -> float {     // element `off` of car a's row (TJ:336-362)
+        if (!sal[a]) return 0.0f;
+        if (off < hdr) return off == 0 ? s0[a] : off == 1 ? s1[a] : off == 2 ? s2[a] : s3[a];
+        const int k = off - hdr;
+        const int seg = (int)(((float)k + 0.5f) * inv_vocab);
+        const int ch = k - seg * vocab;
+        const int2 t = tab[a * WW + seg];
+        float z = (ch == t.x) ? 1.0f : 0.0f;
+        if (ch == car_class) z += (float)t.y;
+        return z;
+    };
+    const int L = N * obs_dim;
+    const long long b0 = (long long)e * L;                 // first float of this env in the whole tensor
+    const int head = (int)((4 - (b0 & 3)) & 3);
+    const int nb = (L - head) >> 2, tail = (L - head) & 3;
+    float* out = obs + b0;
+    if ((int)threadIdx.x < head) out[threadIdx.x] = value(0, (int)threadIdx.x);                       // head < 4 <= hdr.. row 0
+    if ((int)threadIdx.x < tail) {
+        const int f = head + 4 * nb + (int)threadIdx.x;
+        out[f] = value(f / obs_dim, f % obs_dim);
+    }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
+    const int o = (int)(((b0 + head) >> 2) & 63);           // 1 KiB-aligned wave stores
+    int j = (int)threadIdx.x - o;
+    if (j < 0) j += NT;
+    int f = head + 4 * j;
+    int a = f / obs_dim, off = f - a * obs_dim;
+    const int step = 4 * NT, da = step / obs_dim, doff = step - da * obs_dim;
+    for (; j < nb; j += NT) {
+        f32x4 z;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ai = a, oi = off + i;
+            if (oi >= obs_dim) {
+                oi -= obs_dim;
+                ++ai;
+            }
+            z[i] = value(ai, oi);
+        }
+        out4[j] = z;
+        a += da;
+        off += doff;
+        if (off >= obs_dim) {
+            off -= obs_dim;
+            ++a;
+        }
+    }
+}
+
 // sparse encoder for Traffic-Junction rows (see pp_encode_kernel): enc[a] = bias (dead car: obs row is zero)
 // or bias + last_act*Wt[0] + route_frac*Wt[1] + sum_cells ( Wt[2+cell*vocab+id] + ncar*Wt[2+cell*vocab+CAR] ).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -361,8 +457,17 @@ int tj_observe(ic3_env* env, float* obs, hipStream_t s)
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window;
     const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
-    // 256 threads per env: unlike the float4 PP kernel, this dword-store kernel is slower with 1024 threads inside the
-    // rollout loop (TJ-hard 4.5 vs 5.1 TB/s, measured)
+    // measured on MI355X in the rollout loop: TJ-hard v1 (26 500 floats/env) 5.64 TB/s with the float4 kernel vs 5.12
+    // with dword stores; TJ-medium v1 (5 330 floats/env) 3.83 vs 4.32 -> float4 only for large chunks
+    if ((long long)c.N * d.obs_dim >= 8192 && d.obs_dim >= 8) {
+        hipLaunchKernelGGL(tj_obs_vec4_kernel, dim3(c.E), dim3(1024), lds, s, env->f("alive"), env->f("loc_r"),
+                           env->f("loc_c"), env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h,
+                           d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
+        IC3_HIP(hipGetLastError());
+        return 0;
+    }
+    // small rows: 256 threads per env with dword stores (with 1024 threads this dword kernel is slower inside the
+    // rollout loop: TJ-hard 4.5 vs 5.1 TB/s, measured)
     hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
                        d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
