@@ -432,3 +432,69 @@ def test_max_agents_per_env_vs_oracle():
     from ic3net_amd.envs import PredatorPreyEnv
     with pytest.raises(ValueError):
         PredatorPreyEnv().multi_agent_init(pp_args(65, 10, 1, "mixed", 2))       # N > 64 is rejected, not mis-simulated
+
+
+def test_randomized_config_sweep_vs_oracle():
+    """40 random Predator-Prey and 30 random Traffic-Junction configurations (odd/even dims -> both obs store paths,
+    vision 0..2, every lane-group size, all modes / difficulties / vocab types, enemy_comm) for a few steps each,
+    compared env by env with the oracle."""
+    import oracle
+    rs = np.random.RandomState(2024)
+    for trial in range(40):
+        dim = int(rs.randint(2, 13))
+        N = int(rs.randint(1, min(12, dim * dim - 1) + 1))
+        v = int(rs.randint(0, 3))
+        mode = ["mixed", "cooperative", "competitive"][rs.randint(3)]
+        ec = bool(rs.rand() < 0.3)
+        no_stay = bool(rs.rand() < 0.2)
+        E = int(rs.randint(1, 20))
+        seed, off = int(rs.randint(1 << 30)), int(rs.randint(1 << 20))
+        env = make_pp(N, dim, v, mode, E, seed=seed, offset=off, no_stay=no_stay, enemy_comm=ec)
+        orcs = [oracle.PPOracle(N, dim, v, mode, stay=not no_stay, seed=seed, env_gid=off + e, enemy_comm=ec)
+                for e in range(E)]
+        R = N + (1 if ec else 0)
+        obs = env.reset().cpu().numpy()
+        for e, o in enumerate(orcs):
+            np.testing.assert_array_equal(obs[e], o.reset(), err_msg="pp reset trial %d" % trial)
+        for t in range(6):
+            act = rs.randint(0, 4 if no_stay else 5, size=(E, R))
+            obs, rew, done, _ = env.step(act)
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            for e, o in enumerate(orcs):
+                if o.over.value:
+                    assert done[e] == 1
+                    continue
+                oo, orew, od = o.step(act[e])
+                np.testing.assert_array_equal(obs[e], oo, err_msg="pp obs trial %d" % trial)
+                np.testing.assert_array_equal(rew[e], orew.astype(np.float32), err_msg="pp reward trial %d" % trial)
+                assert done[e] == int(od)
+    tj_dims = {"easy": [6, 8, 10], "medium": [6, 8, 10, 14], "hard": [9, 12, 15, 18]}
+    for trial in range(30):
+        diff = ["easy", "medium", "hard"][rs.randint(3)]
+        dim = int(tj_dims[diff][rs.randint(len(tj_dims[diff]))])
+        v = int(rs.randint(0, 3))
+        if diff != "hard" and dim < 4 + v:
+            v = 0
+        N = int(rs.randint(1, 25))
+        rate = float([0.05, 0.3, 0.7, 1.0][rs.randint(4)])
+        vt = "scalar" if rs.rand() < 0.3 else "bool"
+        E = int(rs.randint(1, 12))
+        seed, off = int(rs.randint(1 << 30)), int(rs.randint(1 << 20))
+        env = make_tj(N, dim, v, diff, E, seed=seed, offset=off, add_rate_min=rate, add_rate_max=rate, vocab_type=vt)
+        orcs = [oracle.TJOracle(N, dim, v, diff, add_rate_min=rate, add_rate_max=rate, seed=seed, env_gid=off + e,
+                                vocab_type=vt) for e in range(E)]
+        env.reset(0)
+        for o in orcs:
+            o.reset(0)
+        for t in range(10):
+            act = (rs.rand(E, N) < 0.4).astype(np.int32)
+            obs, rew, done, info = env.step(act)
+            obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+            st = env.get_state()
+            for e, o in enumerate(orcs):
+                oo, orew, _ = o.step(act[e])
+                np.testing.assert_array_equal(st["alive"][e], o.alive, err_msg="tj alive trial %d" % trial)
+                np.testing.assert_array_equal(st["route_id"][e], o.route_id)
+                np.testing.assert_array_equal(obs[e], oo, err_msg="tj obs trial %d (%s dim %d v %d N %d %s)" %
+                                              (trial, diff, dim, v, N, vt))
+                np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
