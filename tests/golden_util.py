@@ -33,3 +33,15 @@ class SparseObs(object):
         for a, i, v in self.by_key.get((e, ep, t), []):
             out[a, i] = v
         return out
+
+
+def crc_of(*arrays):
+    """CRC32 chain used by tests/golden/make_golden_sweep.py"""
+    import zlib
+    c = 0
+    for a in arrays:
+        c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
+    return c
+
+
+SWEEP_RATES = [0.05, 0.3, 0.7, 1.0]

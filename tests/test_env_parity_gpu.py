@@ -498,3 +498,42 @@ def test_randomized_config_sweep_vs_oracle():
                 np.testing.assert_array_equal(obs[e], oo, err_msg="tj obs trial %d (%s dim %d v %d N %d %s)" %
                                               (trial, diff, dim, v, N, vt))
                 np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+
+
+def test_hip_reproduces_reference_checksum_sweep():
+    """The same 210-configuration checksum sweep recorded from the reference, through the HIP path (one handle per
+    configuration, E = 1 like the reference)."""
+    from golden_util import crc_of, SWEEP_RATES
+    fx = load("sweep_checksums")
+    seed = int(fx["seed"])
+    for cfg, acts, crcs in zip(fx["pp_cfg"], fx["pp_act"], fx["pp_crc"]):
+        N, dim, v, mode, ec, ns, gid = [int(x) for x in cfg]
+        env = make_pp(N, dim, v, MODES[mode], 1, seed=seed, offset=gid, no_stay=bool(ns), enemy_comm=bool(ec))
+        obs = env.reset().cpu().numpy()[0]
+        st = env.get_state()
+        loc = np.stack([st["loc_r"][0], st["loc_c"][0]], -1)
+        assert crc_of(loc[:N], loc[N:], obs) == crcs[0], cfg
+        over = False
+        for t in range(acts.shape[0]):
+            if over:
+                assert crcs[t + 1] == 0
+                continue
+            obs, rew, done, _ = env.step(acts[t:t + 1, :N + ec])
+            st = env.get_state()
+            loc = np.stack([st["loc_r"][0], st["loc_c"][0]], -1)
+            over = bool(done.cpu().numpy()[0])
+            got = crc_of(loc[:N], st["reached"][0], rew.cpu().numpy()[0], obs.cpu().numpy()[0], np.int32(int(over)))
+            assert got == crcs[t + 1], (cfg, t)
+    for cfg, acts, crcs in zip(fx["tj_cfg"], fx["tj_act"], fx["tj_crc"]):
+        N, dim, v, diff, rate_i, scalar, gid = [int(x) for x in cfg]
+        r = SWEEP_RATES[rate_i]
+        env = make_tj(N, dim, v, DIFFS[diff], 1, seed=seed, offset=gid, add_rate_min=r, add_rate_max=r,
+                      vocab_type='scalar' if scalar else 'bool')
+        env.reset(0)
+        for t in range(acts.shape[0]):
+            obs, rew, _, _ = env.step(acts[t:t + 1, :N])
+            st = env.get_state()
+            loc = np.stack([st["loc_r"][0], st["loc_c"][0]], -1)
+            got = crc_of(st["alive"][0], st["wait"][0], loc, st["last_act"][0], st["route_loc"][0], st["route_id"][0],
+                         rew.cpu().numpy()[0], obs.cpu().numpy()[0])
+            assert got == crcs[t], (cfg, t)

@@ -116,3 +116,32 @@ def test_tj_oracle_matches_reference(name):
                 assert env.add_rate.value == fx["add_rate_seen"][e, ep, t]
                 ref_obs = sp.dense(e, ep, t + 1)
                 np.testing.assert_array_equal(obs, ref_obs)
+
+
+def test_oracle_reproduces_reference_checksum_sweep():
+    """120 random PP and 90 random TJ configurations run through the REFERENCE (tests/golden/make_golden_sweep.py):
+    the oracle must reproduce the CRC32 of (state, reward, obs) at every step — pins it across the config space."""
+    from golden_util import crc_of, SWEEP_RATES
+    fx = load("sweep_checksums")
+    seed = int(fx["seed"])
+    for cfg, acts, crcs in zip(fx["pp_cfg"], fx["pp_act"], fx["pp_crc"]):
+        N, dim, v, mode, ec, ns, gid = [int(x) for x in cfg]
+        env = oracle.PPOracle(N, dim, v, MODES[mode], stay=not ns, seed=seed, env_gid=gid, enemy_comm=bool(ec))
+        obs = env.reset()
+        assert crc_of(env.loc[:N], env.loc[N:], obs) == crcs[0], cfg
+        for t in range(acts.shape[0]):
+            if env.over.value:
+                assert crcs[t + 1] == 0
+                continue
+            obs, rew, done = env.step(acts[t, :N + ec])
+            assert crc_of(env.loc[:N], env.reached, rew.astype(np.float32), obs, np.int32(int(done))) == crcs[t + 1], (cfg, t)
+    for cfg, acts, crcs in zip(fx["tj_cfg"], fx["tj_act"], fx["tj_crc"]):
+        N, dim, v, diff, rate_i, scalar, gid = [int(x) for x in cfg]
+        r = SWEEP_RATES[rate_i]
+        env = oracle.TJOracle(N, dim, v, DIFFS[diff], add_rate_min=r, add_rate_max=r, seed=seed, env_gid=gid,
+                              vocab_type='scalar' if scalar else 'bool')
+        env.reset(0)
+        for t in range(acts.shape[0]):
+            obs, rew, _ = env.step(acts[t, :N])
+            got = crc_of(env.alive, env.wait, env.loc, env.last_act, env.route_loc, env.route_id, rew.astype(np.float32), obs)
+            assert got == crcs[t], (cfg, t)
