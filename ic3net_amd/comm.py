@@ -102,8 +102,8 @@ class CommNetMLP(nn.Module):
     # ------------------------------------------------------------------------------------------
     # Fused rollout path (no autograd): the same math as forward() for the recurrent LSTM policy with one
     # communication pass, restructured around one persistent [inp | h] buffer XH (R, 2H) so that a step is
-    #   encode -> XH[:, :H]      (sparse gather, bias = encoder.bias + C.bias)  \  one launch
-    #   comm_masked_mean(XH[:, H:]) -> comm                                     /  (ic3_env_encode_comm)
+    #   encode -> XH[:, :H]      (sparse gather, bias = encoder.bias + C.bias)          1 kernel
+    #   comm_masked_mean(XH[:, H:])                                                     1 kernel
     #   XH[:, :H] += comm_sum @ C^T                       (fp32 MFMA GEMM, hipBLASLt)   1 kernel
     #   gates = XH @ [W_ih | W_hh]^T + (b_ih + b_hh)      (fp32 MFMA GEMM, hipBLASLt)   1 kernel
     #   lstm_cell: (gates, c) -> c (in place), h' -> XH[:, H:]                          1 kernel
@@ -165,23 +165,17 @@ class CommNetMLP(nn.Module):
         alive = self._mask(info, 'alive_mask', batch, dev)
         comm_action = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
         mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
-        # encoder(x) + C.bias -> XH[:, :H]   (and, with the env's sparse encoder, comm_masked_mean(XH[:, H:]) -> comm
-        # in the same launch: both are one-workgroup-per-env kernels)
-        comm_done = False
+        # encoder(x) + C.bias -> XH[:, :H]
         if self.obs_encoder is not None:
-            self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H],
-                             comm=dict(h=xh.view(batch, n, 2 * H)[:, :, H:], alive=alive, gate=comm_action,
-                                       out=buf['comm'], mode_avg=mode_avg, mask_self=not self.args.comm_mask_zero))
-            comm_done = True
+            self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H])
         else:
             enc = buf.get('enc')
             if enc is None:
                 enc = buf['enc'] = torch.empty((R, H), dtype=torch.float32, device=dev)
             torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)           # dense encoder GEMM
             xh[:, :H].copy_(enc)
-        if not comm_done:
-            ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg,
-                                       not self.args.comm_mask_zero, out=buf['comm'])
+        ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg,
+                                   not self.args.comm_mask_zero, out=buf['comm'])
         xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                          # inp = enc + C(comm_sum)
         if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
             ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel

@@ -279,29 +279,8 @@ int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out,
     if (!env || !Wt || !bias || !out) return fail(-22, "ic3_env_encode: null argument");
     if (ldo <= 0) ldo = H;
     if (H <= 0 || (H & 3) || (ldo & 3) || ldo < H) return fail(-22, "ic3_env_encode: H and ldo must be positive multiples of 4");
-    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, out, ldo, H, CommArgs(), (hipStream_t)stream)
-                                   : tj_encode(env, Wt, bias, out, ldo, H, CommArgs(), (hipStream_t)stream);
-}
-
-int ic3_env_encode_comm(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, const float* h,
-                        int ldh, const int32_t* alive, const int32_t* comm_action, float* comm_out, int mode_avg,
-                        int mask_self, ic3_stream stream)
-{
-    if (!env || !Wt || !bias || !out || !h || !comm_out) return fail(-22, "ic3_env_encode_comm: null argument");
-    if (ldo <= 0) ldo = H;
-    if (ldh <= 0) ldh = H;
-    if (H <= 0 || (H & 3) || (ldo & 3) || ldo < H || (ldh & 3) || ldh < H)
-        return fail(-22, "ic3_env_encode_comm: H, ldo and ldh must be positive multiples of 4");
-    CommArgs cm;
-    cm.h = h;
-    cm.ldh = ldh;
-    cm.alive = alive;
-    cm.gate = comm_action;
-    cm.out = comm_out;
-    cm.mode_avg = mode_avg;
-    cm.mask_self = mask_self;
-    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, out, ldo, H, cm, (hipStream_t)stream)
-                                   : tj_encode(env, Wt, bias, out, ldo, H, cm, (hipStream_t)stream);
+    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream)
+                                   : tj_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream);
 }
 
 int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,

@@ -44,16 +44,6 @@ __host__ __device__ inline uint32_t philox_x24(uint32_t seed, uint32_t env_gid, 
 // floor(u * n) with u = x24 / 2^24, exact in integers
 __host__ __device__ inline uint32_t scale24(uint32_t x24, uint32_t n) { return (uint32_t)(((uint64_t)x24 * n) >> 24); }
 
-// Arguments of the optional communication half of ic3_env_encode_comm (see policy_ops.hip: comm_masked_mean_kernel)
-struct CommArgs {
-    const float* h = nullptr;       // [R][ldh] hidden rows (may be a column slice of the [inp | h] buffer)
-    int ldh = 0;
-    const int32_t* alive = nullptr; // [E][N] or null (all alive)
-    const int32_t* gate = nullptr;  // [E][N] comm_action or null (all talk)
-    float* out = nullptr;           // [E][N][H] contiguous; null = no communication half
-    int mode_avg = 1, mask_self = 1;
-};
-
 struct Field {
     const char* name;
     int64_t off;    // int32 words from state base
@@ -67,36 +57,6 @@ inline int group_lanes(int n)
     while (g < n) g <<= 1;
     return g;
 }
-
-#if defined(__HIPCC__)
-// Communication block of one env (comm.py:181-205, closed form — see comm_masked_mean_kernel) executed by a whole
-// workgroup: idx -> (agent j, 4 hidden columns c4).  sS: LDS scratch of H4 float4s for S = sum_i m_i h_i.
-typedef float comm_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void comm_block_wg(const CommArgs& cm, int e, int N, int H4, comm_f32x4* sS)
-{
-    int n_alive = 0;
-    for (int j = 0; j < N; ++j) n_alive += cm.alive ? cm.alive[(size_t)e * N + j] : 1;
-    const float scale = (cm.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
-    const float* he = cm.h + (size_t)e * N * cm.ldh;
-    for (int k = threadIdx.x; k < H4; k += blockDim.x) {
-        comm_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
-        for (int i = 0; i < N; ++i) {
-            const int m = (cm.alive ? cm.alive[(size_t)e * N + i] : 1) * (cm.gate ? cm.gate[(size_t)e * N + i] : 1);
-            S += (float)m * *reinterpret_cast<const comm_f32x4*>(he + (size_t)i * cm.ldh + 4 * k);
-        }
-        sS[k] = S;
-    }
-    __syncthreads();
-    comm_f32x4* oe = reinterpret_cast<comm_f32x4*>(cm.out) + (size_t)e * N * H4;
-    for (int idx = threadIdx.x; idx < N * H4; idx += blockDim.x) {
-        const int j = idx / H4, k = idx - j * H4;
-        const float m = (float)((cm.alive ? cm.alive[(size_t)e * N + j] : 1) * (cm.gate ? cm.gate[(size_t)e * N + j] : 1));
-        const comm_f32x4 hv = *reinterpret_cast<const comm_f32x4*>(he + (size_t)j * cm.ldh + 4 * k);
-        const comm_f32x4 z = { 0.f, 0.f, 0.f, 0.f };
-        oe[idx] = cm.mask_self ? m * (sS[k] - m * hv) * scale : z;
-    }
-}
-#endif
 
 }  // namespace ic3
 
@@ -140,15 +100,13 @@ int pp_reset(ic3_env* env, hipStream_t s);
 int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s);
 int pp_observe(ic3_env* env, float* obs, hipStream_t s);
-int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, const ic3::CommArgs& cm,
-              hipStream_t s);
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
 // tj_kernels.hip
 int tj_reset(ic3_env* env, hipStream_t s);
 int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s);
 int tj_observe(ic3_env* env, float* obs, hipStream_t s);
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, const ic3::CommArgs& cm,
-              hipStream_t s);
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
 // tj_tables.cpp (host)
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,

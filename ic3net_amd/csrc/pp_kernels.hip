@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ loc_c,
                                                         const f32x4* __restrict__ Wt, const f32x4* __restrict__ bias,
                                                         f32x4* __restrict__ out, int ldo4, int N, int nprey, int dim,
-                                                        int v, int H4, int rows, CommArgs cm)
+                                                        int v, int H4, int rows)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -296,23 +296,17 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
         }
         out[((size_t)e * rows + a) * ldo4 + c4] = acc;
     }
-    if (cm.out) {   // optional communication half (same env, same launch): reuses the LDS behind the descriptor table
-        __syncthreads();
-        comm_block_wg(cm, e, rows, H4, reinterpret_cast<comm_f32x4*>(smem));
-    }
 }
 
-int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, const CommArgs& cm,
-              hipStream_t s)
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
     const int rows = env->dims.N;
     const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = rows * W * W;
-    size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
-    if (cm.out && lds < (size_t)H * sizeof(float)) lds = (size_t)H * sizeof(float);
+    const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
                        reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
-                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows, cm);
+                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows);
     IC3_HIP(hipGetLastError());
     return 0;
 }

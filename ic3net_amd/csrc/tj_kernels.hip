@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ grid, const f32x4* __restrict__ Wt,
                                                         const f32x4* __restrict__ bias, f32x4* __restrict__ out, int ldo4,
                                                         int N, int h, int w, int v, int vocab, int outside,
-                                                        int car_class, int npath, int H4, int hdr, CommArgs cm)
+                                                        int car_class, int npath, int H4, int hdr)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -393,24 +393,18 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
         }
         out[((size_t)e * N + a) * ldo4 + c4] = acc;
     }
-    if (cm.out) {   // optional communication half (same env, same launch)
-        __syncthreads();
-        comm_block_wg(cm, e, N, H4, reinterpret_cast<comm_f32x4*>(smem));
-    }
 }
 
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, const CommArgs& cm,
-              hipStream_t s)
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window;
-    size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
-    if (cm.out && lds < (size_t)H * sizeof(float)) lds = (size_t)H * sizeof(float);
+    const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
     hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
                        reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, c.N, d.grid_h, d.grid_w,
-                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2, cm);
+                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2);
     IC3_HIP(hipGetLastError());
     return 0;
 }

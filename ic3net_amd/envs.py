@@ -100,11 +100,9 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
         return self._obs
 
-    def encode(self, weight_t, bias, out=None, comm=None):
+    def encode(self, weight_t, bias, out=None):
         """encoder(obs(current state)) as a sparse gather (ic3_env_encode): weight_t = encoder.weight.t()
-        contiguous (obs_dim, H), bias (H,) -> (E, N, H) float32.  Equals self.observe() @ weight_t + bias.
-        comm = dict(h, alive, gate, out, mode_avg, mask_self): additionally run the communication block
-        (ops.comm_masked_mean_raw) for the same envs in the same launch (ic3_env_encode_comm)."""
+        contiguous (obs_dim, H), bias (H,) -> (E, N, H) float32.  Equals self.observe() @ weight_t + bias."""
         self._require()
         H = weight_t.shape[1]
         if weight_t.shape[0] != self.obs_dim or not weight_t.is_contiguous() or weight_t.dtype != torch.float32:
@@ -112,14 +110,7 @@ class _BatchedEnv(object):
         if out is None:
             out = torch.empty((self.nenvs, self.nagents_env, H), dtype=torch.float32, device=self.device)
         ldo = H if out.dim() == 3 else out.stride(0)     # (E*N, H) column slice of a wider buffer: row stride
-        if comm is None:
-            check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
-            return out
-        h = comm['h']                                    # (E, N, H), rows unit-stride and evenly spaced
-        assert h.stride(2) == 1 and h.stride(0) == h.shape[1] * h.stride(1) and comm['out'].is_contiguous()
-        check(_lib.lib().ic3_env_encode_comm(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, ptr(h), h.stride(1),
-                                             ptr(comm.get('alive')), ptr(comm.get('gate')), ptr(comm['out']),
-                                             int(comm.get('mode_avg', True)), int(comm.get('mask_self', True)), stream()))
+        check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
         return out
 
     def device_stats(self):

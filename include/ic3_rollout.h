@@ -131,13 +131,6 @@ int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream);
 int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo /* out row stride in floats, 0 = H */,
                    int H, ic3_stream stream);
 
-/* ic3_env_encode + ic3_comm_masked_mean of the same env in ONE launch (both are one-workgroup-per-env kernels over the
- * policy's [inp | h] buffer): out as ic3_env_encode; comm_out [E][N][H] as ic3_comm_masked_mean(h, ldh, alive,
- * comm_action, ...).  The two results are independent (comm reads h, not the fresh encoder output). */
-int ic3_env_encode_comm(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, const float* h,
-                        int ldh, const int32_t* alive, const int32_t* comm_action, float* comm_out, int mode_avg,
-                        int mask_self, ic3_stream stream);
-
 /* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
 int ic3_env_check(ic3_env* env, ic3_stream stream);
 

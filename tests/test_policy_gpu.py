@@ -272,34 +272,3 @@ def test_baseline_models_match_reference(name):
                 logp, v = net(x)
             assert np.abs(logp[0].cpu().numpy() - fx["logp0"][t]).max() < TOL
             assert np.abs(v.cpu().numpy() - fx["value"][t]).max() < TOL
-
-
-def test_encode_comm_fused_launch_equals_separate_ops():
-    """ic3_env_encode_comm == ic3_env_encode + ic3_comm_masked_mean (same env, one launch), PP and TJ."""
-    from test_env_parity_gpu import make_pp, make_tj
-    from ic3net_amd import ops
-    torch.manual_seed(0)
-    for kind in ("pp", "tj"):
-        if kind == "pp":
-            E, N, H = 40, 10, 128
-            env = make_pp(N, 20, 1, "mixed", E, seed=3)
-            env.reset()
-        else:
-            E, N, H = 24, 20, 64
-            env = make_tj(N, 18, 1, "hard", E, seed=3, add_rate_min=0.5, add_rate_max=0.5)
-            env.reset(0)
-            for t in range(6):
-                env.step(torch.zeros((E, N), dtype=torch.int32, device='cuda'))
-        lin = torch.nn.Linear(env.obs_dim, H).cuda()
-        wt, b = lin.weight.detach().t().contiguous(), lin.bias.detach()
-        xh = torch.randn(E * N, 2 * H, device='cuda')
-        alive = (torch.rand(E, N, device='cuda') < 0.7).int()
-        gate = (torch.rand(E, N, device='cuda') < 0.6).int()
-        for a_, g_, avg, ms in ((alive, gate, True, True), (None, gate, False, True), (alive, None, True, False)):
-            ref_xh = xh.clone()
-            env.encode(wt, b, out=ref_xh[:, :H])
-            ref_comm = ops.comm_masked_mean_raw(ref_xh.view(E, N, 2 * H)[:, :, H:], a_, g_, avg, ms)
-            got_xh, got_comm = xh.clone(), torch.empty(E, N, H, device='cuda')
-            env.encode(wt, b, out=got_xh[:, :H], comm=dict(h=got_xh.view(E, N, 2 * H)[:, :, H:], alive=a_, gate=g_,
-                                                            out=got_comm, mode_avg=avg, mask_self=ms))
-            assert torch.equal(got_xh, ref_xh) and torch.equal(got_comm, ref_comm)
