@@ -13,6 +13,7 @@ Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -213,9 +214,10 @@ def main():
     if o.tune_gemm:
         try:
             import torch.cuda.tunable as tunable
+            if hasattr(tunable, 'write_file_on_exit'):          # absent in some torch builds
+                tunable.write_file_on_exit(False)
             tunable.enable(True)
             tunable.tuning_enable(True)
-            tunable.write_file_on_exit(False)
             tunable.set_filename(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ic3_tunableop_%d.csv' % os.getpid()))
         except Exception as exc:
             sys.stderr.write("bench.py: TunableOp unavailable (%r); using the default GEMM heuristics\n" % (exc,))
@@ -272,6 +274,11 @@ def main():
             backend = 'gloo'
     torch.cuda.synchronize()
     raw_env.obs_timer = []
+    # A full CPython GC pass over this process's heap (torch + numpy + the CPU-baseline imports) costs 35-80 ms —
+    # as much as the whole timed region — and where it lands depends on allocation counts, not on the work.
+    # Collect now and move the survivors to the permanent generation, as timeit-style harnesses do.
+    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     t_in_ep = run(o.steps, t_in_ep)
     host_dt = time.perf_counter() - t0        # host-side enqueue time (diagnostic: host- vs GPU-bound)

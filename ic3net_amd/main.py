@@ -11,6 +11,7 @@ multi_processing.py:74-98); `--plot` (visdom) and `--display` through curses are
 text view).  The printed lines keep the format plot_script.py parses.
 """
 import argparse
+import gc
 import os
 import sys
 import time
@@ -157,6 +158,8 @@ def run(argv=None, out=print):
     log = checkpoint.new_log()
     if args.load != '':
         checkpoint.load(args.load, policy_net, log, trainer, map_location=torch.device('cuda', args.device))
+    gc.collect()
+    gc.freeze()            # a full GC pass over the torch heap stalls the launch thread for 35-80 ms
     for ep in range(args.num_epochs):                 # main.py:206-258
         t0 = time.time()
         stat = dict()

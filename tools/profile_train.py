@@ -8,7 +8,14 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 tr, a = bench.build_trainer('pp_hard', E, 0, 0, 0)
 a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                   batch_size=E * a.max_steps)
+if os.environ.get('TUNE', '0') == '1':
+    import torch.cuda.tunable as tunable
+    tunable.enable(True); tunable.tuning_enable(True)
+    tunable.set_filename(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ic3_tunableop_%d.csv' % os.getpid()))
+    tunable.set_max_tuning_duration(30); tunable.set_max_tuning_iterations(20)
 tr.train_batch(0)
+if os.environ.get('TUNE', '0') == '1':
+    torch.cuda.tunable.tuning_enable(False)
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
 for it in range(2):
     a.rollout_grad = True
