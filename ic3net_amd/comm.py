@@ -53,8 +53,9 @@ class CommNetMLP(nn.Module):
         self.value_head = nn.Linear(self.hid_size, 1)
         # Optional fast path for the encoder during rollouts: a callable (weight_t, bias) -> (E,N,H) that evaluates
         # encoder(current observation) straight from env state (envs.encode, the sparse-gather HIP kernel).  Set by
-        # Trainer when args.sparse_encoder; only used under torch.no_grad() (no backward through the gather yet).
+        # Trainer when args.sparse_encoder; under autograd the differentiable variant ops.env_encode is used when obs_env is set.
         self.obs_encoder = None
+        self.obs_env = None         # env handle for the differentiable variant (ops.env_encode); set by Trainer
         self._wt_cache = (None, None)
 
     # ------------------------------------------------------------------------------------------
@@ -193,12 +194,15 @@ class CommNetMLP(nn.Module):
 
     def _encode(self, x):
         """self.encoder(x) (comm.py:51,119); during no-grad rollouts optionally via the env's sparse gather."""
-        if self.obs_encoder is not None and not torch.is_grad_enabled() and self.hid_size % 4 == 0:
+        if self.obs_encoder is not None and self.hid_size % 4 == 0:
             w = self.encoder.weight
             key = (w._version, w.data_ptr())
             if self._wt_cache[0] != key:
                 self._wt_cache = (key, w.detach().t().contiguous())
-            return self.obs_encoder(self._wt_cache[1], self.encoder.bias.detach())
+            if not torch.is_grad_enabled():
+                return self.obs_encoder(self._wt_cache[1], self.encoder.bias.detach())
+            if self.obs_env is not None:       # update half: same gather, backward = ic3_env_encode_backward
+                return ops.env_encode(self.obs_env, w, self.encoder.bias, self._wt_cache[1])
         return self.encoder(x)
 
     def init_hidden(self, batch_size):                            # comm.py:250-253

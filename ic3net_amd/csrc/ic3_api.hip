@@ -283,6 +283,31 @@ int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out,
                                    : tj_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream);
 }
 
+int ic3_env_snapshot(const ic3_env* env, int32_t* snap, ic3_stream stream)
+{
+    if (!env || !snap) return fail(-22, "ic3_env_snapshot: null argument");
+    IC3_HIP(hipMemcpyAsync(snap, env->state, (size_t)env->dims.state_words * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return 0;
+}
+
+int64_t ic3_env_encode_backward_work(const ic3_env* env, int H)
+{
+    if (!env || H <= 0 || (H & 3)) return fail(-22, "ic3_env_encode_backward_work: H must be a positive multiple of 4");
+    return env->kind == IC3_ENV_PP ? pp_encode_bwd_work(env, H) : tj_encode_bwd_work(env, H);
+}
+
+int ic3_env_encode_backward(ic3_env* env, const int32_t* snap, const float* grad_out, int ldg, int H, float* dWt,
+                            float* dbias, float* work, ic3_stream stream)
+{
+    if (!env || !grad_out || !dWt || !work) return fail(-22, "ic3_env_encode_backward: null argument");
+    if (ldg <= 0) ldg = H;
+    if (H <= 0 || (H & 3) || (ldg & 3) || ldg < H)
+        return fail(-22, "ic3_env_encode_backward: H and ldg must be positive multiples of 4");
+    return env->kind == IC3_ENV_PP ? pp_encode_bwd(env, snap, grad_out, ldg, H, dWt, dbias, work, (hipStream_t)stream)
+                                   : tj_encode_bwd(env, snap, grad_out, ldg, H, dWt, dbias, work, (hipStream_t)stream);
+}
+
 int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,
                  int32_t* is_completed, ic3_stream stream)
 {

@@ -107,6 +107,13 @@ int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, 
             hipStream_t s);
 int tj_observe(ic3_env* env, float* obs, hipStream_t s);
 int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
+// sparse-encoder backward (enc_bwd.hpp)
+int64_t pp_encode_bwd_work(const ic3_env* env, int H);
+int64_t tj_encode_bwd_work(const ic3_env* env, int H);
+int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias, float* work,
+                  hipStream_t s);
+int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias, float* work,
+                  hipStream_t s);
 // tj_tables.cpp (host)
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,

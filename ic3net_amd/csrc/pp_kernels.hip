@@ -3,6 +3,9 @@
 // Reference semantics: /root/reference/ic3net-envs/ic3net_envs/predator_prey_env.py (cited "PP:line").
 // State is struct-of-arrays in HBM, one int32 array per field, env-major ([e][n]) so that the lane
 // mapping (env, agent) -> consecutive lanes reads/writes consecutive words.
+#include <algorithm>
+
+#include "enc_bwd.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -307,6 +310,117 @@ int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
     hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
                        reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
                        reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of pp_encode_kernel (enc_bwd.hpp).  Slots: 2*cell -> PREDATOR count (col cell*vocab + vocab-1),
+// 2*cell+1 -> PREY count (col cell*vocab + vocab-2); position of row a = loc[a] (always on the grid).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pp_encode_bwd_kernel(const int32_t* __restrict__ loc_r,
+                                                            const int32_t* __restrict__ loc_c,
+                                                            const float* __restrict__ g, int ldg, float* __restrict__ P,
+                                                            float* __restrict__ Dpart, int E, int chunk, int N, int nprey,
+                                                            int dim, int v, int H, int rows, int tab_words)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int WW = (2 * v + 1) * (2 * v + 1), nslots = 2 * WW;
+    float* gl = reinterpret_cast<float*>(smem + tab_words);
+    float* Dl = gl + rows * H;
+    for (int i = threadIdx.x; i < (nslots + 1) * H; i += blockDim.x) Dl[i] = 0.f;
+    const int e0 = blockIdx.x * chunk, e1 = min(E, e0 + chunk);
+    for (int e = e0; e < e1; ++e) {
+        const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v, rows);   // ends with a barrier
+        const int32_t* sr = smem;
+        const int32_t* sc = smem + (N + nprey);
+        enc_bwd_accumulate(
+            g, ldg, (size_t)e * rows, rows, H, gl, Dl, nslots, P,
+            [&](int a, int s) {
+                const int y = tab[a * WW + (s >> 1)].y;
+                return (float)((s & 1) ? (y >> 16) : (y & 0xffff));
+            },
+            [&](int a) { return sr[a] * dim + sc[a]; });
+    }
+    float* dst = Dpart + (size_t)blockIdx.x * (nslots + 1) * H;
+    for (int i = threadIdx.x; i < (nslots + 1) * H; i += blockDim.x) dst[i] = Dl[i];
+}
+
+// Stage 2 for PP: dWt (zeroed by the caller) += P through the id map, class columns and dbias from the partials.
+__global__ __launch_bounds__(256) void pp_encode_bwd_expand_kernel(const float* __restrict__ P,
+                                                                   const float* __restrict__ Dpart, int nwg,
+                                                                   float* __restrict__ dWt, float* __restrict__ dbias,
+                                                                   int dim, int v, int H)
+{
+    const int W = 2 * v + 1, WW = W * W, nslots = 2 * WW, npos = dim * dim, vocab = dim * dim + 4;
+    const int OUTSIDE = dim * dim + 1;
+    // partials: ENCB_SPLIT of them per thread, so that the reduction over workgroups is spread over many threads
+    const int nsplit = (nwg + ENCB_SPLIT - 1) / ENCB_SPLIT;
+    const long long nA = (long long)WW * npos * H, nB = (long long)(nslots + 1) * H * nsplit;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (i < nA) {
+            const int h = (int)(i % H);
+            const int pos = (int)((i / H) % npos), cell = (int)(i / ((long long)H * npos));
+            const float val = P[(size_t)pos * H + h];
+            if (val == 0.f) continue;
+            const int gr = pos / dim + cell / W - v, gc = pos % dim + cell % W - v;
+            const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
+            atomicAdd(dWt + ((size_t)cell * vocab + id) * H + h, val);
+        } else {
+            const long long j = i - nA;
+            const int h = (int)(j % H), s = (int)((j / H) % (nslots + 1)), part = (int)(j / ((long long)H * (nslots + 1)));
+            float acc = 0.f;
+            const int w1 = min(nwg, (part + 1) * ENCB_SPLIT);
+            for (int w = part * ENCB_SPLIT; w < w1; ++w) acc += Dpart[((size_t)w * (nslots + 1) + s) * H + h];
+            if (s == nslots) {
+                if (dbias) atomicAdd(dbias + h, acc);
+            } else {
+                const int col = (s >> 1) * vocab + ((s & 1) ? vocab - 2 : vocab - 1);
+                atomicAdd(dWt + (size_t)col * H + h, acc);
+            }
+        }
+    }
+}
+
+int encode_bwd_chunk(int E) { return (E + 511) / 512; }
+int encode_bwd_items_b(int nwg, int nslots1, int H) { return nslots1 * H * ((nwg + ENCB_SPLIT - 1) / ENCB_SPLIT); }
+
+int64_t pp_encode_bwd_work(const ic3_env* env, int H)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int WW = (2 * c.vision + 1) * (2 * c.vision + 1);
+    const int chunk = encode_bwd_chunk(c.E), nwg = (c.E + chunk - 1) / chunk;
+    return (int64_t)c.dim * c.dim * H + (int64_t)nwg * (2 * WW + 1) * H;
+}
+
+int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias,
+                  float* work, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int rows = env->dims.N;
+    const int total = c.N + c.nprey, W = 2 * c.vision + 1, WW = W * W, nseg = rows * WW;
+    const int tab_words = (((2 * total + 3) & ~3) + 2 * nseg + 3) & ~3;
+    const size_t lds = ((size_t)tab_words + (size_t)rows * H + (size_t)(2 * WW + 1) * H) * sizeof(int32_t);
+    if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
+    if (lds > 64 * 1024)
+        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pp_encode_bwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int chunk = encode_bwd_chunk(c.E), nwg = (c.E + chunk - 1) / chunk;
+    const int32_t* base = snap ? snap : env->state;
+    const int32_t* loc_r = base + (env->f("loc_r") - env->state);
+    const int32_t* loc_c = base + (env->f("loc_c") - env->state);
+    float* P = work;
+    float* Dpart = work + (size_t)c.dim * c.dim * H;
+    IC3_HIP(hipMemsetAsync(P, 0, (size_t)c.dim * c.dim * H * sizeof(float), s));
+    IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)env->dims.obs_dim * H * sizeof(float), s));
+    hipLaunchKernelGGL(pp_encode_bwd_kernel, dim3(nwg), dim3(256), lds, s, loc_r, loc_c, g, ldg, P, Dpart, c.E, chunk, c.N,
+                       c.nprey, c.dim, c.vision, H, rows, tab_words);
+    if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
+    const long long items = (long long)WW * c.dim * c.dim * H + encode_bwd_items_b(nwg, 2 * WW + 1, H);
+    const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
+    hipLaunchKernelGGL(pp_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, Dpart, nwg, dWt, dbias, c.dim,
+                       c.vision, H);
     IC3_HIP(hipGetLastError());
     return 0;
 }

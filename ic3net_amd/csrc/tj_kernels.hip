@@ -4,6 +4,9 @@
 // One lane group (G = pow2 >= max(N, 8) lanes, inside one wavefront) per environment; the order-dependent
 // `_add_cars` loop runs as <= 8 uniform iterations with ballot-ranked dead-slot selection, the O(N^2)
 // collision test as N lane broadcasts.
+#include <algorithm>
+
+#include "enc_bwd.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -405,6 +408,141 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
                        env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
                        reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, c.N, d.grid_h, d.grid_w,
                        c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of tj_encode_kernel (enc_bwd.hpp).  Slots: 0..hdr-1 the header scalars (cols 0..hdr-1), hdr+cell the
+// car count of window cell `cell` (col hdr + cell*vocab + car_class).  Dead cars have an all-zero obs row: they
+// contribute to dbias only.  Position of a live car = its grid cell.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tj_encode_bwd_kernel(const int32_t* __restrict__ alive_s,
+                                                            const int32_t* __restrict__ loc_r,
+                                                            const int32_t* __restrict__ loc_c,
+                                                            const int32_t* __restrict__ last_act_s,
+                                                            const int32_t* __restrict__ route_id_s,
+                                                            const float* __restrict__ g, int ldg, float* __restrict__ P,
+                                                            float* __restrict__ Dpart, int E, int chunk, int N, int h,
+                                                            int w, int v, int npath, int H, int hdr, int tab_words)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int W = 2 * v + 1, WW = W * W, nseg = N * WW, nslots = hdr + WW;
+    int32_t* sr = smem;
+    int32_t* sc = sr + N;
+    int32_t* sal = sc + N;
+    float* sh = reinterpret_cast<float*>(sal + N);   // [4][N] header scalars
+    int32_t* ncar = smem + ((7 * N + 3) & ~3);        // [nseg]
+    float* gl = reinterpret_cast<float*>(smem + tab_words);
+    float* Dl = gl + N * H;
+    for (int i = threadIdx.x; i < (nslots + 1) * H; i += blockDim.x) Dl[i] = 0.f;
+    const int e0 = blockIdx.x * chunk, e1 = min(E, e0 + chunk);
+    for (int e = e0; e < e1; ++e) {
+        for (int a = threadIdx.x; a < N; a += blockDim.x) {
+            const size_t i = (size_t)e * N + a;
+            sr[a] = loc_r[i];
+            sc[a] = loc_c[i];
+            sal[a] = alive_s[i];
+            sh[a] = (float)((double)last_act_s[i] / 1.0);                       // same expressions as the forward
+            sh[N + a] = (float)((double)route_id_s[i] / (double)(npath - 1));
+            sh[2 * N + a] = (float)((double)sr[a] / (double)(h - 1));
+            sh[3 * N + a] = (float)((double)sc[a] / (double)(w - 1));
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
+            const int a = s / WW, q = s - a * WW;
+            const int gr = sr[a] + q / W - v, gc = sc[a] + q % W - v;
+            int n = 0;
+            for (int p = 0; p < N; ++p) n += (sr[p] == gr) & (sc[p] == gc);
+            ncar[s] = n;
+        }
+        __syncthreads();
+        enc_bwd_accumulate(
+            g, ldg, (size_t)e * N, N, H, gl, Dl, nslots, P,
+            [&](int a, int s) {
+                if (!sal[a]) return 0.f;
+                return s < hdr ? sh[s * N + a] : (float)ncar[a * WW + (s - hdr)];
+            },
+            [&](int a) { return sal[a] ? sr[a] * w + sc[a] : -1; });
+    }
+    float* dst = Dpart + (size_t)blockIdx.x * (nslots + 1) * H;
+    for (int i = threadIdx.x; i < (nslots + 1) * H; i += blockDim.x) dst[i] = Dl[i];
+}
+
+__global__ __launch_bounds__(256) void tj_encode_bwd_expand_kernel(const float* __restrict__ P,
+                                                                   const float* __restrict__ Dpart, int nwg,
+                                                                   const int32_t* __restrict__ grid,
+                                                                   float* __restrict__ dWt, float* __restrict__ dbias,
+                                                                   int h, int w, int v, int vocab, int outside,
+                                                                   int car_class, int H, int hdr)
+{
+    const int W = 2 * v + 1, WW = W * W, nslots = hdr + WW, npos = h * w;
+    const int nsplit = (nwg + ENCB_SPLIT - 1) / ENCB_SPLIT;
+    const long long nA = (long long)WW * npos * H, nB = (long long)(nslots + 1) * H * nsplit;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (i < nA) {
+            const int c = (int)(i % H);
+            const int pos = (int)((i / H) % npos), cell = (int)(i / ((long long)H * npos));
+            const float val = P[(size_t)pos * H + c];
+            if (val == 0.f) continue;
+            const int gr = pos / w + cell / W - v, gc = pos % w + cell % W - v;
+            const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
+            if (id >= 0) atomicAdd(dWt + ((size_t)hdr + (size_t)cell * vocab + id) * H + c, val);   // -1: scalar vocab, off-road
+        } else {
+            const long long j = i - nA;
+            const int c = (int)(j % H), s = (int)((j / H) % (nslots + 1)), part = (int)(j / ((long long)H * (nslots + 1)));
+            float acc = 0.f;
+            const int k1 = min(nwg, (part + 1) * ENCB_SPLIT);
+            for (int k = part * ENCB_SPLIT; k < k1; ++k) acc += Dpart[((size_t)k * (nslots + 1) + s) * H + c];
+            if (s == nslots) {
+                if (dbias) atomicAdd(dbias + c, acc);
+            } else {
+                const size_t col = s < hdr ? (size_t)s : (size_t)hdr + (size_t)(s - hdr) * vocab + car_class;
+                atomicAdd(dWt + col * H + c, acc);
+            }
+        }
+    }
+}
+
+int encode_bwd_chunk(int E);
+int encode_bwd_items_b(int nwg, int nslots1, int H);
+
+int64_t tj_encode_bwd_work(const ic3_env* env, int H)
+{
+    const ic3_dims& d = env->dims;
+    const int WW = d.window * d.window, hdr = env->tj.vocab_type ? 4 : 2;
+    const int chunk = encode_bwd_chunk(env->tj.E), nwg = (env->tj.E + chunk - 1) / chunk;
+    return (int64_t)d.grid_h * d.grid_w * H + (int64_t)nwg * (hdr + WW + 1) * H;
+}
+
+int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias,
+                  float* work, hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const ic3_dims& d = env->dims;
+    const int WW = d.window * d.window, hdr = c.vocab_type ? 4 : 2;
+    const int tab_words = (((7 * c.N + 3) & ~3) + c.N * WW + 3) & ~3;
+    const size_t lds = ((size_t)tab_words + (size_t)c.N * H + (size_t)(hdr + WW + 1) * H) * sizeof(int32_t);
+    if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
+    if (lds > 64 * 1024)
+        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tj_encode_bwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int chunk = encode_bwd_chunk(c.E), nwg = (c.E + chunk - 1) / chunk;
+    const int32_t* base = snap ? snap : env->state;
+    auto fld = [&](const char* name) { return base + (env->f(name) - env->state); };
+    float* P = work;
+    float* Dpart = work + (size_t)d.grid_h * d.grid_w * H;
+    IC3_HIP(hipMemsetAsync(P, 0, (size_t)d.grid_h * d.grid_w * H * sizeof(float), s));
+    IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)d.obs_dim * H * sizeof(float), s));
+    hipLaunchKernelGGL(tj_encode_bwd_kernel, dim3(nwg), dim3(256), lds, s, fld("alive"), fld("loc_r"), fld("loc_c"),
+                       fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, chunk, c.N, d.grid_h, d.grid_w, c.vision,
+                       d.npath, H, hdr, tab_words);
+    if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
+    const long long items = (long long)WW * d.grid_h * d.grid_w * H + encode_bwd_items_b(nwg, hdr + WW + 1, H);
+    const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
+    hipLaunchKernelGGL(tj_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, Dpart, nwg, env->d_grid, dWt, dbias,
+                       d.grid_h, d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, H, hdr);
     IC3_HIP(hipGetLastError());
     return 0;
 }

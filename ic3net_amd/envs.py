@@ -113,6 +113,37 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
         return out
 
+    def snapshot(self, out=None):
+        """Device copy of the integer state (ic3_env_snapshot), the handle encode_backward needs later."""
+        self._require()
+        if out is None:
+            out = torch.empty((self.dims.state_words,), dtype=torch.int32, device=self.device)
+        check(_lib.lib().ic3_env_snapshot(self._h, ptr(out), stream()))
+        return out
+
+    def encode_backward(self, grad_out, snap=None, want_bias=True):
+        """Gradient of encode() w.r.t. (weight_t, bias) for the state in `snap` (None = current state):
+        returns (obs^T @ grad_out as (obs_dim, H), grad_out.sum over rows as (H,))  — ic3_env_encode_backward."""
+        self._require()
+        H = grad_out.shape[-1]
+        g = grad_out.reshape(-1, H)
+        if g.dtype != torch.float32 or g.stride(1) != 1 or g.shape[0] != self.nenvs * self.nagents_env:
+            raise ValueError("encode_backward: grad_out must be float32 (E*N, H) with unit inner stride")
+        key = ('encb', H)
+        work = self._scratch.get(key) if hasattr(self, '_scratch') else None
+        if work is None:
+            if not hasattr(self, '_scratch'):
+                self._scratch = {}
+            n = _lib.lib().ic3_env_encode_backward_work(self._h, H)
+            if n < 0:
+                check(int(n))
+            work = self._scratch[key] = torch.empty((n,), dtype=torch.float32, device=self.device)
+        dwt = torch.empty((self.obs_dim, H), dtype=torch.float32, device=self.device)
+        dbias = torch.empty((H,), dtype=torch.float32, device=self.device) if want_bias else None
+        check(_lib.lib().ic3_env_encode_backward(self._h, ptr(snap) if snap is not None else None, ptr(g), g.stride(0), H,
+                                                 ptr(dwt), ptr(dbias) if want_bias else None, ptr(work), stream()))
+        return dwt, dbias
+
     def device_stats(self):
         s = _lib.Stats()
         check(_lib.lib().ic3_env_stats(self._h, C.byref(s), stream()))

@@ -39,7 +39,7 @@ _FLAGS = [
     ('share_weights', 'flag', False),
 ]
 # engine flags (new)
-_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', 'flag', False)]
+_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', 'flag', False), ('tune_gemm', 'flag', False)]
 
 
 def build_parser(argv):
@@ -158,6 +158,11 @@ def run(argv=None, out=print):
     log = checkpoint.new_log()
     if args.load != '':
         checkpoint.load(args.load, policy_net, log, trainer, map_location=torch.device('cuda', args.device))
+    if args.tune_gemm:     # TunableOp times the hipBLASLt/rocBLAS candidates for every GEMM shape of the first update
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_filename(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ic3_tunableop_%d.csv' % os.getpid()))
     gc.collect()
     gc.freeze()            # a full GC pass over the torch heap stalls the launch thread for 35-80 ms
     for ep in range(args.num_epochs):                 # main.py:206-258
@@ -168,6 +173,8 @@ def run(argv=None, out=print):
                 trainer.display = True
             merge_stat(trainer.train_batch(ep), stat)
             trainer.display = False
+            if args.tune_gemm and ep == 0 and n == 0:
+                torch.cuda.tunable.tuning_enable(False)      # keep the selections, stop tuning
         epoch_time = time.time() - t0
         epoch = normalise_epoch(stat, log)
         if rank == 0:

@@ -24,6 +24,32 @@ class _CommMaskedMean(torch.autograd.Function):
         return comm_masked_mean_raw(g.contiguous(), ctx.alive, ctx.comm_action, ctx.mode_avg, ctx.mask_self), None, None, None, None
 
 
+class _EnvEncode(torch.autograd.Function):
+    """encoder(obs(env state)) with a backward: forward = the sparse gather ic3_env_encode, backward = the
+    position-sum scatter ic3_env_encode_backward on a snapshot of the integer state (no dense obs is kept)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, env, weight_t):
+        out = env.encode(weight_t, bias.detach())
+        ctx.env = env
+        ctx.snap = env.snapshot()
+        ctx.need_bias = bias.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dwt, dbias = ctx.env.encode_backward(g.contiguous(), ctx.snap, want_bias=ctx.need_bias)
+        return dwt.t().contiguous(), dbias, None, None      # contiguous: grads may be all-reduced (sharding.py)
+
+
+def env_encode(env, weight, bias, weight_t=None):
+    """nn.Linear(obs_dim, H)(env's current observation) -> (E, N, H), differentiable w.r.t. weight (H, obs_dim) and
+    bias; weight_t = weight.t().contiguous() if the caller caches it."""
+    if weight_t is None:
+        weight_t = weight.detach().t().contiguous()
+    return _EnvEncode.apply(weight, bias, env, weight_t)
+
+
 def _rows(t, H):
     """(tensor usable by the kernels, row stride in floats) for a (..., H) fp32 tensor whose rows are unit-stride
     and evenly spaced (e.g. a column slice of a wider row-major buffer); anything else is made contiguous."""

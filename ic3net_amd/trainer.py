@@ -50,6 +50,8 @@ class Trainer(object):
         if getattr(args, 'sparse_encoder', True) and hasattr(policy_net, 'obs_encoder') \
                 and hasattr(getattr(env, 'env', None), 'encode'):
             policy_net.obs_encoder = env.env.encode
+            if getattr(args, 'sparse_encoder_grad', True) and hasattr(policy_net, 'obs_env'):
+                policy_net.obs_env = env.env        # rollouts under autograd: gather forward + scatter backward
 
     # ------------------------------------------------------------------------------------------
     def get_episode(self, epoch):
@@ -148,7 +150,7 @@ class Trainer(object):
         with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):
             if t == 0 and args.hard_attn and args.commnet:         # trainer.py:45-46 (quirk Q22)
                 info['comm_action'] = self._zeros_comm
-            if torch.is_grad_enabled():
+            if torch.is_grad_enabled() and getattr(self.policy_net, 'obs_env', None) is None:
                 state = state.clone()          # the env reuses its obs buffer; autograd keeps the encoder input
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:

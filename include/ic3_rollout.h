@@ -131,6 +131,19 @@ int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream);
 int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo /* out row stride in floats, 0 = H */,
                    int H, ic3_stream stream);
 
+/* Backward of ic3_env_encode for the update half (trainer.py:128-225 backpropagates through comm.py:51,119's
+ * nn.Linear): given grad_out = dL/d out [E][N][H] (row stride ldg floats, 0 = H) it overwrites
+ *   dWt   [obs_dim][H] = obs^T x grad_out   (the gradient of encoder.weight, transposed)
+ *   dbias [H]          = sum of grad_out rows (may be NULL)
+ * for the observation of the state held in `snap` (a device copy of the integer state taken with ic3_env_snapshot
+ * at the time of the forward; NULL = the current state).  `work` is caller-owned scratch of
+ * ic3_env_encode_backward_work(env, H) floats.  Mathematically identical to the dense product (fp32 atomics: the
+ * summation order, hence the last ulp, varies from run to run). */
+int ic3_env_snapshot(const ic3_env* env, int32_t* snap /* device, dims.state_words int32 */, ic3_stream stream);
+int64_t ic3_env_encode_backward_work(const ic3_env* env, int H);
+int ic3_env_encode_backward(ic3_env* env, const int32_t* snap, const float* grad_out, int ldg, int H, float* dWt,
+                            float* dbias, float* work, ic3_stream stream);
+
 /* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
 int ic3_env_check(ic3_env* env, ic3_stream stream);
 

@@ -1,0 +1,99 @@
+"""ic3_env_encode_backward (the update half's gradient of comm.py:51,119's nn.Linear, trainer.py:128-225) against the
+dense fp64 product obs^T @ g, on states reached by random play; plus the autograd wiring (ops.env_encode) and the
+snapshot semantics (backward of an earlier step after the env has moved on)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("pp", dict(N=10, dim=20, v=1, H=128, E=96)), ("pp", dict(N=3, dim=5, v=0, H=64, E=33)),
+         ("pp", dict(N=32, dim=40, v=2, H=256, E=5)), ("pp", dict(N=4, dim=7, v=1, H=32, E=700)),
+         ("pp", dict(N=5, dim=8, v=1, H=32, E=64, enemy_comm=True)),
+         ("tj", dict(N=10, dim=14, v=1, diff="medium", H=128, E=64)), ("tj", dict(N=20, dim=18, v=0, diff="hard", H=128, E=32)),
+         ("tj", dict(N=5, dim=6, v=1, diff="easy", H=32, E=17)), ("tj", dict(N=5, dim=6, v=1, diff="easy", H=32, E=1100)),
+         ("tj", dict(N=10, dim=14, v=1, diff="medium", H=64, E=48, vocab_type="scalar"))]
+
+
+def build(kind, c, seed=1):
+    from test_env_parity_gpu import make_pp, make_tj
+    if kind == "pp":
+        env = make_pp(c['N'], c['dim'], c['v'], "mixed" if not c.get('enemy_comm') else "cooperative", c['E'], seed=seed,
+                      **({'enemy_comm': True} if c.get('enemy_comm') else {}))
+        env.reset()
+        return env, 5
+    env = make_tj(c['N'], c['dim'], c['v'], c['diff'], c['E'], seed=seed, add_rate_min=0.4, add_rate_max=0.4,
+                  **({'vocab_type': c['vocab_type']} if c.get('vocab_type') else {}))
+    env.reset(0)
+    return env, 2
+
+
+def play(env, nact, steps, gen):
+    E, N = env.nenvs, env.nagents_env
+    for _ in range(steps):
+        env.step(torch.randint(0, nact, (E, N), device='cuda', dtype=torch.int32, generator=gen))
+
+
+@pytest.mark.parametrize("kind,c", CASES)
+def test_encode_backward_equals_dense(kind, c):
+    env, nact = build(kind, c)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    H, R = c['H'], env.nenvs * env.nagents_env
+    for steps in (0, 6, 7):
+        play(env, nact, steps, gen)
+        obs = env.observe().reshape(R, -1).double()
+        g = torch.randn(R, H, device='cuda', generator=gen)
+        dwt, db = env.encode_backward(g)
+        ref = obs.t() @ g.double()
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((dwt.double() - ref).abs().max()) <= 2e-6 * scale
+        torch.testing.assert_close(db.double(), g.double().sum(0), atol=2e-6 * max(1.0, R ** 0.5), rtol=0)
+        # strided grad_out (a column slice of a wider buffer) and no bias
+        wide = torch.randn(R, 2 * H, device='cuda', generator=gen)
+        dwt2, none = env.encode_backward(wide[:, H:], want_bias=False)
+        assert none is None
+        ref2 = obs.t() @ wide[:, H:].double()
+        assert float((dwt2.double() - ref2).abs().max()) <= 2e-6 * max(1.0, float(ref2.abs().max()))
+
+
+def test_snapshot_is_the_state_of_the_forward():
+    env, nact = build("pp", CASES[0][1])
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    play(env, nact, 4, gen)
+    R, H = env.nenvs * env.nagents_env, 128
+    obs_then = env.observe().reshape(R, -1).double().clone()
+    snap = env.snapshot()
+    play(env, nact, 5, gen)                                   # the env moves on
+    g = torch.randn(R, H, device='cuda', generator=gen)
+    dwt, _ = env.encode_backward(g, snap)
+    ref = obs_then.t() @ g.double()
+    assert float((dwt.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    now = env.observe().reshape(R, -1).double().t() @ g.double()
+    assert float((dwt.double() - now).abs().max()) > 1e-3      # and it is not the current state's gradient
+
+
+@pytest.mark.parametrize("kind,c", [CASES[0], CASES[5]])
+def test_env_encode_autograd_matches_linear(kind, c):
+    """Two-step chain through ops.env_encode: parameter gradients equal those of nn.Linear on the cloned observations."""
+    from ic3net_amd import ops
+    env, nact = build(kind, c)
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(env.obs_dim, c['H']).cuda()
+    ref = torch.nn.Linear(env.obs_dim, c['H']).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    loss, loss_ref = 0, 0
+    for step in range(3):
+        play(env, nact, 2, gen)
+        mix = torch.randn(env.nenvs, env.nagents_env, c['H'], device='cuda', generator=gen)
+        out = ops.env_encode(env, lin.weight, lin.bias)
+        out_ref = ref(env.observe().double().clone())
+        torch.testing.assert_close(out.double(), out_ref, atol=2e-6, rtol=0)
+        loss = loss + (torch.tanh(out) * mix).sum()
+        loss_ref = loss_ref + (torch.tanh(out_ref) * mix.double()).sum()
+    loss.backward()
+    loss_ref.backward()
+    for p, q in zip(lin.parameters(), ref.parameters()):
+        assert p.grad.is_contiguous()
+        scale = max(1.0, float(q.grad.abs().max()))
+        assert float((p.grad.double() - q.grad).abs().max()) <= 5e-6 * scale

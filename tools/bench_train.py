@@ -14,7 +14,19 @@ def main():
     tr, a = bench.build_trainer('pp_hard', E, 0, 0, 0)
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=E * a.max_steps)
+    tune = os.environ.get('TUNE', '1') == '1'
+    if tune:                                  # TunableOp picks the GEMM solutions during the first (untimed) update
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_filename(os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ic3_tunableop_%d.csv' % os.getpid()))
     tr.train_batch(0)
+    if tune:
+        torch.cuda.tunable.tuning_enable(False)
+    import gc
+    gc.collect()
+    gc.freeze()
+    torch.cuda.reset_peak_memory_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps = 0
@@ -24,8 +36,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("train_batch PP-hard E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
-          "peak mem %.1f GB" % (E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates, steps // updates,
-                                torch.cuda.max_memory_allocated() / 2 ** 30))
+          "peak mem %.1f GB, gemm %s" % (E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates, steps // updates,
+                                torch.cuda.max_memory_allocated() / 2 ** 30, 'TunableOp' if tune else 'default'))
 
 
 if __name__ == '__main__':
