@@ -188,6 +188,8 @@ def main():
                    help='replay the per-step launch sequence as hipGraphs (Trainer args.hip_graph)')
     p.add_argument('--no-dense-obs', action='store_true',
                    help='diagnostic: skip obs assembly (sparse encoder consumes env state directly); NOT the headline config')
+    p.add_argument('--overlap-obs', type=int, default=int(os.environ.get('IC3_BENCH_OVERLAP_OBS', '0')),
+                   help='assemble the dense observation on a second stream, overlapped with the next step (graph mode)')
     p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
                    help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
     p.add_argument('--tune-gemm', type=int, default=int(os.environ.get('IC3_BENCH_TUNE_GEMM', '1')),
@@ -226,6 +228,7 @@ def main():
     a.hip_graph = bool(o.graph)
     a.dense_obs = not o.no_dense_obs
     a.fused_lstm = bool(o.fused_lstm)
+    a.overlap_obs = bool(o.overlap_obs)
     T = a.max_steps
     raw_env = trainer.env.env
 
@@ -317,6 +320,7 @@ def main():
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
                        "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world,
                        "launch": "hipGraph replay" if o.graph else "eager", "dense_obs": not o.no_dense_obs,
+                       "overlap_obs": bool(o.overlap_obs),
                        "gemm": "TunableOp-selected" if o.tune_gemm else "default heuristics"},
             "roofline": {"kernel": "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

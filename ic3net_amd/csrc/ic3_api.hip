@@ -274,6 +274,15 @@ int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream)
     return env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
 }
 
+int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream stream)
+{
+    if (!env || !obs) return fail(-22, "ic3_env_observe_at: null argument");
+    env->view = snap;
+    const int rc = env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
+    env->view = nullptr;
+    return rc;
+}
+
 int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, ic3_stream stream)
 {
     if (!env || !Wt || !bias || !out) return fail(-22, "ic3_env_encode: null argument");

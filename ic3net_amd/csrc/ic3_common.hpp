@@ -81,6 +81,8 @@ struct ic3_env {
     double exact_rate = 0, add_rate = 0, epoch_last_update = 0;
 
     int32_t* f(const char* name) const;
+    const int32_t* view = nullptr;  // when set: the observation kernels read this snapshot instead of `state`
+    const int32_t* fv(const char* name) const { return (view ? view : state) + (f(name) - state); }
 };
 
 namespace ic3 {

@@ -463,14 +463,14 @@ int pp_observe(ic3_env* env, float* obs, hipStream_t s)
     // (9 stores per thread for PP-hard) beat 256 (36 per thread) by 4 % — fewer stores per thread is better here.
     const long long Q = (long long)nseg * (vocab / 4);
     if ((vocab & 3) == 0 && Q >= 4096) {
-        hipLaunchKernelGGL((pp_obs_kernel<true, false, true, 1024>), dim3(c.E), dim3(1024), lds, s, env->f("loc_r"),
-                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
+        hipLaunchKernelGGL((pp_obs_kernel<true, false, true, 1024>), dim3(c.E), dim3(1024), lds, s, env->fv("loc_r"),
+                           env->fv("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
     } else if ((vocab & 3) == 0) {
-        hipLaunchKernelGGL((pp_obs_kernel<true, false, true>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
-                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
+        hipLaunchKernelGGL((pp_obs_kernel<true, false, true>), dim3(c.E), dim3(256), lds, s, env->fv("loc_r"),
+                           env->fv("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
     } else {   // vocab % 4 != 0 (odd dim): dword stores
-        hipLaunchKernelGGL((pp_obs_kernel<false, false, false>), dim3(c.E), dim3(256), lds, s, env->f("loc_r"),
-                           env->f("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
+        hipLaunchKernelGGL((pp_obs_kernel<false, false, false>), dim3(c.E), dim3(256), lds, s, env->fv("loc_r"),
+                           env->fv("loc_c"), obs, c.N, c.nprey, c.dim, c.vision, rows);
     }
     IC3_HIP(hipGetLastError());
     return 0;

@@ -598,16 +598,16 @@ int tj_observe(ic3_env* env, float* obs, hipStream_t s)
     // measured on MI355X in the rollout loop: TJ-hard v1 (26 500 floats/env) 5.64 TB/s with the float4 kernel vs 5.12
     // with dword stores; TJ-medium v1 (5 330 floats/env) 3.83 vs 4.32 -> float4 only for large chunks
     if ((long long)c.N * d.obs_dim >= 8192 && d.obs_dim >= 8) {
-        hipLaunchKernelGGL(tj_obs_vec4_kernel, dim3(c.E), dim3(1024), lds, s, env->f("alive"), env->f("loc_r"),
-                           env->f("loc_c"), env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h,
+        hipLaunchKernelGGL(tj_obs_vec4_kernel, dim3(c.E), dim3(1024), lds, s, env->fv("alive"), env->fv("loc_r"),
+                           env->fv("loc_c"), env->fv("last_act"), env->fv("route_id"), env->d_grid, obs, c.N, d.grid_h,
                            d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
         IC3_HIP(hipGetLastError());
         return 0;
     }
     // small rows: 256 threads per env with dword stores (with 1024 threads this dword kernel is slower inside the
     // rollout loop: TJ-hard 4.5 vs 5.1 TB/s, measured)
-    hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
-                       env->f("last_act"), env->f("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
+    hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->fv("alive"), env->fv("loc_r"), env->fv("loc_c"),
+                       env->fv("last_act"), env->fv("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
                        d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
     IC3_HIP(hipGetLastError());
     return 0;

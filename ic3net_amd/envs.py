@@ -180,14 +180,17 @@ class _BatchedEnv(object):
         self._last = (reward, done, alive, completed)
         return self._obs, reward, done
 
-    def observe_timed(self):
-        """The obs-assembly launch, bracketed by HIP events on the launch stream when `obs_timer` is a list."""
+    def observe_timed(self, snap=None):
+        """The obs-assembly launch (of the current state, or of a snapshot), bracketed by HIP events on the launch
+        stream when `obs_timer` is a list."""
+        sp = ptr(snap) if snap is not None else None
         if self.obs_timer is None:
-            return self.observe()
+            check(_lib.lib().ic3_env_observe_at(self._h, sp, ptr(self._obs), stream()))
+            return self._obs
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())
-        check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
+        check(_lib.lib().ic3_env_observe_at(self._h, sp, ptr(self._obs), stream()))
         e1.record(torch.cuda.current_stream())
         self.obs_timer.append((e0, e1))
         return self._obs

@@ -138,7 +138,10 @@ class Trainer(object):
         self.clock.t = t
         g['graph'].replay()
         if not g['obs_inside'] and self._dense_obs():
-            raw.observe_timed()
+            if getattr(self.args, 'overlap_obs', False):
+                self._observe_on_side_stream(raw)
+            else:
+                raw.observe_timed()
         self._state, self._info, self._prev_hid, self._step_out[t] = g['outputs']
         self._nsteps = t + 1
 
@@ -185,10 +188,35 @@ class Trainer(object):
             self._info = info
             self._nsteps = t + 1
 
+    def _observe_on_side_stream(self, raw):
+        """args.overlap_obs: the dense observation of the new state is assembled on a second stream from a snapshot
+        of the integer state (ic3_env_snapshot / ic3_env_observe_at), so this HBM-write-bound launch overlaps the
+        MFMA-bound policy kernels of the next step instead of delaying them.  Nothing on the rollout path reads the
+        dense observation (the encoder gathers from the state); consumers join in end_episode()."""
+        main = torch.cuda.current_stream()
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=main.device)
+            self._snaps = [raw.snapshot(), raw.snapshot()]
+            self._snap_busy = [None, None]
+            self._snap_k = 0
+        k = self._snap_k
+        self._snap_k ^= 1
+        if self._snap_busy[k] is not None:
+            main.wait_event(self._snap_busy[k])          # the launch that read this snapshot two steps ago
+        raw.snapshot(out=self._snaps[k])
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            raw.observe_timed(self._snaps[k])
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._snap_busy[k] = ev
+
     def end_episode(self):
         """Everything get_episode derives per step in the reference (trainer.py:70-105), vectorised over the
         episode buffers: live / alive / episode masks, per-agent reward and comm-action sums, step counts."""
         args = self.args
+        if getattr(self, '_side', None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)    # observations assembled on the side stream
         n, buf = self._nsteps, self._buf
         E, N = buf['reward'].shape[1:]
         dev = buf['reward'].device

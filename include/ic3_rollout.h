@@ -123,6 +123,9 @@ int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward
 
 /* Observation of the current state without stepping (what reset/step return), obs [E][N][obs_dim]. */
 int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream);
+/* Same for the state held in a snapshot (ic3_env_snapshot; NULL = current state): lets the caller assemble the
+ * observation of step t on a second stream while the policy / step kernels of step t+1 already run. */
+int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream stream);
 
 /* encoder(obs(state)) without reading the observation back: out[e][n][:] = bias + sum_k obs[e][n][k] * Wt[k][:]
  * — the nn.Linear(obs_dim, hid) of comm.py:51,119 evaluated as a gather over the few non-zero obs entries
