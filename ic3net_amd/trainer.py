@@ -120,7 +120,7 @@ class Trainer(object):
         if g is None:
             # capture: the launch sequence of step t (policy kernels, sampling, env step [, obs assembly]) with the
             # buffers it reads/writes.  The obs launch stays outside the graph while it is being event-timed.
-            in_graph_obs = raw.obs_timer is None and self._dense_obs()
+            in_graph_obs = raw.obs_timer is None and self._dense_obs() and not getattr(self.args, 'overlap_obs', False)
             saved = (self._state, self._info, self._prev_hid)
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:

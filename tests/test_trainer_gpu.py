@@ -147,10 +147,11 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
     from ic3net_amd.action_utils import parse_action_args
     from ic3net_amd.comm import CommNetMLP
 
-    def run(graph):
+    def run(graph, overlap=False):
         a = build_args(env_name, dict(flags), flags['nagents'], 12, 64, 5)
         a.env_id_offset = 0
         a.hip_graph = graph
+        a.overlap_obs = overlap
         env = data.init(env_name, a, False)
         a.num_actions = [env.num_actions]
         a.dim_actions = env.dim_actions
@@ -174,13 +175,21 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
     eager, _ = run(False)
     graphed, tr = run(True)
     assert len(tr._graphs) == 12
-    for ep, (e, g) in enumerate(zip(eager, graphed)):
-        for i in range(4):
-            for x, y in zip(e[i], g[i]):
-                assert torch.equal(x, y), (ep, i)
-        assert set(e[4]) == set(g[4])
-        for k in e[4]:
-            np.testing.assert_array_equal(e[4][k], g[4][k], err_msg=k)
+    # args.overlap_obs: observation assembled on a second stream from a state snapshot (ic3_env_observe_at)
+    lapped, tr2 = run(True, overlap=True)
+    assert tr2._side is not None
+    raw = tr2.env.env
+    torch.cuda.synchronize()
+    last_obs = raw._obs.clone()
+    assert torch.equal(last_obs, raw.observe())            # the side stream produced the observation of the final state
+    for other in (graphed, lapped):
+        for ep, (e, g) in enumerate(zip(eager, other)):
+            for i in range(4):
+                for x, y in zip(e[i], g[i]):
+                    assert torch.equal(x, y), (ep, i)
+            assert set(e[4]) == set(g[4])
+            for k in e[4]:
+                np.testing.assert_array_equal(e[4][k], g[4][k], err_msg=k)
 
 
 GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_commnet_norm", "predator_prey"),
