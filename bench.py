@@ -224,6 +224,11 @@ def main():
         except Exception as exc:
             sys.stderr.write("bench.py: TunableOp unavailable (%r); using the default GEMM heuristics\n" % (exc,))
             o.tune_gemm = 0
+            try:                                     # leave nothing half-enabled
+                torch.cuda.tunable.tuning_enable(False)
+                torch.cuda.tunable.enable(False)
+            except Exception:
+                pass
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
     a.hip_graph = bool(o.graph)
     a.dense_obs = not o.no_dense_obs

@@ -15,7 +15,6 @@ Differences forced by batching:
 from collections import namedtuple
 from inspect import signature
 
-import numpy as np
 import torch
 from torch import optim
 

@@ -1,7 +1,6 @@
 """ic3_env_encode_backward (the update half's gradient of comm.py:51,119's nn.Linear, trainer.py:128-225) against the
 dense fp64 product obs^T @ g, on states reached by random play; plus the autograd wiring (ops.env_encode) and the
 snapshot semantics (backward of an earlier step after the env has moved on)."""
-import numpy as np
 import pytest
 import torch
 

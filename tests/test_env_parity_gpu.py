@@ -230,7 +230,6 @@ def test_bad_action_flag_and_errors():
 
 def test_reference_style_single_env_calls():
     """E = 1 drop-in: list-of-arrays actions through GymWrapper like the reference's Trainer passes them."""
-    import argparse as ap
     from ic3net_amd import data
     import oracle
     a = pp_args(3, 5, 1, "mixed", 1, seed=4, offset=17)
