@@ -50,7 +50,9 @@ EXPORTS = {
     "ic3_env_step": (C.c_int, [C.c_void_p] * 7 + [C.c_void_p]),
     "ic3_env_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_observe_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "ic3_env_encode_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ic3_env_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_encode_backward_work": (C.c_int64, [C.c_void_p, C.c_int]),
     "ic3_env_encode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -55,8 +55,9 @@ class CommNetMLP(nn.Module):
         # encoder(current observation) straight from env state (envs.encode, the sparse-gather HIP kernel).  Set by
         # Trainer when args.sparse_encoder; under autograd the differentiable variant ops.env_encode is used when obs_env is set.
         self.obs_encoder = None
+        self.obs_table = None       # envs.encode_table: per-position pre-sums of the location rows (per weight version)
         self.obs_env = None         # env handle for the differentiable variant (ops.env_encode); set by Trainer
-        self._wt_cache = (None, None)
+        self._wt_cache = (None, None, None)
 
     # ------------------------------------------------------------------------------------------
     def _mask(self, info, key, batch, device):
@@ -141,6 +142,7 @@ class CommNetMLP(nn.Module):
                         if self.hid_size in ops.LSTM_FUSED_SIZES and getattr(self.args, 'fused_lstm', False) else None),
                     w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
                     b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
+                self._fc['loc_table'] = self.obs_table(self._fc['wt']) if self.obs_table is not None else None
             self._fc_key = key
         return self._fc
 
@@ -168,7 +170,7 @@ class CommNetMLP(nn.Module):
         mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
         # encoder(x) + C.bias -> XH[:, :H]
         if self.obs_encoder is not None:
-            self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H])
+            self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H], loc_table=fc['loc_table'])
         else:
             enc = buf.get('enc')
             if enc is None:
@@ -198,11 +200,12 @@ class CommNetMLP(nn.Module):
             w = self.encoder.weight
             key = (w._version, w.data_ptr())
             if self._wt_cache[0] != key:
-                self._wt_cache = (key, w.detach().t().contiguous())
+                wt = w.detach().t().contiguous()
+                self._wt_cache = (key, wt, self.obs_table(wt) if self.obs_table is not None else None)
             if not torch.is_grad_enabled():
-                return self.obs_encoder(self._wt_cache[1], self.encoder.bias.detach())
+                return self.obs_encoder(self._wt_cache[1], self.encoder.bias.detach(), loc_table=self._wt_cache[2])
             if self.obs_env is not None:       # update half: same gather, backward = ic3_env_encode_backward
-                return ops.env_encode(self.obs_env, w, self.encoder.bias, self._wt_cache[1])
+                return ops.env_encode(self.obs_env, w, self.encoder.bias, self._wt_cache[1], self._wt_cache[2])
         return self.encoder(x)
 
     def init_hidden(self, batch_size):                            # comm.py:250-253

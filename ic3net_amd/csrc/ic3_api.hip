@@ -283,13 +283,22 @@ int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream
     return rc;
 }
 
-int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, ic3_stream stream)
+int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
+                   ic3_stream stream)
 {
     if (!env || !Wt || !bias || !out) return fail(-22, "ic3_env_encode: null argument");
     if (ldo <= 0) ldo = H;
     if (H <= 0 || (H & 3) || (ldo & 3) || ldo < H) return fail(-22, "ic3_env_encode: H and ldo must be positive multiples of 4");
-    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream)
-                                   : tj_encode(env, Wt, bias, out, ldo, H, (hipStream_t)stream);
+    return env->kind == IC3_ENV_PP ? pp_encode(env, Wt, bias, loc_table, out, ldo, H, (hipStream_t)stream)
+                                   : tj_encode(env, Wt, bias, loc_table, out, ldo, H, (hipStream_t)stream);
+}
+
+int ic3_env_encode_table(ic3_env* env, const float* Wt, int H, float* loc_table, ic3_stream stream)
+{
+    if (!env || !Wt || !loc_table) return fail(-22, "ic3_env_encode_table: null argument");
+    if (H <= 0 || (H & 3)) return fail(-22, "ic3_env_encode_table: H must be a positive multiple of 4");
+    return env->kind == IC3_ENV_PP ? pp_encode_table(env, Wt, H, loc_table, (hipStream_t)stream)
+                                   : tj_encode_table(env, Wt, H, loc_table, (hipStream_t)stream);
 }
 
 int ic3_env_snapshot(const ic3_env* env, int32_t* snap, ic3_stream stream)

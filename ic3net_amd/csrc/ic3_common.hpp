@@ -102,13 +102,17 @@ int pp_reset(ic3_env* env, hipStream_t s);
 int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s);
 int pp_observe(ic3_env* env, float* obs, hipStream_t s);
-int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
+              hipStream_t s);
+int pp_encode_table(ic3_env* env, const float* Wt, int H, float* table, hipStream_t s);
 // tj_kernels.hip
 int tj_reset(ic3_env* env, hipStream_t s);
 int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s);
 int tj_observe(ic3_env* env, float* obs, hipStream_t s);
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s);
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
+              hipStream_t s);
+int tj_encode_table(ic3_env* env, const float* Wt, int H, float* table, hipStream_t s);
 // sparse-encoder backward (enc_bwd.hpp)
 int64_t pp_encode_bwd_work(const ic3_env* env, int H);
 int64_t tj_encode_bwd_work(const ic3_env* env, int H);

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ loc_c,
                                                         const f32x4* __restrict__ Wt, const f32x4* __restrict__ bias,
                                                         f32x4* __restrict__ out, int ldo4, int N, int nprey, int dim,
-                                                        int v, int H4, int rows)
+                                                        int v, int H4, int rows, const f32x4* __restrict__ loc_table)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -289,10 +289,13 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
     for (int idx = threadIdx.x; idx < rows * H4; idx += blockDim.x) {
         const int a = idx / H4, c4 = idx - a * H4;
         f32x4 acc = bias[c4];
+        // the one-hot location channels of all window cells depend only on the agent's position: one row of the
+        // pre-summed table (pp_encode_table_kernel) replaces W*W gathered rows
+        if (loc_table) acc += loc_table[(size_t)(smem[a] * dim + smem[N + nprey + a]) * H4 + c4];
         for (int cell = 0; cell < WW; ++cell) {
             const int2 t = tab[a * WW + cell];
             const size_t row = (size_t)cell * vocab;
-            acc += Wt[(row + t.x) * H4 + c4];
+            if (!loc_table) acc += Wt[(row + t.x) * H4 + c4];
             const int npred = t.y & 0xffff, npr = t.y >> 16;
             if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
             if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
@@ -301,7 +304,35 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
     }
 }
 
-int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
+// loc_table[pos] = sum_cells Wt[cell*vocab + id(pos, cell)]  (same cell order as the gather it replaces)
+__global__ __launch_bounds__(256) void pp_encode_table_kernel(const f32x4* __restrict__ Wt, f32x4* __restrict__ table,
+                                                              int dim, int v, int H4)
+{
+    const int W = 2 * v + 1, WW = W * W, vocab = dim * dim + 4, OUTSIDE = dim * dim + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dim * dim * H4) return;
+    const int pos = i / H4, c4 = i - pos * H4;
+    f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+    for (int cell = 0; cell < WW; ++cell) {
+        const int gr = pos / dim + cell / W - v, gc = pos % dim + cell % W - v;
+        const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
+        acc += Wt[((size_t)cell * vocab + id) * H4 + c4];
+    }
+    table[i] = acc;
+}
+
+int pp_encode_table(ic3_env* env, const float* Wt, int H, float* table, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int n = c.dim * c.dim * (H / 4);
+    hipLaunchKernelGGL(pp_encode_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const f32x4*>(Wt),
+                       reinterpret_cast<f32x4*>(table), c.dim, c.vision, H / 4);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+int pp_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
+              hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
     const int rows = env->dims.N;
@@ -309,7 +340,8 @@ int pp_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
     hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
                        reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
-                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows);
+                       reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows,
+                       reinterpret_cast<const f32x4*>(loc_table));
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
                                                         const int32_t* __restrict__ grid, const f32x4* __restrict__ Wt,
                                                         const f32x4* __restrict__ bias, f32x4* __restrict__ out, int ldo4,
                                                         int N, int h, int w, int v, int vocab, int outside,
-                                                        int car_class, int npath, int H4, int hdr)
+                                                        int car_class, int npath, int H4, int hdr,
+                                                        const f32x4* __restrict__ loc_table)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
@@ -387,10 +388,11 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
                 acc += s2[a] * Wt[2 * H4 + c4];
                 acc += s3[a] * Wt[3 * H4 + c4];
             }
+            if (loc_table) acc += loc_table[(size_t)(sr[a] * w + sc[a]) * H4 + c4];   // see pp_encode_kernel
             for (int cell = 0; cell < WW; ++cell) {
                 const int2 t = tab[a * WW + cell];
                 const size_t row = hdr + (size_t)cell * vocab;
-                if (t.x >= 0) acc += Wt[(row + t.x) * H4 + c4];          // scalar vocab: -1 = not a road cell
+                if (!loc_table && t.x >= 0) acc += Wt[(row + t.x) * H4 + c4];   // scalar vocab: -1 = not a road cell
                 if (t.y) acc += (float)t.y * Wt[(row + car_class) * H4 + c4];
             }
         }
@@ -398,7 +400,36 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restric
     }
 }
 
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo, int H, hipStream_t s)
+__global__ __launch_bounds__(256) void tj_encode_table_kernel(const f32x4* __restrict__ Wt, const int32_t* __restrict__ grid,
+                                                              f32x4* __restrict__ table, int h, int w, int v, int vocab,
+                                                              int outside, int H4, int hdr)
+{
+    const int W = 2 * v + 1, WW = W * W;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * w * H4) return;
+    const int pos = i / H4, c4 = i - pos * H4;
+    f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
+    for (int cell = 0; cell < WW; ++cell) {
+        const int gr = pos / w + cell / W - v, gc = pos % w + cell % W - v;
+        const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
+        if (id >= 0) acc += Wt[((size_t)hdr + (size_t)cell * vocab + id) * H4 + c4];
+    }
+    table[i] = acc;
+}
+
+int tj_encode_table(ic3_env* env, const float* Wt, int H, float* table, hipStream_t s)
+{
+    const ic3_dims& d = env->dims;
+    const int n = d.grid_h * d.grid_w * (H / 4);
+    hipLaunchKernelGGL(tj_encode_table_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const f32x4*>(Wt),
+                       env->d_grid, reinterpret_cast<f32x4*>(table), d.grid_h, d.grid_w, env->tj.vision, d.vocab,
+                       d.vocab - 3, H / 4, env->tj.vocab_type ? 4 : 2);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
+              hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
@@ -407,7 +438,8 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int 
     hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
                        env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
                        reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, c.N, d.grid_h, d.grid_w,
-                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2);
+                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2,
+                       reinterpret_cast<const f32x4*>(loc_table));
     IC3_HIP(hipGetLastError());
     return 0;
 }

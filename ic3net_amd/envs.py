@@ -100,18 +100,30 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_observe(self._h, ptr(self._obs), stream()))
         return self._obs
 
-    def encode(self, weight_t, bias, out=None):
+    def encode(self, weight_t, bias, out=None, loc_table=None):
         """encoder(obs(current state)) as a sparse gather (ic3_env_encode): weight_t = encoder.weight.t()
-        contiguous (obs_dim, H), bias (H,) -> (E, N, H) float32.  Equals self.observe() @ weight_t + bias."""
+        contiguous (obs_dim, H), bias (H,) -> (E, N, H) float32.  Equals self.observe() @ weight_t + bias.
+        loc_table = self.encode_table(weight_t) (valid while the weights are unchanged) makes it cheaper."""
         self._require()
         H = weight_t.shape[1]
         if weight_t.shape[0] != self.obs_dim or not weight_t.is_contiguous() or weight_t.dtype != torch.float32:
             raise ValueError("encode: weight_t must be a contiguous float32 (obs_dim, H) tensor")
+        if loc_table is not None and (tuple(loc_table.shape) != (self.dims.grid_h * self.dims.grid_w, H)
+                                      or not loc_table.is_contiguous() or loc_table.dtype != torch.float32):
+            raise ValueError("encode: loc_table must be the contiguous float32 (grid_h*grid_w, H) tensor of encode_table")
         if out is None:
             out = torch.empty((self.nenvs, self.nagents_env, H), dtype=torch.float32, device=self.device)
         ldo = H if out.dim() == 3 else out.stride(0)     # (E*N, H) column slice of a wider buffer: row stride
-        check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(out), ldo, H, stream()))
+        check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(loc_table), ptr(out), ldo, H, stream()))
         return out
+
+    def encode_table(self, weight_t):
+        """Per-position sums of the location rows of weight_t (ic3_env_encode_table) for encode(loc_table=...)."""
+        self._require()
+        H = weight_t.shape[1]
+        table = torch.empty((self.dims.grid_h * self.dims.grid_w, H), dtype=torch.float32, device=self.device)
+        check(_lib.lib().ic3_env_encode_table(self._h, ptr(weight_t), H, ptr(table), stream()))
+        return table
 
     def snapshot(self, out=None):
         """Device copy of the integer state (ic3_env_snapshot), the handle encode_backward needs later."""

@@ -29,8 +29,8 @@ class _EnvEncode(torch.autograd.Function):
     position-sum scatter ic3_env_encode_backward on a snapshot of the integer state (no dense obs is kept)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, env, weight_t):
-        out = env.encode(weight_t, bias.detach())
+    def forward(ctx, weight, bias, env, weight_t, loc_table):
+        out = env.encode(weight_t, bias.detach(), loc_table=loc_table)
         ctx.env = env
         ctx.snap = env.snapshot()
         ctx.need_bias = bias.requires_grad
@@ -39,15 +39,15 @@ class _EnvEncode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dwt, dbias = ctx.env.encode_backward(g.contiguous(), ctx.snap, want_bias=ctx.need_bias)
-        return dwt.t().contiguous(), dbias, None, None      # contiguous: grads may be all-reduced (sharding.py)
+        return dwt.t().contiguous(), dbias, None, None, None      # contiguous: grads may be all-reduced (sharding.py)
 
 
-def env_encode(env, weight, bias, weight_t=None):
+def env_encode(env, weight, bias, weight_t=None, loc_table=None):
     """nn.Linear(obs_dim, H)(env's current observation) -> (E, N, H), differentiable w.r.t. weight (H, obs_dim) and
     bias; weight_t = weight.t().contiguous() if the caller caches it."""
     if weight_t is None:
         weight_t = weight.detach().t().contiguous()
-    return _EnvEncode.apply(weight, bias, env, weight_t)
+    return _EnvEncode.apply(weight, bias, env, weight_t, loc_table)
 
 
 def _rows(t, H):

@@ -49,6 +49,8 @@ class Trainer(object):
         if getattr(args, 'sparse_encoder', True) and hasattr(policy_net, 'obs_encoder') \
                 and hasattr(getattr(env, 'env', None), 'encode'):
             policy_net.obs_encoder = env.env.encode
+            if hasattr(policy_net, 'obs_table') and getattr(args, 'encoder_table', True):
+                policy_net.obs_table = env.env.encode_table
             if getattr(args, 'sparse_encoder_grad', True) and hasattr(policy_net, 'obs_env'):
                 policy_net.obs_env = env.env        # rollouts under autograd: gather forward + scatter backward
 

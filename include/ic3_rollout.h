@@ -131,8 +131,13 @@ int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream
  * — the nn.Linear(obs_dim, hid) of comm.py:51,119 evaluated as a gather over the few non-zero obs entries
  * (<= 3 per window cell for PP, 2 + 2 per cell for TJ).  Wt = encoder.weight transposed, [obs_dim][H] row-major,
  * bias [H], out [E][N][H]; H % 4 == 0.  Mathematically identical to obs @ Wt + bias (fp32 sum order differs). */
-int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, float* out, int ldo /* out row stride in floats, 0 = H */,
-                   int H, ic3_stream stream);
+int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table /* or NULL */, float* out,
+                   int ldo /* out row stride in floats, 0 = H */, int H, ic3_stream stream);
+/* Optional accelerator for ic3_env_encode: the one-hot location channels of all window cells depend only on the
+ * agent's grid position, so their W*W gathered rows can be pre-summed per position once per weight version:
+ * loc_table [grid_h*grid_w][H] (dims.grid_h/w; PP: dim x dim), loc_table[pos] = sum_cells Wt[col(cell, id(pos, cell))].
+ * With a table the encode gathers 1 + (#occupied cells) rows per agent instead of W*W + (#occupied cells). */
+int ic3_env_encode_table(ic3_env* env, const float* Wt, int H, float* loc_table, ic3_stream stream);
 
 /* Backward of ic3_env_encode for the update half (trainer.py:128-225 backpropagates through comm.py:51,119's
  * nn.Linear): given grad_out = dL/d out [E][N][H] (row stride ldg floats, 0 = H) it overwrites

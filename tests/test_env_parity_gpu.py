@@ -345,8 +345,11 @@ def test_pp_enemy_comm_vs_oracle_random():
             np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
     with torch.no_grad():   # the sparse encoder covers the prey rows too
         dense = obs.double() @ lin.weight.double().t() + lin.bias.double()
-        sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
+        wt = lin.weight.detach().t().contiguous()
+        sparse = env.encode(wt, lin.bias.detach())
+        tabled = env.encode(wt, lin.bias.detach(), loc_table=env.encode_table(wt))
     torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
+    torch.testing.assert_close(tabled.double(), dense, atol=2e-6, rtol=0)
 
 
 def test_tj_scalar_vocab_vs_oracle_and_encoder():
@@ -375,8 +378,11 @@ def test_tj_scalar_vocab_vs_oracle_and_encoder():
             np.testing.assert_array_equal(rew[e].cpu().numpy(), orew.astype(np.float32))
     with torch.no_grad():
         dense = obs.double() @ lin.weight.double().t() + lin.bias.double()
-        sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
+        wt = lin.weight.detach().t().contiguous()
+        sparse = env.encode(wt, lin.bias.detach())
+        tabled = env.encode(wt, lin.bias.detach(), loc_table=env.encode_table(wt))
     torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
+    torch.testing.assert_close(tabled.double(), dense, atol=2e-6, rtol=0)
     grid, off, rc = env.tables()
     assert set(np.unique(grid)) == {0, 1}                      # the reference's self.grid holds road flags here
 

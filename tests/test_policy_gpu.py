@@ -170,8 +170,11 @@ def test_sparse_encoder_equals_dense(kind, cfg):
             obs = env.observe()
             with torch.no_grad():
                 dense = lin(obs.double().cpu().cuda()) if False else (obs.double() @ lin.weight.double().t() + lin.bias.double())
-                sparse = env.encode(lin.weight.detach().t().contiguous(), lin.bias.detach())
+                wt = lin.weight.detach().t().contiguous()
+                sparse = env.encode(wt, lin.bias.detach())
+                tabled = env.encode(wt, lin.bias.detach(), loc_table=env.encode_table(wt))   # pre-summed location rows
             torch.testing.assert_close(sparse.double(), dense, atol=2e-6, rtol=0)
+            torch.testing.assert_close(tabled.double(), dense, atol=2e-6, rtol=0)
 
 
 def test_policy_sparse_encoder_hook_matches_dense():
