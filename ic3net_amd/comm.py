@@ -55,6 +55,10 @@ class CommNetMLP(nn.Module):
         # encoder(current observation) straight from env state (envs.encode, the sparse-gather HIP kernel).  Set by
         # Trainer when args.sparse_encoder; under autograd the differentiable variant ops.env_encode is used when obs_env is set.
         self.obs_encoder = None
+        # (raw env, (heads, E, N) int32 buffer): set by the Trainer for one forward call when the fused policy path may
+        # draw the actions itself (ic3_lstm_cell_heads); `sampled` reports whether it did
+        self.sample_into = None
+        self.sampled = False
         self.obs_table = None       # envs.encode_table: per-position pre-sums of the location rows (per weight version)
         self.obs_env = None         # env handle for the differentiable variant (ops.env_encode); set by Trainer
         self._wt_cache = (None, None, None)
@@ -180,12 +184,21 @@ class CommNetMLP(nn.Module):
         ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg,
                                    not self.args.comm_mask_zero, out=buf['comm'])
         xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                          # inp = enc + C(comm_sum)
+        out, self.sampled = None, False
         if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
             ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel
         else:
             torch.addmm(fc['b_cat'], xh, fc['w_cat_t'], out=buf['gates'])              # all four gates (hipBLASLt)
-            ops.lstm_cell_(buf['gates'], c, h_view)
-        out = ops.policy_heads(h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads)
+            if getattr(self.args, 'fused_heads', True) and ops.lstm_cell_heads_ok(H):
+                # cell + heads + value + log_softmax (+ the action draws when the Trainer asked for them) in one launch
+                sink = self.sample_into
+                out = ops.lstm_cell_heads_(buf['gates'], c, h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads,
+                                           env=sink[0] if sink else None, action=sink[1] if sink else None)
+                self.sampled = sink is not None
+            else:
+                ops.lstm_cell_(buf['gates'], c, h_view)
+        if out is None:
+            out = ops.policy_heads(h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads)
         OT = out.shape[1]
         action, off = [], 0
         for A in self.args.naction_heads:

@@ -161,6 +161,101 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
         if (o == off) orow[o] = acc[o] + b[o];  // value head
 }
 
+// lstm_cell_kernel + policy_heads_kernel + sample_actions_env_kernel in one pass: the H/4 lanes that produce a row of
+// h' also hold it in registers, so the head / value dot products are a lane-local FMA block plus a log2(H/4)-step
+// shuffle reduce; lane 0 of the row finishes log_softmax (same arithmetic as policy_heads_kernel) and, when an env
+// handle is given, draws the actions of every head (same arithmetic and Philox counters as sample_actions_env_kernel).
+// Saves re-reading h (R*H*4 bytes) and three launches per step.  H/4 must be a power of two <= 64.
+template <int H4, int MAXO>
+__global__ __launch_bounds__(256) void lstm_cell_heads_kernel(const float* __restrict__ gates, float* __restrict__ c,
+                                                              float* __restrict__ h_out, int ldh, int R,
+                                                              const float* __restrict__ W, const float* __restrict__ b,
+                                                              float* __restrict__ out, int OT, int nheads, int a0, int a1,
+                                                              int a2, int a3, const int32_t* __restrict__ episode,
+                                                              const int32_t* __restrict__ tstep, uint32_t seed,
+                                                              uint32_t gid0, int N, int32_t* __restrict__ action)
+{
+    extern __shared__ __attribute__((aligned(16))) float sW[];  // [OT][4*H4] weights, then [RPB][OT] logits
+    constexpr int RPB = 256 / H4;                               // rows per workgroup
+    float* sZ = sW + OT * 4 * H4;
+    for (int i = threadIdx.x; i < OT * H4; i += blockDim.x)
+        reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(W)[i];
+    __syncthreads();
+    const int lrow = (int)threadIdx.x / H4, k = (int)threadIdx.x % H4;
+    const int row = blockIdx.x * RPB + lrow;
+    float acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.0f;
+    if (row < R) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(gates + (size_t)row * 16 * H4);
+        const f32x4 gi = g[k], gf = g[H4 + k], gg = g[2 * H4 + k], go = g[3 * H4 + k];
+        f32x4* cp = reinterpret_cast<f32x4*>(c + (size_t)row * 4 * H4) + k;
+        const f32x4 c0 = *cp;
+        f32x4 c1, h1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c1[q] = sigmoidf_(gf[q]) * c0[q] + sigmoidf_(gi[q]) * tanhf(gg[q]);
+            h1[q] = sigmoidf_(go[q]) * tanhf(c1[q]);
+        }
+        *cp = c1;
+        *reinterpret_cast<f32x4*>(h_out + (size_t)row * ldh + 4 * k) = h1;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            if (o < OT) {
+                const f32x4 w = reinterpret_cast<const f32x4*>(sW)[o * H4 + k];
+                acc[o] = h1.x * w.x + h1.y * w.y + h1.z * w.z + h1.w * w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        if (o < OT) {
+#pragma unroll
+            for (int m = 1; m < H4; m <<= 1) acc[o] += __shfl_xor(acc[o], m);
+            if (k == 0) sZ[lrow * OT + o] = acc[o] + b[o];
+        }
+    }
+    __syncthreads();
+    // tail: one thread per (row, head) — log_softmax + draw — and one per row for the value head
+    const int task = threadIdx.x;
+    if (task >= RPB * (nheads + 1)) return;
+    const int tr = task / (nheads + 1), hd = task - tr * (nheads + 1);
+    const int grow = blockIdx.x * RPB + tr;
+    if (grow >= R) return;
+    const float* z = sZ + tr * OT;
+    float* orow = out + (size_t)grow * OT;
+    const int sizes[4] = { a0, a1, a2, a3 };
+    int off = 0;
+    for (int i = 0; i < hd && i < nheads; ++i) off += sizes[i];
+    if (hd == nheads) {                     // value head (last column)
+        orow[off] = z[off];
+        return;
+    }
+    const int A = sizes[hd];
+    float mx = -INFINITY;
+    for (int o = 0; o < A; ++o) mx = fmaxf(mx, z[off + o]);
+    float sum = 0.0f;
+    for (int o = 0; o < A; ++o) sum += expf(z[off + o] - mx);
+    const float lse = mx + logf(sum);
+    for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
+    if (action) {
+        const int e = grow / N, n = grow - e * N;
+        const uint32_t x = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)episode[e], (uint32_t)tstep[e],
+                                      (uint32_t)(hd * N + n));
+        const float u = (float)x * (1.0f / 16777216.0f);
+        float cdf = 0.0f;
+        int a = A - 1;
+        for (int o = 0; o < A - 1; ++o) {
+            cdf += expf(z[off + o] - lse);
+            if (u < cdf) {
+                a = o;
+                break;
+            }
+        }
+        action[(size_t)hd * R + grow] = a;
+    }
+}
+
 // action_utils.py:32-36: torch.multinomial(exp(logp), 1) per row.  Inverse-CDF on the injected uniform:
 // first a with u < sum_{b<=a} exp(logp_b), last action as fallback (fp32, left-to-right).
 __global__ __launch_bounds__(256) void sample_actions_kernel(const float* __restrict__ logp, int ld, int A, int head,
@@ -266,6 +361,51 @@ extern "C" int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh
     const long long n = (long long)R * (H / 4);
     hipLaunchKernelGGL(ic3::lstm_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
                        c, h_out, ldh, R, H / 4);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_lstm_cell_heads(const float* gates, float* c, float* h_out, int ldh, int R, int H, const float* W,
+                                   const float* b, const int32_t* head_sizes, int nheads, float* out, const ic3_env* env,
+                                   int32_t* action, ic3_stream stream)
+{
+    if (!gates || !c || !h_out || !W || !b || !head_sizes || !out || R <= 0 || H <= 0 || (H & 3) || (ldh & 3) || ldh < H ||
+        nheads < 1 || nheads > 4)
+        return ic3::fail(-22, "ic3_lstm_cell_heads: bad arguments (1..4 heads, H and ldh multiples of 4)");
+    const int H4 = H / 4;
+    if (H4 > 64 || (H4 & (H4 - 1))) return ic3::fail(-38, "ic3_lstm_cell_heads: H/4 must be a power of two <= 64");
+    int sz[4] = { 0, 0, 0, 0 }, OT = 1;
+    for (int i = 0; i < nheads; ++i) { sz[i] = head_sizes[i]; OT += head_sizes[i]; }
+    if (OT > IC3_MAX_OT) return ic3::fail(-22, "ic3_lstm_cell_heads: more than 15 actions in total");
+    const int32_t *ep = nullptr, *ts = nullptr;
+    uint32_t seed = 0, gid0 = 0;
+    int N = 1;
+    if (action) {
+        if (!env || env->dims.E * env->dims.N != R)
+            return ic3::fail(-22, "ic3_lstm_cell_heads: sampling needs the env handle whose E*N equals R");
+        ep = env->f("episode");
+        ts = env->f("t");
+        seed = env->kind == IC3_ENV_PP ? env->pp.seed : env->tj.seed;
+        gid0 = env->kind == IC3_ENV_PP ? env->pp.env_id_offset : env->tj.env_id_offset;
+        N = env->dims.N;
+    }
+    const int rpb = 256 / H4;
+    const size_t lds = ((size_t)OT * H + (size_t)rpb * OT) * sizeof(float);
+    const dim3 grid((R + rpb - 1) / rpb), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define IC3_LCH(h4)                                                                                                      \
+    case h4:                                                                                                             \
+        if (OT <= 8)                                                                                                     \
+            hipLaunchKernelGGL((ic3::lstm_cell_heads_kernel<h4, 8>), grid, block, lds, s, gates, c, h_out, ldh, R, W, b,  \
+                               out, OT, nheads, sz[0], sz[1], sz[2], sz[3], ep, ts, seed, gid0, N, action);               \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ic3::lstm_cell_heads_kernel<h4, IC3_MAX_OT>), grid, block, lds, s, gates, c, h_out, ldh,  \
+                               R, W, b, out, OT, nheads, sz[0], sz[1], sz[2], sz[3], ep, ts, seed, gid0, N, action);      \
+        break;
+    switch (H4) {
+        IC3_LCH(1) IC3_LCH(2) IC3_LCH(4) IC3_LCH(8) IC3_LCH(16) IC3_LCH(32) IC3_LCH(64)
+    }
+#undef IC3_LCH
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -124,6 +124,32 @@ def policy_heads(h, W, b, head_sizes, out=None):
     return out
 
 
+def lstm_cell_heads_ok(H):
+    """ic3_lstm_cell_heads needs H/4 to be a power of two <= 64."""
+    return H % 4 == 0 and H // 4 <= 64 and (H // 4) & (H // 4 - 1) == 0
+
+
+def lstm_cell_heads_(gates, c, h_out, W, b, head_sizes, out=None, env=None, action=None):
+    """lstm_cell_ + policy_heads (+ the action draws of every head into `action` (heads, E, N) int32 when `env`, the
+    raw batched env, is given) in one launch.  Returns out (R, OT)."""
+    import ctypes as C
+    _need_cuda(gates, "lstm_cell_heads_")
+    R, H = c.shape
+    OT = W.shape[0]
+    assert gates.is_contiguous() and c.is_contiguous() and h_out.stride(1) == 1 and W.is_contiguous()
+    assert OT == sum(head_sizes) + 1
+    if out is None:
+        out = torch.empty((R, OT), dtype=torch.float32, device=c.device)
+    if action is not None:
+        assert env is not None and action.is_contiguous() and action.dtype == torch.int32 \
+            and action.numel() == len(head_sizes) * R
+    sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
+    check(_lib.lib().ic3_lstm_cell_heads(ptr(gates), ptr(c), ptr(h_out), h_out.stride(0), R, H, ptr(W), ptr(b), sizes,
+                                         len(head_sizes), ptr(out), env._h if action is not None else None, ptr(action),
+                                         stream()))
+    return out
+
+
 def comm_masked_mean(h, alive=None, comm_action=None, mode_avg=True, mask_self=True):
     """h (E,N,H) f32; alive / comm_action (E,N) int32 CUDA tensors or None -> (E,N,H)."""
     if alive is not None:

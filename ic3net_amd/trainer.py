@@ -19,6 +19,7 @@ import torch
 from torch import optim
 
 from .action_utils import SampleClock, select_action, translate_action
+from .action_utils import select_action as _select_action_default     # tests monkeypatch `select_action` (action tapes)
 from .utils import merge_stat
 
 Transition = namedtuple('Transition', ('state', 'action', 'action_out', 'value', 'episode_mask', 'episode_mini_mask',
@@ -159,14 +160,26 @@ class Trainer(object):
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:
                     self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
-                action_out, value, prev_hid = self.policy_net([state, self._prev_hid], info)
+                fuse_draw = not torch.is_grad_enabled() and self.clock.env is not None \
+                    and hasattr(self.policy_net, 'sample_into') and select_action is _select_action_default
+                if fuse_draw:
+                    self.policy_net.sample_into = (self.clock.env, buf['action'][t])
+                try:
+                    action_out, value, prev_hid = self.policy_net([state, self._prev_hid], info)
+                finally:
+                    if fuse_draw:
+                        self.policy_net.sample_into = None
                 if (t + 1) % args.detach_gap == 0:                 # trainer.py:56-60
                     prev_hid = (prev_hid[0].detach(), prev_hid[1].detach()) if args.rnn_type == 'LSTM' \
                         else prev_hid.detach()
                 self._prev_hid = prev_hid
             else:
                 action_out, value = self.policy_net(state, info)
-            action = select_action(args, action_out, self.clock, out=buf['action'][t])   # trainer.py:65
+            if getattr(self.policy_net, 'sampled', False):                               # drawn by the policy launch
+                self.policy_net.sampled = False
+                action = buf['action'][t]
+            else:
+                action = select_action(args, action_out, self.clock, out=buf['action'][t])   # trainer.py:65
             action, actual = translate_action(args, self.env, action)                    # trainer.py:66
             cur_state = state.clone() if store else None
             raw = self.env.env

@@ -208,6 +208,14 @@ int ic3_lstm_fused(float* XH, int ldx, const float* Wp, const float* bias, float
 int ic3_policy_heads(const float* h, int ldh, const float* W, const float* b, const int32_t* head_sizes, int nheads,
                      float* out, int R, int H, ic3_stream stream);
 
+/* ic3_lstm_cell + ic3_policy_heads (+ ic3_env_sample_actions for every head when `action` is non-NULL) in one launch:
+ * the lanes that produce a row of h' keep it in registers for the head / value dot products.  out [R][sum A_k + 1] as
+ * ic3_policy_heads; action [nheads][R] int32 (action_utils.py:32-36 draws, Philox counters (episode, t) read from
+ * `env`, which must satisfy E*N == R) or NULL.  Returns -ENOSYS unless H/4 is a power of two <= 64. */
+int ic3_lstm_cell_heads(const float* gates, float* c, float* h_out, int ldh, int R, int H, const float* W, const float* b,
+                        const int32_t* head_sizes, int nheads, float* out, const ic3_env* env, int32_t* action,
+                        ic3_stream stream);
+
 /* select_action (action_utils.py:32-36): one multinomial draw per (env, agent) row from exp(logp),
  * as inverse-CDF on Philox uniforms: counter (head*N+n, t, episode, DOMAIN_SAMPLE), key (seed, env_id_offset+e).
  *   logp [E*N rows][ld] f32 (first A columns of each row) -> action [E][N] int32, chosen_logp [E][N] f32 or NULL. */

@@ -228,6 +228,43 @@ def test_lstm_cell_and_heads_kernels_vs_torch():
             torch.testing.assert_close(out[:, off], z[:, off], atol=3e-6, rtol=0)
 
 
+@pytest.mark.parametrize("N,H,sizes", [(10, 128, [5, 2]), (5, 64, [2]), (3, 256, [5, 2]), (7, 32, [5, 2, 3, 4]), (4, 16, [9])])
+def test_lstm_cell_heads_sample_fused_kernel(N, H, sizes):
+    """ic3_lstm_cell_heads == lstm_cell_ + policy_heads (+ sample_actions_env per head) — cell outputs bit-identical,
+    heads within fp32 rounding (different reduction order), draws bit-identical to the separate sampling kernel run on
+    the fused kernel's own log-probabilities."""
+    from ic3net_amd import ops
+    from test_env_parity_gpu import make_pp
+    E = 37
+    env = make_pp(N, 8, 1, "mixed", E, seed=9, offset=4)
+    env.reset()
+    for _ in range(3):                                  # move the device-side (episode, t) counters off zero
+        env.step(torch.randint(0, 5, (E, N), device='cuda', dtype=torch.int32))
+    torch.manual_seed(N + H)
+    R, OT = E * N, sum(sizes) + 1
+    gates = torch.randn(R, 4 * H, device='cuda')
+    c0 = torch.randn(R, H, device='cuda')
+    W, b = torch.randn(OT, H, device='cuda') * 0.3, torch.randn(OT, device='cuda')
+    xh_a, xh_b = torch.zeros(R, 2 * H, device='cuda'), torch.zeros(R, 2 * H, device='cuda')
+    c_a, c_b = c0.clone(), c0.clone()
+    ops.lstm_cell_(gates, c_a, xh_a[:, H:])
+    out_a = ops.policy_heads(xh_a[:, H:], W, b, sizes)
+    act = torch.full((len(sizes), E, N), -1, dtype=torch.int32, device='cuda')
+    assert ops.lstm_cell_heads_ok(H)
+    out_b = ops.lstm_cell_heads_(gates, c_b, xh_b[:, H:], W, b, sizes, env=env, action=act)
+    assert torch.equal(c_a, c_b) and torch.equal(xh_a, xh_b)
+    torch.testing.assert_close(out_b, out_a, atol=3e-6, rtol=0)
+    off = 0
+    for k, A in enumerate(sizes):
+        lp = out_b.view(E, N, OT)[:, :, off:off + A]
+        assert torch.equal(act[k], ops.sample_actions_env(env, lp, k))
+        off += A
+    # without an env handle: no draws, same outputs
+    c_c, xh_c = c0.clone(), torch.zeros(R, 2 * H, device='cuda')
+    out_c = ops.lstm_cell_heads_(gates, c_c, xh_c[:, H:], W, b, sizes)
+    assert torch.equal(out_c, out_b) and torch.equal(c_c, c_b)
+
+
 @pytest.mark.parametrize("R,H", [(640, 128), (1000, 128), (77, 64), (300, 256), (64, 128), (1, 128)])
 def test_lstm_fused_mfma_kernel_vs_torch(R, H):
     """Hand-written fp32-MFMA LSTM kernel (gate GEMM + cell epilogue, in-place h') against torch.nn.LSTMCell;
