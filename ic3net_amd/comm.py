@@ -140,6 +140,8 @@ class CommNetMLP(nn.Module):
                     wt=self.encoder.weight.t().contiguous(),
                     enc_bias=(self.encoder.bias + self.C_modules[0].bias).contiguous(),    # comm.py:206 bias, Q24
                     c_wt=self.C_modules[0].weight.t().contiguous(),
+                    c_wp=(ops.comm_pack_weights(self.C_modules[0].weight)
+                          if self.hid_size in ops.COMM_FUSED_SIZES and getattr(self.args, 'fused_comm', False) else None),
                     w_cat_t=torch.cat([self.f_module.weight_ih, self.f_module.weight_hh], 1).t().contiguous(),
                     b_cat=(self.f_module.bias_ih + self.f_module.bias_hh).contiguous(),
                     wp=(ops.lstm_pack_weights(self.f_module.weight_ih, self.f_module.weight_hh)
@@ -181,9 +183,14 @@ class CommNetMLP(nn.Module):
                 enc = buf['enc'] = torch.empty((R, H), dtype=torch.float32, device=dev)
             torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)           # dense encoder GEMM
             xh[:, :H].copy_(enc)
-        ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg,
-                                   not self.args.comm_mask_zero, out=buf['comm'])
-        xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                          # inp = enc + C(comm_sum)
+        if self.args.comm_mask_zero:
+            pass                                                                       # comm.py:40-41: C(0) = bias only
+        elif fc['c_wp'] is not None and n <= 64:
+            ops.comm_fused_(xh, fc['c_wp'], alive, comm_action, batch, n, mode_avg)    # inp += C(comm(h)), one launch
+        else:
+            ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg, True,
+                                     out=buf['comm'])
+            xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                      # inp = enc + C(comm_sum)
         out, self.sampled = None, False
         if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
             ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel

@@ -124,6 +124,29 @@ def policy_heads(h, W, b, head_sizes, out=None):
     return out
 
 
+COMM_FUSED_SIZES = (64, 128, 256)
+
+
+def comm_pack_weights(c_weight):
+    """C.weight (H, H) -> the packed layout ic3_comm_fused streams (ic3_comm_pack_weights)."""
+    _need_cuda(c_weight, "comm_pack_weights")
+    H = c_weight.shape[0]
+    w = c_weight.detach().contiguous()
+    wp = torch.empty((H * H,), dtype=torch.float32, device=w.device)
+    check(_lib.lib().ic3_comm_pack_weights(ptr(w), ptr(wp), H, stream()))
+    return wp
+
+
+def comm_fused_(xh, wp, alive, comm_action, E, N, mode_avg):
+    """xh (E*N, 2H) = [inp | h]:  inp += comm(h) @ C.weight^T in one launch (ic3_comm_fused), in place."""
+    _need_cuda(xh, "comm_fused_")
+    H = xh.shape[1] // 2
+    assert xh.stride(1) == 1 and xh.shape[0] == E * N and wp.numel() == H * H
+    check(_lib.lib().ic3_comm_fused(ptr(xh), xh.stride(0), ptr(wp), ptr(alive), ptr(comm_action), E, N, H,
+                                    1 if mode_avg else 0, stream()))
+    return xh
+
+
 def lstm_cell_heads_ok(H):
     """ic3_lstm_cell_heads needs H/4 to be a power of two <= 64."""
     return H % 4 == 0 and H // 4 <= 64 and (H // 4) & (H // 4 - 1) == 0

@@ -122,18 +122,22 @@ class Trainer(object):
         if g is None:
             # capture: the launch sequence of step t (policy kernels, sampling, env step [, obs assembly]) with the
             # buffers it reads/writes.  The obs launch stays outside the graph while it is being event-timed.
-            in_graph_obs = raw.obs_timer is None and self._dense_obs() and not getattr(self.args, 'overlap_obs', False)
+            in_graph_obs = self._dense_obs() and not self._obs_outside_graph(raw, t)
             saved = (self._state, self._info, self._prev_hid)
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             # thread_local: calls made by other threads (e.g. an RCCL watchdog) must not invalidate the capture
-            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
-                self._step_body(t, observe=in_graph_obs)
+            timer, raw.obs_timer = raw.obs_timer, None        # no event records inside a capture
+            try:
+                with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+                    self._step_body(t, observe=in_graph_obs)
+            finally:
+                raw.obs_timer = timer
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
             # capture does not execute: fall through to a replay so that step t actually runs
-        if g['obs_inside'] and raw.obs_timer is not None:
+        if g['obs_inside'] and self._obs_outside_graph(raw, t):
             # timing was switched on after capture: re-capture without the obs launch
             del self._graphs[t]
             return self.step_episode(t)
@@ -201,6 +205,12 @@ class Trainer(object):
             self._state = next_state
             self._info = info
             self._nsteps = t + 1
+
+    def _obs_outside_graph(self, raw, t):
+        """The obs-assembly launch stays outside the captured step graph when it runs on the side stream
+        (args.overlap_obs) or is being event-timed (HIP events recorded in a captured graph cannot be timed; timing
+        only every k-th step and keeping the other launches in their graphs was measured: no difference)."""
+        return bool(getattr(self.args, 'overlap_obs', False)) or raw.obs_timer is not None
 
     def _observe_on_side_stream(self, raw):
         """args.overlap_obs: the dense observation of the new state is assembled on a second stream from a snapshot

@@ -216,6 +216,15 @@ int ic3_lstm_cell_heads(const float* gates, float* c, float* h_out, int ldh, int
                         const int32_t* head_sizes, int nheads, float* out, const ic3_env* env, int32_t* action,
                         ic3_stream stream);
 
+/* The communication block of comm.py:181-206 in one launch, in place on the [inp | h] buffer XH (R = E*N rows, row
+ * stride ldx >= 2H floats):  XH[:, :H] += comm(XH[:, H:2H]) . C.weight^T  with comm the closed form of
+ * ic3_comm_masked_mean (alive / comm_action [E][N] int32 or NULL, mode_avg as there; comm_mask_zero callers simply
+ * skip the call).  Wp = C.weight packed by ic3_comm_pack_weights (H*H floats).  fp32 MFMA; the comm rows only exist in
+ * LDS.  -ENOSYS unless H in {64, 128, 256} and N <= 64 (use ic3_comm_masked_mean + a GEMM otherwise). */
+int ic3_comm_pack_weights(const float* C_weight /* [H][H] */, float* Wp, int H, ic3_stream stream);
+int ic3_comm_fused(float* XH, int ldx, const float* Wp, const int32_t* alive, const int32_t* comm_action, int E, int N,
+                   int H, int mode_avg, ic3_stream stream);
+
 /* select_action (action_utils.py:32-36): one multinomial draw per (env, agent) row from exp(logp),
  * as inverse-CDF on Philox uniforms: counter (head*N+n, t, episode, DOMAIN_SAMPLE), key (seed, env_id_offset+e).
  *   logp [E*N rows][ld] f32 (first A columns of each row) -> action [E][N] int32, chosen_logp [E][N] f32 or NULL. */
