@@ -17,6 +17,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // H4 = H/4 lanes per env (each lane owns 4 hidden columns as one 16-byte access); a 256-thread workgroup holds
 // 256/H4 envs.  h rows may be strided (ldh floats) so the op can read the [inp | h] buffer of the fused LSTM path.
+template <int NMAX>
 __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __restrict__ h, int ldh,
                                                                const int32_t* __restrict__ alive,
                                                                const int32_t* __restrict__ comm_action,
@@ -36,6 +37,30 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
         return;
     }
     f32x4 S = { 0.f, 0.f, 0.f, 0.f };
+    if (NMAX > 0 && N <= NMAX) {
+        // all rows of the env requested at once and kept in registers: one HBM read of h (the two-pass loop below
+        // re-fetched every row — PMC FETCH_SIZE showed 2x the algorithmic bytes — and serialised the latencies)
+        constexpr int NR = NMAX > 0 ? NMAX : 1;
+        f32x4 hv[NR];
+        float mm[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (i < N) {
+                hv[i] = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + i) * ldh + 4 * k);
+                mm[i] = (float)((alive ? alive[(size_t)e * N + i] : 1) * (comm_action ? comm_action[(size_t)e * N + i] : 1));
+            } else {
+                hv[i] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+                mm[i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (i < N) S += mm[i] * hv[i];
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            if (j < N) oe[(size_t)j * H4] = mm[j] * (S - mm[j] * hv[j]) * scale;
+        return;
+    }
     for (int i = 0; i < N; ++i) {
         const int m = (alive ? alive[(size_t)e * N + i] : 1) * (comm_action ? comm_action[(size_t)e * N + i] : 1);
         const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + i) * ldh + 4 * k);
@@ -343,8 +368,17 @@ extern "C" int ic3_comm_masked_mean(const float* h, int ldh, const int32_t* aliv
     if (ldh <= 0) ldh = H;
     if ((H & 3) == 0 && (ldh & 3) == 0 && H / 4 <= 256) {
         const int H4 = H / 4, per_block = 256 / H4;
-        hipLaunchKernelGGL(ic3::comm_masked_mean_kernel, dim3((E + per_block - 1) / per_block), dim3(256), 0,
-                           (hipStream_t)stream, h, ldh, alive, comm_action, out, E, N, H4, mode_avg, mask_self);
+        const dim3 grid((E + per_block - 1) / per_block);
+        hipStream_t s = (hipStream_t)stream;
+        if (N <= 16)
+            hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<16>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
+                               H4, mode_avg, mask_self);
+        else if (N <= 32)
+            hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<32>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
+                               H4, mode_avg, mask_self);
+        else
+            hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<0>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
+                               H4, mode_avg, mask_self);
     } else {
         const int threads = H >= 256 ? 256 : ((H + 63) / 64) * 64;
         hipLaunchKernelGGL(ic3::comm_masked_mean_scalar_kernel, dim3(E), dim3(threads), 0, (hipStream_t)stream, h, ldh,
