@@ -313,7 +313,8 @@ def main():
         tf = os.path.join(ROOT, 'profiles', 'obs_traffic.json')
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(o.workload)
+                tab = json.load(open(tf))
+                traffic = tab.get(o.workload) if o.nenvs == tab.get('_nenvs', 8192) else None   # measured at that size
             except Exception:
                 traffic = None
         out = {
