@@ -97,6 +97,21 @@ int fail(int code, const std::string& msg);
             return ic3::fail(-5 /*EIO*/, std::string(#expr) + ": " + hipGetErrorString(_e));               \
     } while (0)
 
+// LSTM nonlinearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each), shared by the
+// pointwise cell kernels and the fused MFMA kernel.  The accurate ocml expf/tanhf made those kernels VALU-bound
+// (~4000 VALU cycles per wave against ~700 cycles of memory time in lstm_cell_heads_kernel).  Absolute error <= ~2e-7
+// on outputs in [-1, 1] (the parity bar is 1e-5); overflow-safe: exp2(+big) = inf -> 1/(1+inf) = 0.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+#endif
+
 // pp_kernels.hip
 int pp_reset(ic3_env* env, hipStream_t s);
 int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,

@@ -28,19 +28,6 @@ namespace ic3 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Epilogue nonlinearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each): the accurate
-// ocml expf/tanhf cost ~35k VALU cycles per wave and tile here — as much as the tile's MFMA work — and the two
-// co-resident workgroups run in lock-step, so that time is not hidden.  Absolute error <= ~2e-7 on outputs in
-// [-1, 1] (the parity bar is 1e-5); overflow-safe: exp2(+big) = inf -> 1/(1+inf) = 0.
-__device__ __forceinline__ float fast_sigmoid(float x)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float fast_tanh(float x)
-{
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-}
-
 template <int H>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_fused_kernel(float* __restrict__ XH, int ldx,
                                                                                const f32x4* __restrict__ Wp,

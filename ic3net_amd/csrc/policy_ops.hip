@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void comm_masked_mean_scalar_kernel(const floa
 // torch.nn.LSTMCell pointwise half (comm.py:215, gate order i,f,g,o): gates [R][4H] already hold
 // W_ih x + b_ih + W_hh h + b_hh.  c is updated in place, h' is written with row stride ldh (into the
 // [inp | h] buffer).  HBM-bound: reads 4H+H, writes 2H floats per row.
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gates, float* __restrict__ c,
                                                         float* __restrict__ h_out, int ldh, int R, int H4)
@@ -118,8 +117,8 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
     f32x4 c1, h1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        c1[q] = sigmoidf_(gf[q]) * c0[q] + sigmoidf_(gi[q]) * tanhf(gg[q]);
-        h1[q] = sigmoidf_(go[q]) * tanhf(c1[q]);
+        c1[q] = fast_sigmoid(gf[q]) * c0[q] + fast_sigmoid(gi[q]) * fast_tanh(gg[q]);
+        h1[q] = fast_sigmoid(go[q]) * fast_tanh(c1[q]);
     }
     *cp = c1;
     *reinterpret_cast<f32x4*>(h_out + (size_t)row * ldh + 4 * k) = h1;
@@ -219,8 +218,8 @@ __global__ __launch_bounds__(256) void lstm_cell_heads_kernel(const float* __res
         f32x4 c1, h1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            c1[q] = sigmoidf_(gf[q]) * c0[q] + sigmoidf_(gi[q]) * tanhf(gg[q]);
-            h1[q] = sigmoidf_(go[q]) * tanhf(c1[q]);
+            c1[q] = fast_sigmoid(gf[q]) * c0[q] + fast_sigmoid(gi[q]) * fast_tanh(gg[q]);
+            h1[q] = fast_sigmoid(go[q]) * fast_tanh(c1[q]);
         }
         *cp = c1;
         *reinterpret_cast<f32x4*>(h_out + (size_t)row * ldh + 4 * k) = h1;
