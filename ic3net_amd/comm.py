@@ -129,6 +129,21 @@ class CommNetMLP(nn.Module):
             return False
         return isinstance(x, (list, tuple)) and x[0].is_cuda and self.encoder.weight.dtype == torch.float32
 
+    def _x_is_env_obs(self, x):
+        """The sparse encoder evaluates encoder(obs(env's CURRENT integer state)) without reading x; that is only
+        the answer when x IS that observation, i.e. the env's own obs buffer (which env.reset/step keep in sync with
+        the state).  Any other tensor (a stored / foreign state) takes the dense GEMM."""
+        if self.obs_encoder is None:
+            return False
+        env = getattr(self.obs_encoder, '__self__', None)
+        own = getattr(env, '_obs', None)
+        if own is None:
+            return True                         # a custom encoder hook: the caller vouches for it
+        return x.data_ptr() == own.data_ptr() and x.shape == own.shape
+
+    def _mega_wanted(self):
+        return bool(getattr(self.args, 'mega_policy', True)) and self.hid_size in ops.POLICY_STEP_SIZES
+
     def _fused_cache(self):
         ps = [self.encoder.weight, self.encoder.bias, self.C_modules[0].weight, self.C_modules[0].bias,
               self.f_module.weight_ih, self.f_module.weight_hh, self.f_module.bias_ih, self.f_module.bias_hh,
@@ -136,7 +151,7 @@ class CommNetMLP(nn.Module):
         key = tuple((p._version, p.data_ptr()) for p in ps)
         if getattr(self, '_fc_key', None) != key:
             with torch.no_grad():
-                self._fc = dict(
+                new = dict(
                     wt=self.encoder.weight.t().contiguous(),
                     enc_bias=(self.encoder.bias + self.C_modules[0].bias).contiguous(),    # comm.py:206 bias, Q24
                     c_wt=self.C_modules[0].weight.t().contiguous(),
@@ -148,7 +163,24 @@ class CommNetMLP(nn.Module):
                         if self.hid_size in ops.LSTM_FUSED_SIZES and getattr(self.args, 'fused_lstm', False) else None),
                     w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
                     b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
-                self._fc['loc_table'] = self.obs_table(self._fc['wt']) if self.obs_table is not None else None
+                new['loc_table'] = self.obs_table(new['wt']) if self.obs_table is not None else None
+                if self._mega_wanted():
+                    new.update(ops.policy_step_pack(self.C_modules[0].weight, self.f_module.weight_ih,
+                                                    self.f_module.weight_hh))
+                old = getattr(self, '_fc', None)
+                same = old is not None and old.keys() == new.keys() and all(
+                    (old[k] is None) == (new[k] is None) and (new[k] is None or (old[k].shape == new[k].shape
+                                                                                 and old[k].device == new[k].device))
+                    for k in new)
+                if same:
+                    # a new weight version: refresh the derived tensors IN PLACE — captured step graphs hold their
+                    # addresses (a re-allocation would leave the graphs reading freed / stale memory)
+                    for k, v in new.items():
+                        if v is not None:
+                            old[k].copy_(v)
+                else:
+                    self._fc = new
+                    self.cache_generation = getattr(self, 'cache_generation', 0) + 1   # addresses changed: graphs stale
             self._fc_key = key
         return self._fc
 
@@ -175,7 +207,7 @@ class CommNetMLP(nn.Module):
         comm_action = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
         mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
         # encoder(x) + C.bias -> XH[:, :H]
-        if self.obs_encoder is not None:
+        if self._x_is_env_obs(x):
             self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H], loc_table=fc['loc_table'])
         else:
             enc = buf.get('enc')
@@ -216,7 +248,7 @@ class CommNetMLP(nn.Module):
 
     def _encode(self, x):
         """self.encoder(x) (comm.py:51,119); during no-grad rollouts optionally via the env's sparse gather."""
-        if self.obs_encoder is not None and self.hid_size % 4 == 0:
+        if self.hid_size % 4 == 0 and self._x_is_env_obs(x):
             w = self.encoder.weight
             key = (w._version, w.data_ptr())
             if self._wt_cache[0] != key:

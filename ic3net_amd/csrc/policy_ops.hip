@@ -260,43 +260,44 @@ __global__ __launch_bounds__(256) void lstm_cell_heads_kernel(const float* __res
         }
     }
     __syncthreads();
-    // tail: one thread per (row, head) — log_softmax + draw — and one per row for the value head
-    const int task = threadIdx.x;
-    if (task >= RPB * (nheads + 1)) return;
-    const int tr = task / (nheads + 1), hd = task - tr * (nheads + 1);
-    const int grow = blockIdx.x * RPB + tr;
-    if (grow >= R) return;
-    const float* z = sZ + tr * OT;
-    float* orow = out + (size_t)grow * OT;
+    // tail: one task per (row, head) — log_softmax + draw — and one per row for the value head.  RPB * (nheads + 1) can
+    // exceed the 256 threads for small H (H = 8 with two heads: 128 rows x 3 tasks), hence the loop.
     const int sizes[4] = { a0, a1, a2, a3 };
-    int off = 0;
-    for (int i = 0; i < hd && i < nheads; ++i) off += sizes[i];
-    if (hd == nheads) {                     // value head (last column)
-        orow[off] = z[off];
-        return;
-    }
-    const int A = sizes[hd];
-    float mx = -INFINITY;
-    for (int o = 0; o < A; ++o) mx = fmaxf(mx, z[off + o]);
-    float sum = 0.0f;                       // hardware exp2 / log2 (~1 ulp): |error| of a log-prob ~1e-7, bar 1e-5
-    for (int o = 0; o < A; ++o) sum += __builtin_amdgcn_exp2f(1.4426950408889634f * (z[off + o] - mx));
-    const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
-    for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
-    if (action) {
-        const int e = grow / N, n = grow - e * N;
-        const uint32_t x = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)episode[e], (uint32_t)tstep[e],
-                                      (uint32_t)(hd * N + n));
-        const float u = (float)x * (1.0f / 16777216.0f);
-        float cdf = 0.0f;
-        int a = A - 1;
-        for (int o = 0; o < A - 1; ++o) {
-            cdf += expf(z[off + o] - lse);
-            if (u < cdf) {
-                a = o;
-                break;
-            }
+    for (int task = threadIdx.x; task < RPB * (nheads + 1); task += blockDim.x) {
+        const int tr = task / (nheads + 1), hd = task - tr * (nheads + 1);
+        const int grow = blockIdx.x * RPB + tr;
+        if (grow >= R) continue;
+        const float* z = sZ + tr * OT;
+        float* orow = out + (size_t)grow * OT;
+        int off = 0;
+        for (int i = 0; i < hd && i < nheads; ++i) off += sizes[i];
+        if (hd == nheads) {                     // value head (last column)
+            orow[off] = z[off];
+            continue;
         }
-        action[(size_t)hd * R + grow] = a;
+        const int A = sizes[hd];
+        float mx = -INFINITY;
+        for (int o = 0; o < A; ++o) mx = fmaxf(mx, z[off + o]);
+        float sum = 0.0f;                       // hardware exp2 / log2 (~1 ulp): |error| of a log-prob ~1e-7, bar 1e-5
+        for (int o = 0; o < A; ++o) sum += __builtin_amdgcn_exp2f(1.4426950408889634f * (z[off + o] - mx));
+        const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
+        for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
+        if (action) {
+            const int e = grow / N, n = grow - e * N;
+            const uint32_t x = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)episode[e], (uint32_t)tstep[e],
+                                          (uint32_t)(hd * N + n));
+            const float u = (float)x * (1.0f / 16777216.0f);
+            float cdf = 0.0f;
+            int a = A - 1;
+            for (int o = 0; o < A - 1; ++o) {
+                cdf += expf(z[off + o] - lse);
+                if (u < cdf) {
+                    a = o;
+                    break;
+                }
+            }
+            action[(size_t)hd * R + grow] = a;
+        }
     }
 }
 

@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-from . import checkpoint, data, models
+from . import checkpoint, data, models, sharding
 from .action_utils import parse_action_args
 from .comm import CommNetMLP
 from .trainer import Trainer
@@ -148,7 +148,11 @@ def run(argv=None, out=print):
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', args.device))
     derive_args(args)
     if args.seed == -1:                               # main.py:157-159
-        args.seed = np.random.randint(0, 10000)
+        args.seed = int(np.random.randint(0, 10000))
+    if world > 1:
+        # one seed for the whole job (the reference's workers inherit the master's args, main.py:177-178): the env /
+        # sampling streams are keyed by (seed, global env id) and every replica must initialise the same policy
+        args.seed = sharding.broadcast_seed(args.seed)
     args.env_id_offset = rank * args.nenvs            # shard-invariant env streams (global env ids)
     torch.manual_seed(args.seed)
     env = data.init(args.env_name, args, False)
@@ -158,6 +162,10 @@ def run(argv=None, out=print):
     log = checkpoint.new_log()
     if args.load != '':
         checkpoint.load(args.load, policy_net, log, trainer, map_location=torch.device('cuda', args.device))
+    if world > 1:
+        # the reference's workers share ONE parameter set (share_memory_, main.py:177-178); replicas get rank 0's
+        # parameters (and RMSprop state after --load) so that identical all-reduced gradients keep them identical
+        sharding.broadcast_parameters(policy_net, trainer.optimizer)
     if args.tune_gemm:     # TunableOp times the hipBLASLt/rocBLAS candidates for every GEMM shape of the first update
         import torch.cuda.tunable as tunable
         tunable.enable(True)

@@ -20,6 +20,42 @@ def worker_seed(seed, rank):
     return seed if rank == 0 else seed + (rank - 1) + 1
 
 
+def _dist_device(group=None):
+    import torch.distributed as dist
+    return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+
+
+def broadcast_seed(seed, src=0, group=None):
+    """Every rank adopts rank `src`'s seed (main.py:157-159 draws it once; the reference's workers inherit it)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(seed)
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=_dist_device(group))
+    dist.broadcast(t, src=src, group=group)
+    return int(t.item())
+
+
+def broadcast_parameters(module, optimizer=None, src=0, group=None):
+    """Replicas start from rank `src`'s parameters, buffers and optimizer state tensors (the reference keeps one
+    shared-memory parameter set, main.py:177-178 / multi_processing.py:24-27)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    if optimizer is not None:
+        for pid in sorted(optimizer.state_dict()['state']):
+            st = optimizer.state_dict()['state'][pid]
+            tensors += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
+    dev = _dist_device(group)
+    for t in tensors:
+        if t.device == dev:
+            dist.broadcast(t, src=src, group=group)
+        else:                                   # e.g. CPU tensors under an RCCL group (RMSprop's `step`)
+            tmp = t.to(dev)
+            dist.broadcast(tmp, src=src, group=group)
+            t.copy_(tmp)
+
+
 def allreduce_stats(stat, group=None):
     """merge_stat across ranks (multi_processing.py:86-88): numeric / ndarray entries are summed."""
     import torch.distributed as dist

@@ -43,6 +43,7 @@ class Trainer(object):
         # during the second episode (the first runs eagerly as warm-up) and replayed afterwards.
         self._graphs = {}
         self._graph_pool = None
+        self._graph_gen = None          # policy_net.cache_generation the graphs were captured against
         self._episodes_played = 0
         self._static = None
         # encoder(obs) as a sparse gather from env state (ic3_env_encode) instead of a dense obs_dim x H GEMM;
@@ -97,6 +98,16 @@ class Trainer(object):
         self._step_out = [(None, None, None, None)] * T          # (state, action_out, value, next_state) per step
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
+        if self._use_graph() and self._graphs and getattr(self.policy_net, '_fc', None) is not None:
+            # weights may have changed since the capture (optimizer.step, checkpoint.load): replays never call
+            # forward(), so refresh the derived weight tensors here — in place, the graphs hold their addresses; if
+            # they had to be re-allocated the captured graphs are stale and are dropped
+            with torch.no_grad():
+                self.policy_net._fused_cache()
+            gen = getattr(self.policy_net, 'cache_generation', 0)
+            if gen != self._graph_gen:
+                self._graphs.clear()
+                self._episodes_played = min(self._episodes_played, 1)   # next episode re-captures
 
     def _dense_obs(self):
         """args.dense_obs=False skips the obs-assembly launch when nothing consumes the dense observation (sparse
@@ -134,6 +145,7 @@ class Trainer(object):
                     self._step_body(t, observe=in_graph_obs)
             finally:
                 raw.obs_timer = timer
+            self._graph_gen = getattr(self.policy_net, 'cache_generation', 0)
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
             # capture does not execute: fall through to a replay so that step t actually runs
@@ -144,7 +156,7 @@ class Trainer(object):
         self.clock.t = t
         g['graph'].replay()
         if not g['obs_inside'] and self._dense_obs():
-            if getattr(self.args, 'overlap_obs', False):
+            if self._overlap_obs():
                 self._observe_on_side_stream(raw)
             else:
                 raw.observe_timed()
@@ -210,7 +222,13 @@ class Trainer(object):
         """The obs-assembly launch stays outside the captured step graph when it runs on the side stream
         (args.overlap_obs) or is being event-timed (HIP events recorded in a captured graph cannot be timed; timing
         only every k-th step and keeping the other launches in their graphs was measured: no difference)."""
-        return bool(getattr(self.args, 'overlap_obs', False)) or raw.obs_timer is not None
+        return self._overlap_obs() or raw.obs_timer is not None
+
+    def _overlap_obs(self):
+        """args.overlap_obs is only honoured when nothing on the rollout path reads the dense observation (the sparse
+        encoder is active): otherwise the next forward's encoder GEMM would race with the side-stream obs launch."""
+        return bool(getattr(self.args, 'overlap_obs', False)) and getattr(self.policy_net, 'obs_encoder', None) is not None \
+            and self.args.hid_size % 4 == 0
 
     def _observe_on_side_stream(self, raw):
         """args.overlap_obs: the dense observation of the new state is assembled on a second stream from a snapshot

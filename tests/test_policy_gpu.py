@@ -293,7 +293,8 @@ def test_comm_fused_mfma_kernel(N, H, E, masks, mode_avg):
     assert float((xh[:, :H].double() - want[:, :H]).abs().max()) <= 3e-6 * scale
 
 
-@pytest.mark.parametrize("N,H,sizes", [(10, 128, [5, 2]), (5, 64, [2]), (3, 256, [5, 2]), (7, 32, [5, 2, 3, 4]), (4, 16, [9])])
+@pytest.mark.parametrize("N,H,sizes", [(10, 128, [5, 2]), (5, 64, [2]), (3, 256, [5, 2]), (7, 32, [5, 2, 3, 4]), (4, 16, [9]),
+                                         (6, 8, [5, 2]), (5, 4, [3]), (3, 16, [2, 2, 2, 2])])
 def test_lstm_cell_heads_sample_fused_kernel(N, H, sizes):
     """ic3_lstm_cell_heads == lstm_cell_ + policy_heads (+ sample_actions_env per head) — cell outputs bit-identical,
     heads within fp32 rounding (different reduction order), draws bit-identical to the separate sampling kernel run on
