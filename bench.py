@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (f32 in / f32 acc), same guide
 
 
 WORKLOADS = {
@@ -175,6 +176,20 @@ def cpu_baseline(workload, envs_per_proc=256, episodes=1, seed=0, budget_s=12.0)
                       "%d env-steps in %.1f s wall" % (procs, workload, budget_s, env_steps, wall)}
 
 
+def mfma_roofline(a, nenvs, step_ms):
+    """The MFMA-bound kernel of the step: policy_step_kernel.  Algorithmic flops per launch = the two dense layers of
+    comm.py (C: H x H, LSTMCell: 2H x 4H) plus the heads, 2 flops per multiply-add, for E*N rows."""
+    R, H = nenvs * a.nagents, a.hid_size
+    OT = sum(int(x) for x in a.naction_heads) + 1
+    flops = 2.0 * R * (2 * H * 4 * H + H * H + H * OT)
+    avg = sum(step_ms) / len(step_ms)
+    tf = flops / (avg * 1e-3) / 1e12
+    return {"kernel": "policy_step_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops,
+            "avg_launch_ms": round(avg, 4), "launches": len(step_ms),
+            "hbm_bytes_per_launch_algorithmic": R * (4 * H + OT + 2 * len(a.naction_heads) + 1) * 4}
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -190,6 +205,11 @@ def main():
                    help='diagnostic: skip obs assembly (sparse encoder consumes env state directly); NOT the headline config')
     p.add_argument('--overlap-obs', type=int, default=int(os.environ.get('IC3_BENCH_OVERLAP_OBS', '0')),
                    help='assemble the dense observation on a second stream, overlapped with the next step (graph mode)')
+    p.add_argument('--mega', type=int, default=int(os.environ.get('IC3_BENCH_MEGA', '1')),
+                   help='policy forward + action draws + env.step as ONE launch (ic3_policy_step); 0 = the launch chain')
+    p.add_argument('--time-kernels', type=int, default=int(os.environ.get('IC3_BENCH_TIME_KERNELS', '1')),
+                   help='bracket the policy+step launch and the obs-assembly launch with HIP events in the timed region '
+                        '(roofline numbers); the two launches are then issued eagerly instead of as graph replays')
     p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
                    help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
     p.add_argument('--tune-gemm', type=int, default=int(os.environ.get('IC3_BENCH_TUNE_GEMM', '1')),
@@ -213,6 +233,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
 
+    if o.mega:
+        o.tune_gemm = 0        # no library GEMM on the one-launch path (the chain fallback uses the default heuristics)
     if o.tune_gemm:
         try:
             import torch.cuda.tunable as tunable
@@ -234,8 +256,10 @@ def main():
     a.dense_obs = not o.no_dense_obs
     a.fused_lstm = bool(o.fused_lstm)
     a.overlap_obs = bool(o.overlap_obs)
+    a.mega_policy = bool(o.mega)
     T = a.max_steps
     raw_env = trainer.env.env
+    live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
 
     def run(nsteps, t_in_ep):
         for _ in range(nsteps):
@@ -244,7 +268,7 @@ def main():
             trainer.step_episode(t_in_ep)
             t_in_ep += 1
             if t_in_ep == T:
-                trainer.end_episode()             # stats reduced on device, one host read per episode
+                live_done[0] += trainer.end_episode()[1]['num_steps']   # stats reduced on device, one host read per episode
                 t_in_ep = 0
         return t_in_ep
 
@@ -262,6 +286,7 @@ def main():
             torch.cuda.synchronize()
             trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
             a.hip_graph, a.dense_obs, o.graph = False, not o.no_dense_obs, 0
+            a.mega_policy = bool(o.mega)
             raw_env = trainer.env.env
             raw_env.obs_timer = []
     t_in_ep = run(o.warmup, 0)
@@ -282,6 +307,10 @@ def main():
             backend = 'gloo'
     torch.cuda.synchronize()
     raw_env.obs_timer = []
+    mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use
+    if o.time_kernels and mega_live:
+        raw_env.step_timer = []               # both launches of a step are event-timed and issued eagerly
+    live0 = live_done[0] - raw_env.device_stats().live_env_steps      # minus the part of the running episode played so far
     # A full CPython GC pass over this process's heap (torch + numpy + the CPU-baseline imports) costs 35-80 ms —
     # as much as the whole timed region — and where it lands depends on allocation counts, not on the work.
     # Collect now and move the survivors to the permanent generation, as timeit-style harnesses do.
@@ -302,10 +331,20 @@ def main():
 
     obs_ms = [s.elapsed_time(e) for s, e in raw_env.obs_timer]
     raw_env.obs_timer = None
+    step_ms = [s.elapsed_time(e) for s, e, t in (raw_env.step_timer or []) if t > 0]   # t = 0 adds the h, c resets
+    raw_env.step_timer = None
+    live_steps = live_done[0] + raw_env.device_stats().live_env_steps - live0          # this rank, timed region
+    if world > 1:
+        lt = torch.tensor([live_steps], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(lt, op=dist.ReduceOp.SUM)
+        live_steps = float(lt.item())
     if rank == 0:
         N = a.nagents
         E_total = o.nenvs * world
-        value = N * E_total * o.steps / dt
+        # agent-steps actually simulated: envs whose episode ended early are frozen until the lock-step reset and do
+        # not count (a random-init PP-hard policy never ends early: live_frac = 1)
+        value = N * live_steps / dt
+        live_frac = live_steps / float(E_total * o.steps)
         obs_bytes = o.nenvs * N * raw_env.obs_dim * 4          # algorithmic bytes of one obs-assembly launch
         avg_ms = sum(obs_ms) / max(len(obs_ms), 1)
         achieved = obs_bytes / (avg_ms * 1e-3) / 1e9 if obs_ms else 0.0
@@ -325,14 +364,21 @@ def main():
             "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
                        "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world,
-                       "launch": "hipGraph replay" if o.graph else "eager", "dense_obs": not o.no_dense_obs,
-                       "overlap_obs": bool(o.overlap_obs),
-                       "gemm": "TunableOp-selected" if o.tune_gemm else "default heuristics"},
+                       "launch": ("eager, event-timed: policy+step launch, obs launch" if step_ms else
+                                  "hipGraph replay" if o.graph else "eager"),
+                       "dense_obs": not o.no_dense_obs, "overlap_obs": bool(o.overlap_obs),
+                       "policy": "one launch per step (ic3_policy_step)" if mega_live else "launch chain",
+                       "gemm": ("hand-written fp32 MFMA" if mega_live else
+                                "TunableOp-selected" if o.tune_gemm else "default heuristics")},
+            "live_frac": round(live_frac, 6),
             "roofline": {"kernel": "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "rocprofv3 PMC passes of this command, profiles/obs_traffic.json (not re-measured "
+                                           "in this run)" if traffic is not None else None,
                          "bytes_per_launch": obs_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": len(obs_ms)},
             "cpu_baseline": cpu,
+            "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms) if step_ms else None,
             "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),
         }
         print(json.dumps(out))

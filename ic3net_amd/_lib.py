@@ -38,6 +38,14 @@ class Stats(C.Structure):
                 ("live_env_steps", C.c_int64)]
 
 
+class Policy(C.Structure):
+    """ic3_policy (include/ic3_rollout.h): host struct of device pointers for ic3_policy_step."""
+    _fields_ = [("H", C.c_int32), ("nheads", C.c_int32), ("head_sizes", C.c_int32 * 4), ("mode_avg", C.c_int32),
+                ("comm_zero", C.c_int32), ("enc_wt", C.c_void_p), ("enc_bias", C.c_void_p), ("loc_table", C.c_void_p),
+                ("c_wp", C.c_void_p), ("lstm_wp", C.c_void_p), ("lstm_bias", C.c_void_p), ("head_w", C.c_void_p),
+                ("head_b", C.c_void_p)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "ic3_version": (C.c_int, []),
@@ -81,6 +89,10 @@ EXPORTS = {
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_env_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
+    "ic3_policy_pack": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
+    "ic3_policy_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
+    "ic3_policy_forward": (C.c_int, [C.POINTER(Policy), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "ic3_policy_step": (C.c_int, [C.c_void_p, C.POINTER(Policy)] + [C.c_void_p] * 12),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_int, C.c_void_p]),
 }

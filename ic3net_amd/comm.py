@@ -191,6 +191,32 @@ class CommNetMLP(nn.Module):
         R = batch * n
         dev = x.device
         fc = self._fused_cache()
+        alive = self._mask(info, 'alive_mask', batch, dev)
+        comm_action = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
+        mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
+        self.sampled = False
+        if 'ps_l_wp' in fc and n <= 64:
+            # everything after the encoder in ONE launch (ic3_policy_forward: communication block, C, LSTMCell, heads,
+            # log_softmax; comm / inp / gates stay in LDS and registers)
+            mb = getattr(self, '_mb', None)
+            if mb is None or mb['h'].shape[0] != R or mb['h'].device != dev:
+                mb = self._mb = dict(h=torch.empty((R, H), dtype=torch.float32, device=dev),
+                                     c=torch.empty((R, H), dtype=torch.float32, device=dev))
+            h, c = mb['h'], mb['c']
+            if hidden_state.data_ptr() != h.data_ptr():            # fresh hidden state from the caller (t = 0)
+                h.copy_(hidden_state.detach().reshape(R, H))
+            if cell_state.data_ptr() != c.data_ptr():
+                c.copy_(cell_state.detach().reshape(R, H))
+            enc = mb.get('enc')
+            if enc is None:
+                enc = mb['enc'] = torch.empty((R, H), dtype=torch.float32, device=dev)
+            if self._x_is_env_obs(x):
+                self.obs_encoder(fc['wt'], fc['enc_bias'], out=enc, loc_table=fc['loc_table'])
+            else:
+                torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)       # dense encoder GEMM
+            out = ops.policy_forward(fc, H, self.args.naction_heads, mode_avg, bool(self.args.comm_mask_zero), enc, batch,
+                                     n, h, c, alive, comm_action)
+            return self._split_out(out, batch, n) + ((h, c),)
         buf = getattr(self, '_fb', None)
         if buf is None or buf['xh'].shape[0] != R or buf['xh'].device != dev:
             buf = self._fb = dict(xh=torch.empty((R, 2 * H), dtype=torch.float32, device=dev),
@@ -203,9 +229,6 @@ class CommNetMLP(nn.Module):
             h_view.copy_(hidden_state.detach().reshape(R, H))
         if cell_state.data_ptr() != c.data_ptr():
             c.copy_(cell_state.detach().reshape(R, H))
-        alive = self._mask(info, 'alive_mask', batch, dev)
-        comm_action = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
-        mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
         # encoder(x) + C.bias -> XH[:, :H]
         if self._x_is_env_obs(x):
             self.obs_encoder(fc['wt'], fc['enc_bias'], out=xh[:, :H], loc_table=fc['loc_table'])
@@ -223,7 +246,7 @@ class CommNetMLP(nn.Module):
             ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg, True,
                                      out=buf['comm'])
             xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                      # inp = enc + C(comm_sum)
-        out, self.sampled = None, False
+        out = None
         if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
             ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel
         else:
@@ -238,13 +261,65 @@ class CommNetMLP(nn.Module):
                 ops.lstm_cell_(buf['gates'], c, h_view)
         if out is None:
             out = ops.policy_heads(h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads)
+        return self._split_out(out, batch, n) + ((h_view, c),)
+
+    def _split_out(self, out, batch, n):
+        """(R, OT) [log-probs of every head | value] -> ([ (E,N,A_k) ], value (R,1))"""
         OT = out.shape[1]
         action, off = [], 0
         for A in self.args.naction_heads:
             action.append(out.view(batch, n, OT)[:, :, off:off + A])
             off += A
-        value_head = out[:, off:off + 1]
-        return action, value_head, (h_view, c)
+        return action, out[:, off:off + 1]
+
+    # ------------------------------------------------------------------------------------------
+    # One-launch rollout iteration (ic3_policy_step, csrc/policy_step.hip): forward + select_action + env.step for a
+    # tile of whole envs per workgroup; encoder output, communication vectors, gates and logits never reach HBM.
+    # Same contract as _forward_fused (no autograd, recurrent LSTM policy, one communication pass, state read through
+    # the env's integer state), plus: the caller hands over the env and the buffers env.step would fill.
+    # ------------------------------------------------------------------------------------------
+    def mega_ok(self, env, x):
+        """True when step_env() may replace forward + select_action + env.step for this input."""
+        if not (self._mega_wanted() and self._fused_ok(x) and hasattr(env, '_h')):
+            return False
+        if getattr(self.obs_encoder, '__self__', None) is not env or not self._x_is_env_obs(x[0]):
+            return False
+        if x[0].shape[0] != env.nenvs or self.nagents != env.nagents_env:
+            return False
+        ok = getattr(self, '_mega_sup', None)
+        if ok is None or ok[0] is not env:
+            ok = self._mega_sup = (env, ops.policy_step_supported(env, self.hid_size))
+        return ok[1]
+
+    def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None):
+        """action_out, value, (h, c) = forward(x, info); `action` (heads, E, N) int32 <- select_action (Philox draws
+        positioned by the env's own counters); env.step(action[0]) -> reward (E,N) f32, done (E,) i32, alive /
+        is_completed (E,N) i32 [, obs (E,N,obs_dim)].  trainer.py:49-67 in one launch."""
+        n, H = self.nagents, self.hid_size
+        x, (hidden_state, cell_state) = x
+        batch = x.size(0)
+        R = batch * n
+        dev = x.device
+        fc = self._fused_cache()
+        mb = getattr(self, '_mb', None)
+        if mb is None or mb['h'].shape[0] != R or mb['h'].device != dev:
+            mb = self._mb = dict(h=torch.empty((R, H), dtype=torch.float32, device=dev),
+                                 c=torch.empty((R, H), dtype=torch.float32, device=dev))
+        h, c = mb['h'], mb['c']
+        if hidden_state.data_ptr() != h.data_ptr():            # fresh hidden state from the caller (t = 0)
+            h.copy_(hidden_state.detach().reshape(R, H))
+        if cell_state.data_ptr() != c.data_ptr():
+            c.copy_(cell_state.detach().reshape(R, H))
+        alive_in = self._mask(info, 'alive_mask', batch, dev)
+        comm_in = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
+        mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
+        heads = [int(a) for a in self.args.naction_heads]
+        OT = sum(heads) + 1
+        out = torch.empty((R, OT), dtype=torch.float32, device=dev)    # per call: a Transition keeps its action_out
+        ops.policy_step(env, fc, H, heads, mode_avg, bool(self.args.comm_mask_zero), h, c, alive_in, comm_in, out, action,
+                        reward, done, alive, is_completed, obs)
+        self.mega_steps = getattr(self, 'mega_steps', 0) + 1
+        return self._split_out(out, batch, n) + ((h, c),)
 
     def _encode(self, x):
         """self.encoder(x) (comm.py:51,119); during no-grad rollouts optionally via the env's sparse gather."""

@@ -1,0 +1,385 @@
+// env_device.hpp — device-side bodies of the Predator-Prey / Traffic-Junction step and of the sparse-encoder row,
+// shared by the stand-alone kernels (pp_kernels.hip, tj_kernels.hip) and by the fused policy+step kernel
+// (policy_step.hip), so that every launch geometry runs the same arithmetic.  gfx950 only.
+//
+// Reference semantics: /root/reference/ic3net-envs/ic3net_envs/predator_prey_env.py ("PP:line") and
+// traffic_junction_env.py ("TJ:line").
+#pragma once
+
+#include <type_traits>
+
+#include "ic3_common.hpp"
+
+namespace ic3 {
+
+typedef float dv_f32x4 __attribute__((ext_vector_type(4)));
+
+// Sum over an aligned group of G lanes (G a power of two <= 64), result in every lane of the group.  The steps inside a
+// 16-lane row are DPP moves on the VALU (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror) instead of ds_bpermute
+// round trips; only the 16- and 32-lane steps go through __shfl_xor.
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                     0xf, 0xf, false));
+    };
+    if constexpr (G >= 2) v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    if constexpr (G >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Predator-Prey
+// ------------------------------------------------------------------------------------------------
+struct PPState {
+    int32_t *loc_r, *loc_c, *reached, *over, *success, *tstep;
+    int Np;       // predators (cfg.N)
+    int nprey;
+    int dim, v, mode, naction;
+    int rows;     // rows seen by the policy: Np, or Np + nprey with enemy_comm
+};
+
+struct StepOut {
+    float* reward;
+    int32_t *done, *alive_out, *comp_out, *err;
+};
+
+__device__ __forceinline__ bool padded_outside(int pr, int pc, int v, int dim)
+{
+    return pr < v || pr >= v + dim || pc < v || pc >= v + dim;  // np.pad(grid, vision, OUTSIDE_CLASS) PP:184
+}
+
+// step: PP:112-144 = _take_action for every predator (PP:212-252), then _get_reward (PP:254-290).  Called by ALL
+// lanes of a wave (ballots); lane (e, n) with n < G, G = pow2 >= rows lanes per env, groups aligned inside the wave.
+// `act_of()` returns the env action of (e, n) — only evaluated for lanes with e < E and n < rows.
+template <class ActFn>
+__device__ __forceinline__ void pp_step_lanes(const PPState& s, const StepOut& o, int e, int n, int E, int G, ActFn act_of)
+{
+    const int N = s.Np, rows = s.rows, dim = s.dim, v = s.v, mode = s.mode;
+    const bool in_env = (e < E) && (n < rows);
+    const bool valid = in_env && (n < N);
+    const int total = N + s.nprey;
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
+
+    int r = 0, c = 0, pr = -1, pc = -1, rch = 0, act = 4, was_over = 1;
+    if (in_env) {
+        act = act_of();
+        was_over = s.over[e];
+        if (act > s.naction) atomicOr(o.err, 1);  // PP:137 (<=, quirk Q2; checked on every entry of `action`)
+    }
+    if (valid) {
+        const size_t li = (size_t)e * total + n;
+        r = s.loc_r[li];
+        c = s.loc_c[li];
+        pr = s.loc_r[(size_t)e * total + N];  // prey 0 only: (N,2)==(1,2) broadcast, quirk Q7 PP:258
+        pc = s.loc_c[(size_t)e * total + N];
+        rch = s.reached[(size_t)e * N + n];
+    }
+    const bool live = valid && !was_over;
+    if (live && rch != 1 && act != 5) {  // frozen PP:221-222; (sic) STAY guard PP:224-226
+        if (act == 0) {                  // UP PP:229-232
+            int qr = r + v - 1;
+            qr = qr < 0 ? 0 : qr;
+            if (!padded_outside(qr, c + v, v, dim)) r = (r - 1 > 0) ? r - 1 : 0;
+        } else if (act == 1) {           // RIGHT PP:235-239 (padded index clamped to dim-1, sic)
+            int qc = c + v + 1;
+            qc = qc > dim - 1 ? dim - 1 : qc;
+            if (!padded_outside(r + v, qc, v, dim)) c = (c + 1 < dim - 1) ? c + 1 : dim - 1;
+        } else if (act == 2) {           // DOWN PP:242-246
+            int qr = r + v + 1;
+            qr = qr > dim - 1 ? dim - 1 : qr;
+            if (!padded_outside(qr, c + v, v, dim)) r = (r + 1 < dim - 1) ? r + 1 : dim - 1;
+        } else if (act == 3) {           // LEFT PP:249-252
+            int qc = c + v - 1;
+            qc = qc < 0 ? 0 : qc;
+            if (!padded_outside(r + v, qc, v, dim)) c = (c - 1 > 0) ? c - 1 : 0;
+        }
+    }
+    const bool on = live && (r == pr) && (c == pc);
+    const int n_on = __popcll(__ballot(on) & gmask);
+    const int rch_new = (rch == 1 || on) ? 1 : 0;  // PP:271
+    const int n_reached = __popcll(__ballot(live && rch_new) & gmask);
+    if (!in_env) return;
+    if (!valid) {   // prey row (enemy_comm): reward 0.05 while no predator is on it, else 0 (PP:276-281)
+        o.reward[(size_t)e * rows + n] = was_over ? 0.0f : (n_on == 0 ? (float)0.05 : 0.0f);
+        if (o.alive_out) o.alive_out[(size_t)e * rows + n] = 1;
+        if (o.comp_out) o.comp_out[(size_t)e * rows + n] = 0;
+        return;
+    }
+    float rew = 0.0f;
+    if (live) {
+        double rd = -0.05;  // TIMESTEP_PENALTY PP:256
+        if (on) {
+            if (mode == IC3_PP_COOPERATIVE) rd = 0.05 * (double)n_on;        // PP:262
+            else if (mode == IC3_PP_COMPETITIVE) rd = 0.05 / (double)n_on;   // PP:265
+            else rd = 0.0;                                                   // PP:267
+        }
+        rew = (float)rd;
+        const size_t li = (size_t)e * total + n;
+        s.loc_r[li] = r;
+        s.loc_c[li] = c;
+        s.reached[(size_t)e * N + n] = rch_new;
+    }
+    o.reward[(size_t)e * rows + n] = rew;
+    if (o.alive_out) o.alive_out[(size_t)e * rows + n] = 1;
+    if (o.comp_out) o.comp_out[(size_t)e * rows + n] = 0;
+    if (n == 0) {
+        int ov = was_over;
+        if (live) {
+            ov = (n_reached == N && mode == IC3_PP_MIXED) ? 1 : 0;                 // PP:273-274
+            if (mode != IC3_PP_COMPETITIVE) s.success[e] = (n_on == N) ? 1 : 0;    // PP:284-288
+            s.over[e] = ov;
+            s.tstep[e] += 1;
+        }
+        o.done[e] = ov;
+    }
+}
+
+// Window descriptors of ONE env in LDS: sr/sc = positions of its Np + nprey entities, tab[a*W*W + dy*W + dx] =
+// (one-hot channel, #predators | #prey << 16) for entity a's window cell (dy, dx).  Entry s of the env's table:
+__device__ __forceinline__ int2 pp_tab_entry(const int32_t* sr, const int32_t* sc, int s, int N, int total, int dim, int v)
+{
+    const int W = 2 * v + 1;
+    const int OUTSIDE = dim * dim + 1;
+    const int a = s / (W * W), w = s - a * (W * W);
+    const int dy = w / W, dx = w - dy * W;
+    const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
+    const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
+    int npred = 0, npr = 0;
+    for (int p = 0; p < N; ++p) npred += (sr[p] == gr) & (sc[p] == gc);             // PP:191-192
+    for (int p = N; p < total; ++p) npr += (sr[p] == gr) & (sc[p] == gc);           // PP:194-195
+    return make_int2(id, npred | (npr << 16));
+}
+
+// encoder(obs row of entity a)[4*c4 .. 4*c4+3] from the env's LDS descriptors (see pp_encode_kernel)
+__device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
+                                                  int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
+                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table)
+{
+    dv_f32x4 acc = bias[c4];
+    // the one-hot location channels of all window cells depend only on the entity's position: one row of the
+    // pre-summed table (pp_encode_table_kernel) replaces W*W gathered rows
+    if (loc_table) acc += loc_table[(size_t)(sr[a] * dim + sc[a]) * H4 + c4];
+    for (int cell = 0; cell < WW; ++cell) {
+        const int2 t = tab[a * WW + cell];
+        const size_t row = (size_t)cell * vocab;
+        if (!loc_table) acc += Wt[(row + t.x) * H4 + c4];
+        const int npred = t.y & 0xffff, npr = t.y >> 16;
+        if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
+        if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traffic-Junction
+// ------------------------------------------------------------------------------------------------
+struct TJState {
+    int32_t *alive, *wait, *loc_r, *loc_c, *last_act, *route_loc, *route_id, *completed, *cars, *failed;
+    const int32_t *over, *episode;
+    int32_t* tstep;
+    const int32_t *route_off, *route_rc, *grid, *thr;
+    int N, narrival, rpa;
+    int h, w, v, vocab, outside, car_class, npath, hdr;
+    uint32_t seed, gid0;
+};
+
+// step: TJ:206-252 = _take_action (TJ:540-581), _add_cars (TJ:369-393), _get_reward (TJ:585-595).  Called by all lanes
+// of a wave; G = pow2 >= max(N, 8) lanes per env.
+template <class ActFn>
+__device__ __forceinline__ void tj_step_lanes(const TJState& s, const StepOut& o, int e, int n, int E, int G, ActFn act_of)
+{
+    const int N = s.N, narrival = s.narrival, rpa = s.rpa;
+    const bool env_ok = e < E;
+    const bool valid = env_ok && n < N;
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
+    const size_t i = (size_t)e * N + n;
+
+    int alive = 0, wait = 0, r = 0, c = 0, last_act = 0, rloc = -1, rid = -1, completed = 0, act = 1;
+    uint32_t ep = 0, t = 0;
+    if (env_ok) {
+        ep = (uint32_t)s.episode[e];
+        t = (uint32_t)s.tstep[e];
+    }
+    if (valid) {
+        alive = s.alive[i];
+        wait = s.wait[i];
+        r = s.loc_r[i];
+        c = s.loc_c[i];
+        last_act = s.last_act[i];
+        rloc = s.route_loc[i];
+        rid = s.route_id[i];
+        act = act_of();
+        if (act > 2) atomicOr(o.err, 1);  // TJ:228 (naction = 2, <=, quirk Q2)
+    }
+    // ---- _take_action TJ:540-581 ----
+    if (valid && alive) {
+        wait += 1;                      // TJ:546
+        if (act == 1) {
+            last_act = 1;               // TJ:549-551
+        } else if (act == 0) {
+            rloc += 1;                  // TJ:556
+            const int off = s.route_off[rid], len = s.route_off[rid + 1] - off;
+            if (rloc == len) {          // TJ:560-568 reached the end of its route
+                alive = 0;
+                wait = 0;
+                r = c = 0;
+                completed = 1;
+            } else {
+                const int rc = s.route_rc[off + rloc];  // TJ:575-578
+                r = rc >> 16;
+                c = rc & 0xffff;
+                last_act = 0;           // TJ:581
+            }
+        }
+    }
+    // ---- _add_cars TJ:369-393: lane j of the group pre-draws arrival point j's three uniforms ----
+    const int32_t thr = *s.thr;  // floor(add_rate * 2^24): u <= add_rate <=> x24 <= thr (exact)
+    uint32_t x0 = 0, x1 = 0, x2 = 0;
+    if (env_ok && n < narrival) {
+        x0 = philox_x24(s.seed, s.gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 0u);
+        x1 = philox_x24(s.seed, s.gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 1u);
+        x2 = philox_x24(s.seed, s.gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 2u);
+    }
+    for (int a = 0; a < narrival; ++a) {
+        const unsigned long long am = __ballot(valid && alive) & gmask;
+        const unsigned long long dm = __ballot(valid && !alive) & gmask;
+        const int cars = __popcll(am), nd = __popcll(dm);
+        const uint32_t u0 = (uint32_t)__shfl((int)x0, gbase + a);
+        const uint32_t u1 = (uint32_t)__shfl((int)x1, gbase + a);
+        const uint32_t u2 = (uint32_t)__shfl((int)x2, gbase + a);
+        const bool add = (cars < N) && ((int32_t)u0 <= thr);              // TJ:371-372, 375
+        if (add && valid && !alive) {
+            const int k = (int)scale24(u1, (uint32_t)nd);                 // _choose_dead TJ:614-618: k-th dead slot
+            const int rank = __popcll(dm & ((1ull << lane) - 1ull));
+            if (rank == k) {
+                alive = 1;                                                // TJ:380
+                rid = (int)scale24(u2, (uint32_t)rpa) + a * rpa;          // TJ:383-385
+                rloc = 0;                                                 // TJ:389
+                const int rc = s.route_rc[s.route_off[rid]];              // TJ:390
+                r = rc >> 16;
+                c = rc & 0xffff;
+            }
+        }
+    }
+    const int cars_now = __popcll(__ballot(valid && alive) & gmask);     // == cars_in_sys (TJ:393,561)
+    // ---- _get_reward TJ:585-595: crash iff another car (alive or parked dead) shares a non-(0,0) cell ----
+    const int packed = valid ? ((r << 16) | c) : -1;
+    bool same = false;
+    for (int j = 0; j < N; ++j) {
+        const int pj = __shfl(packed, gbase + j);
+        same |= (j != n) && (pj == packed);
+    }
+    const bool crash = valid && same && (packed != 0);                   // l.any(): loc != (0,0), quirk Q10
+    const bool any_crash = (__ballot(crash) & gmask) != 0ull;
+    if (!valid) return;
+    double rd = -0.01 * (double)wait;                                     // TJ:586
+    if (crash) rd += -10.0;                                               // TJ:591
+    rd = (double)alive * rd;                                              // TJ:594
+    o.reward[i] = (float)rd;
+    s.alive[i] = alive;
+    s.wait[i] = wait;
+    s.loc_r[i] = r;
+    s.loc_c[i] = c;
+    s.last_act[i] = last_act;
+    s.route_loc[i] = rloc;
+    s.route_id[i] = rid;
+    s.completed[i] = completed;
+    if (o.alive_out) o.alive_out[i] = alive;                              // info['alive_mask'] TJ:244
+    if (o.comp_out) o.comp_out[i] = completed;                            // info['is_completed'] TJ:247
+    if (n == 0) {
+        s.cars[e] = cars_now;
+        if (any_crash) s.failed[e] = 1;                                   // TJ:592
+        s.tstep[e] = (int32_t)t + 1;
+        o.done[e] = s.over[e];                                            // never set by TJ (quirk Q12)
+    }
+}
+
+// Per-env LDS block of the TJ observation / encoder kernels: [sr | sc | sal | s0 | s1 | s2 | s3] (N words each), then
+// tab[N*WW] = (one-hot channel, #cars).
+struct TJTile {
+    int32_t *sr, *sc, *sal;
+    float *s0, *s1, *s2, *s3;
+    int2* tab;
+};
+
+__device__ __forceinline__ int tj_tile_words(int N, int WW) { return ((7 * N + 3) & ~3) + 2 * N * WW; }
+
+__device__ __forceinline__ TJTile tj_tile_at(int32_t* base, int N)
+{
+    TJTile t;
+    t.sr = base;
+    t.sc = t.sr + N;
+    t.sal = t.sc + N;
+    t.s0 = reinterpret_cast<float*>(t.sal + N);
+    t.s1 = t.s0 + N;
+    t.s2 = t.s1 + N;
+    t.s3 = t.s2 + N;
+    t.tab = reinterpret_cast<int2*>(base + ((7 * N + 3) & ~3));
+    return t;
+}
+
+__device__ __forceinline__ void tj_tile_load_car(const TJTile& t, const TJState& s, int e, int a)
+{
+    const size_t i = (size_t)e * s.N + a;
+    t.sr[a] = s.loc_r[i];
+    t.sc[a] = s.loc_c[i];
+    t.sal[a] = s.alive[i];
+    t.s0[a] = (float)((double)s.last_act[i] / 1.0);                          // TJ:338 naction-1 == 1
+    t.s1[a] = (float)((double)s.route_id[i] / (double)(s.npath - 1));        // TJ:341
+    t.s2[a] = (float)((double)t.sr[a] / (double)(s.h - 1));                  // TJ:344
+    t.s3[a] = (float)((double)t.sc[a] / (double)(s.w - 1));
+}
+
+__device__ __forceinline__ int2 tj_tab_entry(const TJTile& t, const TJState& s, int q)
+{
+    const int W = 2 * s.v + 1, WW = W * W;
+    const int a = q / WW, cell = q - a * WW;
+    const int dy = cell / W, dx = cell - dy * W;
+    const int gr = t.sr[a] + dy - s.v, gc = t.sc[a] + dx - s.v;
+    const int id = (gr >= 0 && gr < s.h && gc >= 0 && gc < s.w) ? s.grid[gr * s.w + gc] : s.outside;   // pad_grid TJ:317
+    int ncar = 0;
+    for (int p = 0; p < s.N; ++p) ncar += (t.sr[p] == gr) & (t.sc[p] == gc);                          // TJ:326-327
+    return make_int2(id, ncar);
+}
+
+// encoder(obs row of car a)[4*c4 ..] (see tj_encode_kernel): bias only for a dead car (its obs row is zero)
+__device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
+                                                  const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
+                                                  const dv_f32x4* __restrict__ loc_table)
+{
+    const int W = 2 * s.v + 1, WW = W * W;
+    dv_f32x4 acc = bias[c4];
+    if (t.sal[a]) {
+        acc += t.s0[a] * Wt[c4];
+        acc += t.s1[a] * Wt[H4 + c4];
+        if (s.hdr == 4) {
+            acc += t.s2[a] * Wt[2 * H4 + c4];
+            acc += t.s3[a] * Wt[3 * H4 + c4];
+        }
+        if (loc_table) acc += loc_table[(size_t)(t.sr[a] * s.w + t.sc[a]) * H4 + c4];   // see pp_encode_kernel
+        for (int cell = 0; cell < WW; ++cell) {
+            const int2 d = t.tab[a * WW + cell];
+            const size_t row = s.hdr + (size_t)cell * s.vocab;
+            if (!loc_table && d.x >= 0) acc += Wt[(row + d.x) * H4 + c4];   // scalar vocab: -1 = not a road cell
+            if (d.y) acc += (float)d.y * Wt[(row + s.car_class) * H4 + c4];
+        }
+    }
+    return acc;
+}
+
+// host helpers (pp_kernels.hip / tj_kernels.hip): device views of a handle's state
+PPState pp_state_of(const ic3_env* env);
+TJState tj_state_of(const ic3_env* env);
+int tj_group(int N);
+
+}  // namespace ic3

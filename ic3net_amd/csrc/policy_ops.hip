@@ -4,6 +4,7 @@
 // plus synthetic uniform actions for env-only benchmarks.
 #include <type_traits>
 
+#include "env_device.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -192,25 +193,7 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
 // shuffle reduce; lane 0 of the row finishes log_softmax (same arithmetic as policy_heads_kernel) and, when an env
 // handle is given, draws the actions of every head (same arithmetic and Philox counters as sample_actions_env_kernel).
 // Saves re-reading h (R*H*4 bytes) and three launches per step.  H/4 must be a power of two <= 64.
-// Sum over an aligned group of G lanes (G a power of two <= 64), result in every lane of the group.  The steps inside a
-// 16-lane row are DPP moves on the VALU (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror) instead of ds_bpermute
-// round trips; only the 16- and 32-lane steps go through __shfl_xor.
-template <int G>
-__device__ __forceinline__ float group_sum(float v)
-{
-    auto dpp = [](float x, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
-                                                                     0xf, 0xf, false));
-    };
-    if constexpr (G >= 2) v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-    if constexpr (G >= 4) v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-    if constexpr (G >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    if constexpr (G >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
-    if constexpr (G >= 32) v += __shfl_xor(v, 16);
-    if constexpr (G >= 64) v += __shfl_xor(v, 32);
-    return v;
-}
-
+// (group_sum<G>: env_device.hpp)
 template <int H4, int MAXO>
 __global__ __launch_bounds__(256) void lstm_cell_heads_kernel(const float* __restrict__ gates, float* __restrict__ c,
                                                               float* __restrict__ h_out, int ldh, int R,

@@ -1,0 +1,586 @@
+// policy_step.hip — ONE launch per rollout step (gfx950): the whole iteration of /root/reference/trainer.py:43-108
+// for a tile of whole environments,
+//     CommNetMLP.forward (comm.py:134-244: encoder -> masked communication mean -> C -> LSTMCell -> heads, log_softmax)
+//     select_action      (action_utils.py:32-36, Philox inverse-CDF)
+//     env.step           (predator_prey_env.py:112-144 / traffic_junction_env.py:206-252, without the observation)
+// Communication only mixes agents of the SAME env (comm.py:181-205), so a workgroup that owns EPT = 64/N whole envs
+// (<= 64 agent rows) needs nothing from any other workgroup: the encoder output, the communication vectors, `inp`,
+// the (rows x 4H) gate pre-activations and the logits only ever exist in LDS / registers.  HBM traffic per row:
+// read h, c (2H floats) + write h', c' (2H) + log-probs/value/actions/reward — the six-kernel chain it replaces moved
+// ~11H floats per row through HBM (enc, comm, inp, gates written and re-read).
+//
+// MFMA-bound: 2*R*(2H*4H + H*H) flops on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate; 157 TFLOP/s
+// peak).  Decomposition for H = 128 (256 threads, 2 workgroups per CU so that one workgroup's staging / epilogue
+// phases run under the other's MFMA loop):
+//   * tile = 64 rows x ALL 4H gate columns; wave w owns hidden columns [32w, 32w+32) of the four gates -> 2 (row
+//     tiles) x 4 (gates) accumulators of 32x32; a lane holds the SAME (row, column) of all four gates, so the LSTM
+//     nonlinearity needs no cross-lane traffic;
+//   * A = [inp | h] tile in LDS, row stride 2H+4 floats: one ds_read_b128 per lane feeds four MFMA k-steps
+//     (k = 8kb + 4*(lane>>5) + j), conflict-free (16-lane phase groups hit 16 distinct 4-bank slots);
+//   * B = weights streamed from L2, pre-packed as Wp[k/8][col][(k>>2)&1][k&3] (ic3_policy_pack): one coalesced
+//     16-byte load per lane per gate per 8 k, two register buffers refilled a full 32-MFMA block ahead;
+//   * LDS budget 64 x (2H+4) floats = 66.5 KB: the encoder output is staged through the h half, parked in the
+//     accumulators of the C product (which it initialises), and the communication tile takes the inp half.
+#include "env_device.hpp"
+#include "ic3_common.hpp"
+
+namespace ic3 {
+
+typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
+
+struct StepArgs {
+    // policy (ic3_policy)
+    const ps_f32x4* Wt;         // encoder.weight^T [obs_dim][H/4]
+    const ps_f32x4* enc_bias;   // encoder.bias + C.bias [H/4]
+    const ps_f32x4* loc_table;  // ic3_env_encode_table or null
+    const float* enc_in;        // KIND 0 (no env): encoder(x) + C.bias computed by the caller, [R][H]
+    const ps_f32x4* c_wp;       // packed C.weight
+    const ps_f32x4* l_wp;       // packed [W_ih | W_hh]
+    const float* l_bias;        // b_ih + b_hh [4H]
+    const float* head_w;        // [OT][H]  heads then value head
+    const float* head_b;        // [OT]
+    int OT, nheads, a0, a1, a2, a3;
+    int mode_avg, comm_zero;
+    // recurrent state, masks, outputs
+    float* h;                   // [R][H] in place
+    float* c;                   // [R][H] in place
+    const int32_t* alive_in;    // [R] or null (t = 0: everyone alive, quirk Q21)
+    const int32_t* comm_in;     // [R] or null (gate sampled at t-1, quirk Q22)
+    float* out;                 // [R][OT] log-probs | value
+    int32_t* action;            // [nheads][R]
+    // env
+    int E, N, EPT, G;
+    uint32_t seed, gid0;
+    const int32_t* episode;
+    const int32_t* tstep;
+    StepOut so;
+    PPState pp;
+    TJState tj;
+};
+
+template <int H, int KIND>
+__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(const StepArgs a)
+{
+    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                            // [BM][LDA]: cols [0,H) inp / comm, [H,2H) h / enc / h'
+    ps_f32x4* As4 = reinterpret_cast<ps_f32x4*>(smem);
+    float* sm = As + BM * LDA;                                   // [BM] m_j = alive_j * comm_action_j
+    float* sscale = sm + BM;                                     // [BM] per-env 1/(n_alive-1)
+    int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
+    int32_t* tile = sact + BM;                                   // env descriptors of the tile's envs
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int N = a.N;
+    const int e0 = blockIdx.x * a.EPT;
+    const int nenv = min(a.EPT, a.E - e0);
+    const int rows = nenv * N;                                   // valid rows of this tile (<= 64)
+    const size_t r0 = (size_t)e0 * N;
+
+    // ---- S0: masks, per-env scale (comm.py:102-107,194-196; quirks Q21/Q23), entity positions --------------------
+    for (int r = tid; r < BM; r += NT) {
+        float m = 0.f;
+        if (r < rows) m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
+        sm[r] = m;
+    }
+    for (int el = tid; el < nenv; el += NT) {
+        int n_alive = 0;
+        for (int j = 0; j < N; ++j) n_alive += a.alive_in ? a.alive_in[r0 + (size_t)el * N + j] : 1;
+        sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
+    }
+    // tile layout PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x (tj_tile_words) blocks
+    const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
+    const int total = a.pp.Np + a.pp.nprey;
+    const int nsegE = N * WW;
+    int32_t* sr = tile;
+    int32_t* sc = tile + a.EPT * total;
+    int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
+    const int tjw = tj_tile_words(N, WW);
+    if constexpr (KIND == IC3_ENV_PP) {
+        for (int i = tid; i < nenv * total; i += NT) {
+            sr[i] = a.pp.loc_r[(size_t)e0 * total + i];
+            sc[i] = a.pp.loc_c[(size_t)e0 * total + i];
+        }
+    } else if constexpr (KIND == IC3_ENV_TJ) {
+        for (int i = tid; i < rows; i += NT) {
+            const int el = i / N;
+            tj_tile_load_car(tj_tile_at(tile + el * tjw, N), a.tj, e0 + el, i - el * N);
+        }
+    }
+    // h rows of the tile: requested now (HBM latency runs under S1/S2), parked in registers until the encoder output
+    // has left the h half of the LDS tile
+    ps_f32x4 hv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / H4, c4 = idx - row * H4;
+        hv[i] = row < rows ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4) : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+    }
+    __syncthreads();
+
+    // ---- S1: window descriptors ------------------------------------------------------------------------------------
+    if constexpr (KIND != 0) {
+        for (int s = tid; s < nenv * nsegE; s += NT) {
+            const int el = s / nsegE, q = s - el * nsegE;
+            if constexpr (KIND == IC3_ENV_PP) {
+                ptab[s] = pp_tab_entry(sr + el * total, sc + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
+            } else {
+                const TJTile t = tj_tile_at(tile + el * tjw, N);
+                t.tab[q] = tj_tab_entry(t, a.tj, q);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / H4, c4 = idx - row * H4;
+        ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+        if (row < rows) {
+            const int el = row / N, aa = row - el * N;
+            if constexpr (KIND == 0) {
+                v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
+            } else if constexpr (KIND == IC3_ENV_PP) {
+                v = pp_encode_row(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
+                                  a.pp.dim * a.pp.dim + 4, a.pp.dim, a.Wt, a.enc_bias, a.loc_table);
+            } else {
+                v = tj_encode_row(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, a.Wt, a.enc_bias, a.loc_table);
+            }
+        }
+        As4[row * LDA4 + H4 + c4] = v;
+    }
+    __syncthreads();
+
+    // ---- S3: the encoder output moves into the accumulators of the C product (MFMA C/D layout:
+    //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------------------------------------------------
+    const int col = 32 * w + li;
+    ps_f32x16 accC[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            accC[rt][reg] = As[lr * LDA + H + col];
+        }
+    __syncthreads();
+
+    // ---- S4: h -> h half ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * NT;
+        const int row = idx / H4, c4 = idx - row * H4;
+        As4[row * LDA4 + H4 + c4] = hv[i];
+    }
+    __syncthreads();
+
+    if (!a.comm_zero) {   // comm_mask_zero (comm.py:40-41): C sees zeros, inp = enc + C.bias
+        // ---- S5: comm_j = m_j (S_e - m_j h_j) scale_e (closed form of comm.py:181-205) -> inp half --------------------
+        {
+            const int c4 = tid % H4;
+            for (int el = tid / H4; el < nenv; el += NT / H4) {
+                const ps_f32x4* hp = As4 + (el * N) * LDA4 + H4 + c4;
+                const float scl = sscale[el];
+                ps_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
+                for (int i = 0; i < N; ++i) S += sm[el * N + i] * hp[i * LDA4];
+                for (int j = 0; j < N; ++j) {
+                    const float m = sm[el * N + j];
+                    As4[(el * N + j) * LDA4 + c4] = m * (S - m * hp[j * LDA4]) * scl;
+                }
+            }
+            for (int idx = rows * H4 + tid; idx < BM * H4; idx += NT) {
+                const int row = idx / H4, c4p = idx - row * H4;
+                As4[row * LDA4 + c4p] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+            }
+        }
+        // B fragments of C: lane (li, lh) of wave w reads Wp[kb][32w + li][lh] -> k = 8kb + 4lh + j, j = 0..3
+        constexpr int KBC = H / 8, CH = (KBC < 8) ? KBC : 8, NCH = KBC / CH;
+        const ps_f32x4* cwp = a.c_wp + ((size_t)col * 2 + lh);
+        ps_f32x4 cb[2][CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) cb[0][k] = cwp[(size_t)k * H * 2];
+        __syncthreads();
+        // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp[(size_t)((ch + 1) * CH + k) * H * 2];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int kb = ch * CH + k;
+                const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+                const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    accC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cb[ch & 1][k][j], accC[0], 0, 0, 0);
+                    accC[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], cb[ch & 1][k][j], accC[1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // every wave has read the comm tile
+    }
+
+    // gate weights: the first two 8-k blocks are requested before inp is written back
+    const ps_f32x4* wp = a.l_wp + ((size_t)col * 2 + lh);
+    constexpr int KB = K / 8;
+    constexpr size_t KB_STRIDE = (size_t)4 * H * 2;   // float4s per kb
+    ps_f32x4 b0[4], b1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        b0[g] = wp[(size_t)g * H * 2];
+        b1[g] = wp[KB_STRIDE + (size_t)g * H * 2];
+    }
+    // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            As[lr * LDA + col] = accC[rt][reg];
+        }
+    __syncthreads();
+
+    // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell) --------------------------------------
+    ps_f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
+    auto block = [&](const ps_f32x4 (&bq)[4], int kb) {
+        const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+        const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[g][j], acc[0][g], 0, 0, 0);
+                acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[g][j], acc[1][g], 0, 0, 0);
+            }
+        }
+    };
+    static_assert(KB % 2 == 0, "K/8 must be even");
+    // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
+    // their first use, which exposes the full L2 latency every block).
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += 2) {
+        block(b0, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < KB) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        block(b1, kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 3 < KB) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
+    {
+        const float bi = a.l_bias[col], bf = a.l_bias[H + col], bg = a.l_bias[2 * H + col], bo = a.l_bias[3 * H + col];
+        float cold[2][16];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                cold[rt][reg] = lr < rows ? a.c[(r0 + lr) * H + col] : 0.0f;
+            }
+        __syncthreads();   // every wave is done with the A tile
+        for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
+            const int o = i / H4, c4 = i - o * H4;
+            As4[o * LDA4 + c4] = reinterpret_cast<const ps_f32x4*>(a.head_w)[i];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
+                const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
+                const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
+                const float h1 = fast_sigmoid(go) * fast_tanh(c1);
+                if (lr < rows) {
+                    a.c[(r0 + lr) * H + col] = c1;
+                    a.h[(r0 + lr) * H + col] = h1;
+                }
+                As[lr * LDA + H + col] = h1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S10: heads + value head (comm.py:228,239): NW lanes per row, 32 columns each ---------------------------------
+    // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
+    constexpr int PER = H / 16;
+    {
+        const int row = tid / NW, part = tid - row * NW;
+        float z[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) z[o] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const ps_f32x4 x = As4[row * LDA4 + H4 + 8 * part + q];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                if (o < a.OT) {
+                    const ps_f32x4 wv = As4[o * LDA4 + 8 * part + q];
+                    z[o] += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            if (o < a.OT) {
+                z[o] = group_sum<NW>(z[o]);
+                if (part == 0) As[(16 + row / PER) * LDA + (row % PER) * 16 + o] = z[o] + a.head_b[o];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- S11: log_softmax per head + the action draws (action_utils.py:32-36; same arithmetic and Philox counters as
+    //      lstm_cell_heads_kernel / sample_actions_env_kernel), one task per (row, head) + one per row for the value ----
+    {
+        const int sizes[4] = { a.a0, a.a1, a.a2, a.a3 };
+        const int R = a.E * N;
+        for (int task = tid; task < rows * (a.nheads + 1); task += NT) {
+            const int tr = task / (a.nheads + 1), hd = task - tr * (a.nheads + 1);
+            const size_t grow = r0 + tr;
+            const float* z = As + (16 + tr / PER) * LDA + (tr % PER) * 16;
+            float* orow = a.out + grow * a.OT;
+            int off = 0;
+            for (int i = 0; i < hd && i < a.nheads; ++i) off += sizes[i];
+            if (hd == a.nheads) {                   // value head (last column)
+                orow[off] = z[off];
+                continue;
+            }
+            const int A = sizes[hd];
+            float mx = -INFINITY;
+            for (int o = 0; o < A; ++o) mx = fmaxf(mx, z[off + o]);
+            float sum = 0.0f;                       // hardware exp2 / log2 (~1 ulp): |error| of a log-prob ~1e-7, bar 1e-5
+            for (int o = 0; o < A; ++o) sum += __builtin_amdgcn_exp2f(1.4426950408889634f * (z[off + o] - mx));
+            const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
+            for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
+            if (KIND == 0) continue;                // forward only: the caller draws (ic3_sample_actions)
+            const int el = tr / N, n = tr - el * N;
+            const int e = e0 + el;
+            const uint32_t x = philox_x24(a.seed, a.gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)a.episode[e],
+                                          (uint32_t)a.tstep[e], (uint32_t)(hd * N + n));
+            const float u = (float)x * (1.0f / 16777216.0f);
+            float cdf = 0.0f;
+            int act = A - 1;
+            for (int o = 0; o < A - 1; ++o) {
+                cdf += expf(z[off + o] - lse);
+                if (u < cdf) {
+                    act = o;
+                    break;
+                }
+            }
+            a.action[(size_t)hd * R + grow] = act;
+            if (hd == 0) sact[tr] = act;
+        }
+    }
+    __syncthreads();
+
+    // ---- S12: env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) ----------------------------
+    if constexpr (KIND != 0) {
+        for (int base = 0; base < a.EPT * a.G; base += NT) {
+            const int lt = base + tid;
+            const int el = lt / a.G, n = lt - el * a.G;
+            const int e = el < nenv ? e0 + el : a.E;
+            if constexpr (KIND == IC3_ENV_PP) {
+                pp_step_lanes(a.pp, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+            } else {
+                tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+            }
+        }
+    }
+}
+
+// Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
+__global__ void policy_pack_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb, float* __restrict__ Wp,
+                                   int C, int Ka, int Kb)
+{
+    const int Kt = Ka + Kb;
+    const long long n = (long long)C * Kt;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3), hh = (int)((i >> 2) & 1);
+        const long long rest = i >> 3;
+        const int colx = (int)(rest % C), kb = (int)(rest / C);
+        const int k = 8 * kb + 4 * hh + j;
+        Wp[i] = k < Ka ? Wa[(size_t)colx * Ka + k] : Wb[(size_t)colx * Kb + (k - Ka)];
+    }
+}
+
+template <int H, int KIND>
+static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
+{
+    static bool attr_set = false;
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && (!attr_set || lds > attr_lds)) {
+        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(tiles), dim3(2 * H), lds, s, a);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ic3
+
+using namespace ic3;
+
+extern "C" int ic3_policy_pack(const float* c_weight, const float* w_ih, const float* w_hh, float* c_wp, float* lstm_wp,
+                               int H, ic3_stream stream)
+{
+    if (!c_weight || !w_ih || !w_hh || !c_wp || !lstm_wp || H <= 0 || (H & 31))
+        return fail(-22, "ic3_policy_pack: H must be a positive multiple of 32");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, s, c_weight, (const float*)nullptr, c_wp, H, H, 0);
+    hipLaunchKernelGGL(policy_pack_kernel, dim3(256), dim3(256), 0, s, w_ih, w_hh, lstm_wp, 4 * H, H, H);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_policy_step_supported(const ic3_env* env, int H)
+{
+    if (!env) return 0;
+    if (H != 64 && H != 128 && H != 256) return 0;
+    const int N = env->dims.N;
+    if (N < 1 || N > 64) return 0;
+    const int EPT = 64 / N;
+    const int WW = env->dims.window * env->dims.window;
+    size_t tile_words;
+    if (env->kind == IC3_ENV_PP) {
+        const int total = env->pp.N + env->pp.nprey;
+        tile_words = (size_t)((2 * EPT * total + 3) & ~3) + (size_t)2 * EPT * N * WW;
+    } else {
+        tile_words = (size_t)EPT * (((7 * N + 3) & ~3) + 2 * N * WW);
+    }
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + tile_words) * sizeof(float);
+    const size_t limit = (H <= 128) ? 80 * 1024 : 160 * 1024;   // two workgroups per CU up to H = 128
+    return lds <= limit ? (int)lds : 0;
+}
+
+static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
+{
+    if (!p->c_wp || !p->lstm_wp || !p->lstm_bias || !p->head_w || !p->head_b)
+        return fail(-22, std::string(who) + ": incomplete ic3_policy");
+    if (p->nheads < 1 || p->nheads > 4) return fail(-22, std::string(who) + ": 1..4 action heads");
+    a.Wt = reinterpret_cast<const ps_f32x4*>(p->enc_wt);
+    a.enc_bias = reinterpret_cast<const ps_f32x4*>(p->enc_bias);
+    a.loc_table = reinterpret_cast<const ps_f32x4*>(p->loc_table);
+    a.c_wp = reinterpret_cast<const ps_f32x4*>(p->c_wp);
+    a.l_wp = reinterpret_cast<const ps_f32x4*>(p->lstm_wp);
+    a.l_bias = p->lstm_bias;
+    a.head_w = p->head_w;
+    a.head_b = p->head_b;
+    a.nheads = p->nheads;
+    int sz[4] = { 0, 0, 0, 0 };
+    a.OT = 1;
+    for (int i = 0; i < p->nheads; ++i) {
+        sz[i] = p->head_sizes[i];
+        if (sz[i] < 1) return fail(-22, std::string(who) + ": empty action head");
+        a.OT += sz[i];
+    }
+    if (a.OT > 16) return fail(-22, std::string(who) + ": more than 15 actions in total");
+    a.a0 = sz[0];
+    a.a1 = sz[1];
+    a.a2 = sz[2];
+    a.a3 = sz[3];
+    a.mode_avg = p->mode_avg;
+    a.comm_zero = p->comm_zero;
+    return 0;
+}
+
+extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, int N, float* h, float* c,
+                                  const int32_t* alive_in, const int32_t* comm_in, float* out, ic3_stream stream)
+{
+    if (!p || !enc || !h || !c || !out || E <= 0 || N <= 0) return fail(-22, "ic3_policy_forward: bad arguments");
+    const int H = p->H;
+    if ((H != 64 && H != 128 && H != 256) || N > 64)
+        return fail(-38, "ic3_policy_forward: needs hid_size 64/128/256 and <= 64 agents per env");
+    StepArgs a{};
+    int rc = fill_policy(a, p, "ic3_policy_forward");
+    if (rc) return rc;
+    a.enc_in = enc;
+    a.h = h;
+    a.c = c;
+    a.alive_in = alive_in;
+    a.comm_in = comm_in;
+    a.out = out;
+    a.E = E;
+    a.N = N;
+    a.EPT = 64 / N;
+    a.G = 1;
+    const int tiles = (E + a.EPT - 1) / a.EPT;
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
+    if (H == 64) return launch_step<64, 0>(a, tiles, lds, s);
+    return launch_step<256, 0>(a, tiles, lds, s);
+}
+
+extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, float* c, const int32_t* alive_in,
+                               const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward,
+                               int32_t* done, int32_t* alive, int32_t* is_completed, ic3_stream stream)
+{
+    if (!env || !p || !h || !c || !out || !action || !reward || !done)
+        return fail(-22, "ic3_policy_step: null argument");
+    if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");
+    if (!p->enc_wt || !p->enc_bias) return fail(-22, "ic3_policy_step: incomplete ic3_policy (encoder)");
+    const int H = p->H;
+    const int lds = ic3_policy_step_supported(env, H);
+    if (!lds)
+        return fail(-38, "ic3_policy_step: needs hid_size 64/128/256, <= 64 agents per env and an env tile that fits "
+                         "in LDS (use ic3_env_encode + ic3_comm_masked_mean + GEMMs + ic3_lstm_cell_heads + ic3_env_step)");
+    StepArgs a{};
+    int frc = fill_policy(a, p, "ic3_policy_step");
+    if (frc) return frc;
+    a.h = h;
+    a.c = c;
+    a.alive_in = alive_in;
+    a.comm_in = comm_in;
+    a.out = out;
+    a.action = action;
+    a.E = env->dims.E;
+    a.N = env->dims.N;
+    a.EPT = 64 / a.N;
+    a.episode = env->f("episode");
+    a.tstep = env->f("t");
+    a.so = StepOut{ reward, done, alive, is_completed, env->d_err };
+    const bool pp = env->kind == IC3_ENV_PP;
+    if (pp) {
+        a.pp = pp_state_of(env);
+        a.G = group_lanes(a.N);
+        a.seed = env->pp.seed;
+        a.gid0 = env->pp.env_id_offset;
+    } else {
+        a.tj = tj_state_of(env);
+        a.G = tj_group(a.N);
+        a.seed = env->tj.seed;
+        a.gid0 = env->tj.env_id_offset;
+    }
+    const int tiles = (a.E + a.EPT - 1) / a.EPT;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (H == 128) rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s);
+    else if (H == 64) rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s);
+    else rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s);
+    if (rc) return rc;
+    if (obs) return ic3_env_observe(env, obs, stream);
+    return 0;
+}

@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "enc_bwd.hpp"
+#include "env_device.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -56,103 +57,13 @@ __global__ __launch_bounds__(256) void pp_reset_kernel(int32_t* __restrict__ loc
 // G = pow2 >= N lanes per env; the per-env reductions (predators on prey, all reached) are wave
 // ballots restricted to the env's lane group.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool padded_outside(int pr, int pc, int v, int dim)
+// The step body lives in env_device.hpp (pp_step_lanes): the fused policy+step kernel runs the same code.
+__global__ __launch_bounds__(256) void pp_step_kernel(PPState st, StepOut out, const int32_t* __restrict__ actions, int E,
+                                                      int G)
 {
-    return pr < v || pr >= v + dim || pc < v || pc >= v + dim;  // np.pad(grid, vision, OUTSIDE_CLASS) PP:184
-}
-
-__global__ __launch_bounds__(256) void pp_step_kernel(int32_t* __restrict__ loc_r, int32_t* __restrict__ loc_c,
-                                                      int32_t* __restrict__ reached, int32_t* __restrict__ over,
-                                                      int32_t* __restrict__ success, int32_t* __restrict__ tstep,
-                                                      const int32_t* __restrict__ actions, float* __restrict__ reward,
-                                                      int32_t* __restrict__ done, int32_t* __restrict__ alive_out,
-                                                      int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E,
-                                                      int N, int nprey, int dim, int v, int mode, int naction, int G,
-                                                      int rows)
-{
-    // rows = N, or N + nprey with enemy_comm: the prey then own an action slot (ignored: fixed prey, PP:214-219), a
-    // reward (PP:276-281) and an observation row; lanes n >= N only take part in that.
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / G, n = tid - e * G;
-    const bool in_env = (e < E) && (n < rows);
-    const bool valid = in_env && (n < N);
-    const int total = N + nprey;
-    const int lane = threadIdx.x & 63;
-    const int gbase = lane & ~(G - 1);
-    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
-
-    int r = 0, c = 0, pr = -1, pc = -1, rch = 0, act = 4, was_over = 1;
-    if (in_env) {
-        act = actions[(size_t)e * rows + n];
-        was_over = over[e];
-        if (act > naction) atomicOr(err, 1);  // PP:137 (<=, quirk Q2; checked on every entry of `action`)
-    }
-    if (valid) {
-        const size_t li = (size_t)e * total + n;
-        r = loc_r[li];
-        c = loc_c[li];
-        pr = loc_r[(size_t)e * total + N];  // prey 0 only: (N,2)==(1,2) broadcast, quirk Q7 PP:258
-        pc = loc_c[(size_t)e * total + N];
-        rch = reached[(size_t)e * N + n];
-    }
-    const bool live = valid && !was_over;
-    if (live && rch != 1 && act != 5) {  // frozen PP:221-222; (sic) STAY guard PP:224-226
-        if (act == 0) {                  // UP PP:229-232
-            int qr = r + v - 1;
-            qr = qr < 0 ? 0 : qr;
-            if (!padded_outside(qr, c + v, v, dim)) r = (r - 1 > 0) ? r - 1 : 0;
-        } else if (act == 1) {           // RIGHT PP:235-239 (padded index clamped to dim-1, sic)
-            int qc = c + v + 1;
-            qc = qc > dim - 1 ? dim - 1 : qc;
-            if (!padded_outside(r + v, qc, v, dim)) c = (c + 1 < dim - 1) ? c + 1 : dim - 1;
-        } else if (act == 2) {           // DOWN PP:242-246
-            int qr = r + v + 1;
-            qr = qr > dim - 1 ? dim - 1 : qr;
-            if (!padded_outside(qr, c + v, v, dim)) r = (r + 1 < dim - 1) ? r + 1 : dim - 1;
-        } else if (act == 3) {           // LEFT PP:249-252
-            int qc = c + v - 1;
-            qc = qc < 0 ? 0 : qc;
-            if (!padded_outside(r + v, qc, v, dim)) c = (c - 1 > 0) ? c - 1 : 0;
-        }
-    }
-    const bool on = live && (r == pr) && (c == pc);
-    const int n_on = __popcll(__ballot(on) & gmask);
-    const int rch_new = (rch == 1 || on) ? 1 : 0;  // PP:271
-    const int n_reached = __popcll(__ballot(live && rch_new) & gmask);
-    if (!in_env) return;
-    if (!valid) {   // prey row (enemy_comm): reward 0.05 while no predator is on it, else 0 (PP:276-281)
-        reward[(size_t)e * rows + n] = was_over ? 0.0f : (n_on == 0 ? (float)0.05 : 0.0f);
-        if (alive_out) alive_out[(size_t)e * rows + n] = 1;
-        if (comp_out) comp_out[(size_t)e * rows + n] = 0;
-        return;
-    }
-    float rew = 0.0f;
-    if (live) {
-        double rd = -0.05;  // TIMESTEP_PENALTY PP:256
-        if (on) {
-            if (mode == IC3_PP_COOPERATIVE) rd = 0.05 * (double)n_on;        // PP:262
-            else if (mode == IC3_PP_COMPETITIVE) rd = 0.05 / (double)n_on;   // PP:265
-            else rd = 0.0;                                                   // PP:267
-        }
-        rew = (float)rd;
-        const size_t li = (size_t)e * total + n;
-        loc_r[li] = r;
-        loc_c[li] = c;
-        reached[(size_t)e * N + n] = rch_new;
-    }
-    reward[(size_t)e * rows + n] = rew;
-    if (alive_out) alive_out[(size_t)e * rows + n] = 1;
-    if (comp_out) comp_out[(size_t)e * rows + n] = 0;
-    if (n == 0) {
-        int ov = was_over;
-        if (live) {
-            ov = (n_reached == N && mode == IC3_PP_MIXED) ? 1 : 0;                 // PP:273-274
-            if (mode != IC3_PP_COMPETITIVE) success[e] = (n_on == N) ? 1 : 0;      // PP:284-288
-            over[e] = ov;
-            tstep[e] += 1;
-        }
-        done[e] = ov;
-    }
+    pp_step_lanes(st, out, e, n, E, G, [&]() { return actions[(size_t)e * st.rows + n]; });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -176,7 +87,6 @@ __device__ __forceinline__ const int2* pp_build_tab(int32_t* smem, const int32_t
     // rows = observed agents: the N predators, plus the prey with enemy_comm (PP:203-207); entity a's window is
     // centred on loc[a] either way (prey positions follow the predators in the loc arrays)
     const int total = N + nprey, W = 2 * v + 1, nseg = rows * W * W;
-    const int OUTSIDE = dim * dim + 1;
     int32_t* sr = smem;              // [total]
     int32_t* sc = sr + total;        // [total]
     int2* tab = reinterpret_cast<int2*>(smem + ((2 * total + 3) & ~3));  // [nseg]
@@ -185,16 +95,7 @@ __device__ __forceinline__ const int2* pp_build_tab(int32_t* smem, const int32_t
         sc[i] = loc_c[(size_t)e * total + i];
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
-        const int a = s / (W * W), w = s - a * (W * W);
-        const int dy = w / W, dx = w - dy * W;
-        const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
-        const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
-        int npred = 0, npr = 0;
-        for (int p = 0; p < N; ++p) npred += (sr[p] == gr) & (sc[p] == gc);             // PP:191-192
-        for (int p = N; p < total; ++p) npr += (sr[p] == gr) & (sc[p] == gc);           // PP:194-195
-        tab[s] = make_int2(id, npred | (npr << 16));
-    }
+    for (int s = threadIdx.x; s < nseg; s += blockDim.x) tab[s] = pp_tab_entry(sr, sc, s, N, total, dim, v);
     __syncthreads();
     return tab;
 }
@@ -288,19 +189,8 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
     const int2* tab = pp_build_tab(smem, loc_r, loc_c, e, N, nprey, dim, v, rows);
     for (int idx = threadIdx.x; idx < rows * H4; idx += blockDim.x) {
         const int a = idx / H4, c4 = idx - a * H4;
-        f32x4 acc = bias[c4];
-        // the one-hot location channels of all window cells depend only on the agent's position: one row of the
-        // pre-summed table (pp_encode_table_kernel) replaces W*W gathered rows
-        if (loc_table) acc += loc_table[(size_t)(smem[a] * dim + smem[N + nprey + a]) * H4 + c4];
-        for (int cell = 0; cell < WW; ++cell) {
-            const int2 t = tab[a * WW + cell];
-            const size_t row = (size_t)cell * vocab;
-            if (!loc_table) acc += Wt[(row + t.x) * H4 + c4];
-            const int npred = t.y & 0xffff, npr = t.y >> 16;
-            if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
-            if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
-        }
-        out[((size_t)e * rows + a) * ldo4 + c4] = acc;
+        out[((size_t)e * rows + a) * ldo4 + c4] =
+            pp_encode_row(smem, smem + (N + nprey), tab, a, c4, H4, WW, vocab, dim, Wt, bias, loc_table);
     }
 }
 
@@ -468,17 +358,35 @@ int pp_reset(ic3_env* env, hipStream_t s)
     return 0;
 }
 
+PPState pp_state_of(const ic3_env* env)
+{
+    const ic3_pp_cfg& c = env->pp;
+    PPState st;
+    st.loc_r = env->f("loc_r");
+    st.loc_c = env->f("loc_c");
+    st.reached = env->f("reached");
+    st.over = env->f("over");
+    st.success = env->f("success");
+    st.tstep = env->f("t");
+    st.Np = c.N;
+    st.nprey = c.nprey;
+    st.dim = c.dim;
+    st.v = c.vision;
+    st.mode = c.mode;
+    st.naction = c.stay ? 5 : 4;
+    st.rows = env->dims.N;
+    return st;
+}
+
 int pp_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s)
 {
     const ic3_pp_cfg& c = env->pp;
-    const int rows = env->dims.N;
-    const int G = group_lanes(rows);
+    const int G = group_lanes(env->dims.N);
     const long long threads = (long long)c.E * G;
     const int blocks = (int)((threads + 255) / 256);
-    hipLaunchKernelGGL(pp_step_kernel, dim3(blocks), dim3(256), 0, s, env->f("loc_r"), env->f("loc_c"),
-                       env->f("reached"), env->f("over"), env->f("success"), env->f("t"), actions, reward, done, alive,
-                       is_completed, env->d_err, c.E, c.N, c.nprey, c.dim, c.vision, c.mode, c.stay ? 5 : 4, G, rows);
+    const StepOut out = { reward, done, alive, is_completed, env->d_err };
+    hipLaunchKernelGGL(pp_step_kernel, dim3(blocks), dim3(256), 0, s, pp_state_of(env), out, actions, c.E, G);
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "enc_bwd.hpp"
+#include "env_device.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -39,123 +40,13 @@ __global__ __launch_bounds__(256) void tj_reset_kernel(int32_t* __restrict__ ali
     }
 }
 
-__global__ __launch_bounds__(256) void tj_step_kernel(
-    int32_t* __restrict__ alive_s, int32_t* __restrict__ wait_s, int32_t* __restrict__ loc_r, int32_t* __restrict__ loc_c,
-    int32_t* __restrict__ last_act_s, int32_t* __restrict__ route_loc_s, int32_t* __restrict__ route_id_s,
-    int32_t* __restrict__ completed_s, int32_t* __restrict__ cars_s, int32_t* __restrict__ failed_s,
-    const int32_t* __restrict__ over_s, const int32_t* __restrict__ episode_s, int32_t* __restrict__ tstep_s,
-    const int32_t* __restrict__ route_off, const int32_t* __restrict__ route_rc, const int32_t* __restrict__ actions,
-    float* __restrict__ reward, int32_t* __restrict__ done, int32_t* __restrict__ alive_out,
-    int32_t* __restrict__ comp_out, int32_t* __restrict__ err, int E, int N, int G, int narrival, int rpa,
-    const int32_t* __restrict__ thr_p, uint32_t seed, uint32_t gid0)
+// The step body lives in env_device.hpp (tj_step_lanes): the fused policy+step kernel runs the same code.
+__global__ __launch_bounds__(256) void tj_step_kernel(TJState st, StepOut out, const int32_t* __restrict__ actions, int E,
+                                                      int G)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / G, n = tid - e * G;
-    const bool env_ok = e < E;
-    const bool valid = env_ok && n < N;
-    const int lane = threadIdx.x & 63;
-    const int gbase = lane & ~(G - 1);
-    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
-    const size_t i = (size_t)e * N + n;
-
-    int alive = 0, wait = 0, r = 0, c = 0, last_act = 0, rloc = -1, rid = -1, completed = 0, act = 1;
-    uint32_t ep = 0, t = 0;
-    if (env_ok) {
-        ep = (uint32_t)episode_s[e];
-        t = (uint32_t)tstep_s[e];
-    }
-    if (valid) {
-        alive = alive_s[i];
-        wait = wait_s[i];
-        r = loc_r[i];
-        c = loc_c[i];
-        last_act = last_act_s[i];
-        rloc = route_loc_s[i];
-        rid = route_id_s[i];
-        act = actions[i];
-        if (act > 2) atomicOr(err, 1);  // TJ:228 (naction = 2, <=, quirk Q2)
-    }
-    // ---- _take_action TJ:540-581 ----
-    if (valid && alive) {
-        wait += 1;                      // TJ:546
-        if (act == 1) {
-            last_act = 1;               // TJ:549-551
-        } else if (act == 0) {
-            rloc += 1;                  // TJ:556
-            const int o = route_off[rid], len = route_off[rid + 1] - o;
-            if (rloc == len) {          // TJ:560-568 reached the end of its route
-                alive = 0;
-                wait = 0;
-                r = c = 0;
-                completed = 1;
-            } else {
-                const int rc = route_rc[o + rloc];  // TJ:575-578
-                r = rc >> 16;
-                c = rc & 0xffff;
-                last_act = 0;           // TJ:581
-            }
-        }
-    }
-    // ---- _add_cars TJ:369-393: lane j of the group pre-draws arrival point j's three uniforms ----
-    const int32_t thr = *thr_p;  // floor(add_rate * 2^24): u <= add_rate <=> x24 <= thr (exact)
-    uint32_t x0 = 0, x1 = 0, x2 = 0;
-    if (env_ok && n < narrival) {
-        x0 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 0u);
-        x1 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 1u);
-        x2 = philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_TJ_ADD, ep, t, 3u * n + 2u);
-    }
-    for (int a = 0; a < narrival; ++a) {
-        const unsigned long long am = __ballot(valid && alive) & gmask;
-        const unsigned long long dm = __ballot(valid && !alive) & gmask;
-        const int cars = __popcll(am), nd = __popcll(dm);
-        const uint32_t u0 = (uint32_t)__shfl((int)x0, gbase + a);
-        const uint32_t u1 = (uint32_t)__shfl((int)x1, gbase + a);
-        const uint32_t u2 = (uint32_t)__shfl((int)x2, gbase + a);
-        const bool add = (cars < N) && ((int32_t)u0 <= thr);              // TJ:371-372, 375
-        if (add && valid && !alive) {
-            const int k = (int)scale24(u1, (uint32_t)nd);                 // _choose_dead TJ:614-618: k-th dead slot
-            const int rank = __popcll(dm & ((1ull << lane) - 1ull));
-            if (rank == k) {
-                alive = 1;                                                // TJ:380
-                rid = (int)scale24(u2, (uint32_t)rpa) + a * rpa;          // TJ:383-385
-                rloc = 0;                                                 // TJ:389
-                const int rc = route_rc[route_off[rid]];                  // TJ:390
-                r = rc >> 16;
-                c = rc & 0xffff;
-            }
-        }
-    }
-    const int cars_now = __popcll(__ballot(valid && alive) & gmask);     // == cars_in_sys (TJ:393,561)
-    // ---- _get_reward TJ:585-595: crash iff another car (alive or parked dead) shares a non-(0,0) cell ----
-    const int packed = valid ? ((r << 16) | c) : -1;
-    bool same = false;
-    for (int j = 0; j < N; ++j) {
-        const int pj = __shfl(packed, gbase + j);
-        same |= (j != n) && (pj == packed);
-    }
-    const bool crash = valid && same && (packed != 0);                   // l.any(): loc != (0,0), quirk Q10
-    const bool any_crash = (__ballot(crash) & gmask) != 0ull;
-    if (!valid) return;
-    double rd = -0.01 * (double)wait;                                     // TJ:586
-    if (crash) rd += -10.0;                                               // TJ:591
-    rd = (double)alive * rd;                                              // TJ:594
-    reward[i] = (float)rd;
-    alive_s[i] = alive;
-    wait_s[i] = wait;
-    loc_r[i] = r;
-    loc_c[i] = c;
-    last_act_s[i] = last_act;
-    route_loc_s[i] = rloc;
-    route_id_s[i] = rid;
-    completed_s[i] = completed;
-    if (alive_out) alive_out[i] = alive;                                  // info['alive_mask'] TJ:244
-    if (comp_out) comp_out[i] = completed;                                // info['is_completed'] TJ:247
-    if (n == 0) {
-        cars_s[e] = cars_now;
-        if (any_crash) failed_s[e] = 1;                                   // TJ:592
-        tstep_s[e] = (int32_t)t + 1;
-        done[e] = over_s[e];                                              // never set by TJ (quirk Q12)
-    }
+    tj_step_lanes(st, out, e, n, E, G, [&]() { return actions[(size_t)e * st.N + n]; });
 }
 
 // TJ:321-366 _get_obs ('bool' vocab) + env_wrappers.py:88-100: row a = [last_act/(naction-1),
@@ -336,67 +227,21 @@ __global__ __launch_bounds__(1024) void tj_obs_vec4_kernel(const int32_t* __rest
 // or bias + last_act*Wt[0] + route_frac*Wt[1] + sum_cells ( Wt[2+cell*vocab+id] + ncar*Wt[2+cell*vocab+CAR] ).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void tj_encode_kernel(const int32_t* __restrict__ alive_s,
-                                                        const int32_t* __restrict__ loc_r, const int32_t* __restrict__ loc_c,
-                                                        const int32_t* __restrict__ last_act_s,
-                                                        const int32_t* __restrict__ route_id_s,
-                                                        const int32_t* __restrict__ grid, const f32x4* __restrict__ Wt,
+__global__ __launch_bounds__(256) void tj_encode_kernel(TJState st, const f32x4* __restrict__ Wt,
                                                         const f32x4* __restrict__ bias, f32x4* __restrict__ out, int ldo4,
-                                                        int N, int h, int w, int v, int vocab, int outside,
-                                                        int car_class, int npath, int H4, int hdr,
-                                                        const f32x4* __restrict__ loc_table)
+                                                        int H4, const f32x4* __restrict__ loc_table)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     const int e = blockIdx.x;
-    const int W = 2 * v + 1, WW = W * W, nseg = N * WW;
-    int32_t* sr = smem;
-    int32_t* sc = sr + N;
-    int32_t* sal = sc + N;
-    float* s0 = reinterpret_cast<float*>(sal + N);
-    float* s1 = s0 + N;
-    float* s2 = s1 + N;
-    float* s3 = s2 + N;
-    int2* tab = reinterpret_cast<int2*>(smem + ((7 * N + 3) & ~3));
-    for (int a = threadIdx.x; a < N; a += blockDim.x) {
-        const size_t i = (size_t)e * N + a;
-        sr[a] = loc_r[i];
-        sc[a] = loc_c[i];
-        sal[a] = alive_s[i];
-        s0[a] = (float)((double)last_act_s[i] / 1.0);
-        s1[a] = (float)((double)route_id_s[i] / (double)(npath - 1));
-        s2[a] = (float)((double)sr[a] / (double)(h - 1));
-        s3[a] = (float)((double)sc[a] / (double)(w - 1));
-    }
+    const int N = st.N, W = 2 * st.v + 1, WW = W * W, nseg = N * WW;
+    const TJTile t = tj_tile_at(smem, N);
+    for (int a = threadIdx.x; a < N; a += blockDim.x) tj_tile_load_car(t, st, e, a);
     __syncthreads();
-    for (int s = threadIdx.x; s < nseg; s += blockDim.x) {
-        const int a = s / WW, q = s - a * WW;
-        const int dy = q / W, dx = q - dy * W;
-        const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
-        const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
-        int ncar = 0;
-        for (int p = 0; p < N; ++p) ncar += (sr[p] == gr) & (sc[p] == gc);
-        tab[s] = make_int2(id, ncar);
-    }
+    for (int q = threadIdx.x; q < nseg; q += blockDim.x) t.tab[q] = tj_tab_entry(t, st, q);
     __syncthreads();
     for (int idx = threadIdx.x; idx < N * H4; idx += blockDim.x) {
         const int a = idx / H4, c4 = idx - a * H4;
-        f32x4 acc = bias[c4];
-        if (sal[a]) {
-            acc += s0[a] * Wt[c4];
-            acc += s1[a] * Wt[H4 + c4];
-            if (hdr == 4) {
-                acc += s2[a] * Wt[2 * H4 + c4];
-                acc += s3[a] * Wt[3 * H4 + c4];
-            }
-            if (loc_table) acc += loc_table[(size_t)(sr[a] * w + sc[a]) * H4 + c4];   // see pp_encode_kernel
-            for (int cell = 0; cell < WW; ++cell) {
-                const int2 t = tab[a * WW + cell];
-                const size_t row = hdr + (size_t)cell * vocab;
-                if (!loc_table && t.x >= 0) acc += Wt[(row + t.x) * H4 + c4];   // scalar vocab: -1 = not a road cell
-                if (t.y) acc += (float)t.y * Wt[(row + car_class) * H4 + c4];
-            }
-        }
-        out[((size_t)e * N + a) * ldo4 + c4] = acc;
+        out[((size_t)e * N + a) * ldo4 + c4] = tj_encode_row(t, st, a, c4, H4, Wt, bias, loc_table);
     }
 }
 
@@ -428,17 +273,58 @@ int tj_encode_table(ic3_env* env, const float* Wt, int H, float* table, hipStrea
     return 0;
 }
 
+int tj_group(int N)
+{
+    const int g = group_lanes(N);
+    return g < 8 ? 8 : g;
+}
+
+TJState tj_state_of(const ic3_env* env)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const ic3_dims& d = env->dims;
+    TJState st;
+    st.alive = env->f("alive");
+    st.wait = env->f("wait");
+    st.loc_r = env->f("loc_r");
+    st.loc_c = env->f("loc_c");
+    st.last_act = env->f("last_act");
+    st.route_loc = env->f("route_loc");
+    st.route_id = env->f("route_id");
+    st.completed = env->f("is_completed");
+    st.cars = env->f("cars_in_sys");
+    st.failed = env->f("has_failed");
+    st.over = env->f("over");
+    st.episode = env->f("episode");
+    st.tstep = env->f("t");
+    st.route_off = env->d_route_off;
+    st.route_rc = env->d_route_rc;
+    st.grid = env->d_grid;
+    st.thr = env->d_thr;
+    st.N = c.N;
+    st.narrival = d.narrival;
+    st.rpa = d.npath / d.narrival;
+    st.h = d.grid_h;
+    st.w = d.grid_w;
+    st.v = c.vision;
+    st.vocab = d.vocab;
+    st.outside = d.vocab - 3;
+    st.car_class = d.vocab - 1;
+    st.npath = d.npath;
+    st.hdr = c.vocab_type ? 4 : 2;
+    st.seed = c.seed;
+    st.gid0 = c.env_id_offset;
+    return st;
+}
+
 int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
               hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
-    const ic3_dims& d = env->dims;
-    const int WW = d.window * d.window;
+    const int WW = env->dims.window * env->dims.window;
     const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
-    hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("alive"), env->f("loc_r"), env->f("loc_c"),
-                       env->f("last_act"), env->f("route_id"), env->d_grid, reinterpret_cast<const f32x4*>(Wt),
-                       reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, c.N, d.grid_h, d.grid_w,
-                       c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, H / 4, c.vocab_type ? 4 : 2,
+    hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, tj_state_of(env), reinterpret_cast<const f32x4*>(Wt),
+                       reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, H / 4,
                        reinterpret_cast<const f32x4*>(loc_table));
     IC3_HIP(hipGetLastError());
     return 0;
@@ -598,25 +484,15 @@ int tj_reset(ic3_env* env, hipStream_t s)
     return 0;
 }
 
-static int tj_group(int N)
-{
-    const int g = group_lanes(N);
-    return g < 8 ? 8 : g;
-}
-
 int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed,
             hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
     const int G = tj_group(c.N);
     const long long threads = (long long)c.E * G;
-    const int rpa = env->dims.npath / env->dims.narrival;
-    hipLaunchKernelGGL(tj_step_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, env->f("alive"),
-                       env->f("wait"), env->f("loc_r"), env->f("loc_c"), env->f("last_act"), env->f("route_loc"),
-                       env->f("route_id"), env->f("is_completed"), env->f("cars_in_sys"), env->f("has_failed"),
-                       env->f("over"), env->f("episode"), env->f("t"), env->d_route_off, env->d_route_rc, actions, reward,
-                       done, alive, is_completed, env->d_err, c.E, c.N, G, env->dims.narrival, rpa, env->d_thr, c.seed,
-                       c.env_id_offset);
+    const StepOut out = { reward, done, alive, is_completed, env->d_err };
+    hipLaunchKernelGGL(tj_step_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, tj_state_of(env), out, actions,
+                       c.E, G);
     IC3_HIP(hipGetLastError());
     return 0;
 }

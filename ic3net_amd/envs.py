@@ -25,6 +25,7 @@ class _BatchedEnv(object):
         self.stat = dict()
         self.episode_over = False
         self.obs_timer = None     # set to a list to collect (start, end) HIP events around every obs launch
+        self.step_timer = None    # likewise around every one-launch policy+step (Trainer._step_body_mega)
         self.out = None           # optional {'reward','done','alive','is_completed'} output tensors for step()
         self._last = None
 

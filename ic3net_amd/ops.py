@@ -147,6 +147,76 @@ def comm_fused_(xh, wp, alive, comm_action, E, N, mode_avg):
     return xh
 
 
+POLICY_STEP_SIZES = (64, 128, 256)
+
+
+def policy_step_pack(c_weight, w_ih, w_hh):
+    """C.weight (H,H) and [W_ih | W_hh] (4H, 2H) in the layout ic3_policy_step streams (ic3_policy_pack)."""
+    _need_cuda(c_weight, "policy_step_pack")
+    H = c_weight.shape[0]
+    dev = c_weight.device
+    c_wp = torch.empty((H * H,), dtype=torch.float32, device=dev)
+    l_wp = torch.empty((8 * H * H,), dtype=torch.float32, device=dev)
+    check(_lib.lib().ic3_policy_pack(ptr(c_weight.detach().contiguous().float()), ptr(w_ih.detach().contiguous().float()),
+                                     ptr(w_hh.detach().contiguous().float()), ptr(c_wp), ptr(l_wp), H, stream()))
+    return dict(ps_c_wp=c_wp, ps_l_wp=l_wp)
+
+
+def policy_step_supported(env, H):
+    """True when ic3_policy_step can run this env / hid_size (env: the raw batched env object)."""
+    return H in POLICY_STEP_SIZES and _lib.lib().ic3_policy_step_supported(env._h, int(H)) > 0
+
+
+def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True):
+    pol = _lib.Policy()
+    pol.H, pol.nheads = int(H), len(head_sizes)
+    for i, a in enumerate(head_sizes):
+        pol.head_sizes[i] = int(a)
+    pol.mode_avg, pol.comm_zero = int(bool(mode_avg)), int(bool(comm_zero))
+    if encoder:
+        pol.enc_wt, pol.enc_bias = fc['wt'].data_ptr(), fc['enc_bias'].data_ptr()
+        pol.loc_table = fc['loc_table'].data_ptr() if fc.get('loc_table') is not None else None
+    pol.c_wp, pol.lstm_wp, pol.lstm_bias = fc['ps_c_wp'].data_ptr(), fc['ps_l_wp'].data_ptr(), fc['b_cat'].data_ptr()
+    pol.head_w, pol.head_b = fc['w_heads'].data_ptr(), fc['b_heads'].data_ptr()
+    return pol
+
+
+def policy_forward(fc, H, head_sizes, mode_avg, comm_zero, enc, E, N, h, c, alive_in, comm_in, out=None):
+    """The policy half of policy_step for a caller-supplied encoder output enc (E*N, H) = encoder(x) + C.bias
+    (ic3_policy_forward): communication block, C, LSTMCell, heads, log_softmax in one launch; h, c in place."""
+    import ctypes as C
+    _need_cuda(enc, "policy_forward")
+    R = E * N
+    assert enc.is_contiguous() and enc.shape == (R, H) and h.is_contiguous() and c.is_contiguous()
+    for m in (alive_in, comm_in):
+        assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+    if out is None:
+        out = torch.empty((R, sum(head_sizes) + 1), dtype=torch.float32, device=enc.device)
+    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=False)
+    check(_lib.lib().ic3_policy_forward(C.byref(pol), ptr(enc), E, N, ptr(h), ptr(c), ptr(alive_in), ptr(comm_in), ptr(out),
+                                        stream()))
+    return out
+
+
+def policy_step(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, comm_in, out, action, reward, done,
+                alive=None, is_completed=None, obs=None):
+    """One whole rollout iteration (policy forward -> action draws -> env.step) in one launch — ic3_policy_step.
+    `fc`: the policy's derived-weight cache (wt, enc_bias, loc_table, ps_c_wp, ps_l_wp, b_cat, w_heads, b_heads);
+    h, c (E*N, H) contiguous, updated in place; out (E*N, OT); action (heads, E, N) int32."""
+    _need_cuda(h, "policy_step")
+    R = h.shape[0]
+    assert h.is_contiguous() and c.is_contiguous() and h.shape == (R, H) and c.shape == (R, H)
+    assert out.is_contiguous() and action.is_contiguous() and action.dtype == torch.int32
+    assert action.numel() == len(head_sizes) * R and out.shape == (R, sum(head_sizes) + 1)
+    for m in (alive_in, comm_in):
+        assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero)
+    import ctypes as C
+    check(_lib.lib().ic3_policy_step(env._h, C.byref(pol), ptr(h), ptr(c), ptr(alive_in), ptr(comm_in), ptr(out),
+                                     ptr(action), ptr(obs), ptr(reward), ptr(done), ptr(alive), ptr(is_completed), stream()))
+    return out
+
+
 def lstm_cell_heads_ok(H):
     """ic3_lstm_cell_heads needs H/4 to be a power of two <= 64."""
     return H % 4 == 0 and H // 4 <= 64 and (H // 4) & (H // 4 - 1) == 0

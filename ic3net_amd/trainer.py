@@ -121,7 +121,8 @@ class Trainer(object):
         a = self.args
         return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
             and not getattr(a, 'rollout_grad', False) and self.clock.env is not None \
-            and not getattr(self, '_should_display', False)
+            and not getattr(self, '_should_display', False) \
+            and getattr(self.clock.env, 'step_timer', None) is None      # event-timed launches stay eager
 
     def step_episode(self, t):
         """One iteration of the hot loop trainer.py:43-108 for all E envs (eager, or as a hipGraph replay)."""
@@ -178,6 +179,10 @@ class Trainer(object):
                     self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
                 fuse_draw = not torch.is_grad_enabled() and self.clock.env is not None \
                     and hasattr(self.policy_net, 'sample_into') and select_action is _select_action_default
+                raw = self.env.env
+                if fuse_draw and self.clock.env is raw and getattr(self.policy_net, 'mega_ok', None) is not None \
+                        and self.policy_net.mega_ok(raw, [state, self._prev_hid]):
+                    return self._step_body_mega(t, observe)
                 if fuse_draw:
                     self.policy_net.sample_into = (self.clock.env, buf['action'][t])
                 try:
@@ -217,6 +222,40 @@ class Trainer(object):
             self._state = next_state
             self._info = info
             self._nsteps = t + 1
+
+    def _step_body_mega(self, t, observe):
+        """The same iteration as _step_body through CommNetMLP.step_env (ic3_policy_step): policy forward, the action
+        draws of every head and env.step are ONE launch; the obs-assembly launch follows when `observe`."""
+        args, buf, state, info = self.args, self._buf, self._state, self._info
+        raw = self.env.env
+        store = bool(getattr(args, 'store_states', False))
+        cur_state = state.clone() if store else None
+        timer = getattr(raw, 'step_timer', None)                   # bench: HIP events around the one launch
+        if timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+        action_out, value, prev_hid = self.policy_net.step_env(
+            raw, [state, self._prev_hid], info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
+            alive=buf['alive'][t], is_completed=buf['is_completed'][t])
+        if timer is not None:
+            e1.record(torch.cuda.current_stream())
+            timer.append((e0, e1, t))
+        self._prev_hid = prev_hid                                  # no autograd here: detach_gap is moot
+        if observe:
+            raw.observe_timed()
+        next_state = self.env._flatten_obs(raw._obs) if hasattr(self.env, '_flatten_obs') else raw._obs
+        if raw.dims.kind == 2:                                     # TJ:244-247
+            info = {'alive_mask': buf['alive'][t], 'is_completed': buf['is_completed'][t]}
+        else:
+            info = {'alive_mask_device': buf['alive'][t]}
+        if args.hard_attn and args.commnet:                        # trainer.py:70-71 (gate for the NEXT step)
+            info['comm_action'] = buf['action'][t][-1] if not args.comm_action_one else self._ones_comm
+        if getattr(self, '_should_display', False):                # trainer.py:101-102
+            self.env.display()
+        self._step_out[t] = (cur_state, action_out, value, next_state.clone() if store else None)
+        self._state = next_state
+        self._info = info
+        self._nsteps = t + 1
 
     def _obs_outside_graph(self, raw, t):
         """The obs-assembly launch stays outside the captured step graph when it runs on the side stream

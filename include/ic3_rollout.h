@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IC3_VERSION 100 /* 0.1.0 */
+#define IC3_VERSION 200 /* 0.2.0 */
 
 typedef struct ic3_env ic3_env; /* opaque */
 typedef void* ic3_stream;       /* hipStream_t */
@@ -237,6 +237,64 @@ int ic3_sample_actions(const float* logp, int ld /* logp row stride in floats, 0
  * steps, so a hipGraph capture of the rollout step can be replayed for the whole run. */
 int ic3_env_sample_actions(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action,
                            float* chosen_logp, ic3_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * One launch per rollout step: the body of the reference's hot loop trainer.py:43-108 for all E envs —
+ *     action_out, value, (h, c) = policy_net([state, (h, c)], info)      comm.py:134-244 (recurrent CommNet / IC3Net,
+ *                                                                          one communication pass)
+ *     action = select_action(args, action_out)                            action_utils.py:32-36 (Philox draws as
+ *                                                                          ic3_env_sample_actions, every head)
+ *     next_state, reward, done, info = env.step(action[0])                PP:112-144 / TJ:206-252
+ * The policy reads the observation through the env's integer state (sparse encoder, ic3_env_encode), never through
+ * a dense obs tensor.  A workgroup owns 64/N whole envs; encoder output, communication vectors, gate pre-activations
+ * and logits stay in LDS / registers (fp32 MFMA, exact f32 products).
+ *
+ * The ic3_policy struct holds DEVICE pointers, all float32:
+ *   enc_wt    [obs_dim][H]  encoder.weight^T                       comm.py:51
+ *   enc_bias  [H]           encoder.bias + C_modules[0].bias        comm.py:119,206 (quirk Q24)
+ *   loc_table [grid][H]     ic3_env_encode_table(enc_wt) or NULL
+ *   c_wp      [H*H]         C_modules[0].weight, packed by ic3_policy_pack
+ *   lstm_wp   [4H*2H]       [f_module.weight_ih | weight_hh], packed by ic3_policy_pack
+ *   lstm_bias [4H]          bias_ih + bias_hh
+ *   head_w    [OT][H]       heads.k.weight stacked, then value_head.weight; head_b [OT] likewise; OT = sum A_k + 1 <= 16
+ *   mode_avg  args.comm_mode == 'avg' (comm.py:194);  comm_zero  args.comm_mask_zero (comm.py:40-41)
+ * Arguments:
+ *   h, c       [E*N][H]  LSTM state, updated in place                 trainer.py:49-60
+ *   alive_in   [E][N] int32 or NULL   info['alive_mask'] of the PREVIOUS step (NULL at t = 0, quirk Q21)
+ *   comm_in    [E][N] int32 or NULL   info['comm_action'] (gate sampled at t-1, zeros at t = 0, quirk Q22; NULL = all talk)
+ *   out        [E*N][OT]  log_softmax of every head, then the value
+ *   action     [nheads][E][N] int32   the draws of every head
+ *   obs        [E][N][obs_dim] or NULL   next_state, assembled by ic3_env_observe after the step when non-NULL
+ *   reward / done / alive / is_completed   as ic3_env_step
+ * Returns -ENOSYS when ic3_policy_step_supported(env, H) == 0 (H not in {64,128,256}, > 64 agents, or an env tile
+ * that does not fit in LDS): use the separate entry points then. */
+typedef struct {
+    int32_t H;
+    int32_t nheads;
+    int32_t head_sizes[4];
+    int32_t mode_avg;
+    int32_t comm_zero;
+    const float* enc_wt;
+    const float* enc_bias;
+    const float* loc_table;
+    const float* c_wp;
+    const float* lstm_wp;
+    const float* lstm_bias;
+    const float* head_w;
+    const float* head_b;
+} ic3_policy;
+
+int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */,
+                    float* c_wp /* H*H */, float* lstm_wp /* 4H*2H */, int H, ic3_stream stream);
+int ic3_policy_step_supported(const ic3_env* env, int H); /* 0, or the LDS bytes per workgroup */
+/* The policy half alone, for callers that bring their own encoder output (a dense observation that is not an env's
+ * current state, comm.py:119 evaluated as a GEMM): enc [E*N][H] = encoder(x) + C.bias -> out [E*N][OT] as above, h / c
+ * updated in place; p->enc_wt / enc_bias / loc_table are not read.  No draws, no env step.  H in {64,128,256}, N <= 64. */
+int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, int N, float* h, float* c, const int32_t* alive_in,
+                       const int32_t* comm_in, float* out, ic3_stream stream);
+int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, float* c, const int32_t* alive_in,
+                    const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward, int32_t* done,
+                    int32_t* alive, int32_t* is_completed, ic3_stream stream);
 
 /* Synthetic uniform actions in [0, naction) for env-only benchmarks (DOMAIN_BENCH). */
 int ic3_random_actions(int32_t* action, int naction, uint32_t seed, uint32_t env_id_offset, uint32_t episode,

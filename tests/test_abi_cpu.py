@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), s
     assert set(syms) == set(_lib.EXPORTS), set(syms) ^ set(_lib.EXPORTS)
-    assert l.ic3_version() == 100
+    assert l.ic3_version() == 200
 
 
 def test_product_tj_tables_match_reference():
