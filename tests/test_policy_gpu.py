@@ -20,15 +20,22 @@ def build(pc):
     return net.cuda().float()
 
 
-@pytest.mark.parametrize("fused", [True, False, "mfma_lstm"])
+@pytest.mark.parametrize("fused", ["mega", "chain", False, "mfma_lstm"])
 @pytest.mark.parametrize("name", POLICY_FIXTURES)
 def test_policy_matches_reference(name, fused):
-    """fused=True: the no-grad rollout fast path (one [inp|h] buffer, lstm_cell / policy_heads HIP kernels) where it
-    applies (recurrent, one comm pass); fused=False: the generic torch path + comm_masked_mean op."""
+    """"mega": the no-grad rollout fast path with everything after the encoder as ONE launch (ic3_policy_forward, the
+    policy half of ic3_policy_step: communication block, C, LSTMCell, heads, log_softmax) where it applies (recurrent,
+    one comm pass, H in {64,128,256}); "chain": the same path as separate launches (one [inp|h] buffer, library GEMMs,
+    lstm_cell / policy_heads HIP kernels); False: the generic torch path + comm_masked_mean op."""
     pc = PolicyCase(name)
     fx = pc.fx
     net = build(pc)
     net.args.fused_policy = bool(fused)
+    net.args.mega_policy = (fused == "mega")
+    if fused == "mega":
+        from ic3net_amd import ops
+        if not (pc.recurrent and pc.comm_passes == 1 and pc.H in ops.POLICY_STEP_SIZES):
+            pytest.skip("the one-launch policy kernel needs recurrent, one comm pass, H in {64,128,256}")
     net.args.fused_lstm = (fused == "mfma_lstm")     # the hand-written fp32-MFMA LSTM kernel inside the fused path
     if fused == "mfma_lstm" and not (pc.recurrent and pc.comm_passes == 1 and pc.H in (64, 128, 256)):
         pytest.skip("fused LSTM kernel needs recurrent, one comm pass, H in {64,128,256}")
