@@ -310,7 +310,7 @@ def main():
     mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use
     if o.time_kernels and mega_live:
         raw_env.step_timer = []               # both launches of a step are event-timed and issued eagerly
-    live0 = live_done[0] - raw_env.device_stats().live_env_steps      # minus the part of the running episode played so far
+    live0 = live_done[0] + raw_env.device_stats().live_env_steps      # finished episodes + the running episode so far
     # A full CPython GC pass over this process's heap (torch + numpy + the CPU-baseline imports) costs 35-80 ms —
     # as much as the whole timed region — and where it lands depends on allocation counts, not on the work.
     # Collect now and move the survivors to the permanent generation, as timeit-style harnesses do.

@@ -92,8 +92,14 @@ class _RefPickle(object):
     __name__ = 'pickle'
 
 
+def read(path, map_location=None):
+    """The raw {'policy_net', 'log', 'trainer'} dict of a checkpoint written here or by the reference (its `utils.LogField`
+    entries come back as this package's LogField; plain torch.load needs an importable `utils` module for them)."""
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_RefPickle)
+
+
 def load(path, policy_net, log, trainer, map_location=None):   # main.py:267-272
-    d = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_RefPickle)
+    d = read(path, map_location)
     own = policy_net.state_dict()
     sd = {k: v.to(dtype=own[k].dtype) if torch.is_tensor(v) and k in own else v for k, v in d['policy_net'].items()}
     policy_net.load_state_dict(sd)                               # strict: same keys as the reference (SURVEY A.3)

@@ -21,6 +21,8 @@
 //     16-byte load per lane per gate per 8 k, two register buffers refilled a full 32-MFMA block ahead;
 //   * LDS budget 64 x (2H+4) floats = 66.5 KB: the encoder output is staged through the h half, parked in the
 //     accumulators of the C product (which it initialises), and the communication tile takes the inp half.
+#include <cstdlib>
+
 #include "env_device.hpp"
 #include "ic3_common.hpp"
 
@@ -42,6 +44,8 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
+    int dbg;                    // timing ablations (IC3_PS_DEBUG bit mask; results are wrong when set): 1 gate MFMA loop,
+                                // 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic
     // recurrent state, masks, outputs
     float* h;                   // [R][H] in place
     float* c;                   // [R][H] in place
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const int idx = tid + i * NT;
         const int row = idx / H4, c4 = idx - row * H4;
         ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
-        if (row < rows) {
+        if (row < rows && !(a.dbg & 4)) {
             const int el = row / N, aa = row - el * N;
             if constexpr (KIND == 0) {
                 v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __syncthreads();
         // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
+        for (int ch = 0; ch < ((a.dbg & 2) ? 0 : NCH); ++ch) {
             if (ch + 1 < NCH) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp[(size_t)((ch + 1) * CH + k) * H * 2];
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
     // their first use, which exposes the full L2 latency every block).
 #pragma unroll 1
-    for (int kb = 0; kb < KB; kb += 2) {
+    for (int kb = 0; kb < ((a.dbg & 1) ? 0 : KB); kb += 2) {
         block(b0, kb);
         __builtin_amdgcn_sched_barrier(0);
         if (kb + 2 < KB) {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                cold[rt][reg] = lr < rows ? a.c[(r0 + lr) * H + col] : 0.0f;
+                cold[rt][reg] = (lr < rows && !(a.dbg & 16)) ? a.c[(r0 + lr) * H + col] : 0.0f;
             }
         __syncthreads();   // every wave is done with the A tile
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
                 const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
                 const float h1 = fast_sigmoid(go) * fast_tanh(c1);
-                if (lr < rows) {
+                if (lr < rows && !(a.dbg & 16)) {
                     a.c[(r0 + lr) * H + col] = c1;
                     a.h[(r0 + lr) * H + col] = h1;
                 }
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     }
     __syncthreads();
+    if (a.dbg & 8) return;
 
     // ---- S10: heads + value head (comm.py:228,239): NW lanes per row, 32 columns each ---------------------------------
     // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
@@ -503,6 +508,8 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
     a.a3 = sz[3];
     a.mode_avg = p->mode_avg;
     a.comm_zero = p->comm_zero;
+    static const int dbg = getenv("IC3_PS_DEBUG") ? atoi(getenv("IC3_PS_DEBUG")) : 0;
+    a.dbg = dbg;
     return 0;
 }
 

@@ -105,6 +105,115 @@ def policy_case(name, N, obs_dim, H, steps, seed, B=1, closed_form=False, **flag
     print(name, 'params', len(sd), 'steps', steps)
 
 
+def fullsize_case(name, env_name, N, H, steps, seed, heads, tj=None, pp=None, gate='random', B=1, **flags):
+    """F4 at BASELINE shapes (configs 3-5): the reference CommNetMLP (fp64) with closed-form weights, free-running over
+    `steps` steps on REAL observations and alive masks — a Traffic-Junction / Predator-Prey rollout of the build's CPU
+    oracle env (itself pinned to the reference env by the trajectory fixtures) under random actions, so the inputs have
+    the sparsity and the alive patterns (n_alive = 0, 1, ...) the engine sees.  The policy's own outputs do not feed
+    back into the env here (actions are random): what is pinned is comm.py:134-244 on realistic input sequences.
+    Stored: sparse x, alive, comm_action, log-probs / value in fp64, h / c as float32 (file size)."""
+    import oracle
+    ref = rh.load_reference()
+    torch.set_default_dtype(torch.float64)
+    a = rh.make_args(env_name, nagents=N, hid_size=H, **flags)
+    if tj is not None:
+        envs = [oracle.TJOracle(N, tj['dim'], tj['vision'], tj['difficulty'], add_rate_min=tj['add_rate'],
+                                add_rate_max=tj['add_rate'], seed=seed, env_gid=900 + b) for b in range(B)]
+    else:
+        envs = [oracle.PPOracle(N, pp['dim'], pp['vision'], pp.get('mode', 'mixed'), seed=seed, env_gid=900 + b)
+                for b in range(B)]
+    obs_dim = envs[0].obs_dim
+    a.num_inputs = obs_dim
+    a.naction_heads = list(heads)
+    a.continuous = False
+    a.num_actions = list(heads)
+    a.dim_actions = len(heads)
+    a.recurrent = True
+    a.rnn_type = 'LSTM'
+    torch.manual_seed(seed)
+    net = ref['comm'].CommNetMLP(a, obs_dim)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    w = closed_form_weights(shapes)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    rs = np.random.RandomState(seed)
+    xs, alives, cas, outs_logp, outs_val, outs_h, outs_c = [], [], [], [[] for _ in heads], [], [], []
+    hid = net.init_hidden(B)
+    x = np.stack([e.reset(0) if tj is not None else e.reset() for e in envs]).astype(np.float64)
+    alive = None
+    for t in range(steps):
+        info = {}
+        if alive is not None:
+            info['alive_mask'] = alive[0].copy()       # the reference shares ONE (N,) mask over the batch (comm.py:102-107)
+        if t == 0:
+            ca = np.zeros((B, N), np.int64)                                  # Q22
+        elif gate == 'ones' or (gate == 'mixed' and t < steps // 2):
+            ca = np.ones((B, N), np.int64)                                   # TJ --ic3net preset (Q27)
+        else:
+            ca = (rs.rand(B, N) < 0.6).astype(np.int64)
+        ca[:] = ca[0]                                   # likewise one (N,) gate vector (comm.py:173)
+        if a.hard_attn:
+            info['comm_action'] = ca[0]
+        with torch.no_grad():
+            logp, val, hid = net([torch.from_numpy(x), hid], info)
+        xs.append(x)
+        alives.append(np.full((B, N), -1.0) if alive is None else alive.astype(np.float64))
+        cas.append(ca)
+        for k in range(len(heads)):
+            outs_logp[k].append(logp[k].numpy())
+        outs_val.append(val.numpy().reshape(B * N, 1))
+        outs_h.append(hid[0].numpy().astype(np.float32))
+        outs_c.append(hid[1].numpy().astype(np.float32))
+        nxt, al = [], []
+        for e in envs:                                                        # random env actions
+            if tj is not None:
+                o, _, _ = e.step((rs.rand(N) < 0.3).astype(np.int32))
+                al.append(e.alive.copy())
+            else:
+                if not e.over.value:
+                    o, _, _ = e.step(rs.randint(0, heads[0], size=N).astype(np.int32))
+                else:
+                    o = e.obs()
+                al.append(np.ones(N))
+            nxt.append(o)
+        x = np.stack(nxt).astype(np.float64)
+        alive = np.stack(al).astype(np.float64) if tj is not None else None
+    X = np.array(xs)                                                          # (steps, B, N, obs)
+    nz = np.nonzero(X)
+    out = dict(cfg=np.array([N, obs_dim, H, steps, B, 1, 1, int(a.comm_mode == 'avg'), int(a.comm_mask_zero),
+                             int(bool(a.hard_attn)), 0, len(heads), 1], np.int32),
+               heads=np.array(heads, np.int32), x_nz=np.stack(nz).astype(np.int32), x_val=X[nz].astype(np.float32),
+               alive=np.array(alives)[:, 0], comm_action=np.array(cas)[:, 0], value=np.array(outs_val),
+               h=np.array(outs_h), c=np.array(outs_c))
+    for k in range(len(heads)):
+        out['logp%d' % k] = np.array(outs_logp[k])
+    out['param_names'] = np.array(sorted(shapes))
+    out['param_shapes'] = np.array([str(shapes[k]) for k in sorted(shapes)])
+    n_alive = [int(v.sum()) for v in np.array(alives).reshape(steps, -1, N)[:, 0] if v[0] >= 0]
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(name, 'obs_dim', obs_dim, 'steps', steps, 'n_alive seen', sorted(set(n_alive)),
+          os.path.getsize(os.path.join(HERE, name + '.npz')) // 1024, 'KB')
+
+
+def fullsize_main():
+    # BASELINE config 3: TJ medium, CommNet recurrent (one head), N = 10, obs 533
+    fullsize_case('policy_tjmedium_closed', 'traffic_junction', 10, 128, 40, 41, [2],
+                  tj=dict(dim=14, vision=1, difficulty='medium', add_rate=0.15), commnet=True, recurrent=True)
+    # BASELINE config 4: TJ hard, IC3Net, N = 20, obs 1325, 80 steps, real alive masks (0, 1, ... cars)
+    fullsize_case('policy_tjhard_closed', 'traffic_junction', 20, 128, 80, 42, [2, 2],
+                  tj=dict(dim=18, vision=1, difficulty='hard', add_rate=0.1), gate='mixed', ic3net=True, recurrent=True)
+    # BASELINE config 5: PP scaled, IC3Net hid 256, N = 32, dim 40, vision 2 (obs 40 100)
+    fullsize_case('policy_ppscaled_closed', 'predator_prey', 32, 256, 20, 43, [5, 2],
+                  pp=dict(dim=40, vision=2), ic3net=True, recurrent=True)
+    # the one-launch kernel's other instantiations / branches at H = 64
+    fullsize_case('policy_h64_commnet_sum', 'traffic_junction', 5, 64, 24, 44, [2],
+                  tj=dict(dim=6, vision=1, difficulty='easy', add_rate=0.3), commnet=True, recurrent=True,
+                  comm_mode='sum')
+    fullsize_case('policy_h64_maskzero_b3', 'predator_prey', 3, 64, 12, 45, [5, 2], B=3,
+                  pp=dict(dim=5, vision=1), ic3net=True, recurrent=True, comm_mask_zero=True)
+    fullsize_case('policy_h64_ic3net_b3', 'traffic_junction', 6, 64, 24, 46, [2, 2], B=3,
+                  tj=dict(dim=6, vision=0, difficulty='easy', add_rate=0.4), ic3net=True, recurrent=True)
+
+
 def baseline_case(name, kind, N, obs_dim, H, steps, seed, B=2, rnn_type='MLP'):
     """IC / IRIC baselines: the reference's models.MLP / models.RNN (models.py:8-97), free-running."""
     ref = rh.load_reference()
@@ -317,4 +426,9 @@ def trainer_main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':
+        fullsize_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
+        trainer_main()
+    else:
+        main()

@@ -7,7 +7,11 @@ from golden_util import load
 
 POLICY_FIXTURES = ["policy_ic3net_small", "policy_ic3net_b3", "policy_commnet_rec", "policy_commnet_mlp2",
                    "policy_commnet_sum", "policy_commnet_maskzero", "policy_commnet_share",
-                   "policy_commnet_initzeros", "policy_pphard_closed"]
+                   "policy_commnet_initzeros", "policy_pphard_closed",
+                   # BASELINE configs 3-5 at full size + the H = 64 branches, on real env observations / alive masks
+                   # (make_golden_policy.py fullsize)
+                   "policy_tjmedium_closed", "policy_tjhard_closed", "policy_ppscaled_closed",
+                   "policy_h64_commnet_sum", "policy_h64_maskzero_b3", "policy_h64_ic3net_b3"]
 
 
 def closed_form_weights(shapes, scale=0.05):
@@ -31,13 +35,25 @@ class PolicyCase(object):
         if closed:
             shapes = {str(n): eval(str(s)) for n, s in zip(fx["param_names"], fx["param_shapes"])}
             self.params = closed_form_weights(shapes)
-            x = np.zeros((self.steps, self.B, self.N, self.obs_dim))
-            x[tuple(fx["x_nz"])] = fx["x_val"]
-            self.x = x
+            nz, val = fx["x_nz"], fx["x_val"]
+            order = np.argsort(nz[0], kind='stable')
+            self._nz, self._val = nz[:, order], val[order]
+            self._start = np.searchsorted(self._nz[0], np.arange(self.steps + 1))
+            self._x = None
         else:
             self.params = {k[2:]: fx[k] for k in fx.files if k.startswith("w:")}
-            self.x = fx["x"]
-        self.heads = [5, 2][:self.nheads]
+            self._x = fx["x"]
+        self.heads = [int(v) for v in fx["heads"]] if "heads" in fx.files else [5, 2][:self.nheads]
+        self.state_f32 = self.recurrent and fx["h"].dtype == np.float32     # h / c stored as float32(reference fp64)
+
+    def x_step(self, t):
+        """dense (B, N, obs_dim) float64 input of step t (closed-form fixtures keep it sparse)"""
+        if self._x is not None:
+            return self._x[t]
+        x = np.zeros((self.B, self.N, self.obs_dim))
+        lo, hi = self._start[t], self._start[t + 1]
+        x[tuple(self._nz[1:, lo:hi])] = self._val[lo:hi]
+        return x
 
     def alive(self, t):
         a = self.fx["alive"][t]

@@ -42,7 +42,8 @@ def test_pp_run_prints_reference_format(tmp_path):
         assert len(log[k].data) == 2 and np.all(np.isfinite(np.asarray(log[k].data[-1], dtype=np.float64)))
     assert 0 < log['steps_taken'].data[-1] <= 20
     # resume: the log continues from epoch 3 and the weights are the saved ones
-    saved = torch.load(path, weights_only=False)
+    from ic3net_amd import checkpoint
+    saved = checkpoint.read(path)        # the log is pickled as the reference's utils.LogField (checkpoint.py)
     lines2, log2 = run(PP + ['--load', path, '--num_epochs', '1'])
     assert [l.split('\t')[0] for l in lines2 if l.startswith('Epoch')] == ['Epoch 3']
     assert log2['epoch'].data == [1, 2, 3]

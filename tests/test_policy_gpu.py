@@ -48,7 +48,7 @@ def test_policy_matches_reference(name, fused):
                 info['alive_mask'] = torch.from_numpy(pc.alive(t)).int().cuda()
             if pc.hard_attn:
                 info['comm_action'] = torch.from_numpy(pc.comm_action(t)).int().cuda()
-            x = torch.from_numpy(pc.x[t]).float().cuda()
+            x = torch.from_numpy(pc.x_step(t)).float().cuda()
             if pc.recurrent:
                 logp, val, hid = net([x, hid], info)
             else:

@@ -101,9 +101,10 @@ def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_
                 assert float((logpA[k] - logpB[k]).abs().max()) < tol, (t, k)
             assert float((valA - valB).abs().max()) < tol * max(1.0, float(valA.abs().max()))
             assert float((hA - hB).abs().max()) < tol and float((cA - cB).abs().max()) < tol * max(1.0, float(cA.abs().max()))
-            # draws: bit-identical to the stand-alone sampler on the kernel's own log-probs, same stream position
+            # draws: bit-identical to the stand-alone sampler on the kernel's own log-probs at the envs' own stream
+            # positions (the twin env A has not stepped yet: same per-env (episode, t); a finished env keeps its t)
             for k in range(len(heads)):
-                want = ops.sample_actions(logpB[k], k, seed, offset, episode, t)
+                want = ops.sample_actions_env(envA, logpB[k], k)
                 assert torch.equal(act[k], want), (t, k)
             # env transition: the stand-alone step kernel on the twin env, same actions
             obsA, rA, dA, infoA = envA.step(act[0])
@@ -158,6 +159,55 @@ def test_policy_step_masks_and_dead_envs():
                                                   torch.zeros(E, dtype=torch.int32, device='cuda'))
         for x, y in ((logpA[0], logpB[0]), (logpA[1], logpB[1]), (valA, valB), (hA, hB), (cA, cB)):
             assert float((x - y).abs().max()) < 2e-5 * max(1.0, float(x.abs().max()))
+
+
+def test_policy_step_is_deterministic_and_graph_replay_identical():
+    """Same inputs -> bit-identical outputs, launch after launch and as a hipGraph replay (no data race between the
+    phases of the kernel: every LDS hand-over sits behind a barrier)."""
+    from ic3net_amd.comm import CommNetMLP
+    E, N, H = 96, 10, 128
+    env = make_env("pp", dict(N=N, dim=20, vision=1, mode="mixed"), E, 5, 0)
+    torch.manual_seed(2)
+    net = CommNetMLP(policy_args(N, H, [5, 2], True), env.obs_dim).cuda().float()
+    net.obs_encoder, net.obs_table = env.encode, env.encode_table
+    env.reset()
+    st0 = env.get_state()
+    h0 = torch.randn(E * N, H, device='cuda') * 0.5
+    c0 = torch.randn(E * N, H, device='cuda') * 0.5
+    gate = (torch.rand(E, N, device='cuda') < 0.5).int()
+    info = {'comm_action': gate}
+    bufs = dict(act=torch.zeros((2, E, N), dtype=torch.int32, device='cuda'), rew=torch.zeros(E, N, device='cuda'),
+                done=torch.zeros(E, dtype=torch.int32, device='cuda'))
+
+    def once():
+        env.set_state(**st0)
+        with torch.no_grad():
+            logp, val, (h, c) = net.step_env(env, [env._obs, (h0.clone(), c0.clone())], info, bufs['act'], bufs['rew'],
+                                             bufs['done'])
+        return [x.clone() for x in (logp[0], logp[1], val, h, c, bufs['act'], bufs['rew'])]
+
+    ref = once()
+    for rep in range(10):
+        got = once()
+        for i, (x, y) in enumerate(zip(ref, got)):
+            assert torch.equal(x, y), (rep, i)
+    # the same launch captured and replayed
+    env.set_state(**st0)
+    hh, cc = h0.clone(), c0.clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        logp, val, (h, c) = net.step_env(env, [env._obs, (hh, cc)], info, bufs['act'], bufs['rew'], bufs['done'])
+    for rep in range(3):
+        env.set_state(**st0)
+        net._mb['h'].copy_(h0)
+        net._mb['c'].copy_(c0)
+        hh.copy_(h0)
+        cc.copy_(c0)
+        g.replay()
+        got = [logp[0], logp[1], val, h, c, bufs['act'], bufs['rew']]
+        for i, (x, y) in enumerate(zip(ref, got)):
+            assert torch.equal(x, y), ("graph", rep, i)
 
 
 def test_policy_step_rejects_what_it_cannot_run():

@@ -44,8 +44,9 @@ if __name__ == '__main__':
     workload = sys.argv[1] if len(sys.argv) > 1 else 'pp_hard'
     nenvs = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 60
-    for mega in (1, 0):
+    modes = (1,) if os.environ.get('IC3_PS_DEBUG') or (len(sys.argv) > 4 and sys.argv[4] == 'mega') else (1, 0)
+    for mega in modes:
         med, best, tf, n = time_steps(workload, nenvs, steps, mega)
-        print("%s E=%d %s: median %.1f us, best %.1f us per step (policy+draws+env.step, no obs) = %.1f TFLOP/s fp32 "
-              "[one-launch calls: %d]" % (workload, nenvs, "ic3_policy_step" if mega else "launch chain", med * 1e3,
+        print("[IC3_PS_DEBUG=%s] %s E=%d %s: median %.1f us, best %.1f us per step (policy+draws+env.step, no obs) = %.1f TFLOP/s fp32 "
+              "[one-launch calls: %d]" % (os.environ.get('IC3_PS_DEBUG', '0'), workload, nenvs, "ic3_policy_step" if mega else "launch chain", med * 1e3,
                                           best * 1e3, tf, n))
