@@ -44,6 +44,8 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
+    int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
+                                // between the two co-resident workgroups of a CU; speed only)
     int dbg;                    // timing ablations (IC3_PS_DEBUG bit mask; results are wrong when set): 1 gate MFMA loop,
                                 // 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic
     // recurrent state, masks, outputs
@@ -75,6 +77,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
     int32_t* tile = sact + BM;                                   // env descriptors of the tile's envs
 
+    if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int N = a.N;
     const int e0 = blockIdx.x * a.EPT;
@@ -232,12 +236,15 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     const ps_f32x4* wp = a.l_wp + ((size_t)col * 2 + lh);
     constexpr int KB = K / 8;
     constexpr size_t KB_STRIDE = (size_t)4 * H * 2;   // float4s per kb
+    // (same issue order as inside the loop — all of b0, then all of b1 — so that the s_waitcnt vmcnt(n) the compiler
+    // places in front of each MFMA group count exactly the loads that group needs on both paths into the loop)
     ps_f32x4 b0[4], b1[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        b0[g] = wp[(size_t)g * H * 2];
-        b1[g] = wp[KB_STRIDE + (size_t)g * H * 2];
-    }
+    for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)g * H * 2];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b1[g] = wp[KB_STRIDE + (size_t)g * H * 2];
+    __builtin_amdgcn_sched_barrier(0);
     // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -271,20 +278,24 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     static_assert(KB % 2 == 0, "K/8 must be even");
     // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
     // their first use, which exposes the full L2 latency every block).
+    // The refills are unconditional (the last two re-read the final blocks): with a branch around them the compiler
+    // must assume the shorter in-flight queue and waits for vmcnt(0) — i.e. for the loads it has only just issued.
 #pragma unroll 1
     for (int kb = 0; kb < ((a.dbg & 1) ? 0 : KB); kb += 2) {
         block(b0, kb);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 2 < KB) {
+        {
+            const int kn = (kb + 2 < KB) ? kb + 2 : KB - 2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)kn * KB_STRIDE + (size_t)g * H * 2];
         }
         __builtin_amdgcn_sched_barrier(0);
         block(b1, kb + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 3 < KB) {
+        {
+            const int kn = (kb + 3 < KB) ? kb + 3 : KB - 1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)kn * KB_STRIDE + (size_t)g * H * 2];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -510,6 +521,8 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
     a.comm_zero = p->comm_zero;
     static const int dbg = getenv("IC3_PS_DEBUG") ? atoi(getenv("IC3_PS_DEBUG")) : 0;
     a.dbg = dbg;
+    static const int skew = getenv("IC3_PS_SKEW") ? atoi(getenv("IC3_PS_SKEW")) : 0;
+    a.skew = skew;
     return 0;
 }
 

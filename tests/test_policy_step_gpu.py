@@ -251,8 +251,11 @@ def test_trainer_takes_the_one_launch_path_and_graph_replay_is_identical(workloa
         ops.policy_step = orig
     for ep in range(3):
         for i in range(4):
-            for x, y in zip(runs["eager"][ep][i], runs["graph"][ep][i]):
-                assert torch.equal(x, y), (ep, i)
+            for t, (x, y) in enumerate(zip(runs["eager"][ep][i], runs["graph"][ep][i])):
+                if not torch.equal(x, y):
+                    d = (x.float() - y.float()).abs().reshape(-1)
+                    raise AssertionError("episode %d field %d step %d: %d of %d entries differ, max |d| = %g at %d" %
+                                         (ep, i, t, int((d != 0).sum()), d.numel(), float(d.max()), int(d.argmax())))
         assert runs["eager"][ep][4]['num_steps'] == runs["graph"][ep][4]['num_steps']
     v0, v1 = runs["eager"][0][2][0], runs["chain"][0][2][0]
     assert float((v0 - v1).abs().max()) < 2e-5
