@@ -450,6 +450,18 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
         attr_set = true;
         attr_lds = lds;
     }
+    // IC3_PS_WGS=1: ask for more than half of the CU's LDS so that only ONE workgroup is resident per CU (experiments
+    // with a concurrent obs-assembly launch on a second stream, which then finds free wave slots and registers)
+    static const int one_wg = getenv("IC3_PS_WGS") ? atoi(getenv("IC3_PS_WGS")) == 1 : 0;
+    if (one_wg && lds < 84 * 1024) {
+        lds = 84 * 1024;
+        if (!attr_set || lds > attr_lds) {
+            IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+            attr_lds = lds;
+        }
+    }
     hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(tiles), dim3(2 * H), lds, s, a);
     IC3_HIP(hipGetLastError());
     return 0;

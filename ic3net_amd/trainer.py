@@ -242,7 +242,10 @@ class Trainer(object):
             timer.append((e0, e1, t))
         self._prev_hid = prev_hid                                  # no autograd here: detach_gap is moot
         if observe:
-            raw.observe_timed()
+            if self._overlap_obs() and not torch.cuda.is_current_stream_capturing():
+                self._observe_on_side_stream(raw)                  # obs(t) on a second stream, beside step t+1
+            else:
+                raw.observe_timed()
         next_state = self.env._flatten_obs(raw._obs) if hasattr(self.env, '_flatten_obs') else raw._obs
         if raw.dims.kind == 2:                                     # TJ:244-247
             info = {'alive_mask': buf['alive'][t], 'is_completed': buf['is_completed'][t]}
