@@ -210,6 +210,8 @@ def main():
     p.add_argument('--time-kernels', type=int, default=int(os.environ.get('IC3_BENCH_TIME_KERNELS', '1')),
                    help='bracket the policy+step launch and the obs-assembly launch with HIP events in the timed region '
                         '(roofline numbers); the two launches are then issued eagerly instead of as graph replays')
+    p.add_argument('--fused-obs', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_OBS', '1')),
+                   help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
     p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
                    help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
     p.add_argument('--tune-gemm', type=int, default=int(os.environ.get('IC3_BENCH_TUNE_GEMM', '1')),
@@ -257,6 +259,7 @@ def main():
     a.fused_lstm = bool(o.fused_lstm)
     a.overlap_obs = bool(o.overlap_obs)
     a.mega_policy = bool(o.mega)
+    a.fused_obs = bool(o.fused_obs)
     T = a.max_steps
     raw_env = trainer.env.env
     live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
@@ -287,6 +290,7 @@ def main():
             trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
             a.hip_graph, a.dense_obs, o.graph = False, not o.no_dense_obs, 0
             a.mega_policy = bool(o.mega)
+            a.fused_obs = bool(o.fused_obs)
             raw_env = trainer.env.env
             raw_env.obs_timer = []
     t_in_ep = run(o.warmup, 0)
@@ -346,14 +350,23 @@ def main():
         value = N * live_steps / dt
         live_frac = live_steps / float(E_total * o.steps)
         obs_bytes = o.nenvs * N * raw_env.obs_dim * 4          # algorithmic bytes of one obs-assembly launch
-        avg_ms = sum(obs_ms) / max(len(obs_ms), 1)
-        achieved = obs_bytes / (avg_ms * 1e-3) / 1e9 if obs_ms else 0.0
+        fused_obs = bool(step_ms) and not obs_ms and not o.no_dense_obs    # next_state rows stored by policy_step_kernel
+        hbm_kernel = "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel"
+        hbm_bytes = obs_bytes
+        hbm_ms = obs_ms
+        if fused_obs:
+            hbm_kernel = "policy_step_kernel (policy + draws + env.step + obs assembly in one launch)"
+            hbm_bytes = obs_bytes + mfma_roofline(a, o.nenvs, step_ms)["hbm_bytes_per_launch_algorithmic"]
+            hbm_ms = step_ms
+        avg_ms = sum(hbm_ms) / max(len(hbm_ms), 1)
+        achieved = hbm_bytes / (avg_ms * 1e-3) / 1e9 if hbm_ms else 0.0
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'obs_traffic.json')
         if os.path.exists(tf):
             try:
                 tab = json.load(open(tf))
-                traffic = tab.get(o.workload) if o.nenvs == tab.get('_nenvs', 8192) else None   # measured at that size
+                key = o.workload + ('_fused' if fused_obs else '')
+                traffic = tab.get(key) if o.nenvs == tab.get('_nenvs', 8192) else None   # measured at that size
             except Exception:
                 traffic = None
         out = {
@@ -364,19 +377,21 @@ def main():
             "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
                        "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world,
-                       "launch": ("eager, event-timed: policy+step launch, obs launch" if step_ms else
+                       "launch": ("eager, event-timed: ONE launch per step" if fused_obs else
+                                  "eager, event-timed: policy+step launch, obs launch" if step_ms else
                                   "hipGraph replay" if o.graph else "eager"),
                        "dense_obs": not o.no_dense_obs, "overlap_obs": bool(o.overlap_obs),
                        "policy": "one launch per step (ic3_policy_step)" if mega_live else "launch chain",
                        "gemm": ("hand-written fp32 MFMA" if mega_live else
                                 "TunableOp-selected" if o.tune_gemm else "default heuristics")},
             "live_frac": round(live_frac, 6),
-            "roofline": {"kernel": "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel", "bound": "hbm",
+            "roofline": {"kernel": hbm_kernel, "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "rocprofv3 PMC passes of this command, profiles/obs_traffic.json (not re-measured "
                                            "in this run)" if traffic is not None else None,
-                         "bytes_per_launch": obs_bytes, "avg_launch_ms": round(avg_ms, 4), "launches": len(obs_ms)},
+                         "bytes_per_launch": hbm_bytes, "obs_bytes_per_launch": obs_bytes,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms)},
             "cpu_baseline": cpu,
             "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms) if step_ms else None,
             "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),

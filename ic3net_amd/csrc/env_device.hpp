@@ -377,6 +377,124 @@ __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState
     return acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Observation rows of a RUN of consecutive envs [e0, e0 + nenv) streamed out by a group of `nthr` threads (thread
+// index `t`), restricted to the slice [part, part + 1) / nparts of the run, so that a caller can issue the stores in
+// pieces between other work.  Same element values as pp_obs_kernel / tj_obs_kernel (predator_prey_env.py:188-210,
+// traffic_junction_env.py:321-366); descriptors in LDS: PP tab[el*N*WW + a*WW + cell], TJ one TJTile per env.
+// The runs of consecutive envs are contiguous in the obs tensor: one address range per call.
+// ------------------------------------------------------------------------------------------------
+// PP, vocab % 4 == 0: every float4 lies inside one window cell; lane -> float4 map shifted so that wave stores are
+// 1 KiB-aligned in the global address space (see pp_obs_kernel).
+__device__ __forceinline__ void pp_obs_store_run(const int2* tab, float* __restrict__ obs, long long e0, int nenv,
+                                                 int nsegE, int vocab, int t, int nthr, int part, int nparts)
+{
+    const int segq = vocab >> 2;
+    const long long Qe = (long long)nsegE * segq;                 // float4s per env
+    const int Q = (int)(Qe * nenv);                               // float4s of the run
+    dv_f32x4* out = reinterpret_cast<dv_f32x4*>(obs) + e0 * Qe;
+    const int o = (int)((e0 * Qe) & 63);
+    const int rounds = (Q + o + nthr - 1) / nthr;                 // passes of the whole group over the (shifted) run
+    const int r0 = (int)((long long)rounds * part / nparts), r1 = (int)((long long)rounds * (part + 1) / nparts);
+    const float inv_segq = 1.0f / (float)segq;
+    const bool small = Q < (1 << 20);                             // (g + 0.5) / segq is exact in fp32 below 2^20
+    for (int r = r0; r < r1; ++r) {
+        const int g = r * nthr + t - o;
+        if (g < 0 || g >= Q) continue;
+        const int seg = small ? (int)(((float)g + 0.5f) * inv_segq) : g / segq;
+        const int q = g - seg * segq;
+        const int2 d = tab[seg];
+        dv_f32x4 z = { 0.f, 0.f, 0.f, 0.f };
+        if ((d.x >> 2) == q) {
+            const int j = d.x & 3;
+            z.x = (j == 0) ? 1.f : 0.f;
+            z.y = (j == 1) ? 1.f : 0.f;
+            z.z = (j == 2) ? 1.f : 0.f;
+            z.w = (j == 3) ? 1.f : 0.f;
+        }
+        if (q == segq - 1) {
+            z.z += (float)(d.y >> 16);
+            z.w += (float)(d.y & 0xffff);
+        }
+        out[g] = z;
+    }
+}
+
+// PP, any vocab: dword stores
+__device__ __forceinline__ void pp_obs_store_run_scalar(const int2* tab, float* __restrict__ obs, long long e0, int nenv,
+                                                        int nsegE, int vocab, int t, int nthr, int part, int nparts)
+{
+    const long long Le = (long long)nsegE * vocab;
+    const int L = (int)(Le * nenv);
+    float* out = obs + e0 * Le;
+    const int rounds = (L + nthr - 1) / nthr;
+    const int r0 = (int)((long long)rounds * part / nparts), r1 = (int)((long long)rounds * (part + 1) / nparts);
+    for (int r = r0; r < r1; ++r) {
+        const int g = r * nthr + t;
+        if (g >= L) continue;
+        const int seg = g / vocab, ch = g - seg * vocab;
+        const int2 d = tab[seg];
+        float z = (ch == d.x) ? 1.f : 0.f;
+        if (ch == vocab - 2) z += (float)(d.y >> 16);
+        if (ch == vocab - 1) z += (float)(d.y & 0xffff);
+        out[g] = z;
+    }
+}
+
+// TJ element `off` of car a's row (TJ:336-362) from the env's LDS tile
+__device__ __forceinline__ float tj_obs_value(const TJTile& t, const TJState& s, int a, int off, int WW, float inv_vocab)
+{
+    if (!t.sal[a]) return 0.0f;
+    if (off < s.hdr) return off == 0 ? t.s0[a] : off == 1 ? t.s1[a] : off == 2 ? t.s2[a] : t.s3[a];
+    const int k = off - s.hdr;
+    const int seg = (int)(((float)k + 0.5f) * inv_vocab);        // exact for k < 2^20
+    const int ch = k - seg * s.vocab;
+    const int2 d = t.tab[a * WW + seg];
+    float z = (ch == d.x) ? 1.0f : 0.0f;
+    if (ch == s.car_class) z += (float)d.y;
+    return z;
+}
+
+// TJ: rows are hdr + WW*vocab floats (no 16-byte structure): <= 3 head and tail dwords, float4 body with 1 KiB-aligned
+// wave stores, every element evaluated on its own (see tj_obs_vec4_kernel).  tiles: LDS base of the run's TJTiles.
+__device__ __forceinline__ void tj_obs_store_run(int32_t* tiles, int tile_words, const TJState& s, float* __restrict__ obs,
+                                                 long long e0, int nenv, int t, int nthr, int part, int nparts)
+{
+    const int N = s.N, W = 2 * s.v + 1, WW = W * W, obs_dim = s.hdr + WW * s.vocab;
+    const float inv_vocab = 1.0f / (float)s.vocab;
+    const int Le = N * obs_dim;
+    const int L = Le * nenv;
+    const long long b0 = e0 * (long long)Le;
+    float* out = obs + b0;
+    auto value = [&](int f) -> float {
+        const int el = f / Le, fr = f - el * Le;
+        const int a = fr / obs_dim, off = fr - a * obs_dim;
+        return tj_obs_value(tj_tile_at(tiles + el * tile_words, N), s, a, off, WW, inv_vocab);
+    };
+    const int head = (int)((4 - (b0 & 3)) & 3);
+    const int nb = (L - head) >> 2, tail = (L - head) & 3;
+    if (part == 0) {
+        if (t < head && t < L) out[t] = value(t);
+        if (t < tail) {
+            const int f = head + 4 * nb + t;
+            out[f] = value(f);
+        }
+    }
+    dv_f32x4* out4 = reinterpret_cast<dv_f32x4*>(out + head);
+    const int o = (int)(((b0 + head) >> 2) & 63);
+    const int rounds = (nb + o + nthr - 1) / nthr;
+    const int r0 = (int)((long long)rounds * part / nparts), r1 = (int)((long long)rounds * (part + 1) / nparts);
+    for (int r = r0; r < r1; ++r) {
+        const int j = r * nthr + t - o;
+        if (j < 0 || j >= nb) continue;
+        const int f = head + 4 * j;
+        dv_f32x4 z;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = value(f + i);
+        out4[j] = z;
+    }
+}
+
 // host helpers (pp_kernels.hip / tj_kernels.hip): device views of a handle's state
 PPState pp_state_of(const ic3_env* env);
 TJState tj_state_of(const ic3_env* env);

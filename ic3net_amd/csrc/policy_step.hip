@@ -55,8 +55,11 @@ struct StepArgs {
     const int32_t* comm_in;     // [R] or null (gate sampled at t-1, quirk Q22)
     float* out;                 // [R][OT] log-probs | value
     int32_t* action;            // [nheads][R]
+    float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
+    int ntiles;                 // tiles of EPT envs; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     // env
     int E, N, EPT, G;
+    int tile_words;             // int32 words of one env-descriptor block in LDS
     uint32_t seed, gid0;
     const int32_t* episode;
     const int32_t* tstep;
@@ -76,12 +79,71 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     float* sscale = sm + BM;                                     // [BM] per-env 1/(n_alive-1)
     int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
     int32_t* tile = sact + BM;                                   // env descriptors of the tile's envs
+    int32_t* otile = tile + a.tile_words;                        // (a.obs) descriptors of the PREVIOUS tile's new state
 
     if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    int tid = threadIdx.x;      // (re-derived from an opaque value inside the tile loop, see `tz`)
     const int N = a.N;
-    const int e0 = blockIdx.x * a.EPT;
+    const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
+    const int total = a.pp.Np + a.pp.nprey;
+    const int nsegE = N * WW;
+    const int tjw = tj_tile_words(N, WW);
+    // env descriptors of `ne` envs starting at env `eb`, into the LDS block `tl` (two phases around a barrier):
+    //   PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x TJTile
+    auto desc_positions = [&](int32_t* tl, int eb, int ne) {
+        if constexpr (KIND == IC3_ENV_PP) {
+            int32_t* psr = tl;
+            int32_t* psc = tl + a.EPT * total;
+            for (int i = tid; i < ne * total; i += NT) {
+                psr[i] = a.pp.loc_r[(size_t)eb * total + i];
+                psc[i] = a.pp.loc_c[(size_t)eb * total + i];
+            }
+        } else if constexpr (KIND == IC3_ENV_TJ) {
+            for (int i = tid; i < ne * N; i += NT) {
+                const int el = i / N;
+                tj_tile_load_car(tj_tile_at(tl + el * tjw, N), a.tj, eb + el, i - el * N);
+            }
+        }
+    };
+    auto desc_tab = [&](int32_t* tl, int ne) {
+        if constexpr (KIND != 0) {
+            int2* pt = reinterpret_cast<int2*>(tl + ((2 * a.EPT * total + 3) & ~3));
+            for (int s = tid; s < ne * nsegE; s += NT) {
+                const int el = s / nsegE, q = s - el * nsegE;
+                if constexpr (KIND == IC3_ENV_PP) {
+                    pt[s] = pp_tab_entry(tl + el * total, tl + a.EPT * total + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
+                } else {
+                    const TJTile t = tj_tile_at(tl + el * tjw, N);
+                    t.tab[q] = tj_tab_entry(t, a.tj, q);
+                }
+            }
+        }
+    };
+    // next_state rows of the envs [eb, eb + ne) whose descriptors sit in `otile`: slice part/nparts of the stores
+    auto obs_store = [&](int eb, int ne, int part, int nparts) {
+        if constexpr (KIND == IC3_ENV_PP) {
+            const int2* pt = reinterpret_cast<const int2*>(otile + ((2 * a.EPT * total + 3) & ~3));
+            const int vocab = a.pp.dim * a.pp.dim + 4;
+            if ((vocab & 3) == 0) pp_obs_store_run(pt, a.obs, eb, ne, nsegE, vocab, tid, NT, part, nparts);
+            else pp_obs_store_run_scalar(pt, a.obs, eb, ne, nsegE, vocab, tid, NT, part, nparts);
+        } else if constexpr (KIND == IC3_ENV_TJ) {
+            tj_obs_store_run(otile, tjw, a.tj, a.obs, eb, ne, tid, NT, part, nparts);
+        }
+    };
+    int pend_e0 = -1, pend_nenv = 0;     // tile whose next_state rows are still to be stored (descriptors in otile)
+
+#pragma unroll 1
+    for (int tile_id = blockIdx.x; tile_id < a.ntiles; tile_id += gridDim.x) {
+    // an opaque zero, re-made every iteration and added to the addresses of everything that does not depend on the
+    // tile (weights, biases): keeps the compiler from hoisting those loads out of the tile loop, where they would stay
+    // live across all phases (the first persistent version spilled ~250 registers that way)
+    int tz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
+    tid = (int)threadIdx.x + tz;   // every per-lane index below is re-derived per tile (nothing to hoist and keep live)
+    const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int col = 32 * w + li;
+    const int e0 = tile_id * a.EPT;
     const int nenv = min(a.EPT, a.E - e0);
     const int rows = nenv * N;                                   // valid rows of this tile (<= 64)
     const size_t r0 = (size_t)e0 * N;
@@ -97,25 +159,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int j = 0; j < N; ++j) n_alive += a.alive_in ? a.alive_in[r0 + (size_t)el * N + j] : 1;
         sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
     }
-    // tile layout PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x (tj_tile_words) blocks
-    const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
-    const int total = a.pp.Np + a.pp.nprey;
-    const int nsegE = N * WW;
     int32_t* sr = tile;
     int32_t* sc = tile + a.EPT * total;
     int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
-    const int tjw = tj_tile_words(N, WW);
-    if constexpr (KIND == IC3_ENV_PP) {
-        for (int i = tid; i < nenv * total; i += NT) {
-            sr[i] = a.pp.loc_r[(size_t)e0 * total + i];
-            sc[i] = a.pp.loc_c[(size_t)e0 * total + i];
-        }
-    } else if constexpr (KIND == IC3_ENV_TJ) {
-        for (int i = tid; i < rows; i += NT) {
-            const int el = i / N;
-            tj_tile_load_car(tj_tile_at(tile + el * tjw, N), a.tj, e0 + el, i - el * N);
-        }
-    }
+    desc_positions(tile, e0, nenv);
     // h rows of the tile: requested now (HBM latency runs under S1/S2), parked in registers until the encoder output
     // has left the h half of the LDS tile
     ps_f32x4 hv[8];
@@ -125,19 +172,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const int row = idx / H4, c4 = idx - row * H4;
         hv[i] = row < rows ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4) : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
+    // next_state rows of the previous tile: 3/4 of the stores go out here, behind the loads just requested — the store
+    // stream and this tile's latency chain (S0..S7) share the time; the last quarter is issued right before the gate
+    // loop and drains under it (a wave streaming fp32 MFMAs leaves no issue slots to anything else on its SIMD, but
+    // stores already in flight complete on their own)
+    if (KIND != 0 && a.obs && pend_e0 >= 0) {
+        obs_store(pend_e0, pend_nenv, 0, 4);
+        obs_store(pend_e0, pend_nenv, 1, 4);
+        obs_store(pend_e0, pend_nenv, 2, 4);
+    }
     __syncthreads();
 
     // ---- S1: window descriptors ------------------------------------------------------------------------------------
     if constexpr (KIND != 0) {
-        for (int s = tid; s < nenv * nsegE; s += NT) {
-            const int el = s / nsegE, q = s - el * nsegE;
-            if constexpr (KIND == IC3_ENV_PP) {
-                ptab[s] = pp_tab_entry(sr + el * total, sc + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
-            } else {
-                const TJTile t = tj_tile_at(tile + el * tjw, N);
-                t.tab[q] = tj_tab_entry(t, a.tj, q);
-            }
-        }
+        desc_tab(tile, nenv);
         __syncthreads();
     }
 
@@ -153,9 +201,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
             } else if constexpr (KIND == IC3_ENV_PP) {
                 v = pp_encode_row(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
-                                  a.pp.dim * a.pp.dim + 4, a.pp.dim, a.Wt, a.enc_bias, a.loc_table);
+                                  a.pp.dim * a.pp.dim + 4, a.pp.dim, a.Wt, a.enc_bias + tz, a.loc_table);
             } else {
-                v = tj_encode_row(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, a.Wt, a.enc_bias, a.loc_table);
+                v = tj_encode_row(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, a.Wt, a.enc_bias + tz, a.loc_table);
             }
         }
         As4[row * LDA4 + H4 + c4] = v;
@@ -164,7 +212,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 
     // ---- S3: the encoder output moves into the accumulators of the C product (MFMA C/D layout:
     //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------------------------------------------------
-    const int col = 32 * w + li;
     ps_f32x16 accC[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -205,7 +252,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         // B fragments of C: lane (li, lh) of wave w reads Wp[kb][32w + li][lh] -> k = 8kb + 4lh + j, j = 0..3
         constexpr int KBC = H / 8, CH = (KBC < 8) ? KBC : 8, NCH = KBC / CH;
-        const ps_f32x4* cwp = a.c_wp + ((size_t)col * 2 + lh);
+        const ps_f32x4* cwp = a.c_wp + ((size_t)col * 2 + lh) + tz;
         ps_f32x4 cb[2][CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) cb[0][k] = cwp[(size_t)k * H * 2];
@@ -233,7 +280,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 
     // gate weights: the first two 8-k blocks are requested before inp is written back
-    const ps_f32x4* wp = a.l_wp + ((size_t)col * 2 + lh);
+    const ps_f32x4* wp = a.l_wp + ((size_t)col * 2 + lh) + tz;
     constexpr int KB = K / 8;
     constexpr size_t KB_STRIDE = (size_t)4 * H * 2;   // float4s per kb
     // (same issue order as inside the loop — all of b0, then all of b1 — so that the s_waitcnt vmcnt(n) the compiler
@@ -253,6 +300,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             As[lr * LDA + col] = accC[rt][reg];
         }
+    if (KIND != 0 && a.obs && pend_e0 >= 0) obs_store(pend_e0, pend_nenv, 3, 4);   // drains under the gate loop
     __syncthreads();
 
     // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell) --------------------------------------
@@ -302,7 +350,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
     {
-        const float bi = a.l_bias[col], bf = a.l_bias[H + col], bg = a.l_bias[2 * H + col], bo = a.l_bias[3 * H + col];
+        const float* lb = a.l_bias + tz;
+        const float bi = lb[col], bf = lb[H + col], bg = lb[2 * H + col], bo = lb[3 * H + col];
         float cold[2][16];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -314,7 +363,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __syncthreads();   // every wave is done with the A tile
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
             const int o = i / H4, c4 = i - o * H4;
-            As4[o * LDA4 + c4] = reinterpret_cast<const ps_f32x4*>(a.head_w)[i];
+            As4[o * LDA4 + c4] = reinterpret_cast<const ps_f32x4*>(a.head_w)[i + tz];
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -334,7 +383,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     }
     __syncthreads();
-    if (a.dbg & 8) return;
+    if (a.dbg & 8) continue;
 
     // ---- S10: heads + value head (comm.py:228,239): NW lanes per row, 32 columns each ---------------------------------
     // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
@@ -359,7 +408,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int o = 0; o < 16; ++o) {
             if (o < a.OT) {
                 z[o] = group_sum<NW>(z[o]);
-                if (part == 0) As[(16 + row / PER) * LDA + (row % PER) * 16 + o] = z[o] + a.head_b[o];
+                if (part == 0) As[(16 + row / PER) * LDA + (row % PER) * 16 + o] = z[o] + a.head_b[o + tz];
             }
         }
     }
@@ -421,7 +470,18 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
             }
         }
+        if (a.obs) {   // descriptors of the tile's NEW state (same workgroup wrote it: visible after the barrier)
+            __syncthreads();
+            desc_positions(otile, e0, nenv);
+            __syncthreads();
+            desc_tab(otile, nenv);
+            pend_e0 = e0;
+            pend_nenv = nenv;
+        }
     }
+    __syncthreads();   // LDS (tile, masks, A tile) is reused by the next tile
+    }   // tiles
+    if (KIND != 0 && a.obs && pend_e0 >= 0) obs_store(pend_e0, pend_nenv, 0, 1);
 }
 
 // Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
@@ -437,6 +497,18 @@ __global__ void policy_pack_kernel(const float* __restrict__ Wa, const float* __
         const int k = 8 * kb + 4 * hh + j;
         Wp[i] = k < Ka ? Wa[(size_t)colx * Ka + k] : Wb[(size_t)colx * Kb + (k - Ka)];
     }
+}
+
+static int resident_workgroups(int H)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
+        cus = prop.multiProcessorCount;
+    }
+    return cus * (H <= 128 ? 2 : 1);
 }
 
 template <int H, int KIND>
@@ -462,7 +534,9 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
             attr_lds = lds;
         }
     }
-    hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(tiles), dim3(2 * H), lds, s, a);
+    // persistent: at most one resident set of workgroups, each walking tiles blockIdx.x + k * gridDim.x
+    const int grid = tiles < resident_workgroups(H) ? tiles : resident_workgroups(H);
+    hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, a);
     IC3_HIP(hipGetLastError());
     return 0;
 }
@@ -483,7 +557,8 @@ extern "C" int ic3_policy_pack(const float* c_weight, const float* w_ih, const f
     return 0;
 }
 
-extern "C" int ic3_policy_step_supported(const ic3_env* env, int H)
+// LDS bytes of one workgroup (0 = unsupported shape); *tile_words_out = int32 words of one env-descriptor block
+static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_words_out)
 {
     if (!env) return 0;
     if (H != 64 && H != 128 && H != 256) return 0;
@@ -498,10 +573,14 @@ extern "C" int ic3_policy_step_supported(const ic3_env* env, int H)
     } else {
         tile_words = (size_t)EPT * (((7 * N + 3) & ~3) + 2 * N * WW);
     }
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + tile_words) * sizeof(float);
+    tile_words = (tile_words + 3) & ~(size_t)3;
+    if (tile_words_out) *tile_words_out = (int)tile_words;
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + tile_words * (with_obs ? 2 : 1)) * sizeof(float);
     const size_t limit = (H <= 128) ? 80 * 1024 : 160 * 1024;   // two workgroups per CU up to H = 128
     return lds <= limit ? (int)lds : 0;
 }
+
+extern "C" int ic3_policy_step_supported(const ic3_env* env, int H) { return policy_step_lds(env, H, 0, nullptr); }
 
 static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
 {
@@ -559,6 +638,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     a.EPT = 64 / N;
     a.G = 1;
     const int tiles = (E + a.EPT - 1) / a.EPT;
+    a.ntiles = tiles;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
@@ -575,7 +655,13 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");
     if (!p->enc_wt || !p->enc_bias) return fail(-22, "ic3_policy_step: incomplete ic3_policy (encoder)");
     const int H = p->H;
-    const int lds = ic3_policy_step_supported(env, H);
+    // next_state rows are stored from inside the kernel when their descriptors fit in LDS next to the tile's own
+    // (IC3_PS_OBS=0: always as a separate ic3_env_observe launch after the kernel)
+    static const int obs_inside = getenv("IC3_PS_OBS") ? atoi(getenv("IC3_PS_OBS")) : 1;
+    int tile_words = 0;
+    int lds = (obs && obs_inside) ? policy_step_lds(env, H, 1, &tile_words) : 0;
+    const bool fused_obs = lds != 0;
+    if (!lds) lds = policy_step_lds(env, H, 0, &tile_words);
     if (!lds)
         return fail(-38, "ic3_policy_step: needs hid_size 64/128/256, <= 64 agents per env and an env tile that fits "
                          "in LDS (use ic3_env_encode + ic3_comm_masked_mean + GEMMs + ic3_lstm_cell_heads + ic3_env_step)");
@@ -607,12 +693,15 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.gid0 = env->tj.env_id_offset;
     }
     const int tiles = (a.E + a.EPT - 1) / a.EPT;
+    a.ntiles = tiles;
+    a.tile_words = tile_words;
+    a.obs = fused_obs ? obs : nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (H == 128) rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s);
     else if (H == 64) rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s);
     else rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s);
     if (rc) return rc;
-    if (obs) return ic3_env_observe(env, obs, stream);
+    if (obs && !fused_obs) return ic3_env_observe(env, obs, stream);
     return 0;
 }

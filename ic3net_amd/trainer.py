@@ -134,7 +134,8 @@ class Trainer(object):
         if g is None:
             # capture: the launch sequence of step t (policy kernels, sampling, env step [, obs assembly]) with the
             # buffers it reads/writes.  The obs launch stays outside the graph while it is being event-timed.
-            in_graph_obs = self._dense_obs() and not self._obs_outside_graph(raw, t)
+            in_graph_obs = self._dense_obs() and (not self._obs_outside_graph(raw, t) or
+                                                  (getattr(self, '_mega_last', False) and self._fused_obs()))
             saved = (self._state, self._info, self._prev_hid)
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
@@ -150,7 +151,8 @@ class Trainer(object):
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
             # capture does not execute: fall through to a replay so that step t actually runs
-        if g['obs_inside'] and self._obs_outside_graph(raw, t):
+        if g['obs_inside'] and self._obs_outside_graph(raw, t) and not (getattr(self, '_mega_last', False)
+                                                                        and self._fused_obs()):
             # timing was switched on after capture: re-capture without the obs launch
             del self._graphs[t]
             return self.step_episode(t)
@@ -234,14 +236,19 @@ class Trainer(object):
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
+        # next_state rows are written by the same launch (args.fused_obs, default) unless they are wanted on a second
+        # stream (args.overlap_obs) — ic3_policy_step falls back to a separate obs launch by itself when the obs
+        # descriptors of a tile do not fit in LDS
+        fused = observe and self._fused_obs()
         action_out, value, prev_hid = self.policy_net.step_env(
             raw, [state, self._prev_hid], info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
-            alive=buf['alive'][t], is_completed=buf['is_completed'][t])
+            alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None)
+        self._mega_last = True
         if timer is not None:
             e1.record(torch.cuda.current_stream())
             timer.append((e0, e1, t))
         self._prev_hid = prev_hid                                  # no autograd here: detach_gap is moot
-        if observe:
+        if observe and not fused:
             if self._overlap_obs() and not torch.cuda.is_current_stream_capturing():
                 self._observe_on_side_stream(raw)                  # obs(t) on a second stream, beside step t+1
             else:
@@ -265,6 +272,9 @@ class Trainer(object):
         (args.overlap_obs) or is being event-timed (HIP events recorded in a captured graph cannot be timed; timing
         only every k-th step and keeping the other launches in their graphs was measured: no difference)."""
         return self._overlap_obs() or raw.obs_timer is not None
+
+    def _fused_obs(self):
+        return bool(getattr(self.args, 'fused_obs', True)) and not self._overlap_obs()
 
     def _overlap_obs(self):
         """args.overlap_obs is only honoured when nothing on the rollout path reads the dense observation (the sparse

@@ -95,7 +95,11 @@ def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_
                 done = torch.full((E,), -1, dtype=torch.int32, device=dev)
                 alive = torch.full((E, N), -1, dtype=torch.int32, device=dev)
                 comp = torch.full((E, N), -1, dtype=torch.int32, device=dev)
-                logpB, valB, (hB, cB) = netB.step_env(envB, [envB._obs, hid], info, act, rew, done, alive, comp)
+                with_obs = (t % 3 != 2)       # next_state rows from the same launch (two steps out of three)
+                if with_obs:
+                    envB._obs.fill_(-5.0)
+                logpB, valB, (hB, cB) = netB.step_env(envB, [envB._obs, hid], info, act, rew, done, alive, comp,
+                                                      obs=envB._obs if with_obs else None)
             tol = 2e-5
             for k in range(len(heads)):
                 assert float((logpA[k] - logpB[k]).abs().max()) < tol, (t, k)
@@ -120,7 +124,10 @@ def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_
                 info = {}
             if hard_attn:
                 info['comm_action'] = act[-1].clone()
-            envB.observe()                                 # keep B's obs buffer in step (not needed by the kernel)
+            if with_obs:                                   # bit-identical to the stand-alone obs-assembly kernel
+                assert torch.equal(envB._obs, obsA), "obs t=%d: %d entries differ" % (t, int((envB._obs != obsA).sum()))
+            else:
+                envB.observe()
             hid = (hB, cB)
 
 
