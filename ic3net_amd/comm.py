@@ -294,7 +294,9 @@ class CommNetMLP(nn.Module):
     def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None):
         """action_out, value, (h, c) = forward(x, info); `action` (heads, E, N) int32 <- select_action (Philox draws
         positioned by the env's own counters); env.step(action[0]) -> reward (E,N) f32, done (E,) i32, alive /
-        is_completed (E,N) i32 [, obs (E,N,obs_dim)].  trainer.py:49-67 in one launch."""
+        is_completed (E,N) i32.  trainer.py:49-67 in one launch.  `obs` (E,N,obs_dim), when given, receives the dense
+        observation of the state this call ACTS ON (the reference's `state` argument of policy_net at this step),
+        assembled by the same launch; the observation of the new state is what the next call writes (or env.observe())."""
         n, H = self.nagents, self.hid_size
         x, (hidden_state, cell_state) = x
         batch = x.size(0)

@@ -466,9 +466,12 @@ __device__ __forceinline__ void tj_obs_store_run(int32_t* tiles, int tile_words,
     const int L = Le * nenv;
     const long long b0 = e0 * (long long)Le;
     float* out = obs + b0;
+    const float inv_row = 1.0f / (float)obs_dim;
+    const bool small = L < (1 << 20);                      // (f + 0.5) / obs_dim is exact in fp32 below 2^20
     auto value = [&](int f) -> float {
-        const int el = f / Le, fr = f - el * Le;
-        const int a = fr / obs_dim, off = fr - a * obs_dim;
+        const int row = small ? (int)(((float)f + 0.5f) * inv_row) : f / obs_dim;   // row of the run = el * N + a
+        const int off = f - row * obs_dim;
+        const int el = row / N, a = row - el * N;          // N <= 64: cheap
         return tj_obs_value(tj_tile_at(tiles + el * tile_words, N), s, a, off, WW, inv_vocab);
     };
     const int head = (int)((4 - (b0 & 3)) & 3);

@@ -79,7 +79,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     float* sscale = sm + BM;                                     // [BM] per-env 1/(n_alive-1)
     int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
     int32_t* tile = sact + BM;                                   // env descriptors of the tile's envs
-    int32_t* otile = tile + a.tile_words;                        // (a.obs) descriptors of the PREVIOUS tile's new state
 
     if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
@@ -120,18 +119,17 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     };
-    // next_state rows of the envs [eb, eb + ne) whose descriptors sit in `otile`: slice part/nparts of the stores
+    // dense observation rows of the envs [eb, eb + ne) (descriptors in `tile`): slice part/nparts of the stores
     auto obs_store = [&](int eb, int ne, int part, int nparts) {
         if constexpr (KIND == IC3_ENV_PP) {
-            const int2* pt = reinterpret_cast<const int2*>(otile + ((2 * a.EPT * total + 3) & ~3));
+            const int2* pt = reinterpret_cast<const int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
             const int vocab = a.pp.dim * a.pp.dim + 4;
             if ((vocab & 3) == 0) pp_obs_store_run(pt, a.obs, eb, ne, nsegE, vocab, tid, NT, part, nparts);
             else pp_obs_store_run_scalar(pt, a.obs, eb, ne, nsegE, vocab, tid, NT, part, nparts);
         } else if constexpr (KIND == IC3_ENV_TJ) {
-            tj_obs_store_run(otile, tjw, a.tj, a.obs, eb, ne, tid, NT, part, nparts);
+            tj_obs_store_run(tile, tjw, a.tj, a.obs, eb, ne, tid, NT, part, nparts);
         }
     };
-    int pend_e0 = -1, pend_nenv = 0;     // tile whose next_state rows are still to be stored (descriptors in otile)
 
 #pragma unroll 1
     for (int tile_id = blockIdx.x; tile_id < a.ntiles; tile_id += gridDim.x) {
@@ -172,15 +170,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const int row = idx / H4, c4 = idx - row * H4;
         hv[i] = row < rows ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4) : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
-    // next_state rows of the previous tile: 3/4 of the stores go out here, behind the loads just requested — the store
-    // stream and this tile's latency chain (S0..S7) share the time; the last quarter is issued right before the gate
-    // loop and drains under it (a wave streaming fp32 MFMAs leaves no issue slots to anything else on its SIMD, but
-    // stores already in flight complete on their own)
-    if (KIND != 0 && a.obs && pend_e0 >= 0) {
-        obs_store(pend_e0, pend_nenv, 0, 4);
-        obs_store(pend_e0, pend_nenv, 1, 4);
-        obs_store(pend_e0, pend_nenv, 2, 4);
-    }
     __syncthreads();
 
     // ---- S1: window descriptors ------------------------------------------------------------------------------------
@@ -188,6 +177,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         desc_tab(tile, nenv);
         __syncthreads();
     }
+    // Dense observation of the state this step acts on (the `state` the reference hands to policy_net, trainer.py:49),
+    // written by the launch that consumes it.  A wave that streams fp32 MFMAs leaves no issue slots to any other wave
+    // of its SIMD (measured, tools/exp/ws_probe.hip), so a store stream can only share time with the matrix work from
+    // INSIDE the same instruction stream: the stores go out in four bursts (<= 64 per wave in flight) — behind the
+    // encoder gathers, before the gate loop, in its middle and after it — and drain while the wave computes.
+    const bool obs_here = (KIND != 0) && a.obs != nullptr;
+    if (obs_here) obs_store(e0, nenv, 0, 4);
 
     // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
 #pragma unroll 2
@@ -300,7 +296,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             As[lr * LDA + col] = accC[rt][reg];
         }
-    if (KIND != 0 && a.obs && pend_e0 >= 0) obs_store(pend_e0, pend_nenv, 3, 4);   // drains under the gate loop
+    if (obs_here) obs_store(e0, nenv, 1, 4);   // drains under the first half of the gate loop
     __syncthreads();
 
     // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell) --------------------------------------
@@ -340,6 +336,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __builtin_amdgcn_sched_barrier(0);
         block(b1, kb + 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (obs_here && kb == KB / 2 - 2) obs_store(e0, nenv, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
         {
             const int kn = (kb + 3 < KB) ? kb + 3 : KB - 1;
 #pragma unroll
@@ -348,6 +346,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (obs_here) obs_store(e0, nenv, 3, 4);
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
     {
         const float* lb = a.l_bias + tz;
@@ -470,18 +469,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
             }
         }
-        if (a.obs) {   // descriptors of the tile's NEW state (same workgroup wrote it: visible after the barrier)
-            __syncthreads();
-            desc_positions(otile, e0, nenv);
-            __syncthreads();
-            desc_tab(otile, nenv);
-            pend_e0 = e0;
-            pend_nenv = nenv;
-        }
     }
     __syncthreads();   // LDS (tile, masks, A tile) is reused by the next tile
     }   // tiles
-    if (KIND != 0 && a.obs && pend_e0 >= 0) obs_store(pend_e0, pend_nenv, 0, 1);
 }
 
 // Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
@@ -535,7 +525,10 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
         }
     }
     // persistent: at most one resident set of workgroups, each walking tiles blockIdx.x + k * gridDim.x
-    const int grid = tiles < resident_workgroups(H) ? tiles : resident_workgroups(H);
+    // one workgroup per tile: the hardware dispatcher balances the tiles over the CUs (a fixed resident set walking a
+    // strided tile list ran 3 full rounds on a third of the CUs where 2.67 were needed)
+    const int grid = tiles;
+    (void)resident_workgroups;
     hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, a);
     IC3_HIP(hipGetLastError());
     return 0;
@@ -575,7 +568,8 @@ static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_wo
     }
     tile_words = (tile_words + 3) & ~(size_t)3;
     if (tile_words_out) *tile_words_out = (int)tile_words;
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + tile_words * (with_obs ? 2 : 1)) * sizeof(float);
+    (void)with_obs;
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + tile_words) * sizeof(float);
     const size_t limit = (H <= 128) ? 80 * 1024 : 160 * 1024;   // two workgroups per CU up to H = 128
     return lds <= limit ? (int)lds : 0;
 }
@@ -698,10 +692,12 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.obs = fused_obs ? obs : nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    if (obs && !fused_obs) {   // same contents, as a launch of its own in front (the step below changes the state)
+        rc = ic3_env_observe(env, obs, stream);
+        if (rc) return rc;
+    }
     if (H == 128) rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s);
     else if (H == 64) rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s);
     else rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s);
-    if (rc) return rc;
-    if (obs && !fused_obs) return ic3_env_observe(env, obs, stream);
-    return 0;
+    return rc;
 }

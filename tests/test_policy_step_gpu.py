@@ -95,7 +95,8 @@ def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_
                 done = torch.full((E,), -1, dtype=torch.int32, device=dev)
                 alive = torch.full((E, N), -1, dtype=torch.int32, device=dev)
                 comp = torch.full((E, N), -1, dtype=torch.int32, device=dev)
-                with_obs = (t % 3 != 2)       # next_state rows from the same launch (two steps out of three)
+                with_obs = (t % 3 != 2)       # dense obs of the state acted on, from the same launch (2 steps of 3)
+                obs_in = obsA.clone()
                 if with_obs:
                     envB._obs.fill_(-5.0)
                 logpB, valB, (hB, cB) = netB.step_env(envB, [envB._obs, hid], info, act, rew, done, alive, comp,
@@ -124,10 +125,9 @@ def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_
                 info = {}
             if hard_attn:
                 info['comm_action'] = act[-1].clone()
-            if with_obs:                                   # bit-identical to the stand-alone obs-assembly kernel
-                assert torch.equal(envB._obs, obsA), "obs t=%d: %d entries differ" % (t, int((envB._obs != obsA).sum()))
-            else:
-                envB.observe()
+            if with_obs:        # the observation of the INPUT state, bit-identical to the stand-alone obs-assembly kernel
+                assert torch.equal(envB._obs, obs_in), "obs t=%d: %d entries differ" % (t, int((envB._obs != obs_in).sum()))
+            envB.observe()
             hid = (hB, cB)
 
 
