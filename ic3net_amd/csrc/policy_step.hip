@@ -56,6 +56,7 @@ struct StepArgs {
     float* out;                 // [R][OT] log-probs | value
     int32_t* action;            // [nheads][R]
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
+    int obs_dim;                // floats per observation row
     int ntiles;                 // tiles of EPT envs; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     // env
     int E, N, EPT, G;
@@ -119,18 +120,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     };
-    // dense observation rows of the envs [eb, eb + ne) (descriptors in `tile`): slice part/nparts of the stores
-    auto obs_store = [&](int eb, int ne, int part, int nparts) {
-        if constexpr (KIND == IC3_ENV_PP) {
-            const int2* pt = reinterpret_cast<const int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
-            const int vocab = a.pp.dim * a.pp.dim + 4;
-            if ((vocab & 3) == 0) pp_obs_store_run(pt, a.obs, eb, ne, nsegE, vocab, tid, NT, part, nparts);
-            else pp_obs_store_run_scalar(pt, a.obs, eb, ne, nsegE, vocab, tid, NT, part, nparts);
-        } else if constexpr (KIND == IC3_ENV_TJ) {
-            tj_obs_store_run(tile, tjw, a.tj, a.obs, eb, ne, tid, NT, part, nparts);
-        }
-    };
-
 #pragma unroll 1
     for (int tile_id = blockIdx.x; tile_id < a.ntiles; tile_id += gridDim.x) {
     // an opaque zero, re-made every iteration and added to the addresses of everything that does not depend on the
@@ -145,6 +134,30 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     const int nenv = min(a.EPT, a.E - e0);
     const int rows = nenv * N;                                   // valid rows of this tile (<= 64)
     const size_t r0 = (size_t)e0 * N;
+
+    // ---- dense observation of the state this step acts on (the `state` the reference hands to policy_net,
+    // trainer.py:49), written by the launch that consumes it.  A wave that streams fp32 MFMAs leaves no issue slots to
+    // any other wave of its SIMD (measured: tools/exp/ws_probe.hip), so the store stream can only share time with the
+    // matrix work from INSIDE the same instruction stream — and there every instruction counts.  The rows are ~98 %
+    // zeros: the tile's contiguous slice of the obs tensor is ZERO-FILLED by stores sprinkled between the MFMAs of the
+    // C product and the gate loop (address arithmetic only), and the few non-zero entries (<= 3 per window cell) are
+    // patched in at the very end, after every wave has seen its zero stores complete (s_waitcnt + barrier).
+    const bool obs_here = (KIND != 0) && a.obs != nullptr;
+    const long long ob0 = (long long)e0 * N * a.obs_dim;         // first float of the tile's rows
+    const int oL = rows * a.obs_dim;                             // floats of the tile
+    const int ohead = (int)((4 - (ob0 & 3)) & 3);
+    const int onb = obs_here ? (oL - ohead) >> 2 : 0;            // float4s of the body
+    ps_f32x4* const obody = reinterpret_cast<ps_f32x4*>(a.obs + ob0 + ohead);
+    int zq = tid - (int)(((ob0 + ohead) >> 2) & 63);             // 1 KiB-aligned wave stores (see pp_obs_kernel)
+    auto zero_store = [&]() {
+        if (zq >= 0 && zq < onb) obody[zq] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        zq += NT;
+    };
+    if (obs_here) {
+        const int otail = (oL - ohead) & 3;
+        if (tid < ohead) a.obs[ob0 + tid] = 0.f;
+        if (tid < otail) a.obs[ob0 + ohead + 4 * (long long)onb + tid] = 0.f;
+    }
 
     // ---- S0: masks, per-env scale (comm.py:102-107,194-196; quirks Q21/Q23), entity positions --------------------
     for (int r = tid; r < BM; r += NT) {
@@ -177,14 +190,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         desc_tab(tile, nenv);
         __syncthreads();
     }
-    // Dense observation of the state this step acts on (the `state` the reference hands to policy_net, trainer.py:49),
-    // written by the launch that consumes it.  A wave that streams fp32 MFMAs leaves no issue slots to any other wave
-    // of its SIMD (measured, tools/exp/ws_probe.hip), so a store stream can only share time with the matrix work from
-    // INSIDE the same instruction stream: the stores go out in four bursts (<= 64 per wave in flight) — behind the
-    // encoder gathers, before the gate loop, in its middle and after it — and drain while the wave computes.
-    const bool obs_here = (KIND != 0) && a.obs != nullptr;
-    if (obs_here) obs_store(e0, nenv, 0, 4);
-
     // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
 #pragma unroll 2
     for (int i = 0; i < 8; ++i) {
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                     accC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cb[ch & 1][k][j], accC[0], 0, 0, 0);
                     accC[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], cb[ch & 1][k][j], accC[1], 0, 0, 0);
                 }
+                if (obs_here) zero_store();
             }
         }
         __syncthreads();   // every wave has read the comm tile
@@ -296,7 +302,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             As[lr * LDA + col] = accC[rt][reg];
         }
-    if (obs_here) obs_store(e0, nenv, 1, 4);   // drains under the first half of the gate loop
     __syncthreads();
 
     // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell) --------------------------------------
@@ -317,36 +322,35 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[g][j], acc[0][g], 0, 0, 0);
                 acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[g][j], acc[1][g], 0, 0, 0);
             }
+            if (obs_here) {   // two zero stores per 8 MFMAs
+                zero_store();
+                zero_store();
+            }
         }
     };
     static_assert(KB % 2 == 0, "K/8 must be even");
     // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
     // their first use, which exposes the full L2 latency every block).
-    // The refills are unconditional (the last two re-read the final blocks): with a branch around them the compiler
-    // must assume the shorter in-flight queue and waits for vmcnt(0) — i.e. for the loads it has only just issued.
 #pragma unroll 1
     for (int kb = 0; kb < ((a.dbg & 1) ? 0 : KB); kb += 2) {
         block(b0, kb);
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int kn = (kb + 2 < KB) ? kb + 2 : KB - 2;
+        if (kb + 2 < KB) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)kn * KB_STRIDE + (size_t)g * H * 2];
+            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
         }
         __builtin_amdgcn_sched_barrier(0);
         block(b1, kb + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (obs_here && kb == KB / 2 - 2) obs_store(e0, nenv, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const int kn = (kb + 3 < KB) ? kb + 3 : KB - 1;
+        if (kb + 3 < KB) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)kn * KB_STRIDE + (size_t)g * H * 2];
+            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (obs_here) obs_store(e0, nenv, 3, 4);
+    if (obs_here)
+        while (zq < onb) zero_store();    // tiles with more obs than the loop has slots for (obs-dominated shapes)
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
     {
         const float* lb = a.l_bias + tz;
@@ -467,6 +471,48 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 pp_step_lanes(a.pp, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
             } else {
                 tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+            }
+        }
+    }
+    if (obs_here) {
+        // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
+        // first non-zero entry goes out to the same lines
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* orow0 = a.obs + ob0;
+        if constexpr (KIND == IC3_ENV_PP) {
+            const int vocab = a.pp.dim * a.pp.dim + 4;
+            for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
+                const int2 d = ptab[sg];
+                float* cell = orow0 + (size_t)sg * vocab;
+                const float npred = (float)(d.y & 0xffff), nprey = (float)(d.y >> 16);
+                // channels: d.x one-hot (grid id or OUTSIDE), vocab-2 #prey, vocab-1 #predators (counts add, quirk Q3)
+                cell[d.x] = 1.f + (d.x == vocab - 2 ? nprey : 0.f) + (d.x == vocab - 1 ? npred : 0.f);
+                if (d.x != vocab - 2 && nprey != 0.f) cell[vocab - 2] = nprey;
+                if (d.x != vocab - 1 && npred != 0.f) cell[vocab - 1] = npred;
+            }
+        } else if constexpr (KIND == IC3_ENV_TJ) {
+            const int obs_dim = a.obs_dim;
+            for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
+                const int el = sg / (nsegE + N), q = sg - el * (nsegE + N);
+                const TJTile t = tj_tile_at(tile + el * tjw, N);
+                if (q < N) {                                     // header of car q's row (TJ:338-344)
+                    if (!t.sal[q]) continue;
+                    float* row = orow0 + ((size_t)el * N + q) * obs_dim;
+                    row[0] = t.s0[q];
+                    row[1] = t.s1[q];
+                    if (a.tj.hdr == 4) {
+                        row[2] = t.s2[q];
+                        row[3] = t.s3[q];
+                    }
+                } else {                                         // window cell (TJ:331-332,352-356)
+                    const int qq = q - N, car = qq / WW, cellx = qq - car * WW;
+                    if (!t.sal[car]) continue;
+                    const int2 d = t.tab[qq];
+                    float* cell = orow0 + ((size_t)el * N + car) * obs_dim + a.tj.hdr + (size_t)cellx * a.tj.vocab;
+                    if (d.x >= 0) cell[d.x] = 1.f + (d.x == a.tj.car_class ? (float)d.y : 0.f);
+                    if (d.x != a.tj.car_class && d.y != 0) cell[a.tj.car_class] = (float)d.y;
+                }
             }
         }
     }
@@ -690,6 +736,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.ntiles = tiles;
     a.tile_words = tile_words;
     a.obs = fused_obs ? obs : nullptr;
+    a.obs_dim = env->dims.obs_dim;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (obs && !fused_obs) {   // same contents, as a launch of its own in front (the step below changes the state)
