@@ -44,6 +44,7 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
+    int zb, zl;                 // zero-store pacing: per burst in front of the gate loop, per 8 MFMAs inside it
     int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
                                 // between the two co-resident workgroups of a CU; speed only)
     int dbg;                    // timing ablations (IC3_PS_DEBUG bit mask; results are wrong when set): 1 gate MFMA loop,
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         if (zq >= 0 && zq < onb) obody[zq] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
         zq += NT;
     };
+    auto zero_burst = [&](int n) {
+        if (obs_here) {
+#pragma unroll 1
+            for (int i = 0; i < n; ++i) zero_store();
+        }
+    };
     if (obs_here) {
         const int otail = (oL - ohead) & 3;
         if (tid < ohead) a.obs[ob0 + tid] = 0.f;
@@ -183,6 +190,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const int row = idx / H4, c4 = idx - row * H4;
         hv[i] = row < rows ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4) : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
+    // the zero stores are spread over the tile's whole lifetime (a PP-hard tile has 214 per thread): ~80 between the
+    // phases in front of the gate loop, one per 8 MFMAs inside it — bunching them up (all in the loop, or front-loaded)
+    // fills the store queue and stalls the wave in the middle of its MFMA stream (measured: 0.50 vs 0.47 ms)
+    zero_burst(a.zb);
     __syncthreads();
 
     // ---- S1: window descriptors ------------------------------------------------------------------------------------
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         desc_tab(tile, nenv);
         __syncthreads();
     }
+    zero_burst(a.zb);
     // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
 #pragma unroll 2
     for (int i = 0; i < 8; ++i) {
@@ -223,6 +235,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     __syncthreads();
 
+    zero_burst(a.zb);
     // ---- S4: h -> h half ---------------------------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
     __syncthreads();
 
+    zero_burst(a.zb);
     if (!a.comm_zero) {   // comm_mask_zero (comm.py:40-41): C sees zeros, inp = enc + C.bias
         // ---- S5: comm_j = m_j (S_e - m_j h_j) scale_e (closed form of comm.py:181-205) -> inp half --------------------
         {
@@ -294,6 +308,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) b1[g] = wp[KB_STRIDE + (size_t)g * H * 2];
     __builtin_amdgcn_sched_barrier(0);
+    zero_burst(a.zb);
     // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -322,9 +337,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[g][j], acc[0][g], 0, 0, 0);
                 acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[g][j], acc[1][g], 0, 0, 0);
             }
-            if (obs_here) {   // two zero stores per 8 MFMAs
+            if (obs_here) {
                 zero_store();
-                zero_store();
+                if (a.zl > 1) zero_store();
             }
         }
     };
@@ -737,6 +752,17 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.tile_words = tile_words;
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;
+    {   // pacing of the zero stores: per-thread count of a tile, 5 bursts in front + KB*4 slots in the loop
+        static const int zb_env = getenv("IC3_PS_ZB") ? atoi(getenv("IC3_PS_ZB")) : -1;
+        static const int zl_env = getenv("IC3_PS_ZL") ? atoi(getenv("IC3_PS_ZL")) : -1;
+        const long long per_thread = ((long long)a.EPT * a.N * a.obs_dim / 4 + 2 * H - 1) / (2 * H) + 1;
+        const int slots = (2 * H / 8) * 4;                       // one per 8 MFMAs
+        a.zl = zl_env >= 0 ? zl_env : 1;
+        long long front = per_thread - (long long)slots * a.zl - H / 8;   // H/8 more go out inside the C product
+        if (front < 0) front = 0;
+        a.zb = zb_env >= 0 ? zb_env : (int)((front + 4) / 5);
+        if (a.zb > 48) a.zb = 48;
+    }
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (obs && !fused_obs) {   // same contents, as a launch of its own in front (the step below changes the state)
