@@ -7,7 +7,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libic3rollout.so")
+SO_PATH = os.environ.get("IC3_ROLLOUT_LIB") or os.path.join(_HERE, "csrc", "libic3rollout.so")   # (override: A/B builds)
 
 ENV_PP, ENV_TJ = 1, 2
 PP_MODES = {"mixed": 0, "cooperative": 1, "competitive": 2}

@@ -31,6 +31,27 @@ namespace ic3 {
 typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
 typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
 
+// v_mfma_f32_32x32x2_f32 with the accumulator pinned to AGPRs: hipcc picks the all-VGPR form when the registers fit,
+// which runs ~6 % slower (144 vs 153 TFLOP/s in tools/exp/ws_probe.hip).  The asm is opaque to the hazard recogniser:
+// whoever reads the accumulator afterwards calls mfma_settle() first.
+#ifndef IC3_PS_AGPR
+#define IC3_PS_AGPR 1
+#endif
+__device__ __forceinline__ void mfma_acc(ps_f32x16& acc, float x, float y)
+{
+#if IC3_PS_AGPR
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
+#else
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void mfma_settle()
+{
+#if IC3_PS_AGPR
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
 struct StepArgs {
     // policy (ic3_policy)
     const ps_f32x4* Wt;         // encoder.weight^T [obs_dim][H/4]
@@ -286,12 +307,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    accC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cb[ch & 1][k][j], accC[0], 0, 0, 0);
-                    accC[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], cb[ch & 1][k][j], accC[1], 0, 0, 0);
+                    mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
+                    mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
                 }
                 if (obs_here) zero_store();
             }
         }
+        mfma_settle();
         __syncthreads();   // every wave has read the comm tile
     }
 
@@ -334,8 +356,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bq[g][j], acc[0][g], 0, 0, 0);
-                acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bq[g][j], acc[1][g], 0, 0, 0);
+                mfma_acc(acc[0][g], a0[j], bq[g][j]);
+                mfma_acc(acc[1][g], a1[j], bq[g][j]);
             }
             if (obs_here) {
                 zero_store();
@@ -364,6 +386,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    mfma_settle();
     if (obs_here)
         while (zq < onb) zero_store();    // tiles with more obs than the loop has slots for (obs-dominated shapes)
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
