@@ -158,40 +158,24 @@ __device__ __forceinline__ int2 pp_tab_entry(const int32_t* sr, const int32_t* s
     return make_int2(id, npred | (npr << 16));
 }
 
-// encoder(obs row of entity a)[4*c4 .. 4*c4+3] from the env's LDS descriptors (see pp_encode_kernel).  Branch-free: the
-// count rows of EVERY window cell are loaded and scaled by the (mostly zero) counts — `acc += 0 * w` leaves acc
-// bit-identical to skipping the term, and without the data-dependent branches all gathers of a row are independent
-// loads in flight together instead of a chain of L2 round trips (9.7 -> ~3 us per 64-row tile in policy_step_kernel).
-// CELLS > 0: compile-time window size (fully unrolled).
-template <int CELLS>
-__device__ __forceinline__ dv_f32x4 pp_encode_row_n(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
-                                                    int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
-                                                    const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table)
+// encoder(obs row of entity a)[4*c4 .. 4*c4+3] from the env's LDS descriptors (see pp_encode_kernel)
+__device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
+                                                  int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
+                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table)
 {
     dv_f32x4 acc = bias[c4];
     // the one-hot location channels of all window cells depend only on the entity's position: one row of the
     // pre-summed table (pp_encode_table_kernel) replaces W*W gathered rows
     if (loc_table) acc += loc_table[(size_t)(sr[a] * dim + sc[a]) * H4 + c4];
-    const int ncell = CELLS > 0 ? CELLS : WW;
-#pragma unroll
-    for (int cell = 0; cell < ncell; ++cell) {
-        const int2 t = tab[a * ncell + cell];
+    for (int cell = 0; cell < WW; ++cell) {
+        const int2 t = tab[a * WW + cell];
         const size_t row = (size_t)cell * vocab;
         if (!loc_table) acc += Wt[(row + t.x) * H4 + c4];
-        acc += (float)(t.y & 0xffff) * Wt[(row + vocab - 1) * H4 + c4];
-        acc += (float)(t.y >> 16) * Wt[(row + vocab - 2) * H4 + c4];
+        const int npred = t.y & 0xffff, npr = t.y >> 16;
+        if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
+        if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
     }
     return acc;
-}
-
-__device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
-                                                  int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
-                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table)
-{
-    if (WW == 9) return pp_encode_row_n<9>(sr, sc, tab, a, c4, H4, WW, vocab, dim, Wt, bias, loc_table);
-    if (WW == 1) return pp_encode_row_n<1>(sr, sc, tab, a, c4, H4, WW, vocab, dim, Wt, bias, loc_table);
-    if (WW == 25) return pp_encode_row_n<25>(sr, sc, tab, a, c4, H4, WW, vocab, dim, Wt, bias, loc_table);
-    return pp_encode_row_n<0>(sr, sc, tab, a, c4, H4, WW, vocab, dim, Wt, bias, loc_table);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,14 +352,12 @@ __device__ __forceinline__ int2 tj_tab_entry(const TJTile& t, const TJState& s, 
     return make_int2(id, ncar);
 }
 
-// encoder(obs row of car a)[4*c4 ..] (see tj_encode_kernel): bias only for a dead car (its obs row is zero).  The car
-// count rows are loaded for every cell and scaled by the count (see pp_encode_row_n).
-template <int CELLS>
-__device__ __forceinline__ dv_f32x4 tj_encode_row_n(const TJTile& t, const TJState& s, int a, int c4, int H4,
-                                                    const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
-                                                    const dv_f32x4* __restrict__ loc_table)
+// encoder(obs row of car a)[4*c4 ..] (see tj_encode_kernel): bias only for a dead car (its obs row is zero)
+__device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
+                                                  const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
+                                                  const dv_f32x4* __restrict__ loc_table)
 {
-    const int W = 2 * s.v + 1, WW = CELLS > 0 ? CELLS : W * W;
+    const int W = 2 * s.v + 1, WW = W * W;
     dv_f32x4 acc = bias[c4];
     if (t.sal[a]) {
         acc += t.s0[a] * Wt[c4];
@@ -385,26 +367,14 @@ __device__ __forceinline__ dv_f32x4 tj_encode_row_n(const TJTile& t, const TJSta
             acc += t.s3[a] * Wt[3 * H4 + c4];
         }
         if (loc_table) acc += loc_table[(size_t)(t.sr[a] * s.w + t.sc[a]) * H4 + c4];   // see pp_encode_kernel
-#pragma unroll
         for (int cell = 0; cell < WW; ++cell) {
             const int2 d = t.tab[a * WW + cell];
             const size_t row = s.hdr + (size_t)cell * s.vocab;
             if (!loc_table && d.x >= 0) acc += Wt[(row + d.x) * H4 + c4];   // scalar vocab: -1 = not a road cell
-            acc += (float)d.y * Wt[(row + s.car_class) * H4 + c4];
+            if (d.y) acc += (float)d.y * Wt[(row + s.car_class) * H4 + c4];
         }
     }
     return acc;
-}
-
-__device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
-                                                  const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
-                                                  const dv_f32x4* __restrict__ loc_table)
-{
-    const int W = 2 * s.v + 1;
-    if (W == 3) return tj_encode_row_n<9>(t, s, a, c4, H4, Wt, bias, loc_table);
-    if (W == 1) return tj_encode_row_n<1>(t, s, a, c4, H4, Wt, bias, loc_table);
-    if (W == 5) return tj_encode_row_n<25>(t, s, a, c4, H4, Wt, bias, loc_table);
-    return tj_encode_row_n<0>(t, s, a, c4, H4, Wt, bias, loc_table);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -31,11 +31,11 @@ namespace ic3 {
 typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
 typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
 
-// v_mfma_f32_32x32x2_f32 with the accumulator pinned to AGPRs: hipcc picks the all-VGPR form when the registers fit,
-// which runs ~6 % slower (144 vs 153 TFLOP/s in tools/exp/ws_probe.hip).  The asm is opaque to the hazard recogniser:
-// whoever reads the accumulator afterwards calls mfma_settle() first.
+// v_mfma_f32_32x32x2_f32, optionally with the accumulator pinned to AGPRs (IC3_PS_AGPR=1): hipcc picks the all-VGPR
+// form when the registers fit, which streams ~6 % slower in isolation (144 vs 153 TFLOP/s, tools/exp/ws_probe.hip).
+// The asm is opaque to the hazard recogniser: whoever reads the accumulator afterwards calls mfma_settle() first.
 #ifndef IC3_PS_AGPR
-#define IC3_PS_AGPR 1
+#define IC3_PS_AGPR 0   // measured: the 128/128 VGPR/AGPR split spills in the phases around the loops; net slower (0.57 vs 0.52 ms)
 #endif
 __device__ __forceinline__ void mfma_acc(ps_f32x16& acc, float x, float y)
 {
@@ -79,7 +79,8 @@ struct StepArgs {
     int32_t* action;            // [nheads][R]
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
     int obs_dim;                // floats per observation row
-    int ntiles;                 // tiles of EPT envs; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    int n_full, EPTh;           // tiles [0, n_full) hold EPT envs; the rest hold EPTh envs (<= 32 rows: one row tile of MFMAs)
+    int ntiles;                 // all tiles; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     // env
     int E, N, EPT, G;
     int tile_words;             // int32 words of one env-descriptor block in LDS
@@ -152,9 +153,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     tid = (int)threadIdx.x + tz;   // every per-lane index below is re-derived per tile (nothing to hoist and keep live)
     const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li;
-    const int e0 = tile_id * a.EPT;
-    const int nenv = min(a.EPT, a.E - e0);
-    const int rows = nenv * N;                                   // valid rows of this tile (<= 64)
+    // full tiles first; the envs left over after the last full round of all resident workgroups go out as HALF tiles
+    // (<= 32 rows, one row tile of MFMAs: half the matrix time) so that the tail round costs half instead of a full one
+    const bool half = tile_id >= a.n_full;
+    const int e0 = half ? a.n_full * a.EPT + (tile_id - a.n_full) * a.EPTh : tile_id * a.EPT;
+    const int nenv = min(half ? a.EPTh : a.EPT, a.E - e0);
+    const int rows = nenv * N;                                   // valid rows of this tile (<= 64; <= 32 in a half tile)
+    const bool two = rows > 32;                                  // second 32-row MFMA tile in use (workgroup-uniform)
     const size_t r0 = (size_t)e0 * N;
 
     // ---- dense observation of the state this step acts on (the `state` the reference hands to policy_net,
@@ -294,24 +299,32 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int k = 0; k < CH; ++k) cb[0][k] = cwp[(size_t)k * H * 2];
         __syncthreads();
         // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
+        auto cprod = [&](auto two_c) {
+            constexpr bool TWO = decltype(two_c)::value;
 #pragma unroll
-        for (int ch = 0; ch < ((a.dbg & 2) ? 0 : NCH); ++ch) {
-            if (ch + 1 < NCH) {
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + 1 < NCH) {
 #pragma unroll
-                for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp[(size_t)((ch + 1) * CH + k) * H * 2];
-            }
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int kb = ch * CH + k;
-                const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-                const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
-                    mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
+                    for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp[(size_t)((ch + 1) * CH + k) * H * 2];
                 }
-                if (obs_here) zero_store();
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int kb = ch * CH + k;
+                    const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+                    ps_f32x4 a1;
+                    if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
+                        if constexpr (TWO) mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
+                    }
+                    if (obs_here) zero_store();
+                }
             }
+        };
+        if (!(a.dbg & 2)) {
+            if (two) cprod(std::true_type{});
+            else cprod(std::false_type{});
         }
         mfma_settle();
         __syncthreads();   // every wave has read the comm tile
@@ -349,42 +362,48 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
-    auto block = [&](const ps_f32x4 (&bq)[4], int kb) {
-        const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-        const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+    auto gate_loop = [&](auto two_c) {
+        constexpr bool TWO = decltype(two_c)::value;
+        auto block = [&](const ps_f32x4 (&bq)[4], int kb) {
+            const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+            ps_f32x4 a1;
+            if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                mfma_acc(acc[0][g], a0[j], bq[g][j]);
-                mfma_acc(acc[1][g], a1[j], bq[g][j]);
+                for (int g = 0; g < 4; ++g) {
+                    mfma_acc(acc[0][g], a0[j], bq[g][j]);
+                    if constexpr (TWO) mfma_acc(acc[1][g], a1[j], bq[g][j]);
+                }
+                if (obs_here) {
+                    zero_store();
+                    if (a.zl > 1) zero_store();
+                }
             }
-            if (obs_here) {
-                zero_store();
-                if (a.zl > 1) zero_store();
+        };
+        // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
+        // their first use, which exposes the full L2 latency every block).
+#pragma unroll 1
+        for (int kb = 0; kb < ((a.dbg & 1) ? 0 : KB); kb += 2) {
+            block(b0, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 2 < KB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            block(b1, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 3 < KB) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     static_assert(KB % 2 == 0, "K/8 must be even");
-    // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
-    // their first use, which exposes the full L2 latency every block).
-#pragma unroll 1
-    for (int kb = 0; kb < ((a.dbg & 1) ? 0 : KB); kb += 2) {
-        block(b0, kb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kb + 2 < KB) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        block(b1, kb + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kb + 3 < KB) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    if (two) gate_loop(std::true_type{});
+    else gate_loop(std::false_type{});
 
     mfma_settle();
     if (obs_here)
@@ -408,6 +427,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
+            if (rt == 1 && !two) break;          // half tile: rows 32..63 are padding (their h' is never read)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
@@ -585,6 +605,29 @@ static int resident_workgroups(int H)
     return cus * (H <= 128 ? 2 : 1);
 }
 
+// Tile plan (a.E, a.N, a.EPT set): full tiles of EPT envs for every COMPLETE round of the resident workgroups, then
+// the remaining envs as half tiles of floor(32/N) envs when they fit in one round (each costs half the matrix time);
+// problems smaller than one round keep full tiles.  IC3_PS_HALF=0 disables the half tiles.
+static int plan_tiles(StepArgs& a, int H)
+{
+    static const int use_half = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : 1;
+    const int slots = resident_workgroups(H);
+    const int all_full = (a.E + a.EPT - 1) / a.EPT;
+    a.EPTh = 32 / a.N;
+    a.n_full = all_full;
+    a.ntiles = all_full;
+    if (use_half && a.EPTh >= 1 && a.E / a.EPT >= slots) {
+        const int n_full = (a.E / a.EPT) / slots * slots;
+        const int rem = a.E - n_full * a.EPT;
+        const int n_half = (rem + a.EPTh - 1) / a.EPTh;
+        if (rem > 0 && n_half <= slots) {
+            a.n_full = n_full;
+            a.ntiles = n_full + n_half;
+        }
+    }
+    return a.ntiles;
+}
+
 template <int H, int KIND>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
 {
@@ -715,8 +758,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     a.N = N;
     a.EPT = 64 / N;
     a.G = 1;
-    const int tiles = (E + a.EPT - 1) / a.EPT;
-    a.ntiles = tiles;
+    const int tiles = plan_tiles(a, H);
     const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
@@ -770,8 +812,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.seed = env->tj.seed;
         a.gid0 = env->tj.env_id_offset;
     }
-    const int tiles = (a.E + a.EPT - 1) / a.EPT;
-    a.ntiles = tiles;
+    const int tiles = plan_tiles(a, H);
     a.tile_words = tile_words;
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;

@@ -40,6 +40,9 @@ CASES = [
     ("tj", dict(N=5, dim=6, vision=0, difficulty="easy", add_rate_min=0.5, add_rate_max=0.5), 64, True, 30, 10),
     ("tj", dict(N=6, dim=6, vision=1, difficulty="easy", add_rate_min=0.4, add_rate_max=0.4, vocab_type='scalar'), 128,
      True, 11, 8),
+    # more envs than one round of resident workgroups (512 x 6): full tiles + a tail of half tiles (3 envs, one MFMA row tile)
+    ("pp", dict(N=10, dim=8, vision=1, mode="mixed"), 128, True, 512 * 6 + 25, 2),
+    ("tj", dict(N=20, dim=18, vision=0, difficulty="hard", add_rate_min=0.3, add_rate_max=0.3), 128, True, 512 * 3 + 7, 2),
 ]
 
 
