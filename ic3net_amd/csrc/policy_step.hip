@@ -607,10 +607,11 @@ static int resident_workgroups(int H)
 
 // Tile plan (a.E, a.N, a.EPT set): full tiles of EPT envs for every COMPLETE round of the resident workgroups, then
 // the remaining envs as half tiles of floor(32/N) envs when they fit in one round (each costs half the matrix time);
-// problems smaller than one round keep full tiles.  IC3_PS_HALF=0 disables the half tiles.
+// problems smaller than one round keep full tiles.  Opt-in (IC3_PS_HALF=1): on PP-hard / TJ-hard at 8192 envs the step
+// time did not move.
 static int plan_tiles(StepArgs& a, int H)
 {
-    static const int use_half = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : 1;
+    static const int use_half = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : 0;   // measured: no gain (0.500 vs 0.493 ms), off
     const int slots = resident_workgroups(H);
     const int all_full = (a.E + a.EPT - 1) / a.EPT;
     a.EPTh = 32 / a.N;

@@ -250,13 +250,15 @@ def test_trainer_takes_the_one_launch_path_and_graph_replay_is_identical(workloa
             a.hip_graph = mode == "graph"
             a.mega_policy = mode != "chain"
             n0 = len(calls)
-            eps = [tr.get_episode(ep) for ep in range(3)]
+            runs[mode] = []
+            for ep in range(3):       # copy out per episode: in graph mode action_out / value are the graphs' static outputs
+                e, s = tr.get_episode(ep)
+                runs[mode].append(([t.action.clone() for t in e], [t.reward.clone() for t in e],
+                                   [t.value.clone() for t in e], [t.action_out[0].clone() for t in e], s))
             if mode == "eager":
                 assert len(calls) - n0 == 3 * a.max_steps
             if mode == "chain":
                 assert len(calls) == n0
-            runs[mode] = [([t.action.clone() for t in e], [t.reward.clone() for t in e], [t.value.clone() for t in e],
-                           [t.action_out[0].clone() for t in e], s) for e, s in eps]
     finally:
         ops.policy_step = orig
     for ep in range(3):
