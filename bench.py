@@ -298,17 +298,22 @@ def main():
     if world > 1:
         # RCCL is used only for the timing barrier / max-reduce (no collective on the rollout path); it is brought
         # up after the untimed warm-up so that graph capture never runs next to a communicator's helper threads.
-        try:
-            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-            dist.barrier()
-            backend = 'nccl'
-        except Exception as exc:                   # timing barrier only: gloo is an acceptable stand-in
-            sys.stderr.write("bench.py: RCCL bring-up failed (%r); using gloo for the timing barrier\n" % (exc,))
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        if 'IC3_BENCH_DEVICE' in os.environ:       # test hook (several ranks on one GPU): RCCL refuses duplicate devices
             dist.init_process_group(backend='gloo')
             dist.barrier()
             backend = 'gloo'
+        else:
+            try:
+                dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+                dist.barrier()
+                backend = 'nccl'
+            except Exception as exc:                   # timing barrier only: gloo is an acceptable stand-in
+                sys.stderr.write("bench.py: RCCL bring-up failed (%r); using gloo for the timing barrier\n" % (exc,))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend='gloo')
+                dist.barrier()
+                backend = 'gloo'
     torch.cuda.synchronize()
     raw_env.obs_timer = []
     mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use

@@ -1,4 +1,7 @@
 // ic3_api.hip — C ABI entry points of libic3rollout.so (declared in include/ic3_rollout.h).
+#include <dlfcn.h>
+
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -7,6 +10,41 @@
 namespace ic3 {
 
 static thread_local std::string g_err;
+
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)();
+roctx_push_t g_push = nullptr;
+roctx_pop_t g_pop = nullptr;
+int g_roctx = -1;   // -1 not probed, 0 off, 1 on
+
+bool roctx_on()
+{
+    if (g_roctx < 0) {
+        g_roctx = 0;
+        const char* e = getenv("IC3_ROCTX");
+        if (e && atoi(e) != 0) {
+            void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                g_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+                g_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+                if (g_push && g_pop) g_roctx = 1;
+            }
+        }
+    }
+    return g_roctx == 1;
+}
+}  // namespace
+
+Range::Range(const char* name) : on(roctx_on())
+{
+    if (on) g_push(name);
+}
+Range::~Range()
+{
+    if (on) g_pop();
+}
 
 void set_error(const std::string& msg) { g_err = msg; }
 int fail(int code, const std::string& msg)
@@ -244,6 +282,7 @@ static double py_float_floordiv(double vx, double wx)
 
 int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
 {
+    ic3::Range range_("ic3_env_reset");
     if (!env) return fail(-22, "ic3_env_reset: null handle");
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -270,12 +309,14 @@ int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
 
 int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream)
 {
+    ic3::Range range_("ic3_env_observe");
     if (!env || !obs) return fail(-22, "ic3_env_observe: null argument");
     return env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
 }
 
 int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream stream)
 {
+    ic3::Range range_("ic3_env_observe");
     if (!env || !obs) return fail(-22, "ic3_env_observe_at: null argument");
     env->view = snap;
     const int rc = env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
@@ -286,6 +327,7 @@ int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream
 int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
                    ic3_stream stream)
 {
+    ic3::Range range_("ic3_env_encode");
     if (!env || !Wt || !bias || !out) return fail(-22, "ic3_env_encode: null argument");
     if (ldo <= 0) ldo = H;
     if (H <= 0 || (H & 3) || (ldo & 3) || ldo < H) return fail(-22, "ic3_env_encode: H and ldo must be positive multiples of 4");
@@ -329,6 +371,7 @@ int ic3_env_encode_backward(ic3_env* env, const int32_t* snap, const float* grad
 int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,
                  int32_t* is_completed, ic3_stream stream)
 {
+    ic3::Range range_("ic3_env_step");
     if (!env || !actions || !reward || !done) return fail(-22, "ic3_env_step: null argument");
     if (env->resets == 0) return fail(-22, "ic3_env_step: reset() has not been called");
     hipStream_t s = (hipStream_t)stream;
@@ -342,6 +385,7 @@ int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward
 int ic3_env_sample_actions(const ic3_env* env, const float* logp, int ld, int A, int head, int32_t* action,
                            float* chosen_logp, ic3_stream stream)
 {
+    ic3::Range range_("ic3_env_sample_actions");
     if (!env || !logp || !action || A <= 0) return fail(-22, "ic3_env_sample_actions: bad arguments");
     return sample_actions_env(env, logp, ld, A, head, action, chosen_logp, (hipStream_t)stream);
 }

@@ -90,6 +90,16 @@ namespace ic3 {
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 
+// roctx ranges around the launches of the hot loop (the reference's unused utils.Timer, utils.py:86-98):
+// `IC3_ROCTX=1 rocprofv3 --marker-trace --kernel-trace ...` shows reset / step / observe / encode / policy_step /
+// sample spans above the kernels.  librocprofiler-sdk-roctx is dlopen()ed on first use; without IC3_ROCTX the
+// constructor is one predictable branch.
+struct Range {
+    explicit Range(const char* name);
+    ~Range();
+    bool on;
+};
+
 #define IC3_HIP(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \

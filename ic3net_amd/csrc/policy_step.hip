@@ -742,6 +742,7 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
 extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, int N, float* h, float* c,
                                   const int32_t* alive_in, const int32_t* comm_in, float* out, ic3_stream stream)
 {
+    ic3::Range range_("ic3_policy_forward");
     if (!p || !enc || !h || !c || !out || E <= 0 || N <= 0) return fail(-22, "ic3_policy_forward: bad arguments");
     const int H = p->H;
     if ((H != 64 && H != 128 && H != 256) || N > 64)
@@ -771,6 +772,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
                                const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward,
                                int32_t* done, int32_t* alive, int32_t* is_completed, ic3_stream stream)
 {
+    ic3::Range range_("ic3_policy_step");
     if (!env || !p || !h || !c || !out || !action || !reward || !done)
         return fail(-22, "ic3_policy_step: null argument");
     if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");

@@ -39,7 +39,8 @@ _FLAGS = [
     ('share_weights', 'flag', False),
 ]
 # engine flags (new)
-_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', 'flag', False), ('tune_gemm', 'flag', False)]
+_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', 'flag', False), ('tune_gemm', 'flag', False),
+                 ('dist_backend', str, 'nccl')]     # 'nccl' = RCCL over xGMI; 'gloo' for several ranks on one GPU (tests)
 
 
 def build_parser(argv):
@@ -145,7 +146,10 @@ def run(argv=None, out=print):
     torch.cuda.set_device(args.device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', args.device))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', args.device))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     derive_args(args)
     if args.seed == -1:                               # main.py:157-159
         args.seed = int(np.random.randint(0, 10000))
@@ -192,6 +196,10 @@ def run(argv=None, out=print):
                 checkpoint.save(args.save + '_' + str(ep), policy_net, log, trainer)
             if args.save != '':
                 checkpoint.save(args.save, policy_net, log, trainer)
+    dump = os.environ.get('IC3_DUMP_PARAMS')           # tests: every rank's final parameters + last epoch's stats
+    if dump:
+        torch.save({'params': {k: v.detach().cpu() for k, v in policy_net.state_dict().items()},
+                    'log': {k: list(v.data) for k, v in log.items()}}, '%s.rank%d.pt' % (dump, rank))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
