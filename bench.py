@@ -95,8 +95,22 @@ def build_trainer(workload, nenvs, seed, env_id_offset, device):
 # cores of this box on a bounded sample of the same workload.  One env object per step call, batch-1
 # fp64 policy calls — the reference's cost structure — in `procs` forked workers (README: nprocesses 16).
 # --------------------------------------------------------------------------------------------------
+# Probe numbers of the ACTUAL reference (fp64 torch, CPU), measured in the build container with
+# tests/golden/bench_reference.py and BASELINE.md §2's harness — NOT on the GPU box (the reference cannot travel);
+# reported next to the same-box legs, labelled with their host.
+REFERENCE_PROBE = {
+    "host": "build container, 8 x Intel Xeon @ 2.10 GHz, torch 2.10 CPU fp64, OMP_NUM_THREADS=1 (BASELINE.md §2)",
+    "unit": "agent-steps/s",
+    "pp_hard": {"rollout_1proc": 5580, "train_batch_1proc": 2872, "train_batch_8proc": 14693, "train_batch_16proc": 14311},
+    "pp_easy": {"rollout_1proc": 3732, "train_batch_1proc": 1981, "train_batch_16proc": 11656},
+    "tj_medium": {"rollout_1proc": 7570, "train_batch_1proc": 4520, "train_batch_16proc": 23512},
+    "tj_hard": {"rollout_1proc": 9320, "train_batch_1proc": 6041, "train_batch_16proc": 18269},
+}
+
+
 def _cpu_worker(job):
-    workload, env_ids, episodes, seed, budget_s = job
+    workload, env_ids, episodes, seed, budget_s = job[:5]
+    shaped = len(job) > 5 and job[5]          # leg (ii): the reference-shaped numpy env (dense one-hot copy per step)
     os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     try:
@@ -115,12 +129,15 @@ def _cpu_worker(job):
     for gid in env_ids:
         if time.perf_counter() - t0 > budget_s:
             break
-        if env_name == 'predator_prey':
+        if env_name == 'predator_prey' and shaped:
+            from oracle.pp_numpy import PPNumpyEnv
+            env = PPNumpyEnv(N, f['dim'], f['vision'], f['mode'], seed=seed, env_gid=gid)
+        elif env_name == 'predator_prey':
             env = oracle.PPOracle(N, f['dim'], f['vision'], f['mode'], seed=seed, env_gid=gid)
         else:
             env = oracle.TJOracle(N, f['dim'], f['vision'], f['difficulty'], add_rate_min=f['add_rate_min'],
                                   add_rate_max=f['add_rate_max'], seed=seed, env_gid=gid)
-        heads = [env.cfg.naction if env_name == 'predator_prey' else 2] + ([2] if f.get('ic3net') else [])
+        heads = [5 if env_name == 'predator_prey' else 2] + ([2] if f.get('ic3net') else [])
         if params is None:
             k = 1.0 / np.sqrt(H)
             shp = {'encoder.weight': (H, env.obs_dim), 'encoder.bias': (H,), 'f_module.weight_ih': (4 * H, H),
@@ -156,24 +173,43 @@ def _cpu_worker(job):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline(workload, envs_per_proc=256, episodes=1, seed=0, budget_s=12.0):
-    """Every worker plays whole episodes on fresh envs until `budget_s` of CPU time is spent (bounded sample)."""
+def _cpu_leg(workload, procs, envs_per_proc, episodes, seed, budget_s, shaped):
     import multiprocessing as mp
-    sys.path.insert(0, ROOT)
-    import oracle
-    oracle.build()
-    procs = max(1, min(16, os.cpu_count() or 1))        # the reference's nprocesses=16 (README.md:46)
-    jobs = [(workload, list(range(p * envs_per_proc, (p + 1) * envs_per_proc)), episodes, seed, budget_s)
+    jobs = [(workload, list(range(p * envs_per_proc, (p + 1) * envs_per_proc)), episodes, seed, budget_s, shaped)
             for p in range(procs)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(procs) as pool:
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
-    env_steps = sum(r[0] for r in res)
+    return sum(r[0] for r in res), wall
+
+
+def cpu_baseline(workload, envs_per_proc=256, episodes=1, seed=0, budget_s=10.0):
+    """The three legs of SURVEY §8(d), on a bounded sample (every worker plays whole episodes on fresh envs until
+    `budget_s` of CPU time is spent):
+      (i)   "port": the C oracle env + batch-1 fp64 numpy policy in 16 forked processes  -> value / unit / cores
+      (ii)  "reference_shaped": the same loop with the reference-shaped numpy env (one dense one-hot grid copy per step,
+            oracle/pp_numpy.py) — Predator-Prey workloads
+      (iii) "reference_probe": numbers of the actual reference from the build container, labelled with their host."""
+    sys.path.insert(0, ROOT)
+    import oracle
+    oracle.build()
+    procs = max(1, min(16, os.cpu_count() or 1))        # the reference's nprocesses=16 (README.md:46)
     N = WORKLOADS[workload][1]['nagents']
-    return {"value": round(N * env_steps / wall, 1), "unit": "agent-steps/s", "cores": procs, "kind": "port",
-            "sample": "%d procs x whole %s episodes for %.0f s each, batch-1 fp64 numpy policy + C oracle env: "
-                      "%d env-steps in %.1f s wall" % (procs, workload, budget_s, env_steps, wall)}
+    env_steps, wall = _cpu_leg(workload, procs, envs_per_proc, episodes, seed, budget_s, False)
+    out = {"value": round(N * env_steps / wall, 1), "unit": "agent-steps/s", "cores": procs, "kind": "port",
+           "sample": "%d procs x whole %s episodes for %.0f s each, batch-1 fp64 numpy policy + C oracle env: "
+                     "%d env-steps in %.1f s wall" % (procs, workload, budget_s, env_steps, wall)}
+    if WORKLOADS[workload][0] == 'predator_prey':
+        es2, wall2 = _cpu_leg(workload, procs, envs_per_proc, episodes, seed, budget_s, True)
+        out["reference_shaped"] = {
+            "value": round(N * es2 / wall2, 1), "unit": "agent-steps/s", "cores": procs,
+            "sample": "%d procs, reference-shaped numpy env (dense one-hot grid copy per step) + batch-1 fp64 numpy "
+                      "policy: %d env-steps in %.1f s wall" % (procs, es2, wall2)}
+    probe = REFERENCE_PROBE.get(workload)
+    if probe:
+        out["reference_probe"] = dict(probe, host=REFERENCE_PROBE["host"], unit=REFERENCE_PROBE["unit"])
+    return out
 
 
 def mfma_roofline(a, nenvs, step_ms):
