@@ -14,7 +14,11 @@ sys.path.insert(0, ROOT)
 def test_cpu_baseline_leg(workload):
     import bench
     out = bench.cpu_baseline(workload, envs_per_proc=2, episodes=1, budget_s=0.3)
-    assert set(out) == {"value", "unit", "cores", "kind", "sample"}
+    pp = bench.WORKLOADS[workload][0] == 'predator_prey'
+    assert set(out) == {"value", "unit", "cores", "kind", "sample", "reference_probe"} | ({"reference_shaped"} if pp else set())
+    if pp:      # leg (ii): the reference-shaped numpy env (dense one-hot grid copy per step)
+        assert out["reference_shaped"]["value"] > 0 and out["reference_shaped"]["unit"] == "agent-steps/s"
+    assert out["reference_probe"]["rollout_1proc"] > 0 and "build container" in out["reference_probe"]["host"]
     assert out["unit"] == "agent-steps/s" and out["kind"] == "port" and out["cores"] >= 1
     assert out["value"] > 0
     N, T = bench.WORKLOADS[workload][1]['nagents'], bench.WORKLOADS[workload][1]['max_steps']
