@@ -35,7 +35,8 @@ class Dims(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("success_sum", C.c_double), ("add_rate", C.c_double), ("episodes", C.c_int64),
-                ("live_env_steps", C.c_int64)]
+                ("live_env_steps", C.c_int64), ("auto_success_sum", C.c_double), ("auto_episodes", C.c_int64),
+                ("auto_env_steps", C.c_int64)]
 
 
 class Policy(C.Structure):
@@ -56,6 +57,7 @@ EXPORTS = {
     "ic3_env_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
     "ic3_env_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ic3_env_step": (C.c_int, [C.c_void_p] * 7 + [C.c_void_p]),
+    "ic3_env_set_auto_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_env_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_observe_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

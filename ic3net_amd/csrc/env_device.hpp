@@ -36,8 +36,20 @@ __device__ __forceinline__ float group_sum(float v)
 // ------------------------------------------------------------------------------------------------
 // Predator-Prey
 // ------------------------------------------------------------------------------------------------
+// Auto-reset (ic3_env_set_auto_reset): an env whose episode ends at this step — episode_over, or max_steps steps played
+// — starts its next episode inside the same launch, like the reference's loop `while ...: get_episode()`
+// (trainer.py:107-108,227-242): episode += 1, t = 0, fresh state on the episode's own Philox key; `done` reports the
+// end, and the finished episode's success flag / length go to per-env accumulators (env.stat is per episode).
+struct AutoReset {
+    int max_steps;                  // 0 = off (lock-step mode: finished envs freeze until reset())
+    int32_t *episode;               // [E] episode counters (Philox key)
+    int32_t *acc_success, *acc_episodes, *acc_steps;   // [E] sums over the episodes finished since reset()
+    uint32_t seed, gid0;
+};
+
 struct PPState {
     int32_t *loc_r, *loc_c, *reached, *over, *success, *tstep;
+    AutoReset ar;
     int Np;       // predators (cfg.N)
     int nprey;
     int dim, v, mode, naction;
@@ -113,6 +125,10 @@ __device__ __forceinline__ void pp_step_lanes(const PPState& s, const StepOut& o
         if (o.comp_out) o.comp_out[(size_t)e * rows + n] = 0;
         return;
     }
+    // env-uniform: every lane of the group evaluates the same values
+    const int ov_new = live ? ((n_reached == N && mode == IC3_PP_MIXED) ? 1 : 0) : was_over;   // PP:273-274
+    const int t_new = s.tstep[e] + (live ? 1 : 0);
+    const bool restart = s.ar.max_steps > 0 && live && (ov_new || t_new >= s.ar.max_steps);
     float rew = 0.0f;
     if (live) {
         double rd = -0.05;  // TIMESTEP_PENALTY PP:256
@@ -122,23 +138,52 @@ __device__ __forceinline__ void pp_step_lanes(const PPState& s, const StepOut& o
             else rd = 0.0;                                                   // PP:267
         }
         rew = (float)rd;
-        const size_t li = (size_t)e * total + n;
-        s.loc_r[li] = r;
-        s.loc_c[li] = c;
-        s.reached[(size_t)e * N + n] = rch_new;
+        if (!restart) {                      // (a restarting env's state is written by lane 0 below)
+            const size_t li = (size_t)e * total + n;
+            s.loc_r[li] = r;
+            s.loc_c[li] = c;
+            s.reached[(size_t)e * N + n] = rch_new;
+        }
     }
     o.reward[(size_t)e * rows + n] = rew;
     if (o.alive_out) o.alive_out[(size_t)e * rows + n] = 1;
     if (o.comp_out) o.comp_out[(size_t)e * rows + n] = 0;
     if (n == 0) {
-        int ov = was_over;
-        if (live) {
-            ov = (n_reached == N && mode == IC3_PP_MIXED) ? 1 : 0;                 // PP:273-274
+        if (live && !restart) {
             if (mode != IC3_PP_COMPETITIVE) s.success[e] = (n_on == N) ? 1 : 0;    // PP:284-288
-            s.over[e] = ov;
-            s.tstep[e] += 1;
+            s.over[e] = ov_new;
+            s.tstep[e] = t_new;
         }
-        o.done[e] = ov;
+        o.done[e] = restart ? 1 : ov_new;
+        if (restart) {
+            // the finished episode's env.stat (PP:284-288) and length, then reset(): PP:146-175 on the next episode's key
+            if (mode != IC3_PP_COMPETITIVE) s.ar.acc_success[e] += (n_on == N) ? 1 : 0;
+            s.ar.acc_episodes[e] += 1;
+            s.ar.acc_steps[e] += t_new;
+            const uint32_t ep = (uint32_t)(s.ar.episode[e] + 1);
+            const uint32_t ncell = (uint32_t)(dim * dim);
+            int32_t* rr = s.loc_r + (size_t)e * total;
+            int32_t* cc = s.loc_c + (size_t)e * total;
+            int m = 0;
+            uint32_t d = 0;
+            while (m < total) {
+                const uint32_t k = scale24(philox_x24(s.ar.seed, s.ar.gid0 + (uint32_t)e, DOMAIN_PP_RESET, ep, 0u, d), ncell);
+                ++d;
+                const int kr = (int)(k / (uint32_t)dim), kc = (int)(k % (uint32_t)dim);
+                bool dup = false;
+                for (int j = 0; j < m; ++j) dup |= (rr[j] == kr) & (cc[j] == kc);
+                if (!dup) {
+                    rr[m] = kr;
+                    cc[m] = kc;
+                    ++m;
+                }
+            }
+            for (int i = 0; i < N; ++i) s.reached[(size_t)e * N + i] = 0;
+            s.over[e] = 0;
+            s.success[e] = 0;
+            s.ar.episode[e] = (int32_t)ep;
+            s.tstep[e] = 0;
+        }
     }
 }
 
@@ -185,6 +230,7 @@ struct TJState {
     int32_t *alive, *wait, *loc_r, *loc_c, *last_act, *route_loc, *route_id, *completed, *cars, *failed;
     const int32_t *over, *episode;
     int32_t* tstep;
+    AutoReset ar;
     const int32_t *route_off, *route_rc, *grid, *thr;
     int N, narrival, rpa;
     int h, w, v, vocab, outside, car_class, npath, hdr;
@@ -286,21 +332,45 @@ __device__ __forceinline__ void tj_step_lanes(const TJState& s, const StepOut& o
     if (crash) rd += -10.0;                                               // TJ:591
     rd = (double)alive * rd;                                              // TJ:594
     o.reward[i] = (float)rd;
-    s.alive[i] = alive;
-    s.wait[i] = wait;
-    s.loc_r[i] = r;
-    s.loc_c[i] = c;
-    s.last_act[i] = last_act;
-    s.route_loc[i] = rloc;
-    s.route_id[i] = rid;
-    s.completed[i] = completed;
     if (o.alive_out) o.alive_out[i] = alive;                              // info['alive_mask'] TJ:244
     if (o.comp_out) o.comp_out[i] = completed;                            // info['is_completed'] TJ:247
+    const bool restart = s.ar.max_steps > 0 && (int)t + 1 >= s.ar.max_steps;   // TJ episodes always run max_steps (Q12)
+    if (!restart) {
+        s.alive[i] = alive;
+        s.wait[i] = wait;
+        s.loc_r[i] = r;
+        s.loc_c[i] = c;
+        s.last_act[i] = last_act;
+        s.route_loc[i] = rloc;
+        s.route_id[i] = rid;
+        s.completed[i] = completed;
+    } else {                                                              // reset(): TJ:160-190
+        s.alive[i] = 0;
+        s.wait[i] = 0;
+        s.loc_r[i] = 0;
+        s.loc_c[i] = 0;
+        s.last_act[i] = 0;
+        s.route_loc[i] = -1;
+        s.route_id[i] = -1;
+        s.completed[i] = 0;
+    }
     if (n == 0) {
-        s.cars[e] = cars_now;
-        if (any_crash) s.failed[e] = 1;                                   // TJ:592
-        s.tstep[e] = (int32_t)t + 1;
-        o.done[e] = s.over[e];                                            // never set by TJ (quirk Q12)
+        if (!restart) {
+            s.cars[e] = cars_now;
+            if (any_crash) s.failed[e] = 1;                               // TJ:592
+            s.tstep[e] = (int32_t)t + 1;
+            o.done[e] = s.over[e];                                        // never set by TJ (quirk Q12)
+        } else {
+            const int failed = (any_crash || s.failed[e]) ? 1 : 0;
+            s.ar.acc_success[e] += 1 - failed;                            // stat['success'] = 1 - has_failed, TJ:249
+            s.ar.acc_episodes[e] += 1;
+            s.ar.acc_steps[e] += (int32_t)t + 1;
+            s.cars[e] = 0;
+            s.failed[e] = 0;
+            s.ar.episode[e] = (int32_t)ep + 1;
+            s.tstep[e] = 0;
+            o.done[e] = 1;
+        }
     }
 }
 

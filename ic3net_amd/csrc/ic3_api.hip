@@ -55,7 +55,8 @@ int fail(int code, const std::string& msg)
 
 // stats: sum over envs of a per-env int32 flag (success / has_failed) + live step counter
 __global__ __launch_bounds__(256) void stats_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ tstep,
-                                                    double* __restrict__ out, int E, int invert)
+                                                    const int32_t* __restrict__ acc, double* __restrict__ out, int E,
+                                                    int invert)
 {
     __shared__ double sh[2][4];
     double a = 0.0, b = 0.0;
@@ -63,6 +64,13 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t* __restrict__ 
         const int f = flag[e];
         a += (double)(invert ? 1 - f : f);
         b += (double)tstep[e];
+    }
+    if (blockIdx.x == 0) {   // sums over the episodes that ended inside step launches (auto-reset): acc[3][E]
+        for (int k = 0; k < 3; ++k) {
+            double v = 0.0;
+            for (int e = threadIdx.x; e < E; e += blockDim.x) v += (double)acc[(size_t)k * E + e];
+            atomicAdd(&out[2 + k], v);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_down(a, o);
@@ -82,21 +90,24 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t* __restrict__ 
 
 int env_stats(ic3_env* env, ic3_stats* out, hipStream_t s)
 {
-    IC3_HIP(hipMemsetAsync(env->d_stats, 0, 2 * sizeof(double), s));
+    IC3_HIP(hipMemsetAsync(env->d_stats, 0, 5 * sizeof(double), s));
     const int E = env->dims.E;
     int blocks = (E + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     const bool pp = env->kind == IC3_ENV_PP;
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, s, env->f(pp ? "success" : "has_failed"), env->f("t"),
-                       env->d_stats, E, pp ? 0 : 1);
+                       env->f("acc_success"), env->d_stats, E, pp ? 0 : 1);
     IC3_HIP(hipGetLastError());
-    double h[2];
+    double h[5];
     IC3_HIP(hipMemcpyAsync(h, env->d_stats, sizeof(h), hipMemcpyDeviceToHost, s));
     IC3_HIP(hipStreamSynchronize(s));
     out->success_sum = h[0];
     out->live_env_steps = (int64_t)h[1];
     out->add_rate = pp ? 0.0 : env->add_rate;
     out->episodes = env->resets * (int64_t)E;
+    out->auto_success_sum = h[2];
+    out->auto_episodes = (int64_t)h[3];
+    out->auto_env_steps = (int64_t)h[4];
     return 0;
 }
 
@@ -123,7 +134,7 @@ static int finish_create(ic3_env* env, int device)
     }
     IC3_HIP(hipMalloc(&env->d_err, sizeof(int32_t)));
     IC3_HIP(hipMemset(env->d_err, 0, sizeof(int32_t)));
-    IC3_HIP(hipMalloc(&env->d_stats, 2 * sizeof(double)));
+    IC3_HIP(hipMalloc(&env->d_stats, 5 * sizeof(double)));
     IC3_HIP(hipMalloc(&env->d_thr, sizeof(int32_t)));
     IC3_HIP(hipMemset(env->d_thr, 0, sizeof(int32_t)));
     return 0;
@@ -176,6 +187,7 @@ int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out)
     add_field(env, "success", E);
     add_field(env, "episode", E);
     add_field(env, "t", E);
+    for (const char* nm : { "acc_success", "acc_episodes", "acc_steps" }) add_field(env, nm, E);   // auto-reset sums
     int rc = finish_create(env, device);
     if (rc) { ic3_env_destroy(env); return rc; }
     *out = env;
@@ -225,6 +237,7 @@ int ic3_tj_create(const ic3_tj_cfg* cfg, int device, ic3_env** out)
     for (const char* nm : { "alive", "wait", "loc_r", "loc_c", "last_act", "route_loc", "route_id", "is_completed" })
         add_field(env, nm, E * N);
     for (const char* nm : { "cars_in_sys", "has_failed", "over", "episode", "t" }) add_field(env, nm, E);
+    for (const char* nm : { "acc_success", "acc_episodes", "acc_steps" }) add_field(env, nm, E);   // auto-reset sums
     rc = finish_create(env, device);
     if (rc) { ic3_env_destroy(env); return rc; }
     std::vector<int32_t> packed(env->h_route_rc.size() / 2);
@@ -302,8 +315,16 @@ int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
         rc = tj_reset(env, s);
     }
     if (rc) return rc;
+    IC3_HIP(hipMemsetAsync(env->f("acc_success"), 0, (size_t)3 * env->dims.E * sizeof(int32_t), s));   // 3 adjacent fields
     env->resets += 1;
     if (obs) return ic3_env_observe(env, obs, stream);
+    return 0;
+}
+
+int ic3_env_set_auto_reset(ic3_env* env, int max_steps)
+{
+    if (!env || max_steps < 0) return fail(-22, "ic3_env_set_auto_reset: bad arguments");
+    env->auto_max_steps = max_steps;
     return 0;
 }
 

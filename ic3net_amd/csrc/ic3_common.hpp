@@ -72,6 +72,7 @@ struct ic3_env {
     double* d_stats = nullptr; // small device scratch for ic3_env_stats
     int32_t* d_thr = nullptr;  // TJ: floor(add_rate * 2^24), device-resident so captured step graphs stay valid
     int64_t resets = 0;
+    int auto_max_steps = 0;    // ic3_env_set_auto_reset: > 0 = finished envs restart inside the step launch
     // Traffic-Junction constant tables (device + host copies)
     int32_t* d_grid = nullptr;       // [h*w] road ids
     int32_t* d_route_off = nullptr;  // [npath+1]

@@ -83,6 +83,7 @@ struct StepArgs {
     int ntiles;                 // all tiles; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     // env
     int E, N, EPT, G;
+    int auto_reset;             // env handle in auto-reset mode: an env with t == 0 starts an episode (h = c = 0, gate 0)
     int tile_words;             // int32 words of one env-descriptor block in LDS
     uint32_t seed, gid0;
     const int32_t* episode;
@@ -193,14 +194,19 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 
     // ---- S0: masks, per-env scale (comm.py:102-107,194-196; quirks Q21/Q23), entity positions --------------------
+    // auto-reset: an env whose t == 0 is at the start of an episode — no alive mask yet (everyone counts as alive,
+    // quirk Q21), gate 0 (no communication on the first step, quirk Q22), zero LSTM state (trainer.py:38-51)
+    auto fresh_env = [&](int el) { return KIND != 0 && a.auto_reset && a.tstep[e0 + el] == 0; };
     for (int r = tid; r < BM; r += NT) {
         float m = 0.f;
-        if (r < rows) m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
+        if (r < rows && !fresh_env(r / N))
+            m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
         sm[r] = m;
     }
     for (int el = tid; el < nenv; el += NT) {
         int n_alive = 0;
-        for (int j = 0; j < N; ++j) n_alive += a.alive_in ? a.alive_in[r0 + (size_t)el * N + j] : 1;
+        const bool fr = fresh_env(el);
+        for (int j = 0; j < N; ++j) n_alive += (a.alive_in && !fr) ? a.alive_in[r0 + (size_t)el * N + j] : 1;
         sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
     }
     int32_t* sr = tile;
@@ -214,7 +220,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * NT;
         const int row = idx / H4, c4 = idx - row * H4;
-        hv[i] = row < rows ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4) : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        hv[i] = (row < rows && !fresh_env(row / N)) ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4)
+                                                    : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
     // the zero stores are spread over the tile's whole lifetime (a PP-hard tile has 214 per thread): ~80 between the
     // phases in front of the gate loop, one per 8 MFMAs inside it — bunching them up (all in the loop, or front-loaded)
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                cold[rt][reg] = (lr < rows && !(a.dbg & 16)) ? a.c[(r0 + lr) * H + col] : 0.0f;
+                cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !fresh_env(lr / N)) ? a.c[(r0 + lr) * H + col] : 0.0f;
             }
         __syncthreads();   // every wave is done with the A tile
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
@@ -819,6 +826,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.tile_words = tile_words;
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;
+    a.auto_reset = env->auto_max_steps > 0;
     {   // pacing of the zero stores: per-thread count of a tile, 5 bursts in front + KB*4 slots in the loop
         static const int zb_env = getenv("IC3_PS_ZB") ? atoi(getenv("IC3_PS_ZB")) : -1;
         static const int zl_env = getenv("IC3_PS_ZL") ? atoi(getenv("IC3_PS_ZL")) : -1;

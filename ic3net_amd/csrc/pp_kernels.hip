@@ -375,6 +375,8 @@ PPState pp_state_of(const ic3_env* env)
     st.mode = c.mode;
     st.naction = c.stay ? 5 : 4;
     st.rows = env->dims.N;
+    st.ar = AutoReset{ env->auto_max_steps, env->f("episode"), env->f("acc_success"), env->f("acc_episodes"),
+                       env->f("acc_steps"), c.seed, c.env_id_offset };
     return st;
 }
 

@@ -314,6 +314,8 @@ TJState tj_state_of(const ic3_env* env)
     st.hdr = c.vocab_type ? 4 : 2;
     st.seed = c.seed;
     st.gid0 = c.env_id_offset;
+    st.ar = AutoReset{ env->auto_max_steps, env->f("episode"), env->f("acc_success"), env->f("acc_episodes"),
+                       env->f("acc_steps"), c.seed, c.env_id_offset };
     return st;
 }
 

@@ -65,12 +65,17 @@ class GymWrapper(object):
         'add_rate' (traffic_junction_env.py:249-250).  'steps_taken' is dropped like env_wrappers.py:104."""
         s = self.env.device_stats()
         stat = {k: v for k, v in self.env.stat.items() if k != 'steps_taken'}
+        # auto-reset mode: the episodes that ended inside step launches + the ones cut at the end of the window
+        success = s.success_sum + s.auto_success_sum
+        episodes = self.env.nenvs + s.auto_episodes
         if self.env.dims.kind == 1:
             if self.env.mode != 'competitive':
-                stat['success'] = s.success_sum
+                stat['success'] = success
         else:
-            stat['success'] = s.success_sum
-            stat['add_rate'] = s.add_rate * self.env.nenvs
+            stat['success'] = success
+            stat['add_rate'] = s.add_rate * episodes
+        if getattr(self.env, 'auto_max_steps', 0):
+            stat['_episodes'] = episodes                  # Trainer.run_batch counts these instead of nenvs
         return stat
 
     def display(self):

@@ -157,6 +157,13 @@ class _BatchedEnv(object):
                                                  ptr(dwt), ptr(dbias) if want_bias else None, ptr(work), stream()))
         return dwt, dbias
 
+    def set_auto_reset(self, max_steps):
+        """max_steps > 0: an env whose episode ends (episode_over, or max_steps steps played) starts its next episode
+        inside the same step launch (ic3_env_set_auto_reset); 0: lock-step episodes (finished envs freeze)."""
+        self._require()
+        check(_lib.lib().ic3_env_set_auto_reset(self._h, int(max_steps)))
+        self.auto_max_steps = int(max_steps)
+
     def device_stats(self):
         s = _lib.Stats()
         check(_lib.lib().ic3_env_stats(self._h, C.byref(s), stream()))
@@ -271,7 +278,7 @@ class PredatorPreyEnv(_BatchedEnv):
     def _fields(self):
         E, N, T = self.nenvs, self.npredator, self.npredator + self.nprey
         return [("loc_r", (E, T)), ("loc_c", (E, T)), ("reached", (E, N)), ("over", (E,)), ("success", (E,)),
-                ("episode", (E,)), ("t", (E,))]
+                ("episode", (E,)), ("t", (E,)), ("acc_success", (E,)), ("acc_episodes", (E,)), ("acc_steps", (E,))]
 
     def render(self, mode='human', close=False, env_index=0):
         """Debug view of ONE env from a state readback (the reference draws the same grid with curses,
@@ -365,7 +372,7 @@ class TrafficJunctionEnv(_BatchedEnv):
     def _fields(self):
         E, N = self.nenvs, self.ncar
         per_agent = ["alive", "wait", "loc_r", "loc_c", "last_act", "route_loc", "route_id", "is_completed"]
-        per_env = ["cars_in_sys", "has_failed", "over", "episode", "t"]
+        per_env = ["cars_in_sys", "has_failed", "over", "episode", "t", "acc_success", "acc_episodes", "acc_steps"]
         return [(n, (E, N)) for n in per_agent] + [(n, (E,)) for n in per_env]
 
     @property

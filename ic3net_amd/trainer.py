@@ -68,8 +68,17 @@ class Trainer(object):
                 break                                               # trainer.py:107-108 (every env is done)
         return self.end_episode()
 
+    def _auto_reset(self):
+        """args.auto_reset: an env that finishes restarts inside the step launch and keeps producing transitions
+        (the reference's `while: get_episode()` collection, trainer.py:227-242) instead of idling until the lock-step
+        reset; one get_episode() call is then a WINDOW of max_steps steps over E streams of consecutive episodes."""
+        return bool(getattr(self.args, 'auto_reset', False))
+
     def begin_episode(self, epoch):
         args = self.args
+        raw0 = getattr(self.env, 'env', None)
+        if hasattr(raw0, 'set_auto_reset') and getattr(raw0, 'auto_max_steps', 0) != (args.max_steps if self._auto_reset() else 0):
+            raw0.set_auto_reset(args.max_steps if self._auto_reset() else 0)
         if 'epoch' in signature(self.env.reset).parameters:        # trainer.py:28-32
             state = self.env.reset(epoch)
         else:
@@ -185,6 +194,10 @@ class Trainer(object):
                 if fuse_draw and self.clock.env is raw and getattr(self.policy_net, 'mega_ok', None) is not None \
                         and self.policy_net.mega_ok(raw, [state, self._prev_hid]):
                     return self._step_body_mega(t, observe)
+                if self._auto_reset():
+                    raise NotImplementedError("args.auto_reset needs the one-launch rollout step (ic3_policy_step: "
+                                              "recurrent CommNet/IC3Net, hid_size 64/128/256, no autograd): per-env "
+                                              "episode starts are handled inside that launch")
                 if fuse_draw:
                     self.policy_net.sample_into = (self.clock.env, buf['action'][t])
                 try:
@@ -318,11 +331,12 @@ class Trainer(object):
         done = buf['done'][:n].to(torch.bool)                      # (n, E) episode_over after step t
         not_done = (~done).to(torch.float32)
         live = torch.ones((n, E), dtype=torch.float32, device=dev) # live[t] = env still running when step t starts
-        if n > 1:
-            live[1:] = torch.cumprod(not_done[:-1], dim=0)
+        if n > 1 and not self._auto_reset():                       # (auto-reset: every slot is a real transition; `done`
+            live[1:] = torch.cumprod(not_done[:-1], dim=0)         #  already includes the max_steps cut of each episode)
         done_t = done.clone()
         if n == args.max_steps:
-            done_t[n - 1] = True                                   # trainer.py:90 forced done at the last step
+            done_t[n - 1] = True                                   # trainer.py:90 forced done at the last step (auto-reset:
+                                                                   # the window's last slot cuts the running episodes)
         reward = buf['reward'][:n]
         if self._use_graph():
             # static buffers are rewritten by the next episode's replays: hand out copies (action_out / value of a
@@ -355,6 +369,8 @@ class Trainer(object):
         for t in range(n):
             cur_state, action_out, value, next_state = self._step_out[t]
             misc = {'alive_mask': alive_mask[t], 'live': live[t]}
+            if self._auto_reset():
+                misc['done'] = done_t[t]                           # (E,) this transition ends its env's episode
             episode.append(Transition(cur_state, action[t], action_out, value, episode_mask[t], episode_mini_mask[t],
                                       next_state, reward[t], misc))
         if hasattr(self.env, 'reward_terminal'):                   # trainer.py:112-121 (zeros for PP/TJ)
@@ -365,7 +381,15 @@ class Trainer(object):
             if enemy:
                 stat['enemy_reward'] = stat['enemy_reward'] + rts[args.nfriendly:]
         if hasattr(self.env, 'get_stat'):                          # trainer.py:124-125
-            merge_stat(self.env.get_stat(), stat)
+            env_stat = self.env.get_stat()
+            if '_episodes' in env_stat:
+                # auto-reset: an env that restarted on the window's last slot holds a zero-length episode: not counted
+                eps = float(env_stat['_episodes'])
+                n_zero = float(done[n - 1].sum().item())
+                if 'add_rate' in env_stat and eps > 0:
+                    env_stat['add_rate'] = env_stat['add_rate'] * (eps - n_zero) / eps
+                env_stat['_episodes'] = eps - n_zero
+            merge_stat(env_stat, stat)
         self._live = live[-1] * not_done[-1]
         self._episodes_played += 1
         return (episode, stat)
@@ -381,8 +405,9 @@ class Trainer(object):
                 self.last_step = True
             episode, episode_stat = self.get_episode(epoch)
             nsteps += episode_stat['num_steps']
+            n_ep = episode_stat.pop('_episodes', E)               # auto-reset: E streams can hold more than E episodes
             merge_stat(episode_stat, self.stats)
-            self.stats['num_episodes'] += E
+            self.stats['num_episodes'] += n_ep
             batch += episode
         self.last_step = False
         self.stats['num_steps'] = nsteps

@@ -89,7 +89,11 @@ typedef struct {
     double success_sum;    /* PP: sum_e stat['success'] (PP:284-288); TJ: sum_e (1 - has_failed) (TJ:249) */
     double add_rate;       /* TJ stat['add_rate'] (TJ:250); 0 for PP */
     int64_t episodes;      /* number of resets so far * E */
-    int64_t live_env_steps;/* env-steps actually simulated (not-yet-done envs) since the last reset */
+    int64_t live_env_steps;/* env-steps actually simulated (not-yet-done envs) in the episodes now running */
+    /* auto-reset mode (ic3_env_set_auto_reset): sums over the episodes that ENDED inside step launches since reset() */
+    double auto_success_sum;  /* their stat['success'] */
+    int64_t auto_episodes;    /* how many */
+    int64_t auto_env_steps;   /* their lengths */
 } ic3_stats;
 
 int ic3_version(void);
@@ -106,6 +110,17 @@ int ic3_env_dims(const ic3_env* env, ic3_dims* out);
 /* Env.reset([epoch]) for all E envs: predator_prey_env.py:146-168 / traffic_junction_env.py:160-204.
  * epoch < 0 means "no epoch" (reset() without argument).  obs may be NULL. */
 int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream);
+
+/* Auto-reset: with max_steps > 0 an env whose episode ends at a step (episode_over, or max_steps steps played — the
+ * trainer's forced done, trainer.py:90) starts its next episode inside the same step launch: episode += 1, t = 0, a
+ * fresh state on the new episode's Philox key, exactly what a reset() would have drawn for that episode.  This is the
+ * reference's collection loop (every finished episode is followed at once by the next one, trainer.py:107-108,
+ * 227-242) without idling finished envs until a lock-step reset.  `done` then reports every episode end (1 also at the
+ * max_steps cut); reward / alive / is_completed of that step belong to the finished episode, the next observation /
+ * policy input to the new one; ic3_stats.auto_* accumulate the finished episodes' statistics.  ic3_policy_step in this
+ * mode treats an env whose t == 0 as an episode start (h = c = 0, no alive mask, gate 0: trainer.py:38-46, quirks
+ * Q21/Q22).  max_steps = 0 (default) restores lock-step episodes (finished envs freeze until ic3_env_reset). */
+int ic3_env_set_auto_reset(ic3_env* env, int max_steps);
 
 /* Env.step(action) for all E envs: predator_prey_env.py:112-144 / traffic_junction_env.py:206-252.
  *   actions       [E][N] int32   the env-action head only (GymWrapper.step drops the talk head, env_wrappers.py:76-77)
