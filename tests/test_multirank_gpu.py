@@ -51,7 +51,9 @@ def test_bench_two_ranks_share_one_device():
 
 PP = ['--env_name', 'predator_prey', '--nagents', '3', '--nprocesses', '1', '--num_epochs', '2', '--epoch_size', '1',
       '--hid_size', '64', '--detach_gap', '10', '--lrate', '0.001', '--dim', '5', '--max_steps', '20', '--ic3net',
-      '--vision', '0', '--recurrent', '--dist_backend', 'gloo', '--device', '0']
+      '--vision', '0', '--recurrent', '--dist_backend', 'gloo', '--device', '0',
+      '--batch_size', '100']      # one get_episode() per update on every rank (batch_size counts per process, like the
+                                  # reference's per-worker batch_size): 2 x 8 envs and 1 x 16 envs then play the same episodes
 
 
 def _load(prefix, rank):
