@@ -79,8 +79,7 @@ struct StepArgs {
     int32_t* action;            // [nheads][R]
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
     int obs_dim;                // floats per observation row
-    int n_full, EPTh;           // tiles [0, n_full) hold EPT envs; the rest hold EPTh envs (<= 32 rows: one row tile of MFMAs)
-    int ntiles;                 // all tiles; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    int ntiles;                 // tiles; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     // env
     int E, N, EPT, G;
     int auto_reset;             // env handle in auto-reset mode: an env with t == 0 starts an episode (h = c = 0, gate 0)
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 
     if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    int tid = threadIdx.x;      // (re-derived from an opaque value inside the tile loop, see `tz`)
+    const int tid = threadIdx.x;
     const int N = a.N;
     const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
     const int total = a.pp.Np + a.pp.nprey;
@@ -144,23 +143,15 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     };
-#pragma unroll 1
-    for (int tile_id = blockIdx.x; tile_id < a.ntiles; tile_id += gridDim.x) {
-    // an opaque zero, re-made every iteration and added to the addresses of everything that does not depend on the
-    // tile (weights, biases): keeps the compiler from hoisting those loads out of the tile loop, where they would stay
-    // live across all phases (the first persistent version spilled ~250 registers that way)
-    int tz;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
-    tid = (int)threadIdx.x + tz;   // every per-lane index below is re-derived per tile (nothing to hoist and keep live)
+    // one workgroup per tile: the hardware dispatcher balances the tiles over the CUs (a resident set of workgroups
+    // walking a strided tile list was measured slower: 350 vs 327 us, and needed tricks against hoisted loads)
+    const int tile_id = blockIdx.x;
+    constexpr int tz = 0;
     const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li;
-    // full tiles first; the envs left over after the last full round of all resident workgroups go out as HALF tiles
-    // (<= 32 rows, one row tile of MFMAs: half the matrix time) so that the tail round costs half instead of a full one
-    const bool half = tile_id >= a.n_full;
-    const int e0 = half ? a.n_full * a.EPT + (tile_id - a.n_full) * a.EPTh : tile_id * a.EPT;
-    const int nenv = min(half ? a.EPTh : a.EPT, a.E - e0);
-    const int rows = nenv * N;                                   // valid rows of this tile (<= 64; <= 32 in a half tile)
-    const bool two = rows > 32;                                  // second 32-row MFMA tile in use (workgroup-uniform)
+    const int e0 = tile_id * a.EPT;
+    const int nenv = min(a.EPT, a.E - e0);
+    const int rows = nenv * N;                                   // valid rows of this tile (<= 64)
     const size_t r0 = (size_t)e0 * N;
 
     // ---- dense observation of the state this step acts on (the `state` the reference hands to policy_net,
@@ -196,16 +187,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // ---- S0: masks, per-env scale (comm.py:102-107,194-196; quirks Q21/Q23), entity positions --------------------
     // auto-reset: an env whose t == 0 is at the start of an episode — no alive mask yet (everyone counts as alive,
     // quirk Q21), gate 0 (no communication on the first step, quirk Q22), zero LSTM state (trainer.py:38-51)
-    auto fresh_env = [&](int el) { return KIND != 0 && a.auto_reset && a.tstep[e0 + el] == 0; };
+    const bool autor = (KIND != 0) && a.auto_reset;              // workgroup-uniform
+    auto fresh_row = [&](int row) {                              // only called when autor
+        const int el = (int)(((float)row + 0.5f) * (1.0f / (float)N));   // row / N, exact for row < 64
+        return a.tstep[e0 + el] == 0;
+    };
     for (int r = tid; r < BM; r += NT) {
         float m = 0.f;
-        if (r < rows && !fresh_env(r / N))
+        if (r < rows && !(autor && fresh_row(r)))
             m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
         sm[r] = m;
     }
     for (int el = tid; el < nenv; el += NT) {
         int n_alive = 0;
-        const bool fr = fresh_env(el);
+        const bool fr = autor && a.tstep[e0 + el] == 0;
         for (int j = 0; j < N; ++j) n_alive += (a.alive_in && !fr) ? a.alive_in[r0 + (size_t)el * N + j] : 1;
         sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
     }
@@ -220,8 +215,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * NT;
         const int row = idx / H4, c4 = idx - row * H4;
-        hv[i] = (row < rows && !fresh_env(row / N)) ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4)
-                                                    : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        hv[i] = (row < rows && !(autor && fresh_row(row))) ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4)
+                                                           : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
     // the zero stores are spread over the tile's whole lifetime (a PP-hard tile has 214 per thread): ~80 between the
     // phases in front of the gate loop, one per 8 MFMAs inside it — bunching them up (all in the loop, or front-loaded)
@@ -329,10 +324,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         };
-        if (!(a.dbg & 2)) {
-            if (two) cprod(std::true_type{});
-            else cprod(std::false_type{});
-        }
+        if (!(a.dbg & 2)) cprod(std::true_type{});
         mfma_settle();
         __syncthreads();   // every wave has read the comm tile
     }
@@ -409,8 +401,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     };
     static_assert(KB % 2 == 0, "K/8 must be even");
-    if (two) gate_loop(std::true_type{});
-    else gate_loop(std::false_type{});
+    gate_loop(std::true_type{});
 
     mfma_settle();
     if (obs_here)
@@ -425,7 +416,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !fresh_env(lr / N)) ? a.c[(r0 + lr) * H + col] : 0.0f;
+                cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !(autor && fresh_row(lr))) ? a.c[(r0 + lr) * H + col] : 0.0f;
             }
         __syncthreads();   // every wave is done with the A tile
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
@@ -434,7 +425,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            if (rt == 1 && !two) break;          // half tile: rows 32..63 are padding (their h' is never read)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
@@ -451,7 +441,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     }
     __syncthreads();
-    if (a.dbg & 8) continue;
+    if (a.dbg & 8) return;
 
     // ---- S10: heads + value head (comm.py:228,239): NW lanes per row, 32 columns each ---------------------------------
     // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
@@ -581,8 +571,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     }
-    __syncthreads();   // LDS (tile, masks, A tile) is reused by the next tile
-    }   // tiles
 }
 
 // Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
@@ -612,27 +600,12 @@ static int resident_workgroups(int H)
     return cus * (H <= 128 ? 2 : 1);
 }
 
-// Tile plan (a.E, a.N, a.EPT set): full tiles of EPT envs for every COMPLETE round of the resident workgroups, then
-// the remaining envs as half tiles of floor(32/N) envs when they fit in one round (each costs half the matrix time);
-// problems smaller than one round keep full tiles.  Opt-in (IC3_PS_HALF=1): on PP-hard / TJ-hard at 8192 envs the step
-// time did not move.
+// Tile plan (a.E, a.N, a.EPT set): tiles of EPT whole envs.  (A tail of half-size tiles — one 32-row MFMA tile each — for
+// the envs left over after the last full round of resident workgroups was tried: no change in step time, removed.)
 static int plan_tiles(StepArgs& a, int H)
 {
-    static const int use_half = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : 0;   // measured: no gain (0.500 vs 0.493 ms), off
-    const int slots = resident_workgroups(H);
-    const int all_full = (a.E + a.EPT - 1) / a.EPT;
-    a.EPTh = 32 / a.N;
-    a.n_full = all_full;
-    a.ntiles = all_full;
-    if (use_half && a.EPTh >= 1 && a.E / a.EPT >= slots) {
-        const int n_full = (a.E / a.EPT) / slots * slots;
-        const int rem = a.E - n_full * a.EPT;
-        const int n_half = (rem + a.EPTh - 1) / a.EPTh;
-        if (rem > 0 && n_half <= slots) {
-            a.n_full = n_full;
-            a.ntiles = n_full + n_half;
-        }
-    }
+    (void)H;
+    a.ntiles = (a.E + a.EPT - 1) / a.EPT;
     return a.ntiles;
 }
 
