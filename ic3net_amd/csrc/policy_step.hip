@@ -65,6 +65,7 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
+    int zmode;                  // cache policy of the zero stores
     int zb, zl;                 // zero-store pacing: per burst in front of the gate loop, per 8 MFMAs inside it
     int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
                                 // between the two co-resident workgroups of a CU; speed only)
@@ -168,8 +169,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     const int onb = obs_here ? (oL - ohead) >> 2 : 0;            // float4s of the body
     ps_f32x4* const obody = reinterpret_cast<ps_f32x4*>(a.obs + ob0 + ohead);
     int zq = tid - (int)(((ob0 + ohead) >> 2) & 63);             // 1 KiB-aligned wave stores (see pp_obs_kernel)
+    // cache policy of the zero stores (a.zmode & 3, IC3_PS_ZMODE): 0 plain, 1 sc1 (write-through), 2 nt (default),
+    // 3 sc0 sc1.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights every tile
+    // streams from there: with non-temporal stores the kernel takes 0.43 ms instead of 0.52 (plain, sc1: no change).
+    // (+4: h' / c' stores nt; +8: h / c loads nt — experiments)
     auto zero_store = [&]() {
-        if (zq >= 0 && zq < onb) obody[zq] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        if (zq >= 0 && zq < onb) {
+            ps_f32x4* ptr = obody + zq;
+            const ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
+            const int zm = a.zmode & 3;
+            if (zm == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(zv) : "memory");
+            else if (zm == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(zv) : "memory");
+            else if (zm == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(zv) : "memory");
+            else *ptr = zv;
+        }
         zq += NT;
     };
     auto zero_burst = [&](int n) {
@@ -215,7 +228,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * NT;
         const int row = idx / H4, c4 = idx - row * H4;
-        hv[i] = (row < rows && !(autor && fresh_row(row))) ? *reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4)
+        const ps_f32x4* hp = reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4);
+        hv[i] = (row < rows && !(autor && fresh_row(row))) ? ((a.zmode & 8) ? __builtin_nontemporal_load(hp) : *hp)
                                                            : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
     // the zero stores are spread over the tile's whole lifetime (a PP-hard tile has 214 per thread): ~80 between the
@@ -416,7 +430,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !(autor && fresh_row(lr))) ? a.c[(r0 + lr) * H + col] : 0.0f;
+                const float* cp = a.c + (r0 + lr) * H + col;
+                cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !(autor && fresh_row(lr)))
+                                    ? ((a.zmode & 8) ? __builtin_nontemporal_load(cp) : *cp) : 0.0f;
             }
         __syncthreads();   // every wave is done with the A tile
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
@@ -433,8 +449,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
                 const float h1 = fast_sigmoid(go) * fast_tanh(c1);
                 if (lr < rows && !(a.dbg & 16)) {
-                    a.c[(r0 + lr) * H + col] = c1;
-                    a.h[(r0 + lr) * H + col] = h1;
+                    if (a.zmode & 4) {
+                        __builtin_nontemporal_store(c1, a.c + (r0 + lr) * H + col);
+                        __builtin_nontemporal_store(h1, a.h + (r0 + lr) * H + col);
+                    } else {
+                        a.c[(r0 + lr) * H + col] = c1;
+                        a.h[(r0 + lr) * H + col] = h1;
+                    }
                 }
                 As[lr * LDA + H + col] = h1;
             }
@@ -801,6 +822,8 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.obs_dim = env->dims.obs_dim;
     a.auto_reset = env->auto_max_steps > 0;
     {   // pacing of the zero stores: per-thread count of a tile, 5 bursts in front + KB*4 slots in the loop
+        static const int zmode_env = getenv("IC3_PS_ZMODE") ? atoi(getenv("IC3_PS_ZMODE")) : 2;   // nt: measured 0.43 vs 0.52 ms
+        a.zmode = zmode_env;
         static const int zb_env = getenv("IC3_PS_ZB") ? atoi(getenv("IC3_PS_ZB")) : -1;
         static const int zl_env = getenv("IC3_PS_ZL") ? atoi(getenv("IC3_PS_ZL")) : -1;
         const long long per_thread = ((long long)a.EPT * a.N * a.obs_dim / 4 + 2 * H - 1) / (2 * H) + 1;
