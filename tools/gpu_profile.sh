@@ -1,19 +1,36 @@
 #!/bin/bash
-# Profiles of the default bench command (round 2): kernel trace + stats, then the two HBM PMC passes, into gpurun_out/prof
+# Round-2 evidence run: smoke, the whole GPU suite, the default bench command with its kernel trace / stats and the two
+# HBM PMC passes (separate runs, as the microarch guide prescribes), the other workloads, the separate / chain variants.
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02prof
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_multirank_gpu.py -q -p no:cacheprovider > $O/tests_multirank.log 2>&1
+timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" > $O/summary.txt
+timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests_gpu.log 2>&1; echo "gpu suite rc=$?" >> $O/summary.txt
 B="python bench.py --steps 160 --warmup 16 --no-cpu-baseline"
-timeout 600 python bench.py --steps 160 --warmup 16 > $O/bench_default.json 2> $O/bench_default.err
+timeout 600 python bench.py --steps 160 --warmup 16 > $O/bench_pp_hard.json 2> $O/bench_pp_hard.err
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_pp_hard_driver_args.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- $B > $O/pmc_w.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- $B > $O/pmc_f.log 2>&1
 for w in tj_hard tj_medium pp_easy; do timeout 300 $B --workload $w > $O/bench_$w.json 2> /dev/null; done
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sep -- $B --fused-obs 0 > $O/kt_sep.log 2>&1
-timeout 300 $B --fused-obs 0 > $O/bench_separate.json 2>/dev/null
-timeout 300 $B --mega 0 --time-kernels 0 > $O/bench_chain.json 2>/dev/null
+timeout 300 $B --workload pp_scaled --nenvs 2048 --steps 20 --warmup 4 > $O/bench_pp_scaled_e2048.json 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_tj_hard -- $B --workload tj_hard > $O/kt_tj_hard.log 2>&1
+timeout 300 $B --fused-obs 0 > $O/bench_pp_hard_separate_obs.json 2>/dev/null
+timeout 300 $B --fused-obs 0 --overlap-obs 1 --time-kernels 0 > $O/bench_pp_hard_overlap_obs.json 2>/dev/null
+timeout 300 $B --mega 0 --time-kernels 0 > $O/bench_pp_hard_chain_r01.json 2>/dev/null
+timeout 300 $B --time-kernels 0 > $O/bench_pp_hard_graph.json 2>/dev/null
+IC3_PS_ZMODE=0 timeout 300 $B > $O/bench_pp_hard_plain_stores.json 2>/dev/null
 IC3_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d $O/roctx -- python bench.py --steps 8 --warmup 2 --nenvs 1024 --no-cpu-baseline > $O/roctx.log 2>&1
-find $O -name "*.csv" | head -40; du -sh $O; tail -3 $O/tests_multirank.log; cat $O/bench_default.json
+./tools/exp/ws_probe > $O/ws_probe.txt 2>&1
+cat $O/summary.txt; tail -n 2 $O/smoke.log; tail -n 1 $O/tests_gpu.log; du -sh $O
+for f in $O/bench_*.json; do python - $f <<'PY'
+import json,sys,os
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r=d.get('roofline') or {}; m=d.get('roofline_mfma') or {}
+    print("%-40s %.4f ms/step %.1f M/s | hbm %.4f ms %.0f GB/s frac %.3f | mfma %s TF" % (os.path.basename(sys.argv[1]), d['ms_per_step'], d['value']/1e6, r.get('avg_launch_ms',0), r.get('achieved',0), r.get('frac',0), m.get('achieved')))
+except Exception as e: print(sys.argv[1],'FAILED',e)
+PY
+done

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 def time_steps(workload, nenvs, steps, mega):
     tr, a = bench.build_trainer(workload, nenvs, 0, 0, 0)
     a.mega_policy = bool(mega)
-    a.dense_obs = False                       # obs=NULL: only the policy + sampling + step launches
+    a.dense_obs = os.environ.get('IC3_MB_OBS', '0') == '1'   # default obs=NULL: only the policy + sampling + step work
     T = a.max_steps
     tr.begin_episode(0)
     for t in range(8):                        # warm-up (also fills the packed-weight cache)
