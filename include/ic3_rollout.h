@@ -279,8 +279,15 @@ int ic3_env_sample_actions(const ic3_env* env, const float* logp, int ld, int A,
  *   comm_in    [E][N] int32 or NULL   info['comm_action'] (gate sampled at t-1, zeros at t = 0, quirk Q22; NULL = all talk)
  *   out        [E*N][OT]  log_softmax of every head, then the value
  *   action     [nheads][E][N] int32   the draws of every head
- *   obs        [E][N][obs_dim] or NULL   next_state, assembled by ic3_env_observe after the step when non-NULL
+ *   obs        [E][N][obs_dim] or NULL   the dense observation of the state this call ACTS ON — the `state` the reference
+ *              hands to policy_net at this step (trainer.py:49), i.e. what ic3_env_observe would return BEFORE the call —
+ *              written by the same launch: the tile's slice is zero-filled by non-temporal stores issued between the
+ *              MFMAs and its few non-zero entries are patched in at the end (bit-identical to ic3_env_observe).  The
+ *              observation of the NEW state is what the next call writes (or ic3_env_observe).  When the descriptors do
+ *              not fit in LDS the library launches ic3_env_observe in front of the kernel instead: same contents.
  *   reward / done / alive / is_completed   as ic3_env_step
+ * In auto-reset mode (ic3_env_set_auto_reset) an env whose t == 0 is at an episode start: its h, c count as zero, its
+ * alive mask as absent and its gate as 0, whatever the arguments hold (trainer.py:38-51).
  * Returns -ENOSYS when ic3_policy_step_supported(env, H) == 0 (H not in {64,128,256}, > 64 agents, or an env tile
  * that does not fit in LDS): use the separate entry points then. */
 typedef struct {
