@@ -329,11 +329,11 @@ def main():
             a.fused_obs = bool(o.fused_obs)
             raw_env = trainer.env.env
             raw_env.obs_timer = []
-    t_in_ep = run(o.warmup, 0)
     torch.cuda.synchronize()
+    backend = None
     if world > 1:
         # RCCL is used only for the timing barrier / max-reduce (no collective on the rollout path); it is brought
-        # up after the untimed warm-up so that graph capture never runs next to a communicator's helper threads.
+        # up after the untimed graph captures so that a capture never runs next to a communicator's helper threads.
         if 'IC3_BENCH_DEVICE' in os.environ:       # test hook (several ranks on one GPU): RCCL refuses duplicate devices
             dist.init_process_group(backend='gloo')
             dist.barrier()
@@ -350,17 +350,24 @@ def main():
                 dist.init_process_group(backend='gloo')
                 dist.barrier()
                 backend = 'gloo'
-    torch.cuda.synchronize()
-    raw_env.obs_timer = []
     mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use
     if o.time_kernels and mega_live:
         raw_env.step_timer = []               # both launches of a step are event-timed and issued eagerly
-    live0 = live_done[0] + raw_env.device_stats().live_env_steps      # finished episodes + the running episode so far
     # A full CPython GC pass over this process's heap (torch + numpy + the CPU-baseline imports) costs 35-80 ms —
     # as much as the whole timed region — and where it lands depends on allocation counts, not on the work.
-    # Collect now and move the survivors to the permanent generation, as timeit-style harnesses do.
+    # Collect now and move the survivors to the permanent generation, as timeit-style harnesses do.  All of this host
+    # work sits BEFORE the W warm-up steps: the timed region follows them directly (an idle GPU clocks down, and a
+    # 10 ms timed region would start on the ramp).
     gc.collect()
     gc.freeze()
+    t_in_ep = run(o.warmup, 0)                # W untimed warm-up steps, in the measured configuration
+    raw_env.obs_timer = []
+    if raw_env.step_timer is not None:
+        raw_env.step_timer = []
+    live0 = live_done[0] + raw_env.device_stats().live_env_steps      # (synchronises) finished episodes + the running one
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     t_in_ep = run(o.steps, t_in_ep)
     host_dt = time.perf_counter() - t0        # host-side enqueue time (diagnostic: host- vs GPU-bound)

@@ -70,7 +70,7 @@ struct StepArgs {
     int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
                                 // between the two co-resident workgroups of a CU; speed only)
     int dbg;                    // timing ablations (IC3_PS_DEBUG bit mask; results are wrong when set): 1 gate MFMA loop,
-                                // 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic
+                                // 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic, 32 obs patch pass
     // recurrent state, masks, outputs
     float* h;                   // [R][H] in place
     float* c;                   // [R][H] in place
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     }
-    if (obs_here) {
+    if (obs_here && !(a.dbg & 32)) {
         // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
         // first non-zero entry goes out to the same lines
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -175,8 +175,11 @@ class _BatchedEnv(object):
     # --- common reset / step ---------------------------------------------------------------------
     def _reset(self, epoch):
         self._require()
+        # skip_reset_obs (set by the Trainer when every rollout step writes the observation of the state it acts on —
+        # ic3_policy_step with obs): the obs launch of reset() would only be overwritten by step 0's
+        obs = None if getattr(self, 'skip_reset_obs', False) else self._obs
         with torch.cuda.device(self.device):
-            check(_lib.lib().ic3_env_reset(self._h, -1 if epoch is None else int(epoch), ptr(self._obs), stream()))
+            check(_lib.lib().ic3_env_reset(self._h, -1 if epoch is None else int(epoch), ptr(obs), stream()))
         self.stat = dict()
         self.episode_over = False
         return self._obs

@@ -79,6 +79,9 @@ class Trainer(object):
         raw0 = getattr(self.env, 'env', None)
         if hasattr(raw0, 'set_auto_reset') and getattr(raw0, 'auto_max_steps', 0) != (args.max_steps if self._auto_reset() else 0):
             raw0.set_auto_reset(args.max_steps if self._auto_reset() else 0)
+        if raw0 is not None and hasattr(raw0, '_h'):
+            raw0.skip_reset_obs = bool(getattr(self, '_mega_last', False) and self._fused_obs() and self._dense_obs()
+                                       and not getattr(args, 'store_states', False))
         if 'epoch' in signature(self.env.reset).parameters:        # trainer.py:28-32
             state = self.env.reset(epoch)
         else:
