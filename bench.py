@@ -311,6 +311,32 @@ def main():
                 t_in_ep = 0
         return t_in_ep
 
+    # Host-side set-up that idles the GPU goes FIRST (an idle MI355X clocks down and needs several ms of work to come
+    # back: a 10 ms timed region right behind an idle gap would be measured on the ramp): the full CPython GC pass
+    # (35-80 ms over torch + numpy + the CPU-baseline imports; survivors are frozen so that no collection lands in the
+    # timed region), then RCCL bring-up (only the timing barrier / max-reduce use it — no collective on the rollout
+    # path).  The untimed eager + capture episodes below then double as the warm-up of the clocks, and the W warm-up
+    # steps and the timed region follow them without a gap.
+    gc.collect()
+    gc.freeze()
+    backend = None
+    if world > 1:
+        if 'IC3_BENCH_DEVICE' in os.environ:       # test hook (several ranks on one GPU): RCCL refuses duplicate devices
+            dist.init_process_group(backend='gloo')
+            dist.barrier()
+            backend = 'gloo'
+        else:
+            try:
+                dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+                dist.barrier()
+                backend = 'nccl'
+            except Exception as exc:                   # timing barrier only: gloo is an acceptable stand-in
+                sys.stderr.write("bench.py: RCCL bring-up failed (%r); using gloo for the timing barrier\n" % (exc,))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend='gloo')
+                dist.barrier()
+                backend = 'gloo'
     raw_env.obs_timer = []                    # event-time the obs launch from the start (graphs are captured in this mode)
     if o.tune_gemm:                           # untimed: every GEMM shape is met (and tuned) in one eager episode
         saved_graph, a.hip_graph = a.hip_graph, False
@@ -329,37 +355,12 @@ def main():
             a.fused_obs = bool(o.fused_obs)
             raw_env = trainer.env.env
             raw_env.obs_timer = []
-    torch.cuda.synchronize()
-    backend = None
-    if world > 1:
-        # RCCL is used only for the timing barrier / max-reduce (no collective on the rollout path); it is brought
-        # up after the untimed graph captures so that a capture never runs next to a communicator's helper threads.
-        if 'IC3_BENCH_DEVICE' in os.environ:       # test hook (several ranks on one GPU): RCCL refuses duplicate devices
-            dist.init_process_group(backend='gloo')
-            dist.barrier()
-            backend = 'gloo'
-        else:
-            try:
-                dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-                dist.barrier()
-                backend = 'nccl'
-            except Exception as exc:                   # timing barrier only: gloo is an acceptable stand-in
-                sys.stderr.write("bench.py: RCCL bring-up failed (%r); using gloo for the timing barrier\n" % (exc,))
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend='gloo')
-                dist.barrier()
-                backend = 'gloo'
+    else:
+        run(T, 0)                             # no graphs: one untimed eager episode (first-use set-up, clocks)
     mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use
     if o.time_kernels and mega_live:
         raw_env.step_timer = []               # both launches of a step are event-timed and issued eagerly
-    # A full CPython GC pass over this process's heap (torch + numpy + the CPU-baseline imports) costs 35-80 ms —
-    # as much as the whole timed region — and where it lands depends on allocation counts, not on the work.
-    # Collect now and move the survivors to the permanent generation, as timeit-style harnesses do.  All of this host
-    # work sits BEFORE the W warm-up steps: the timed region follows them directly (an idle GPU clocks down, and a
-    # 10 ms timed region would start on the ramp).
-    gc.collect()
-    gc.freeze()
+    gc.disable()                              # (like timeit: no collector pause in the warm-up + timed steps)
     t_in_ep = run(o.warmup, 0)                # W untimed warm-up steps, in the measured configuration
     raw_env.obs_timer = []
     if raw_env.step_timer is not None:
@@ -371,6 +372,7 @@ def main():
     t0 = time.perf_counter()
     t_in_ep = run(o.steps, t_in_ep)
     host_dt = time.perf_counter() - t0        # host-side enqueue time (diagnostic: host- vs GPU-bound)
+    gc.enable()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -208,14 +208,25 @@ __device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32
                                                   int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
                                                   const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table)
 {
+    // The entity's own cell (the window centre) always carries a count: its two count rows are gathered
+    // unconditionally (scaled by the counts; `+ 0 * w` is exact), together with the bias and the table row — four
+    // independent loads in flight per row, and for most rows nothing else.  The other cells keep the data-dependent
+    // gathers (a neighbour inside the window is the exception); making those unconditional too was measured slower.
+    const int centre = WW >> 1;
+    const int2 tc = tab[a * WW + centre];
     dv_f32x4 acc = bias[c4];
+    const dv_f32x4 w_pred = Wt[((size_t)centre * vocab + vocab - 1) * H4 + c4];
+    const dv_f32x4 w_prey = Wt[((size_t)centre * vocab + vocab - 2) * H4 + c4];
     // the one-hot location channels of all window cells depend only on the entity's position: one row of the
     // pre-summed table (pp_encode_table_kernel) replaces W*W gathered rows
     if (loc_table) acc += loc_table[(size_t)(sr[a] * dim + sc[a]) * H4 + c4];
+    acc += (float)(tc.y & 0xffff) * w_pred;
+    acc += (float)(tc.y >> 16) * w_prey;
     for (int cell = 0; cell < WW; ++cell) {
         const int2 t = tab[a * WW + cell];
         const size_t row = (size_t)cell * vocab;
         if (!loc_table) acc += Wt[(row + t.x) * H4 + c4];
+        if (cell == centre) continue;
         const int npred = t.y & 0xffff, npr = t.y >> 16;
         if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
         if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
@@ -427,21 +438,25 @@ __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState
                                                   const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
                                                   const dv_f32x4* __restrict__ loc_table)
 {
-    const int W = 2 * s.v + 1, WW = W * W;
+    const int W = 2 * s.v + 1, WW = W * W, centre = WW >> 1;
     dv_f32x4 acc = bias[c4];
     if (t.sal[a]) {
-        acc += t.s0[a] * Wt[c4];
-        acc += t.s1[a] * Wt[H4 + c4];
+        // header rows, the table row and the car-count row of the car's own cell (count >= 1): independent loads
+        const dv_f32x4 w0 = Wt[c4], w1 = Wt[H4 + c4];
+        const dv_f32x4 w_car = Wt[((size_t)s.hdr + (size_t)centre * s.vocab + s.car_class) * H4 + c4];
+        acc += t.s0[a] * w0;
+        acc += t.s1[a] * w1;
         if (s.hdr == 4) {
             acc += t.s2[a] * Wt[2 * H4 + c4];
             acc += t.s3[a] * Wt[3 * H4 + c4];
         }
         if (loc_table) acc += loc_table[(size_t)(t.sr[a] * s.w + t.sc[a]) * H4 + c4];   // see pp_encode_kernel
+        acc += (float)t.tab[a * WW + centre].y * w_car;
         for (int cell = 0; cell < WW; ++cell) {
             const int2 d = t.tab[a * WW + cell];
             const size_t row = s.hdr + (size_t)cell * s.vocab;
             if (!loc_table && d.x >= 0) acc += Wt[(row + d.x) * H4 + c4];   // scalar vocab: -1 = not a road cell
-            if (d.y) acc += (float)d.y * Wt[(row + s.car_class) * H4 + c4];
+            if (cell != centre && d.y) acc += (float)d.y * Wt[(row + s.car_class) * H4 + c4];
         }
     }
     return acc;

@@ -1,0 +1,23 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/r02r
+mkdir -p $O
+run() { name=$1; shift; timeout 300 env "$@" > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r=d.get('roofline') or {}
+    print("%-28s %.4f ms/step  %.1f M/s | hbm-kernel %.4f ms %.0f GB/s" % (sys.argv[2], d['ms_per_step'], d['value']/1e6, r.get('avg_launch_ms',0), r.get('achieved',0)))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+}
+B="python bench.py --no-cpu-baseline"
+run s160            $B --steps 160 --warmup 16
+run s20_w5          $B --steps 20 --warmup 5
+run s20_w5_b        $B --steps 20 --warmup 5
+run s160_chain      $B --steps 160 --warmup 16 --mega 0 --time-kernels 0
+run tj_hard         $B --steps 160 --warmup 16 --workload tj_hard
+run tj_medium       $B --steps 160 --warmup 16 --workload tj_medium
+timeout 900 python -m pytest tests/test_policy_step_gpu.py tests/test_policy_gpu.py tests/test_trainer_gpu.py tests/test_auto_reset_gpu.py tests/test_env_parity_gpu.py -q -p no:cacheprovider > $O/tests.log 2>&1
+tail -n 1 $O/tests.log
