@@ -47,6 +47,16 @@ class Policy(C.Structure):
                 ("head_b", C.c_void_p)]
 
 
+class Episode(C.Structure):
+    """ic3_episode (include/ic3_rollout.h): episode buffers in, masks and reduced statistics out."""
+    _fields_ = [("n", C.c_int32), ("E", C.c_int32), ("N", C.c_int32), ("auto_reset", C.c_int32),
+                ("forced_last", C.c_int32), ("gate_ones", C.c_int32), ("done", C.c_void_p), ("alive", C.c_void_p),
+                ("is_completed", C.c_void_p), ("reward", C.c_void_p), ("gate", C.c_void_p), ("gate_stride", C.c_int64),
+                ("live", C.c_void_p), ("alive_mask", C.c_void_p), ("episode_mask", C.c_void_p),
+                ("episode_mini_mask", C.c_void_p), ("live_after", C.c_void_p), ("stats", C.c_void_p),
+                ("scratch", C.c_void_p), ("counter", C.c_void_p)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "ic3_version": (C.c_int, []),
@@ -95,6 +105,8 @@ EXPORTS = {
     "ic3_policy_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_policy_forward": (C.c_int, [C.POINTER(Policy), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "ic3_policy_step": (C.c_int, [C.c_void_p, C.POINTER(Policy)] + [C.c_void_p] * 12),
+    "ic3_episode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ic3_episode_finalize": (C.c_int, [C.POINTER(Episode), C.c_void_p]),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_int, C.c_void_p]),
 }

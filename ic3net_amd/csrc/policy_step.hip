@@ -66,7 +66,7 @@ struct StepArgs {
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
     int zmode;                  // cache policy of the zero stores
-    int zb, zl;                 // zero-store pacing: per burst in front of the gate loop, per 8 MFMAs inside it
+    int zb, zl, zc;               // zero-store pacing: per burst in front of the gate loop; inside it one nibble per k sub-step
     int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
                                 // between the two co-resident workgroups of a CU; speed only)
     int dbg;                    // timing ablations (IC3_PS_DEBUG bit mask; results are wrong when set): 1 gate MFMA loop,
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int k = 0; k < CH; ++k) cb[0][k] = cwp[(size_t)k * H * 2];
         __syncthreads();
         // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
-        auto cprod = [&](auto two_c) {
-            constexpr bool TWO = decltype(two_c)::value;
+        auto cprod = [&]() {
+            constexpr bool TWO = true;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) {
@@ -334,11 +334,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
                         if constexpr (TWO) mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
                     }
-                    if (obs_here) zero_store();
+                    if (obs_here && kb < a.zc) zero_store();
                 }
             }
         };
-        if (!(a.dbg & 2)) cprod(std::true_type{});
+        if (!(a.dbg & 2)) cprod();
         mfma_settle();
         __syncthreads();   // every wave has read the comm tile
     }
@@ -375,47 +375,60 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
-    auto gate_loop = [&](auto two_c) {
-        constexpr bool TWO = decltype(two_c)::value;
-        auto block = [&](const ps_f32x4 (&bq)[4], int kb) {
-            const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-            ps_f32x4 a1;
-            if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+    auto block = [&](const ps_f32x4 (&bq)[4], int kb) {
+        const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+        const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    mfma_acc(acc[0][g], a0[j], bq[g][j]);
-                    if constexpr (TWO) mfma_acc(acc[1][g], a1[j], bq[g][j]);
-                }
-                if (obs_here) {
-                    zero_store();
-                    if (a.zl > 1) zero_store();
-                }
+            for (int g = 0; g < 4; ++g) {
+                mfma_acc(acc[0][g], a0[j], bq[g][j]);
+                mfma_acc(acc[1][g], a1[j], bq[g][j]);
             }
-        };
-        // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
-        // their first use, which exposes the full L2 latency every block).
+            if (obs_here) {
+                const int nz = (a.zl >> (4 * j)) & 15;           // wave-uniform
+                if (nz > 0) zero_store();
+                if (nz > 1) zero_store();
 #pragma unroll 1
-        for (int kb = 0; kb < ((a.dbg & 1) ? 0 : KB); kb += 2) {
-            block(b0, kb);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 2 < KB) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+                for (int i = 2; i < nz; ++i) zero_store();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            block(b1, kb + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 3 < KB) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    static_assert(KB % 2 == 0, "K/8 must be even");
-    gate_loop(std::true_type{});
+    static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
+    // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
+    // their first use, which exposes the full L2 latency every block).
+    const int kb_end = (a.dbg & 1) ? 0 : KB - 2;
+#pragma unroll 1
+    for (int kb = 0; kb < kb_end; kb += 2) {
+        block(b0, kb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+        __builtin_amdgcn_sched_barrier(0);
+        block(b1, kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the old cell state: one touch per 128 B line of this wave's (64 rows x 32 columns) before the last two blocks
+    // (64 MFMAs) brings it from HBM into the L2 under them; the epilogue's loads then hit there.  (Holding the values
+    // themselves over the two blocks costs 32 registers the loop does not have.)
+    // The load's destination register stays reserved until the epilogue has waited for it (the compiler does not
+    // know that an asm load completes later).
+    float sink = 0.0f;
+    const bool warm_c = !(a.zmode & 16) && lane < rows && !(a.dbg & 16);
+    if (warm_c) {
+        const float* cp = a.c + (r0 + lane) * H + 32 * w;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(cp) : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.dbg & 1)) {
+        block(b0, KB - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        block(b1, KB - 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     mfma_settle();
     if (obs_here)
@@ -434,6 +447,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !(autor && fresh_row(lr)))
                                     ? ((a.zmode & 8) ? __builtin_nontemporal_load(cp) : *cp) : 0.0f;
             }
+        // loads complete in order: this is the wait the first use of cold[] needs anyway
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
         __syncthreads();   // every wave is done with the A tile
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
             const int o = i / H4, c4 = i - o * H4;
@@ -825,11 +840,26 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         static const int zmode_env = getenv("IC3_PS_ZMODE") ? atoi(getenv("IC3_PS_ZMODE")) : 2;   // nt: measured 0.43 vs 0.52 ms
         a.zmode = zmode_env;
         static const int zb_env = getenv("IC3_PS_ZB") ? atoi(getenv("IC3_PS_ZB")) : -1;
-        static const int zl_env = getenv("IC3_PS_ZL") ? atoi(getenv("IC3_PS_ZL")) : -1;
+        static const int zl_env = getenv("IC3_PS_ZL") ? (int)strtol(getenv("IC3_PS_ZL"), nullptr, 0) : -1;
         const long long per_thread = ((long long)a.EPT * a.N * a.obs_dim / 4 + 2 * H - 1) / (2 * H) + 1;
         const int slots = (2 * H / 8) * 4;                       // one per 8 MFMAs
-        a.zl = zl_env >= 0 ? zl_env : 1;
-        long long front = per_thread - (long long)slots * a.zl - H / 8;   // H/8 more go out inside the C product
+        // zl: one nibble per k sub-step of a K block (8 MFMAs each) = zero stores issued after it.  Everything that
+        // fits goes into the gate loop, spread evenly: stores in front of it delay the loads of the phases there
+        // (memory operations of a wave complete in order), measured 0.439 -> 0.429 ms on PP-hard.
+        static const int zc_env = getenv("IC3_PS_ZC") ? atoi(getenv("IC3_PS_ZC")) : -1;
+        a.zc = zc_env >= 0 ? zc_env : 0;                         // inside the C product (one per 8 MFMAs): none, 0.4198 -> 0.4177 ms
+        if (a.zc > H / 8) a.zc = H / 8;
+        if (zl_env >= 0) {
+            a.zl = zl_env;
+        } else {
+            long long want = (per_thread - a.zc + slots / 4 - 1) / (slots / 4);   // per K block
+            if (want > 60) want = 60;
+            if (want < 0) want = 0;
+            a.zl = 0;
+            for (int j = 0; j < 4; ++j) a.zl |= (int)((want + 3 - j) / 4) << (4 * j);
+        }
+        const int per_block = (a.zl & 15) + ((a.zl >> 4) & 15) + ((a.zl >> 8) & 15) + ((a.zl >> 12) & 15);
+        long long front = per_thread - (long long)(slots / 4) * per_block - a.zc;
         if (front < 0) front = 0;
         a.zb = zb_env >= 0 ? zb_env : (int)((front + 4) / 5);
         if (a.zb > 48) a.zb = 48;

@@ -218,6 +218,8 @@ class _BatchedEnv(object):
         self.obs_timer.append((e0, e1))
         return self._obs
 
+    has_terminal_reward = False                    # reward_terminal() is identically zero: the Trainer skips the add
+
     def reward_terminal(self):
         return torch.zeros_like(self._reward)      # PP:292-293 / TJ:611-612: zeros
 

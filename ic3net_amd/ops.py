@@ -217,6 +217,45 @@ def policy_step(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, com
     return out
 
 
+def episode_finalize(done, reward, alive=None, is_completed=None, gate=None, gate_ones=False, auto_reset=False,
+                     forced_last=False, work=None):
+    """The per-step derivations of get_episode (trainer.py:70-105,109-110) for n slots of E envs in one launch —
+    ic3_episode_finalize.  done (n, E) int32; reward (n, E, N) f32; alive / is_completed (n, E, N) int32 or None;
+    gate (n, E, N) int32 view with contiguous (E, N) slots (the talk head's actions) or None.
+    Returns dict(live (n,E), alive_mask, episode_mask (n,E), episode_mini_mask, live_after (E,), stats) where `stats`
+    is a device fp64 tensor [num_steps, zero_len_envs, reward_sum[N], gate_sum[N]] (read it after a sync).
+    `work`: dict reused between calls for the scratch buffers."""
+    import ctypes as C
+    _need_cuda(reward, "episode_finalize")
+    n, E, N = reward.shape
+    dev = reward.device
+    assert done.dtype == torch.int32 and done.shape == (n, E) and done.is_contiguous()
+    assert reward.dtype == torch.float32 and reward.is_contiguous()
+    for m in (alive, is_completed):
+        assert m is None or (m.dtype == torch.int32 and m.shape == (n, E, N) and m.is_contiguous())
+    gate_stride = 0
+    if gate is not None:
+        assert gate.dtype == torch.int32 and gate.shape == (n, E, N) and gate[0].is_contiguous()
+        gate_stride = gate.stride(0) if n > 1 else E * N
+    work = work if work is not None else dict()
+    key = (E, N, str(dev))
+    if work.get('key') != key:
+        nbytes = int(_lib.lib().ic3_episode_scratch_bytes(E, N))
+        if nbytes == 0:
+            raise ValueError("episode_finalize: unsupported sizes E=%d N=%d" % (E, N))
+        work.update(key=key, scratch=torch.empty(nbytes // 8, dtype=torch.float64, device=dev),
+                    counter=torch.zeros(1, dtype=torch.int32, device=dev))
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    res = dict(live=f(n, E), alive_mask=f(n, E, N), episode_mask=f(n, E), episode_mini_mask=f(n, E, N),
+               live_after=f(E), stats=torch.empty(2 + 2 * N, dtype=torch.float64, device=dev))
+    ep = _lib.Episode(n, E, N, int(bool(auto_reset)), int(bool(forced_last)), int(bool(gate_ones)), ptr(done),
+                      ptr(alive), ptr(is_completed), ptr(reward), ptr(gate), gate_stride, ptr(res['live']),
+                      ptr(res['alive_mask']), ptr(res['episode_mask']), ptr(res['episode_mini_mask']),
+                      ptr(res['live_after']), ptr(res['stats']), ptr(work['scratch']), ptr(work['counter']))
+    check(_lib.lib().ic3_episode_finalize(C.byref(ep), stream()))
+    return res
+
+
 def lstm_cell_heads_ok(H):
     """ic3_lstm_cell_heads needs H/4 to be a power of two <= 64."""
     return H % 4 == 0 and H // 4 <= 64 and (H // 4) & (H // 4 - 1) == 0

@@ -20,6 +20,7 @@ from torch import optim
 
 from .action_utils import SampleClock, select_action, translate_action
 from .action_utils import select_action as _select_action_default     # tests monkeypatch `select_action` (action tapes)
+from . import ops
 from .utils import merge_stat
 
 Transition = namedtuple('Transition', ('state', 'action', 'action_out', 'value', 'episode_mask', 'episode_mini_mask',
@@ -46,6 +47,7 @@ class Trainer(object):
         self._graph_gen = None          # policy_net.cache_generation the graphs were captured against
         self._episodes_played = 0
         self._static = None
+        self._fin_work = dict()         # scratch of ic3_episode_finalize
         # encoder(obs) as a sparse gather from env state (ic3_env_encode) instead of a dense obs_dim x H GEMM;
         # the dense observation is still assembled by env.step (API contract / store_states).
         if getattr(args, 'sparse_encoder', True) and hasattr(policy_net, 'obs_encoder') \
@@ -329,73 +331,115 @@ class Trainer(object):
             torch.cuda.current_stream().wait_stream(self._side)    # observations assembled on the side stream
         n, buf = self._nsteps, self._buf
         E, N = buf['reward'].shape[1:]
-        dev = buf['reward'].device
         has_info = self.env.env.dims.kind == 2                     # TJ reports alive_mask / is_completed in info
-        done = buf['done'][:n].to(torch.bool)                      # (n, E) episode_over after step t
-        not_done = (~done).to(torch.float32)
-        live = torch.ones((n, E), dtype=torch.float32, device=dev) # live[t] = env still running when step t starts
-        if n > 1 and not self._auto_reset():                       # (auto-reset: every slot is a real transition; `done`
-            live[1:] = torch.cumprod(not_done[:-1], dim=0)         #  already includes the max_steps cut of each episode)
-        done_t = done.clone()
-        if n == args.max_steps:
-            done_t[n - 1] = True                                   # trainer.py:90 forced done at the last step (auto-reset:
-                                                                   # the window's last slot cuts the running episodes)
-        reward = buf['reward'][:n]
-        if self._use_graph():
-            # static buffers are rewritten by the next episode's replays: hand out copies (action_out / value of a
-            # Transition stay graph-owned and are valid until the same step of the next episode)
-            reward = reward.clone()
-        alive = buf['alive'][:n].to(torch.float32) if has_info else torch.ones_like(reward)   # trainer.py:78-81
-        alive_mask = alive * live.unsqueeze(2)
-        episode_mask = (~done_t).to(torch.float32).unsqueeze(2).expand(n, E, N)                # trainer.py:92-96
-        episode_mini_mask = torch.ones_like(reward)
-        if has_info:                                               # trainer.py:98-99 (only when not done, Q26)
-            episode_mini_mask = torch.where(done_t.unsqueeze(2), episode_mini_mask,
-                                            1.0 - buf['is_completed'][:n].to(torch.float32))
-        action = buf['action'][:n].clone() if self._use_graph() else buf['action'][:n]
-        stat = dict()
-        num_steps = float(live.sum().item())
-        stat['num_steps'] = num_steps                              # trainer.py:109-110
-        stat['steps_taken'] = num_steps
-        enemy = bool(getattr(args, 'enemy_comm', False))
-        rsum = reward.double().sum((0, 1)).cpu().numpy()
-        stat['reward'] = rsum[:args.nfriendly]                     # trainer.py:86
-        if enemy:
-            stat['enemy_reward'] = rsum[args.nfriendly:]           # trainer.py:87-88
-        if args.hard_attn and args.commnet:                        # trainer.py:73-75
-            gate = torch.ones_like(reward) if args.comm_action_one else action[:, -1].to(torch.float32)
-            csum = (gate * live.unsqueeze(2)).double().sum((0, 1)).cpu().numpy()
-            stat['comm_action'] = csum[:args.nfriendly]
-            if enemy:
-                stat['enemy_comm'] = csum[args.nfriendly:]
+        graph = self._use_graph()
+        # static buffers are rewritten by the next episode's replays: hand out copies (action_out / value of a
+        # Transition stay graph-owned and are valid until the same step of the next episode)
+        reward = buf['reward'][:n].clone() if graph else buf['reward'][:n]
+        action = buf['action'][:n].clone() if graph else buf['action'][:n]
+        gated = bool(args.hard_attn and args.commnet)              # trainer.py:73-75
+        gate = action[:, -1] if gated and not args.comm_action_one else None
+        m = self._finalize(n, buf['done'][:n], reward, buf['alive'][:n] if has_info else None,
+                           buf['is_completed'][:n] if has_info else None, gate, gated and bool(args.comm_action_one))
+        alive_mask, episode_mini_mask, live = m['alive_mask'], m['episode_mini_mask'], m['live']
+        episode_mask = m['episode_mask'].unsqueeze(2).expand(n, E, N)                          # trainer.py:92-96
+        done_t = (m['episode_mask'] == 0) if self._auto_reset() else None
         episode = []
         for t in range(n):
             cur_state, action_out, value, next_state = self._step_out[t]
             misc = {'alive_mask': alive_mask[t], 'live': live[t]}
-            if self._auto_reset():
+            if done_t is not None:
                 misc['done'] = done_t[t]                           # (E,) this transition ends its env's episode
             episode.append(Transition(cur_state, action[t], action_out, value, episode_mask[t], episode_mini_mask[t],
                                       next_state, reward[t], misc))
-        if hasattr(self.env, 'reward_terminal'):                   # trainer.py:112-121 (zeros for PP/TJ)
-            rt = self.env.reward_terminal()
+        stat = dict()
+        enemy = bool(getattr(args, 'enemy_comm', False))
+        rts = None
+        raw = getattr(self.env, 'env', None)
+        if hasattr(self.env, 'reward_terminal') and getattr(raw, 'has_terminal_reward', True):
+            rt = self.env.reward_terminal()                        # trainer.py:112-121 (PP / TJ: zeros — skipped)
             episode[-1] = episode[-1]._replace(reward=episode[-1].reward + rt)
             rts = rt.double().sum(0).cpu().numpy()
+        env_stat = self.env.get_stat() if hasattr(self.env, 'get_stat') else None   # trainer.py:124-125 (synchronises)
+        sums = m['read_stats']()                                   # [num_steps, zero-length envs, reward[N], gate[N]]
+        num_steps = float(sums[0])
+        stat['num_steps'] = num_steps                              # trainer.py:109-110
+        stat['steps_taken'] = num_steps
+        rsum = sums[2:2 + N]
+        stat['reward'] = rsum[:args.nfriendly].copy()              # trainer.py:86
+        if enemy:
+            stat['enemy_reward'] = rsum[args.nfriendly:].copy()    # trainer.py:87-88
+        if gated:
+            csum = sums[2 + N:2 + 2 * N]
+            stat['comm_action'] = csum[:args.nfriendly].copy()
+            if enemy:
+                stat['enemy_comm'] = csum[args.nfriendly:].copy()
+        if rts is not None:
             stat['reward'] = stat['reward'] + rts[:args.nfriendly]
             if enemy:
                 stat['enemy_reward'] = stat['enemy_reward'] + rts[args.nfriendly:]
-        if hasattr(self.env, 'get_stat'):                          # trainer.py:124-125
-            env_stat = self.env.get_stat()
+        if env_stat is not None:
             if '_episodes' in env_stat:
                 # auto-reset: an env that restarted on the window's last slot holds a zero-length episode: not counted
                 eps = float(env_stat['_episodes'])
-                n_zero = float(done[n - 1].sum().item())
+                n_zero = float(sums[1])
                 if 'add_rate' in env_stat and eps > 0:
                     env_stat['add_rate'] = env_stat['add_rate'] * (eps - n_zero) / eps
                 env_stat['_episodes'] = eps - n_zero
             merge_stat(env_stat, stat)
-        self._live = live[-1] * not_done[-1]
+        self._live = m['live_after']
         self._episodes_played += 1
         return (episode, stat)
+
+    def _finalize(self, n, done, reward, alive, is_completed, gate, gate_ones):
+        """Masks and reduced statistics of the n slots just played: one ic3_episode_finalize launch whose fp64 sums
+        reach the host with the (synchronising) env statistics read that follows; `args.fused_finalize=False` keeps
+        the same derivations as separate tensor ops (the formulation the launch is tested against)."""
+        args = self.args
+        forced_last = n == args.max_steps                          # trainer.py:90 (auto-reset: the window's last slot
+        auto = self._auto_reset()                                  # cuts the running episodes)
+        if getattr(args, 'fused_finalize', True):
+            m = ops.episode_finalize(done, reward, alive, is_completed, gate, gate_ones, auto, forced_last,
+                                     work=self._fin_work)
+            host = self._fin_work.get('host')
+            if host is None or host.numel() != m['stats'].numel():
+                host = self._fin_work['host'] = torch.empty(m['stats'].numel(), dtype=torch.float64).pin_memory()
+            host.copy_(m['stats'], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+
+            def read_stats():
+                ev.synchronize()
+                return host.numpy().copy()
+            m['read_stats'] = read_stats
+            return m
+        return self._finalize_torch(n, done, reward, alive, is_completed, gate, gate_ones, auto, forced_last)
+
+    @staticmethod
+    def _finalize_torch(n, done, reward, alive, is_completed, gate, gate_ones, auto, forced_last):
+        E, N = reward.shape[1:]
+        dev = reward.device
+        done = done.to(torch.bool)                                 # (n, E) episode_over after step t
+        not_done = (~done).to(torch.float32)
+        live = torch.ones((n, E), dtype=torch.float32, device=dev) # live[t] = env still running when step t starts
+        if n > 1 and not auto:                                     # (auto-reset: every slot is a real transition; `done`
+            live[1:] = torch.cumprod(not_done[:-1], dim=0)         #  already includes the max_steps cut of each episode)
+        done_t = done.clone()
+        if forced_last:
+            done_t[n - 1] = True
+        al = alive.to(torch.float32) if alive is not None else torch.ones_like(reward)         # trainer.py:78-81
+        mini = torch.ones_like(reward)
+        if is_completed is not None:                               # trainer.py:98-99 (only when not done, Q26)
+            mini = torch.where(done_t.unsqueeze(2), mini, 1.0 - is_completed.to(torch.float32))
+        csum = torch.zeros(N, dtype=torch.float64, device=dev)
+        if gate_ones or gate is not None:
+            g = torch.ones_like(reward) if gate_ones else gate.to(torch.float32)
+            csum = (g * live.unsqueeze(2)).double().sum((0, 1))
+        stats = torch.cat([live.double().sum().reshape(1), done[n - 1].double().sum().reshape(1),
+                           reward.double().sum((0, 1)), csum])
+        return dict(live=live, alive_mask=al * live.unsqueeze(2), episode_mask=(~done_t).to(torch.float32),
+                    episode_mini_mask=mini, live_after=live[-1] * not_done[-1], stats=stats,
+                    read_stats=lambda: stats.cpu().numpy())
 
     def run_batch(self, epoch):                                    # trainer.py:227-242
         batch = []

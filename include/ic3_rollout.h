@@ -196,6 +196,40 @@ int ic3_tj_get_add_rate(const ic3_env* env, double* add_rate, double* exact_rate
 /* Reduced episode statistics (synchronising; host struct): env.stat (PP:284-288, TJ:249-250). */
 int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream);
 
+/* What get_episode derives per step next to the policy / env calls (trainer.py:70-105,109-110), for n lock-step
+ * slots of E envs, as one launch over the step-major episode buffers the step launches wrote:
+ *   live[t][e]            1 while env e is still running when slot t starts (auto_reset: always 1)
+ *   alive_mask[t][e][j]   alive * live                          (trainer.py:78-81)
+ *   episode_mask[t][e]    0 where the transition ends the episode (done, or the last of max_steps slots: forced_last,
+ *                         trainer.py:90-96), else 1
+ *   episode_mini_mask     1 - is_completed unless the transition is done (trainer.py:98-99, quirk Q26)
+ *   live_after[e]         live[n-1] * (1 - done[n-1])
+ *   stats (device)        [0] num_steps = sum live, [1] envs with done set in slot n-1, [2, 2+N) per-agent reward sums
+ *                         (trainer.py:86), [2+N, 2+2N) per-agent comm-action sums over live slots (trainer.py:73-75;
+ *                         gate == NULL and !gate_ones: zeros), fp64, summed in a fixed order.
+ * alive / is_completed may be NULL (PP: all ones / not reported).  scratch: ic3_episode_scratch_bytes(E, N) bytes;
+ * counter: one int32 that is 0 before the first call (the launch leaves it at 0).  Asynchronous on `stream`. */
+typedef struct ic3_episode {
+    int32_t n, E, N;
+    int32_t auto_reset, forced_last, gate_ones;
+    const int32_t* done;          /* [n][E] */
+    const int32_t* alive;         /* [n][E][N] or NULL */
+    const int32_t* is_completed;  /* [n][E][N] or NULL */
+    const float* reward;          /* [n][E][N] */
+    const int32_t* gate;          /* talk-head actions, slot t at gate + t * gate_stride, [E][N] each; or NULL */
+    int64_t gate_stride;
+    float* live;                  /* [n][E] */
+    float* alive_mask;            /* [n][E][N] */
+    float* episode_mask;          /* [n][E] */
+    float* episode_mini_mask;     /* [n][E][N] */
+    float* live_after;            /* [E] */
+    double* stats;                /* [2 + 2N] */
+    double* scratch;
+    int32_t* counter;
+} ic3_episode;
+size_t ic3_episode_scratch_bytes(int E, int N);
+int ic3_episode_finalize(const ic3_episode* ep, ic3_stream stream);
+
 /* CommNetMLP communication block, comm.py:181-205, in closed form per env (SURVEY B.5 i):
  *   m_j = alive_j * comm_action_j ; out_j = m_j * (sum_i m_i h_i - m_j h_j) [ / (n_alive - 1) if mode_avg && n_alive > 1 ]
  * n_alive = sum_j alive_j (NOT the talker count, quirk Q23) or N when alive == NULL (quirk Q21).
