@@ -168,29 +168,51 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     const int ohead = (int)((4 - (ob0 & 3)) & 3);
     const int onb = obs_here ? (oL - ohead) >> 2 : 0;            // float4s of the body
     ps_f32x4* const obody = reinterpret_cast<ps_f32x4*>(a.obs + ob0 + ohead);
-    int zq = tid - (int)(((ob0 + ohead) >> 2) & 63);             // 1 KiB-aligned wave stores (see pp_obs_kernel)
-    // cache policy of the zero stores (a.zmode & 3, IC3_PS_ZMODE): 0 plain, 1 sc1 (write-through), 2 nt (default),
-    // 3 sc0 sc1.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights every tile
-    // streams from there: with non-temporal stores the kernel takes 0.43 ms instead of 0.52 (plain, sc1: no change).
-    // (+4: h' / c' stores nt; +8: h / c loads nt — experiments)
+    // The body is cut into 1 KiB-aligned chunks of 64 float4s (see pp_obs_kernel); chunk c holds body indices
+    // [64c - mis, 64c - mis + 64).  The (at most two) ragged chunks at the ends go out here with lane predicates; the
+    // full ones are dealt round-robin to the waves and issued by zero_store() with wave-uniform control only: a scalar
+    // count, a scalar base address (SGPR pair, bumped by scalar adds), one constant lane offset and a zero vector held
+    // in registers — no vector ALU work, no exec masking, nothing for the matrix pipe to wait for.
+    // Cache policy: non-temporal.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights
+    // every tile streams from there: with plain stores (IC3_PS_ZMODE=0) the kernel takes 0.52 ms instead of 0.43.
+    // (zmode +4: h' / c' stores nt; +8: h / c loads nt; +16: no L2 warm-up of c — experiments)
+    const int mis = (int)(((ob0 + ohead) >> 2) & 63);
+    const int c_lo = mis ? 1 : 0, c_hi = (mis + onb) >> 6;       // full chunks: [c_lo, c_hi)
+    const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int zleft = 0;
+    uint32_t zb_lo = 0, zb_hi = 0;
+    if (obs_here) {
+        zleft = __builtin_amdgcn_readfirstlane(max(0, (c_hi - c_lo - ws + NW - 1) / NW));
+        const uint64_t zb = (uint64_t)obody + (uint64_t)((long long)(64 * (c_lo + ws) - mis) * 16);
+        zb_lo = __builtin_amdgcn_readfirstlane((uint32_t)zb);
+        zb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(zb >> 32));
+    }
+    const uint32_t zoff = (uint32_t)lane * 16u;
+    ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
+    asm volatile("" : "+v"(zv));                                 // keep it in registers (no re-materialisation per store)
+    const bool z_nt = (a.zmode & 3) != 0;
     auto zero_store = [&]() {
-        if (zq >= 0 && zq < onb) {
-            ps_f32x4* ptr = obody + zq;
-            const ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
-            const int zm = a.zmode & 3;
-            if (zm == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(zv) : "memory");
-            else if (zm == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(zv) : "memory");
-            else if (zm == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(zv) : "memory");
-            else *ptr = zv;
+        if (zleft > 0) {
+            const uint64_t zb = ((uint64_t)zb_hi << 32) | zb_lo;
+            if (z_nt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+            const uint64_t nb = zb + (uint64_t)NW * 1024u;
+            zb_lo = (uint32_t)nb;
+            zb_hi = (uint32_t)(nb >> 32);
+            --zleft;
         }
-        zq += NT;
     };
     auto zero_burst = [&](int n) {
-        if (obs_here) {
 #pragma unroll 1
-            for (int i = 0; i < n; ++i) zero_store();
-        }
+        for (int i = 0; i < n; ++i) zero_store();
     };
+    if (obs_here) {
+        // ragged chunks: chunk 0 when the body starts inside it, chunk c_hi when the body ends inside it
+        const int q0 = lane - mis, q1 = 64 * c_hi - mis + lane;
+        if (ws == 0 && mis && q0 >= 0 && q0 < onb) obody[q0] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        if (ws == 1 % NW && ((mis + onb) & 63) && (c_hi > 0 || !mis) && q1 >= 0 && q1 < onb)
+            obody[q1] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+    }
     if (obs_here) {
         const int otail = (oL - ohead) & 3;
         if (tid < ohead) a.obs[ob0 + tid] = 0.f;
@@ -431,8 +453,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 
     mfma_settle();
-    if (obs_here)
-        while (zq < onb) zero_store();    // tiles with more obs than the loop has slots for (obs-dominated shapes)
+    while (zleft > 0) zero_store();       // tiles with more obs than the loop has slots for (obs-dominated shapes)
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
     {
         const float* lb = a.l_bias + tz;
