@@ -65,7 +65,7 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
-    int zmode;                  // cache policy of the zero stores
+    int zmode;                  // experiment bits (+4 / +8 / +16, see the kernel)
     int zb, zl, zc;               // zero-store pacing: per burst in front of the gate loop; inside it one nibble per k sub-step
     int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
                                 // between the two co-resident workgroups of a CU; speed only)
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // count, a scalar base address (SGPR pair, bumped by scalar adds), one constant lane offset and a zero vector held
     // in registers — no vector ALU work, no exec masking, nothing for the matrix pipe to wait for.
     // Cache policy: non-temporal.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights
-    // every tile streams from there: with plain stores (IC3_PS_ZMODE=0) the kernel takes 0.52 ms instead of 0.43.
+    // every tile streams from there: with plain stores (a -DIC3_PS_PLAIN_STORES build) the kernel takes 0.50 ms
+    // instead of 0.38.
     // (zmode +4: h' / c' stores nt; +8: h / c loads nt; +16: no L2 warm-up of c — experiments)
     const int mis = (int)(((ob0 + ohead) >> 2) & 63);
     const int c_lo = mis ? 1 : 0, c_hi = (mis + onb) >> 6;       // full chunks: [c_lo, c_hi)
@@ -190,12 +191,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     const uint32_t zoff = (uint32_t)lane * 16u;
     ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
     asm volatile("" : "+v"(zv));                                 // keep it in registers (no re-materialisation per store)
-    const bool z_nt = (a.zmode & 3) != 0;
     auto zero_store = [&]() {
         if (zleft > 0) {
             const uint64_t zb = ((uint64_t)zb_hi << 32) | zb_lo;
-            if (z_nt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+#ifdef IC3_PS_PLAIN_STORES
+            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+#else
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+#endif
             const uint64_t nb = zb + (uint64_t)NW * 1024u;
             zb_lo = (uint32_t)nb;
             zb_hi = (uint32_t)(nb >> 32);
@@ -402,18 +405,18 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const int nz = (a.zl >> (4 * j)) & 15;               // wave-uniform, loop-invariant
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 mfma_acc(acc[0][g], a0[j], bq[g][j]);
                 mfma_acc(acc[1][g], a1[j], bq[g][j]);
+                // the scalar bookkeeping of a store slot fits into the 64-cycle shadow of one MFMA: one slot after
+                // the 4th and one after the 8th of a k sub-step rather than both at its end
+                if (g == 1 && nz > 1) zero_store();
+                if (g == 3 && nz > 0) zero_store();
             }
-            if (obs_here) {
-                const int nz = (a.zl >> (4 * j)) & 15;           // wave-uniform
-                if (nz > 0) zero_store();
-                if (nz > 1) zero_store();
 #pragma unroll 1
-                for (int i = 2; i < nz; ++i) zero_store();
-            }
+            for (int i = 2; i < nz; ++i) zero_store();
         }
     };
     static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
@@ -453,7 +456,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 
     mfma_settle();
-    while (zleft > 0) zero_store();       // tiles with more obs than the loop has slots for (obs-dominated shapes)
+    if (a.zmode & 32)
+        while (zleft > 0) zero_store();   // (experiment: the rest right behind the loop instead of inside the epilogue)
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
     {
         const float* lb = a.l_bias + tz;
@@ -484,6 +488,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
                 const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
                 const float h1 = fast_sigmoid(go) * fast_tanh(c1);
+                zero_store();                      // what the gate loop left of the zero fill goes out between the
+                zero_store();                      // transcendental work of the cell (2 x 32 slots, then the rest)
                 if (lr < rows && !(a.dbg & 16)) {
                     if (a.zmode & 4) {
                         __builtin_nontemporal_store(c1, a.c + (r0 + lr) * H + col);
@@ -496,6 +502,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 As[lr * LDA + H + col] = h1;
             }
         }
+        while (zleft > 0) zero_store();            // obs-dominated shapes
     }
     __syncthreads();
     if (a.dbg & 8) return;
@@ -857,32 +864,32 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;
     a.auto_reset = env->auto_max_steps > 0;
-    {   // pacing of the zero stores: per-thread count of a tile, 5 bursts in front + KB*4 slots in the loop
-        static const int zmode_env = getenv("IC3_PS_ZMODE") ? atoi(getenv("IC3_PS_ZMODE")) : 2;   // nt: measured 0.43 vs 0.52 ms
+    {   // pacing of the zero stores: per-thread count of a tile; KB*4 slots in the loop, then the cell epilogue
+        static const int zmode_env = getenv("IC3_PS_ZMODE") ? atoi(getenv("IC3_PS_ZMODE")) : 0;
         a.zmode = zmode_env;
         static const int zb_env = getenv("IC3_PS_ZB") ? atoi(getenv("IC3_PS_ZB")) : -1;
         static const int zl_env = getenv("IC3_PS_ZL") ? (int)strtol(getenv("IC3_PS_ZL"), nullptr, 0) : -1;
         const long long per_thread = ((long long)a.EPT * a.N * a.obs_dim / 4 + 2 * H - 1) / (2 * H) + 1;
         const int slots = (2 * H / 8) * 4;                       // one per 8 MFMAs
-        // zl: one nibble per k sub-step of a K block (8 MFMAs each) = zero stores issued after it.  Everything that
-        // fits goes into the gate loop, spread evenly: stores in front of it delay the loads of the phases there
-        // (memory operations of a wave complete in order), measured 0.439 -> 0.429 ms on PP-hard.
+        // zl: one nibble per k sub-step of a K block (8 MFMAs each) = zero stores issued after it.  None in front of
+        // the loop: stores there delay the loads of the phases there (memory operations of a wave complete in
+        // order), measured 0.439 -> 0.429 ms on PP-hard.
         static const int zc_env = getenv("IC3_PS_ZC") ? atoi(getenv("IC3_PS_ZC")) : -1;
         a.zc = zc_env >= 0 ? zc_env : 0;                         // inside the C product (one per 8 MFMAs): none, 0.4198 -> 0.4177 ms
         if (a.zc > H / 8) a.zc = H / 8;
         if (zl_env >= 0) {
             a.zl = zl_env;
         } else {
-            long long want = (per_thread - a.zc + slots / 4 - 1) / (slots / 4);   // per K block
+            // ~70 % of a tile's stores inside the loop (PP-hard: 5 of the 7.1 per K block, 0.397 -> 0.381 ms against
+            // all of them), the rest inside the cell epilogue
+            static const int zfrac = getenv("IC3_PS_ZFRAC") ? atoi(getenv("IC3_PS_ZFRAC")) : 70;
+            long long want = ((per_thread - a.zc) * zfrac / 100 + slots / 8) / (slots / 4);   // per K block, rounded
             if (want > 60) want = 60;
             if (want < 0) want = 0;
             a.zl = 0;
             for (int j = 0; j < 4; ++j) a.zl |= (int)((want + 3 - j) / 4) << (4 * j);
         }
-        const int per_block = (a.zl & 15) + ((a.zl >> 4) & 15) + ((a.zl >> 8) & 15) + ((a.zl >> 12) & 15);
-        long long front = per_thread - (long long)(slots / 4) * per_block - a.zc;
-        if (front < 0) front = 0;
-        a.zb = zb_env >= 0 ? zb_env : (int)((front + 4) / 5);
+        a.zb = zb_env >= 0 ? zb_env : 0;                         // per burst between the phases in front of the loop
         if (a.zb > 48) a.zb = 48;
     }
     hipStream_t s = (hipStream_t)stream;

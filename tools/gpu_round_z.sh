@@ -1,0 +1,29 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/r02z
+mkdir -p $O
+run() { name=$1; shift; timeout 300 env "$@" > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r=d.get('roofline') or {}
+    print("%-28s %.4f ms/step  %.1f M/s | hbm-kernel %.4f ms %.0f GB/s" % (sys.argv[2], d['ms_per_step'], d['value']/1e6, r.get('avg_launch_ms',0), r.get('achieved',0)))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+}
+B="python bench.py --no-cpu-baseline"
+timeout 900 python -m pytest tests/test_policy_step_gpu.py tests/test_trainer_gpu.py tests/test_auto_reset_gpu.py -q -x -p no:cacheprovider > $O/tests.log 2>&1
+tail -n 3 $O/tests.log
+run warm            $B --steps 160 --warmup 16
+run base            $B --steps 160 --warmup 16
+run flush_after     IC3_PS_ZMODE=32 $B --steps 160 --warmup 16
+run frac100         IC3_PS_ZFRAC=100 $B --steps 160 --warmup 16
+run frac85          IC3_PS_ZFRAC=85 $B --steps 160 --warmup 16
+run frac55          IC3_PS_ZFRAC=55 $B --steps 160 --warmup 16
+run frac40          IC3_PS_ZFRAC=40 $B --steps 160 --warmup 16
+run zc16            IC3_PS_ZC=16 $B --steps 160 --warmup 16
+run base_b          $B --steps 160 --warmup 16
+run s20_w5          $B --steps 20 --warmup 5
+run tj_hard         $B --steps 160 --warmup 16 --workload tj_hard
+run tj_medium       $B --steps 160 --warmup 16 --workload tj_medium
