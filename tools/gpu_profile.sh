@@ -21,9 +21,13 @@ timeout 300 $B --fused-obs 0 > $O/bench_pp_hard_separate_obs.json 2>/dev/null
 timeout 300 $B --fused-obs 0 --overlap-obs 1 --time-kernels 0 > $O/bench_pp_hard_overlap_obs.json 2>/dev/null
 timeout 300 $B --mega 0 --time-kernels 0 > $O/bench_pp_hard_chain_r01.json 2>/dev/null
 timeout 300 $B --time-kernels 0 > $O/bench_pp_hard_graph.json 2>/dev/null
-IC3_PS_ZMODE=0 timeout 300 $B > $O/bench_pp_hard_plain_stores.json 2>/dev/null
+IC3_ROLLOUT_LIB=$R/ic3net_amd/csrc/libic3rollout_plain.so timeout 300 $B > $O/bench_pp_hard_plain_stores.json 2>/dev/null
 IC3_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d $O/roctx -- python bench.py --steps 8 --warmup 2 --nenvs 1024 --no-cpu-baseline > $O/roctx.log 2>&1
 ./tools/exp/ws_probe > $O/ws_probe.txt 2>&1
+timeout 600 python tools/exp/two_stream.py pp_hard 8192 2>&1 | grep -v amdgpu.ids > $O/two_stream.txt
+for D in 0 1 2 4 8 16 32; do IC3_PS_DEBUG=$D IC3_MB_OBS=1 timeout 200 python tools/microbench_policy_step.py pp_hard 8192 48 2>/dev/null | grep "ic3_policy_step"; done > $O/policy_step_ablation_e8192.txt
+for D in 0 1 2 4 8 16 32; do IC3_PS_DEBUG=$D IC3_MB_OBS=1 timeout 200 python tools/microbench_policy_step.py pp_hard 384 48 2>/dev/null | grep "ic3_policy_step"; done > $O/policy_step_ablation_lone_tile_e384.txt
+for E in 384 3072 6144 8192 9216 12288; do for OB in 0 1; do IC3_MB_OBS=$OB timeout 200 python tools/microbench_policy_step.py pp_hard $E 48 2>/dev/null | grep "ic3_policy_step" | sed "s/^/obs=$OB /"; done; done > $O/policy_step_env_count_sweep.txt
 cat $O/summary.txt; tail -n 2 $O/smoke.log; tail -n 1 $O/tests_gpu.log; du -sh $O
 for f in $O/bench_*.json; do python - $f <<'PY'
 import json,sys,os
