@@ -160,8 +160,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // any other wave of its SIMD (measured: tools/exp/ws_probe.hip), so the store stream can only share time with the
     // matrix work from INSIDE the same instruction stream — and there every instruction counts.  The rows are ~98 %
     // zeros: the tile's contiguous slice of the obs tensor is ZERO-FILLED by stores sprinkled between the MFMAs of the
-    // C product and the gate loop (address arithmetic only), and the few non-zero entries (<= 3 per window cell) are
-    // patched in at the very end, after every wave has seen its zero stores complete (s_waitcnt + barrier).
+    // gate loop and the transcendentals of the LSTM epilogue (scalar bookkeeping only), and the few non-zero entries
+    // (<= 3 per window cell) are patched in at the very end, after every wave has seen its zero stores complete
+    // (s_waitcnt + barrier).
     const bool obs_here = (KIND != 0) && a.obs != nullptr;
     const long long ob0 = (long long)e0 * N * a.obs_dim;         // first float of the tile's rows
     const int oL = rows * a.obs_dim;                             // floats of the tile
@@ -257,9 +258,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         hv[i] = (row < rows && !(autor && fresh_row(row))) ? ((a.zmode & 8) ? __builtin_nontemporal_load(hp) : *hp)
                                                            : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
-    // the zero stores are spread over the tile's whole lifetime (a PP-hard tile has 214 per thread): ~80 between the
-    // phases in front of the gate loop, one per 8 MFMAs inside it — bunching them up (all in the loop, or front-loaded)
-    // fills the store queue and stalls the wave in the middle of its MFMA stream (measured: 0.50 vs 0.47 ms)
+    // (zb = 0 by default: zero stores in front of the gate loop delay the loads of the phases here — memory operations
+    // of a wave complete in order; IC3_PS_ZB keeps the experiment)
     zero_burst(a.zb);
     __syncthreads();
 
