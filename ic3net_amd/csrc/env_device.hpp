@@ -61,6 +61,10 @@ struct StepOut {
     int32_t *done, *alive_out, *comp_out, *err;
 };
 
+// x / d for 0 <= x < 2^20 through the float pipe: inv = 1.0f / d.  (x + 0.5) / d is at least 0.5 / d away from the next
+// integer, the float error is below x * 2^-22 / d: exact.  A runtime integer division expands to ~25 VALU instructions.
+__device__ __forceinline__ int div_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
 __device__ __forceinline__ bool padded_outside(int pr, int pc, int v, int dim)
 {
     return pr < v || pr >= v + dim || pc < v || pc >= v + dim;  // np.pad(grid, vision, OUTSIDE_CLASS) PP:184
@@ -193,8 +197,8 @@ __device__ __forceinline__ int2 pp_tab_entry(const int32_t* sr, const int32_t* s
 {
     const int W = 2 * v + 1;
     const int OUTSIDE = dim * dim + 1;
-    const int a = s / (W * W), w = s - a * (W * W);
-    const int dy = w / W, dx = w - dy * W;
+    const int a = div_small(s, 1.0f / (float)(W * W)), w = s - a * (W * W);
+    const int dy = div_small(w, 1.0f / (float)W), dx = w - dy * W;
     const int gr = sr[a] + dy - v, gc = sc[a] + dx - v;
     const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
     int npred = 0, npr = 0;
@@ -204,9 +208,14 @@ __device__ __forceinline__ int2 pp_tab_entry(const int32_t* sr, const int32_t* s
 }
 
 // encoder(obs row of entity a)[4*c4 .. 4*c4+3] from the env's LDS descriptors (see pp_encode_kernel)
+// `cells`: bit c set = window cell c may carry a predator / prey count (the centre is handled apart); ~0u = unknown.
+// With the location table present only those cells are visited (in ascending order, as the full scan would): the
+// fused policy+step kernel builds the bit set once per row next to the descriptors instead of letting each of the H/4
+// lanes of a row re-scan all W*W cells.
 __device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
                                                   int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
-                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table)
+                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table,
+                                                  unsigned cells = ~0u)
 {
     // The entity's own cell (the window centre) always carries a count: its two count rows are gathered
     // unconditionally (scaled by the counts; `+ 0 * w` is exact), together with the bias and the table row — four
@@ -222,6 +231,19 @@ __device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32
     if (loc_table) acc += loc_table[(size_t)(sr[a] * dim + sc[a]) * H4 + c4];
     acc += (float)(tc.y & 0xffff) * w_pred;
     acc += (float)(tc.y >> 16) * w_prey;
+    if (loc_table && WW <= 32) {
+        unsigned m = cells & ~(1u << centre) & (WW == 32 ? ~0u : ((1u << WW) - 1u));
+        while (m) {
+            const int cell = __builtin_ctz(m);
+            m &= m - 1;
+            const int2 t = tab[a * WW + cell];
+            const size_t row = (size_t)cell * vocab;
+            const int npred = t.y & 0xffff, npr = t.y >> 16;
+            if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
+            if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
+        }
+        return acc;
+    }
     for (int cell = 0; cell < WW; ++cell) {
         const int2 t = tab[a * WW + cell];
         const size_t row = (size_t)cell * vocab;
@@ -424,8 +446,8 @@ __device__ __forceinline__ void tj_tile_load_car(const TJTile& t, const TJState&
 __device__ __forceinline__ int2 tj_tab_entry(const TJTile& t, const TJState& s, int q)
 {
     const int W = 2 * s.v + 1, WW = W * W;
-    const int a = q / WW, cell = q - a * WW;
-    const int dy = cell / W, dx = cell - dy * W;
+    const int a = div_small(q, 1.0f / (float)WW), cell = q - a * WW;
+    const int dy = div_small(cell, 1.0f / (float)W), dx = cell - dy * W;
     const int gr = t.sr[a] + dy - s.v, gc = t.sc[a] + dx - s.v;
     const int id = (gr >= 0 && gr < s.h && gc >= 0 && gc < s.w) ? s.grid[gr * s.w + gc] : s.outside;   // pad_grid TJ:317
     int ncar = 0;
@@ -436,7 +458,7 @@ __device__ __forceinline__ int2 tj_tab_entry(const TJTile& t, const TJState& s, 
 // encoder(obs row of car a)[4*c4 ..] (see tj_encode_kernel): bias only for a dead car (its obs row is zero)
 __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
                                                   const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
-                                                  const dv_f32x4* __restrict__ loc_table)
+                                                  const dv_f32x4* __restrict__ loc_table, unsigned cells = ~0u)
 {
     const int W = 2 * s.v + 1, WW = W * W, centre = WW >> 1;
     dv_f32x4 acc = bias[c4];
@@ -452,6 +474,16 @@ __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState
         }
         if (loc_table) acc += loc_table[(size_t)(t.sr[a] * s.w + t.sc[a]) * H4 + c4];   // see pp_encode_kernel
         acc += (float)t.tab[a * WW + centre].y * w_car;
+        if (loc_table && WW <= 32) {               // only the cells that carry a car count (see pp_encode_row)
+            unsigned m = cells & ~(1u << centre) & (WW == 32 ? ~0u : ((1u << WW) - 1u));
+            while (m) {
+                const int cell = __builtin_ctz(m);
+                m &= m - 1;
+                const int2 d = t.tab[a * WW + cell];
+                if (d.y) acc += (float)d.y * Wt[((size_t)s.hdr + (size_t)cell * s.vocab + s.car_class) * H4 + c4];
+            }
+            return acc;
+        }
         for (int cell = 0; cell < WW; ++cell) {
             const int2 d = t.tab[a * WW + cell];
             const size_t row = s.hdr + (size_t)cell * s.vocab;

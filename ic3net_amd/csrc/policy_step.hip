@@ -21,7 +21,9 @@
 //     16-byte load per lane per gate per 8 k, two register buffers refilled a full 32-MFMA block ahead;
 //   * LDS budget 64 x (2H+4) floats = 66.5 KB: the encoder output is staged through the h half, parked in the
 //     accumulators of the C product (which it initialises), and the communication tile takes the inp half.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "env_device.hpp"
 #include "ic3_common.hpp"
@@ -34,6 +36,19 @@ typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
 // v_mfma_f32_32x32x2_f32, optionally with the accumulator pinned to AGPRs (IC3_PS_AGPR=1): hipcc picks the all-VGPR
 // form when the registers fit, which streams ~6 % slower in isolation (144 vs 153 TFLOP/s, tools/exp/ws_probe.hip).
 // The asm is opaque to the hazard recogniser: whoever reads the accumulator afterwards calls mfma_settle() first.
+// -DIC3_PS_TRACE: wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries into a device buffer;
+// the 40th ic3_policy_step call of the process dumps it to $IC3_PS_TRACE_OUT (tools/build_variant.sh trace -DIC3_PS_TRACE)
+#ifdef IC3_PS_TRACE
+#define IC3_TR(k)                                                                                       \
+    do {                                                                                                \
+        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 20 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define IC3_TR(k) do { } while (0)
+#endif
+#ifndef IC3_PS_ENC_UNROLL
+#define IC3_PS_ENC_UNROLL 2   // rows of the sparse encoder gather in flight per thread
+#endif
 #ifndef IC3_PS_AGPR
 #define IC3_PS_AGPR 0   // measured: the 128/128 VGPR/AGPR split spills in the phases around the loops; net slower (0.57 vs 0.52 ms)
 #endif
@@ -66,6 +81,7 @@ struct StepArgs {
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
     int zmode;                  // experiment bits (+4 / +8 / +16, see the kernel)
+    unsigned long long* trace;  // IC3_PS_TRACE builds: [tiles][20] phase time stamps
     int zb, zl, zc;               // zero-store pacing: per burst in front of the gate loop; inside it one nibble per k sub-step
     int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
                                 // between the two co-resident workgroups of a CU; speed only)
@@ -103,16 +119,26 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     float* sm = As + BM * LDA;                                   // [BM] m_j = alive_j * comm_action_j
     float* sscale = sm + BM;                                     // [BM] per-env 1/(n_alive-1)
     int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
-    int32_t* tile = sact + BM;                                   // env descriptors of the tile's envs
+    uint32_t* rmask = reinterpret_cast<uint32_t*>(sact + BM);    // [BM] window cells of every row that carry a count
+    int32_t* tile = reinterpret_cast<int32_t*>(rmask + BM);     // env descriptors of the tile's envs
 
     if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
     const int tid = threadIdx.x;
+    IC3_TR(0);
+#ifdef IC3_PS_TRACE
+    if (a.trace && tid == 0) {
+        a.trace[(size_t)blockIdx.x * 20 + 18] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        a.trace[(size_t)blockIdx.x * 20 + 19] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+#endif
     const int N = a.N;
     const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
     const int total = a.pp.Np + a.pp.nprey;
     const int nsegE = N * WW;
     const int tjw = tj_tile_words(N, WW);
+    const float inv_WW = 1.0f / (float)max(WW, 1);
+    const float invN = 1.0f / (float)N, inv_nsegE = 1.0f / (float)max(nsegE, 1);   // div_small(): no integer divisions
     // env descriptors of `ne` envs starting at env `eb`, into the LDS block `tl` (two phases around a barrier):
     //   PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x TJTile
     auto desc_positions = [&](int32_t* tl, int eb, int ne) {
@@ -125,7 +151,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         } else if constexpr (KIND == IC3_ENV_TJ) {
             for (int i = tid; i < ne * N; i += NT) {
-                const int el = i / N;
+                const int el = div_small(i, invN);
                 tj_tile_load_car(tj_tile_at(tl + el * tjw, N), a.tj, eb + el, i - el * N);
             }
         }
@@ -134,12 +160,19 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         if constexpr (KIND != 0) {
             int2* pt = reinterpret_cast<int2*>(tl + ((2 * a.EPT * total + 3) & ~3));
             for (int s = tid; s < ne * nsegE; s += NT) {
-                const int el = s / nsegE, q = s - el * nsegE;
+                const int el = div_small(s, inv_nsegE), q = s - el * nsegE;
+                int2 d;
                 if constexpr (KIND == IC3_ENV_PP) {
-                    pt[s] = pp_tab_entry(tl + el * total, tl + a.EPT * total + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
+                    d = pp_tab_entry(tl + el * total, tl + a.EPT * total + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
+                    pt[s] = d;
                 } else {
                     const TJTile t = tj_tile_at(tl + el * tjw, N);
-                    t.tab[q] = tj_tab_entry(t, a.tj, q);
+                    d = tj_tab_entry(t, a.tj, q);
+                    t.tab[q] = d;
+                }
+                if (d.y != 0 && WW <= 32) {          // rows of the encoder only visit the cells flagged here
+                    const int ag = div_small(q, inv_WW);
+                    atomicOr(&rmask[el * N + ag], 1u << (q - ag * WW));
                 }
             }
         }
@@ -236,6 +269,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         if (r < rows && !(autor && fresh_row(r)))
             m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
         sm[r] = m;
+        if constexpr (KIND != 0) rmask[r] = (WW <= 32) ? 0u : ~0u;   // filled next to the window descriptors (S1)
     }
     for (int el = tid; el < nenv; el += NT) {
         int n_alive = 0;
@@ -262,33 +296,37 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // of a wave complete in order; IC3_PS_ZB keeps the experiment)
     zero_burst(a.zb);
     __syncthreads();
+    IC3_TR(1);
 
     // ---- S1: window descriptors ------------------------------------------------------------------------------------
     if constexpr (KIND != 0) {
         desc_tab(tile, nenv);
         __syncthreads();
+        IC3_TR(2);
     }
     zero_burst(a.zb);
     // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
-#pragma unroll 2
+#pragma unroll IC3_PS_ENC_UNROLL
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * NT;
         const int row = idx / H4, c4 = idx - row * H4;
         ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
         if (row < rows && !(a.dbg & 4)) {
-            const int el = row / N, aa = row - el * N;
+            const int el = div_small(row, invN), aa = row - el * N;
             if constexpr (KIND == 0) {
                 v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
             } else if constexpr (KIND == IC3_ENV_PP) {
                 v = pp_encode_row(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
-                                  a.pp.dim * a.pp.dim + 4, a.pp.dim, a.Wt, a.enc_bias + tz, a.loc_table);
+                                  a.pp.dim * a.pp.dim + 4, a.pp.dim, a.Wt, a.enc_bias + tz, a.loc_table, rmask[row]);
             } else {
-                v = tj_encode_row(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, a.Wt, a.enc_bias + tz, a.loc_table);
+                v = tj_encode_row(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, a.Wt, a.enc_bias + tz, a.loc_table,
+                                  rmask[row]);
             }
         }
         As4[row * LDA4 + H4 + c4] = v;
     }
     __syncthreads();
+    IC3_TR(3);
 
     // ---- S3: the encoder output moves into the accumulators of the C product (MFMA C/D layout:
     //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------------------------------------------------
@@ -301,6 +339,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             accC[rt][reg] = As[lr * LDA + H + col];
         }
     __syncthreads();
+    IC3_TR(4);
 
     zero_burst(a.zb);
     // ---- S4: h -> h half ---------------------------------------------------------------------------------------------
@@ -311,6 +350,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         As4[row * LDA4 + H4 + c4] = hv[i];
     }
     __syncthreads();
+    IC3_TR(5);
 
     zero_burst(a.zb);
     if (!a.comm_zero) {   // comm_mask_zero (comm.py:40-41): C sees zeros, inp = enc + C.bias
@@ -339,6 +379,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
         for (int k = 0; k < CH; ++k) cb[0][k] = cwp[(size_t)k * H * 2];
         __syncthreads();
+        IC3_TR(6);
         // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
         auto cprod = [&]() {
             constexpr bool TWO = true;
@@ -366,6 +407,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         if (!(a.dbg & 2)) cprod();
         mfma_settle();
         __syncthreads();   // every wave has read the comm tile
+        IC3_TR(7);
     }
 
     // gate weights: the first two 8-k blocks are requested before inp is written back
@@ -391,6 +433,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             As[lr * LDA + col] = accC[rt][reg];
         }
     __syncthreads();
+    IC3_TR(8);
 
     // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell) --------------------------------------
     ps_f32x16 acc[2][4];
@@ -455,7 +498,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    IC3_TR(9);
     mfma_settle();
+    IC3_TR(10);
     if (a.zmode & 32)
         while (zleft > 0) zero_store();   // (experiment: the rest right behind the loop instead of inside the epilogue)
     // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
@@ -475,6 +520,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // loads complete in order: this is the wait the first use of cold[] needs anyway
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
         __syncthreads();   // every wave is done with the A tile
+        IC3_TR(11);
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
             const int o = i / H4, c4 = i - o * H4;
             As4[o * LDA4 + c4] = reinterpret_cast<const ps_f32x4*>(a.head_w)[i + tz];
@@ -505,6 +551,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         while (zleft > 0) zero_store();            // obs-dominated shapes
     }
     __syncthreads();
+    IC3_TR(12);
     if (a.dbg & 8) return;
 
     // ---- S10: heads + value head (comm.py:228,239): NW lanes per row, 32 columns each ---------------------------------
@@ -535,14 +582,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     }
     __syncthreads();
+    IC3_TR(13);
 
     // ---- S11: log_softmax per head + the action draws (action_utils.py:32-36; same arithmetic and Philox counters as
     //      lstm_cell_heads_kernel / sample_actions_env_kernel), one task per (row, head) + one per row for the value ----
     {
         const int sizes[4] = { a.a0, a.a1, a.a2, a.a3 };
         const int R = a.E * N;
+        const float inv_nh1 = 1.0f / (float)(a.nheads + 1);
         for (int task = tid; task < rows * (a.nheads + 1); task += NT) {
-            const int tr = task / (a.nheads + 1), hd = task - tr * (a.nheads + 1);
+            const int tr = div_small(task, inv_nh1), hd = task - tr * (a.nheads + 1);
             const size_t grow = r0 + tr;
             const float* z = As + (16 + tr / PER) * LDA + (tr % PER) * 16;
             float* orow = a.out + grow * a.OT;
@@ -560,7 +609,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
             for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
             if (KIND == 0) continue;                // forward only: the caller draws (ic3_sample_actions)
-            const int el = tr / N, n = tr - el * N;
+            const int el = div_small(tr, invN), n = tr - el * N;
             const int e = e0 + el;
             const uint32_t x = philox_x24(a.seed, a.gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)a.episode[e],
                                           (uint32_t)a.tstep[e], (uint32_t)(hd * N + n));
@@ -579,12 +628,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
     }
     __syncthreads();
+    IC3_TR(14);
 
     // ---- S12: env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) ----------------------------
     if constexpr (KIND != 0) {
+        const int lgG = __builtin_ctz(a.G);
         for (int base = 0; base < a.EPT * a.G; base += NT) {
             const int lt = base + tid;
-            const int el = lt / a.G, n = lt - el * a.G;
+            const int el = lt >> lgG, n = lt - (el << lgG);         // G is a power of two
             const int e = el < nenv ? e0 + el : a.E;
             if constexpr (KIND == IC3_ENV_PP) {
                 pp_step_lanes(a.pp, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
@@ -593,11 +644,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     }
+    IC3_TR(15);
     if (obs_here && !(a.dbg & 32)) {
         // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
         // first non-zero entry goes out to the same lines
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        IC3_TR(16);
         float* orow0 = a.obs + ob0;
         if constexpr (KIND == IC3_ENV_PP) {
             const int vocab = a.pp.dim * a.pp.dim + 4;
@@ -613,7 +666,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         } else if constexpr (KIND == IC3_ENV_TJ) {
             const int obs_dim = a.obs_dim;
             for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
-                const int el = sg / (nsegE + N), q = sg - el * (nsegE + N);
+                const int el = div_small(sg, 1.0f / (float)(nsegE + N)), q = sg - el * (nsegE + N);
                 const TJTile t = tj_tile_at(tile + el * tjw, N);
                 if (q < N) {                                     // header of car q's row (TJ:338-344)
                     if (!t.sal[q]) continue;
@@ -625,7 +678,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         row[3] = t.s3[q];
                     }
                 } else {                                         // window cell (TJ:331-332,352-356)
-                    const int qq = q - N, car = qq / WW, cellx = qq - car * WW;
+                    const int qq = q - N, car = div_small(qq, 1.0f / (float)WW), cellx = qq - car * WW;
                     if (!t.sal[car]) continue;
                     const int2 d = t.tab[qq];
                     float* cell = orow0 + ((size_t)el * N + car) * obs_dim + a.tj.hdr + (size_t)cellx * a.tj.vocab;
@@ -635,6 +688,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
     }
+    IC3_TR(17);
 }
 
 // Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
@@ -741,7 +795,7 @@ static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_wo
     tile_words = (tile_words + 3) & ~(size_t)3;
     if (tile_words_out) *tile_words_out = (int)tile_words;
     (void)with_obs;
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + tile_words) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64 + tile_words) * sizeof(float);
     const size_t limit = (H <= 128) ? 80 * 1024 : 160 * 1024;   // two workgroups per CU up to H = 128
     return lds <= limit ? (int)lds : 0;
 }
@@ -805,7 +859,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     a.EPT = 64 / N;
     a.G = 1;
     const int tiles = plan_tiles(a, H);
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
     if (H == 64) return launch_step<64, 0>(a, tiles, lds, s);
@@ -898,8 +952,35 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         rc = ic3_env_observe(env, obs, stream);
         if (rc) return rc;
     }
+#ifdef IC3_PS_TRACE
+    static unsigned long long* trace_buf = nullptr;
+    static int trace_call = 0, trace_tiles = 0;
+    if (getenv("IC3_PS_TRACE_OUT")) {
+        if (!trace_buf) {
+            trace_tiles = tiles;
+            IC3_HIP(hipMalloc(&trace_buf, (size_t)tiles * 20 * sizeof(unsigned long long)));
+            IC3_HIP(hipMemset(trace_buf, 0, (size_t)tiles * 20 * sizeof(unsigned long long)));
+        }
+        if (tiles == trace_tiles) a.trace = trace_buf;
+    }
+#endif
     if (H == 128) rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s);
     else if (H == 64) rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s);
     else rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s);
+#ifdef IC3_PS_TRACE
+    if (a.trace && ++trace_call == 40) {
+        IC3_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)trace_tiles * 20);
+        IC3_HIP(hipMemcpy(h.data(), trace_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("IC3_PS_TRACE_OUT"), "w")) {
+            for (int t = 0; t < trace_tiles; ++t) {
+                fprintf(f, "%d", t);
+                for (int k = 0; k < 20; ++k) fprintf(f, ",%llu", h[(size_t)t * 20 + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+#endif
     return rc;
 }

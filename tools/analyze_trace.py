@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-tile phase timeline of policy_step_kernel from an IC3_PS_TRACE build (see policy_step.hip):
+python tools/analyze_trace.py trace.csv  — s_memrealtime ticks are 10 ns."""
+import sys
+
+import numpy as np
+
+NAMES = ["start", "S0 loads", "S1 desc", "S2 encoder", "S3 enc->acc", "S4 h->LDS", "S5 comm+Bload", "S6 C product",
+         "S7 inp->LDS", "S8 gate loop", "settle", "cold loads+wait", "S9 epilogue", "S10 heads", "S11 draws",
+         "S12 env step", "patch wait", "patches"]
+
+
+def main(path):
+    d = np.loadtxt(path, delimiter=',', dtype=np.int64)
+    t = d[:, 1:19].astype(np.float64) * 0.01          # us
+    hw, xcc = d[:, 19], d[:, 20]
+    t0 = t[:, 0].min()
+    start, end = t[:, 0] - t0, t[:, 17] - t0
+    print("tiles %d, launch span %.1f us" % (len(d), end.max()))
+    cu = (xcc & 15) * 1024 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 32 + ((hw >> 8) & 15)   # xcc, se, sh, cu
+    print("distinct CUs seen: %d" % len(np.unique(cu)))
+    order = np.argsort(start)
+    dur = np.diff(t, axis=1)
+    life = end - start
+    rounds = [("first 512 by start", order[:512]), ("next 512", order[512:1024]), ("rest", order[1024:])]
+    for name, idx in rounds:
+        if len(idx) == 0:
+            continue
+        print("\n%s: n=%d start %.1f..%.1f us, lifetime mean %.1f us (min %.1f max %.1f)" %
+              (name, len(idx), start[idx].min(), start[idx].max(), life[idx].mean(), life[idx].min(), life[idx].max()))
+        for k in range(17):
+            print("   %-16s %6.2f us  (p10 %6.2f  p90 %6.2f)" % (NAMES[k + 1], dur[idx, k].mean(),
+                                                               np.percentile(dur[idx, k], 10), np.percentile(dur[idx, k], 90)))
+    # co-residency: for each tile of the last group, how many other tiles overlap it in time on the same CU
+    print("\nper-CU tile counts: min %d max %d" % (np.bincount(np.unique(cu, return_inverse=True)[1]).min(),
+                                                   np.bincount(np.unique(cu, return_inverse=True)[1]).max()))
+    inv = np.unique(cu, return_inverse=True)[1]
+    busy_end = np.zeros(inv.max() + 1)
+    for c in range(inv.max() + 1):
+        busy_end[c] = end[inv == c].max()
+    print("CU finish time: mean %.1f p10 %.1f p90 %.1f max %.1f us" % (busy_end.mean(), np.percentile(busy_end, 10),
+                                                                      np.percentile(busy_end, 90), busy_end.max()))
+    # phase skew between co-resident workgroups: tiles on the same CU whose lifetimes overlap
+    lags = []
+    for c in range(inv.max() + 1):
+        ids = np.where(inv == c)[0]
+        ids = ids[np.argsort(start[ids])]
+        for a, b in zip(ids[:-1], ids[1:]):
+            if start[b] < end[a]:
+                lags.append(t[b, 8] - t[a, 8])          # difference of gate-loop start times
+    lags = np.array(lags)
+    if len(lags):
+        print("gate-loop start lag between overlapping tiles of a CU: mean %.1f us, p10 %.1f, p50 %.1f, p90 %.1f (n=%d)" %
+              (lags.mean(), np.percentile(lags, 10), np.percentile(lags, 50), np.percentile(lags, 90), len(lags)))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
