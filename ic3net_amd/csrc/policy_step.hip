@@ -210,7 +210,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // Cache policy: non-temporal.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights
     // every tile streams from there: with plain stores (a -DIC3_PS_PLAIN_STORES build) the kernel takes 0.50 ms
     // instead of 0.38.
-    // (zmode +4: h' / c' stores nt; +8: h / c loads nt; +16: no L2 warm-up of c — experiments)
+    // (zmode +8: h loads nt; +16: no L2 warm-up of c; +32: rest of the zero fill right behind the loop — experiments)
     const int mis = (int)(((ob0 + ohead) >> 2) & 63);
     const int c_lo = mis ? 1 : 0, c_hi = (mis + onb) >> 6;       // full chunks: [c_lo, c_hi)
     const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -507,18 +507,22 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     {
         const float* lb = a.l_bias + tz;
         const float bi = lb[col], bf = lb[H + col], bg = lb[2 * H + col], bo = lb[3 * H + col];
+        // c / h rows of the tile through buffer descriptors: one 32-bit lane offset + a constant per element instead of
+        // a 64-bit address pair each, and the hardware range check (num_records = the tile's valid rows) stands in
+        // for the `row < rows` predicates — an out-of-range load returns 0, an out-of-range store is dropped.
+        const uint32_t nrec = (a.dbg & 16) ? 0u : (uint32_t)rows * H * 4u;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c + r0 * H), 0, nrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h + r0 * H), 0, nrec, 0x00020000);
+        const int voff = (4 * lh * H + col) * 4;
         float cold[2][16];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                const float* cp = a.c + (r0 + lr) * H + col;
-                cold[rt][reg] = (lr < rows && !(a.dbg & 16) && !(autor && fresh_row(lr)))
-                                    ? ((a.zmode & 8) ? __builtin_nontemporal_load(cp) : *cp) : 0.0f;
+                const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+                cold[rt][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, voff + lc * H * 4, 0, 0));
+                if (autor && fresh_row(lc + 4 * lh)) cold[rt][reg] = 0.0f;
             }
-        // loads complete in order: this is the wait the first use of cold[] needs anyway
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
         __syncthreads();   // every wave is done with the A tile
         IC3_TR(11);
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
@@ -536,19 +540,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 const float h1 = fast_sigmoid(go) * fast_tanh(c1);
                 zero_store();                      // what the gate loop left of the zero fill goes out between the
                 zero_store();                      // transcendental work of the cell (2 x 32 slots, then the rest)
-                if (lr < rows && !(a.dbg & 16)) {
-                    if (a.zmode & 4) {
-                        __builtin_nontemporal_store(c1, a.c + (r0 + lr) * H + col);
-                        __builtin_nontemporal_store(h1, a.h + (r0 + lr) * H + col);
-                    } else {
-                        a.c[(r0 + lr) * H + col] = c1;
-                        a.h[(r0 + lr) * H + col] = h1;
-                    }
-                }
+                const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
                 As[lr * LDA + H + col] = h1;
             }
         }
         while (zleft > 0) zero_store();            // obs-dominated shapes
+        // the warm-up load's destination stayed reserved up to here: memory operations complete in order, so it landed
+        // before the first cold[] value (requested after it) was consumed
+        asm volatile("" : : "v"(sink));
     }
     __syncthreads();
     IC3_TR(12);

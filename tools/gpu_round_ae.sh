@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r02ae
+O=gpurun_out/r02af
 mkdir -p $O
 run() { name=$1; shift; timeout 300 env "$@" > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
 import json,sys
