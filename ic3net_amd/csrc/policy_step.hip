@@ -559,27 +559,23 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
     constexpr int PER = H / 16;
     {
+        // lane (row, part) owns the float4 columns {q * NW + part}: the NW lanes of a row read consecutive float4s
+        // (no LDS bank conflicts; `8 * part + q` put all of them on the same banks), weight reads are broadcasts
         const int row = tid / NW, part = tid - row * NW;
-        float z[16];
+        ps_f32x4 x[8];
 #pragma unroll
-        for (int o = 0; o < 16; ++o) z[o] = 0.0f;
+        for (int q = 0; q < 8; ++q) x[q] = As4[row * LDA4 + H4 + q * NW + part];
+        float* zrow = As + (16 + row / PER) * LDA + (row % PER) * 16;
+#pragma unroll 1
+        for (int o = 0; o < a.OT; ++o) {
+            float z = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const ps_f32x4 x = As4[row * LDA4 + H4 + 8 * part + q];
-#pragma unroll
-            for (int o = 0; o < 16; ++o) {
-                if (o < a.OT) {
-                    const ps_f32x4 wv = As4[o * LDA4 + 8 * part + q];
-                    z[o] += x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w;
-                }
+            for (int q = 0; q < 8; ++q) {
+                const ps_f32x4 wv = As4[o * LDA4 + q * NW + part];
+                z += x[q].x * wv.x + x[q].y * wv.y + x[q].z * wv.z + x[q].w * wv.w;
             }
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            if (o < a.OT) {
-                z[o] = group_sum<NW>(z[o]);
-                if (part == 0) As[(16 + row / PER) * LDA + (row % PER) * 16 + o] = z[o] + a.head_b[o + tz];
-            }
+            z = group_sum<NW>(z);
+            if (part == 0) zrow[o] = z + a.head_b[o + tz];
         }
     }
     __syncthreads();

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r02af
+O=gpurun_out/r02ag
 mkdir -p $O
 run() { name=$1; shift; timeout 300 env "$@" > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
 import json,sys
@@ -14,7 +14,7 @@ PY
 }
 B="python bench.py --no-cpu-baseline --steps 160 --warmup 16"
 L=$PWD/ic3net_amd/csrc
-timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $O/tests.log 2>&1
+timeout 1200 python -m pytest tests/test_policy_step_gpu.py tests/test_policy_gpu.py tests/test_trainer_gpu.py -q -x -p no:cacheprovider > $O/tests.log 2>&1
 tail -n 2 $O/tests.log
 run warm    $B
 run base_1  $B
