@@ -3,7 +3,7 @@
 // per-agent reward and comm-action sums, for n lock-step slots of E envs, as ONE launch over the episode buffers the
 // step launches wrote ([T][E] / [T][E][N], step-major).  One thread per (env, agent) walks the n slots (its env's
 // `done` history is a running product), so every access is coalesced across the (env, agent) index; the sums are
-// reduced in a fixed order (block partials, then the last block to finish), so the statistics are reproducible.
+// reduced in a fixed order (block partials, then a one-block launch over them), so the statistics are reproducible.
 #include <hip/hip_runtime.h>
 
 #include "ic3_common.hpp"
@@ -14,11 +14,13 @@ constexpr int EF_THREADS = 256;
 
 // stats layout: [0] num_steps (sum of live), [1] envs whose last held slot has done set, [2, 2+N) reward sums,
 // [2+N, 2+2N) gate (comm_action) sums
-__global__ __launch_bounds__(EF_THREADS) void episode_finalize_kernel(ic3_episode a, int epb /* envs per block */, int nblocks)
+// INFO: alive / is_completed present (TJ); GATE: talk-head actions present — compile-time so that every load of a batch
+// is unconditional (a load under a branch is followed by its own s_waitcnt: one round trip per load)
+template <bool INFO, bool GATE>
+__global__ __launch_bounds__(EF_THREADS) void episode_finalize_kernel(ic3_episode a, int epb /* envs per block */)
 {
     __shared__ double sh[EF_THREADS][2];
     __shared__ double shn[EF_THREADS][2];
-    __shared__ int last_block;
     const int tid = threadIdx.x, N = a.N, E = a.E, n = a.n;
     const int el = tid / N, ag = tid - el * N;
     const int e = blockIdx.x * epb + el;
@@ -28,24 +30,49 @@ __global__ __launch_bounds__(EF_THREADS) void episode_finalize_kernel(ic3_episod
         const size_t EN = (size_t)E * N;
         const size_t en = (size_t)e * N + ag;
         float live = 1.0f;
-        for (int t = 0; t < n; ++t) {
-            const bool d = a.done[(size_t)t * E + e] != 0;
-            const bool done_t = d || (a.forced_last && t == n - 1);            // trainer.py:90
-            const size_t i = (size_t)t * EN + en;
-            const float al = a.alive ? (float)a.alive[i] : 1.0f;                // trainer.py:78-81
-            a.alive_mask[i] = al * live;
-            float mini = 1.0f;                                                  // trainer.py:98-99 (only when not done, Q26)
-            if (a.is_completed && !done_t) mini = 1.0f - (float)a.is_completed[i];
-            a.episode_mini_mask[i] = mini;
-            rsum += (double)a.reward[i];                                        // trainer.py:86
-            if (a.gate_ones) gsum += (double)live;                              // trainer.py:73-75
-            else if (a.gate) gsum += (double)((float)a.gate[(size_t)t * a.gate_stride + en] * live);
-            if (ag == 0) {
-                a.live[(size_t)t * E + e] = live;
-                a.episode_mask[(size_t)t * E + e] = done_t ? 0.0f : 1.0f;        // trainer.py:92-96
-                steps += (double)live;                                          // trainer.py:109-110
+        // slots in batches of TB: all loads of a batch are issued before its first store (the compiler cannot move a
+        // load above a store through these pointers, and one slot per round trip made the launch latency-bound: 218 us
+        // for 20 x 8192 x 10 transitions)
+        constexpr int TB = 5;
+        for (int t0 = 0; t0 < n; t0 += TB) {
+            int dn[TB], alv[TB], cmp[TB], gt[TB];
+            float rw[TB];
+#pragma unroll
+            for (int k = 0; k < TB; ++k) {
+                const int tc = min(t0 + k, n - 1);                 // slots past the end re-read the last one (ignored)
+                const size_t i = (size_t)tc * EN + en;
+                dn[k] = a.done[(size_t)tc * E + e];
+                alv[k] = 1;
+                cmp[k] = 0;
+                gt[k] = 0;
+                if constexpr (INFO) {
+                    alv[k] = a.alive[i];
+                    cmp[k] = a.is_completed[i];
+                }
+                rw[k] = a.reward[i];
+                if constexpr (GATE) gt[k] = a.gate[(size_t)tc * a.gate_stride + en];
             }
-            if (!a.auto_reset && d) live = 0.0f;     // lock-step: a finished env idles (auto-reset: every slot is real)
+#pragma unroll
+            for (int k = 0; k < TB; ++k) {
+                const int t = t0 + k;
+                if (t >= n) break;
+                const bool d = dn[k] != 0;
+                const bool done_t = d || (a.forced_last && t == n - 1);            // trainer.py:90
+                const size_t i = (size_t)t * EN + en;
+                a.alive_mask[i] = (float)alv[k] * live;                             // trainer.py:78-81
+                float mini = 1.0f;                                                  // trainer.py:98-99 (only when not done, Q26)
+                if (INFO && !done_t) mini = 1.0f - (float)cmp[k];
+                a.episode_mini_mask[i] = mini;
+                rsum += (double)rw[k];                                              // trainer.py:86
+                if (a.gate_ones) gsum += (double)live;                              // trainer.py:73-75
+                else if (GATE) gsum += (double)((float)gt[k] * live);
+                if (ag == 0) {
+                    a.live[(size_t)t * E + e] = live;
+                    a.episode_mask[(size_t)t * E + e] = done_t ? 0.0f : 1.0f;        // trainer.py:92-96
+                    steps += (double)live;                                          // trainer.py:109-110
+                }
+                if (!a.auto_reset && d) live = 0.0f;     // lock-step: a finished env idles (auto-reset: every slot is real)
+            }
         }
         if (ag == 0) {
             const bool dl = n > 0 && a.done[(size_t)(n - 1) * E + e] != 0;
@@ -83,18 +110,49 @@ __global__ __launch_bounds__(EF_THREADS) void episode_finalize_kernel(ic3_episod
         part[0] = s;
         part[1] = z;
     }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) last_block = (atomicAdd(a.counter, 1) == nblocks - 1);
-    __syncthreads();
-    if (!last_block) return;
-    __threadfence();
-    for (int k = tid; k < 2 + 2 * N; k += EF_THREADS) {      // fixed order over the blocks
+}
+
+// Second launch (one block): a kernel boundary publishes the block partials; a device-scope fence per block inside the
+// first launch wrote back the whole L2 each time (the masks it had just stored) and made it 5x slower.
+__global__ __launch_bounds__(EF_THREADS) void episode_reduce_kernel(ic3_episode a, int nblocks)
+{
+    __shared__ double sh[EF_THREADS][2];
+    const int tid = threadIdx.x, N = a.N;
+    // fixed-order sum over the blocks: the block range is cut into `nseg` segments summed by different threads with
+    // several loads in flight (one thread per value walking all blocks took ~200 us of serialised load latency),
+    // then the segment sums are added in order
+    const int KK = 2 + 2 * N;
+    const int nseg = KK <= EF_THREADS ? EF_THREADS / KK : 1;
+    const int per = (nblocks + nseg - 1) / nseg;
+    double* segsum = &sh[0][0];                              // [nseg][KK] when KK <= EF_THREADS (2 * EF_THREADS doubles)
+    for (int k0 = 0; k0 < KK; k0 += EF_THREADS) {
+        const int k = k0 + (KK <= EF_THREADS ? tid % KK : tid), seg = KK <= EF_THREADS ? tid / KK : 0;
         double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += __builtin_nontemporal_load(a.scratch + (size_t)b * (2 + 2 * N) + k);
-        a.stats[k] = v;
+        if (k < KK && seg < nseg) {
+            const int b0 = seg * per, b1 = min(nblocks, b0 + per);
+            constexpr int U = 8;
+            for (int b = b0; b < b1; b += U) {
+                double x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    x[u] = (b + u < b1) ? __builtin_nontemporal_load(a.scratch + (size_t)(b + u) * KK + k) : 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) v += x[u];
+            }
+        }
+        if (KK <= EF_THREADS) {
+            __syncthreads();
+            if (seg < nseg) segsum[seg * KK + k] = v;
+            __syncthreads();
+            if (tid < KK) {
+                double t = 0.0;
+                for (int sg = 0; sg < nseg; ++sg) t += segsum[sg * KK + tid];
+                a.stats[tid] = t;
+            }
+        } else if (k < KK) {
+            a.stats[k] = v;
+        }
     }
-    if (tid == 0) *a.counter = 0;                            // ready for the next call
 }
 
 }  // namespace ic3
@@ -119,11 +177,21 @@ int ic3_episode_finalize(const ic3_episode* ep, ic3_stream stream)
     if (a.E <= 0 || a.N <= 0 || a.n < 0) return fail(-22, "ic3_episode_finalize: bad sizes");
     if (a.N > EF_THREADS) return fail(-22, "ic3_episode_finalize: more than 256 agents per env");
     if (!a.done || !a.reward || !a.live || !a.alive_mask || !a.episode_mask || !a.episode_mini_mask || !a.live_after ||
-        !a.stats || !a.scratch || !a.counter)
+        !a.stats || !a.scratch)
         return fail(-22, "ic3_episode_finalize: null buffer");
     const int epb = EF_THREADS / a.N;
     const int nblocks = (a.E + epb - 1) / epb;
-    hipLaunchKernelGGL(episode_finalize_kernel, dim3(nblocks), dim3(EF_THREADS), 0, (hipStream_t)stream, a, epb, nblocks);
+    if ((a.alive == nullptr) != (a.is_completed == nullptr))
+        return fail(-22, "ic3_episode_finalize: alive and is_completed come together (both or neither)");
+    const bool info = a.alive != nullptr, gate = a.gate != nullptr && !a.gate_ones;
+    const dim3 grid(nblocks), block(EF_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (info && gate) hipLaunchKernelGGL((episode_finalize_kernel<true, true>), grid, block, 0, st, a, epb);
+    else if (info) hipLaunchKernelGGL((episode_finalize_kernel<true, false>), grid, block, 0, st, a, epb);
+    else if (gate) hipLaunchKernelGGL((episode_finalize_kernel<false, true>), grid, block, 0, st, a, epb);
+    else hipLaunchKernelGGL((episode_finalize_kernel<false, false>), grid, block, 0, st, a, epb);
+    IC3_HIP(hipGetLastError());
+    hipLaunchKernelGGL(episode_reduce_kernel, dim3(1), dim3(EF_THREADS), 0, (hipStream_t)stream, a, nblocks);
     IC3_HIP(hipGetLastError());
     return 0;
 }

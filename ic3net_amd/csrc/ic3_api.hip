@@ -58,34 +58,22 @@ __global__ __launch_bounds__(256) void stats_kernel(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ acc, double* __restrict__ out, int E,
                                                     int invert)
 {
-    __shared__ double sh[2][4];
-    double a = 0.0, b = 0.0;
+    __shared__ double sh[5][4];
+    double v[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };   // flag, t, and the sums over the episodes that ended inside step launches
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
         const int f = flag[e];
-        a += (double)(invert ? 1 - f : f);
-        b += (double)tstep[e];
-    }
-    if (blockIdx.x == 0) {   // sums over the episodes that ended inside step launches (auto-reset): acc[3][E]
-        for (int k = 0; k < 3; ++k) {
-            double v = 0.0;
-            for (int e = threadIdx.x; e < E; e += blockDim.x) v += (double)acc[(size_t)k * E + e];
-            atomicAdd(&out[2 + k], v);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_down(a, o);
-        b += __shfl_down(b, o);
+        v[0] += (double)(invert ? 1 - f : f);
+        v[1] += (double)tstep[e];
+        for (int k = 0; k < 3; ++k) v[2 + k] += (double)acc[(size_t)k * E + e];     // (auto-reset): acc[3][E]
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-        sh[0][wave] = a;
-        sh[1][wave] = b;
+    for (int k = 0; k < 5; ++k) {
+        double x = v[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if (lane == 0) sh[k][wave] = x;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&out[0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-        atomicAdd(&out[1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-    }
+    if (threadIdx.x < 5) atomicAdd(&out[threadIdx.x], sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
 int env_stats(ic3_env* env, ic3_stats* out, hipStream_t s)

@@ -48,6 +48,7 @@ class Trainer(object):
         self._episodes_played = 0
         self._static = None
         self._fin_work = dict()         # scratch of ic3_episode_finalize
+        self._reset_takes_epoch = None
         # encoder(obs) as a sparse gather from env state (ic3_env_encode) instead of a dense obs_dim x H GEMM;
         # the dense observation is still assembled by env.step (API contract / store_states).
         if getattr(args, 'sparse_encoder', True) and hasattr(policy_net, 'obs_encoder') \
@@ -84,7 +85,9 @@ class Trainer(object):
         if raw0 is not None and hasattr(raw0, '_h'):
             raw0.skip_reset_obs = bool(getattr(self, '_mega_last', False) and self._fused_obs() and self._dense_obs()
                                        and not getattr(args, 'store_states', False))
-        if 'epoch' in signature(self.env.reset).parameters:        # trainer.py:28-32
+        if self._reset_takes_epoch is None:                        # (inspect.signature costs ~0.1 ms: once)
+            self._reset_takes_epoch = 'epoch' in signature(self.env.reset).parameters
+        if self._reset_takes_epoch:                                # trainer.py:28-32
             state = self.env.reset(epoch)
         else:
             state = self.env.reset()

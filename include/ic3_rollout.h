@@ -208,7 +208,8 @@ int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream);
  *                         (trainer.py:86), [2+N, 2+2N) per-agent comm-action sums over live slots (trainer.py:73-75;
  *                         gate == NULL and !gate_ones: zeros), fp64, summed in a fixed order.
  * alive / is_completed may be NULL (PP: all ones / not reported).  scratch: ic3_episode_scratch_bytes(E, N) bytes;
- * counter: one int32 that is 0 before the first call (the launch leaves it at 0).  Asynchronous on `stream`. */
+ * counter: reserved (may be NULL).  Two launches (derivations + block partials, then a one-block fixed-order
+ * reduction); asynchronous on `stream`. */
 typedef struct ic3_episode {
     int32_t n, E, N;
     int32_t auto_reset, forced_last, gate_ones;
