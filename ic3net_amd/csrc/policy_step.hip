@@ -292,8 +292,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         hv[i] = (row < rows && !(autor && fresh_row(row))) ? ((a.zmode & 8) ? __builtin_nontemporal_load(hp) : *hp)
                                                            : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
     }
-    // (zb = 0 by default: zero stores in front of the gate loop delay the loads of the phases here — memory operations
-    // of a wave complete in order; IC3_PS_ZB keeps the experiment)
+    // (a few zero stores per burst in front of the gate loop, see the pacing notes in ic3_policy_step)
     zero_burst(a.zb);
     __syncthreads();
     IC3_TR(1);
@@ -940,7 +939,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
             a.zl = 0;
             for (int j = 0; j < 4; ++j) a.zl |= (int)((want + 3 - j) / 4) << (4 * j);
         }
-        a.zb = zb_env >= 0 ? zb_env : 0;                         // per burst between the phases in front of the loop
+        // per burst between the five phases in front of the loop: 3 % of the tile's stores each (PP-hard: 7 of 228 per
+        // thread; 0.327 -> 0.314 ms; more — or any, before the phases there lost their spills and scans — delays the
+        // loads of those phases: memory operations of a wave complete in order)
+        a.zb = zb_env >= 0 ? zb_env : (int)((per_thread * 3 + 50) / 100);
         if (a.zb > 48) a.zb = 48;
     }
     hipStream_t s = (hipStream_t)stream;
