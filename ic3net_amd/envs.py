@@ -11,6 +11,8 @@ info['alive_mask'] / info['is_completed'] (E, N) int32.
 import ctypes as C
 
 import numpy as np
+
+from . import render as _render
 import torch
 
 from . import _lib, spaces
@@ -286,19 +288,14 @@ class PredatorPreyEnv(_BatchedEnv):
                 ("episode", (E,)), ("t", (E,)), ("acc_success", (E,)), ("acc_episodes", (E,)), ("acc_steps", (E,))]
 
     def render(self, mode='human', close=False, env_index=0):
-        """Debug view of ONE env from a state readback (the reference draws the same grid with curses,
-        PP:307-336): 'X' predator, 'P' prey, a leading count when several share a cell, '0' empty."""
+        """ONE env from a state readback, drawn the way the reference does with curses (PP:307-336): mode='cells' returns
+        the draw calls `[row, x, text, color_pair]` (ic3net_amd/render.py, pinned to the reference's own drawing),
+        'ansi' their text block, 'human' prints it."""
         st = self.get_state()
-        dim, N = self.dim, self.npredator
-        cells = [['0'] * dim for _ in range(dim)]
-        marks = {}
-        for i in range(N + self.nprey):
-            key = (int(st['loc_r'][env_index, i]), int(st['loc_c'][env_index, i]))
-            marks.setdefault(key, []).append('X' if i < N else 'P')
-        for (r, c), m in marks.items():
-            nx, npr = m.count('X'), m.count('P')
-            cells[r][c] = (str(nx) if nx > 1 else '') + ('X' if nx else '') + ('P' if npr else '')
-        text = _grid_to_text(cells)
+        calls = _render.pp_cells(st['loc_r'][env_index], st['loc_c'][env_index], self.npredator, self.dim)
+        if mode == 'cells':
+            return calls
+        text = _render.cells_to_text(calls)
         if mode == 'human':
             print(text + "\n")
         return text
@@ -398,25 +395,19 @@ class TrafficJunctionEnv(_BatchedEnv):
         return grid, off, rc.reshape(-1, 2)
 
     def render(self, mode='human', close=False, env_index=0):
-        """Debug view of ONE env (the reference's curses drawing, TJ:254-292, as text): '_' road, '<>' car that last
-        moved, '<b>' car that last braked, a count prefix when cars share a cell (a crash)."""
+        """ONE env from a state readback, drawn the way the reference does with curses (TJ:254-292, including its
+        quirks: an easy-difficulty road whose id equals OUTSIDE_CLASS shows as blank, dead cars sit on the never-drawn
+        cell (0, 0)): mode='cells' / 'ansi' / 'human' as for Predator-Prey."""
         st = self.get_state()
         grid, _, _ = self.tables()
-        h, w = grid.shape
-        road = (grid != self.OUTSIDE_CLASS) if self.vocab_type == 'bool' else (grid == 1)
-        if self.vocab_type == 'bool' and self.difficulty == 'easy':
-            road = np.zeros_like(road)
-            road[h // 2, :] = True
-            road[:, w // 2] = True                        # quirk Q9: an easy road id equals OUTSIDE_CLASS
-        cells = [['_' if road[r, c] else '' for c in range(w)] for r in range(h)]
-        marks = {}
-        for i in range(self.ncar):
-            if st['alive'][env_index, i]:
-                key = (int(st['loc_r'][env_index, i]), int(st['loc_c'][env_index, i]))
-                marks.setdefault(key, []).append('<b>' if st['last_act'][env_index, i] else '<>')
-        for (r, c), m in marks.items():
-            cells[r][c] = (str(len(m)) if len(m) > 1 else '') + m[0]
-        text = _grid_to_text(cells)
+        if self.vocab_type != 'bool':
+            grid = np.where(grid == 1, 1, self.OUTSIDE_CLASS)      # the uploaded scalar-vocab grid holds road flags
+        dead = st['alive'][env_index] == 0                         # TJ:566-567: a car that left is parked on (0, 0)
+        calls = _render.tj_cells(grid.tolist(), self.OUTSIDE_CLASS, np.where(dead, 0, st['loc_r'][env_index]),
+                                 np.where(dead, 0, st['loc_c'][env_index]), st['last_act'][env_index])
+        if mode == 'cells':
+            return calls
+        text = _render.cells_to_text(calls)
         if mode == 'human':
             print(text + "\n")
         return text

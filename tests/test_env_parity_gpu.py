@@ -387,18 +387,24 @@ def test_tj_scalar_vocab_vs_oracle_and_encoder():
     assert set(np.unique(grid)) == {0, 1}                      # the reference's self.grid holds road flags here
 
 
-def test_render_text_views():
-    env = make_pp(2, 3, 0, "mixed", 2, seed=0)
+def test_render_views_follow_the_reference_drawing():
+    """env.render() of a state set through the handle == the draw calls the reference's curses code makes for that state
+    (tests/golden/render_fixture.json, recorded from predator_prey_env.py:307-336 / traffic_junction_env.py:254-292)."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'render_fixture.json')))
+    pp = [o for o in fx if o['env'] == 'pp' and o['N'] == 3]
+    env = make_pp(3, 5, 1, "mixed", len(pp), seed=0)
     env.reset()
-    env.set_state(loc_r=[[0, 0, 2], [1, 1, 1]], loc_c=[[0, 0, 1], [0, 2, 2]])
-    txt = env.render(mode='ansi', env_index=0).split("\n")
-    assert [c.strip() for c in txt[0].split("  ") if c.strip()][0] == '2X' and 'P' in txt[2]
-    assert 'XP' in env.render(mode='ansi', env_index=1)
-    tj = make_tj(5, 6, 0, "easy", 2, seed=1, add_rate_min=1.0, add_rate_max=1.0)
-    tj.reset(0)
-    tj.step(np.zeros((2, 5), np.int32))
-    t = tj.render(mode='ansi')
-    assert '<>' in t and '_' in t
+    env.set_state(loc_r=[o['loc_r'] for o in pp], loc_c=[o['loc_c'] for o in pp])
+    for k, o in enumerate(pp):
+        assert env.render(mode='cells', env_index=k) == o['cells']
+    assert 'XXXP' in env.render(mode='ansi', env_index=1)
+    for o in [o for o in fx if o['env'] == 'tj' and o['difficulty'] in ('medium', 'hard')][::3]:
+        tj = make_tj(o['N'], o['dim'], o['vision'], o['difficulty'], 1, seed=1)
+        tj.reset(0)
+        tj.set_state(alive=[o['alive']], loc_r=[o['loc_r']], loc_c=[o['loc_c']], last_act=[o['last_act']])
+        assert tj.render(mode='cells') == o['cells'], (o['difficulty'], o['t'])
 
 
 def test_max_agents_per_env_vs_oracle():
