@@ -96,7 +96,8 @@ struct StepArgs {
     int32_t* action;            // [nheads][R]
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
     int obs_dim;                // floats per observation row
-    int ntiles;                 // tiles; a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    int ntiles;                 // workgroups = tiles: n_full tiles of EPT envs, then half tiles of EPTh envs
+    int n_full, EPTh;
     // env
     int E, N, EPT, G;
     int auto_reset;             // env handle in auto-reset mode: an env with t == 0 starts an episode (h = c = 0, gate 0)
@@ -183,9 +184,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     constexpr int tz = 0;
     const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li;
-    const int e0 = tile_id * a.EPT;
-    const int nenv = min(a.EPT, a.E - e0);
-    const int rows = nenv * N;                                   // valid rows of this tile (<= 64)
+    // full tiles first; the envs left over behind the last round that gives every CU the same number of them go out as
+    // HALF tiles (<= 32 rows: one 32-row MFMA tile, half the matrix work) — see plan_tiles()
+    const bool half = tile_id >= a.n_full;
+    const int e0 = half ? a.n_full * a.EPT + (tile_id - a.n_full) * a.EPTh : tile_id * a.EPT;
+    const int nenv = min(half ? a.EPTh : a.EPT, a.E - e0);
+    const int rows = nenv * N;                                   // valid rows of this tile (<= 64; <= 32 in a half tile)
+    const bool two = rows > 32;                                  // second 32-row MFMA tile in use (workgroup-uniform)
     const size_t r0 = (size_t)e0 * N;
 
     // ---- dense observation of the state this step acts on (the `state` the reference hands to policy_net,
@@ -331,12 +336,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------------------------------------------------
     ps_f32x16 accC[2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 2; ++rt) {
+        if (rt == 1 && !two) break;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             accC[rt][reg] = As[lr * LDA + H + col];
         }
+    }
     __syncthreads();
     IC3_TR(4);
 
@@ -380,8 +387,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __syncthreads();
         IC3_TR(6);
         // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
-        auto cprod = [&]() {
-            constexpr bool TWO = true;
+        auto cprod = [&](auto two_c) {
+            constexpr bool TWO = decltype(two_c)::value;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) {
@@ -403,7 +410,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         };
-        if (!(a.dbg & 2)) cprod();
+        if (!(a.dbg & 2)) {
+            if (two) cprod(std::true_type{});
+            else cprod(std::false_type{});
+        }
         mfma_settle();
         __syncthreads();   // every wave has read the comm tile
         IC3_TR(7);
@@ -425,12 +435,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     zero_burst(a.zb);
     // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------------
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 2; ++rt) {
+        if (rt == 1 && !two) break;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             As[lr * LDA + col] = accC[rt][reg];
         }
+    }
     __syncthreads();
     IC3_TR(8);
 
@@ -442,16 +454,18 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
-    auto block = [&](const ps_f32x4 (&bq)[4], int kb) {
+    auto block = [&](auto two_c, const ps_f32x4 (&bq)[4], int kb) {
+        constexpr bool TWO = decltype(two_c)::value;
         const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-        const ps_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+        ps_f32x4 a1;
+        if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nz = (a.zl >> (4 * j)) & 15;               // wave-uniform, loop-invariant
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 mfma_acc(acc[0][g], a0[j], bq[g][j]);
-                mfma_acc(acc[1][g], a1[j], bq[g][j]);
+                if constexpr (TWO) mfma_acc(acc[1][g], a1[j], bq[g][j]);
                 // the scalar bookkeeping of a store slot fits into the 64-cycle shadow of one MFMA: one slot after
                 // the 4th and one after the 8th of a k sub-step rather than both at its end
                 if (g == 1 && nz > 1) zero_store();
@@ -461,42 +475,45 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int i = 2; i < nz; ++i) zero_store();
         }
     };
-    static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
-    // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
-    // their first use, which exposes the full L2 latency every block).
-    const int kb_end = (a.dbg & 1) ? 0 : KB - 2;
-#pragma unroll 1
-    for (int kb = 0; kb < kb_end; kb += 2) {
-        block(b0, kb);
+    float sink = 0.0f;   // destination of the L2 warm-up load of c (see below)
+    auto gate_loop = [&](auto two_c) {
+        static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
+        // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
+        // their first use, which exposes the full L2 latency every block).
+        const int kb_end = (a.dbg & 1) ? 0 : KB - 2;
+    #pragma unroll 1
+        for (int kb = 0; kb < kb_end; kb += 2) {
+            block(two_c, b0, kb);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+            __builtin_amdgcn_sched_barrier(0);
+            block(two_c, b1, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the old cell state: one touch per 128 B line of this wave's (64 rows x 32 columns) before the last two blocks
+        // (64 MFMAs) brings it from HBM into the L2 under them; the epilogue's loads then hit there.  (Holding the values
+        // themselves over the two blocks costs 32 registers the loop does not have.)
+        // The load's destination register stays reserved until the epilogue has waited for it (the compiler does not
+        // know that an asm load completes later).
+        const bool warm_c = !(a.zmode & 16) && lane < rows && !(a.dbg & 16);
+        if (warm_c) {
+            const float* cp = a.c + (r0 + lane) * H + 32 * w;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(cp) : "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
-        __builtin_amdgcn_sched_barrier(0);
-        block(b1, kb + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // the old cell state: one touch per 128 B line of this wave's (64 rows x 32 columns) before the last two blocks
-    // (64 MFMAs) brings it from HBM into the L2 under them; the epilogue's loads then hit there.  (Holding the values
-    // themselves over the two blocks costs 32 registers the loop does not have.)
-    // The load's destination register stays reserved until the epilogue has waited for it (the compiler does not
-    // know that an asm load completes later).
-    float sink = 0.0f;
-    const bool warm_c = !(a.zmode & 16) && lane < rows && !(a.dbg & 16);
-    if (warm_c) {
-        const float* cp = a.c + (r0 + lane) * H + 32 * w;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(cp) : "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(a.dbg & 1)) {
-        block(b0, KB - 2);
-        __builtin_amdgcn_sched_barrier(0);
-        block(b1, KB - 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
+        if (!(a.dbg & 1)) {
+            block(two_c, b0, KB - 2);
+            __builtin_amdgcn_sched_barrier(0);
+            block(two_c, b1, KB - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (two) gate_loop(std::true_type{});
+    else gate_loop(std::false_type{});
     IC3_TR(9);
     mfma_settle();
     IC3_TR(10);
@@ -515,13 +532,15 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const int voff = (4 * lh * H + col) * 4;
         float cold[2][16];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt) {
+            if (rt == 1 && !two) break;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
                 cold[rt][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, voff + lc * H * 4, 0, 0));
                 if (autor && fresh_row(lc + 4 * lh)) cold[rt][reg] = 0.0f;
             }
+        }
         __syncthreads();   // every wave is done with the A tile
         IC3_TR(11);
         for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
@@ -530,6 +549,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
+            if (rt == 1 && !two) break;              // half tile: rows 32..63 are padding (their h' is never read)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
@@ -714,12 +734,47 @@ static int resident_workgroups(int H)
     return cus * (H <= 128 ? 2 : 1);
 }
 
-// Tile plan (a.E, a.N, a.EPT set): tiles of EPT whole envs.  (A tail of half-size tiles — one 32-row MFMA tile each — for
-// the envs left over after the last full round of resident workgroups was tried: no change in step time, removed.)
+// Tile plan (a.E, a.N, a.EPT set).  Two workgroups share a CU and all tiles cost the same, so a launch whose tile count
+// is not a multiple of the slot count ends with a round in which some CUs still hold two tiles while others hold one
+// or none (PP-hard: 1366 tiles = 2.67 rounds of 512 slots cost 3).  Plan B: as many FULL tiles (EPT envs, two 32-row
+// MFMA tiles) as give every CU the same number, the rest as HALF tiles (EPTh = floor(32 / N) envs, one MFMA tile) that
+// are dispatched last and land next to a CU's last full tile (or alone).  A half tile is not half the time — the phases
+// around the MFMA loops and the weight stream stay — so plan B is chosen only when a cost model calibrated on PP-hard /
+// TJ-hard / E = 384 says it ends earlier: pair of full tiles 1.0, full + half 0.91, pair of halves 0.70, lone full
+// 0.6, lone half 0.47 (PP-hard 0.321 -> 0.311 ms, TJ-medium 0.297 -> 0.290; TJ-hard and PP-easy stay with plan A).
+// IC3_PS_HALF=0 / 1 forces plan A / B.
+static double tiles_cost(int k_full, int k_half)
+{
+    double c = (k_full / 2) * 1.0;
+    if (k_full & 1) {
+        if (k_half > 0) {
+            c += 0.91;
+            --k_half;
+        } else {
+            c += 0.6;
+        }
+    }
+    return c + (k_half / 2) * 0.70 + (k_half & 1) * 0.47;
+}
+
 static int plan_tiles(StepArgs& a, int H)
 {
-    (void)H;
-    a.ntiles = (a.E + a.EPT - 1) / a.EPT;
+    static const int force = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : -1;
+    const int cus = resident_workgroups(H) / (H <= 128 ? 2 : 1);
+    const int n_all = (a.E + a.EPT - 1) / a.EPT;
+    a.EPTh = 32 / a.N;
+    a.n_full = n_all;
+    a.ntiles = n_all;
+    if (a.EPTh < 1 || H > 128 || force == 0) return a.ntiles;
+    const int n_full = (a.E / a.EPT) / cus * cus;               // every CU the same number of full tiles
+    const int rem = a.E - n_full * a.EPT;
+    const int n_half = (rem + a.EPTh - 1) / a.EPTh;
+    const double cost_a = tiles_cost((n_all + cus - 1) / cus, 0);
+    const double cost_b = tiles_cost(n_full / cus, (n_half + cus - 1) / cus);
+    if (force == 1 || cost_b < cost_a - 1e-9) {
+        a.n_full = n_full;
+        a.ntiles = n_full + n_half;
+    }
     return a.ntiles;
 }
 
