@@ -455,6 +455,32 @@ __device__ __forceinline__ int2 tj_tab_entry(const TJTile& t, const TJState& s, 
     return make_int2(id, ncar);
 }
 
+// The non-zero entries of ONE env's observation rows (TJ:331-344,352-356) on top of a zero-filled chunk: item q < N is
+// the header of car q's row, item N + a * WW + cell one window cell of car a's row (<= 2 entries: the one-hot id and the
+// car count).  Rows of dead cars stay zero.  `env_rows` = first float of the env's N rows.
+__device__ __forceinline__ void tj_obs_patch(const TJTile& t, const TJState& s, float* __restrict__ env_rows, int obs_dim,
+                                             int WW, int q)
+{
+    const int N = s.N;
+    if (q < N) {                                     // header of car q's row (TJ:338-344)
+        if (!t.sal[q]) return;
+        float* row = env_rows + (size_t)q * obs_dim;
+        row[0] = t.s0[q];
+        row[1] = t.s1[q];
+        if (s.hdr == 4) {
+            row[2] = t.s2[q];
+            row[3] = t.s3[q];
+        }
+    } else {                                         // window cell (TJ:331-332,352-356)
+        const int qq = q - N, car = div_small(qq, 1.0f / (float)WW), cellx = qq - car * WW;
+        if (!t.sal[car]) return;
+        const int2 d = t.tab[qq];
+        float* cell = env_rows + (size_t)car * obs_dim + s.hdr + (size_t)cellx * s.vocab;
+        if (d.x >= 0) cell[d.x] = 1.f + (d.x == s.car_class ? (float)d.y : 0.f);
+        if (d.x != s.car_class && d.y != 0) cell[s.car_class] = (float)d.y;
+    }
+}
+
 // encoder(obs row of car a)[4*c4 ..] (see tj_encode_kernel): bias only for a dead car (its obs row is zero)
 __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
                                                   const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,

@@ -683,24 +683,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int obs_dim = a.obs_dim;
             for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
                 const int el = div_small(sg, 1.0f / (float)(nsegE + N)), q = sg - el * (nsegE + N);
-                const TJTile t = tj_tile_at(tile + el * tjw, N);
-                if (q < N) {                                     // header of car q's row (TJ:338-344)
-                    if (!t.sal[q]) continue;
-                    float* row = orow0 + ((size_t)el * N + q) * obs_dim;
-                    row[0] = t.s0[q];
-                    row[1] = t.s1[q];
-                    if (a.tj.hdr == 4) {
-                        row[2] = t.s2[q];
-                        row[3] = t.s3[q];
-                    }
-                } else {                                         // window cell (TJ:331-332,352-356)
-                    const int qq = q - N, car = div_small(qq, 1.0f / (float)WW), cellx = qq - car * WW;
-                    if (!t.sal[car]) continue;
-                    const int2 d = t.tab[qq];
-                    float* cell = orow0 + ((size_t)el * N + car) * obs_dim + a.tj.hdr + (size_t)cellx * a.tj.vocab;
-                    if (d.x >= 0) cell[d.x] = 1.f + (d.x == a.tj.car_class ? (float)d.y : 0.f);
-                    if (d.x != a.tj.car_class && d.y != 0) cell[a.tj.car_class] = (float)d.y;
-                }
+                tj_obs_patch(tj_tile_at(tile + el * tjw, N), a.tj, orow0 + (size_t)el * N * obs_dim, obs_dim, WW, q);
             }
         }
     }

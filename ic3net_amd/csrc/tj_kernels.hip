@@ -499,23 +499,66 @@ int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, 
     return 0;
 }
 
+// Small rows (chunks below 8192 floats, e.g. TJ-medium: 5 330 floats = 21 KB per env): the rows are ~96 % zeros, so the
+// env's chunk is zero-filled with 1 KiB-aligned float4 wave stores (<= 3 ragged floats at either end as dwords) and the
+// <= 2 + 2 W^2 non-zero entries per live car are patched in behind a barrier — 1/4 of the store instructions of the
+// element-wise dword kernel and no per-element evaluation.  Same bytes, same values (tests: bit-equal to the oracle).
+__global__ __launch_bounds__(1024) void tj_obs_fill_kernel(TJState st, float* __restrict__ obs, int obs_dim, int WW)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    const int e = blockIdx.x, NT = blockDim.x, tid = threadIdx.x, N = st.N;
+    const TJTile t = tj_tile_at(smem, N);
+    const int L = N * obs_dim;
+    const long long b0 = (long long)e * L;                 // first float of this env in the whole tensor
+    float* out = obs + b0;
+    // zero fill first: it does not depend on the state, so its stores run under the descriptor loads below
+    const int head = (int)((4 - (b0 & 3)) & 3);
+    const int nb = (L - head) >> 2, tail = (L - head) & 3;
+    if (tid < head) out[tid] = 0.0f;
+    if (tid < tail) out[head + 4 * nb + tid] = 0.0f;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4* out4 = reinterpret_cast<f32x4*>(out + head);
+    const int o = (int)(((b0 + head) >> 2) & 63);           // 1 KiB-aligned wave stores
+    int j = tid - o;
+    if (j < 0) j += NT;
+    const f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
+    for (; j < nb; j += NT) out4[j] = z4;
+    for (int a = tid; a < N; a += NT) tj_tile_load_car(t, st, e, a);
+    __syncthreads();
+    for (int q = tid; q < N * WW; q += NT) t.tab[q] = tj_tab_entry(t, st, q);
+    __syncthreads();                                        // (also: every zero store of the workgroup has completed)
+    for (int q = tid; q < N + N * WW; q += NT) tj_obs_patch(t, st, out, obs_dim, WW, q);
+}
+
 int tj_observe(ic3_env* env, float* obs, hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window;
     const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
+    static const int fill = getenv("IC3_TJ_OBS_FILL") ? atoi(getenv("IC3_TJ_OBS_FILL")) : 1;
+    const bool big = (long long)c.N * d.obs_dim >= 8192 && d.obs_dim >= 8;
+    if (fill == 2 && big) {   // experiment: zero fill + patch for large chunks too, 1024 threads per env
+        hipLaunchKernelGGL(tj_obs_fill_kernel, dim3(c.E), dim3(1024), lds, s, tj_state_of(env), obs, d.obs_dim, WW);
+        IC3_HIP(hipGetLastError());
+        return 0;
+    }
     // measured on MI355X in the rollout loop: TJ-hard v1 (26 500 floats/env) 5.64 TB/s with the float4 kernel vs 5.12
     // with dword stores; TJ-medium v1 (5 330 floats/env) 3.83 vs 4.32 -> float4 only for large chunks
-    if ((long long)c.N * d.obs_dim >= 8192 && d.obs_dim >= 8) {
+    if (big) {
         hipLaunchKernelGGL(tj_obs_vec4_kernel, dim3(c.E), dim3(1024), lds, s, env->fv("alive"), env->fv("loc_r"),
                            env->fv("loc_c"), env->fv("last_act"), env->fv("route_id"), env->d_grid, obs, c.N, d.grid_h,
                            d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
         IC3_HIP(hipGetLastError());
         return 0;
     }
-    // small rows: 256 threads per env with dword stores (with 1024 threads this dword kernel is slower inside the
-    // rollout loop: TJ-hard 4.5 vs 5.1 TB/s, measured)
+    // small rows: zero fill + patches, 256 threads per env (TJ-medium: 5.66 TB/s = 0.71 of peak; the element-wise dword
+    // kernel below, kept as IC3_TJ_OBS_FILL=0, reached 4.35)
+    if (fill) {
+        hipLaunchKernelGGL(tj_obs_fill_kernel, dim3(c.E), dim3(256), lds, s, tj_state_of(env), obs, d.obs_dim, WW);
+        IC3_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(tj_obs_kernel, dim3(c.E), dim3(256), lds, s, env->fv("alive"), env->fv("loc_r"), env->fv("loc_c"),
                        env->fv("last_act"), env->fv("route_id"), env->d_grid, obs, c.N, d.grid_h, d.grid_w, c.vision,
                        d.vocab, d.vocab - 3, d.vocab - 1, d.npath, c.vocab_type ? 4 : 2);
