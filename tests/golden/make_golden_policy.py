@@ -423,6 +423,15 @@ def trainer_main():
     trainer_case('trainer_tj_medium_commnet', 'traffic_junction', 40, 2, 2, 24, nagents=10, dim=14, vision=1,
                  hid_size=16, commnet=True, recurrent=True, detach_gap=10, add_rate_min=0.2, add_rate_max=0.2,
                  difficulty='medium')
+    trainer_fullsize_main()
+
+
+def trainer_fullsize_main():
+    """F5 at BASELINE shapes: PP-hard (configs[1]) and TJ-hard (configs[3]), IC3Net recurrent hid 128, 80 steps."""
+    trainer_case('trainer_pp_hard', 'predator_prey', 80, 2, 1, 25, greedy=True, nagents=10, dim=20, vision=1,
+                 hid_size=128, ic3net=True, recurrent=True, detach_gap=10)
+    trainer_case('trainer_tj_hard', 'traffic_junction', 80, 2, 1, 26, nagents=20, dim=18, vision=1, hid_size=128,
+                 ic3net=True, recurrent=True, detach_gap=10, add_rate_min=0.05, add_rate_max=0.05, difficulty='hard')
 
 
 if __name__ == '__main__':
@@ -430,5 +439,7 @@ if __name__ == '__main__':
         fullsize_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         trainer_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':
+        trainer_fullsize_main()
     else:
         main()

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 from golden_util import load  # noqa: E402
 
 FIXTURES = [("trainer_pp_easy", "predator_prey"), ("trainer_pp_medium", "predator_prey"),
-            ("trainer_tj_easy", "traffic_junction"), ("trainer_tj_medium_commnet", "traffic_junction")]
+            ("trainer_tj_easy", "traffic_junction"), ("trainer_tj_medium_commnet", "traffic_junction"),
+            ("trainer_pp_hard", "predator_prey"), ("trainer_tj_hard", "traffic_junction")]   # BASELINE shapes, 80 steps
 
 
 def build_args(env_name, flags, N, T, nenv, seed):
