@@ -291,6 +291,18 @@ class CommNetMLP(nn.Module):
             ok = self._mega_sup = (env, ops.policy_step_supported(env, self.hid_size))
         return ok[1]
 
+    def zero_hidden(self, batch_size, device):
+        """init_hidden() for the one-launch rollout path: the persistent (h, c) buffers step_env() updates in place,
+        zeroed — two fills instead of two allocations + fills + two copies at every episode start."""
+        R, H = batch_size * self.nagents, self.hid_size
+        mb = getattr(self, '_mb', None)
+        if mb is None or mb['h'].shape[0] != R or mb['h'].device != device:
+            mb = self._mb = dict(h=torch.empty((R, H), dtype=torch.float32, device=device),
+                                 c=torch.empty((R, H), dtype=torch.float32, device=device))
+        mb['h'].zero_()
+        mb['c'].zero_()
+        return (mb['h'], mb['c'])
+
     def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None):
         """action_out, value, (h, c) = forward(x, info); `action` (heads, E, N) int32 <- select_action (Philox draws
         positioned by the env's own counters); env.step(action[0]) -> reward (E,N) f32, done (E,) i32, alive /

@@ -99,7 +99,9 @@ class Trainer(object):
         self._state = state
         self.clock.episode += 1
         self._info = dict()
-        self._prev_hid = torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)  # trainer.py:41
+        # trainer.py:41; an LSTM policy replaces it by init_hidden() at t = 0 (trainer.py:50-51), so not allocated then
+        lstm = bool(getattr(args, 'recurrent', False)) and getattr(args, 'rnn_type', '') == 'LSTM'
+        self._prev_hid = None if lstm else torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)
         self._nsteps = 0
         # Episode buffers [T, ...]: the env / sampling kernels write step t's outputs straight into slice t, so the
         # hot loop launches no bookkeeping kernels; masks and statistics are derived once in end_episode().
@@ -195,7 +197,12 @@ class Trainer(object):
                 state = state.clone()          # the env reuses its obs buffer; autograd keeps the encoder input
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:
-                    self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
+                    if getattr(self, '_mega_last', False) and not torch.is_grad_enabled() \
+                            and hasattr(self.policy_net, 'zero_hidden'):
+                        # the previous step went through the one-launch path: hand it its own buffers, zeroed
+                        self._prev_hid = self.policy_net.zero_hidden(state.shape[0], state.device)
+                    else:
+                        self._prev_hid = self.policy_net.init_hidden(batch_size=state.shape[0])
                 fuse_draw = not torch.is_grad_enabled() and self.clock.env is not None \
                     and hasattr(self.policy_net, 'sample_into') and select_action is _select_action_default
                 raw = self.env.env
