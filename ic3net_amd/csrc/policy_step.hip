@@ -10,8 +10,8 @@
 // ~11H floats per row through HBM (enc, comm, inp, gates written and re-read).
 //
 // MFMA-bound: 2*R*(2H*4H + H*H) flops on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate; 157 TFLOP/s
-// peak).  Decomposition for H = 128 (256 threads, 2 workgroups per CU so that one workgroup's staging / epilogue
-// phases run under the other's MFMA loop):
+// peak).  Decomposition for H = 128 (256 threads, 2 workgroups per CU: what they overlap is each other's non-matrix
+// phases — an fp32 MFMA stream leaves the other waves of its SIMD no issue slots):
 //   * tile = 64 rows x ALL 4H gate columns; wave w owns hidden columns [32w, 32w+32) of the four gates -> 2 (row
 //     tiles) x 4 (gates) accumulators of 32x32; a lane holds the SAME (row, column) of all four gates, so the LSTM
 //     nonlinearity needs no cross-lane traffic;
@@ -784,11 +784,9 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
             attr_lds = lds;
         }
     }
-    // persistent: at most one resident set of workgroups, each walking tiles blockIdx.x + k * gridDim.x
-    // one workgroup per tile: the hardware dispatcher balances the tiles over the CUs (a fixed resident set walking a
-    // strided tile list ran 3 full rounds on a third of the CUs where 2.67 were needed)
+    // one workgroup per tile, dispatched in tile order (full tiles first, see plan_tiles): the hardware dispatcher
+    // balances them over the CUs (a fixed resident set walking a strided tile list was measured slower)
     const int grid = tiles;
-    (void)resident_workgroups;
     hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, a);
     IC3_HIP(hipGetLastError());
     return 0;
