@@ -574,27 +574,34 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     IC3_TR(12);
     if (a.dbg & 8) return;
 
-    // ---- S10: heads + value head (comm.py:228,239): NW lanes per row, 32 columns each ---------------------------------
+    // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of 16
+    //      rows per wave, the OT <= 16 output columns are the weight rows [0, 16) of the inp half (rows >= OT hold
+    //      stale finite data and only feed output columns nobody reads).  Operand layout of the instruction: A[i][k] in
+    //      lane 16k + i, B[k][j] in lane 16k + j, D[4(l/16) + v][l % 16] in element v of lane l; one ds_read_b128 per
+    //      operand feeds four k-steps (k = 16 sg + 4 (l/16) + j — any k order is valid as long as A and B agree).
     // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
     constexpr int PER = H / 16;
     {
-        // lane (row, part) owns the float4 columns {q * NW + part}: the NW lanes of a row read consecutive float4s
-        // (no LDS bank conflicts; `8 * part + q` put all of them on the same banks), weight reads are broadcasts
-        const int row = tid / NW, part = tid - row * NW;
-        ps_f32x4 x[8];
+        const int l16 = lane & 15, kq = lane >> 4;
+        const float hb = l16 < a.OT ? a.head_b[l16 + tz] : 0.0f;
+        for (int rtile = w; rtile < BM / 16; rtile += NW) {
+            if (16 * rtile >= rows) break;
+            ps_f32x4 z = { 0.f, 0.f, 0.f, 0.f };
+            const ps_f32x4* xa = As4 + (16 * rtile + l16) * LDA4 + H4 + kq;
+            const ps_f32x4* wb = As4 + l16 * LDA4 + kq;
+#pragma unroll 4
+            for (int sg = 0; sg < H / 16; ++sg) {
+                const ps_f32x4 x4 = xa[4 * sg], w4 = wb[4 * sg];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = As4[row * LDA4 + H4 + q * NW + part];
-        float* zrow = As + (16 + row / PER) * LDA + (row % PER) * 16;
-#pragma unroll 1
-        for (int o = 0; o < a.OT; ++o) {
-            float z = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const ps_f32x4 wv = As4[o * LDA4 + q * NW + part];
-                z += x[q].x * wv.x + x[q].y * wv.y + x[q].z * wv.z + x[q].w * wv.w;
+                for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[j], w4[j], z, 0, 0, 0);
             }
-            z = group_sum<NW>(z);
-            if (part == 0) zrow[o] = z + a.head_b[o + tz];
+            if (l16 < a.OT) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * rtile + 4 * kq + v;
+                    As[(16 + r / PER) * LDA + (r % PER) * 16 + l16] = z[v] + hb;
+                }
+            }
         }
     }
     __syncthreads();
