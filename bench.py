@@ -235,6 +235,9 @@ def main():
     p.add_argument('--nenvs', type=int, default=8192, help='environments per GPU')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--dispatch-events', type=int, default=1,
+                   help='1: the HIP events that time the step launch are stamped by the dispatch itself '
+                        '(hipExtLaunchKernel); 0: recorded into the stream before / after it')
     p.add_argument('--graph', type=int, default=int(os.environ.get('IC3_BENCH_GRAPH', '1')),
                    help='replay the per-step launch sequence as hipGraphs (Trainer args.hip_graph)')
     p.add_argument('--no-dense-obs', action='store_true',
@@ -359,7 +362,8 @@ def main():
         run(T, 0)                             # no graphs: one untimed eager episode (first-use set-up, clocks)
     mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use
     if o.time_kernels and mega_live:
-        raw_env.step_timer = []               # both launches of a step are event-timed and issued eagerly
+        raw_env.step_timer = []               # the launch of every step is event-timed and issued eagerly
+        raw_env.dispatch_events = bool(o.dispatch_events)   # events stamped by the dispatch, not recorded around it
     gc.disable()                              # (like timeit: no collector pause in the warm-up + timed steps)
     t_in_ep = run(o.warmup, 0)                # W untimed warm-up steps, in the measured configuration
     raw_env.obs_timer = []

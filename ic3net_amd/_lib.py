@@ -105,6 +105,10 @@ EXPORTS = {
     "ic3_policy_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_policy_forward": (C.c_int, [C.POINTER(Policy), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "ic3_policy_step": (C.c_int, [C.c_void_p, C.POINTER(Policy)] + [C.c_void_p] * 12),
+    "ic3_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ic3_event_destroy": (C.c_int, [C.c_void_p]),
+    "ic3_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "ic3_env_set_step_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_episode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ic3_episode_finalize": (C.c_int, [C.POINTER(Episode), C.c_void_p]),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

@@ -494,6 +494,36 @@ int ic3_tj_get_add_rate(const ic3_env* env, double* add_rate, double* exact_rate
     return 0;
 }
 
+int ic3_event_create(void** event)
+{
+    if (!event) return fail(-22, "ic3_event_create: null argument");
+    hipEvent_t e;
+    IC3_HIP(hipEventCreate(&e));
+    *event = (void*)e;
+    return 0;
+}
+
+int ic3_event_destroy(void* event)
+{
+    if (event) IC3_HIP(hipEventDestroy((hipEvent_t)event));
+    return 0;
+}
+
+int ic3_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    if (!start || !stop || !ms) return fail(-22, "ic3_event_elapsed_ms: null argument");
+    IC3_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+int ic3_env_set_step_events(ic3_env* env, void* start, void* stop)
+{
+    if (!env) return fail(-22, "ic3_env_set_step_events: null argument");
+    env->ev_start = start;
+    env->ev_stop = stop;
+    return 0;
+}
+
 int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream)
 {
     if (!env || !host_out) return fail(-22, "ic3_env_stats: null argument");

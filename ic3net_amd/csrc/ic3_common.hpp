@@ -73,6 +73,7 @@ struct ic3_env {
     int32_t* d_thr = nullptr;  // TJ: floor(add_rate * 2^24), device-resident so captured step graphs stay valid
     int64_t resets = 0;
     int auto_max_steps = 0;    // ic3_env_set_auto_reset: > 0 = finished envs restart inside the step launch
+    void *ev_start = nullptr, *ev_stop = nullptr;   // ic3_env_set_step_events: recorded by the next ic3_policy_step launch
     // Traffic-Junction constant tables (device + host copies)
     int32_t* d_grid = nullptr;       // [h*w] road ids
     int32_t* d_route_off = nullptr;  // [npath+1]

@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "env_device.hpp"
 #include "ic3_common.hpp"
 
@@ -769,7 +771,8 @@ static int plan_tiles(StepArgs& a, int H)
 }
 
 template <int H, int KIND>
-static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
+static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0 = nullptr,
+                       hipEvent_t ev1 = nullptr)
 {
     static bool attr_set = false;
     static size_t attr_lds = 0;
@@ -794,7 +797,11 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s)
     // one workgroup per tile, dispatched in tile order (full tiles first, see plan_tiles): the hardware dispatcher
     // balances them over the CUs (a fixed resident set walking a strided tile list was measured slower)
     const int grid = tiles;
-    hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, a);
+    if (ev0 || ev1) {   // timed launch: the dispatch itself stamps the events (no separate record packets around it)
+        hipExtLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, ev0, ev1, 0, a);
+    } else {
+        hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, a);
+    }
     IC3_HIP(hipGetLastError());
     return 0;
 }
@@ -1006,9 +1013,14 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         if (tiles == trace_tiles) a.trace = trace_buf;
     }
 #endif
-    if (H == 128) rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s);
-    else if (H == 64) rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s);
-    else rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s);
+    hipEvent_t ev0 = (hipEvent_t)env->ev_start, ev1 = (hipEvent_t)env->ev_stop;   // one-shot (ic3_env_set_step_events)
+    env->ev_start = env->ev_stop = nullptr;
+    if (H == 128)
+        rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
+    else if (H == 64)
+        rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
+    else
+        rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
 #ifdef IC3_PS_TRACE
     if (a.trace && ++trace_call == 40) {
         IC3_HIP(hipStreamSynchronize(s));

@@ -19,6 +19,27 @@ from . import _lib, spaces
 from ._lib import check, ptr, stream
 
 
+class DispatchEvent(object):
+    """A HIP event owned by the library (ic3_event_create): handed to `ic3_env_set_step_events`, it is stamped by the
+    ic3_policy_step dispatch itself — no event-record packets in the stream around the launch."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(_lib.lib().ic3_event_create(C.byref(h)))
+        self.handle = h
+
+    def elapsed_time(self, end):             # same call shape as torch.cuda.Event.elapsed_time (ms)
+        ms = C.c_float()
+        check(_lib.lib().ic3_event_elapsed_ms(self.handle, end.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _lib.lib().ic3_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class _BatchedEnv(object):
     """Shared plumbing: handle lifetime, output buffers, state dump / injection."""
 
@@ -28,6 +49,7 @@ class _BatchedEnv(object):
         self.episode_over = False
         self.obs_timer = None     # set to a list to collect (start, end) HIP events around every obs launch
         self.step_timer = None    # likewise around every one-launch policy+step (Trainer._step_body_mega)
+        self.dispatch_events = False   # step_timer pairs stamped by the dispatch (DispatchEvent) instead of records
         self.out = None           # optional {'reward','done','alive','is_completed'} output tensors for step()
         self._last = None
 
@@ -165,6 +187,10 @@ class _BatchedEnv(object):
         self._require()
         check(_lib.lib().ic3_env_set_auto_reset(self._h, int(max_steps)))
         self.auto_max_steps = int(max_steps)
+
+    def set_step_events(self, start, stop):
+        """Arm the next ic3_policy_step launch on this handle: the dispatch stamps `start` / `stop` (DispatchEvent)."""
+        check(_lib.lib().ic3_env_set_step_events(self._h, start.handle, stop.handle))
 
     def device_stats(self):
         s = _lib.Stats()

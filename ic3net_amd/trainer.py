@@ -261,7 +261,12 @@ class Trainer(object):
         store = bool(getattr(args, 'store_states', False))
         cur_state = state.clone() if store else None
         timer = getattr(raw, 'step_timer', None)                   # bench: HIP events around the one launch
-        if timer is not None:
+        stamped = timer is not None and getattr(raw, 'dispatch_events', False)
+        if stamped:                                                # ... stamped by the dispatch itself
+            from .envs import DispatchEvent
+            e0, e1 = DispatchEvent(), DispatchEvent()
+            raw.set_step_events(e0, e1)
+        elif timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
         # next_state rows are written by the same launch (args.fused_obs, default) unless they are wanted on a second
@@ -273,7 +278,8 @@ class Trainer(object):
             alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None)
         self._mega_last = True
         if timer is not None:
-            e1.record(torch.cuda.current_stream())
+            if not stamped:
+                e1.record(torch.cuda.current_stream())
             timer.append((e0, e1, t))
         self._prev_hid = prev_hid                                  # no autograd here: detach_gap is moot
         if observe and not fused:

@@ -193,6 +193,15 @@ int ic3_tj_build_tables(int dim, int vision, int difficulty, ic3_dims* dims_out,
 /* TJ curriculum scalar state (traffic_junction_env.py:103-104,196-200,620-626) */
 int ic3_tj_get_add_rate(const ic3_env* env, double* add_rate, double* exact_rate);
 
+/* Measurement support (no reference counterpart): HIP events stamped by the ic3_policy_step dispatch itself.
+ * ic3_env_set_step_events arms the NEXT ic3_policy_step launch on this handle (one shot): `start` is stamped when the
+ * kernel begins, `stop` when it ends — no record packets in the stream around the launch.  Read the pair with
+ * ic3_event_elapsed_ms after the stream has been synchronised. */
+int ic3_event_create(void** event);
+int ic3_event_destroy(void* event);
+int ic3_event_elapsed_ms(void* start, void* stop, float* ms);
+int ic3_env_set_step_events(ic3_env* env, void* start, void* stop);
+
 /* Reduced episode statistics (synchronising; host struct): env.stat (PP:284-288, TJ:249-250). */
 int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream);
 

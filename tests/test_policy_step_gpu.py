@@ -220,6 +220,44 @@ def test_policy_step_is_deterministic_and_graph_replay_identical():
             assert torch.equal(x, y), ("graph", rep, i)
 
 
+def test_dispatch_stamped_events_time_the_launch_and_leave_the_results_alone():
+    """ic3_env_set_step_events: the next ic3_policy_step dispatch stamps the two events (one shot); outputs are the
+    ones of an untimed launch."""
+    from ic3net_amd.comm import CommNetMLP
+    from ic3net_amd.envs import DispatchEvent
+    E, N, H = 512, 10, 128
+    env = make_env("pp", dict(N=N, dim=20, vision=1, mode="mixed"), E, 5, 0)
+    torch.manual_seed(3)
+    net = CommNetMLP(policy_args(N, H, [5, 2], True), env.obs_dim).cuda().float()
+    net.obs_encoder, net.obs_table = env.encode, env.encode_table
+    env.reset()
+    st0 = env.get_state()
+    h0 = torch.randn(E * N, H, device='cuda') * 0.5
+    bufs = dict(act=torch.zeros((2, E, N), dtype=torch.int32, device='cuda'), rew=torch.zeros(E, N, device='cuda'),
+                done=torch.zeros(E, dtype=torch.int32, device='cuda'))
+    info = {'comm_action': torch.ones(E, N, dtype=torch.int32, device='cuda')}
+
+    def once(events=None):
+        env.set_state(**st0)
+        if events is not None:
+            env.set_step_events(*events)
+        with torch.no_grad():
+            logp, val, (h, c) = net.step_env(env, [env._obs, (h0.clone(), h0.clone())], info, bufs['act'], bufs['rew'],
+                                             bufs['done'], obs=env._obs)
+        return [x.clone() for x in (logp[0], logp[1], val, h, c, bufs['act'], bufs['rew'], env._obs)]
+
+    ref = once()
+    e0, e1 = DispatchEvent(), DispatchEvent()
+    timed = once((e0, e1))
+    untimed_again = once()                   # the events were one-shot: this launch must not touch them
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    assert 0.005 < ms < 5.0, ms
+    for x, y, z in zip(ref, timed, untimed_again):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert e0.elapsed_time(e1) == ms
+
+
 def test_policy_step_rejects_what_it_cannot_run():
     from ic3net_amd import ops
     env = make_env("pp", dict(N=10, dim=20, vision=1, mode="mixed"), 4, 1, 0)
