@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02prof
 rm -rf $O; mkdir -p $O
 cd $R
+make -s -C ic3net_amd/csrc libic3rollout_plain.so > /dev/null 2>&1    # A/B build of the same sources (never stale)
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" > $O/summary.txt
 timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests_gpu.log 2>&1; echo "gpu suite rc=$?" >> $O/summary.txt
 B="python bench.py --steps 160 --warmup 16 --no-cpu-baseline"
