@@ -382,10 +382,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         // B fragments of C: lane (li, lh) of wave w reads Wp[kb][32w + li][lh] -> k = 8kb + 4lh + j, j = 0..3
         constexpr int KBC = H / 8, CH = (KBC < 8) ? KBC : 8, NCH = KBC / CH;
-        const ps_f32x4* cwp = a.c_wp + ((size_t)col * 2 + lh) + tz;
+        // weights through a buffer descriptor: lane offset in one VGPR, the k / gate part of the address on the scalar ALU
+        const __amdgpu_buffer_rsrc_t rcw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<ps_f32x4*>(a.c_wp), 0, (uint32_t)((size_t)H * H * sizeof(float)), 0x00020000);
+        const int wlane = (col * 2 + lh) * 16;
+        auto cwp = [&](int k) {
+            return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rcw, wlane, k * (H * 2 * 16), 0));
+        };
         ps_f32x4 cb[2][CH];
 #pragma unroll
-        for (int k = 0; k < CH; ++k) cb[0][k] = cwp[(size_t)k * H * 2];
+        for (int k = 0; k < CH; ++k) cb[0][k] = cwp(k);
         __syncthreads();
         IC3_TR(6);
         // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) {
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp[(size_t)((ch + 1) * CH + k) * H * 2];
+                    for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp((ch + 1) * CH + k);
                 }
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
@@ -422,17 +428,23 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 
     // gate weights: the first two 8-k blocks are requested before inp is written back
-    const ps_f32x4* wp = a.l_wp + ((size_t)col * 2 + lh) + tz;
     constexpr int KB = K / 8;
     constexpr size_t KB_STRIDE = (size_t)4 * H * 2;   // float4s per kb
+    const __amdgpu_buffer_rsrc_t rgw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<ps_f32x4*>(a.l_wp), 0, (uint32_t)((size_t)K * 4 * H * sizeof(float)), 0x00020000);
+    const int glane = (col * 2 + lh) * 16;
+    auto wp = [&](int kb, int g) {   // float4 of gate g, k block kb (KB_STRIDE float4s per block, 2 H per gate)
+        return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rgw, glane, kb * (int)(KB_STRIDE * 16) + g * (H * 2 * 16), 0));
+    };
     // (same issue order as inside the loop — all of b0, then all of b1 — so that the s_waitcnt vmcnt(n) the compiler
     // places in front of each MFMA group count exactly the loads that group needs on both paths into the loop)
     ps_f32x4 b0[4], b1[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)g * H * 2];
+    for (int g = 0; g < 4; ++g) b0[g] = wp(0, g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b1[g] = wp[KB_STRIDE + (size_t)g * H * 2];
+    for (int g = 0; g < 4; ++g) b1[g] = wp(1, g);
     __builtin_amdgcn_sched_barrier(0);
     zero_burst(a.zb);
     // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------------
@@ -488,12 +500,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             block(two_c, b0, kb);
             __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = wp[(size_t)(kb + 2) * KB_STRIDE + (size_t)g * H * 2];
+            for (int g = 0; g < 4; ++g) b0[g] = wp(kb + 2, g);
             __builtin_amdgcn_sched_barrier(0);
             block(two_c, b1, kb + 1);
             __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = wp[(size_t)(kb + 3) * KB_STRIDE + (size_t)g * H * 2];
+            for (int g = 0; g < 4; ++g) b1[g] = wp(kb + 3, g);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the old cell state: one touch per 128 B line of this wave's (64 rows x 32 columns) before the last two blocks
