@@ -207,15 +207,34 @@ __device__ __forceinline__ int2 pp_tab_entry(const int32_t* sr, const int32_t* s
     return make_int2(id, npred | (npr << 16));
 }
 
+// A table of float4 rows (H4 float4s each) behind a plain pointer or a buffer descriptor (32-bit offsets on the lane,
+// no 64-bit address arithmetic per gather).  `if (t)` = present.
+struct PtrRows {
+    const dv_f32x4* p;
+    __device__ __forceinline__ dv_f32x4 at(int row, int H4, int c4) const { return p[(size_t)row * H4 + c4]; }
+    __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+};
+struct BufRows {
+    __amdgpu_buffer_rsrc_t r;
+    bool present;
+    __device__ __forceinline__ dv_f32x4 at(int row, int H4, int c4) const
+    {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (row * H4 + c4) * 16, 0, 0);
+        return __builtin_bit_cast(dv_f32x4, v);
+    }
+    __device__ __forceinline__ explicit operator bool() const { return present; }
+};
+
 // encoder(obs row of entity a)[4*c4 .. 4*c4+3] from the env's LDS descriptors (see pp_encode_kernel)
 // `cells`: bit c set = window cell c may carry a predator / prey count (the centre is handled apart); ~0u = unknown.
 // With the location table present only those cells are visited (in ascending order, as the full scan would): the
 // fused policy+step kernel builds the bit set once per row next to the descriptors instead of letting each of the H/4
 // lanes of a row re-scan all W*W cells.
-__device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
-                                                  int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
-                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table,
-                                                  unsigned cells = ~0u)
+template <class TW, class TL>
+__device__ __forceinline__ dv_f32x4 pp_encode_row_t(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
+                                                    int H4, int WW, int vocab, int dim, const TW Wt,
+                                                    const dv_f32x4* __restrict__ bias, const TL loc_table, unsigned cells)
 {
     // The entity's own cell (the window centre) always carries a count: its two count rows are gathered
     // unconditionally (scaled by the counts; `+ 0 * w` is exact), together with the bias and the table row — four
@@ -224,11 +243,11 @@ __device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32
     const int centre = WW >> 1;
     const int2 tc = tab[a * WW + centre];
     dv_f32x4 acc = bias[c4];
-    const dv_f32x4 w_pred = Wt[((size_t)centre * vocab + vocab - 1) * H4 + c4];
-    const dv_f32x4 w_prey = Wt[((size_t)centre * vocab + vocab - 2) * H4 + c4];
+    const dv_f32x4 w_pred = Wt.at(centre * vocab + vocab - 1, H4, c4);
+    const dv_f32x4 w_prey = Wt.at(centre * vocab + vocab - 2, H4, c4);
     // the one-hot location channels of all window cells depend only on the entity's position: one row of the
     // pre-summed table (pp_encode_table_kernel) replaces W*W gathered rows
-    if (loc_table) acc += loc_table[(size_t)(sr[a] * dim + sc[a]) * H4 + c4];
+    if (loc_table) acc += loc_table.at(sr[a] * dim + sc[a], H4, c4);
     acc += (float)(tc.y & 0xffff) * w_pred;
     acc += (float)(tc.y >> 16) * w_prey;
     if (loc_table && WW <= 32) {
@@ -237,23 +256,31 @@ __device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32
             const int cell = __builtin_ctz(m);
             m &= m - 1;
             const int2 t = tab[a * WW + cell];
-            const size_t row = (size_t)cell * vocab;
+            const int row = cell * vocab;
             const int npred = t.y & 0xffff, npr = t.y >> 16;
-            if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
-            if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
+            if (npred) acc += (float)npred * Wt.at(row + vocab - 1, H4, c4);
+            if (npr) acc += (float)npr * Wt.at(row + vocab - 2, H4, c4);
         }
         return acc;
     }
     for (int cell = 0; cell < WW; ++cell) {
         const int2 t = tab[a * WW + cell];
-        const size_t row = (size_t)cell * vocab;
-        if (!loc_table) acc += Wt[(row + t.x) * H4 + c4];
+        const int row = cell * vocab;
+        if (!loc_table) acc += Wt.at(row + t.x, H4, c4);
         if (cell == centre) continue;
         const int npred = t.y & 0xffff, npr = t.y >> 16;
-        if (npred) acc += (float)npred * Wt[(row + vocab - 1) * H4 + c4];
-        if (npr) acc += (float)npr * Wt[(row + vocab - 2) * H4 + c4];
+        if (npred) acc += (float)npred * Wt.at(row + vocab - 1, H4, c4);
+        if (npr) acc += (float)npr * Wt.at(row + vocab - 2, H4, c4);
     }
     return acc;
+}
+
+__device__ __forceinline__ dv_f32x4 pp_encode_row(const int32_t* sr, const int32_t* sc, const int2* tab, int a, int c4,
+                                                  int H4, int WW, int vocab, int dim, const dv_f32x4* __restrict__ Wt,
+                                                  const dv_f32x4* __restrict__ bias, const dv_f32x4* __restrict__ loc_table,
+                                                  unsigned cells = ~0u)
+{
+    return pp_encode_row_t(sr, sc, tab, a, c4, H4, WW, vocab, dim, PtrRows{ Wt }, bias, PtrRows{ loc_table }, cells);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,23 +509,23 @@ __device__ __forceinline__ void tj_obs_patch(const TJTile& t, const TJState& s, 
 }
 
 // encoder(obs row of car a)[4*c4 ..] (see tj_encode_kernel): bias only for a dead car (its obs row is zero)
-__device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
-                                                  const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
-                                                  const dv_f32x4* __restrict__ loc_table, unsigned cells = ~0u)
+template <class TW, class TL>
+__device__ __forceinline__ dv_f32x4 tj_encode_row_t(const TJTile& t, const TJState& s, int a, int c4, int H4, const TW Wt,
+                                                    const dv_f32x4* __restrict__ bias, const TL loc_table, unsigned cells)
 {
     const int W = 2 * s.v + 1, WW = W * W, centre = WW >> 1;
     dv_f32x4 acc = bias[c4];
     if (t.sal[a]) {
         // header rows, the table row and the car-count row of the car's own cell (count >= 1): independent loads
-        const dv_f32x4 w0 = Wt[c4], w1 = Wt[H4 + c4];
-        const dv_f32x4 w_car = Wt[((size_t)s.hdr + (size_t)centre * s.vocab + s.car_class) * H4 + c4];
+        const dv_f32x4 w0 = Wt.at(0, H4, c4), w1 = Wt.at(1, H4, c4);
+        const dv_f32x4 w_car = Wt.at(s.hdr + centre * s.vocab + s.car_class, H4, c4);
         acc += t.s0[a] * w0;
         acc += t.s1[a] * w1;
         if (s.hdr == 4) {
-            acc += t.s2[a] * Wt[2 * H4 + c4];
-            acc += t.s3[a] * Wt[3 * H4 + c4];
+            acc += t.s2[a] * Wt.at(2, H4, c4);
+            acc += t.s3[a] * Wt.at(3, H4, c4);
         }
-        if (loc_table) acc += loc_table[(size_t)(t.sr[a] * s.w + t.sc[a]) * H4 + c4];   // see pp_encode_kernel
+        if (loc_table) acc += loc_table.at(t.sr[a] * s.w + t.sc[a], H4, c4);   // see pp_encode_kernel
         acc += (float)t.tab[a * WW + centre].y * w_car;
         if (loc_table && WW <= 32) {               // only the cells that carry a car count (see pp_encode_row)
             unsigned m = cells & ~(1u << centre) & (WW == 32 ? ~0u : ((1u << WW) - 1u));
@@ -506,18 +533,25 @@ __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState
                 const int cell = __builtin_ctz(m);
                 m &= m - 1;
                 const int2 d = t.tab[a * WW + cell];
-                if (d.y) acc += (float)d.y * Wt[((size_t)s.hdr + (size_t)cell * s.vocab + s.car_class) * H4 + c4];
+                if (d.y) acc += (float)d.y * Wt.at(s.hdr + cell * s.vocab + s.car_class, H4, c4);
             }
             return acc;
         }
         for (int cell = 0; cell < WW; ++cell) {
             const int2 d = t.tab[a * WW + cell];
-            const size_t row = s.hdr + (size_t)cell * s.vocab;
-            if (!loc_table && d.x >= 0) acc += Wt[(row + d.x) * H4 + c4];   // scalar vocab: -1 = not a road cell
-            if (cell != centre && d.y) acc += (float)d.y * Wt[(row + s.car_class) * H4 + c4];
+            const int row = s.hdr + cell * s.vocab;
+            if (!loc_table && d.x >= 0) acc += Wt.at(row + d.x, H4, c4);   // scalar vocab: -1 = not a road cell
+            if (cell != centre && d.y) acc += (float)d.y * Wt.at(row + s.car_class, H4, c4);
         }
     }
     return acc;
+}
+
+__device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState& s, int a, int c4, int H4,
+                                                  const dv_f32x4* __restrict__ Wt, const dv_f32x4* __restrict__ bias,
+                                                  const dv_f32x4* __restrict__ loc_table, unsigned cells = ~0u)
+{
+    return tj_encode_row_t(t, s, a, c4, H4, PtrRows{ Wt }, bias, PtrRows{ loc_table }, cells);
 }
 
 // ------------------------------------------------------------------------------------------------

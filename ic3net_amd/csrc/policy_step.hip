@@ -217,7 +217,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // Cache policy: non-temporal.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights
     // every tile streams from there: with plain stores (a -DIC3_PS_PLAIN_STORES build) the kernel takes 0.50 ms
     // instead of 0.38.
-    // (zmode +8: h loads nt; +16: no L2 warm-up of c; +32: rest of the zero fill right behind the loop — experiments)
+    // (zmode +16: no L2 warm-up of c; +32: rest of the zero fill right behind the loop — experiments)
     const int mis = (int)(((ob0 + ohead) >> 2) & 63);
     const int c_lo = mis ? 1 : 0, c_hi = (mis + onb) >> 6;       // full chunks: [c_lo, c_hi)
     const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,13 +291,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     // h rows of the tile: requested now (HBM latency runs under S1/S2), parked in registers until the encoder output
     // has left the h half of the LDS tile
     ps_f32x4 hv[8];
+    {
+        // rows are contiguous: float4 number idx of the tile sits at byte 16 * idx; rows >= `rows` read as zeros
+        // (descriptor range check), the constant part of the offset rides on the scalar operand
+        const __amdgpu_buffer_rsrc_t rhh = __builtin_amdgcn_make_buffer_rsrc(
+            static_cast<void*>(a.h + r0 * H), 0, (uint32_t)rows * H * 4u, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = tid + i * NT;
-        const int row = idx / H4, c4 = idx - row * H4;
-        const ps_f32x4* hp = reinterpret_cast<const ps_f32x4*>(a.h + (r0 + row) * H + 4 * c4);
-        hv[i] = (row < rows && !(autor && fresh_row(row))) ? ((a.zmode & 8) ? __builtin_nontemporal_load(hp) : *hp)
-                                                           : ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        for (int i = 0; i < 8; ++i) {
+            hv[i] = __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhh, tid * 16, i * NT * 16, 0));
+            if (autor && fresh_row((tid + i * NT) / H4)) hv[i] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        }
     }
     // (a few zero stores per burst in front of the gate loop, see the pacing notes in ic3_policy_step)
     zero_burst(a.zb);
@@ -311,6 +314,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         IC3_TR(2);
     }
     zero_burst(a.zb);
+    // encoder weight rows / pre-summed location rows behind buffer descriptors (32-bit gather offsets)
+    const BufRows encW = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.Wt), 0,
+                                                             (uint32_t)((size_t)a.obs_dim * H * sizeof(float)), 0x00020000),
+                           a.Wt != nullptr };
+    const BufRows encL = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.loc_table), 0, 0x7fffffffu, 0x00020000),
+                           a.loc_table != nullptr };
     // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
 #pragma unroll IC3_PS_ENC_UNROLL
     for (int i = 0; i < 8; ++i) {
@@ -322,11 +331,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             if constexpr (KIND == 0) {
                 v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
             } else if constexpr (KIND == IC3_ENV_PP) {
-                v = pp_encode_row(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
-                                  a.pp.dim * a.pp.dim + 4, a.pp.dim, a.Wt, a.enc_bias + tz, a.loc_table, rmask[row]);
+                v = pp_encode_row_t(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
+                                    a.pp.dim * a.pp.dim + 4, a.pp.dim, encW, a.enc_bias + tz, encL, rmask[row]);
             } else {
-                v = tj_encode_row(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, a.Wt, a.enc_bias + tz, a.loc_table,
-                                  rmask[row]);
+                v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, a.enc_bias + tz, encL,
+                                    rmask[row]);
             }
         }
         As4[row * LDA4 + H4 + c4] = v;
