@@ -249,6 +249,9 @@ def main():
     p.add_argument('--time-kernels', type=int, default=int(os.environ.get('IC3_BENCH_TIME_KERNELS', '1')),
                    help='bracket the policy+step launch and the obs-assembly launch with HIP events in the timed region '
                         '(roofline numbers); the two launches are then issued eagerly instead of as graph replays')
+    p.add_argument('--auto-reset', type=int, default=0,
+                   help='1: finished envs restart inside the step launch (collection mode of trainer.py:227-242); every '
+                        'slot of the timed region is then a live transition')
     p.add_argument('--fused-obs', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_OBS', '1')),
                    help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
     p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
@@ -299,6 +302,7 @@ def main():
     a.overlap_obs = bool(o.overlap_obs)
     a.mega_policy = bool(o.mega)
     a.fused_obs = bool(o.fused_obs)
+    a.auto_reset = bool(o.auto_reset)
     T = a.max_steps
     raw_env = trainer.env.env
     live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
@@ -392,6 +396,8 @@ def main():
     step_ms = [s.elapsed_time(e) for s, e, t in (raw_env.step_timer or []) if t > 0]   # t = 0 adds the h, c resets
     raw_env.step_timer = None
     live_steps = live_done[0] + raw_env.device_stats().live_env_steps - live0          # this rank, timed region
+    if o.auto_reset:                          # every slot is a real transition (the step counters restart in-launch)
+        live_steps = float(o.nenvs * o.steps)
     if world > 1:
         lt = torch.tensor([live_steps], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(lt, op=dist.ReduceOp.SUM)
@@ -436,6 +442,7 @@ def main():
                                   "hipGraph replay" if o.graph else "eager"),
                        "dense_obs": not o.no_dense_obs, "overlap_obs": bool(o.overlap_obs),
                        "policy": "one launch per step (ic3_policy_step)" if mega_live else "launch chain",
+                       "auto_reset": bool(o.auto_reset),
                        "gemm": ("hand-written fp32 MFMA" if mega_live else
                                 "TunableOp-selected" if o.tune_gemm else "default heuristics")},
             "live_frac": round(live_frac, 6),

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     float* sscale = sm + BM;                                     // [BM] per-env 1/(n_alive-1)
     int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
     uint32_t* rmask = reinterpret_cast<uint32_t*>(sact + BM);    // [BM] window cells of every row that carry a count
-    int32_t* tile = reinterpret_cast<int32_t*>(rmask + BM);     // env descriptors of the tile's envs
+    uint32_t* sfm = rmask + BM;                                  // [2] (+2 pad) bit r: row r starts an episode (auto-reset)
+    int32_t* tile = reinterpret_cast<int32_t*>(sfm + 4);         // env descriptors of the tile's envs
 
     if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
@@ -271,12 +272,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const int el = (int)(((float)row + 0.5f) * (1.0f / (float)N));   // row / N, exact for row < 64
         return a.tstep[e0 + el] == 0;
     };
-    for (int r = tid; r < BM; r += NT) {
+    for (int r = tid; r < BM; r += NT) {                        // (NT >= 128: this is exactly wave 0, all lanes)
         float m = 0.f;
-        if (r < rows && !(autor && fresh_row(r)))
+        const bool fr = autor && r < rows && fresh_row(r);
+        if (r < rows && !fr)
             m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
         sm[r] = m;
         if constexpr (KIND != 0) rmask[r] = (WW <= 32) ? 0u : ~0u;   // filled next to the window descriptors (S1)
+        if (autor) {                                              // one global read per row, here; later phases test a bit
+            const unsigned long long fb = __ballot(fr);
+            if (lane == 0) {
+                sfm[0] = (uint32_t)fb;
+                sfm[1] = (uint32_t)(fb >> 32);
+            }
+        }
     }
     for (int el = tid; el < nenv; el += NT) {
         int n_alive = 0;
@@ -299,13 +308,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             hv[i] = __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhh, tid * 16, i * NT * 16, 0));
-            if (autor && fresh_row((tid + i * NT) / H4)) hv[i] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
         }
     }
     // (a few zero stores per burst in front of the gate loop, see the pacing notes in ic3_policy_step)
     zero_burst(a.zb);
     __syncthreads();
     IC3_TR(1);
+    unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
+    if (autor)
+        fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
+                ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
 
     // ---- S1: window descriptors ------------------------------------------------------------------------------------
     if constexpr (KIND != 0) {
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * NT;
         const int row = idx / H4, c4 = idx - row * H4;
-        As4[row * LDA4 + H4 + c4] = hv[i];
+        As4[row * LDA4 + H4 + c4] = (autor && ((fmask >> row) & 1)) ? ps_f32x4{ 0.f, 0.f, 0.f, 0.f } : hv[i];
     }
     __syncthreads();
     IC3_TR(5);
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int reg = 0; reg < 16; ++reg) {
                 const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
                 cold[rt][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, voff + lc * H * 4, 0, 0));
-                if (autor && fresh_row(lc + 4 * lh)) cold[rt][reg] = 0.0f;
+                if (autor && ((fmask >> (lc + 4 * lh)) & 1)) cold[rt][reg] = 0.0f;
             }
         }
         __syncthreads();   // every wave is done with the A tile
@@ -862,7 +874,7 @@ static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_wo
     tile_words = (tile_words + 3) & ~(size_t)3;
     if (tile_words_out) *tile_words_out = (int)tile_words;
     (void)with_obs;
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64 + tile_words) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64 + 4 + tile_words) * sizeof(float);
     const size_t limit = (H <= 128) ? 80 * 1024 : 160 * 1024;   // two workgroups per CU up to H = 128
     return lds <= limit ? (int)lds : 0;
 }
@@ -926,7 +938,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     a.EPT = 64 / N;
     a.G = 1;
     const int tiles = plan_tiles(a, H);
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64 + 4) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
     if (H == 64) return launch_step<64, 0>(a, tiles, lds, s);

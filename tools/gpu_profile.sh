@@ -22,6 +22,7 @@ timeout 300 $B --fused-obs 0 > $O/bench_pp_hard_separate_obs.json 2>/dev/null
 timeout 300 $B --fused-obs 0 --overlap-obs 1 --time-kernels 0 > $O/bench_pp_hard_overlap_obs.json 2>/dev/null
 timeout 300 $B --mega 0 --time-kernels 0 > $O/bench_pp_hard_chain_r01.json 2>/dev/null
 timeout 300 $B --time-kernels 0 > $O/bench_pp_hard_graph.json 2>/dev/null
+timeout 300 $B --auto-reset 1 > $O/bench_pp_hard_auto_reset.json 2>/dev/null
 IC3_ROLLOUT_LIB=$R/ic3net_amd/csrc/libic3rollout_plain.so timeout 300 $B > $O/bench_pp_hard_plain_stores.json 2>/dev/null
 IC3_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d $O/roctx -- python bench.py --steps 8 --warmup 2 --nenvs 1024 --no-cpu-baseline > $O/roctx.log 2>&1
 ./tools/exp/ws_probe > $O/ws_probe.txt 2>&1
