@@ -66,6 +66,7 @@ EXPORTS = {
     "ic3_env_destroy": (C.c_int, [C.c_void_p]),
     "ic3_env_dims": (C.c_int, [C.c_void_p, C.POINTER(Dims)]),
     "ic3_env_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ic3_env_reset_to": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ic3_env_step": (C.c_int, [C.c_void_p] * 7 + [C.c_void_p]),
     "ic3_env_set_auto_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_env_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -309,6 +309,20 @@ int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
     return 0;
 }
 
+int ic3_env_reset_to(ic3_env* env, int epoch, const int32_t* host_state, size_t bytes, float* obs, ic3_stream stream)
+{
+    ic3::Range range_("ic3_env_reset_to");
+    if (!env) return fail(-22, "ic3_env_reset_to: null handle");
+    if (!host_state) return ic3_env_reset(env, epoch, obs, stream);
+    if (bytes != (size_t)env->dims.state_words * 4) return fail(-22, "ic3_env_reset_to: size mismatch");
+    int rc = ic3_env_reset(env, epoch, nullptr, stream);     // episode bookkeeping, curriculum, accumulators
+    if (rc) return rc;
+    IC3_HIP(hipMemcpyAsync(env->state, host_state, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    IC3_HIP(hipStreamSynchronize((hipStream_t)stream));      // the host buffer may be reused by the caller
+    if (obs) return ic3_env_observe(env, obs, stream);
+    return 0;
+}
+
 int ic3_env_set_auto_reset(ic3_env* env, int max_steps)
 {
     if (!env || max_steps < 0) return fail(-22, "ic3_env_set_auto_reset: bad arguments");

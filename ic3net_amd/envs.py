@@ -114,6 +114,25 @@ class _BatchedEnv(object):
             buf[off.value:off.value + cnt.value] = np.asarray(val, np.int32).reshape(-1)
         check(_lib.lib().ic3_env_set_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
 
+    def reset_to(self, state, epoch=None):
+        """reset() into a given initial state (ic3_env_reset_to): the reset bookkeeping runs (TJ curriculum, statistics),
+        then the integer state is exactly `state` — a dict of fields as from get_state(); fields not given keep the
+        values they had before the call.  Returns the observation of that state."""
+        self._require()
+        lib = _lib.lib()
+        buf = np.empty(self.dims.state_words, np.int32)
+        with torch.cuda.device(self.device):
+            check(lib.ic3_env_get_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
+            for name, val in state.items():
+                off, cnt = C.c_int64(), C.c_int64()
+                check(lib.ic3_env_state_field(self._h, name.encode(), C.byref(off), C.byref(cnt)))
+                buf[off.value:off.value + cnt.value] = np.asarray(val, np.int32).reshape(-1)
+            check(lib.ic3_env_reset_to(self._h, -1 if epoch is None else int(epoch), buf.ctypes.data_as(C.c_void_p),
+                                       buf.nbytes, ptr(self._obs), stream()))
+        self.stat = dict()
+        self.episode_over = False
+        return self._obs
+
     def check_actions(self):
         """Synchronising form of the reference's action-range assert (PP:137 / TJ:228)."""
         rc = _lib.lib().ic3_env_check(self._h, stream())

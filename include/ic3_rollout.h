@@ -111,6 +111,12 @@ int ic3_env_dims(const ic3_env* env, ic3_dims* out);
  * epoch < 0 means "no epoch" (reset() without argument).  obs may be NULL. */
 int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream);
 
+/* reset() into a given initial state (`init_state_or_null`): the reset bookkeeping (episode counters,
+ * TJ curriculum, auto-reset accumulators) runs, then the integer state is replaced by `host_state` — a full dump in the
+ * layout of ic3_env_get_state (`bytes` = dims.state_words * 4) — and obs, when given, is assembled from it.
+ * host_state == NULL: plain ic3_env_reset.  Synchronises the stream (the host buffer is free on return). */
+int ic3_env_reset_to(ic3_env* env, int epoch, const int32_t* host_state, size_t bytes, float* obs, ic3_stream stream);
+
 /* Auto-reset: with max_steps > 0 an env whose episode ends at a step (episode_over, or max_steps steps played — the
  * trainer's forced done, trainer.py:90) starts its next episode inside the same step launch: episode += 1, t = 0, a
  * fresh state on the new episode's Philox key, exactly what a reset() would have drawn for that episode.  This is the

@@ -387,6 +387,36 @@ def test_tj_scalar_vocab_vs_oracle_and_encoder():
     assert set(np.unique(grid)) == {0, 1}                      # the reference's self.grid holds road flags here
 
 
+def test_reset_to_a_given_state():
+    """ic3_env_reset_to (SURVEY 8(b2) `init_state_or_null`): reset into a recorded state == reset + set_state + observe,
+    and stepping from there reproduces the recorded trajectory."""
+    envA = make_pp(5, 8, 1, "mixed", 6, seed=3)
+    envA.reset()
+    rs = np.random.RandomState(0)
+    for _ in range(3):
+        envA.step(rs.randint(0, 5, size=(6, 5)))
+    snap = envA.get_state()
+    obs_snap = envA.observe().clone()
+    acts = rs.randint(0, 5, size=(4, 6, 5))
+    want = [tuple(x.clone() for x in envA.step(a)[:3]) for a in acts]
+    envB = make_pp(5, 8, 1, "mixed", 6, seed=3)
+    envB.reset()                                              # a different state (fresh episode) ...
+    obs = envB.reset_to(snap)                                 # ... replaced by the recorded one
+    assert torch.equal(obs, obs_snap)
+    for k in snap:
+        np.testing.assert_array_equal(envB.get_state()[k], snap[k])
+    for a, (o, r, d) in zip(acts, want):
+        o2, r2, d2, _ = envB.step(a)
+        assert torch.equal(o2, o) and torch.equal(r2, r) and torch.equal(d2, d)
+    tj = make_tj(5, 6, 1, "easy", 3, seed=1, add_rate_min=0.5, add_rate_max=0.5)
+    tj.reset(0)
+    tj.step(np.zeros((3, 5), np.int32))
+    st = tj.get_state()
+    o1 = tj.observe().clone()
+    tj.step(np.ones((3, 5), np.int32))
+    assert torch.equal(tj.reset_to(st, epoch=0), o1)
+
+
 def test_render_views_follow_the_reference_drawing():
     """env.render() of a state set through the handle == the draw calls the reference's curses code makes for that state
     (tests/golden/render_fixture.json, recorded from predator_prey_env.py:307-336 / traffic_junction_env.py:254-292)."""
