@@ -256,6 +256,9 @@ def main():
                    help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
     p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
                    help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
+    p.add_argument('--rccl', type=int, default=int(os.environ.get('IC3_BENCH_RCCL', '0')),
+                   help='1: bring up the RCCL process group even for one rank (world_size 1) so that the timing barrier '
+                        'and the MAX / SUM reductions of the N > 1 path run on device tensors over RCCL')
     p.add_argument('--tune-gemm', type=int, default=int(os.environ.get('IC3_BENCH_TUNE_GEMM', '1')),
                    help='let PyTorch TunableOp pick the fastest hipBLASLt/rocBLAS solution for the two policy GEMMs '
                         'during the eager warm-up episode (seconds; selections are kept in memory)')
@@ -327,23 +330,38 @@ def main():
     gc.collect()
     gc.freeze()
     backend = None
-    if world > 1:
+    use_dist = world > 1 or bool(o.rccl)
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         if 'IC3_BENCH_DEVICE' in os.environ:       # test hook (several ranks on one GPU): RCCL refuses duplicate devices
-            dist.init_process_group(backend='gloo')
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
             dist.barrier()
             backend = 'gloo'
         else:
             try:
-                dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-                dist.barrier()
+                # the rank's GPU is named explicitly (LOCAL_RANK -> device): nothing is inferred from the environment
+                dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                        device_id=torch.device('cuda', local_rank))
+                dist.barrier(device_ids=[local_rank])
                 backend = 'nccl'
             except Exception as exc:                   # timing barrier only: gloo is an acceptable stand-in
                 sys.stderr.write("bench.py: RCCL bring-up failed (%r); using gloo for the timing barrier\n" % (exc,))
                 if dist.is_initialized():
                     dist.destroy_process_group()
-                dist.init_process_group(backend='gloo')
+                dist.init_process_group(backend='gloo', rank=rank, world_size=world)
                 dist.barrier()
                 backend = 'gloo'
+    red_dev = 'cuda' if backend == 'nccl' else 'cpu'
+
+    def barrier():
+        if use_dist:
+            if backend == 'nccl':
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
     raw_env.obs_timer = []                    # event-time the obs launch from the start (graphs are captured in this mode)
     if o.tune_gemm:                           # untimed: every GEMM shape is met (and tuned) in one eager episode
         saved_graph, a.hip_graph = a.hip_graph, False
@@ -370,36 +388,62 @@ def main():
         raw_env.dispatch_events = bool(o.dispatch_events)   # events stamped by the dispatch, not recorded around it
     gc.disable()                              # (like timeit: no collector pause in the warm-up + timed steps)
     t_in_ep = run(o.warmup, 0)                # W untimed warm-up steps, in the measured configuration
-    raw_env.obs_timer = []
-    if raw_env.step_timer is not None:
-        raw_env.step_timer = []
-    live0 = live_done[0] + raw_env.device_stats().live_env_steps      # (synchronises) finished episodes + the running one
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    t_in_ep = run(o.steps, t_in_ep)
-    host_dt = time.perf_counter() - t0        # host-side enqueue time (diagnostic: host- vs GPU-bound)
+
+    def timed_region(t_in_ep):
+        """EXACTLY o.steps steps between barrier + synchronize on both sides; returns this rank's wall time, the
+        event-timed launch durations inside it and the live env-steps it simulated."""
+        raw_env.obs_timer = []
+        if raw_env.step_timer is not None:
+            raw_env.step_timer = []
+        live0 = live_done[0] + raw_env.device_stats().live_env_steps  # (synchronises) finished episodes + the running one
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_in_ep = run(o.steps, t_in_ep)
+        host_dt = time.perf_counter() - t0    # host-side enqueue time (diagnostic: host- vs GPU-bound)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        obs_ms = [s_.elapsed_time(e_) for s_, e_ in raw_env.obs_timer]
+        step_all = [(s_.elapsed_time(e_), t_) for s_, e_, t_ in (raw_env.step_timer or [])]
+        live = live_done[0] + raw_env.device_stats().live_env_steps - live0
+        return t_in_ep, dt, host_dt, obs_ms, step_all, live
+
+    # One 6 ms sample (the driver's 20 steps) can be hit by a clock ramp or a host hiccup.  The region is therefore
+    # checked against the device's own clock: the event-timed launches inside it must account for the wall time
+    # (GPU-bound loop: wall = launches + a few us of gaps per step).  A region whose two clocks disagree by more than
+    # 10 % is measured again (at most 3 attempts, each EXACTLY o.steps steps); the attempt count is reported.
+    attempts = []
+    for attempt in range(3):
+        t_in_ep, dt, host_dt, obs_ms, step_all, live_steps = timed_region(t_in_ep)
+        launch_sum = sum(ms for ms, _ in step_all) + sum(obs_ms)
+        consistent = (not step_all) or abs(dt * 1e3 - launch_sum) <= 0.10 * dt * 1e3
+        attempts.append(dict(ms_per_step=round(dt / o.steps * 1e3, 4), launches_ms=round(launch_sum / o.steps, 4),
+                             consistent=bool(consistent)))
+        all_ok = consistent
+        if use_dist:                          # every rank repeats or none does
+            flag = torch.tensor([0.0 if consistent else 1.0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            all_ok = float(flag.item()) == 0.0
+        if all_ok:
+            break
     gc.enable()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+    rank_ms = [dt / o.steps * 1e3]
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)                          # per-rank times: a straggler is visible next to the MAX
+        rank_ms = [float(g.item()) / o.steps * 1e3 for g in gathered]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
-    obs_ms = [s.elapsed_time(e) for s, e in raw_env.obs_timer]
     raw_env.obs_timer = None
-    step_ms = [s.elapsed_time(e) for s, e, t in (raw_env.step_timer or []) if t > 0]   # t = 0 adds the h, c resets
+    step_ms = [ms for ms, t_ in step_all if t_ > 0]            # t = 0 adds the h, c resets
     raw_env.step_timer = None
-    live_steps = live_done[0] + raw_env.device_stats().live_env_steps - live0          # this rank, timed region
     if o.auto_reset:                          # every slot is a real transition (the step counters restart in-launch)
         live_steps = float(o.nenvs * o.steps)
-    if world > 1:
-        lt = torch.tensor([live_steps], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+    if use_dist:
+        lt = torch.tensor([live_steps], dtype=torch.float64, device=red_dev)
         dist.all_reduce(lt, op=dist.ReduceOp.SUM)
         live_steps = float(lt.item())
     if rank == 0:
@@ -456,9 +500,18 @@ def main():
             "cpu_baseline": cpu,
             "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms) if step_ms else None,
             "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),
+            "ms_per_step_ranks": [round(x, 4) for x in rank_ms],
+            "collectives": backend,
+            "timing": {"attempts": attempts, "consistent": attempts[-1]["consistent"],
+                       "launch_ms_min": round(min(step_ms), 4) if step_ms else None,
+                       "launch_ms_median": round(sorted(step_ms)[len(step_ms) // 2], 4) if step_ms else None,
+                       "launch_ms_max": round(max(step_ms), 4) if step_ms else None},
         }
+        if not attempts[-1]["consistent"]:
+            sys.stderr.write("bench.py: wall clock and event-timed launches disagree by more than 10 %% in all %d "
+                             "attempts: %r\n" % (len(attempts), attempts))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -291,6 +291,23 @@ class CommNetMLP(nn.Module):
             ok = self._mega_sup = (env, ops.policy_step_supported(env, self.hid_size))
         return ok[1]
 
+    def mega_supported(self, env):
+        """mega_ok() without an input: the conditions that do not depend on the tensors of a step (the Trainer asks
+        before an episode starts whether that episode will run on the one-launch path)."""
+        a = self.args
+        if not (self._mega_wanted() and getattr(a, 'fused_policy', True) and hasattr(env, '_h')):
+            return False
+        if not (a.recurrent and getattr(a, 'rnn_type', '') == 'LSTM' and self.comm_passes == 1 and len(self.heads) <= 4):
+            return False
+        if sum(int(o) for o in a.naction_heads) + 1 > 16 or self.encoder.weight.dtype != torch.float32:
+            return False
+        if getattr(self.obs_encoder, '__self__', None) is not env or self.nagents != env.nagents_env:
+            return False
+        ok = getattr(self, '_mega_sup', None)
+        if ok is None or ok[0] is not env:
+            ok = self._mega_sup = (env, ops.policy_step_supported(env, self.hid_size))
+        return ok[1]
+
     def zero_hidden(self, batch_size, device):
         """init_hidden() for the one-launch rollout path: the persistent (h, c) buffers step_env() updates in place,
         zeroed — two fills instead of two allocations + fills + two copies at every episode start."""

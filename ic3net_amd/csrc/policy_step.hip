@@ -17,10 +17,12 @@
 //     nonlinearity needs no cross-lane traffic;
 //   * A = [inp | h] tile in LDS, row stride 2H+4 floats: one ds_read_b128 per lane feeds four MFMA k-steps
 //     (k = 8kb + 4*(lane>>5) + j), conflict-free (16-lane phase groups hit 16 distinct 4-bank slots);
-//   * B = weights streamed from L2, pre-packed as Wp[k/8][col][(k>>2)&1][k&3] (ic3_policy_pack): one coalesced
-//     16-byte load per lane per gate per 8 k, two register buffers refilled a full 32-MFMA block ahead;
+//   * B = weights streamed from L2, pre-packed by ic3_policy_pack as Wq[k][c] = float4 over the four gates of hidden
+//     column c: one coalesced 16-byte load per lane per k-step, a ring of four float4 refilled 24 MFMAs ahead
+//     (the C product keeps Wp[k/8][col][(k>>2)&1][k&3]);
 //   * LDS budget 64 x (2H+4) floats = 66.5 KB: the encoder output is staged through the h half, parked in the
 //     accumulators of the C product (which it initialises), and the communication tile takes the inp half.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -34,6 +36,7 @@ namespace ic3 {
 
 typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
 typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
+typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_32x32x2_f32, optionally with the accumulator pinned to AGPRs (IC3_PS_AGPR=1): hipcc picks the all-VGPR
 // form when the registers fit, which streams ~6 % slower in isolation (144 vs 153 TFLOP/s, tools/exp/ws_probe.hip).
@@ -54,6 +57,12 @@ typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
 #ifndef IC3_PS_AGPR
 #define IC3_PS_AGPR 0   // measured: the 128/128 VGPR/AGPR split spills in the phases around the loops; net slower (0.57 vs 0.52 ms)
 #endif
+// Timing ablations are COMPILE-TIME only (tools/build_variant.sh abl1 -DIC3_PS_ABL=1 ...): a set bit removes a phase and
+// makes the results wrong, so no environment variable of the shipped library can do it.  Bits: 1 gate MFMA loop,
+// 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic, 32 obs patch pass.
+#ifndef IC3_PS_ABL
+#define IC3_PS_ABL 0
+#endif
 __device__ __forceinline__ void mfma_acc(ps_f32x16& acc, float x, float y)
 {
 #if IC3_PS_AGPR
@@ -69,6 +78,32 @@ __device__ __forceinline__ void mfma_settle()
 #endif
 }
 
+// ---- vector-memory bookkeeping --------------------------------------------------------------------------------------
+// A wave has ONE counter (vmcnt) for its outstanding loads AND stores, they complete in issue order, and s_waitcnt
+// takes an immediate.  Round 2 issued the obs zero stores as inline asm behind a run-time count: invisible to the
+// compiler, whose `s_waitcnt vmcnt(n)` in front of each MFMA group therefore counted only the weight loads — with
+// stores in between, "at most n operations outstanding" turned into "the zero stores issued a moment ago have been
+// acknowledged" (the gate loop ran 12 % over its MFMA time, every load behind the loop first drained the store queue).
+// Now every vector-memory operation of the kernel is a compiler-visible builtin and the zero stores are issued
+// UNCONDITIONALLY — the hardware range check of their buffer descriptor drops the ones past the tile's slice
+// (tools/exp/buf_probe.hip: VGPR and SGPR offsets both take part in the check) — so the number of operations between
+// any load and its first use is a compile-time property of the program and the compiler's waits are exact.
+// (A first version kept inline-asm loads with hand-written waits tied to their registers by "+v" operands: the compiler
+// is free to COPY such a register in front of the wait, and did — stale weights whenever the L2 was cold.)
+typedef unsigned int ps_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ ps_f32x4 buf_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 struct StepArgs {
     // policy (ic3_policy)
     const ps_f32x4* Wt;         // encoder.weight^T [obs_dim][H/4]
@@ -82,13 +117,11 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
-    int zmode;                  // experiment bits (+4 / +8 / +16, see the kernel)
     unsigned long long* trace;  // IC3_PS_TRACE builds: [tiles][20] phase time stamps
-    int zb, zl, zc;               // zero-store pacing: per burst in front of the gate loop; inside it one nibble per k sub-step
-    int skew;                   // IC3_PS_SKEW: workgroups 256..511 start this many s_sleep(127) late (phase offset
-                                // between the two co-resident workgroups of a CU; speed only)
-    int dbg;                    // timing ablations (IC3_PS_DEBUG bit mask; results are wrong when set): 1 gate MFMA loop,
-                                // 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic, 32 obs patch pass
+    // pacing of the obs zero fill (speed only — every store slot past the tile's slice is dropped by the hardware):
+    int zs;                     // stores per K block of the gate loop (one of ZS_SET; a block = 32 MFMAs of a full tile)
+    int zf, zepi, zh;           // stores in front of the comm phase; per element of the cell epilogue (0..2); in front of the heads
+    int zrest;                  // stores per wave issued behind the cell epilogue (what the other slots left)
     // recurrent state, masks, outputs
     float* h;                   // [R][H] in place
     float* c;                   // [R][H] in place
@@ -112,624 +145,706 @@ struct StepArgs {
     TJState tj;
 };
 
-template <int H, int KIND>
-__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(const StepArgs a)
-{
-    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                            // [BM][LDA]: cols [0,H) inp / comm, [H,2H) h / enc / h'
-    ps_f32x4* As4 = reinterpret_cast<ps_f32x4*>(smem);
-    float* sm = As + BM * LDA;                                   // [BM] m_j = alive_j * comm_action_j
-    float* sscale = sm + BM;                                     // [BM] per-env 1/(n_alive-1)
-    int32_t* sact = reinterpret_cast<int32_t*>(sscale + BM);     // [BM] env action (head 0) of every row
-    uint32_t* rmask = reinterpret_cast<uint32_t*>(sact + BM);    // [BM] window cells of every row that carry a count
-    uint32_t* sfm = rmask + BM;                                  // [2] (+2 pad) bit r: row r starts an episode (auto-reset)
-    int32_t* tile = reinterpret_cast<int32_t*>(sfm + 4);         // env descriptors of the tile's envs
+// zero-store slots of one K block: 16 slots (one behind every pair of MFMAs of a full tile), S of them in use, evenly
+constexpr bool ps_zslot(int S, int i) { return S > 0 && ((i + 1) * S / 16) > (i * S / 16); }
 
-    if (a.skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < a.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    const int tid = threadIdx.x;
-    IC3_TR(0);
-#ifdef IC3_PS_TRACE
-    if (a.trace && tid == 0) {
-        a.trace[(size_t)blockIdx.x * 20 + 18] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-        a.trace[(size_t)blockIdx.x * 20 + 19] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-    }
-#endif
-    const int N = a.N;
-    const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
-    const int total = a.pp.Np + a.pp.nprey;
-    const int nsegE = N * WW;
-    const int tjw = tj_tile_words(N, WW);
-    const float inv_WW = 1.0f / (float)max(WW, 1);
-    const float invN = 1.0f / (float)N, inv_nsegE = 1.0f / (float)max(nsegE, 1);   // div_small(): no integer divisions
-    // env descriptors of `ne` envs starting at env `eb`, into the LDS block `tl` (two phases around a barrier):
-    //   PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x TJTile
-    auto desc_positions = [&](int32_t* tl, int eb, int ne) {
-        if constexpr (KIND == IC3_ENV_PP) {
-            int32_t* psr = tl;
-            int32_t* psc = tl + a.EPT * total;
-            for (int i = tid; i < ne * total; i += NT) {
-                psr[i] = a.pp.loc_r[(size_t)eb * total + i];
-                psc[i] = a.pp.loc_c[(size_t)eb * total + i];
-            }
-        } else if constexpr (KIND == IC3_ENV_TJ) {
-            for (int i = tid; i < ne * N; i += NT) {
-                const int el = div_small(i, invN);
-                tj_tile_load_car(tj_tile_at(tl + el * tjw, N), a.tj, eb + el, i - el * N);
-            }
-        }
-    };
-    auto desc_tab = [&](int32_t* tl, int ne) {
-        if constexpr (KIND != 0) {
-            int2* pt = reinterpret_cast<int2*>(tl + ((2 * a.EPT * total + 3) & ~3));
-            for (int s = tid; s < ne * nsegE; s += NT) {
-                const int el = div_small(s, inv_nsegE), q = s - el * nsegE;
-                int2 d;
-                if constexpr (KIND == IC3_ENV_PP) {
-                    d = pp_tab_entry(tl + el * total, tl + a.EPT * total + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
-                    pt[s] = d;
-                } else {
-                    const TJTile t = tj_tile_at(tl + el * tjw, N);
-                    d = tj_tab_entry(t, a.tj, q);
-                    t.tab[q] = d;
-                }
-                if (d.y != 0 && WW <= 32) {          // rows of the encoder only visit the cells flagged here
-                    const int ag = div_small(q, inv_WW);
-                    atomicOr(&rmask[el * N + ag], 1u << (q - ag * WW));
-                }
-            }
-        }
-    };
-    // one workgroup per tile: the hardware dispatcher balances the tiles over the CUs (a resident set of workgroups
-    // walking a strided tile list was measured slower: 350 vs 327 us, and needed tricks against hoisted loads)
-    const int tile_id = blockIdx.x;
-    constexpr int tz = 0;
-    const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int col = 32 * w + li;
+// Geometry of one tile, derived from the kernel arguments and the tile index only — the phases behind the gate loop
+// derive it AGAIN from a re-read copy of the arguments instead of keeping ~40 scalars (and the 40 argument pointers)
+// alive across the loop: round 2's kernel spilled 150 SGPRs to VGPR lanes and read them back with ~800 v_readlane per wave.
+struct TileGeom {
+    int e0, nenv, rows;
+    bool two, obs_here;
+    size_t r0;
+    long long ob0;      // first float of the tile's obs rows
+    int oL, ohead, onb, mis, c_lo, c_hi, zend;
+};
+template <int KIND>
+__device__ __forceinline__ TileGeom tile_geom(const StepArgs& a, int tile_id)
+{
+    TileGeom g;
     // full tiles first; the envs left over behind the last round that gives every CU the same number of them go out as
     // HALF tiles (<= 32 rows: one 32-row MFMA tile, half the matrix work) — see plan_tiles()
     const bool half = tile_id >= a.n_full;
-    const int e0 = half ? a.n_full * a.EPT + (tile_id - a.n_full) * a.EPTh : tile_id * a.EPT;
-    const int nenv = min(half ? a.EPTh : a.EPT, a.E - e0);
-    const int rows = nenv * N;                                   // valid rows of this tile (<= 64; <= 32 in a half tile)
-    const bool two = rows > 32;                                  // second 32-row MFMA tile in use (workgroup-uniform)
-    const size_t r0 = (size_t)e0 * N;
-
-    // ---- dense observation of the state this step acts on (the `state` the reference hands to policy_net,
-    // trainer.py:49), written by the launch that consumes it.  A wave that streams fp32 MFMAs leaves no issue slots to
-    // any other wave of its SIMD (measured: tools/exp/ws_probe.hip), so the store stream can only share time with the
-    // matrix work from INSIDE the same instruction stream — and there every instruction counts.  The rows are ~98 %
-    // zeros: the tile's contiguous slice of the obs tensor is ZERO-FILLED by stores sprinkled between the MFMAs of the
-    // gate loop and the transcendentals of the LSTM epilogue (scalar bookkeeping only), and the few non-zero entries
-    // (<= 3 per window cell) are patched in at the very end, after every wave has seen its zero stores complete
-    // (s_waitcnt + barrier).
-    const bool obs_here = (KIND != 0) && a.obs != nullptr;
-    const long long ob0 = (long long)e0 * N * a.obs_dim;         // first float of the tile's rows
-    const int oL = rows * a.obs_dim;                             // floats of the tile
-    const int ohead = (int)((4 - (ob0 & 3)) & 3);
-    const int onb = obs_here ? (oL - ohead) >> 2 : 0;            // float4s of the body
-    ps_f32x4* const obody = reinterpret_cast<ps_f32x4*>(a.obs + ob0 + ohead);
+    g.e0 = half ? a.n_full * a.EPT + (tile_id - a.n_full) * a.EPTh : tile_id * a.EPT;
+    g.nenv = min(half ? a.EPTh : a.EPT, a.E - g.e0);
+    g.rows = g.nenv * a.N;                                       // valid rows of this tile (<= 64; <= 32 in a half tile)
+    g.two = g.rows > 32;                                         // second 32-row MFMA tile in use (workgroup-uniform)
+    g.r0 = (size_t)g.e0 * a.N;
+    g.obs_here = (KIND != 0) && a.obs != nullptr;
+    g.ob0 = (long long)g.e0 * a.N * a.obs_dim;
+    g.oL = g.rows * a.obs_dim;                                   // floats of the tile
+    g.ohead = (int)((4 - (g.ob0 & 3)) & 3);
+    g.onb = g.obs_here ? (g.oL - g.ohead) >> 2 : 0;              // float4s of the 16-byte aligned body
     // The body is cut into 1 KiB-aligned chunks of 64 float4s (see pp_obs_kernel); chunk c holds body indices
-    // [64c - mis, 64c - mis + 64).  The (at most two) ragged chunks at the ends go out here with lane predicates; the
-    // full ones are dealt round-robin to the waves and issued by zero_store() with wave-uniform control only: a scalar
-    // count, a scalar base address (SGPR pair, bumped by scalar adds), one constant lane offset and a zero vector held
-    // in registers — no vector ALU work, no exec masking, nothing for the matrix pipe to wait for.
-    // Cache policy: non-temporal.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of weights
-    // every tile streams from there: with plain stores (a -DIC3_PS_PLAIN_STORES build) the kernel takes 0.50 ms
-    // instead of 0.38.
-    // (zmode +16: no L2 warm-up of c; +32: rest of the zero fill right behind the loop — experiments)
-    const int mis = (int)(((ob0 + ohead) >> 2) & 63);
-    const int c_lo = mis ? 1 : 0, c_hi = (mis + onb) >> 6;       // full chunks: [c_lo, c_hi)
-    const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int zleft = 0;
-    uint32_t zb_lo = 0, zb_hi = 0;
-    if (obs_here) {
-        zleft = __builtin_amdgcn_readfirstlane(max(0, (c_hi - c_lo - ws + NW - 1) / NW));
-        const uint64_t zb = (uint64_t)obody + (uint64_t)((long long)(64 * (c_lo + ws) - mis) * 16);
-        zb_lo = __builtin_amdgcn_readfirstlane((uint32_t)zb);
-        zb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(zb >> 32));
-    }
-    const uint32_t zoff = (uint32_t)lane * 16u;
+    // [64c - mis, 64c - mis + 64); full chunks: [c_lo, c_hi)
+    g.mis = (int)(((g.ob0 + g.ohead) >> 2) & 63);
+    g.c_lo = g.mis ? 1 : 0;
+    g.c_hi = (g.mis + g.onb) >> 6;
+    g.zend = g.obs_here ? max(0, (64 * g.c_hi - g.mis) * 16) : 0;   // bytes of the body up to the last full chunk
+    return g;
+}
+
+// the kernel arguments once more, by scalar loads from the kernarg segment behind an opaque pointer (the compiler cannot
+// tell that they are the values it already holds, so none of the first copy has to stay alive for the second)
+__device__ __forceinline__ void reload_args(StepArgs& a)
+{
+    typedef const __attribute__((address_space(4))) int* KWords;
+    KWords kp = (KWords)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    static_assert(sizeof(StepArgs) % 4 == 0, "StepArgs is a whole number of dwords");
+    int* dst = reinterpret_cast<int*>(&a);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(StepArgs) / 4); ++i) dst[i] = kp[i];
+}
+
+template <int H, int KIND>
+__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(const StepArgs a_in)
+{
+    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
+    constexpr int ABL = IC3_PS_ABL;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                                      // [BM][LDA]: cols [0,H) enc / comm / inp, [H,2H) h / h'
+    ps_f32x4* const As4 = reinterpret_cast<ps_f32x4*>(smem);
+    float* const sm = As + BM * LDA;                             // [BM] m_j = alive_j * comm_action_j
+    float* const sscale = sm + BM;                               // [BM] per-env 1/(n_alive-1)
+    int32_t* const sact = reinterpret_cast<int32_t*>(sscale + BM);   // [BM] env action (head 0) of every row
+    uint32_t* const rmask = reinterpret_cast<uint32_t*>(sact + BM);  // [BM] window cells of every row that carry a count
+    uint32_t* const sfm = rmask + BM;                            // [2] (+2 pad) bit r: row r starts an episode (auto-reset)
+    int32_t* const sep = reinterpret_cast<int32_t*>(sfm + 4);    // [BM] episode counter of the tile's envs (Philox key)
+    int32_t* const sts = sep + BM;                               // [BM] step counter of the tile's envs
+    float* const shb = reinterpret_cast<float*>(sts + BM);       // [16] head / value biases
+    float* const slb = shb + 16;                                 // [4H] b_ih + b_hh
+    int32_t* const tile = reinterpret_cast<int32_t*>(slb + 4 * H);   // env descriptors of the tile's envs
+    constexpr int tz = 0;
+    constexpr int KB = K / 8;
+    constexpr int PER = H / 16;
+
+    // ---- state that crosses the gate loop: accumulators, the old cell state, the zero-store cursor ---------------------
+    ps_f32x16 acc[2][4];
+    float cold[2][16];
+    __amdgpu_buffer_rsrc_t zr;                                   // descriptor of the tile's obs slice (see below)
     ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
     asm volatile("" : "+v"(zv));                                 // keep it in registers (no re-materialisation per store)
+    int zlane, zso;                                              // lane offset; running byte offset of this wave's next chunk (SGPR)
     auto zero_store = [&]() {
-        if (zleft > 0) {
-            const uint64_t zb = ((uint64_t)zb_hi << 32) | zb_lo;
 #ifdef IC3_PS_PLAIN_STORES
-            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, 0);
 #else
-            asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(zoff), "v"(zv), "s"(zb) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, 2);   // nt
 #endif
-            const uint64_t nb = zb + (uint64_t)NW * 1024u;
-            zb_lo = (uint32_t)nb;
-            zb_hi = (uint32_t)(nb >> 32);
-            --zleft;
-        }
+        zso += NW * 1024;
     };
-    auto zero_burst = [&](int n) {
-#pragma unroll 1
-        for (int i = 0; i < n; ++i) zero_store();
-    };
-    if (obs_here) {
-        // ragged chunks: chunk 0 when the body starts inside it, chunk c_hi when the body ends inside it
-        const int q0 = lane - mis, q1 = 64 * c_hi - mis + lane;
-        if (ws == 0 && mis && q0 >= 0 && q0 < onb) obody[q0] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
-        if (ws == 1 % NW && ((mis + onb) & 63) && (c_hi > 0 || !mis) && q1 >= 0 && q1 < onb)
-            obody[q1] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
-    }
-    if (obs_here) {
-        const int otail = (oL - ohead) & 3;
-        if (tid < ohead) a.obs[ob0 + tid] = 0.f;
-        if (tid < otail) a.obs[ob0 + ohead + 4 * (long long)onb + tid] = 0.f;
-    }
 
-    // ---- S0: masks, per-env scale (comm.py:102-107,194-196; quirks Q21/Q23), entity positions --------------------
-    // auto-reset: an env whose t == 0 is at the start of an episode — no alive mask yet (everyone counts as alive,
-    // quirk Q21), gate 0 (no communication on the first step, quirk Q22), zero LSTM state (trainer.py:38-51)
-    const bool autor = (KIND != 0) && a.auto_reset;              // workgroup-uniform
-    auto fresh_row = [&](int row) {                              // only called when autor
-        const int el = (int)(((float)row + 0.5f) * (1.0f / (float)N));   // row / N, exact for row < 64
-        return a.tstep[e0 + el] == 0;
-    };
-    for (int r = tid; r < BM; r += NT) {                        // (NT >= 128: this is exactly wave 0, all lanes)
-        float m = 0.f;
-        const bool fr = autor && r < rows && fresh_row(r);
-        if (r < rows && !fr)
-            m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
-        sm[r] = m;
-        if constexpr (KIND != 0) rmask[r] = (WW <= 32) ? 0u : ~0u;   // filled next to the window descriptors (S1)
-        if (autor) {                                              // one global read per row, here; later phases test a bit
-            const unsigned long long fb = __ballot(fr);
-            if (lane == 0) {
-                sfm[0] = (uint32_t)fb;
-                sfm[1] = (uint32_t)(fb >> 32);
+    // =====================================================================================================================
+    // FRONT: masks, descriptors, encoder, comm, C product, gate GEMM
+    // =====================================================================================================================
+    {
+        const StepArgs& a = a_in;
+        const int tid = threadIdx.x;
+        IC3_TR(0);
+#ifdef IC3_PS_TRACE
+        if (a.trace && tid == 0) {
+            a.trace[(size_t)blockIdx.x * 20 + 18] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+            a.trace[(size_t)blockIdx.x * 20 + 19] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+        }
+#endif
+        const int N = a.N;
+        const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
+        const int total = a.pp.Np + a.pp.nprey;
+        const int nsegE = N * WW;
+        const int tjw = tj_tile_words(N, WW);
+        const float inv_WW = 1.0f / (float)max(WW, 1);
+        const float invN = 1.0f / (float)N, inv_nsegE = 1.0f / (float)max(nsegE, 1);   // div_small(): no integer divisions
+        // env descriptors of `ne` envs starting at env `eb`, into the LDS block `tl` (two phases around a barrier):
+        //   PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x TJTile
+        auto desc_positions = [&](int32_t* tl, int eb, int ne) {
+            if constexpr (KIND == IC3_ENV_PP) {
+                int32_t* psr = tl;
+                int32_t* psc = tl + a.EPT * total;
+                for (int i = tid; i < ne * total; i += NT) {
+                    psr[i] = a.pp.loc_r[(size_t)eb * total + i];
+                    psc[i] = a.pp.loc_c[(size_t)eb * total + i];
+                }
+            } else if constexpr (KIND == IC3_ENV_TJ) {
+                for (int i = tid; i < ne * N; i += NT) {
+                    const int el = div_small(i, invN);
+                    tj_tile_load_car(tj_tile_at(tl + el * tjw, N), a.tj, eb + el, i - el * N);
+                }
+            }
+        };
+        auto desc_tab = [&](int32_t* tl, int ne) {
+            if constexpr (KIND != 0) {
+                int2* pt = reinterpret_cast<int2*>(tl + ((2 * a.EPT * total + 3) & ~3));
+                for (int s = tid; s < ne * nsegE; s += NT) {
+                    const int el = div_small(s, inv_nsegE), q = s - el * nsegE;
+                    int2 d;
+                    if constexpr (KIND == IC3_ENV_PP) {
+                        d = pp_tab_entry(tl + el * total, tl + a.EPT * total + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
+                        pt[s] = d;
+                    } else {
+                        const TJTile t = tj_tile_at(tl + el * tjw, N);
+                        d = tj_tab_entry(t, a.tj, q);
+                        t.tab[q] = d;
+                    }
+                    if (d.y != 0 && WW <= 32) {          // rows of the encoder only visit the cells flagged here
+                        const int ag = div_small(q, inv_WW);
+                        atomicOr(&rmask[el * N + ag], 1u << (q - ag * WW));
+                    }
+                }
+            }
+        };
+        // one workgroup per tile: the hardware dispatcher balances the tiles over the CUs (a resident set of workgroups
+        // walking a strided tile list was measured slower: 350 vs 327 us, and needed tricks against hoisted loads)
+        const TileGeom g = tile_geom<KIND>(a, blockIdx.x);
+        const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+        const int col = 32 * w + li;
+        const int e0 = g.e0, nenv = g.nenv, rows = g.rows;
+        const bool two = g.two;
+        const size_t r0 = g.r0;
+
+        // ---- dense observation of the state this step acts on (the `state` the reference hands to policy_net,
+        // trainer.py:49), written by the launch that consumes it.  A wave that streams fp32 MFMAs leaves the vector ALU
+        // to no other wave of its SIMD (measured: tools/exp/ws_probe.hip), so the store stream shares time with the
+        // matrix work from INSIDE the same instruction stream.  The rows are ~98 % zeros: the tile's contiguous slice of
+        // the obs tensor is ZERO-FILLED by stores sprinkled between the MFMAs of the gate loop and the transcendentals
+        // of the LSTM epilogue, and the few non-zero entries (<= 3 per window cell) are patched in at the very end,
+        // after every wave has seen its zero stores complete (s_waitcnt + barrier).
+        // The (at most two) ragged chunks at the ends of the body go out with lane predicates behind the cell epilogue;
+        // the full ones [c_lo, c_hi) are dealt round-robin to the waves and issued by zero_store(): ONE buffer store
+        // through a descriptor that ends with chunk c_hi - 1 — a slot past the wave's last chunk is dropped by the
+        // hardware range check, so a slot is two instructions with no count, compare or branch, and the number of
+        // stores in flight at any point of the program is a compile-time constant (exact compiler waits, see above).
+        // Cache policy: non-temporal.  1.2 GB of zeros per launch flow through the 4 MB L2s next to the 0.6 MB of
+        // weights every tile streams from there: with plain stores (a -DIC3_PS_PLAIN_STORES build) the kernel takes
+        // 0.50 ms instead of 0.38.
+        {
+            const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int first = (64 * (g.c_lo + ws) - g.mis) * 16;     // this wave's first full chunk (>= 0)
+            const float* obody = a.obs + g.ob0 + g.ohead;
+            zr = make_rsrc(obody, (uint32_t)g.zend);
+            zlane = lane * 16;
+            zso = __builtin_amdgcn_readfirstlane(first);
+        }
+
+        // ---- S0: masks, per-env scale (comm.py:102-107,194-196; quirks Q21/Q23), entity positions ----------------
+        // auto-reset: an env whose t == 0 is at the start of an episode — no alive mask yet (everyone counts as alive,
+        // quirk Q21), gate 0 (no communication on the first step, quirk Q22), zero LSTM state (trainer.py:38-51)
+        const bool autor = (KIND != 0) && a.auto_reset;              // workgroup-uniform
+        auto fresh_row = [&](int row) {                              // only called when autor
+            const int el = (int)(((float)row + 0.5f) * (1.0f / (float)N));   // row / N, exact for row < 64
+            return a.tstep[e0 + el] == 0;
+        };
+        for (int r = tid; r < BM; r += NT) {                        // (NT >= 128: this is exactly wave 0, all lanes)
+            float m = 0.f;
+            const bool fr = autor && r < rows && fresh_row(r);
+            if (r < rows && !fr)
+                m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
+            sm[r] = m;
+            if (r < 16) shb[r] = r < a.OT ? a.head_b[r + tz] : 0.0f;   // (a load behind the gate loop would first
+                                                                       //  wait for every zero store in flight)
+            if constexpr (KIND != 0) {
+                rmask[r] = (WW <= 32) ? 0u : ~0u;                    // filled next to the window descriptors (S1)
+                if (r < nenv) {                                      // Philox counters of the draws (S11): read here, once
+                    sep[r] = a.episode[e0 + r];
+                    sts[r] = a.tstep[e0 + r];
+                }
+            }
+            {                                                     // one global read per row, here; later phases test a bit
+                const unsigned long long fb = __ballot(fr);
+                if (lane == 0) {
+                    sfm[0] = (uint32_t)fb;
+                    sfm[1] = (uint32_t)(fb >> 32);
+                }
             }
         }
-    }
-    for (int el = tid; el < nenv; el += NT) {
-        int n_alive = 0;
-        const bool fr = autor && a.tstep[e0 + el] == 0;
-        for (int j = 0; j < N; ++j) n_alive += (a.alive_in && !fr) ? a.alive_in[r0 + (size_t)el * N + j] : 1;
-        sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
-    }
-    int32_t* sr = tile;
-    int32_t* sc = tile + a.EPT * total;
-    int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
-    desc_positions(tile, e0, nenv);
-    // h rows of the tile: requested now (HBM latency runs under S1/S2), parked in registers until the encoder output
-    // has left the h half of the LDS tile
-    ps_f32x4 hv[8];
-    {
-        // rows are contiguous: float4 number idx of the tile sits at byte 16 * idx; rows >= `rows` read as zeros
-        // (descriptor range check), the constant part of the offset rides on the scalar operand
-        const __amdgpu_buffer_rsrc_t rhh = __builtin_amdgcn_make_buffer_rsrc(
-            static_cast<void*>(a.h + r0 * H), 0, (uint32_t)rows * H * 4u, 0x00020000);
+        for (int i = tid; i < 4 * H; i += NT) slb[i] = a.l_bias[i + tz];
+        for (int el = tid; el < nenv; el += NT) {
+            int n_alive = 0;
+            const bool fr = autor && a.tstep[e0 + el] == 0;
+            for (int j = 0; j < N; ++j) n_alive += (a.alive_in && !fr) ? a.alive_in[r0 + (size_t)el * N + j] : 1;
+            sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
+        }
+        int32_t* sr = tile;
+        int32_t* sc = tile + a.EPT * total;
+        int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
+        desc_positions(tile, e0, nenv);
+        // h rows of the tile: requested now (HBM latency runs under S1/S2), parked in registers until S4
+        ps_f32x4 hv[8];
+        {
+            // rows are contiguous: float4 number idx of the tile sits at byte 16 * idx; rows >= `rows` read as zeros
+            // (descriptor range check)
+            const __amdgpu_buffer_rsrc_t rhh = __builtin_amdgcn_make_buffer_rsrc(
+                static_cast<void*>(a.h + r0 * H), 0, (uint32_t)rows * H * 4u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                hv[i] = __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhh, tid * 16 + i * NT * 16, 0, 0));
+            }
+        }
+        __syncthreads();
+        IC3_TR(1);
+        unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
+        if (autor)
+            fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
+                    ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
+
+        // ---- S1: window descriptors --------------------------------------------------------------------------------
+        if constexpr (KIND != 0) {
+            desc_tab(tile, nenv);
+            __syncthreads();
+            IC3_TR(2);
+        }
+        // encoder weight rows / pre-summed location rows behind buffer descriptors (32-bit gather offsets)
+        const BufRows encW = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.Wt), 0,
+                                                                 (uint32_t)((size_t)a.obs_dim * H * sizeof(float)), 0x00020000),
+                               a.Wt != nullptr };
+        const BufRows encL = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.loc_table), 0, 0x7fffffffu, 0x00020000),
+                               a.loc_table != nullptr };
+        // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> inp half ----------
+#pragma unroll IC3_PS_ENC_UNROLL
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / H4, c4 = idx - row * H4;
+            ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+            if (row < rows && !(ABL & 4)) {
+                const int el = div_small(row, invN), aa = row - el * N;
+                if constexpr (KIND == 0) {
+                    v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
+                } else if constexpr (KIND == IC3_ENV_PP) {
+                    v = pp_encode_row_t(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
+                                        a.pp.dim * a.pp.dim + 4, a.pp.dim, encW, a.enc_bias + tz, encL, rmask[row]);
+                } else {
+                    v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, a.enc_bias + tz, encL,
+                                        rmask[row]);
+                }
+            }
+            As4[row * LDA4 + c4] = v;
+        }
+        // ---- S4 (the other half of the tile: no barrier in front): h -> h half ----------------------------------------
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            hv[i] = __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhh, tid * 16, i * NT * 16, 0));
+            const int idx = tid + i * NT;
+            const int row = idx / H4, c4 = idx - row * H4;
+            As4[row * LDA4 + H4 + c4] = (autor && ((fmask >> row) & 1)) ? ps_f32x4{ 0.f, 0.f, 0.f, 0.f } : hv[i];
         }
-    }
-    // (a few zero stores per burst in front of the gate loop, see the pacing notes in ic3_policy_step)
-    zero_burst(a.zb);
-    __syncthreads();
-    IC3_TR(1);
-    unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
-    if (autor)
-        fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
-                ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
-
-    // ---- S1: window descriptors ------------------------------------------------------------------------------------
-    if constexpr (KIND != 0) {
-        desc_tab(tile, nenv);
         __syncthreads();
-        IC3_TR(2);
-    }
-    zero_burst(a.zb);
-    // encoder weight rows / pre-summed location rows behind buffer descriptors (32-bit gather offsets)
-    const BufRows encW = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.Wt), 0,
-                                                             (uint32_t)((size_t)a.obs_dim * H * sizeof(float)), 0x00020000),
-                           a.Wt != nullptr };
-    const BufRows encL = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.loc_table), 0, 0x7fffffffu, 0x00020000),
-                           a.loc_table != nullptr };
-    // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> h half of the tile ----
-#pragma unroll IC3_PS_ENC_UNROLL
-    for (int i = 0; i < 8; ++i) {
-        const int idx = tid + i * NT;
-        const int row = idx / H4, c4 = idx - row * H4;
-        ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
-        if (row < rows && !(a.dbg & 4)) {
-            const int el = div_small(row, invN), aa = row - el * N;
-            if constexpr (KIND == 0) {
-                v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
-            } else if constexpr (KIND == IC3_ENV_PP) {
-                v = pp_encode_row_t(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
-                                    a.pp.dim * a.pp.dim + 4, a.pp.dim, encW, a.enc_bias + tz, encL, rmask[row]);
-            } else {
-                v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, a.enc_bias + tz, encL,
-                                    rmask[row]);
-            }
-        }
-        As4[row * LDA4 + H4 + c4] = v;
-    }
-    __syncthreads();
-    IC3_TR(3);
+        IC3_TR(3);
 
-    // ---- S3: the encoder output moves into the accumulators of the C product (MFMA C/D layout:
-    //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------------------------------------------------
-    ps_f32x16 accC[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        if (rt == 1 && !two) break;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            accC[rt][reg] = As[lr * LDA + H + col];
-        }
-    }
-    __syncthreads();
-    IC3_TR(4);
-
-    zero_burst(a.zb);
-    // ---- S4: h -> h half ---------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = tid + i * NT;
-        const int row = idx / H4, c4 = idx - row * H4;
-        As4[row * LDA4 + H4 + c4] = (autor && ((fmask >> row) & 1)) ? ps_f32x4{ 0.f, 0.f, 0.f, 0.f } : hv[i];
-    }
-    __syncthreads();
-    IC3_TR(5);
-
-    zero_burst(a.zb);
-    if (!a.comm_zero) {   // comm_mask_zero (comm.py:40-41): C sees zeros, inp = enc + C.bias
-        // ---- S5: comm_j = m_j (S_e - m_j h_j) scale_e (closed form of comm.py:181-205) -> inp half --------------------
-        {
-            const int c4 = tid % H4;
-            for (int el = tid / H4; el < nenv; el += NT / H4) {
-                const ps_f32x4* hp = As4 + (el * N) * LDA4 + H4 + c4;
-                const float scl = sscale[el];
-                ps_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
-                for (int i = 0; i < N; ++i) S += sm[el * N + i] * hp[i * LDA4];
-                for (int j = 0; j < N; ++j) {
-                    const float m = sm[el * N + j];
-                    As4[(el * N + j) * LDA4 + c4] = m * (S - m * hp[j * LDA4]) * scl;
-                }
-            }
-            for (int idx = rows * H4 + tid; idx < BM * H4; idx += NT) {
-                const int row = idx / H4, c4p = idx - row * H4;
-                As4[row * LDA4 + c4p] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
-            }
-        }
-        // B fragments of C: lane (li, lh) of wave w reads Wp[kb][32w + li][lh] -> k = 8kb + 4lh + j, j = 0..3
-        constexpr int KBC = H / 8, CH = (KBC < 8) ? KBC : 8, NCH = KBC / CH;
-        // weights through a buffer descriptor: lane offset in one VGPR, the k / gate part of the address on the scalar ALU
-        const __amdgpu_buffer_rsrc_t rcw = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<ps_f32x4*>(a.c_wp), 0, (uint32_t)((size_t)H * H * sizeof(float)), 0x00020000);
-        const int wlane = (col * 2 + lh) * 16;
-        auto cwp = [&](int k) {
-            return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rcw, wlane, k * (H * 2 * 16), 0));
-        };
-        ps_f32x4 cb[2][CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) cb[0][k] = cwp(k);
-        __syncthreads();
-        IC3_TR(6);
-        // ---- S6: accC (= enc) += comm . C.weight^T ---------------------------------------------------------------------
-        auto cprod = [&](auto two_c) {
-            constexpr bool TWO = decltype(two_c)::value;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                if (ch + 1 < NCH) {
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp((ch + 1) * CH + k);
-                }
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    const int kb = ch * CH + k;
-                    const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-                    ps_f32x4 a1;
-                    if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
-                        if constexpr (TWO) mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
-                    }
-                    if (obs_here && kb < a.zc) zero_store();
-                }
-            }
-        };
-        if (!(a.dbg & 2)) {
-            if (two) cprod(std::true_type{});
-            else cprod(std::false_type{});
-        }
-        mfma_settle();
-        __syncthreads();   // every wave has read the comm tile
-        IC3_TR(7);
-    }
-
-    // gate weights: the first two 8-k blocks are requested before inp is written back
-    constexpr int KB = K / 8;
-    constexpr size_t KB_STRIDE = (size_t)4 * H * 2;   // float4s per kb
-    const __amdgpu_buffer_rsrc_t rgw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<ps_f32x4*>(a.l_wp), 0, (uint32_t)((size_t)K * 4 * H * sizeof(float)), 0x00020000);
-    const int glane = (col * 2 + lh) * 16;
-    auto wp = [&](int kb, int g) {   // float4 of gate g, k block kb (KB_STRIDE float4s per block, 2 H per gate)
-        return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rgw, glane, kb * (int)(KB_STRIDE * 16) + g * (H * 2 * 16), 0));
-    };
-    // (same issue order as inside the loop — all of b0, then all of b1 — so that the s_waitcnt vmcnt(n) the compiler
-    // places in front of each MFMA group count exactly the loads that group needs on both paths into the loop)
-    ps_f32x4 b0[4], b1[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) b0[g] = wp(0, g);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) b1[g] = wp(1, g);
-    __builtin_amdgcn_sched_barrier(0);
-    zero_burst(a.zb);
-    // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------------
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        if (rt == 1 && !two) break;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            As[lr * LDA + col] = accC[rt][reg];
-        }
-    }
-    __syncthreads();
-    IC3_TR(8);
-
-    // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell) --------------------------------------
-    ps_f32x16 acc[2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.0f;
-    auto block = [&](auto two_c, const ps_f32x4 (&bq)[4], int kb) {
-        constexpr bool TWO = decltype(two_c)::value;
-        const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-        ps_f32x4 a1;
-        if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nz = (a.zl >> (4 * j)) & 15;               // wave-uniform, loop-invariant
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                mfma_acc(acc[0][g], a0[j], bq[g][j]);
-                if constexpr (TWO) mfma_acc(acc[1][g], a1[j], bq[g][j]);
-                // the scalar bookkeeping of a store slot fits into the 64-cycle shadow of one MFMA: one slot after
-                // the 4th and one after the 8th of a k sub-step rather than both at its end
-                if (g == 1 && nz > 1) zero_store();
-                if (g == 3 && nz > 0) zero_store();
-            }
-#pragma unroll 1
-            for (int i = 2; i < nz; ++i) zero_store();
-        }
-    };
-    float sink = 0.0f;   // destination of the L2 warm-up load of c (see below)
-    auto gate_loop = [&](auto two_c) {
-        static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
-        // sched_barrier(0) pins the phase order (the machine scheduler otherwise sinks the refill loads to just before
-        // their first use, which exposes the full L2 latency every block).
-        const int kb_end = (a.dbg & 1) ? 0 : KB - 2;
-    #pragma unroll 1
-        for (int kb = 0; kb < kb_end; kb += 2) {
-            block(two_c, b0, kb);
-            __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-            for (int g = 0; g < 4; ++g) b0[g] = wp(kb + 2, g);
-            __builtin_amdgcn_sched_barrier(0);
-            block(two_c, b1, kb + 1);
-            __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-            for (int g = 0; g < 4; ++g) b1[g] = wp(kb + 3, g);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the old cell state: one touch per 128 B line of this wave's (64 rows x 32 columns) before the last two blocks
-        // (64 MFMAs) brings it from HBM into the L2 under them; the epilogue's loads then hit there.  (Holding the values
-        // themselves over the two blocks costs 32 registers the loop does not have.)
-        // The load's destination register stays reserved until the epilogue has waited for it (the compiler does not
-        // know that an asm load completes later).
-        const bool warm_c = !(a.zmode & 16) && lane < rows && !(a.dbg & 16);
-        if (warm_c) {
-            const float* cp = a.c + (r0 + lane) * H + 32 * w;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(cp) : "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(a.dbg & 1)) {
-            block(two_c, b0, KB - 2);
-            __builtin_amdgcn_sched_barrier(0);
-            block(two_c, b1, KB - 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (two) gate_loop(std::true_type{});
-    else gate_loop(std::false_type{});
-    IC3_TR(9);
-    mfma_settle();
-    IC3_TR(10);
-    if (a.zmode & 32)
-        while (zleft > 0) zero_store();   // (experiment: the rest right behind the loop instead of inside the epilogue)
-    // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads ------------
-    {
-        const float* lb = a.l_bias + tz;
-        const float bi = lb[col], bf = lb[H + col], bg = lb[2 * H + col], bo = lb[3 * H + col];
-        // c / h rows of the tile through buffer descriptors: one 32-bit lane offset + a constant per element instead of
-        // a 64-bit address pair each, and the hardware range check (num_records = the tile's valid rows) stands in
-        // for the `row < rows` predicates — an out-of-range load returns 0, an out-of-range store is dropped.
-        const uint32_t nrec = (a.dbg & 16) ? 0u : (uint32_t)rows * H * 4u;
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c + r0 * H), 0, nrec, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h + r0 * H), 0, nrec, 0x00020000);
-        const int voff = (4 * lh * H + col) * 4;
-        float cold[2][16];
+        // ---- S3: the encoder output moves into the accumulators of the C product (MFMA C/D layout:
+        //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ------------------------------------------------
+        ps_f32x16 accC[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             if (rt == 1 && !two) break;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-                cold[rt][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, voff + lc * H * 4, 0, 0));
-                if (autor && ((fmask >> (lc + 4 * lh)) & 1)) cold[rt][reg] = 0.0f;
+                const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                accC[rt][reg] = As[lr * LDA + col];
             }
         }
-        __syncthreads();   // every wave is done with the A tile
-        IC3_TR(11);
-        for (int i = tid; i < a.OT * H4; i += NT) {   // head / value weights -> rows [0, OT) of the inp half
-            const int o = i / H4, c4 = i - o * H4;
-            As4[o * LDA4 + c4] = reinterpret_cast<const ps_f32x4*>(a.head_w)[i + tz];
+        // the old cell state of the tile, requested HERE (a quarter of a tile's life ahead of its use): loads of a wave
+        // return in order, so a load that misses to HBM in front of the gate loop's weight stream would stall that
+        // stream — here the comm phase and the C product cover it — and behind the loop it would queue up behind the
+        // zero stores (one counter, in order).  Rows >= `rows` read as zeros (range check).  32 registers held through
+        // the loop.
+        {
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
+            const int voff = (4 * lh * H + col) * 4;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (rt == 1 && !two) break;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+                    cold[rt][reg] = buf_load_b32(rc, voff + lc * H * 4, 0);
+                }
+            }
         }
+        __syncthreads();   // every wave has its share of the encoder output
+        IC3_TR(4);
+        IC3_TR(5);
+
+        if (g.obs_here) {
+            // (no load is waited for in the comm phase: the acknowledgements of these run under its LDS work)
+#pragma unroll 1
+            for (int i = 0; i < a.zf; ++i) zero_store();
+        }
+        if (!a.comm_zero) {   // comm_mask_zero (comm.py:40-41): C sees zeros, inp = enc + C.bias
+            // ---- S5: comm_j = m_j (S_e - m_j h_j) scale_e (closed form of comm.py:181-205) -> inp half ----------------
+            {
+                const int c4 = tid % H4;
+                for (int el = tid / H4; el < nenv; el += NT / H4) {
+                    const ps_f32x4* hp = As4 + (el * N) * LDA4 + H4 + c4;
+                    const float scl = sscale[el];
+                    ps_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
+                    for (int i = 0; i < N; ++i) S += sm[el * N + i] * hp[i * LDA4];
+                    for (int j = 0; j < N; ++j) {
+                        const float m = sm[el * N + j];
+                        As4[(el * N + j) * LDA4 + c4] = m * (S - m * hp[j * LDA4]) * scl;
+                    }
+                }
+                for (int idx = rows * H4 + tid; idx < BM * H4; idx += NT) {
+                    const int row = idx / H4, c4p = idx - row * H4;
+                    As4[row * LDA4 + c4p] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+                }
+            }
+            // B fragments of C: lane (li, lh) of wave w reads Wp[kb][32w + li][lh] -> k = 8kb + 4lh + j, j = 0..3
+            constexpr int KBC = H / 8, CH = (KBC < 8) ? KBC : 8, NCH = KBC / CH;
+            // weights through a buffer descriptor: lane offset in one VGPR, the k part of the address on the scalar ALU
+            const __amdgpu_buffer_rsrc_t rcw = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<ps_f32x4*>(a.c_wp), 0, (uint32_t)((size_t)H * H * sizeof(float)), 0x00020000);
+            const int wlane = (col * 2 + lh) * 16;
+            auto cwp = [&](int k) {
+                return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rcw, wlane, k * (H * 2 * 16), 0));
+            };
+            ps_f32x4 cb[2][CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) cb[0][k] = cwp(k);
+            __syncthreads();
+            IC3_TR(6);
+            // ---- S6: accC (= enc) += comm . C.weight^T -----------------------------------------------------------------
+            auto cprod = [&](auto two_c) {
+                constexpr bool TWO = decltype(two_c)::value;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (ch + 1 < NCH) {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) cb[(ch + 1) & 1][k] = cwp((ch + 1) * CH + k);
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int kb = ch * CH + k;
+                        const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+                        ps_f32x4 a1;
+                        if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
+                            if constexpr (TWO) mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
+                        }
+                    }
+                }
+            };
+            if (!(ABL & 2)) {
+                if (two) cprod(std::true_type{});
+                else cprod(std::false_type{});
+            }
+            mfma_settle();
+            __syncthreads();   // every wave has read the comm tile
+            IC3_TR(7);
+        }
+
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
+        // gate weights in the layout Wq[k][c] = float4 (W[c][k], W[H+c][k], W[2H+c][k],
+        // W[3H+c][k]) of ic3_policy_pack: ONE 16-byte load per lane feeds a k-step of all four gates, so the operand
+        // ring is four float4 deep (16 registers; round 2 kept two 8-k blocks of four float4 per gate = 32) and a slot
+        // is refilled for the next K block right behind the 8 MFMAs that read it: three k sub-steps (24 MFMAs) ahead.
+        const __amdgpu_buffer_rsrc_t rgw = make_rsrc(a.l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
+        const int glane = (4 * lh * H + col) * 16;               // k = 8 kb + 4 lh + j (must match the A fragments)
+        auto wq = [&](int kb, int j) { return buf_load_b128(rgw, glane, (8 * kb + j) * (H * 16)); };
+        ps_f32x4 wk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wk[j] = wq(0, j);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            if (rt == 1 && !two) break;              // half tile: rows 32..63 are padding (their h' is never read)
+            if (rt == 1 && !two) break;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
-                const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
-                const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
-                const float h1 = fast_sigmoid(go) * fast_tanh(c1);
-                zero_store();                      // what the gate loop left of the zero fill goes out between the
-                zero_store();                      // transcendental work of the cell (2 x 32 slots, then the rest)
-                const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
-                As[lr * LDA + H + col] = h1;
+                As[lr * LDA + col] = accC[rt][reg];
             }
         }
-        while (zleft > 0) zero_store();            // obs-dominated shapes
-        // the warm-up load's destination stayed reserved up to here: memory operations complete in order, so it landed
-        // before the first cold[] value (requested after it) was consumed
-        asm volatile("" : : "v"(sink));
-    }
-    __syncthreads();
-    IC3_TR(12);
-    if (a.dbg & 8) return;
-
-    // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of 16
-    //      rows per wave, the OT <= 16 output columns are the weight rows [0, 16) of the inp half (rows >= OT hold
-    //      stale finite data and only feed output columns nobody reads).  Operand layout of the instruction: A[i][k] in
-    //      lane 16k + i, B[k][j] in lane 16k + j, D[4(l/16) + v][l % 16] in element v of lane l; one ds_read_b128 per
-    //      operand feeds four k-steps (k = 16 sg + 4 (l/16) + j — any k order is valid as long as A and B agree).
-    // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
-    constexpr int PER = H / 16;
-    {
-        const int l16 = lane & 15, kq = lane >> 4;
-        const float hb = l16 < a.OT ? a.head_b[l16 + tz] : 0.0f;
-        for (int rtile = w; rtile < BM / 16; rtile += NW) {
-            if (16 * rtile >= rows) break;
-            ps_f32x4 z = { 0.f, 0.f, 0.f, 0.f };
-            const ps_f32x4* xa = As4 + (16 * rtile + l16) * LDA4 + H4 + kq;
-            const ps_f32x4* wb = As4 + l16 * LDA4 + kq;
-#pragma unroll 4
-            for (int sg = 0; sg < H / 16; ++sg) {
-                const ps_f32x4 x4 = xa[4 * sg], w4 = wb[4 * sg];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[j], w4[j], z, 0, 0, 0);
-            }
-            if (l16 < a.OT) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = 16 * rtile + 4 * kq + v;
-                    As[(16 + r / PER) * LDA + (r % PER) * 16 + l16] = z[v] + hb;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    IC3_TR(13);
-
-    // ---- S11: log_softmax per head + the action draws (action_utils.py:32-36; same arithmetic and Philox counters as
-    //      lstm_cell_heads_kernel / sample_actions_env_kernel), one task per (row, head) + one per row for the value ----
-    {
-        const int sizes[4] = { a.a0, a.a1, a.a2, a.a3 };
-        const int R = a.E * N;
-        const float inv_nh1 = 1.0f / (float)(a.nheads + 1);
-        for (int task = tid; task < rows * (a.nheads + 1); task += NT) {
-            const int tr = div_small(task, inv_nh1), hd = task - tr * (a.nheads + 1);
-            const size_t grow = r0 + tr;
-            const float* z = As + (16 + tr / PER) * LDA + (tr % PER) * 16;
-            float* orow = a.out + grow * a.OT;
-            int off = 0;
-            for (int i = 0; i < hd && i < a.nheads; ++i) off += sizes[i];
-            if (hd == a.nheads) {                   // value head (last column)
-                orow[off] = z[off];
-                continue;
-            }
-            const int A = sizes[hd];
-            float mx = -INFINITY;
-            for (int o = 0; o < A; ++o) mx = fmaxf(mx, z[off + o]);
-            float sum = 0.0f;                       // hardware exp2 / log2 (~1 ulp): |error| of a log-prob ~1e-7, bar 1e-5
-            for (int o = 0; o < A; ++o) sum += __builtin_amdgcn_exp2f(1.4426950408889634f * (z[off + o] - mx));
-            const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
-            for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
-            if (KIND == 0) continue;                // forward only: the caller draws (ic3_sample_actions)
-            const int el = div_small(tr, invN), n = tr - el * N;
-            const int e = e0 + el;
-            const uint32_t x = philox_x24(a.seed, a.gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)a.episode[e],
-                                          (uint32_t)a.tstep[e], (uint32_t)(hd * N + n));
-            const float u = (float)x * (1.0f / 16777216.0f);
-            float cdf = 0.0f;
-            int act = A - 1;
-            for (int o = 0; o < A - 1; ++o) {
-                cdf += expf(z[off + o] - lse);
-                if (u < cdf) {
-                    act = o;
-                    break;
-                }
-            }
-            a.action[(size_t)hd * R + grow] = act;
-            if (hd == 0) sact[tr] = act;
-        }
-    }
-    __syncthreads();
-    IC3_TR(14);
-
-    // ---- S12: env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) ----------------------------
-    if constexpr (KIND != 0) {
-        const int lgG = __builtin_ctz(a.G);
-        for (int base = 0; base < a.EPT * a.G; base += NT) {
-            const int lt = base + tid;
-            const int el = lt >> lgG, n = lt - (el << lgG);         // G is a power of two
-            const int e = el < nenv ? e0 + el : a.E;
-            if constexpr (KIND == IC3_ENV_PP) {
-                pp_step_lanes(a.pp, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
-            } else {
-                tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
-            }
-        }
-    }
-    IC3_TR(15);
-    if (obs_here && !(a.dbg & 32)) {
-        // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
-        // first non-zero entry goes out to the same lines
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        IC3_TR(16);
-        float* orow0 = a.obs + ob0;
-        if constexpr (KIND == IC3_ENV_PP) {
-            const int vocab = a.pp.dim * a.pp.dim + 4;
-            for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
-                const int2 d = ptab[sg];
-                float* cell = orow0 + (size_t)sg * vocab;
-                const float npred = (float)(d.y & 0xffff), nprey = (float)(d.y >> 16);
-                // channels: d.x one-hot (grid id or OUTSIDE), vocab-2 #prey, vocab-1 #predators (counts add, quirk Q3)
-                cell[d.x] = 1.f + (d.x == vocab - 2 ? nprey : 0.f) + (d.x == vocab - 1 ? npred : 0.f);
-                if (d.x != vocab - 2 && nprey != 0.f) cell[vocab - 2] = nprey;
-                if (d.x != vocab - 1 && npred != 0.f) cell[vocab - 1] = npred;
+        IC3_TR(8);
+
+        // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T + b (comm.py:215, torch.nn.LSTMCell) ----------------------------
+        // LAST = no refills (the final K block).  The compiler's waits in front of each k sub-step come out as
+        // vmcnt(3 + S - stores of that sub-step): the three younger refills + the zero stores of one K block.
+        auto block = [&](auto two_c, auto s_c, auto last_c, int kb) {
+            constexpr bool TWO = decltype(two_c)::value;
+            constexpr int S = decltype(s_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+            ps_f32x4 a1;
+            if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    mfma_acc(acc[0][gt], a0[j], wk[j][gt]);
+                    if constexpr (TWO) mfma_acc(acc[1][gt], a1[j], wk[j][gt]);
+                    // a store slot is two instructions that wait for nothing: it rides in the 64-cycle shadow of an MFMA
+                    if (ps_zslot(S, 4 * j + gt)) {                // (folded after unrolling)
+                        __builtin_amdgcn_sched_barrier(0);        // pinned between the MFMAs it follows / precedes
+                        zero_store();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (!LAST) wk[j] = wq(kb + 1, j);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        } else if constexpr (KIND == IC3_ENV_TJ) {
-            const int obs_dim = a.obs_dim;
-            for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
-                const int el = div_small(sg, 1.0f / (float)(nsegE + N)), q = sg - el * (nsegE + N);
-                tj_obs_patch(tj_tile_at(tile + el * tjw, N), a.tj, orow0 + (size_t)el * N * obs_dim, obs_dim, WW, q);
+        };
+        auto gate_loop = [&](auto two_c, auto s_c) {
+            static_assert(KB >= 3, "K/8 >= 3");
+            if (!(ABL & 1)) {
+#pragma unroll 1
+                for (int kb = 0; kb < KB - 1; ++kb) block(two_c, s_c, std::false_type{}, kb);
+                block(two_c, s_c, std::true_type{}, KB - 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto gate_loop_s = [&](auto two_c) {
+            switch (g.obs_here ? a.zs : 0) {   // workgroup-uniform
+            case 1: gate_loop(two_c, std::integral_constant<int, 1>{}); break;
+            case 2: gate_loop(two_c, std::integral_constant<int, 2>{}); break;
+            case 3: gate_loop(two_c, std::integral_constant<int, 3>{}); break;
+            case 4: gate_loop(two_c, std::integral_constant<int, 4>{}); break;
+            case 5: gate_loop(two_c, std::integral_constant<int, 5>{}); break;
+            case 6: gate_loop(two_c, std::integral_constant<int, 6>{}); break;
+            case 7: gate_loop(two_c, std::integral_constant<int, 7>{}); break;
+            case 8: gate_loop(two_c, std::integral_constant<int, 8>{}); break;
+            case 10: gate_loop(two_c, std::integral_constant<int, 10>{}); break;
+            case 12: gate_loop(two_c, std::integral_constant<int, 12>{}); break;
+            case 16: gate_loop(two_c, std::integral_constant<int, 16>{}); break;
+            default: gate_loop(two_c, std::integral_constant<int, 0>{}); break;
+            }
+        };
+        if (two) gate_loop_s(std::true_type{});
+        else gate_loop_s(std::false_type{});
+        IC3_TR(9);
+        mfma_settle();
+        IC3_TR(10);
+    }
+
+    // =====================================================================================================================
+    // BACK: LSTM cell epilogue, heads, draws, env.step, obs patches.  The kernel arguments are read AGAIN from the kernarg
+    // segment (scalar loads behind an opaque pointer) and everything derived from them or from the thread index is derived
+    // again, so that nothing of it occupies registers across the gate loop.
+    // =====================================================================================================================
+    {
+        StepArgs a;
+        reload_args(a);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const TileGeom g = tile_geom<KIND>(a, blockIdx.x);
+        const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+        const int col = 32 * w + li;
+        const int e0 = g.e0, nenv = g.nenv, rows = g.rows;
+        const bool two = g.two, obs_here = g.obs_here;
+        const size_t r0 = g.r0;
+        const int N = a.N;
+        const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
+        const int total = a.pp.Np + a.pp.nprey;
+        const int nsegE = N * WW;
+        const int tjw = tj_tile_words(N, WW);
+        const float invN = 1.0f / (float)N;
+        const bool autor = (KIND != 0) && a.auto_reset;
+        (void)li;
+        (void)total;
+        (void)tjw;
+
+        // ---- S9: LSTM cell epilogue (gate order i,f,g,o); c', h' to HBM, h' also into the h half for the heads --------
+        {
+            // c / h rows of the tile through buffer descriptors: one 32-bit lane offset + a constant per element instead
+            // of a 64-bit address pair each, and the hardware range check (num_records = the tile's valid rows) stands
+            // in for the `row < rows` predicates — an out-of-range store is dropped.
+            const uint32_t nrec = (ABL & 16) ? 0u : (uint32_t)rows * H * 4u;
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c + r0 * H), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h + r0 * H), 0, nrec, 0x00020000);
+            const int voff = (4 * lh * H + col) * 4;
+            const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
+            // (cold[]: requested in front of the C product; every load this wave issued after them has been waited for
+            // in the gate loop and loads return in order, so they have landed)
+            if (autor) {
+                const unsigned long long fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
+                                                 ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if ((fmask >> (32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh)) & 1) cold[rt][reg] = 0.0f;
+            }
+            __syncthreads();   // every wave is done with the A tile
+            IC3_TR(11);
+            // head / value weights -> rows [0, OT) of the inp half: requested now, written to LDS behind the element loop
+            // (the compiler's wait there allows the >= 32 stores issued meanwhile to stay in flight)
+            const __amdgpu_buffer_rsrc_t rhw = make_rsrc(a.head_w, (uint32_t)(a.OT * H * sizeof(float)));
+            const ps_f32x4 hw0 = buf_load_b128(rhw, tid * 16, 0), hw1 = buf_load_b128(rhw, (tid + NT) * 16, 0);
+            static_assert(16 * H4 <= 2 * NT, "head weights: two float4 per thread");
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (rt == 1 && !two) break;              // half tile: rows 32..63 are padding (their h' is never read)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
+                    const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
+                    const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
+                    const float h1 = fast_sigmoid(go) * fast_tanh(c1);
+                    if (obs_here) {                    // what the gate loop left of the zero fill goes out between the
+                        if (a.zepi > 0) zero_store();  // transcendental work of the cell (<= 2 x 32 slots, then the rest)
+                        if (a.zepi > 1) zero_store();
+                    }
+                    const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
+                    As[lr * LDA + H + col] = h1;
+                }
+            }
+            if (tid < a.OT * H4) As4[(tid / H4) * LDA4 + tid % H4] = hw0;
+            if (tid + NT < a.OT * H4) As4[((tid + NT) / H4) * LDA4 + (tid + NT) % H4] = hw1;
+            if (obs_here) {
+#pragma unroll 1
+                for (int i = 0; i < a.zrest; ++i) zero_store();     // obs-dominated shapes
+                // ragged chunks: chunk 0 when the body starts inside it, chunk c_hi when the body ends inside it; the
+                // <= 3 floats in front of / behind the 16-byte aligned body
+                ps_f32x4* const obody = reinterpret_cast<ps_f32x4*>(a.obs + g.ob0 + g.ohead);
+                const int ws = tid >> 6;
+                const int q0 = lane - g.mis, q1 = 64 * g.c_hi - g.mis + lane;
+                if (ws == 0 && g.mis && q0 >= 0 && q0 < g.onb) obody[q0] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+                if (ws == 1 % NW && ((g.mis + g.onb) & 63) && (g.c_hi > 0 || !g.mis) && q1 >= 0 && q1 < g.onb)
+                    obody[q1] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+                const int otail = (g.oL - g.ohead) & 3;
+                if (tid < g.ohead) a.obs[g.ob0 + tid] = 0.f;
+                if (tid < otail) a.obs[g.ob0 + g.ohead + 4 * (long long)g.onb + tid] = 0.f;
             }
         }
+        __syncthreads();
+        IC3_TR(12);
+        if (ABL & 8) return;
+
+        // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of
+        //      16 rows per wave, the OT <= 16 output columns are the weight rows [0, 16) of the inp half (rows >= OT hold
+        //      stale finite data and only feed output columns nobody reads).  Operand layout of the instruction: A[i][k]
+        //      in lane 16k + i, B[k][j] in lane 16k + j, D[4(l/16) + v][l % 16] in element v of lane l; one ds_read_b128
+        //      per operand feeds four k-steps (k = 16 sg + 4 (l/16) + j — any k order is valid as long as A and B agree).
+        // logits of row r -> rows [16, ..) of the inp half: z(r, o) = As[(16 + r / PER) * LDA + (r % PER) * 16 + o]
+        if (obs_here) {
+#pragma unroll 1
+            for (int i = 0; i < a.zh; ++i) zero_store();         // (LDS + matrix work only in this phase: nothing waits for them)
+        }
+        {
+            const int l16 = lane & 15, kq = lane >> 4;
+            const float hb = shb[l16];
+            for (int rtile = w; rtile < BM / 16; rtile += NW) {
+                if (16 * rtile >= rows) break;
+                ps_f32x4 z = { hb, hb, hb, hb };
+                const ps_f32x4* xa = As4 + (16 * rtile + l16) * LDA4 + H4 + kq;
+                const ps_f32x4* wb = As4 + l16 * LDA4 + kq;
+#pragma unroll 4
+                for (int sg = 0; sg < H / 16; ++sg) {
+                    const ps_f32x4 x4 = xa[4 * sg], w4 = wb[4 * sg];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[j], w4[j], z, 0, 0, 0);
+                }
+                if (l16 < a.OT) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int r = 16 * rtile + 4 * kq + v;
+                        As[(16 + r / PER) * LDA + (r % PER) * 16 + l16] = z[v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        IC3_TR(13);
+
+        // ---- S11: log_softmax per head + the action draws (action_utils.py:32-36; same arithmetic and Philox counters
+        //      as lstm_cell_heads_kernel / sample_actions_env_kernel), one task per (row, head) + one per row for the value
+        {
+            const int sizes[4] = { a.a0, a.a1, a.a2, a.a3 };
+            const int R = a.E * N;
+            const float inv_nh1 = 1.0f / (float)(a.nheads + 1);
+            for (int task = tid; task < rows * (a.nheads + 1); task += NT) {
+                const int tr = div_small(task, inv_nh1), hd = task - tr * (a.nheads + 1);
+                const size_t grow = r0 + tr;
+                const float* z = As + (16 + tr / PER) * LDA + (tr % PER) * 16;
+                float* orow = a.out + grow * a.OT;
+                int off = 0;
+                for (int i = 0; i < hd && i < a.nheads; ++i) off += sizes[i];
+                if (hd == a.nheads) {                   // value head (last column)
+                    orow[off] = z[off];
+                    continue;
+                }
+                const int A = sizes[hd];
+                float mx = -INFINITY;
+                for (int o = 0; o < A; ++o) mx = fmaxf(mx, z[off + o]);
+                float sum = 0.0f;                       // hardware exp2 / log2 (~1 ulp): |error| of a log-prob ~1e-7, bar 1e-5
+                for (int o = 0; o < A; ++o) sum += __builtin_amdgcn_exp2f(1.4426950408889634f * (z[off + o] - mx));
+                const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
+                for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
+                if (KIND == 0) continue;                // forward only: the caller draws (ic3_sample_actions)
+                const int el = div_small(tr, invN), n = tr - el * N;
+                const int e = e0 + el;
+                const uint32_t x = philox_x24(a.seed, a.gid0 + (uint32_t)e, DOMAIN_SAMPLE, (uint32_t)sep[el],
+                                              (uint32_t)sts[el], (uint32_t)(hd * N + n));
+                const float u = (float)x * (1.0f / 16777216.0f);
+                float cdf = 0.0f;
+                int act = A - 1;
+                for (int o = 0; o < A - 1; ++o) {
+                    cdf += expf(z[off + o] - lse);
+                    if (u < cdf) {
+                        act = o;
+                        break;
+                    }
+                }
+                a.action[(size_t)hd * R + grow] = act;
+                if (hd == 0) sact[tr] = act;
+            }
+        }
+        __syncthreads();
+        IC3_TR(14);
+
+        // ---- S12: env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) ------------------------
+        if constexpr (KIND != 0) {
+            const int lgG = __builtin_ctz(a.G);
+            for (int base = 0; base < a.EPT * a.G; base += NT) {
+                const int lt = base + tid;
+                const int el = lt >> lgG, n = lt - (el << lgG);         // G is a power of two
+                const int e = el < nenv ? e0 + el : a.E;
+                if constexpr (KIND == IC3_ENV_PP) {
+                    pp_step_lanes(a.pp, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+                } else {
+                    tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+                }
+            }
+        }
+        IC3_TR(15);
+        if (obs_here && !(ABL & 32)) {
+            // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
+            // first non-zero entry goes out to the same lines
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            IC3_TR(16);
+            float* orow0 = a.obs + g.ob0;
+            if constexpr (KIND == IC3_ENV_PP) {
+                const int2* ptab = reinterpret_cast<const int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
+                const int vocab = a.pp.dim * a.pp.dim + 4;
+                for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
+                    const int2 d = ptab[sg];
+                    float* cell = orow0 + (size_t)sg * vocab;
+                    const float npred = (float)(d.y & 0xffff), nprey = (float)(d.y >> 16);
+                    // channels: d.x one-hot (grid id or OUTSIDE), vocab-2 #prey, vocab-1 #predators (counts add, quirk Q3)
+                    cell[d.x] = 1.f + (d.x == vocab - 2 ? nprey : 0.f) + (d.x == vocab - 1 ? npred : 0.f);
+                    if (d.x != vocab - 2 && nprey != 0.f) cell[vocab - 2] = nprey;
+                    if (d.x != vocab - 1 && npred != 0.f) cell[vocab - 1] = npred;
+                }
+            } else if constexpr (KIND == IC3_ENV_TJ) {
+                const int obs_dim = a.obs_dim;
+                for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
+                    const int el = div_small(sg, 1.0f / (float)(nsegE + N)), q = sg - el * (nsegE + N);
+                    tj_obs_patch(tj_tile_at(tile + el * tjw, N), a.tj, orow0 + (size_t)el * N * obs_dim, obs_dim, WW, q);
+                }
+            }
+        }
+        IC3_TR(17);
     }
-    IC3_TR(17);
 }
 
 // Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
@@ -747,16 +862,31 @@ __global__ void policy_pack_kernel(const float* __restrict__ Wa, const float* __
     }
 }
 
-static int resident_workgroups(int H)
+// Wq[k][c] = float4 (W[c][k], W[H + c][k], W[2H + c][k], W[3H + c][k]), W = [w_ih | w_hh] (4H x 2H): the gate GEMM's B
+// operand, one k-step of all four gates of a hidden column per 16-byte load
+__global__ void policy_pack_gates_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, float* __restrict__ Wq, int H)
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
-        cus = prop.multiProcessorCount;
+    const long long n = (long long)8 * H * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int gt = (int)(i & 3);
+        const long long rest = i >> 2;
+        const int c = (int)(rest % H), k = (int)(rest / H);
+        const size_t row = (size_t)gt * H + c;
+        Wq[i] = k < H ? w_ih[row * H + k] : w_hh[row * H + (k - H)];
     }
-    return cus * (H <= 128 ? 2 : 1);
+}
+
+static int device_cus()
+{
+    static int cus[64] = { 0 };   // per device (a process may drive several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
 }
 
 // Tile plan (a.E, a.N, a.EPT set).  Two workgroups share a CU and all tiles cost the same, so a launch whose tile count
@@ -785,7 +915,7 @@ static double tiles_cost(int k_full, int k_half)
 static int plan_tiles(StepArgs& a, int H)
 {
     static const int force = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : -1;
-    const int cus = resident_workgroups(H) / (H <= 128 ? 2 : 1);
+    const int cus = device_cus();
     const int n_all = (a.E + a.EPT - 1) / a.EPT;
     a.EPTh = 32 / a.N;
     a.n_full = n_all;
@@ -807,26 +937,10 @@ template <int H, int KIND>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0 = nullptr,
                        hipEvent_t ev1 = nullptr)
 {
-    static bool attr_set = false;
-    static size_t attr_lds = 0;
-    if (lds > 64 * 1024 && (!attr_set || lds > attr_lds)) {
+    // (hipFuncAttributeMaxDynamicSharedMemorySize is per device and cheap to set: no per-process cache)
+    if (lds > 64 * 1024)
         IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-        attr_lds = lds;
-    }
-    // IC3_PS_WGS=1: ask for more than half of the CU's LDS so that only ONE workgroup is resident per CU (experiments
-    // with a concurrent obs-assembly launch on a second stream, which then finds free wave slots and registers)
-    static const int one_wg = getenv("IC3_PS_WGS") ? atoi(getenv("IC3_PS_WGS")) == 1 : 0;
-    if (one_wg && lds < 84 * 1024) {
-        lds = 84 * 1024;
-        if (!attr_set || lds > attr_lds) {
-            IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-            attr_lds = lds;
-        }
-    }
     // one workgroup per tile, dispatched in tile order (full tiles first, see plan_tiles): the hardware dispatcher
     // balances them over the CUs (a fixed resident set walking a strided tile list was measured slower)
     const int grid = tiles;
@@ -850,10 +964,13 @@ extern "C" int ic3_policy_pack(const float* c_weight, const float* w_ih, const f
         return fail(-22, "ic3_policy_pack: H must be a positive multiple of 32");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, s, c_weight, (const float*)nullptr, c_wp, H, H, 0);
-    hipLaunchKernelGGL(policy_pack_kernel, dim3(256), dim3(256), 0, s, w_ih, w_hh, lstm_wp, 4 * H, H, H);
+    hipLaunchKernelGGL(policy_pack_gates_kernel, dim3(256), dim3(256), 0, s, w_ih, w_hh, lstm_wp, H);
     IC3_HIP(hipGetLastError());
     return 0;
 }
+
+// words of the small LDS arrays behind the A tile: sm, sscale, sact, rmask [64 each], sfm [4], sep, sts [64 each], shb [16], slb [4H]
+static size_t ps_lds_small(int H) { return 6 * 64 + 4 + 16 + 4 * (size_t)H; }
 
 // LDS bytes of one workgroup (0 = unsupported shape); *tile_words_out = int32 words of one env-descriptor block
 static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_words_out)
@@ -874,7 +991,7 @@ static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_wo
     tile_words = (tile_words + 3) & ~(size_t)3;
     if (tile_words_out) *tile_words_out = (int)tile_words;
     (void)with_obs;
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64 + 4 + tile_words) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H) + tile_words) * sizeof(float);
     const size_t limit = (H <= 128) ? 80 * 1024 : 160 * 1024;   // two workgroups per CU up to H = 128
     return lds <= limit ? (int)lds : 0;
 }
@@ -909,10 +1026,6 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
     a.a3 = sz[3];
     a.mode_avg = p->mode_avg;
     a.comm_zero = p->comm_zero;
-    static const int dbg = getenv("IC3_PS_DEBUG") ? atoi(getenv("IC3_PS_DEBUG")) : 0;
-    a.dbg = dbg;
-    static const int skew = getenv("IC3_PS_SKEW") ? atoi(getenv("IC3_PS_SKEW")) : 0;
-    a.skew = skew;
     return 0;
 }
 
@@ -938,7 +1051,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     a.EPT = 64 / N;
     a.G = 1;
     const int tiles = plan_tiles(a, H);
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * 64 + 4) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H)) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
     if (H == 64) return launch_step<64, 0>(a, tiles, lds, s);
@@ -957,7 +1070,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     const int H = p->H;
     // next_state rows are stored from inside the kernel when their descriptors fit in LDS next to the tile's own
     // (IC3_PS_OBS=0: always as a separate ic3_env_observe launch after the kernel)
-    static const int obs_inside = getenv("IC3_PS_OBS") ? atoi(getenv("IC3_PS_OBS")) : 1;
+    static const int obs_inside = getenv("IC3_PS_OBS") ? atoi(getenv("IC3_PS_OBS")) : 1;   // (same rows either way)
     int tile_words = 0;
     int lds = (obs && obs_inside) ? policy_step_lds(env, H, 1, &tile_words) : 0;
     const bool fused_obs = lds != 0;
@@ -997,36 +1110,42 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;
     a.auto_reset = env->auto_max_steps > 0;
-    {   // pacing of the zero stores: per-thread count of a tile; KB*4 slots in the loop, then the cell epilogue
-        static const int zmode_env = getenv("IC3_PS_ZMODE") ? atoi(getenv("IC3_PS_ZMODE")) : 0;
-        a.zmode = zmode_env;
-        static const int zb_env = getenv("IC3_PS_ZB") ? atoi(getenv("IC3_PS_ZB")) : -1;
-        static const int zl_env = getenv("IC3_PS_ZL") ? (int)strtol(getenv("IC3_PS_ZL"), nullptr, 0) : -1;
-        const long long per_thread = ((long long)a.EPT * a.N * a.obs_dim / 4 + 2 * H - 1) / (2 * H) + 1;
-        const int slots = (2 * H / 8) * 4;                       // one per 8 MFMAs
-        // zl: one nibble per k sub-step of a K block (8 MFMAs each) = zero stores issued after it.  None in front of
-        // the loop: stores there delay the loads of the phases there (memory operations of a wave complete in
-        // order), measured 0.439 -> 0.429 ms on PP-hard.
-        static const int zc_env = getenv("IC3_PS_ZC") ? atoi(getenv("IC3_PS_ZC")) : -1;
-        a.zc = zc_env >= 0 ? zc_env : 0;                         // inside the C product (one per 8 MFMAs): none, 0.4198 -> 0.4177 ms
-        if (a.zc > H / 8) a.zc = H / 8;
-        if (zl_env >= 0) {
-            a.zl = zl_env;
-        } else {
-            // ~70 % of a tile's stores inside the loop (PP-hard: 5 of the 7.1 per K block, 0.397 -> 0.381 ms against
-            // all of them), the rest inside the cell epilogue
-            static const int zfrac = getenv("IC3_PS_ZFRAC") ? atoi(getenv("IC3_PS_ZFRAC")) : 70;
-            long long want = ((per_thread - a.zc) * zfrac / 100 + slots / 8) / (slots / 4);   // per K block, rounded
-            if (want > 60) want = 60;
-            if (want < 0) want = 0;
-            a.zl = 0;
-            for (int j = 0; j < 4; ++j) a.zl |= (int)((want + 3 - j) / 4) << (4 * j);
+    {   // pacing of the obs zero fill (speed only: a slot past a wave's last chunk is dropped by the hardware).
+        // A wave of a full tile owns `per_wave` 1 KiB chunks.  Stores issued back to back are exposed at the HBM write
+        // rate; stores between MFMAs ride in their shadows until the rate all CUs ask for exceeds what HBM takes.
+        // IC3_PS_ZS / ZF / ZEPI / ZH override the split (stores per K block of the gate loop; in front of the comm
+        // phase; per element of the cell epilogue; in front of the heads), IC3_PS_ZFRAC the share of the gate loop.
+        static const int zs_env = getenv("IC3_PS_ZS") ? atoi(getenv("IC3_PS_ZS")) : -1;
+        static const int zf_env = getenv("IC3_PS_ZF") ? atoi(getenv("IC3_PS_ZF")) : -1;
+        static const int zh_env = getenv("IC3_PS_ZH") ? atoi(getenv("IC3_PS_ZH")) : -1;
+        static const int zepi_env = getenv("IC3_PS_ZEPI") ? atoi(getenv("IC3_PS_ZEPI")) : -1;
+        static const int zfrac = getenv("IC3_PS_ZFRAC") ? atoi(getenv("IC3_PS_ZFRAC")) : 85;
+        const int NWv = H / 32, KBv = 2 * H / 8;
+        const long long chunks = ((long long)a.EPT * a.N * a.obs_dim / 4 + 63) / 64 + 1;   // 1 KiB chunks of a full tile
+        const long long per_wave = (chunks + NWv - 1) / NWv;
+        static const int ZS_SET[] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16 };
+        int zs = 0;
+        if (fused_obs) {
+            const double want = (double)per_wave * zfrac / 100.0 / KBv;
+            double best = 1e30;
+            for (int cand : ZS_SET) {
+                if (zs_env >= 0 && cand != zs_env) continue;
+                const double d = want > cand ? want - cand : cand - want;
+                if (d < best) {
+                    best = d;
+                    zs = cand;
+                }
+            }
         }
-        // per burst between the five phases in front of the loop: 3 % of the tile's stores each (PP-hard: 7 of 228 per
-        // thread; 0.327 -> 0.314 ms; more — or any, before the phases there lost their spills and scans — delays the
-        // loads of those phases: memory operations of a wave complete in order)
-        a.zb = zb_env >= 0 ? zb_env : (int)((per_thread * 3 + 50) / 100);
-        if (a.zb > 48) a.zb = 48;
+        a.zs = zs;
+        long long left = per_wave - (long long)zs * KBv;
+        a.zf = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zf_env >= 0 ? zf_env : 0) : 0;
+        left -= a.zf;
+        a.zh = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zh_env >= 0 ? zh_env : 0) : 0;
+        left -= a.zh;
+        a.zepi = !fused_obs ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
+        left -= 32LL * a.zepi;
+        a.zrest = fused_obs ? (int)(left > 0 ? left + 1 : 0) : 0;
     }
     hipStream_t s = (hipStream_t)stream;
     int rc;

@@ -115,20 +115,22 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_set_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
 
     def reset_to(self, state, epoch=None):
-        """reset() into a given initial state (ic3_env_reset_to): the reset bookkeeping runs (TJ curriculum, statistics),
-        then the integer state is exactly `state` — a dict of fields as from get_state(); fields not given keep the
-        values they had before the call.  Returns the observation of that state."""
+        """reset() into a given initial state: the reset bookkeeping runs first (episode counter / Philox key, t = 0,
+        over = 0, TJ curriculum, statistics), then the fields given in `state` — a dict as from get_state(), possibly
+        partial — replace what reset() drew; fields not given keep their POST-reset values.  Returns the observation
+        of that state.  (A full dump is what ic3_env_reset_to takes in one call.)"""
         self._require()
         lib = _lib.lib()
         buf = np.empty(self.dims.state_words, np.int32)
         with torch.cuda.device(self.device):
+            check(lib.ic3_env_reset(self._h, -1 if epoch is None else int(epoch), None, stream()))
             check(lib.ic3_env_get_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
             for name, val in state.items():
                 off, cnt = C.c_int64(), C.c_int64()
                 check(lib.ic3_env_state_field(self._h, name.encode(), C.byref(off), C.byref(cnt)))
                 buf[off.value:off.value + cnt.value] = np.asarray(val, np.int32).reshape(-1)
-            check(lib.ic3_env_reset_to(self._h, -1 if epoch is None else int(epoch), buf.ctypes.data_as(C.c_void_p),
-                                       buf.nbytes, ptr(self._obs), stream()))
+            check(lib.ic3_env_set_state(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, stream()))
+            check(lib.ic3_env_observe(self._h, ptr(self._obs), stream()))
         self.stat = dict()
         self.episode_over = False
         return self._obs

@@ -2,6 +2,8 @@
 on the rollout path (envs are independent).  The only exchange is at update time: the
 reference's MultiProcessTrainer sums worker gradients and stats and divides by the total num_steps
 (/root/reference/multi_processing.py:74-98) — here one all-reduce(sum) over RCCL (gloo in CPU tests).
+Whenever a process group is initialised the collectives run — also for a one-rank group, which is how the RCCL code
+path is exercised on a single GPU (tests/test_rccl_world1_gpu.py).
 """
 import numpy as np
 import torch
@@ -28,7 +30,7 @@ def _dist_device(group=None):
 def broadcast_seed(seed, src=0, group=None):
     """Every rank adopts rank `src`'s seed (main.py:157-159 draws it once; the reference's workers inherit it)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return int(seed)
     t = torch.tensor([int(seed)], dtype=torch.int64, device=_dist_device(group))
     dist.broadcast(t, src=src, group=group)
@@ -39,7 +41,7 @@ def broadcast_parameters(module, optimizer=None, src=0, group=None):
     """Replicas start from rank `src`'s parameters, buffers and optimizer state tensors (the reference keeps one
     shared-memory parameter set, main.py:177-178 / multi_processing.py:24-27)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     if optimizer is not None:
@@ -59,7 +61,7 @@ def broadcast_parameters(module, optimizer=None, src=0, group=None):
 def allreduce_stats(stat, group=None):
     """merge_stat across ranks (multi_processing.py:86-88): numeric / ndarray entries are summed."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return stat
     stat = dict(stat)
     keys = sorted(k for k, v in stat.items() if isinstance(v, (int, float, np.ndarray, np.floating, np.integer)))
@@ -85,7 +87,7 @@ def allreduce_grads(params, num_steps_total, group=None):
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():     # (also a one-rank group: the same RCCL path)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)   # one bucket: ~0.6 M fp32 for PP-hard
     flat /= float(num_steps_total)
     i = 0

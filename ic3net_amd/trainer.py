@@ -66,7 +66,8 @@ class Trainer(object):
         check_every = int(getattr(self.args, 'done_check_every', 0))
         for t in range(self.args.max_steps):
             self.step_episode(t)
-            if check_every and (t + 1) % check_every == 0 and \
+            # (auto-reset: done marks an in-launch restart, the window always runs to max_steps)
+            if check_every and not self._auto_reset() and (t + 1) % check_every == 0 and \
                     bool(self._buf['done'][:t + 1].to(torch.bool).any(0).all().item()):
                 break                                               # trainer.py:107-108 (every env is done)
         return self.end_episode()
@@ -82,9 +83,16 @@ class Trainer(object):
         raw0 = getattr(self.env, 'env', None)
         if hasattr(raw0, 'set_auto_reset') and getattr(raw0, 'auto_max_steps', 0) != (args.max_steps if self._auto_reset() else 0):
             raw0.set_auto_reset(args.max_steps if self._auto_reset() else 0)
+            self._graphs.clear()                                   # (a host kernel argument of the captured launches)
+            self._episodes_played = min(self._episodes_played, 1)
         if raw0 is not None and hasattr(raw0, '_h'):
-            raw0.skip_reset_obs = bool(getattr(self, '_mega_last', False) and self._fused_obs() and self._dense_obs()
-                                       and not getattr(args, 'store_states', False))
+            # the reset obs launch is only skipped when the coming episode will take the one-launch path again (its
+            # first step writes the rows of the reset state itself): the previous episode did, and nothing that decides
+            # it has changed since
+            raw0.skip_reset_obs = bool(getattr(self, '_mega_last', False) and self._mega_expected(raw0)
+                                       and self._fused_obs() and self._dense_obs())
+        self._mega_prev = bool(getattr(self, '_mega_last', False))     # (zero_hidden hands the launch its own buffers)
+        self._mega_last = False
         if self._reset_takes_epoch is None:                        # (inspect.signature costs ~0.1 ms: once)
             self._reset_takes_epoch = 'epoch' in signature(self.env.reset).parameters
         if self._reset_takes_epoch:                                # trainer.py:28-32
@@ -128,6 +136,16 @@ class Trainer(object):
                 self._graphs.clear()
                 self._episodes_played = min(self._episodes_played, 1)   # next episode re-captures
 
+    def _mega_expected(self, raw):
+        """Will step_episode go through ic3_policy_step?  (no autograd, default sampling, a policy that supports the
+        env: the same conditions _step_body tests, evaluated before the episode starts)"""
+        a = self.args
+        if getattr(a, 'rollout_grad', False) or not a.recurrent or self.clock.env is not raw \
+                or select_action is not _select_action_default:
+            return False
+        ok = getattr(self.policy_net, 'mega_supported', None)
+        return bool(ok(raw)) if ok is not None else False
+
     def _dense_obs(self):
         """args.dense_obs=False skips the obs-assembly launch when nothing consumes the dense observation (sparse
         encoder active, no store_states, no autograd): env.step(..., obs=NULL) in the C ABI.  Default: assemble it."""
@@ -154,7 +172,7 @@ class Trainer(object):
             # capture: the launch sequence of step t (policy kernels, sampling, env step [, obs assembly]) with the
             # buffers it reads/writes.  The obs launch stays outside the graph while it is being event-timed.
             in_graph_obs = self._dense_obs() and (not self._obs_outside_graph(raw, t) or
-                                                  (getattr(self, '_mega_last', False) and self._fused_obs()))
+                                                  (self._mega_now() and self._fused_obs()))
             saved = (self._state, self._info, self._prev_hid)
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
@@ -170,8 +188,7 @@ class Trainer(object):
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
             # capture does not execute: fall through to a replay so that step t actually runs
-        if g['obs_inside'] and self._obs_outside_graph(raw, t) and not (getattr(self, '_mega_last', False)
-                                                                        and self._fused_obs()):
+        if g['obs_inside'] and self._obs_outside_graph(raw, t) and not (self._mega_now() and self._fused_obs()):
             # timing was switched on after capture: re-capture without the obs launch
             del self._graphs[t]
             return self.step_episode(t)
@@ -197,7 +214,7 @@ class Trainer(object):
                 state = state.clone()          # the env reuses its obs buffer; autograd keeps the encoder input
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:
-                    if getattr(self, '_mega_last', False) and not torch.is_grad_enabled() \
+                    if getattr(self, '_mega_prev', False) and not torch.is_grad_enabled() \
                             and hasattr(self.policy_net, 'zero_hidden'):
                         # the previous step went through the one-launch path: hand it its own buffers, zeroed
                         self._prev_hid = self.policy_net.zero_hidden(state.shape[0], state.device)
@@ -301,6 +318,10 @@ class Trainer(object):
         self._info = info
         self._nsteps = t + 1
 
+    def _mega_now(self):
+        """this episode (or, before its first step, the previous one) runs on the one-launch path"""
+        return bool(getattr(self, '_mega_last', False) or getattr(self, '_mega_prev', False))
+
     def _obs_outside_graph(self, raw, t):
         """The obs-assembly launch stays outside the captured step graph when it runs on the side stream
         (args.overlap_obs) or is being event-timed (HIP events recorded in a captured graph cannot be timed; timing
@@ -308,7 +329,11 @@ class Trainer(object):
         return self._overlap_obs() or raw.obs_timer is not None
 
     def _fused_obs(self):
-        return bool(getattr(self.args, 'fused_obs', True)) and not self._overlap_obs()
+        """ic3_policy_step writes the rows of the state it ACTS ON; a rollout that stores states needs obs(s_{t+1}) in
+        the env's buffer right after the step (Transition.next_state, and `state` of the next slot), so it keeps the
+        stand-alone obs launch behind the step."""
+        return bool(getattr(self.args, 'fused_obs', True)) and not self._overlap_obs() \
+            and not getattr(self.args, 'store_states', False)
 
     def _overlap_obs(self):
         """args.overlap_obs is only honoured when nothing on the rollout path reads the dense observation (the sparse

@@ -1,0 +1,111 @@
+"""ic3_policy_step pinned to the reference IN ONE HOP at BASELINE shapes and sizes (round-2 verdict item 2).
+
+The launch that the headline number is measured on is free-run for a full episode at the PP-hard, TJ-hard, TJ-medium and
+PP-scaled shapes and every per-step output (log-probs of every head, value, h, c) is compared with oracle.policy_ref
+(numpy float64, the reference's own N x N x H expand / mask chain, /root/reference/comm.py:134-244, pinned by the
+policy_* fixtures) driven by the C oracle env (pinned by the trajectory fixtures) on the kernel's own actions, at the
+north_star's 1e-5; rewards and the dense observation rows written by the same launch are compared bit for bit
+(/root/reference/trainer.py:43-108).  Plus the launch geometry of the benchmark itself: one E = 8192 PP-hard run with the
+auto-selected tile plan (full tiles + half tiles) spot-checked on envs of the first full tile, the last full tile and
+half tiles, and one PP-scaled run whose obs tensor exceeds 4 GB (64-bit row offsets) checked on the far-end rows."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5     # north_star: policy forward within 1e-5 fp32
+
+
+def _oracle_env(a, seed, gid):
+    import oracle
+    if a.env_name == 'predator_prey':
+        return oracle.PPOracle(a.nagents, a.dim, a.vision, a.mode, seed=seed, env_gid=gid)
+    return oracle.TJOracle(a.nagents, a.dim, a.vision, a.difficulty, a.add_rate_min, a.add_rate_max, a.curr_start,
+                           a.curr_end, seed=seed, env_gid=gid, vocab_type=a.vocab_type)
+
+
+def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True):
+    """Plays T lock-step iterations through Trainer.step_episode (the one-launch path) and replays the envs in
+    `check_envs` through the fp64 policy + the oracle env on the kernel's actions.  Returns the worst policy error."""
+    import bench
+    from oracle import policy_ref
+    tr, a = bench.build_trainer(workload, E, seed, offset, 0)
+    a.max_steps = T
+    tr.begin_episode(0)
+    raw = tr.env.env
+    N, H = a.nagents, a.hid_size
+    nheads = len(a.naction_heads)
+    params = {k: v.detach().cpu().double().numpy() for k, v in tr.policy_net.state_dict().items()}
+    idx = torch.tensor(check_envs, device='cuda')
+    rec = []
+    for t in range(T):
+        tr.step_episode(t)
+        _, action_out, value, _ = tr._step_out[t]
+        h, c = tr._prev_hid
+        rec.append(dict(
+            logp=[ao.index_select(0, idx).cpu().numpy() for ao in action_out],
+            value=value.reshape(E, N).index_select(0, idx).cpu().numpy(),
+            h=h.reshape(E, N, H).index_select(0, idx).cpu().numpy(),
+            c=c.reshape(E, N, H).index_select(0, idx).cpu().numpy(),
+            act=tr._buf['action'][t].index_select(1, idx).cpu().numpy(),        # (heads, k, N)
+            rew=tr._buf['reward'][t].index_select(0, idx).cpu().numpy(),
+            obs=raw._obs.index_select(0, idx).cpu().numpy() if check_obs else None))
+    assert getattr(tr.policy_net, 'mega_steps', 0) == T, "the one-launch path did not run"
+    worst = 0.0
+    tj = a.env_name == 'traffic_junction'
+    for k, e in enumerate(check_envs):
+        o = _oracle_env(a, seed, offset + e)
+        obs = o.reset(0) if tj else o.reset()
+        hc = (np.zeros((N, H)), np.zeros((N, H)))
+        alive = None                                           # trainer.py:41-46: info is empty at t = 0 (quirk Q21)
+        gate = np.zeros(N)                                     # quirk Q22
+        for t in range(T):
+            r = rec[t]
+            if check_obs:                                      # the rows of the state acted on, from the same launch
+                np.testing.assert_array_equal(r['obs'][k], obs, err_msg="obs rows env %d step %d" % (e, t))
+            logp, val, hc = policy_ref.forward(params, obs[None].astype(np.float64), hc, alive,
+                                               gate if a.hard_attn else None, recurrent=True,
+                                               comm_mode_avg=(a.comm_mode == 'avg'), hard_attn=bool(a.hard_attn),
+                                               nheads=nheads)
+            for hd in range(nheads):
+                worst = max(worst, np.abs(logp[hd][0] - r['logp'][hd][k]).max())
+            worst = max(worst, np.abs(val.reshape(-1) - r['value'][k]).max())
+            worst = max(worst, np.abs(hc[0] - r['h'][k]).max(), np.abs(hc[1] - r['c'][k]).max())
+            assert worst < TOL, (workload, e, t, worst)
+            obs, orew, _ = o.step(r['act'][0, k])
+            np.testing.assert_array_equal(r['rew'][k], np.asarray(orew).astype(np.float32))
+            if tj:
+                alive = o.alive.astype(np.float64)             # info['alive_mask'] of this step (TJ:244-247)
+            if a.hard_attn:                                    # trainer.py:70-71
+                gate = np.ones(N) if a.comm_action_one else r['act'][nheads - 1, k].astype(np.float64)
+    return worst
+
+
+@pytest.mark.parametrize("workload,E,T", [("pp_hard", 13, 80), ("tj_hard", 7, 80), ("tj_medium", 13, 40),
+                                          ("pp_scaled", 3, 20)])
+def test_policy_step_full_episode_vs_fp64_reference_policy(workload, E, T):
+    worst = _free_run(workload, E, T, seed=5, offset=300, check_envs=list(range(E)))
+    assert worst < TOL, worst
+
+
+def test_policy_step_at_benchmark_size_pp_hard():
+    """E = 8192 through the auto-selected tile plan (1280 full tiles of 6 envs + 171 half tiles of 3): envs of the first
+    full tile, the last full tile, the first / a middle / the last half tile."""
+    envs = [0, 5, 7674, 7679, 7680, 7682, 7935, 8189, 8191]
+    worst = _free_run("pp_hard", 8192, 3, seed=9, offset=0, check_envs=envs)
+    assert worst < TOL, worst
+
+
+def test_policy_step_obs_tensor_beyond_4gb_pp_scaled():
+    """PP-scaled, E = 1024: the obs tensor is 5.25 GB — rows on both sides of the 2^31 and 2^32 byte marks and at the far end."""
+    per_env = 32 * 40100 * 4
+    marks = [2 ** 31 // per_env, 2 ** 32 // per_env]
+    envs = sorted(set([0] + [m + d for m in marks for d in (0, 1)] + [1022, 1023]))
+    worst = _free_run("pp_scaled", 1024, 2, seed=4, offset=0, check_envs=envs)
+    assert worst < TOL, worst

@@ -382,3 +382,45 @@ def test_free_running_graph_rollout_replays_through_oracle(workload, E):
             over = bool(od)
     assert stat['num_steps'] == steps
     np.testing.assert_allclose(stat['reward'], total_reward, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("workload,E", [("pp_hard", 7), ("tj_medium", 5)])
+def test_store_states_holds_state_and_next_state(workload, E):
+    """args.store_states (trainer.py:49,67,104: Transition.state is the observation the policy saw, next_state the one
+    env.step returned).  ic3_policy_step writes the rows of the state it ACTS ON, so a storing rollout must not take
+    them for next_state: checked against the oracle env on the rollout's own actions, on the default (one-launch) path
+    and on the launch chain — and a later non-storing, autograd rollout after a one-launch episode still starts from a
+    freshly assembled reset observation (the sticky `_mega_last` flag of round 2)."""
+    import bench
+    import oracle
+    T = 6
+    for mega in (True, False):
+        tr, a = bench.build_trainer(workload, E, 2, 50, 0)
+        a.max_steps, a.store_states, a.mega_policy = T, True, mega
+        episode, _ = tr.get_episode(0)
+        assert (getattr(tr.policy_net, 'mega_steps', 0) > 0) == mega
+        for e in range(E):
+            if a.env_name == 'predator_prey':
+                o = oracle.PPOracle(a.nagents, a.dim, a.vision, a.mode, seed=2, env_gid=50 + e)
+                obs = o.reset()
+            else:
+                o = oracle.TJOracle(a.nagents, a.dim, a.vision, a.difficulty, a.add_rate_min, a.add_rate_max,
+                                    a.curr_start, a.curr_end, seed=2, env_gid=50 + e, vocab_type=a.vocab_type)
+                obs = o.reset(0)
+            for t in range(T):
+                tn = episode[t]
+                np.testing.assert_array_equal(tn.state[e].cpu().numpy(), obs, err_msg="state e=%d t=%d mega=%s" % (e, t, mega))
+                obs, _, _ = o.step(tn.action[0, e].cpu().numpy())
+                np.testing.assert_array_equal(tn.next_state[e].cpu().numpy(), obs,
+                                              err_msg="next_state e=%d t=%d mega=%s" % (e, t, mega))
+    # a one-launch episode followed by an episode on the autograd path: its first forward reads the env's obs buffer
+    tr, a = bench.build_trainer(workload, E, 2, 50, 0)
+    a.max_steps = T
+    tr.get_episode(0)
+    assert getattr(tr.policy_net, 'mega_steps', 0) == T
+    a.rollout_grad, a.sparse_encoder_grad = True, False
+    tr.policy_net.obs_env = None
+    tr.begin_episode(1)
+    got = tr._state.clone()                                          # (the env's own buffer: copy before re-assembling it)
+    fresh = tr.env.env.observe().clone()
+    assert torch.equal(got.reshape(fresh.shape), fresh)              # reset() assembled the observation of the new state
