@@ -74,6 +74,8 @@ EXPORTS = {
     "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p]),
     "ic3_env_encode_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ic3_env_encode_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p]),
     "ic3_env_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_encode_backward_work": (C.c_int64, [C.c_void_p, C.c_int]),
     "ic3_env_encode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -89,6 +91,7 @@ EXPORTS = {
     "ic3_env_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     "ic3_comm_masked_mean": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
     "ic3_lstm_cell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_lstm_cell_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_lstm_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -1,0 +1,210 @@
+"""The update half without autograd — /root/reference/trainer.py:128-225 (`compute_grad`) for the recurrent CommNet /
+IC3Net policy (/root/reference/comm.py:134-244), as an explicit backward-through-time over what a NO-GRAD rollout
+recorded.
+
+The reference (and round 1/2 here) keeps the autograd graph of the whole rollout: every intermediate of every step —
+encoder output, communication vectors, gate pre-activations, log-softmax inputs — stays alive until `loss.backward()`
+(59.5 GB for one PP-hard update at 8192 envs), and the rollout has to run through differentiable ops, i.e. not through
+the one-launch kernel.  Here the rollout is the ordinary rollout (ic3_policy_step where it applies) and records per step
+only what cannot be re-derived: the recurrent state (h, c) that ENTERED the step, a snapshot of the env's integer state
+(a few hundred bytes per env) and the two masks.  The backward pass walks the steps in reverse and, per step,
+  re-evaluates   enc (ic3_env_encode_at on the snapshot), comm (ic3_comm_masked_mean), inp, the gate pre-activations
+  backpropagates heads -> LSTM cell (ic3_lstm_cell_backward: dgates, dc) -> [W_ih | W_hh] -> C -> comm (its mixing matrix
+                 is symmetric: the same kernel on the gradient) -> encoder (ic3_env_encode_backward on the snapshot)
+with the hidden state cut every `detach_gap` steps exactly where the reference detaches it (trainer.py:56-60).  The dense
+products are plain library GEMMs (hipBLASLt fp32 MFMA through torch.mm / addmm_: [R x 4H] x [4H x 2H] and its
+transposes — there is nothing to fuse into them that the HBM traffic of their operands would notice); everything
+pointwise or sparse is a HIP kernel of libic3rollout.
+
+Cost per step (PP-hard): forward 0.30 GFLOP-equivalents of one gate GEMM, backward = recompute (1x) + input gradient (1x)
++ weight gradient (1x): fp32 arithmetic bounds the update at ~4x the rollout's matrix work.
+"""
+import torch
+
+from . import ops
+
+
+def supported(args, net, raw):
+    """Recurrent LSTM CommNet / IC3Net, one communication pass, sparse encoder bound to this env."""
+    if not (getattr(args, 'recurrent', False) and getattr(args, 'rnn_type', '') == 'LSTM' and hasattr(net, 'f_module')):
+        return False
+    if getattr(net, 'comm_passes', 1) != 1 or args.hid_size % 4 or not hasattr(raw, 'encode_at'):
+        return False
+    if getattr(net.obs_encoder, '__self__', None) is not raw or net.nagents != raw.nagents_env:
+        return False
+    return net.encoder.weight.is_cuda and net.encoder.weight.dtype == torch.float32
+
+
+class EpisodeRecord(object):
+    """What one batched episode leaves behind for the backward pass: (h, c) entering every step, the env state of every
+    step, the masks of the communication block."""
+
+    def __init__(self, T, R, H, state_words, device):
+        self.hs = torch.empty((T, R, H), dtype=torch.float32, device=device)
+        self.cs = torch.empty((T, R, H), dtype=torch.float32, device=device)
+        self.snaps = torch.empty((T, state_words), dtype=torch.int32, device=device)
+        self.alive = [None] * T
+        self.gate = [None] * T
+        self.h_last = None
+        self.n = 0
+
+    def record(self, t, net, raw, prev_hid, info):
+        h, c = prev_hid
+        R, H = self.hs.shape[1:]
+        self.hs[t].copy_(h.detach().reshape(R, H))
+        self.cs[t].copy_(c.detach().reshape(R, H))
+        raw.snapshot(out=self.snaps[t])
+        E = R // net.nagents
+        self.alive[t] = net._mask(info, 'alive_mask', E, self.hs.device)
+        self.gate[t] = net._mask(info, 'comm_action', E, self.hs.device) if net.args.hard_attn else None
+        self.n = t + 1
+
+    def finish(self, prev_hid):
+        self.h_last = prev_hid[0].detach().reshape(self.hs.shape[1:]).clone()
+
+
+def loss_gradients(args, batch):
+    """trainer.py:128-218 up to the losses: returns (stat, d_out) with d_out (T, R, OT) = dL/d[logits of every head |
+    value] of every transition (the log-softmax is folded in: gradients w.r.t. its INPUT)."""
+    n = args.nagents
+    rewards = torch.stack(batch.reward)                                   # (T, E, N)
+    T, E = rewards.shape[0], rewards.shape[1]
+    episode_masks = torch.stack(batch.episode_mask)
+    episode_mini_masks = torch.stack(batch.episode_mini_mask)
+    actions = torch.stack(batch.action).permute(0, 2, 3, 1).long()        # (T, E, N, heads)
+    values = torch.stack([v.reshape(E, n) for v in batch.value])          # (T, E, N)
+    nheads = len(batch.action_out[0])
+    log_p_a = [torch.stack([ao[k] for ao in batch.action_out]) for k in range(nheads)]    # (T, E, N, A_k)
+    alive_masks = torch.stack([m['alive_mask'] for m in batch.misc])      # (T, E, N), already x live
+    live = torch.stack([m['live'] for m in batch.misc]).unsqueeze(2).expand(T, E, n)
+
+    coop_returns = torch.empty_like(rewards)
+    ncoop_returns = torch.empty_like(rewards)
+    prev_coop = torch.zeros_like(rewards[0])
+    prev_ncoop = torch.zeros_like(rewards[0])
+    for i in reversed(range(T)):                                          # trainer.py:162-170
+        coop_returns[i] = rewards[i] + args.gamma * prev_coop * episode_masks[i]
+        ncoop_returns[i] = rewards[i] + args.gamma * prev_ncoop * episode_masks[i] * episode_mini_masks[i]
+        prev_coop = coop_returns[i]
+        prev_ncoop = ncoop_returns[i]
+    returns = args.mean_ratio * coop_returns.mean(dim=2, keepdim=True) + (1 - args.mean_ratio) * ncoop_returns
+    advantages = returns - values                                         # trainer.py:173-174 (values carry no graph here)
+    if args.normalize_rewards:                                            # trainer.py:176-177 (live entries only)
+        cnt = live.sum()
+        mean = (advantages * live).sum() / cnt
+        var = (((advantages - mean) ** 2) * live).sum() / (cnt - 1)
+        advantages = (advantages - mean) / var.sqrt()
+    stat = dict()
+    per_head = [lp.gather(3, actions[..., k:k + 1]).squeeze(3) for k, lp in enumerate(log_p_a)]
+    if args.advantages_per_action:                                        # trainer.py:192-197 (the same sum either way)
+        action_loss = sum((-advantages * lp * alive_masks).sum() for lp in per_head)
+    else:
+        action_loss = (-advantages * sum(per_head) * alive_masks).sum()
+    value_loss = ((values - returns).pow(2) * alive_masks).sum()          # trainer.py:203-206
+    entropy = 0
+    for lp in log_p_a:                                                    # trainer.py:211-218 (no alive mask there)
+        entropy = entropy - (lp * lp.exp() * live.unsqueeze(3)).sum()
+    stat['action_loss'] = action_loss.item()
+    stat['value_loss'] = value_loss.item()
+    stat['entropy'] = entropy.item()
+
+    cols = []
+    w_act = (-advantages * alive_masks).unsqueeze(3)                      # d action_loss / d logp[a]
+    for k, lp in enumerate(log_p_a):
+        dlp = torch.zeros_like(lp)
+        dlp.scatter_(3, actions[..., k:k + 1], w_act)
+        if args.entr > 0:                                                 # loss -= entr * entropy
+            dlp = dlp + args.entr * live.unsqueeze(3) * lp.exp() * (lp + 1.0)
+        cols.append(dlp - lp.exp() * dlp.sum(3, keepdim=True))            # through log_softmax: gradient w.r.t. the logits
+    cols.append((2.0 * args.value_coeff * (values - returns) * alive_masks).unsqueeze(3))
+    d_out = torch.cat(cols, 3).reshape(T, E * n, -1).contiguous()
+    return stat, d_out
+
+
+def backward_episode(args, net, raw, rec, d_out, acc):
+    """Backward through one recorded episode; parameter gradients are ADDED into `acc` (fp32 tensors keyed like the
+    fused weight cache)."""
+    fc = net._fused_cache()
+    T, R, H = rec.n, rec.hs.shape[1], rec.hs.shape[2]
+    N = net.nagents
+    E = R // N
+    dev = rec.hs.device
+    mode_avg = getattr(args, 'comm_mode', 'avg') == 'avg'
+    mask_zero = bool(args.comm_mask_zero)
+    w_cat = fc['w_cat_t']                                                 # (2H, 4H) = [W_ih | W_hh]^T
+    w_ih_t, w_hh_t = w_cat[:H], w_cat[H:]
+    z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    inp, comm, gates, dgates = z(R, H), z(E, N, H), z(R, 4 * H), z(R, 4 * H)
+    dinp, dh_prev, dcomm, dcomm_b, dh = z(R, H), z(R, H), z(R, H), z(E, N, H), z(R, H)
+    dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
+    dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
+    gap = int(getattr(args, 'detach_gap', 10000))
+    for t in reversed(range(T)):
+        if (t + 1) % gap == 0:                                            # trainer.py:56-60: (h_t, c_t) handed on detached
+            dh_rec.zero_()
+            dc_rec.zero_()
+        h_prev, c_prev = rec.hs[t], rec.cs[t]
+        h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
+        alive, gate = rec.alive[t], rec.gate[t]
+        # ---- the forward of step t again: enc + C.bias -> inp, comm, gate pre-activations (comm.py:119,181-215)
+        raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp.view(E, N, H), loc_table=fc['loc_table'])
+        if mask_zero:
+            comm.zero_()                                                  # comm.py:40-41: C sees zeros
+        else:
+            ops.comm_masked_mean_raw(h_prev.view(E, N, H), alive, gate, mode_avg, True, out=comm)
+            inp.addmm_(comm.view(R, H), fc['c_wt'])
+        torch.addmm(fc['b_cat'], inp, w_ih_t, out=gates)
+        gates.addmm_(h_prev, w_hh_t)
+        # ---- heads (comm.py:228,239) -> LSTM cell
+        d = d_out[t]
+        torch.addmm(dh_rec, d, fc['w_heads'], out=dh)
+        acc['w_heads'].addmm_(d.t(), h_t)
+        acc['b_heads'].add_(d.sum(0))
+        ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec)  # dc_rec <- dL/dc_{t-1} (in place)
+        # ---- [W_ih | W_hh] (torch.nn.LSTMCell)
+        acc['w_ih'].addmm_(dgates.t(), inp)
+        acc['w_hh'].addmm_(dgates.t(), h_prev)
+        acc['b_cat'].add_(dgates.sum(0))
+        torch.mm(dgates, w_ih_t.t(), out=dinp)                            # (R,4H) x (4H,H)
+        torch.mm(dgates, w_hh_t.t(), out=dh_prev)
+        # ---- inp = encoder(obs) + C(comm) (+ both biases)
+        acc['enc_bias'].add_(dinp.sum(0))
+        if not mask_zero:
+            acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
+            torch.mm(dinp, fc['c_wt'].t(), out=dcomm)                     # d comm = d inp . C.weight
+            ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dcomm_b)
+            dh_prev.add_(dcomm_b.view(R, H))
+        dwt, _ = raw.encode_backward(dinp, rec.snaps[t], want_bias=False)
+        acc['wt'].add_(dwt)
+        dh_rec, dh_prev = dh_prev, dh_rec
+
+
+def new_accumulators(net):
+    fc = net._fused_cache()
+    H = net.hid_size
+    dev = fc['wt'].device
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    return dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_ih=z(4 * H, H), w_hh=z(4 * H, H), b_cat=z(4 * H),
+                w_heads=z(*fc['w_heads'].shape), b_heads=z(fc['b_heads'].shape[0]))
+
+
+def assign_grads(net, acc):
+    """accumulators -> .grad of the reference's parameters (state_dict names of comm.py)."""
+    def put(p, g):
+        p.grad = g.reshape(p.shape).contiguous()
+    put(net.encoder.weight, acc['wt'].t())
+    put(net.encoder.bias, acc['enc_bias'].clone())
+    put(net.C_modules[0].weight, acc['c_w'])
+    put(net.C_modules[0].bias, acc['enc_bias'].clone())                   # inp = enc + C(comm): both biases see d inp
+    put(net.f_module.weight_ih, acc['w_ih'])
+    put(net.f_module.weight_hh, acc['w_hh'])
+    put(net.f_module.bias_ih, acc['b_cat'].clone())
+    put(net.f_module.bias_hh, acc['b_cat'].clone())
+    off = 0
+    for hd in net.heads:
+        A = hd.weight.shape[0]
+        put(hd.weight, acc['w_heads'][off:off + A])
+        put(hd.bias, acc['b_heads'][off:off + A])
+        off += A
+    put(net.value_head.weight, acc['w_heads'][off:off + 1])
+    put(net.value_head.bias, acc['b_heads'][off:off + 1])

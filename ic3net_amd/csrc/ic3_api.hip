@@ -358,6 +358,16 @@ int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, const float
                                    : tj_encode(env, Wt, bias, loc_table, out, ldo, H, (hipStream_t)stream);
 }
 
+int ic3_env_encode_at(ic3_env* env, const int32_t* snap, const float* Wt, const float* bias, const float* loc_table, float* out,
+                      int ldo, int H, ic3_stream stream)
+{
+    if (!env) return fail(-22, "ic3_env_encode_at: null handle");
+    env->view = snap;          // (null: the live state)
+    const int rc = ic3_env_encode(env, Wt, bias, loc_table, out, ldo, H, stream);
+    env->view = nullptr;
+    return rc;
+}
+
 int ic3_env_encode_table(ic3_env* env, const float* Wt, int H, float* loc_table, ic3_stream stream)
 {
     if (!env || !Wt || !loc_table) return fail(-22, "ic3_env_encode_table: null argument");

@@ -127,6 +127,47 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(h_out + (size_t)row * ldh + 4 * k) = h1;
 }
 
+// Backward of the pointwise half of LSTMCell for the update half (trainer.py:128-225 through comm.py:215): from the
+// recomputed gate pre-activations, c_{t-1}, dL/dh_t (heads + what step t+1 sent back) and dL/dc_t -> dL/dgates (the
+// operand of the two weight-gradient / input-gradient GEMMs) and dL/dc_{t-1}.  Nothing of the forward is kept for it:
+// i, f, g, o, c_t and tanh(c_t) are re-evaluated here (the same hardware exp / rcp forms as the forward kernels).
+// HBM-bound: reads 4H + 3H, writes 4H + H floats per row.
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                            const float* __restrict__ dh, const float* __restrict__ dc,
+                                                            float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                                            int R, int H4)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)R * H4) return;
+    const int row = (int)(idx / H4), k = (int)(idx - (long long)row * H4);
+    const f32x4* g = reinterpret_cast<const f32x4*>(gates + (size_t)row * 16 * H4);
+    const f32x4 gi = g[k], gf = g[H4 + k], gg = g[2 * H4 + k], go = g[3 * H4 + k];
+    const size_t rk = (size_t)row * H4 + k;
+    const f32x4 c0 = reinterpret_cast<const f32x4*>(c_prev)[rk];
+    const f32x4 dhv = reinterpret_cast<const f32x4*>(dh)[rk];
+    f32x4 dcv = { 0.f, 0.f, 0.f, 0.f };
+    if (dc) dcv = reinterpret_cast<const f32x4*>(dc)[rk];
+    f32x4 di, df, dg, dO, dcp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float i = fast_sigmoid(gi[q]), f = fast_sigmoid(gf[q]), gt = fast_tanh(gg[q]), o = fast_sigmoid(go[q]);
+        const float c1 = f * c0[q] + i * gt;
+        const float tc = fast_tanh(c1);
+        const float dct = dcv[q] + dhv[q] * o * (1.0f - tc * tc);
+        di[q] = dct * gt * i * (1.0f - i);
+        df[q] = dct * c0[q] * f * (1.0f - f);
+        dg[q] = dct * i * (1.0f - gt * gt);
+        dO[q] = dhv[q] * tc * o * (1.0f - o);
+        dcp[q] = dct * f;
+    }
+    f32x4* dgp = reinterpret_cast<f32x4*>(dgates + (size_t)row * 16 * H4);
+    dgp[k] = di;
+    dgp[H4 + k] = df;
+    dgp[2 * H4 + k] = dg;
+    dgp[3 * H4 + k] = dO;
+    reinterpret_cast<f32x4*>(dc_prev)[rk] = dcp;
+}
+
 // Action heads + value head + log_softmax (comm.py:228,239) in one pass over h: out[row][:] =
 // [log_softmax(W_0 h + b_0) | log_softmax(W_1 h + b_1) | ... | w_v h + b_v], OT = sum A_k + 1 <= 16 columns.
 // 8 lanes per row (each lane a strided set of float4 chunks of the row), W staged in LDS, 3-step shuffle reduce.
@@ -398,6 +439,18 @@ extern "C" int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh
     const long long n = (long long)R * (H / 4);
     hipLaunchKernelGGL(ic3::lstm_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
                        c, h_out, ldh, R, H / 4);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float* dh, const float* dc, float* dgates,
+                                      float* dc_prev, int R, int H, ic3_stream stream)
+{
+    if (!gates || !c_prev || !dh || !dgates || !dc_prev || R <= 0 || H <= 0 || (H & 3))
+        return ic3::fail(-22, "ic3_lstm_cell_backward: bad arguments (H must be a multiple of 4)");
+    const long long n = (long long)R * (H / 4);
+    hipLaunchKernelGGL(ic3::lstm_cell_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                       c_prev, dh, dc, dgates, dc_prev, R, H / 4);
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -59,9 +59,13 @@ typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
 #endif
 // Timing ablations are COMPILE-TIME only (tools/build_variant.sh abl1 -DIC3_PS_ABL=1 ...): a set bit removes a phase and
 // makes the results wrong, so no environment variable of the shipped library can do it.  Bits: 1 gate MFMA loop,
-// 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic, 32 obs patch pass.
+// 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic, 32 obs patch pass, 64 zero
+// stores issued but dropped.
 #ifndef IC3_PS_ABL
 #define IC3_PS_ABL 0
+#endif
+#ifndef IC3_PS_RING
+#define IC3_PS_RING 8   // float4 slots of the gate GEMM's B-operand ring (4: one K block, 8: two)
 #endif
 __device__ __forceinline__ void mfma_acc(ps_f32x16& acc, float x, float y)
 {
@@ -121,6 +125,9 @@ struct StepArgs {
     // pacing of the obs zero fill (speed only — every store slot past the tile's slice is dropped by the hardware):
     int zs;                     // stores per K block of the gate loop (one of ZS_SET; a block = 32 MFMAs of a full tile)
     int zf, zepi, zh;           // stores in front of the comm phase; per element of the cell epilogue (0..2); in front of the heads
+    int z0, z3, zc;             // stores behind the loads of S0; behind the request of the old cell state; K blocks of the C product with a slot
+    int stagger, first_round;   // first-round workgroups that come second on their CU start `stagger` x 3.5 us late
+    int32_t* cu_slots;          // [16384] running count of workgroups per CU (parity = which of the two residents)
     int zrest;                  // stores per wave issued behind the cell epilogue (what the other slots left)
     // recurrent state, masks, outputs
     float* h;                   // [R][H] in place
@@ -181,6 +188,7 @@ __device__ __forceinline__ TileGeom tile_geom(const StepArgs& a, int tile_id)
     g.c_lo = g.mis ? 1 : 0;
     g.c_hi = (g.mis + g.onb) >> 6;
     g.zend = g.obs_here ? max(0, (64 * g.c_hi - g.mis) * 16) : 0;   // bytes of the body up to the last full chunk
+    if (IC3_PS_ABL & 64) g.zend = 0;   // ablation: every zero store is issued and dropped by the range check (no HBM traffic)
     return g;
 }
 
@@ -248,6 +256,21 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             a.trace[(size_t)blockIdx.x * 20 + 19] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
         }
 #endif
+        // The launch starts with two workgroups per CU in lockstep: every CU of the chip reaches its gate loop — and its
+        // obs zero stores — at the same moment, HBM takes ~5.3 TB/s of writes, and the first round's gate loops stretch
+        // to the time their stores need (round-3 phase trace: 76 us against 51 us two rounds later, when the residents
+        // of a CU have drifted apart).  The second resident of each CU therefore starts half a tile life late: the CU's
+        // store stream becomes continuous instead of bursty.  (Speed only; parity from a per-CU arrival count.)
+        if (a.stagger > 0 && a.cu_slots && (int)blockIdx.x < a.first_round) {
+            if (tid == 0) {
+                const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                const uint32_t cu = (xcc & 15u) * 1024u + ((hw >> 13) & 7u) * 64u + ((hw >> 12) & 1u) * 32u + ((hw >> 8) & 15u);
+                sfm[2] = (uint32_t)atomicAdd(&a.cu_slots[cu], 1);
+            }
+            __syncthreads();
+            if (sfm[2] & 1u)
+                for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
         const int N = a.N;
         const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
         const int total = a.pp.Np + a.pp.nprey;
@@ -380,6 +403,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 hv[i] = __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhh, tid * 16 + i * NT * 16, 0, 0));
             }
         }
+        if (g.obs_here) {   // (behind this phase's loads: their waits count these stores as younger, they do not wait for them)
+#pragma unroll 1
+            for (int i = 0; i < a.z0; ++i) zero_store();
+        }
         __syncthreads();
         IC3_TR(1);
         unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
@@ -459,6 +486,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         }
+        if (g.obs_here) {
+#pragma unroll 1
+            for (int i = 0; i < a.z3; ++i) zero_store();
+        }
         __syncthreads();   // every wave has its share of the encoder output
         IC3_TR(4);
         IC3_TR(5);
@@ -521,6 +552,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                             mfma_acc(accC[0], a0[j], cb[ch & 1][k][j]);
                             if constexpr (TWO) mfma_acc(accC[1], a1[j], cb[ch & 1][k][j]);
                         }
+                        if (g.obs_here && kb < a.zc) zero_store();
                     }
                 }
             };
@@ -539,16 +571,19 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
-        // gate weights in the layout Wq[k][c] = float4 (W[c][k], W[H+c][k], W[2H+c][k],
-        // W[3H+c][k]) of ic3_policy_pack: ONE 16-byte load per lane feeds a k-step of all four gates, so the operand
-        // ring is four float4 deep (16 registers; round 2 kept two 8-k blocks of four float4 per gate = 32) and a slot
-        // is refilled for the next K block right behind the 8 MFMAs that read it: three k sub-steps (24 MFMAs) ahead.
+        // gate weights in the layout Wq[k][c] = float4 (W[c][k], W[H+c][k], W[2H+c][k], W[3H+c][k]) of ic3_policy_pack:
+        // ONE 16-byte load per lane feeds a k-step of all four gates.  The operand ring is IC3_PS_RING float4 deep (8 = two
+        // K blocks = 32 registers, what round 2 held as two buffers of four float4 per gate); a slot is refilled right
+        // behind the 8 MFMAs that read it, RING - 1 k sub-steps (56 MFMAs) ahead of its next use — with the obs zero stores
+        // in flight the L2 answers slower than an idle one, a ring of 4 (24 MFMAs ahead) ran the gate loop 5 % slower.
+        constexpr int RING = IC3_PS_RING;
+        static_assert(RING == 4 || RING == 8, "operand ring: one or two K blocks");
         const __amdgpu_buffer_rsrc_t rgw = make_rsrc(a.l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
         const int glane = (4 * lh * H + col) * 16;               // k = 8 kb + 4 lh + j (must match the A fragments)
         auto wq = [&](int kb, int j) { return buf_load_b128(rgw, glane, (8 * kb + j) * (H * 16)); };
-        ps_f32x4 wk[4];
+        ps_f32x4 wk[RING];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wk[j] = wq(0, j);
+        for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------
 #pragma unroll
@@ -563,13 +598,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __syncthreads();
         IC3_TR(8);
 
-        // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T + b (comm.py:215, torch.nn.LSTMCell) ----------------------------
-        // LAST = no refills (the final K block).  The compiler's waits in front of each k sub-step come out as
-        // vmcnt(3 + S - stores of that sub-step): the three younger refills + the zero stores of one K block.
-        auto block = [&](auto two_c, auto s_c, auto last_c, int kb) {
+        // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
+        // `SB` = first ring slot of this K block, REFILL = the ring is refilled for block kb + RING / 4.  The compiler's
+        // waits in front of each k sub-step come out exact: vmcnt(RING - 1 + stores issued since the slot's refill).
+        auto block = [&](auto two_c, auto s_c, auto sb_c, auto refill_c, int kb) {
             constexpr bool TWO = decltype(two_c)::value;
             constexpr int S = decltype(s_c)::value;
-            constexpr bool LAST = decltype(last_c)::value;
+            constexpr int SB = decltype(sb_c)::value;
+            constexpr bool REFILL = decltype(refill_c)::value;
             const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
             ps_f32x4 a1;
             if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
@@ -577,8 +613,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt) {
-                    mfma_acc(acc[0][gt], a0[j], wk[j][gt]);
-                    if constexpr (TWO) mfma_acc(acc[1][gt], a1[j], wk[j][gt]);
+                    mfma_acc(acc[0][gt], a0[j], wk[SB + j][gt]);
+                    if constexpr (TWO) mfma_acc(acc[1][gt], a1[j], wk[SB + j][gt]);
                     // a store slot is two instructions that wait for nothing: it rides in the 64-cycle shadow of an MFMA
                     if (ps_zslot(S, 4 * j + gt)) {                // (folded after unrolling)
                         __builtin_amdgcn_sched_barrier(0);        // pinned between the MFMAs it follows / precedes
@@ -586,16 +622,22 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if constexpr (!LAST) wk[j] = wq(kb + 1, j);
+                if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto gate_loop = [&](auto two_c, auto s_c) {
-            static_assert(KB >= 3, "K/8 >= 3");
+            static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
+            constexpr std::integral_constant<int, 0> s0{};
+            constexpr std::integral_constant<int, RING == 8 ? 4 : 0> s1{};
             if (!(ABL & 1)) {
 #pragma unroll 1
-                for (int kb = 0; kb < KB - 1; ++kb) block(two_c, s_c, std::false_type{}, kb);
-                block(two_c, s_c, std::true_type{}, KB - 1);
+                for (int kb = 0; kb < KB - 2; kb += 2) {
+                    block(two_c, s_c, s0, std::true_type{}, kb);
+                    block(two_c, s_c, s1, std::true_type{}, kb + 1);
+                }
+                block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2);
+                block(two_c, s_c, s1, std::false_type{}, KB - 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -1119,7 +1161,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         static const int zf_env = getenv("IC3_PS_ZF") ? atoi(getenv("IC3_PS_ZF")) : -1;
         static const int zh_env = getenv("IC3_PS_ZH") ? atoi(getenv("IC3_PS_ZH")) : -1;
         static const int zepi_env = getenv("IC3_PS_ZEPI") ? atoi(getenv("IC3_PS_ZEPI")) : -1;
-        static const int zfrac = getenv("IC3_PS_ZFRAC") ? atoi(getenv("IC3_PS_ZFRAC")) : 85;
+        static const int zfrac = getenv("IC3_PS_ZFRAC") ? atoi(getenv("IC3_PS_ZFRAC")) : 70;
+        static const int z0_env = getenv("IC3_PS_Z0") ? atoi(getenv("IC3_PS_Z0")) : -1;
+        static const int z3_env = getenv("IC3_PS_Z3") ? atoi(getenv("IC3_PS_Z3")) : -1;
+        static const int zc_env = getenv("IC3_PS_ZC") ? atoi(getenv("IC3_PS_ZC")) : -1;
         const int NWv = H / 32, KBv = 2 * H / 8;
         const long long chunks = ((long long)a.EPT * a.N * a.obs_dim / 4 + 63) / 64 + 1;   // 1 KiB chunks of a full tile
         const long long per_wave = (chunks + NWv - 1) / NWv;
@@ -1139,13 +1184,40 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         }
         a.zs = zs;
         long long left = per_wave - (long long)zs * KBv;
-        a.zf = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zf_env >= 0 ? zf_env : 0) : 0;
+        auto take = [&](int want) {
+            const int n = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), std::max(want, 0)) : 0;
+            left -= n;
+            return n;
+        };
+        a.z0 = take(z0_env >= 0 ? z0_env : 0);
+        a.z3 = take(z3_env >= 0 ? z3_env : 0);
+        // measured on PP-hard (profiles/r03/pacing_sweep.txt): 70 % in the gate loop, 7 % each inside the C product and in
+        // front of the comm phase, the rest between the transcendentals of the cell epilogue
+        const int share = (int)((per_wave * 7 + 50) / 100);
+        a.zc = take(std::min(zc_env >= 0 ? zc_env : share, H / 8));
+        a.zf = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zf_env >= 0 ? zf_env : share) : 0;
         left -= a.zf;
         a.zh = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zh_env >= 0 ? zh_env : 0) : 0;
         left -= a.zh;
         a.zepi = !fused_obs ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
         left -= 32LL * a.zepi;
         a.zrest = fused_obs ? (int)(left > 0 ? left + 1 : 0) : 0;
+    }
+    {   // first-round stagger (see the kernel): per-device arrival counters, allocated once
+        static const int stagger_env = getenv("IC3_PS_STAGGER") ? atoi(getenv("IC3_PS_STAGGER")) : -1;
+        static int32_t* slots[64] = { nullptr };
+        int dev = 0;
+        a.stagger = 0;
+        const int want = stagger_env >= 0 ? stagger_env : 0;
+        if (fused_obs && want > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!slots[dev]) {
+                IC3_HIP(hipMalloc(&slots[dev], 16384 * sizeof(int32_t)));
+                IC3_HIP(hipMemset(slots[dev], 0, 16384 * sizeof(int32_t)));
+            }
+            a.cu_slots = slots[dev];
+            a.stagger = want;
+            a.first_round = device_cus() * (H <= 128 ? 2 : 1);
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     int rc;

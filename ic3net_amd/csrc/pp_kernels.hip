@@ -228,7 +228,7 @@ int pp_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc
     const int rows = env->dims.N;
     const int total = c.N + c.nprey, W = 2 * c.vision + 1, nseg = rows * W * W;
     const size_t lds = (size_t)(((2 * total + 3) & ~3) + 2 * nseg) * sizeof(int32_t);
-    hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->f("loc_r"), env->f("loc_c"),
+    hipLaunchKernelGGL(pp_encode_kernel, dim3(c.E), dim3(256), lds, s, env->fv("loc_r"), env->fv("loc_c"),   // (view-aware)
                        reinterpret_cast<const f32x4*>(Wt), reinterpret_cast<const f32x4*>(bias),
                        reinterpret_cast<f32x4*>(out), ldo / 4, c.N, c.nprey, c.dim, c.vision, H / 4, rows,
                        reinterpret_cast<const f32x4*>(loc_table));

@@ -325,7 +325,17 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc
     const ic3_tj_cfg& c = env->tj;
     const int WW = env->dims.window * env->dims.window;
     const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
-    hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, tj_state_of(env), reinterpret_cast<const f32x4*>(Wt),
+    TJState st = tj_state_of(env);
+    if (env->view) {   // ic3_env_encode_at: the car fields the encoder reads come from the snapshot
+        st.alive = const_cast<int32_t*>(env->fv("alive"));
+        st.loc_r = const_cast<int32_t*>(env->fv("loc_r"));
+        st.loc_c = const_cast<int32_t*>(env->fv("loc_c"));
+        st.last_act = const_cast<int32_t*>(env->fv("last_act"));
+        st.route_id = const_cast<int32_t*>(env->fv("route_id"));
+        st.route_loc = const_cast<int32_t*>(env->fv("route_loc"));
+        st.wait = const_cast<int32_t*>(env->fv("wait"));
+    }
+    hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, st, reinterpret_cast<const f32x4*>(Wt),
                        reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, H / 4,
                        reinterpret_cast<const f32x4*>(loc_table));
     IC3_HIP(hipGetLastError());

@@ -163,6 +163,20 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(loc_table), ptr(out), ldo, H, stream()))
         return out
 
+    def encode_at(self, snap, weight_t, bias, out=None, loc_table=None):
+        """encode() for the state held in `snap` (a snapshot() tensor; None = the live state) — ic3_env_encode_at: the
+        update half re-evaluates the encoder of a past step from its state snapshot."""
+        self._require()
+        H = weight_t.shape[1]
+        if weight_t.shape[0] != self.obs_dim or not weight_t.is_contiguous() or weight_t.dtype != torch.float32:
+            raise ValueError("encode_at: weight_t must be a contiguous float32 (obs_dim, H) tensor")
+        if out is None:
+            out = torch.empty((self.nenvs, self.nagents_env, H), dtype=torch.float32, device=self.device)
+        ldo = H if out.dim() == 3 else out.stride(0)
+        check(_lib.lib().ic3_env_encode_at(self._h, ptr(snap) if snap is not None else None, ptr(weight_t), ptr(bias),
+                                           ptr(loc_table), ptr(out), ldo, H, stream()))
+        return out
+
     def encode_table(self, weight_t):
         """Per-position sums of the location rows of weight_t (ic3_env_encode_table) for encode(loc_table=...)."""
         self._require()

@@ -86,6 +86,18 @@ def lstm_cell_(gates, c, h_out):
     return h_out, c
 
 
+def lstm_cell_backward(gates, c_prev, dh, dc, dgates, dc_prev):
+    """Backward of lstm_cell_ from the re-computed gate pre-activations (ic3_lstm_cell_backward): gates (R,4H), c_prev,
+    dh, dc (or None) (R,H) -> dgates (R,4H), dc_prev (R,H; may alias dc).  All contiguous float32."""
+    _need_cuda(gates, "lstm_cell_backward")
+    R, H = c_prev.shape
+    for t in (gates, c_prev, dh, dgates, dc_prev):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    check(_lib.lib().ic3_lstm_cell_backward(ptr(gates), ptr(c_prev), ptr(dh), ptr(dc) if dc is not None else None,
+                                            ptr(dgates), ptr(dc_prev), R, H, stream()))
+    return dgates, dc_prev
+
+
 def lstm_pack_weights(w_ih, w_hh):
     """[W_ih | W_hh] (4H x 2H) in the packed layout ic3_lstm_fused streams (see csrc/lstm_fused.hip)."""
     _need_cuda(w_ih, "lstm_pack_weights")

@@ -20,7 +20,7 @@ from torch import optim
 
 from .action_utils import SampleClock, select_action, translate_action
 from .action_utils import select_action as _select_action_default     # tests monkeypatch `select_action` (action tapes)
-from . import ops
+from . import bptt, ops
 from .utils import merge_stat
 
 Transition = namedtuple('Transition', ('state', 'action', 'action_out', 'value', 'episode_mask', 'episode_mini_mask',
@@ -48,6 +48,8 @@ class Trainer(object):
         self._episodes_played = 0
         self._static = None
         self._fin_work = dict()         # scratch of ic3_episode_finalize
+        self._records = None            # native update: one bptt.EpisodeRecord per episode of the batch being collected
+        self._rec = None
         self._reset_takes_epoch = None
         # encoder(obs) as a sparse gather from env state (ic3_env_encode) instead of a dense obs_dim x H GEMM;
         # the dense observation is still assembled by env.step (API contract / store_states).
@@ -123,6 +125,10 @@ class Trainer(object):
                                 zeros=torch.zeros((E, N), dtype=torch.int32, device=dev))
         self._buf = self._static
         self._step_out = [(None, None, None, None)] * T          # (state, action_out, value, next_state) per step
+        self._rec = None
+        if self._records is not None:                              # native update: what the backward pass needs later
+            raw1 = self.env.env
+            self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size, raw1.dims.state_words, dev)
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
         if self._use_graph() and self._graphs and getattr(self.policy_net, '_fc', None) is not None:
@@ -157,7 +163,7 @@ class Trainer(object):
     def _use_graph(self):
         a = self.args
         return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
-            and not getattr(a, 'rollout_grad', False) and self.clock.env is not None \
+            and not getattr(a, 'rollout_grad', False) and self._records is None and self.clock.env is not None \
             and not getattr(self, '_should_display', False) \
             and getattr(self.clock.env, 'step_timer', None) is None      # event-timed launches stay eager
 
@@ -223,6 +229,8 @@ class Trainer(object):
                 fuse_draw = not torch.is_grad_enabled() and self.clock.env is not None \
                     and hasattr(self.policy_net, 'sample_into') and select_action is _select_action_default
                 raw = self.env.env
+                if self._rec is not None:                          # (h, c) entering step t, env state, masks
+                    self._rec.record(t, self.policy_net, raw, self._prev_hid, info)
                 if fuse_draw and self.clock.env is raw and getattr(self.policy_net, 'mega_ok', None) is not None \
                         and self.policy_net.mega_ok(raw, [state, self._prev_hid]):
                     return self._step_body_mega(t, observe)
@@ -430,6 +438,10 @@ class Trainer(object):
             merge_stat(env_stat, stat)
         self._live = m['live_after']
         self._episodes_played += 1
+        if self._rec is not None:
+            self._rec.finish(self._prev_hid)
+            self._records.append(self._rec)
+            self._rec = None
         return (episode, stat)
 
     def _finalize(self, n, done, reward, alive, is_completed, gate, gate_ones):
@@ -556,18 +568,46 @@ class Trainer(object):
         loss.backward()
         return stat
 
+    def _native_update(self):
+        """args.native_update (default): the update runs on a NO-GRAD rollout + an explicit backward through time
+        (ic3net_amd.bptt) when the policy is the recurrent CommNet / IC3Net; otherwise through autograd."""
+        raw = getattr(self.env, 'env', None)
+        return bool(getattr(self.args, 'native_update', True)) and raw is not None and hasattr(raw, '_h') \
+            and bptt.supported(self.args, self.policy_net, raw)
+
+    def compute_grad_native(self, batch, records):
+        """compute_grad() without an autograd graph: losses and dL/d(logits, value) from the batch, then
+        bptt.backward_episode over every recorded episode; fills p.grad like loss.backward() would."""
+        stat, d_out = bptt.loss_gradients(self.args, batch)
+        acc = bptt.new_accumulators(self.policy_net)
+        t0 = 0
+        raw = self.env.env
+        with torch.no_grad():
+            for rec in records:
+                bptt.backward_episode(self.args, self.policy_net, raw, rec, d_out[t0:t0 + rec.n], acc)
+                t0 += rec.n
+            assert t0 == d_out.shape[0], "recorded steps do not match the batch"
+            bptt.assign_grads(self.policy_net, acc)
+        return stat
+
     def train_batch(self, epoch):
         """trainer.py:245-256 (+ multi_processing.py:74-98 when torch.distributed is initialised: gradients and
         stats are summed over ranks and divided by the global num_steps)."""
         from . import sharding
+        native = self._native_update()
         prev = getattr(self.args, 'rollout_grad', False)
-        self.args.rollout_grad = True                   # the rollout keeps the autograd graph, like the reference
+        self.args.rollout_grad = not native             # autograd path: the rollout keeps the graph, like the reference
+        self._records = [] if native else None
         try:
             batch, stat = self.run_batch(epoch)
+            records = self._records
         finally:
             self.args.rollout_grad = prev
+            self._records = None
+            self._rec = None
         self.optimizer.zero_grad()
-        s = self.compute_grad(batch)
+        s = self.compute_grad_native(batch, records) if native else self.compute_grad(batch)
+        del records
         merge_stat(s, stat)
         stat = sharding.allreduce_stats(stat)
         sharding.allreduce_grads(self.params, stat['num_steps'])             # grads /= num_steps (trainer.py:251-253)

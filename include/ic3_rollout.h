@@ -159,6 +159,11 @@ int ic3_env_encode(ic3_env* env, const float* Wt, const float* bias, const float
  * loc_table [grid_h*grid_w][H] (dims.grid_h/w; PP: dim x dim), loc_table[pos] = sum_cells Wt[col(cell, id(pos, cell))].
  * With a table the encode gathers 1 + (#occupied cells) rows per agent instead of W*W + (#occupied cells). */
 int ic3_env_encode_table(ic3_env* env, const float* Wt, int H, float* loc_table, ic3_stream stream);
+/* ic3_env_encode for the state held in `snap` (ic3_env_snapshot; NULL = the live state): the update half re-evaluates
+ * the encoder of step t from the state snapshot of that step instead of keeping its output (or the 145 KB observation
+ * per env) from the rollout — replaces the saved input of comm.py:119's nn.Linear under autograd. */
+int ic3_env_encode_at(ic3_env* env, const int32_t* snap, const float* Wt, const float* bias, const float* loc_table /* or NULL */,
+                      float* out, int ldo, int H, ic3_stream stream);
 
 /* Backward of ic3_env_encode for the update half (trainer.py:128-225 backpropagates through comm.py:51,119's
  * nn.Linear): given grad_out = dL/d out [E][N][H] (row stride ldg floats, 0 = H) it overwrites
@@ -259,6 +264,12 @@ int ic3_comm_masked_mean(const float* h, int ldh /* h row stride in floats, 0 = 
  * W_ih x + b_ih + W_hh h + b_hh (two fp32 MFMA GEMMs, or one over [x | h]).  c [R][H] is updated in place,
  * h' is written to h_out with row stride ldh.  H % 4 == 0. */
 int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream);
+/* Its backward for the update half (trainer.py:128-225 backpropagating through comm.py:215): from the RE-COMPUTED gate
+ * pre-activations gates [R][4H], the cell state c_prev [R][H] that entered the step, dh = dL/dh' [R][H] and dc = dL/dc'
+ * [R][H] (NULL = zeros) -> dgates [R][4H] = dL/dgates (gate order i,f,g,o) and dc_prev [R][H] = dL/dc_prev.  Nothing
+ * of the forward has to be kept besides (h, c) of every step. */
+int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float* dh, const float* dc /* or NULL */,
+                           float* dgates, float* dc_prev, int R, int H, ic3_stream stream);
 
 /* The whole LSTMCell in one hand-written fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact f32): gate GEMM over the
  * [inp | h] buffer XH [R][ldx] (first 2H columns), bias [4H] = b_ih + b_hh, in-register cell epilogue; c [R][H] is

@@ -197,10 +197,13 @@ GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_comm
                  ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction")]
 
 
+@pytest.mark.parametrize("native", [False, True])
 @pytest.mark.parametrize("name,env_name", GRAD_FIXTURES)
-def test_compute_grad_matches_reference(name, env_name):
-    """run_batch (with grad) + compute_grad against the reference's own trainer.py:128-225 on the same weights,
-    action tape and env draws: losses and every parameter gradient (fp32 on GPU vs the reference's fp64)."""
+def test_compute_grad_matches_reference(name, env_name, native):
+    """run_batch + compute_grad against the reference's own trainer.py:128-225 on the same weights, action tape and env
+    draws: losses and every parameter gradient (fp32 on GPU vs the reference's fp64).  native=False: the rollout keeps
+    the autograd graph (like the reference); native=True: a no-grad rollout + the explicit backward through time of
+    ic3net_amd.bptt (recompute per step from the recorded (h, c) and env snapshots) — the default of train_batch."""
     from ic3net_amd import data, trainer as trmod
     from ic3net_amd.action_utils import parse_action_args
     from ic3net_amd.comm import CommNetMLP
@@ -232,14 +235,22 @@ def test_compute_grad_matches_reference(name, env_name):
     orig = trmod.select_action
     trmod.select_action = taped
     try:
-        a.rollout_grad = True
+        a.rollout_grad = not native
         a.batch_size = int(fx["num_steps"])          # exactly nep batched episodes
+        if native:
+            assert tr._native_update()
+            tr._records = []
         batch, stats = tr.run_batch(0)
         assert stats['num_steps'] == int(fx["num_steps"]) and stats['num_episodes'] == nenv * nep
         tr.optimizer.zero_grad()
-        s = tr.compute_grad(batch)
+        if native:
+            assert len(tr._records) == nep and not batch.value[0].requires_grad
+            s = tr.compute_grad_native(batch, tr._records)
+        else:
+            s = tr.compute_grad(batch)
     finally:
         trmod.select_action = orig
+        tr._records = None
     for k in ("action_loss", "value_loss", "entropy"):
         np.testing.assert_allclose(s[k], float(fx[k]), rtol=2e-4, atol=1e-3, err_msg=k)
     for pname, p in net.named_parameters():
@@ -424,3 +435,51 @@ def test_store_states_holds_state_and_next_state(workload, E):
     got = tr._state.clone()                                          # (the env's own buffer: copy before re-assembling it)
     fresh = tr.env.env.observe().clone()
     assert torch.equal(got.reshape(fresh.shape), fresh)              # reset() assembled the observation of the new state
+
+
+@pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7)])
+def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
+    """train_batch's default path at a BASELINE shape: the rollout is the one-launch kernel (ic3_policy_step, hid 128) and
+    the gradients come from ic3net_amd.bptt — compared with loss.backward() through the autograd rollout replaying the
+    same actions (trainer.py:128-225 both ways; detach_gap cuts inside the episode, entropy term on)."""
+    import bench
+    from ic3net_amd import trainer as trmod
+    T = 12
+    extra = dict(gamma=0.95, normalize_rewards=True, entr=0.01, value_coeff=0.01, advantages_per_action=False,
+                 batch_size=E * T, detach_gap=5)
+    tr, a = bench.build_trainer(workload, E, 3, 70, 0)
+    a.__dict__.update(extra)
+    a.max_steps = T
+    assert tr._native_update()
+    tr._records = []
+    batch, _ = tr.run_batch(0)
+    assert getattr(tr.policy_net, 'mega_steps', 0) == T, "the one-launch rollout did not run"
+    tr.optimizer.zero_grad()
+    s1 = tr.compute_grad_native(batch, tr._records)
+    tr._records = None
+    g1 = {k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None}
+    tape = torch.stack(batch.action).clone()                       # (T, heads, E, N)
+
+    tr2, a2 = bench.build_trainer(workload, E, 3, 70, 0)           # same seed: same weights, same env streams
+    a2.__dict__.update(extra)
+    a2.max_steps = T
+
+    def taped(args, action_out, clock, out=None):
+        out.copy_(tape[clock.t])
+        return out
+    orig = trmod.select_action
+    trmod.select_action = taped
+    try:
+        a2.rollout_grad = True
+        batch2, _ = tr2.run_batch(0)
+        tr2.optimizer.zero_grad()
+        s2 = tr2.compute_grad(batch2)
+    finally:
+        trmod.select_action = orig
+    for k in ("action_loss", "value_loss", "entropy"):
+        np.testing.assert_allclose(s1[k], s2[k], rtol=2e-4, atol=1e-4, err_msg=k)
+    g2 = {k: p.grad for k, p in tr2.policy_net.named_parameters() if p.grad is not None}
+    assert set(g1) == set(g2)
+    for k in g1:
+        scale = max(float(g2[k].abs().max()), 1e-6)
+        np.testing.assert_allclose(g1[k].cpu().numpy() / scale, g2[k].cpu().numpy() / scale, rtol=0, atol=5e-4, err_msg=k)

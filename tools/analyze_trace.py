@@ -5,8 +5,9 @@ import sys
 
 import numpy as np
 
-NAMES = ["start", "S0 loads", "S1 desc", "S2 encoder", "S3 enc->acc", "S4 h->LDS", "S5 comm+Bload", "S6 C product",
-         "S7 inp->LDS", "S8 gate loop", "settle", "cold loads+wait", "S9 epilogue", "S10 heads", "S11 draws",
+# round-3 kernel: S2 + S4 share a phase (no barrier between them), the old cell state is requested behind S3
+NAMES = ["start", "S0 loads", "S1 desc", "S2 enc + S4 h->LDS", "S3 enc->acc+c ld", "-", "S5 comm+Bload", "S6 C product",
+         "S7 inp->LDS", "S8 gate loop", "settle", "barrier", "S9 epilogue", "S10 heads", "S11 draws",
          "S12 env step", "patch wait", "patches"]
 
 

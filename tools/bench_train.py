@@ -1,4 +1,6 @@
-"""Throughput of the update path Trainer.train_batch (rollout with autograd + compute_grad + RMSprop), PP-hard."""
+"""Throughput of the update path Trainer.train_batch (rollout + compute_grad + RMSprop), PP-hard:
+python tools/bench_train.py [nenvs] [updates] [native|autograd]   (default native: no-grad one-launch rollout + the
+explicit backward through time of ic3net_amd.bptt; autograd: the rollout keeps the autograd graph, rounds 1-2)."""
 import os
 import sys
 import time
@@ -11,7 +13,9 @@ import bench
 def main():
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     updates = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    mode = sys.argv[3] if len(sys.argv) > 3 else 'native'
     tr, a = bench.build_trainer('pp_hard', E, 0, 0, 0)
+    a.native_update = mode == 'native' 
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=E * a.max_steps)
     tune = os.environ.get('TUNE', '1') == '1'
@@ -35,8 +39,8 @@ def main():
         steps += st['num_steps']
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("train_batch PP-hard E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
-          "peak mem %.1f GB, gemm %s" % (E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates, steps // updates,
+    print("train_batch [%s] PP-hard E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
+          "peak mem %.1f GB, gemm %s" % (mode, E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates, steps // updates,
                                 torch.cuda.max_memory_allocated() / 2 ** 30, 'TunableOp' if tune else 'default'))
 
 
