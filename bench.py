@@ -254,8 +254,6 @@ def main():
                         'slot of the timed region is then a live transition')
     p.add_argument('--fused-obs', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_OBS', '1')),
                    help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
-    p.add_argument('--fused-lstm', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_LSTM', '0')),
-                   help='use the hand-written fp32-MFMA LSTM kernel instead of hipBLASLt GEMM + lstm_cell')
     p.add_argument('--rccl', type=int, default=int(os.environ.get('IC3_BENCH_RCCL', '0')),
                    help='1: bring up the RCCL process group even for one rank (world_size 1) so that the timing barrier '
                         'and the MAX / SUM reductions of the N > 1 path run on device tensors over RCCL')
@@ -301,7 +299,6 @@ def main():
     trainer, a = build_trainer(o.workload, o.nenvs, o.seed, rank * o.nenvs, local_rank)
     a.hip_graph = bool(o.graph)
     a.dense_obs = not o.no_dense_obs
-    a.fused_lstm = bool(o.fused_lstm)
     a.overlap_obs = bool(o.overlap_obs)
     a.mega_policy = bool(o.mega)
     a.fused_obs = bool(o.fused_obs)

@@ -131,11 +131,11 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     dev = rec.hs.device
     mode_avg = getattr(args, 'comm_mode', 'avg') == 'avg'
     mask_zero = bool(args.comm_mask_zero)
-    w_cat = fc['w_cat_t']                                                 # (2H, 4H) = [W_ih | W_hh]^T
-    w_ih_t, w_hh_t = w_cat[:H], w_cat[H:]
+    w_cat_t = fc['w_cat_t']                                               # (2H, 4H) = [W_ih | W_hh]^T
     z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    inp, comm, gates, dgates = z(R, H), z(E, N, H), z(R, 4 * H), z(R, 4 * H)
-    dinp, dh_prev, dcomm, dcomm_b, dh = z(R, H), z(R, H), z(R, H), z(E, N, H), z(R, H)
+    xh, comm, gates, dgates = z(R, 2 * H), z(E, N, H), z(R, 4 * H), z(R, 4 * H)   # xh = [inp | h_{t-1}]
+    dxh, dcomm, dcomm_b, dh = z(R, 2 * H), z(R, H), z(E, N, H), z(R, H)           # dxh = [d inp | d h_{t-1}]
+    inp, dinp = xh[:, :H], dxh[:, :H]
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
@@ -147,36 +147,35 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
         alive, gate = rec.alive[t], rec.gate[t]
         # ---- the forward of step t again: enc + C.bias -> inp, comm, gate pre-activations (comm.py:119,181-215)
-        raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp.view(E, N, H), loc_table=fc['loc_table'])
+        raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp, loc_table=fc['loc_table'])
+        xh[:, H:].copy_(h_prev)
         if mask_zero:
             comm.zero_()                                                  # comm.py:40-41: C sees zeros
         else:
             ops.comm_masked_mean_raw(h_prev.view(E, N, H), alive, gate, mode_avg, True, out=comm)
             inp.addmm_(comm.view(R, H), fc['c_wt'])
-        torch.addmm(fc['b_cat'], inp, w_ih_t, out=gates)
-        gates.addmm_(h_prev, w_hh_t)
+        torch.addmm(fc['b_cat'], xh, w_cat_t, out=gates)                  # one K = 2H product, as in the rollout
         # ---- heads (comm.py:228,239) -> LSTM cell
         d = d_out[t]
         torch.addmm(dh_rec, d, fc['w_heads'], out=dh)
         acc['w_heads'].addmm_(d.t(), h_t)
         acc['b_heads'].add_(d.sum(0))
         ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec)  # dc_rec <- dL/dc_{t-1} (in place)
-        # ---- [W_ih | W_hh] (torch.nn.LSTMCell)
-        acc['w_ih'].addmm_(dgates.t(), inp)
-        acc['w_hh'].addmm_(dgates.t(), h_prev)
+        # ---- [W_ih | W_hh] (torch.nn.LSTMCell): weight gradient and input gradient, one product each
+        acc['w_cat'].addmm_(dgates.t(), xh)                               # (4H, R) x (R, 2H)
         acc['b_cat'].add_(dgates.sum(0))
-        torch.mm(dgates, w_ih_t.t(), out=dinp)                            # (R,4H) x (4H,H)
-        torch.mm(dgates, w_hh_t.t(), out=dh_prev)
+        torch.mm(dgates, w_cat_t.t(), out=dxh)                            # (R, 4H) x (4H, 2H) -> [d inp | d h_{t-1}]
         # ---- inp = encoder(obs) + C(comm) (+ both biases)
         acc['enc_bias'].add_(dinp.sum(0))
         if not mask_zero:
             acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
             torch.mm(dinp, fc['c_wt'].t(), out=dcomm)                     # d comm = d inp . C.weight
             ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dcomm_b)
-            dh_prev.add_(dcomm_b.view(R, H))
+            torch.add(dxh[:, H:], dcomm_b.view(R, H), out=dh_rec)         # dL/dh_{t-1}: what step t - 1 receives
+        else:
+            dh_rec.copy_(dxh[:, H:])
         dwt, _ = raw.encode_backward(dinp, rec.snaps[t], want_bias=False)
         acc['wt'].add_(dwt)
-        dh_rec, dh_prev = dh_prev, dh_rec
 
 
 def new_accumulators(net):
@@ -184,7 +183,7 @@ def new_accumulators(net):
     H = net.hid_size
     dev = fc['wt'].device
     z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-    return dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_ih=z(4 * H, H), w_hh=z(4 * H, H), b_cat=z(4 * H),
+    return dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_cat=z(4 * H, 2 * H), b_cat=z(4 * H),
                 w_heads=z(*fc['w_heads'].shape), b_heads=z(fc['b_heads'].shape[0]))
 
 
@@ -196,8 +195,9 @@ def assign_grads(net, acc):
     put(net.encoder.bias, acc['enc_bias'].clone())
     put(net.C_modules[0].weight, acc['c_w'])
     put(net.C_modules[0].bias, acc['enc_bias'].clone())                   # inp = enc + C(comm): both biases see d inp
-    put(net.f_module.weight_ih, acc['w_ih'])
-    put(net.f_module.weight_hh, acc['w_hh'])
+    H = net.hid_size
+    put(net.f_module.weight_ih, acc['w_cat'][:, :H])
+    put(net.f_module.weight_hh, acc['w_cat'][:, H:])
     put(net.f_module.bias_ih, acc['b_cat'].clone())
     put(net.f_module.bias_hh, acc['b_cat'].clone())
     off = 0

@@ -113,8 +113,6 @@ class CommNetMLP(nn.Module):
     #   XH[:, :H] += comm_sum @ C^T                       (fp32 MFMA GEMM, hipBLASLt)   1 kernel
     #   gates = XH @ [W_ih | W_hh]^T + (b_ih + b_hh)      (fp32 MFMA GEMM, hipBLASLt)   1 kernel
     #   lstm_cell: (gates, c) -> c (in place), h' -> XH[:, H:]                          1 kernel
-    #     (args.fused_lstm: both as ONE hand-written fp32-MFMA kernel, csrc/lstm_fused.hip — at parity with the
-    #      library pair on MI355X, so off by default)
     #   policy_heads: XH[:, H:] -> [log_softmax heads | value]                          1 kernel
     # The returned (h, c) are views of internal buffers, valid until the next forward: one rollout at a time per
     # policy instance in this mode (set args.fused_policy = False to get fresh tensors from the generic path).
@@ -155,12 +153,8 @@ class CommNetMLP(nn.Module):
                     wt=self.encoder.weight.t().contiguous(),
                     enc_bias=(self.encoder.bias + self.C_modules[0].bias).contiguous(),    # comm.py:206 bias, Q24
                     c_wt=self.C_modules[0].weight.t().contiguous(),
-                    c_wp=(ops.comm_pack_weights(self.C_modules[0].weight)
-                          if self.hid_size in ops.COMM_FUSED_SIZES and getattr(self.args, 'fused_comm', False) else None),
                     w_cat_t=torch.cat([self.f_module.weight_ih, self.f_module.weight_hh], 1).t().contiguous(),
                     b_cat=(self.f_module.bias_ih + self.f_module.bias_hh).contiguous(),
-                    wp=(ops.lstm_pack_weights(self.f_module.weight_ih, self.f_module.weight_hh)
-                        if self.hid_size in ops.LSTM_FUSED_SIZES and getattr(self.args, 'fused_lstm', False) else None),
                     w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
                     b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
                 new['loc_table'] = self.obs_table(new['wt']) if self.obs_table is not None else None
@@ -240,25 +234,20 @@ class CommNetMLP(nn.Module):
             xh[:, :H].copy_(enc)
         if self.args.comm_mask_zero:
             pass                                                                       # comm.py:40-41: C(0) = bias only
-        elif fc['c_wp'] is not None and n <= 64:
-            ops.comm_fused_(xh, fc['c_wp'], alive, comm_action, batch, n, mode_avg)    # inp += C(comm(h)), one launch
         else:
             ops.comm_masked_mean_raw(xh.view(batch, n, 2 * H)[:, :, H:], alive, comm_action, mode_avg, True,
                                      out=buf['comm'])
             xh[:, :H].addmm_(buf['comm'].view(R, H), fc['c_wt'])                      # inp = enc + C(comm_sum)
         out = None
-        if fc['wp'] is not None and getattr(self.args, 'fused_lstm', False):
-            ops.lstm_fused_(xh, fc['wp'], fc['b_cat'], c)                              # gate GEMM + cell, one kernel
+        torch.addmm(fc['b_cat'], xh, fc['w_cat_t'], out=buf['gates'])                  # all four gates (hipBLASLt)
+        if getattr(self.args, 'fused_heads', True) and ops.lstm_cell_heads_ok(H):
+            # cell + heads + value + log_softmax (+ the action draws when the Trainer asked for them) in one launch
+            sink = self.sample_into
+            out = ops.lstm_cell_heads_(buf['gates'], c, h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads,
+                                       env=sink[0] if sink else None, action=sink[1] if sink else None)
+            self.sampled = sink is not None
         else:
-            torch.addmm(fc['b_cat'], xh, fc['w_cat_t'], out=buf['gates'])              # all four gates (hipBLASLt)
-            if getattr(self.args, 'fused_heads', True) and ops.lstm_cell_heads_ok(H):
-                # cell + heads + value + log_softmax (+ the action draws when the Trainer asked for them) in one launch
-                sink = self.sample_into
-                out = ops.lstm_cell_heads_(buf['gates'], c, h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads,
-                                           env=sink[0] if sink else None, action=sink[1] if sink else None)
-                self.sampled = sink is not None
-            else:
-                ops.lstm_cell_(buf['gates'], c, h_view)
+            ops.lstm_cell_(buf['gates'], c, h_view)
         if out is None:
             out = ops.policy_heads(h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads)
         return self._split_out(out, batch, n) + ((h_view, c),)

@@ -936,25 +936,151 @@ static int device_cus()
 // or none (PP-hard: 1366 tiles = 2.67 rounds of 512 slots cost 3).  Plan B: as many FULL tiles (EPT envs, two 32-row
 // MFMA tiles) as give every CU the same number, the rest as HALF tiles (EPTh = floor(32 / N) envs, one MFMA tile) that
 // are dispatched last and land next to a CU's last full tile (or alone).  A half tile is not half the time — the phases
-// around the MFMA loops and the weight stream stay — so plan B is chosen only when a cost model calibrated on PP-hard /
-// TJ-hard / E = 384 says it ends earlier: pair of full tiles 1.0, full + half 0.91, pair of halves 0.70, lone full
-// 0.6, lone half 0.47 (PP-hard 0.321 -> 0.311 ms, TJ-medium 0.297 -> 0.290; TJ-hard and PP-easy stay with plan A).
-// IC3_PS_HALF=0 / 1 forces plan A / B.
-static double tiles_cost(int k_full, int k_half)
+// around the MFMA loops and the weight stream stay — so plan B is chosen only when a cost model says it ends earlier.
+// The model's five numbers (what a CU takes for a pair of full tiles = 1, a full + a half, a pair of halves, a lone
+// full, a lone half) are MEASURED on the device the first time a (device, hid_size, agents) shape is planned:
+// calibrate_tile_costs() times the policy half of the kernel (KIND 0, scratch operands) on launches that put exactly that
+// mix on every CU.  Round 2 shipped constants fitted by hand on one box (0.91 / 0.70 / 0.6 / 0.47); they remain the
+// fallback while a stream is being captured.  IC3_PS_HALF=0 / 1 forces plan A / B (same results either way).
+struct TileCosts {
+    double full_half = 0.91, half_pair = 0.70, lone_full = 0.6, lone_half = 0.47;   // relative to a pair of full tiles
+    bool measured = false;
+};
+
+static double tiles_cost(const TileCosts& tc, int k_full, int k_half)
 {
     double c = (k_full / 2) * 1.0;
     if (k_full & 1) {
         if (k_half > 0) {
-            c += 0.91;
+            c += tc.full_half;
             --k_half;
         } else {
-            c += 0.6;
+            c += tc.lone_full;
         }
     }
-    return c + (k_half / 2) * 0.70 + (k_half & 1) * 0.47;
+    return c + (k_half / 2) * tc.half_pair + (k_half & 1) * tc.lone_half;
 }
 
-static int plan_tiles(StepArgs& a, int H)
+template <int H, int KIND>
+static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0 = nullptr,
+                       hipEvent_t ev1 = nullptr);
+// words of the small LDS arrays behind the A tile: sm, sscale, sact, rmask [64 each], sfm [4], sep, sts [64 each], shb [16], slb [4H]
+static size_t ps_lds_small(int H) { return 6 * 64 + 4 + 16 + 4 * (size_t)H; }
+
+static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
+{
+    if (!p->c_wp || !p->lstm_wp || !p->lstm_bias || !p->head_w || !p->head_b)
+        return fail(-22, std::string(who) + ": incomplete ic3_policy");
+    if (p->nheads < 1 || p->nheads > 4) return fail(-22, std::string(who) + ": 1..4 action heads");
+    a.Wt = reinterpret_cast<const ps_f32x4*>(p->enc_wt);
+    a.enc_bias = reinterpret_cast<const ps_f32x4*>(p->enc_bias);
+    a.loc_table = reinterpret_cast<const ps_f32x4*>(p->loc_table);
+    a.c_wp = reinterpret_cast<const ps_f32x4*>(p->c_wp);
+    a.l_wp = reinterpret_cast<const ps_f32x4*>(p->lstm_wp);
+    a.l_bias = p->lstm_bias;
+    a.head_w = p->head_w;
+    a.head_b = p->head_b;
+    a.nheads = p->nheads;
+    int sz[4] = { 0, 0, 0, 0 };
+    a.OT = 1;
+    for (int i = 0; i < p->nheads; ++i) {
+        sz[i] = p->head_sizes[i];
+        if (sz[i] < 1) return fail(-22, std::string(who) + ": empty action head");
+        a.OT += sz[i];
+    }
+    if (a.OT > 16) return fail(-22, std::string(who) + ": more than 15 actions in total");
+    a.a0 = sz[0];
+    a.a1 = sz[1];
+    a.a2 = sz[2];
+    a.a3 = sz[3];
+    a.mode_avg = p->mode_avg;
+    a.comm_zero = p->comm_zero;
+    return 0;
+}
+
+
+// Times `n_full` full + `n_half` half tiles of the policy half (KIND 0) on scratch operands; returns ms (< 0 on error)
+static double time_tile_mix(const ic3_policy* p, int N, int n_full, int n_half, float* scratch, hipStream_t s,
+                            hipEvent_t e0, hipEvent_t e1)
+{
+    const int H = p->H;
+    StepArgs a{};
+    if (fill_policy(a, p, "calibrate_tile_costs")) return -1.0;
+    a.N = N;
+    a.EPT = 64 / N;
+    a.EPTh = 32 / N;
+    a.n_full = n_full;
+    a.ntiles = n_full + n_half;
+    a.E = n_full * a.EPT + n_half * a.EPTh;
+    a.G = 1;
+    const size_t R = (size_t)a.E * N;
+    a.enc_in = scratch;
+    a.h = scratch + R * H;
+    a.c = scratch + 2 * R * H;
+    a.out = scratch + 3 * R * H;
+    const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H)) * sizeof(float);
+    double best = 1e30;
+    for (int rep = 0; rep < 4; ++rep) {
+        if (hipEventRecord(e0, s) != hipSuccess) return -1.0;
+        const int rc = H == 128 ? launch_step<128, 0>(a, a.ntiles, lds, s) : launch_step<64, 0>(a, a.ntiles, lds, s);
+        if (rc || hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0;
+        if (rep > 0 && ms < best) best = ms;      // (the first launch warms caches / clocks)
+    }
+    return best;
+}
+
+static void calibrate_tile_costs(const ic3_policy* p, int N, int cus, hipStream_t s, TileCosts& tc)
+{
+    const int H = p->H, EPT = 64 / N, EPTh = 32 / N;
+    const size_t Rmax = (size_t)2 * cus * EPT * N;
+    float* scratch = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&scratch, (Rmax * (3 * H + 16)) * sizeof(float)) != hipSuccess) return;
+    bool ok = hipMemsetAsync(scratch, 0, (Rmax * (3 * H + 16)) * sizeof(float), s) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (ok) {
+        const double pair = time_tile_mix(p, N, 2 * cus, 0, scratch, s, e0, e1);
+        const double fh = time_tile_mix(p, N, cus, cus, scratch, s, e0, e1);
+        const double hh = time_tile_mix(p, N, 0, 2 * cus, scratch, s, e0, e1);
+        const double lf = time_tile_mix(p, N, cus, 0, scratch, s, e0, e1);
+        const double lh = time_tile_mix(p, N, 0, cus, scratch, s, e0, e1);
+        if (pair > 0 && fh > 0 && hh > 0 && lf > 0 && lh > 0) {
+            tc.full_half = fh / pair;
+            tc.half_pair = hh / pair;
+            tc.lone_full = lf / pair;
+            tc.lone_half = lh / pair;
+            tc.measured = true;
+        }
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(scratch);
+    (void)EPTh;
+}
+
+static const TileCosts& tile_costs(const ic3_policy* p, int N, int H, hipStream_t s)
+{
+    struct Key {
+        int dev, H, N;
+        TileCosts tc;
+    };
+    static std::vector<Key> cache;
+    static const TileCosts fallback{};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fallback;
+    for (const Key& k : cache)
+        if (k.dev == dev && k.H == H && k.N == N) return k.tc;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (!p || H > 128 || hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return fallback;
+    Key k{ dev, H, N, TileCosts{} };
+    calibrate_tile_costs(p, N, device_cus(), s, k.tc);
+    cache.push_back(k);
+    return cache.back().tc;
+}
+
+static int plan_tiles(StepArgs& a, int H, const ic3_policy* p, hipStream_t s)
 {
     static const int force = getenv("IC3_PS_HALF") ? atoi(getenv("IC3_PS_HALF")) : -1;
     const int cus = device_cus();
@@ -966,9 +1092,12 @@ static int plan_tiles(StepArgs& a, int H)
     const int n_full = (a.E / a.EPT) / cus * cus;               // every CU the same number of full tiles
     const int rem = a.E - n_full * a.EPT;
     const int n_half = (rem + a.EPTh - 1) / a.EPTh;
-    const double cost_a = tiles_cost((n_all + cus - 1) / cus, 0);
-    const double cost_b = tiles_cost(n_full / cus, (n_half + cus - 1) / cus);
-    if (force == 1 || cost_b < cost_a - 1e-9) {
+    bool plan_b = force == 1;
+    if (force < 0) {
+        const TileCosts& tc = tile_costs(p, a.N, H, s);
+        plan_b = tiles_cost(tc, n_full / cus, (n_half + cus - 1) / cus) < tiles_cost(tc, (n_all + cus - 1) / cus, 0) - 1e-9;
+    }
+    if (plan_b) {
         a.n_full = n_full;
         a.ntiles = n_full + n_half;
     }
@@ -976,8 +1105,7 @@ static int plan_tiles(StepArgs& a, int H)
 }
 
 template <int H, int KIND>
-static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0 = nullptr,
-                       hipEvent_t ev1 = nullptr)
+static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     // (hipFuncAttributeMaxDynamicSharedMemorySize is per device and cheap to set: no per-process cache)
     if (lds > 64 * 1024)
@@ -1011,8 +1139,6 @@ extern "C" int ic3_policy_pack(const float* c_weight, const float* w_ih, const f
     return 0;
 }
 
-// words of the small LDS arrays behind the A tile: sm, sscale, sact, rmask [64 each], sfm [4], sep, sts [64 each], shb [16], slb [4H]
-static size_t ps_lds_small(int H) { return 6 * 64 + 4 + 16 + 4 * (size_t)H; }
 
 // LDS bytes of one workgroup (0 = unsupported shape); *tile_words_out = int32 words of one env-descriptor block
 static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_words_out)
@@ -1040,36 +1166,6 @@ static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_wo
 
 extern "C" int ic3_policy_step_supported(const ic3_env* env, int H) { return policy_step_lds(env, H, 0, nullptr); }
 
-static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
-{
-    if (!p->c_wp || !p->lstm_wp || !p->lstm_bias || !p->head_w || !p->head_b)
-        return fail(-22, std::string(who) + ": incomplete ic3_policy");
-    if (p->nheads < 1 || p->nheads > 4) return fail(-22, std::string(who) + ": 1..4 action heads");
-    a.Wt = reinterpret_cast<const ps_f32x4*>(p->enc_wt);
-    a.enc_bias = reinterpret_cast<const ps_f32x4*>(p->enc_bias);
-    a.loc_table = reinterpret_cast<const ps_f32x4*>(p->loc_table);
-    a.c_wp = reinterpret_cast<const ps_f32x4*>(p->c_wp);
-    a.l_wp = reinterpret_cast<const ps_f32x4*>(p->lstm_wp);
-    a.l_bias = p->lstm_bias;
-    a.head_w = p->head_w;
-    a.head_b = p->head_b;
-    a.nheads = p->nheads;
-    int sz[4] = { 0, 0, 0, 0 };
-    a.OT = 1;
-    for (int i = 0; i < p->nheads; ++i) {
-        sz[i] = p->head_sizes[i];
-        if (sz[i] < 1) return fail(-22, std::string(who) + ": empty action head");
-        a.OT += sz[i];
-    }
-    if (a.OT > 16) return fail(-22, std::string(who) + ": more than 15 actions in total");
-    a.a0 = sz[0];
-    a.a1 = sz[1];
-    a.a2 = sz[2];
-    a.a3 = sz[3];
-    a.mode_avg = p->mode_avg;
-    a.comm_zero = p->comm_zero;
-    return 0;
-}
 
 extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, int N, float* h, float* c,
                                   const int32_t* alive_in, const int32_t* comm_in, float* out, ic3_stream stream)
@@ -1092,9 +1188,9 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     a.N = N;
     a.EPT = 64 / N;
     a.G = 1;
-    const int tiles = plan_tiles(a, H);
-    const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H)) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    const int tiles = plan_tiles(a, H, p, s);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H)) * sizeof(float);
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
     if (H == 64) return launch_step<64, 0>(a, tiles, lds, s);
     return launch_step<256, 0>(a, tiles, lds, s);
@@ -1147,7 +1243,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.seed = env->tj.seed;
         a.gid0 = env->tj.env_id_offset;
     }
-    const int tiles = plan_tiles(a, H);
+    const int tiles = plan_tiles(a, H, p, (hipStream_t)stream);
     a.tile_words = tile_words;
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;

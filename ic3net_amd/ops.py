@@ -98,29 +98,6 @@ def lstm_cell_backward(gates, c_prev, dh, dc, dgates, dc_prev):
     return dgates, dc_prev
 
 
-def lstm_pack_weights(w_ih, w_hh):
-    """[W_ih | W_hh] (4H x 2H) in the packed layout ic3_lstm_fused streams (see csrc/lstm_fused.hip)."""
-    _need_cuda(w_ih, "lstm_pack_weights")
-    H = w_ih.shape[1]
-    wp = torch.empty(4 * H * 2 * H, dtype=torch.float32, device=w_ih.device)
-    check(_lib.lib().ic3_lstm_pack_weights(ptr(w_ih.detach().contiguous().float()), ptr(w_hh.detach().contiguous().float()),
-                                           ptr(wp), H, stream()))
-    return wp
-
-
-LSTM_FUSED_SIZES = (64, 128, 256)
-
-
-def lstm_fused_(xh, wp, bias, c):
-    """Whole LSTMCell on the [inp | h] buffer xh (R, 2H): c updated in place, h' written to xh[:, H:] (hand-written
-    fp32-MFMA kernel, no gates tensor)."""
-    _need_cuda(xh, "lstm_fused")
-    R, H = c.shape
-    assert xh.stride(1) == 1 and xh.shape[1] >= 2 * H and c.is_contiguous()
-    check(_lib.lib().ic3_lstm_fused(ptr(xh), xh.stride(0), ptr(wp), ptr(bias), ptr(c), R, H, stream()))
-    return xh[:, H:2 * H], c
-
-
 def policy_heads(h, W, b, head_sizes, out=None):
     """h (R,H) rows (unit column stride), W (OT,H), b (OT,) -> out (R,OT) = [log_softmax heads | value]."""
     import ctypes as C
@@ -134,29 +111,6 @@ def policy_heads(h, W, b, head_sizes, out=None):
     check(_lib.lib().ic3_policy_heads(ptr(h), h.stride(0), ptr(W), ptr(b), sizes, len(head_sizes), ptr(out), R, H,
                                       stream()))
     return out
-
-
-COMM_FUSED_SIZES = (64, 128, 256)
-
-
-def comm_pack_weights(c_weight):
-    """C.weight (H, H) -> the packed layout ic3_comm_fused streams (ic3_comm_pack_weights)."""
-    _need_cuda(c_weight, "comm_pack_weights")
-    H = c_weight.shape[0]
-    w = c_weight.detach().contiguous()
-    wp = torch.empty((H * H,), dtype=torch.float32, device=w.device)
-    check(_lib.lib().ic3_comm_pack_weights(ptr(w), ptr(wp), H, stream()))
-    return wp
-
-
-def comm_fused_(xh, wp, alive, comm_action, E, N, mode_avg):
-    """xh (E*N, 2H) = [inp | h]:  inp += comm(h) @ C.weight^T in one launch (ic3_comm_fused), in place."""
-    _need_cuda(xh, "comm_fused_")
-    H = xh.shape[1] // 2
-    assert xh.stride(1) == 1 and xh.shape[0] == E * N and wp.numel() == H * H
-    check(_lib.lib().ic3_comm_fused(ptr(xh), xh.stride(0), ptr(wp), ptr(alive), ptr(comm_action), E, N, H,
-                                    1 if mode_avg else 0, stream()))
-    return xh
 
 
 POLICY_STEP_SIZES = (64, 128, 256)

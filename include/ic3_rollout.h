@@ -271,13 +271,6 @@ int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, in
 int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float* dh, const float* dc /* or NULL */,
                            float* dgates, float* dc_prev, int R, int H, ic3_stream stream);
 
-/* The whole LSTMCell in one hand-written fp32-MFMA kernel (v_mfma_f32_32x32x2_f32, exact f32): gate GEMM over the
- * [inp | h] buffer XH [R][ldx] (first 2H columns), bias [4H] = b_ih + b_hh, in-register cell epilogue; c [R][H] is
- * updated in place and h' is written back to XH[:, H:2H] (race-free: one workgroup owns 64 whole rows).  Wp is the
- * weight matrix [W_ih | W_hh] in the packed layout produced by ic3_lstm_pack_weights (4H*2H floats).  H in {64,128,256}. */
-int ic3_lstm_pack_weights(const float* w_ih, const float* w_hh, float* Wp, int H, ic3_stream stream);
-int ic3_lstm_fused(float* XH, int ldx, const float* Wp, const float* bias, float* c, int R, int H, ic3_stream stream);
-
 /* Action heads + value head + log_softmax (comm.py:228,239) in one pass: out[r][:] =
  * [log_softmax(W_0 h_r + b_0) | ... | log_softmax(W_{k-1} h_r + b_{k-1}) | w_v h_r + b_v], OT = sum A_k + 1 <= 16.
  * W [OT][H] = rows of heads.k.weight stacked, then value_head.weight; b [OT] likewise; head_sizes is a HOST array. */
@@ -291,15 +284,6 @@ int ic3_policy_heads(const float* h, int ldh, const float* W, const float* b, co
 int ic3_lstm_cell_heads(const float* gates, float* c, float* h_out, int ldh, int R, int H, const float* W, const float* b,
                         const int32_t* head_sizes, int nheads, float* out, const ic3_env* env, int32_t* action,
                         ic3_stream stream);
-
-/* The communication block of comm.py:181-206 in one launch, in place on the [inp | h] buffer XH (R = E*N rows, row
- * stride ldx >= 2H floats):  XH[:, :H] += comm(XH[:, H:2H]) . C.weight^T  with comm the closed form of
- * ic3_comm_masked_mean (alive / comm_action [E][N] int32 or NULL, mode_avg as there; comm_mask_zero callers simply
- * skip the call).  Wp = C.weight packed by ic3_comm_pack_weights (H*H floats).  fp32 MFMA; the comm rows only exist in
- * LDS.  -ENOSYS unless H in {64, 128, 256} and N <= 64 (use ic3_comm_masked_mean + a GEMM otherwise). */
-int ic3_comm_pack_weights(const float* C_weight /* [H][H] */, float* Wp, int H, ic3_stream stream);
-int ic3_comm_fused(float* XH, int ldx, const float* Wp, const int32_t* alive, const int32_t* comm_action, int E, int N,
-                   int H, int mode_avg, ic3_stream stream);
 
 /* select_action (action_utils.py:32-36): one multinomial draw per (env, agent) row from exp(logp),
  * as inverse-CDF on Philox uniforms: counter (head*N+n, t, episode, DOMAIN_SAMPLE), key (seed, env_id_offset+e).

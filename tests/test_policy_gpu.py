@@ -20,7 +20,7 @@ def build(pc):
     return net.cuda().float()
 
 
-@pytest.mark.parametrize("fused", ["mega", "chain", False, "mfma_lstm"])
+@pytest.mark.parametrize("fused", ["mega", "chain", False])
 @pytest.mark.parametrize("name", POLICY_FIXTURES)
 def test_policy_matches_reference(name, fused):
     """"mega": the no-grad rollout fast path with everything after the encoder as ONE launch (ic3_policy_forward, the
@@ -36,9 +36,6 @@ def test_policy_matches_reference(name, fused):
         from ic3net_amd import ops
         if not (pc.recurrent and pc.comm_passes == 1 and pc.H in ops.POLICY_STEP_SIZES):
             pytest.skip("the one-launch policy kernel needs recurrent, one comm pass, H in {64,128,256}")
-    net.args.fused_lstm = (fused == "mfma_lstm")     # the hand-written fp32-MFMA LSTM kernel inside the fused path
-    if fused == "mfma_lstm" and not (pc.recurrent and pc.comm_passes == 1 and pc.H in (64, 128, 256)):
-        pytest.skip("fused LSTM kernel needs recurrent, one comm pass, H in {64,128,256}")
     hid = net.init_hidden(pc.B) if pc.recurrent else None
     worst = 0.0
     with torch.no_grad():

@@ -9,6 +9,7 @@ sample_actions, pp/tj_step), step by step over free-running episodes:
     the same actions.
 """
 import argparse
+import os
 import copy
 
 import numpy as np
@@ -311,3 +312,25 @@ def test_trainer_takes_the_one_launch_path_and_graph_replay_is_identical(workloa
     assert float((v0 - v1).abs().max()) < 2e-5
     l0, l1 = runs["eager"][0][3][0], runs["chain"][0][3][0]
     assert float((l0 - l1).abs().max()) < 2e-5
+
+
+def test_result_changing_environment_knobs_are_gone():
+    """Round 2 read IC3_PS_DEBUG / ZMODE / SKEW / WGS with getenv on the hot entry point ("results are wrong when set").
+    They are compile-time switches of variant builds now (tools/build_variant.sh): the shipped library produces the same
+    bits with and without them in the environment; the remaining variables (IC3_PS_ZS / ZF / ZFRAC / HALF ...) only move
+    work around inside the launch."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([_sys.executable, os.path.join(root, "tests", "ps_checksum_worker.py")], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("PS_CRC")][0]
+    base = run({})
+    assert run({"IC3_PS_DEBUG": "63", "IC3_PS_ZMODE": "48", "IC3_PS_SKEW": "9", "IC3_PS_WGS": "1"}) == base
+    assert run({"IC3_PS_ZS": "2", "IC3_PS_ZF": "9", "IC3_PS_ZFRAC": "40", "IC3_PS_HALF": "1", "IC3_PS_ZEPI": "0",
+                "IC3_PS_STAGGER": "3", "IC3_PS_Z0": "5", "IC3_PS_Z3": "5", "IC3_PS_ZC": "4", "IC3_PS_ZH": "6"}) == base
