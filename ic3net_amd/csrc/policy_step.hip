@@ -128,6 +128,7 @@ struct StepArgs {
     int z0, z3, zc;             // stores behind the loads of S0; behind the request of the old cell state; K blocks of the C product with a slot
     int stagger, first_round;   // first-round workgroups that come second on their CU start `stagger` x 3.5 us late
     int32_t* cu_slots;          // [16384] running count of workgroups per CU (parity = which of the two residents)
+    int32_t* cu_lock;           // [16384] or null: one gate loop at a time per CU (see the kernel)
     int zrest;                  // stores per wave issued behind the cell epilogue (what the other slots left)
     // recurrent state, masks, outputs
     float* h;                   // [R][H] in place
@@ -261,12 +262,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // to the time their stores need (round-3 phase trace: 76 us against 51 us two rounds later, when the residents
         // of a CU have drifted apart).  The second resident of each CU therefore starts half a tile life late: the CU's
         // store stream becomes continuous instead of bursty.  (Speed only; parity from a per-CU arrival count.)
+        if (tid == 0) {   // this CU's index (XCC, SE, SH, CU of HW_ID) for the per-CU words below
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            sfm[3] = (xcc & 15u) * 1024u + ((hw >> 13) & 7u) * 64u + ((hw >> 12) & 1u) * 32u + ((hw >> 8) & 15u);
+        }
         if (a.stagger > 0 && a.cu_slots && (int)blockIdx.x < a.first_round) {
-            if (tid == 0) {
-                const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-                const uint32_t cu = (xcc & 15u) * 1024u + ((hw >> 13) & 7u) * 64u + ((hw >> 12) & 1u) * 32u + ((hw >> 8) & 15u);
-                sfm[2] = (uint32_t)atomicAdd(&a.cu_slots[cu], 1);
-            }
+            if (tid == 0) sfm[2] = (uint32_t)atomicAdd(&a.cu_slots[sfm[3]], 1);
             __syncthreads();
             if (sfm[2] & 1u)
                 for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
@@ -595,6 +596,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 As[lr * LDA + col] = accC[rt][reg];
             }
         }
+        // ONE gate loop at a time per CU.  Two co-resident workgroups that start together run their gate loops
+        // together: each MFMA stream gets half of its SIMD, and the phases around the loop — which are mostly waits for
+        // memory and LDS — have nothing to hide behind.  With the loops taking turns, one workgroup streams MFMAs (and
+        // its share of the obs zero stores: the CU's store stream becomes continuous instead of bursty) while the other
+        // one runs its epilogue, heads, draws, env step and the front phases of its next tile in the gaps.  A spin on a
+        // per-CU word in global memory (both residents share an L2); held from here to the barrier behind the loop.
+        if (a.cu_lock && tid == 0) {
+            int32_t* lk = a.cu_lock + sfm[3];
+            while (atomicCAS(lk, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
+        }
         __syncthreads();
         IC3_TR(8);
 
@@ -713,6 +724,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         if ((fmask >> (32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh)) & 1) cold[rt][reg] = 0.0f;
             }
             __syncthreads();   // every wave is done with the A tile
+            if (a.cu_lock && tid == 0) atomicExch(a.cu_lock + sfm[3], 0);   // the other resident's gate loop may start
             IC3_TR(11);
             // head / value weights -> rows [0, OT) of the inp half: requested now, written to LDS behind the element loop
             // (the compiler's wait there allows the >= 32 stores issued meanwhile to stay in flight)
@@ -1265,12 +1277,20 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         const long long chunks = ((long long)a.EPT * a.N * a.obs_dim / 4 + 63) / 64 + 1;   // 1 KiB chunks of a full tile
         const long long per_wave = (chunks + NWv - 1) / NWv;
         static const int ZS_SET[] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16 };
+        // Small obs slices (TJ: <= 128 chunks per wave, a few per K block) go out entirely inside the gate loop — measured
+        // on TJ-hard: 3 per block and nothing elsewhere 0.564 ms, the split below 0.578, none in the loop 0.605.  Large
+        // ones (PP-hard: 228 per wave) would ask HBM for more than it takes while every CU is inside its gate loop:
+        // 70 % in the loop, 7 % each inside the C product and in front of the comm phase, the rest between the
+        // transcendentals of the cell epilogue (profiles/r03/pacing_sweep.txt).
+        const bool small = per_wave <= 4 * KBv;
         int zs = 0;
         if (fused_obs) {
-            const double want = (double)per_wave * zfrac / 100.0 / KBv;
+            const double want = small ? (double)((per_wave + KBv - 1) / KBv) : (double)per_wave * zfrac / 100.0 / KBv;
             double best = 1e30;
             for (int cand : ZS_SET) {
                 if (zs_env >= 0 && cand != zs_env) continue;
+                if (zs_env < 0 && cand == 1) continue;             // (2 slots per unrolled pair of K blocks: the compiler's
+                                                                   //  vmcnt comes out one short of exact for that variant)
                 const double d = want > cand ? want - cand : cand - want;
                 if (d < best) {
                     best = d;
@@ -1287,14 +1307,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         };
         a.z0 = take(z0_env >= 0 ? z0_env : 0);
         a.z3 = take(z3_env >= 0 ? z3_env : 0);
-        // measured on PP-hard (profiles/r03/pacing_sweep.txt): 70 % in the gate loop, 7 % each inside the C product and in
-        // front of the comm phase, the rest between the transcendentals of the cell epilogue
-        const int share = (int)((per_wave * 7 + 50) / 100);
+        const int share = small ? 0 : (int)((per_wave * 7 + 50) / 100);
         a.zc = take(std::min(zc_env >= 0 ? zc_env : share, H / 8));
-        a.zf = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zf_env >= 0 ? zf_env : share) : 0;
-        left -= a.zf;
-        a.zh = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), zh_env >= 0 ? zh_env : 0) : 0;
-        left -= a.zh;
+        a.zf = take(zf_env >= 0 ? zf_env : share);
+        a.zh = take(zh_env >= 0 ? zh_env : 0);
         a.zepi = !fused_obs ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
         left -= 32LL * a.zepi;
         a.zrest = fused_obs ? (int)(left > 0 ? left + 1 : 0) : 0;
@@ -1302,8 +1318,18 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     {   // first-round stagger (see the kernel): per-device arrival counters, allocated once
         static const int stagger_env = getenv("IC3_PS_STAGGER") ? atoi(getenv("IC3_PS_STAGGER")) : -1;
         static int32_t* slots[64] = { nullptr };
+        static int32_t* locks[64] = { nullptr };
+        static const int lock_env = getenv("IC3_PS_GATELOCK") ? atoi(getenv("IC3_PS_GATELOCK")) : 1;
         int dev = 0;
         a.stagger = 0;
+        a.cu_lock = nullptr;
+        if (lock_env && H <= 128 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {   // two residents per CU
+            if (!locks[dev]) {
+                IC3_HIP(hipMalloc(&locks[dev], 16384 * sizeof(int32_t)));
+                IC3_HIP(hipMemset(locks[dev], 0, 16384 * sizeof(int32_t)));
+            }
+            a.cu_lock = locks[dev];
+        }
         const int want = stagger_env >= 0 ? stagger_env : 0;
         if (fused_obs && want > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
             if (!slots[dev]) {

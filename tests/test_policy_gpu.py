@@ -204,36 +204,6 @@ def test_policy_sparse_encoder_hook_matches_dense():
         torch.testing.assert_close(x, y, atol=2e-6, rtol=0)
 
 
-def test_policy_fused_comm_option_matches_default():
-    """args.fused_comm (ic3_comm_fused: comm block + C GEMM in one MFMA kernel) against the default fused policy path
-    (comm_masked_mean + library GEMM) and the generic autograd-capable path."""
-    from test_env_parity_gpu import make_pp
-    from ic3net_amd.comm import CommNetMLP
-    import argparse
-    N, dim, v, H, E = 10, 20, 1, 128, 50
-    env = make_pp(N, dim, v, "mixed", E, seed=2)
-    obs = env.reset()
-    a = argparse.Namespace(nagents=N, hid_size=H, comm_passes=1, recurrent=True, continuous=False,
-                           naction_heads=[5, 2], comm_mask_zero=False, share_weights=False, comm_init='uniform',
-                           hard_attn=True, comm_mode='avg', rnn_type='LSTM')
-    torch.manual_seed(1)
-    net = CommNetMLP(a, env.obs_dim).cuda()
-    info = {'comm_action': (torch.rand(E, N, device='cuda') < 0.5).int(),
-            'alive_mask': (torch.rand(E, N, device='cuda') < 0.8).int()}
-    outs = []
-    for fused in (False, True):
-        a.fused_comm = fused
-        net._fc_key = None
-        with torch.no_grad():
-            torch.manual_seed(5)
-            hid = (torch.randn(E * N, H, device='cuda') * 0.3, torch.randn(E * N, H, device='cuda') * 0.3)
-            logp, val, (h, c) = net([obs, hid], info)
-            outs.append([x.clone() for x in logp] + [val.clone(), h.clone(), c.clone()])
-        assert (net._fc['c_wp'] is not None) == fused
-    for x, y in zip(*outs):
-        torch.testing.assert_close(x, y, atol=3e-6, rtol=0)
-
-
 def test_lstm_cell_and_heads_kernels_vs_torch():
     from ic3net_amd import ops
     torch.manual_seed(3)
@@ -260,41 +230,6 @@ def test_lstm_cell_and_heads_kernels_vs_torch():
                                            rtol=0)
                 off += A
             torch.testing.assert_close(out[:, off], z[:, off], atol=3e-6, rtol=0)
-
-
-@pytest.mark.parametrize("N,H,E", [(10, 128, 100), (10, 128, 6), (20, 128, 33), (3, 64, 50), (32, 256, 7), (64, 128, 3),
-                                   (1, 64, 70), (5, 128, 1)])
-@pytest.mark.parametrize("masks", ["none", "alive", "both"])
-@pytest.mark.parametrize("mode_avg", [True, False])
-def test_comm_fused_mfma_kernel(N, H, E, masks, mode_avg):
-    """ic3_comm_fused (masked mean + C GEMM on fp32 MFMA, in place on [inp | h]) against the fp64 closed form of
-    comm.py:181-206; an asymmetric C catches fragment-layout slips, E not a multiple of 64//N exercises the ragged tile."""
-    from ic3net_amd import ops
-    torch.manual_seed(N * 1000 + H + E)
-    R = E * N
-    xh = torch.randn(R, 2 * H, device='cuda')
-    Cw = torch.randn(H, H, device='cuda') * 0.1 + torch.arange(H * H, device='cuda').view(H, H).float() * 1e-6
-    alive = (torch.rand(E, N, device='cuda') < 0.7).int() if masks != "none" else None
-    gate = (torch.rand(E, N, device='cuda') < 0.5).int() if masks == "both" else None
-    if alive is not None and E > 2:
-        alive[0] = 0                                        # n_alive = 0
-        alive[1] = 0
-        alive[1, 0] = 1                                     # n_alive = 1
-    ref_in = xh.double().clone()
-    h = ref_in[:, H:].view(E, N, H)
-    a = alive.double() if alive is not None else torch.ones(E, N, device='cuda', dtype=torch.float64)
-    m = a * (gate.double() if gate is not None else 1.0)
-    S = (m.unsqueeze(2) * h).sum(1, keepdim=True)
-    comm = m.unsqueeze(2) * (S - m.unsqueeze(2) * h)
-    if mode_avg:
-        n_alive = a.sum(1)
-        comm = comm * torch.where(n_alive > 1, 1.0 / (n_alive - 1).clamp(min=1), torch.ones_like(n_alive)).view(E, 1, 1)
-    want = ref_in.clone()
-    want[:, :H] += comm.view(R, H) @ Cw.double().t()
-    ops.comm_fused_(xh, ops.comm_pack_weights(Cw), alive, gate, E, N, mode_avg)
-    assert torch.equal(xh[:, H:].double(), ref_in[:, H:])                 # h untouched
-    scale = max(1.0, float(want[:, :H].abs().max()))
-    assert float((xh[:, :H].double() - want[:, :H]).abs().max()) <= 3e-6 * scale
 
 
 @pytest.mark.parametrize("N,H,sizes", [(10, 128, [5, 2]), (5, 64, [2]), (3, 256, [5, 2]), (7, 32, [5, 2, 3, 4]), (4, 16, [9]),
@@ -333,28 +268,6 @@ def test_lstm_cell_heads_sample_fused_kernel(N, H, sizes):
     c_c, xh_c = c0.clone(), torch.zeros(R, 2 * H, device='cuda')
     out_c = ops.lstm_cell_heads_(gates, c_c, xh_c[:, H:], W, b, sizes)
     assert torch.equal(out_c, out_b) and torch.equal(c_c, c_b)
-
-
-@pytest.mark.parametrize("R,H", [(640, 128), (1000, 128), (77, 64), (300, 256), (64, 128), (1, 128)])
-def test_lstm_fused_mfma_kernel_vs_torch(R, H):
-    """Hand-written fp32-MFMA LSTM kernel (gate GEMM + cell epilogue, in-place h') against torch.nn.LSTMCell;
-    an asymmetric weight matrix catches any row/column or k-order slip in the fragment layouts."""
-    from ic3net_amd import ops
-    torch.manual_seed(R + H)
-    cell = torch.nn.LSTMCell(H, H).cuda()
-    with torch.no_grad():
-        cell.weight_ih.add_(torch.arange(4 * H * H, device='cuda').view(4 * H, H).float() * 1e-6)   # asymmetric
-        x = torch.randn(R, H, device='cuda')
-        h = torch.randn(R, H, device='cuda') * 0.5
-        c = torch.randn(R, H, device='cuda')
-        h_ref, c_ref = cell(x, (h, c))
-        xh = torch.cat([x, h], 1).contiguous()
-        c2 = c.clone()
-        wp = ops.lstm_pack_weights(cell.weight_ih, cell.weight_hh)
-        ops.lstm_fused_(xh, wp, (cell.bias_ih + cell.bias_hh).contiguous(), c2)
-        torch.testing.assert_close(xh[:, H:], h_ref, atol=3e-6, rtol=0)
-        torch.testing.assert_close(c2, c_ref, atol=3e-6, rtol=0)
-        torch.testing.assert_close(xh[:, :H], x, atol=0, rtol=0)            # the input half is untouched
 
 
 @pytest.mark.parametrize("name", ["baseline_mlp", "baseline_rnn", "baseline_rnn_lstm"])
