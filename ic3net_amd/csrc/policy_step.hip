@@ -596,12 +596,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 As[lr * LDA + col] = accC[rt][reg];
             }
         }
-        // ONE gate loop at a time per CU.  Two co-resident workgroups that start together run their gate loops
-        // together: each MFMA stream gets half of its SIMD, and the phases around the loop — which are mostly waits for
-        // memory and LDS — have nothing to hide behind.  With the loops taking turns, one workgroup streams MFMAs (and
-        // its share of the obs zero stores: the CU's store stream becomes continuous instead of bursty) while the other
-        // one runs its epilogue, heads, draws, env step and the front phases of its next tile in the gaps.  A spin on a
-        // per-CU word in global memory (both residents share an L2); held from here to the barrier behind the loop.
+        // Experiment (IC3_PS_GATELOCK=1, off by default): ONE gate loop at a time per CU — a spin on a per-CU word in
+        // global memory (both residents share an L2), held from here to the barrier behind the loop.  Two co-resident
+        // workgroups that start together run their gate loops together, each MFMA stream getting half of its SIMD; with
+        // the loops taking turns one workgroup streams MFMAs while the other runs its epilogue / heads / draws / env step
+        // and the front phases of its next tile.  Measured (round 3): the loops do take turns (36 us instead of 76) and
+        // the other phases stretch by exactly what the loops gain — an fp32 MFMA stream leaves the vector ALU to nobody,
+        // so the phases around it are not hidden behind it, they are starved by it.
         if (a.cu_lock && tid == 0) {
             int32_t* lk = a.cu_lock + sfm[3];
             while (atomicCAS(lk, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
@@ -1319,7 +1320,9 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         static const int stagger_env = getenv("IC3_PS_STAGGER") ? atoi(getenv("IC3_PS_STAGGER")) : -1;
         static int32_t* slots[64] = { nullptr };
         static int32_t* locks[64] = { nullptr };
-        static const int lock_env = getenv("IC3_PS_GATELOCK") ? atoi(getenv("IC3_PS_GATELOCK")) : 1;
+        // (experiment, off: profiles/r03/gate_lock.txt — the loops do take turns, 36 instead of 76 us each, and the phases
+        //  around them stretch by the same amount: the SIMD issues one or the other, the launch takes the same time)
+        static const int lock_env = getenv("IC3_PS_GATELOCK") ? atoi(getenv("IC3_PS_GATELOCK")) : 0;
         int dev = 0;
         a.stagger = 0;
         a.cu_lock = nullptr;
