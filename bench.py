@@ -330,7 +330,7 @@ def main():
     use_dist = world > 1 or bool(o.rccl)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))   # (only when no launcher set one)
         os.environ.setdefault('RANK', str(rank))
         os.environ.setdefault('WORLD_SIZE', str(world))
         if 'IC3_BENCH_DEVICE' in os.environ:       # test hook (several ranks on one GPU): RCCL refuses duplicate devices

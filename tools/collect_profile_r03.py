@@ -54,7 +54,7 @@ for w in ('pp_hard', 'tj_hard', 'tj_medium', 'pp_scaled'):
     if not ks_:
         print(w, 'no PMC rows')
         continue
-    k = ks_[0]
+    k = max(ks_, key=lambda q: wv[q][1])       # (policy_step_kernel<H, 0> = the few tile-plan calibration launches)
     W, F = wv[k][1] / wv[k][0], (fv[k][1] / fv[k][0] if k in fv else 0.0)
     tot = int(round((W + 2 * F) * 1024))
     with open(dst + '/bench_%s_pmc_hbm.csv' % w, 'w') as o:
