@@ -136,6 +136,11 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     xh, comm, gates, dgates = z(R, 2 * H), z(E, N, H), z(R, 4 * H), z(R, 4 * H)   # xh = [inp | h_{t-1}]
     dxh, dcomm, dcomm_b, dh = z(R, 2 * H), z(R, H), z(E, N, H), z(R, H)           # dxh = [d inp | d h_{t-1}]
     inp, dinp = xh[:, :H], dxh[:, :H]
+    bias_parts, bsum = z(ops.LSTM_BWD_MAX_PARTIALS, 4 * H), z(4 * H)
+    # the weight gradient dgates^T . [inp | h] has K = R: as NB products over row blocks (batched, then summed) the
+    # library fills the chip (tools/exp/microbench_bptt_gemms.py: 118 instead of 83 TFLOP/s at R = 81920)
+    NB = 8 if R % 8 == 0 and R >= 8192 else 1
+    wpart = z(NB, 2 * H, 4 * H) if NB > 1 else None
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
@@ -160,13 +165,17 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         torch.addmm(dh_rec, d, fc['w_heads'], out=dh)
         acc['w_heads'].addmm_(d.t(), h_t)
         acc['b_heads'].add_(d.sum(0))
-        ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec)  # dc_rec <- dL/dc_{t-1} (in place)
+        parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)   # dc_rec <- dL/dc_{t-1}
+        torch.sum(parts, 0, out=bsum)
+        acc['b_cat'].add_(bsum)
         # ---- [W_ih | W_hh] (torch.nn.LSTMCell): weight gradient and input gradient, one product each
-        acc['w_cat'].addmm_(dgates.t(), xh)                               # (4H, R) x (R, 2H)
-        acc['b_cat'].add_(dgates.sum(0))
+        if NB > 1:                                                        # acc_t (2H, 4H) += sum_b xh_b^T . dgates_b
+            torch.bmm(xh.view(NB, R // NB, 2 * H).transpose(1, 2), dgates.view(NB, R // NB, 4 * H), out=wpart)
+            acc['w_cat_t'].add_(wpart.sum(0))
+        else:
+            acc['w_cat_t'].addmm_(xh.t(), dgates)                         # (2H, R) x (R, 4H)
         torch.mm(dgates, w_cat_t.t(), out=dxh)                            # (R, 4H) x (4H, 2H) -> [d inp | d h_{t-1}]
         # ---- inp = encoder(obs) + C(comm) (+ both biases)
-        acc['enc_bias'].add_(dinp.sum(0))
         if not mask_zero:
             acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
             torch.mm(dinp, fc['c_wt'].t(), out=dcomm)                     # d comm = d inp . C.weight
@@ -174,8 +183,9 @@ def backward_episode(args, net, raw, rec, d_out, acc):
             torch.add(dxh[:, H:], dcomm_b.view(R, H), out=dh_rec)         # dL/dh_{t-1}: what step t - 1 receives
         else:
             dh_rec.copy_(dxh[:, H:])
-        dwt, _ = raw.encode_backward(dinp, rec.snaps[t], want_bias=False)
+        dwt, db = raw.encode_backward(dinp, rec.snaps[t], want_bias=True)    # db = sum of the d inp rows: both biases
         acc['wt'].add_(dwt)
+        acc['enc_bias'].add_(db)
 
 
 def new_accumulators(net):
@@ -183,7 +193,7 @@ def new_accumulators(net):
     H = net.hid_size
     dev = fc['wt'].device
     z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-    return dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_cat=z(4 * H, 2 * H), b_cat=z(4 * H),
+    return dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_cat_t=z(2 * H, 4 * H), b_cat=z(4 * H),
                 w_heads=z(*fc['w_heads'].shape), b_heads=z(fc['b_heads'].shape[0]))
 
 
@@ -196,8 +206,8 @@ def assign_grads(net, acc):
     put(net.C_modules[0].weight, acc['c_w'])
     put(net.C_modules[0].bias, acc['enc_bias'].clone())                   # inp = enc + C(comm): both biases see d inp
     H = net.hid_size
-    put(net.f_module.weight_ih, acc['w_cat'][:, :H])
-    put(net.f_module.weight_hh, acc['w_cat'][:, H:])
+    put(net.f_module.weight_ih, acc['w_cat_t'][:H].t())
+    put(net.f_module.weight_hh, acc['w_cat_t'][H:].t())
     put(net.f_module.bias_ih, acc['b_cat'].clone())
     put(net.f_module.bias_hh, acc['b_cat'].clone())
     off = 0

@@ -33,6 +33,7 @@ __device__ __forceinline__ void enc_bwd_accumulate(const float* __restrict__ g, 
         const encb_f32x4 v = reinterpret_cast<const encb_f32x4*>(g + (row0 + a) * (size_t)ldg)[c4];
         reinterpret_cast<encb_f32x4*>(gl)[idx] = v;
         const int p = pos(a);
+#ifndef IC3_ENCB_NOATOMIC   // (timing experiment, round 3: PP-hard E = 8192 takes 212 us per call with these atomics, 81 us without)
         if (p >= 0) {
             float* dst = P + (size_t)p * H + 4 * c4;
             if (v.x != 0.f) atomicAdd(dst + 0, v.x);
@@ -40,6 +41,7 @@ __device__ __forceinline__ void enc_bwd_accumulate(const float* __restrict__ g, 
             if (v.z != 0.f) atomicAdd(dst + 2, v.z);
             if (v.w != 0.f) atomicAdd(dst + 3, v.w);
         }
+#endif
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < (nslots + 1) * H; idx += blockDim.x) {

@@ -132,40 +132,64 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 // operand of the two weight-gradient / input-gradient GEMMs) and dL/dc_{t-1}.  Nothing of the forward is kept for it:
 // i, f, g, o, c_t and tanh(c_t) are re-evaluated here (the same hardware exp / rcp forms as the forward kernels).
 // HBM-bound: reads 4H + 3H, writes 4H + H floats per row.
+// `dbias` (optional, [gridDim.x][4H], one row WRITTEN per workgroup): partial column sums of dgates, whose total is the
+// gradient of b_ih (= that of b_hh) — every thread keeps the sums of its four columns of each gate over the rows it
+// walks, the workgroup folds its row lanes through LDS and stores 4H floats (a separate reduction pass over dgates would
+// read 4H floats per row again; 2048 workgroups adding into the same 4H words with atomics cost more than they saved).
+template <int H4>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                             const float* __restrict__ dh, const float* __restrict__ dc,
                                                             float* __restrict__ dgates, float* __restrict__ dc_prev,
-                                                            int R, int H4)
+                                                            float* __restrict__ dbias, int R)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)R * H4) return;
-    const int row = (int)(idx / H4), k = (int)(idx - (long long)row * H4);
-    const f32x4* g = reinterpret_cast<const f32x4*>(gates + (size_t)row * 16 * H4);
-    const f32x4 gi = g[k], gf = g[H4 + k], gg = g[2 * H4 + k], go = g[3 * H4 + k];
-    const size_t rk = (size_t)row * H4 + k;
-    const f32x4 c0 = reinterpret_cast<const f32x4*>(c_prev)[rk];
-    const f32x4 dhv = reinterpret_cast<const f32x4*>(dh)[rk];
-    f32x4 dcv = { 0.f, 0.f, 0.f, 0.f };
-    if (dc) dcv = reinterpret_cast<const f32x4*>(dc)[rk];
-    f32x4 di, df, dg, dO, dcp;
+    constexpr int RL = 256 / H4;                                  // row lanes of a workgroup
+    __shared__ f32x4 part[4][256];
+    const int k = threadIdx.x % H4, rl = threadIdx.x / H4;
+    f32x4 si = { 0.f, 0.f, 0.f, 0.f }, sf = si, sg = si, so = si;
+    for (int row = blockIdx.x * RL + rl; row < R; row += gridDim.x * RL) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(gates + (size_t)row * 16 * H4);
+        const f32x4 gi = g[k], gf = g[H4 + k], gg = g[2 * H4 + k], go = g[3 * H4 + k];
+        const size_t rk = (size_t)row * H4 + k;
+        const f32x4 c0 = reinterpret_cast<const f32x4*>(c_prev)[rk];
+        const f32x4 dhv = reinterpret_cast<const f32x4*>(dh)[rk];
+        f32x4 dcv = { 0.f, 0.f, 0.f, 0.f };
+        if (dc) dcv = reinterpret_cast<const f32x4*>(dc)[rk];
+        f32x4 di, df, dg, dO, dcp;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float i = fast_sigmoid(gi[q]), f = fast_sigmoid(gf[q]), gt = fast_tanh(gg[q]), o = fast_sigmoid(go[q]);
-        const float c1 = f * c0[q] + i * gt;
-        const float tc = fast_tanh(c1);
-        const float dct = dcv[q] + dhv[q] * o * (1.0f - tc * tc);
-        di[q] = dct * gt * i * (1.0f - i);
-        df[q] = dct * c0[q] * f * (1.0f - f);
-        dg[q] = dct * i * (1.0f - gt * gt);
-        dO[q] = dhv[q] * tc * o * (1.0f - o);
-        dcp[q] = dct * f;
+        for (int q = 0; q < 4; ++q) {
+            const float i = fast_sigmoid(gi[q]), f = fast_sigmoid(gf[q]), gt = fast_tanh(gg[q]), o = fast_sigmoid(go[q]);
+            const float c1 = f * c0[q] + i * gt;
+            const float tc = fast_tanh(c1);
+            const float dct = dcv[q] + dhv[q] * o * (1.0f - tc * tc);
+            di[q] = dct * gt * i * (1.0f - i);
+            df[q] = dct * c0[q] * f * (1.0f - f);
+            dg[q] = dct * i * (1.0f - gt * gt);
+            dO[q] = dhv[q] * tc * o * (1.0f - o);
+            dcp[q] = dct * f;
+        }
+        f32x4* dgp = reinterpret_cast<f32x4*>(dgates + (size_t)row * 16 * H4);
+        dgp[k] = di;
+        dgp[H4 + k] = df;
+        dgp[2 * H4 + k] = dg;
+        dgp[3 * H4 + k] = dO;
+        reinterpret_cast<f32x4*>(dc_prev)[rk] = dcp;
+        si += di;
+        sf += df;
+        sg += dg;
+        so += dO;
     }
-    f32x4* dgp = reinterpret_cast<f32x4*>(dgates + (size_t)row * 16 * H4);
-    dgp[k] = di;
-    dgp[H4 + k] = df;
-    dgp[2 * H4 + k] = dg;
-    dgp[3 * H4 + k] = dO;
-    reinterpret_cast<f32x4*>(dc_prev)[rk] = dcp;
+    if (!dbias) return;
+    part[0][threadIdx.x] = si;
+    part[1][threadIdx.x] = sf;
+    part[2][threadIdx.x] = sg;
+    part[3][threadIdx.x] = so;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * H4; idx += 256) {       // (gate, k): fold the row lanes
+        const int gate = idx / H4, kk = idx - gate * H4;
+        f32x4 acc = part[gate][kk];
+        for (int r = 1; r < RL; ++r) acc += part[gate][r * H4 + kk];
+        reinterpret_cast<f32x4*>(dbias + (size_t)blockIdx.x * 16 * H4)[gate * H4 + kk] = acc;
+    }
 }
 
 // Action heads + value head + log_softmax (comm.py:228,239) in one pass over h: out[row][:] =
@@ -444,15 +468,29 @@ extern "C" int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh
 }
 
 extern "C" int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float* dh, const float* dc, float* dgates,
-                                      float* dc_prev, int R, int H, ic3_stream stream)
+                                      float* dc_prev, float* dbias, int R, int H, ic3_stream stream)
 {
     if (!gates || !c_prev || !dh || !dgates || !dc_prev || R <= 0 || H <= 0 || (H & 3))
         return ic3::fail(-22, "ic3_lstm_cell_backward: bad arguments (H must be a multiple of 4)");
-    const long long n = (long long)R * (H / 4);
-    hipLaunchKernelGGL(ic3::lstm_cell_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
-                       c_prev, dh, dc, dgates, dc_prev, R, H / 4);
+    const int H4 = H / 4;
+    if (H4 > 64 || (H4 & (H4 - 1))) return ic3::fail(-38, "ic3_lstm_cell_backward: H/4 must be a power of two <= 64");
+    const int RL = 256 / H4;
+    int blocks = (R + RL - 1) / RL;
+    if (blocks > IC3_LSTM_BWD_MAX_PARTIALS) blocks = IC3_LSTM_BWD_MAX_PARTIALS;   // grid-stride: one partial row per workgroup
+    hipStream_t s = (hipStream_t)stream;
+#define IC3_LCB(N) hipLaunchKernelGGL(ic3::lstm_cell_bwd_kernel<N>, dim3(blocks), dim3(256), 0, s, gates, c_prev, dh, dc, dgates, dc_prev, dbias, R)
+    switch (H4) {
+    case 1: IC3_LCB(1); break;
+    case 2: IC3_LCB(2); break;
+    case 4: IC3_LCB(4); break;
+    case 8: IC3_LCB(8); break;
+    case 16: IC3_LCB(16); break;
+    case 32: IC3_LCB(32); break;
+    default: IC3_LCB(64); break;
+    }
+#undef IC3_LCB
     IC3_HIP(hipGetLastError());
-    return 0;
+    return blocks;   // rows of `dbias` written
 }
 
 extern "C" int ic3_lstm_cell_heads(const float* gates, float* c, float* h_out, int ldh, int R, int H, const float* W,

@@ -305,7 +305,9 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_expand_kernel(const float* 
     }
 }
 
-int encode_bwd_chunk(int E) { return (E + 511) / 512; }
+// envs per workgroup of the accumulate stage: 2048 workgroups (8 per CU at ~15 KB of LDS each) instead of 512 — a workgroup
+// walks its envs one after the other with three barriers each, so what hides that latency is more workgroups per CU
+int encode_bwd_chunk(int E) { return (E + 2047) / 2048; }
 int encode_bwd_items_b(int nwg, int nslots1, int H) { return nslots1 * H * ((nwg + ENCB_SPLIT - 1) / ENCB_SPLIT); }
 
 int64_t pp_encode_bwd_work(const ic3_env* env, int H)

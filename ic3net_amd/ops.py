@@ -86,16 +86,26 @@ def lstm_cell_(gates, c, h_out):
     return h_out, c
 
 
-def lstm_cell_backward(gates, c_prev, dh, dc, dgates, dc_prev):
+LSTM_BWD_MAX_PARTIALS = 2048
+
+
+def lstm_cell_backward(gates, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None):
     """Backward of lstm_cell_ from the re-computed gate pre-activations (ic3_lstm_cell_backward): gates (R,4H), c_prev,
-    dh, dc (or None) (R,H) -> dgates (R,4H), dc_prev (R,H; may alias dc).  All contiguous float32."""
+    dh, dc (or None) (R,H) -> dgates (R,4H), dc_prev (R,H; may alias dc).  dbias_partials: (LSTM_BWD_MAX_PARTIALS, 4H)
+    scratch — returns the view of the rows the call wrote (their sum over dim 0 = column sums of dgates), else None.
+    All contiguous float32."""
     _need_cuda(gates, "lstm_cell_backward")
     R, H = c_prev.shape
     for t in (gates, c_prev, dh, dgates, dc_prev):
         assert t.is_contiguous() and t.dtype == torch.float32
-    check(_lib.lib().ic3_lstm_cell_backward(ptr(gates), ptr(c_prev), ptr(dh), ptr(dc) if dc is not None else None,
-                                            ptr(dgates), ptr(dc_prev), R, H, stream()))
-    return dgates, dc_prev
+    if dbias_partials is not None:
+        assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == (LSTM_BWD_MAX_PARTIALS, 4 * H)
+    n = _lib.lib().ic3_lstm_cell_backward(ptr(gates), ptr(c_prev), ptr(dh), ptr(dc) if dc is not None else None,
+                                          ptr(dgates), ptr(dc_prev),
+                                          ptr(dbias_partials) if dbias_partials is not None else None, R, H, stream())
+    if n < 0:
+        check(n)
+    return dbias_partials[:n] if dbias_partials is not None else None
 
 
 def policy_heads(h, W, b, head_sizes, out=None):

@@ -266,10 +266,13 @@ int ic3_comm_masked_mean(const float* h, int ldh /* h row stride in floats, 0 = 
 int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream);
 /* Its backward for the update half (trainer.py:128-225 backpropagating through comm.py:215): from the RE-COMPUTED gate
  * pre-activations gates [R][4H], the cell state c_prev [R][H] that entered the step, dh = dL/dh' [R][H] and dc = dL/dc'
- * [R][H] (NULL = zeros) -> dgates [R][4H] = dL/dgates (gate order i,f,g,o) and dc_prev [R][H] = dL/dc_prev.  Nothing
- * of the forward has to be kept besides (h, c) of every step. */
+ * [R][H] (NULL = zeros) -> dgates [R][4H] = dL/dgates (gate order i,f,g,o) and dc_prev [R][H] = dL/dc_prev (may alias
+ * dc).  dbias (or NULL): [IC3_LSTM_BWD_MAX_PARTIALS][4H] scratch; the call WRITES its first n rows with partial column
+ * sums of dgates and returns n > 0 — their sum is dL/db_ih = dL/db_hh.  Nothing of the forward has to be kept besides
+ * (h, c) of every step.  H/4 a power of two <= 64.  Returns n (or 1 without dbias), negative errno on error. */
+#define IC3_LSTM_BWD_MAX_PARTIALS 2048
 int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float* dh, const float* dc /* or NULL */,
-                           float* dgates, float* dc_prev, int R, int H, ic3_stream stream);
+                           float* dgates, float* dc_prev, float* dbias /* or NULL */, int R, int H, ic3_stream stream);
 
 /* Action heads + value head + log_softmax (comm.py:228,239) in one pass: out[r][:] =
  * [log_softmax(W_0 h_r + b_0) | ... | log_softmax(W_{k-1} h_r + b_{k-1}) | w_v h_r + b_v], OT = sum A_k + 1 <= 16.
