@@ -354,46 +354,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // auto-reset: an env whose t == 0 is at the start of an episode — no alive mask yet (everyone counts as alive,
         // quirk Q21), gate 0 (no communication on the first step, quirk Q22), zero LSTM state (trainer.py:38-51)
         const bool autor = (KIND != 0) && a.auto_reset;              // workgroup-uniform
-        auto fresh_row = [&](int row) {                              // only called when autor
-            const int el = (int)(((float)row + 0.5f) * (1.0f / (float)N));   // row / N, exact for row < 64
-            return a.tstep[e0 + el] == 0;
-        };
-        for (int r = tid; r < BM; r += NT) {                        // (NT >= 128: this is exactly wave 0, all lanes)
-            float m = 0.f;
-            const bool fr = autor && r < rows && fresh_row(r);
-            if (r < rows && !fr)
-                m = (float)((a.alive_in ? a.alive_in[r0 + r] : 1) * (a.comm_in ? a.comm_in[r0 + r] : 1));
-            sm[r] = m;
-            if (r < 16) shb[r] = r < a.OT ? a.head_b[r + tz] : 0.0f;   // (a load behind the gate loop would first
-                                                                       //  wait for every zero store in flight)
-            if constexpr (KIND != 0) {
-                rmask[r] = (WW <= 32) ? 0u : ~0u;                    // filled next to the window descriptors (S1)
-                if (r < nenv) {                                      // Philox counters of the draws (S11): read here, once
-                    sep[r] = a.episode[e0 + r];
-                    sts[r] = a.tstep[e0 + r];
-                }
-            }
-            {                                                     // one global read per row, here; later phases test a bit
-                const unsigned long long fb = __ballot(fr);
-                if (lane == 0) {
-                    sfm[0] = (uint32_t)fb;
-                    sfm[1] = (uint32_t)(fb >> 32);
-                }
-            }
-        }
-        for (int i = tid; i < 4 * H; i += NT) slb[i] = a.l_bias[i + tz];
-        for (int el = tid; el < nenv; el += NT) {
-            int n_alive = 0;
-            const bool fr = autor && a.tstep[e0 + el] == 0;
-            for (int j = 0; j < N; ++j) n_alive += (a.alive_in && !fr) ? a.alive_in[r0 + (size_t)el * N + j] : 1;
-            sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
-        }
-        int32_t* sr = tile;
-        int32_t* sc = tile + a.EPT * total;
-        int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
-        desc_positions(tile, e0, nenv);
-        // h rows of the tile: requested now (HBM latency runs under S1/S2), parked in registers until S4
-        ps_f32x4 hv[8];
+        // EVERY global load of this phase is issued before the first LDS write that needs one (round 2/3a: seven
+        // load -> wait -> write sequences one after the other, 4.6 us): the h rows first (the big one), then one clamped,
+        // unconditional load per thread for each small array, then the positions, and only then the writes.
+        ps_f32x4 hv[8];                                              // parked in registers until S4
         {
             // rows are contiguous: float4 number idx of the tile sits at byte 16 * idx; rows >= `rows` read as zeros
             // (descriptor range check)
@@ -404,12 +368,56 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 hv[i] = __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhh, tid * 16 + i * NT * 16, 0, 0));
             }
         }
+        const int rcl = min(tid, max(rows - 1, 0)), ecl = min(tid, max(nenv - 1, 0));   // clamped row / env of this thread
+        int v_alive = 1, v_comm = 1, v_tsrow = 1, v_ep = 0, v_ts = 0;
+        if (a.alive_in) v_alive = a.alive_in[r0 + rcl];              // (uniform branches: a pointer is null or it is not)
+        if (a.comm_in) v_comm = a.comm_in[r0 + rcl];
+        if constexpr (KIND != 0) {                                   // Philox counters of the draws (S11): read here, once
+            v_tsrow = a.tstep[e0 + div_small(rcl, invN)];            // (read whether or not the handle auto-resets: a
+                                                                     //  branch around it would wait for it on the spot)
+            v_ep = a.episode[e0 + ecl];
+            v_ts = a.tstep[e0 + ecl];
+        }
+        const float v_hb = a.head_b[min(tid, a.OT - 1) + tz];
+        const float v_lb0 = a.l_bias[tid + tz], v_lb1 = a.l_bias[tid + NT + tz];   // 4H = 2 NT
+        int32_t* sr = tile;
+        int32_t* sc = tile + a.EPT * total;
+        int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
+        desc_positions(tile, e0, nenv);                              // (its LDS writes wait for everything above too)
+        if (tid < BM) {                                              // wave 0, all lanes
+            // auto-reset: an env whose t == 0 is at the start of an episode (see above); `sact` carries the alive flags
+            // to the per-env scale below (it is the draws' action buffer much later)
+            const bool in = tid < rows, fr = autor && in && v_tsrow == 0;
+            sm[tid] = (in && !fr) ? (float)(v_alive * v_comm) : 0.f;
+            sact[tid] = (in && a.alive_in && !fr) ? v_alive : 1;
+            if (tid < 16) shb[tid] = tid < a.OT ? v_hb : 0.0f;       // (a load behind the gate loop would first wait for
+                                                                     //  every zero store in flight)
+            if constexpr (KIND != 0) {
+                rmask[tid] = (WW <= 32) ? 0u : ~0u;                  // filled next to the window descriptors (S1)
+                if (tid < nenv) {
+                    sep[tid] = v_ep;
+                    sts[tid] = v_ts;
+                }
+            }
+            const unsigned long long fb = __ballot(fr);              // later phases test a bit
+            if (lane == 0) {
+                sfm[0] = (uint32_t)fb;
+                sfm[1] = (uint32_t)(fb >> 32);
+            }
+        }
+        slb[tid] = v_lb0;
+        slb[tid + NT] = v_lb1;
         if (g.obs_here) {   // (behind this phase's loads: their waits count these stores as younger, they do not wait for them)
 #pragma unroll 1
             for (int i = 0; i < a.z0; ++i) zero_store();
         }
         __syncthreads();
         IC3_TR(1);
+        for (int el = tid; el < nenv; el += NT) {                    // per-env 1 / (n_alive - 1) (comm.py:194-196), read at S5
+            int n_alive = 0;
+            for (int j = 0; j < N; ++j) n_alive += sact[el * N + j];
+            sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
+        }
         unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
         if (autor)
             fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
