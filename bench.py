@@ -254,6 +254,10 @@ def main():
                         'slot of the timed region is then a live transition')
     p.add_argument('--fused-obs', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_OBS', '1')),
                    help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
+    p.add_argument('--incremental-obs', type=int, default=0,
+                   help='EXPERIMENT (labelled in the output, never the headline): ic3_policy_step maintains the obs rows '
+                        'incrementally (clears what the previous step painted, paints the new entries) instead of '
+                        'zero-filling them every step; the rows are bit-identical, the HBM traffic is not')
     p.add_argument('--rccl', type=int, default=int(os.environ.get('IC3_BENCH_RCCL', '0')),
                    help='1: bring up the RCCL process group even for one rank (world_size 1) so that the timing barrier '
                         'and the MAX / SUM reductions of the N > 1 path run on device tensors over RCCL')
@@ -303,6 +307,7 @@ def main():
     a.mega_policy = bool(o.mega)
     a.fused_obs = bool(o.fused_obs)
     a.auto_reset = bool(o.auto_reset)
+    a.incremental_obs = bool(o.incremental_obs)
     T = a.max_steps
     raw_env = trainer.env.env
     live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
@@ -484,6 +489,8 @@ def main():
                        "dense_obs": not o.no_dense_obs, "overlap_obs": bool(o.overlap_obs),
                        "policy": "one launch per step (ic3_policy_step)" if mega_live else "launch chain",
                        "auto_reset": bool(o.auto_reset),
+                       "obs_rows": ("EXPERIMENT: maintained incrementally (not rewritten every step) - not the headline "
+                                    "configuration" if o.incremental_obs else "rewritten every step"),
                        "gemm": ("hand-written fp32 MFMA" if mega_live else
                                 "TunableOp-selected" if o.tune_gemm else "default heuristics")},
             "live_frac": round(live_frac, 6),

@@ -74,6 +74,7 @@ EXPORTS = {
     "ic3_env_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_void_p]),
     "ic3_env_encode_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ic3_env_set_incremental_obs": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_env_encode_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_void_p]),
     "ic3_env_snapshot": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -254,6 +254,7 @@ int ic3_env_destroy(ic3_env* env)
     (void)hipFree(env->d_err);
     (void)hipFree(env->d_stats);
     (void)hipFree(env->d_thr);
+    (void)hipFree(env->obs_rec);
     (void)hipFree(env->d_grid);
     (void)hipFree(env->d_route_off);
     (void)hipFree(env->d_route_rc);
@@ -323,6 +324,24 @@ int ic3_env_reset_to(ic3_env* env, int epoch, const int32_t* host_state, size_t 
     return 0;
 }
 
+int ic3_env_set_incremental_obs(ic3_env* env, int on)
+{
+    if (!env) return fail(-22, "ic3_env_set_incremental_obs: null handle");
+    env->painted_valid = false;
+    env->painted_obs = nullptr;
+    if (!on) {
+        if (env->obs_rec) (void)hipFree(env->obs_rec);
+        env->obs_rec = nullptr;
+        return 0;
+    }
+    if (!env->obs_rec) {
+        const int N = env->dims.N, WW = env->dims.window * env->dims.window;
+        const size_t words = env->kind == IC3_ENV_PP ? (size_t)2 * N * WW : (size_t)N + (size_t)2 * N * WW;
+        IC3_HIP(hipMalloc(&env->obs_rec, (size_t)env->dims.E * words * sizeof(int32_t)));
+    }
+    return 0;
+}
+
 int ic3_env_set_auto_reset(ic3_env* env, int max_steps)
 {
     if (!env || max_steps < 0) return fail(-22, "ic3_env_set_auto_reset: bad arguments");
@@ -334,6 +353,7 @@ int ic3_env_observe(ic3_env* env, float* obs, ic3_stream stream)
 {
     ic3::Range range_("ic3_env_observe");
     if (!env || !obs) return fail(-22, "ic3_env_observe: null argument");
+    env->touch_obs(obs);
     return env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
 }
 
@@ -341,6 +361,7 @@ int ic3_env_observe_at(ic3_env* env, const int32_t* snap, float* obs, ic3_stream
 {
     ic3::Range range_("ic3_env_observe");
     if (!env || !obs) return fail(-22, "ic3_env_observe_at: null argument");
+    env->touch_obs(obs);
     env->view = snap;
     const int rc = env->kind == IC3_ENV_PP ? pp_observe(env, obs, (hipStream_t)stream) : tj_observe(env, obs, (hipStream_t)stream);
     env->view = nullptr;

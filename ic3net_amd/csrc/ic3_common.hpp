@@ -74,6 +74,11 @@ struct ic3_env {
     int64_t resets = 0;
     int auto_max_steps = 0;    // ic3_env_set_auto_reset: > 0 = finished envs restart inside the step launch
     void *ev_start = nullptr, *ev_stop = nullptr;   // ic3_env_set_step_events: recorded by the next ic3_policy_step launch
+    // ic3_env_set_incremental_obs (opt-in experiment): per-env record of what ic3_policy_step painted into `painted_obs`
+    int32_t* obs_rec = nullptr;
+    const float* painted_obs = nullptr;
+    bool painted_valid = false;
+    void touch_obs(const float* obs) { if (obs && obs == painted_obs) painted_valid = false; }   // another writer of that buffer
     // Traffic-Junction constant tables (device + host copies)
     int32_t* d_grid = nullptr;       // [h*w] road ids
     int32_t* d_route_off = nullptr;  // [npath+1]

@@ -138,6 +138,8 @@ struct StepArgs {
     float* out;                 // [R][OT] log-probs | value
     int32_t* action;            // [nheads][R]
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
+    int32_t* obs_rec;           // incremental mode (ic3_env_set_incremental_obs): what the rows of `obs` hold painted, per env
+    int obs_incr;               // 1: `obs` still holds exactly what obs_rec describes -> clear those entries, no zero fill
     int obs_dim;                // floats per observation row
     int ntiles;                 // workgroups = tiles: n_full tiles of EPT envs, then half tiles of EPTh envs
     int n_full, EPTh;
@@ -190,6 +192,7 @@ __device__ __forceinline__ TileGeom tile_geom(const StepArgs& a, int tile_id)
     g.c_hi = (g.mis + g.onb) >> 6;
     g.zend = g.obs_here ? max(0, (64 * g.c_hi - g.mis) * 16) : 0;   // bytes of the body up to the last full chunk
     if (IC3_PS_ABL & 64) g.zend = 0;   // ablation: every zero store is issued and dropped by the range check (no HBM traffic)
+    if (a.obs_incr) g.zend = 0;        // incremental rows: nothing to zero-fill (the host also sets every slot count to 0)
     return g;
 }
 
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             if (tid < a.OT * H4) As4[(tid / H4) * LDA4 + tid % H4] = hw0;
             if (tid + NT < a.OT * H4) As4[((tid + NT) / H4) * LDA4 + (tid + NT) % H4] = hw1;
-            if (obs_here) {
+            if (obs_here && !a.obs_incr) {
 #pragma unroll 1
                 for (int i = 0; i < a.zrest; ++i) zero_store();     // obs-dominated shapes
                 // ragged chunks: chunk 0 when the body starts inside it, chunk c_hi when the body ends inside it; the
@@ -886,9 +889,24 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             __syncthreads();
             IC3_TR(16);
             float* orow0 = a.obs + g.ob0;
+            // Incremental rows (opt-in experiment, ic3_env_set_incremental_obs): the caller's buffer still holds what the
+            // previous call painted; its descriptors were recorded per env (PP: the window table, TJ: alive flags + window
+            // table).  Clear exactly those entries, then paint — instead of zero-filling 145 KB per env for ~270 entries.
             if constexpr (KIND == IC3_ENV_PP) {
                 const int2* ptab = reinterpret_cast<const int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
                 const int vocab = a.pp.dim * a.pp.dim + 4;
+                int2* rec = reinterpret_cast<int2*>(a.obs_rec) + (size_t)e0 * nsegE;
+                if (a.obs_incr) {
+                    for (int sg = tid; sg < nenv * nsegE; sg += NT) {
+                        const int2 d = rec[sg];
+                        float* cell = orow0 + (size_t)sg * vocab;
+                        cell[d.x] = 0.f;
+                        if (d.x != vocab - 2 && (d.y >> 16) != 0) cell[vocab - 2] = 0.f;
+                        if (d.x != vocab - 1 && (d.y & 0xffff) != 0) cell[vocab - 1] = 0.f;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a cleared word may be painted again by another thread
+                    __syncthreads();
+                }
                 for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
                     const int2 d = ptab[sg];
                     float* cell = orow0 + (size_t)sg * vocab;
@@ -897,12 +915,46 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                     cell[d.x] = 1.f + (d.x == vocab - 2 ? nprey : 0.f) + (d.x == vocab - 1 ? npred : 0.f);
                     if (d.x != vocab - 2 && nprey != 0.f) cell[vocab - 2] = nprey;
                     if (d.x != vocab - 1 && npred != 0.f) cell[vocab - 1] = npred;
+                    if (a.obs_rec) rec[sg] = d;
                 }
             } else if constexpr (KIND == IC3_ENV_TJ) {
                 const int obs_dim = a.obs_dim;
+                const int recw = N + 2 * nsegE;                      // per env: alive[N] | tab[N * WW] (int2)
+                if (a.obs_incr) {
+                    for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
+                        const int el = div_small(sg, 1.0f / (float)(nsegE + N)), q = sg - el * (nsegE + N);
+                        const int32_t* r = a.obs_rec + (size_t)(e0 + el) * recw;
+                        float* env_rows = orow0 + (size_t)el * N * obs_dim;
+                        if (q < N) {
+                            if (!r[q]) continue;
+                            float* row = env_rows + (size_t)q * obs_dim;
+                            row[0] = 0.f;
+                            row[1] = 0.f;
+                            if (a.tj.hdr == 4) {
+                                row[2] = 0.f;
+                                row[3] = 0.f;
+                            }
+                        } else {
+                            const int qq = q - N, car = div_small(qq, 1.0f / (float)WW), cellx = qq - car * WW;
+                            if (!r[car]) continue;
+                            const int2 d = reinterpret_cast<const int2*>(r + N)[qq];
+                            float* cell = env_rows + (size_t)car * obs_dim + a.tj.hdr + (size_t)cellx * a.tj.vocab;
+                            if (d.x >= 0) cell[d.x] = 0.f;
+                            if (d.x != a.tj.car_class && d.y != 0) cell[a.tj.car_class] = 0.f;
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
                 for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
                     const int el = div_small(sg, 1.0f / (float)(nsegE + N)), q = sg - el * (nsegE + N);
-                    tj_obs_patch(tj_tile_at(tile + el * tjw, N), a.tj, orow0 + (size_t)el * N * obs_dim, obs_dim, WW, q);
+                    const TJTile t = tj_tile_at(tile + el * tjw, N);
+                    tj_obs_patch(t, a.tj, orow0 + (size_t)el * N * obs_dim, obs_dim, WW, q);
+                    if (a.obs_rec) {
+                        int32_t* r = a.obs_rec + (size_t)(e0 + el) * recw;
+                        if (q < N) r[q] = t.sal[q];
+                        else reinterpret_cast<int2*>(r + N)[q - N] = t.tab[q - N];
+                    }
                 }
             }
         }
@@ -1265,6 +1317,15 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.gid0 = env->tj.env_id_offset;
     }
     const int tiles = plan_tiles(a, H, p, (hipStream_t)stream);
+    // incremental obs rows (opt-in): the buffer must be the one the previous call painted, untouched since
+    const bool incr = fused_obs && env->obs_rec != nullptr;
+    const bool incr_valid = incr && env->painted_valid && env->painted_obs == obs;
+    a.obs_rec = incr ? env->obs_rec : nullptr;
+    a.obs_incr = incr_valid ? 1 : 0;
+    if (incr) {
+        env->painted_obs = obs;
+        env->painted_valid = true;
+    }
     a.tile_words = tile_words;
     a.obs = fused_obs ? obs : nullptr;
     a.obs_dim = env->dims.obs_dim;
@@ -1293,7 +1354,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         // transcendentals of the cell epilogue (profiles/r03/pacing_sweep.txt).
         const bool small = per_wave <= 4 * KBv;
         int zs = 0;
-        if (fused_obs) {
+        if (fused_obs && !incr_valid) {
             const double want = small ? (double)((per_wave + KBv - 1) / KBv) : (double)per_wave * zfrac / 100.0 / KBv;
             double best = 1e30;
             for (int cand : ZS_SET) {
@@ -1310,7 +1371,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.zs = zs;
         long long left = per_wave - (long long)zs * KBv;
         auto take = [&](int want) {
-            const int n = fused_obs ? (int)std::min<long long>(std::max<long long>(left, 0), std::max(want, 0)) : 0;
+            const int n = (fused_obs && !incr_valid) ? (int)std::min<long long>(std::max<long long>(left, 0), std::max(want, 0)) : 0;
             left -= n;
             return n;
         };
@@ -1320,9 +1381,9 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.zc = take(std::min(zc_env >= 0 ? zc_env : share, H / 8));
         a.zf = take(zf_env >= 0 ? zf_env : share);
         a.zh = take(zh_env >= 0 ? zh_env : 0);
-        a.zepi = !fused_obs ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
+        a.zepi = (!fused_obs || incr_valid) ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
         left -= 32LL * a.zepi;
-        a.zrest = fused_obs ? (int)(left > 0 ? left + 1 : 0) : 0;
+        a.zrest = (fused_obs && !incr_valid) ? (int)(left > 0 ? left + 1 : 0) : 0;
     }
     {   // first-round stagger (see the kernel): per-device arrival counters, allocated once
         static const int stagger_env = getenv("IC3_PS_STAGGER") ? atoi(getenv("IC3_PS_STAGGER")) : -1;

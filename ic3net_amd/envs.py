@@ -163,6 +163,14 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(loc_table), ptr(out), ldo, H, stream()))
         return out
 
+    def set_incremental_obs(self, on=True):
+        """EXPERIMENT (ic3_env_set_incremental_obs): ic3_policy_step maintains the rows of the obs buffer it is handed
+        (clear what the previous call painted, paint the new entries) instead of zero-filling them every step.  The
+        caller promises not to write that buffer in between."""
+        self._require()
+        check(_lib.lib().ic3_env_set_incremental_obs(self._h, 1 if on else 0))
+        self.incremental_obs = bool(on)
+
     def encode_at(self, snap, weight_t, bias, out=None, loc_table=None):
         """encode() for the state held in `snap` (a snapshot() tensor; None = the live state) — ic3_env_encode_at: the
         update half re-evaluates the encoder of a past step from its state snapshot."""

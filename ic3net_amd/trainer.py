@@ -87,6 +87,9 @@ class Trainer(object):
             raw0.set_auto_reset(args.max_steps if self._auto_reset() else 0)
             self._graphs.clear()                                   # (a host kernel argument of the captured launches)
             self._episodes_played = min(self._episodes_played, 1)
+        if bool(getattr(args, 'incremental_obs', False)) != bool(getattr(raw0, 'incremental_obs', False)) \
+                and hasattr(raw0, 'set_incremental_obs'):
+            raw0.set_incremental_obs(bool(getattr(args, 'incremental_obs', False)))   # experiment, see envs.py
         if raw0 is not None and hasattr(raw0, '_h'):
             # the reset obs launch is only skipped when the coming episode will take the one-launch path again (its
             # first step writes the rows of the reset state itself): the previous episode did, and nothing that decides

@@ -127,6 +127,13 @@ int ic3_env_reset_to(ic3_env* env, int epoch, const int32_t* host_state, size_t 
  * mode treats an env whose t == 0 as an episode start (h = c = 0, no alive mask, gate 0: trainer.py:38-46, quirks
  * Q21/Q22).  max_steps = 0 (default) restores lock-step episodes (finished envs freeze until ic3_env_reset). */
 int ic3_env_set_auto_reset(ic3_env* env, int max_steps);
+/* EXPERIMENT, off by default: incremental observation rows for ic3_policy_step.  With it on, the launch records per env
+ * what it painted into the caller's obs buffer; the next launch that gets the SAME buffer — untouched since, which is the
+ * caller's promise; writes through this handle (ic3_env_observe / step / reset with that buffer) are noticed — clears
+ * exactly those entries and paints the new ones instead of zero-filling N*obs_dim floats per env.  The rows are
+ * bit-identical either way; the HBM traffic is not (a few hundred partial-line writes instead of 145 KB per PP-hard env),
+ * so bench lines measured with it are labelled and never the headline. */
+int ic3_env_set_incremental_obs(ic3_env* env, int on);
 
 /* Env.step(action) for all E envs: predator_prey_env.py:112-144 / traffic_junction_env.py:206-252.
  *   actions       [E][N] int32   the env-action head only (GymWrapper.step drops the talk head, env_wrappers.py:76-77)

@@ -334,3 +334,29 @@ def test_result_changing_environment_knobs_are_gone():
     assert run({"IC3_PS_DEBUG": "63", "IC3_PS_ZMODE": "48", "IC3_PS_SKEW": "9", "IC3_PS_WGS": "1"}) == base
     assert run({"IC3_PS_ZS": "2", "IC3_PS_ZF": "9", "IC3_PS_ZFRAC": "40", "IC3_PS_HALF": "1", "IC3_PS_ZEPI": "0",
                 "IC3_PS_STAGGER": "3", "IC3_PS_Z0": "5", "IC3_PS_Z3": "5", "IC3_PS_ZC": "4", "IC3_PS_ZH": "6"}) == base
+
+
+@pytest.mark.parametrize("workload,E", [("pp_hard", 29), ("tj_hard", 11), ("tj_medium", 16)])
+def test_incremental_obs_rows_are_the_same_rows(workload, E):
+    """EXPERIMENT ic3_env_set_incremental_obs: with it on, ic3_policy_step clears what the previous call painted into the
+    obs buffer and paints the new entries instead of zero-filling the rows — after every step of two episodes (lock-step
+    reset in between, which does not touch the buffer) the buffer equals the stand-alone obs kernel's rows of the state
+    acted on, bit for bit; a foreign write through the handle (observe into that buffer) falls back to a full rewrite."""
+    import bench
+    tr, a = bench.build_trainer(workload, E, 6, 10, 0)
+    a.max_steps = 12
+    a.incremental_obs = True
+    raw = tr.env.env
+    for ep in range(2):
+        tr.begin_episode(ep)
+        for t in range(a.max_steps):
+            from ic3net_amd import _lib
+            from ic3net_amd._lib import check, ptr, stream
+            want = torch.empty_like(raw._obs)                 # the stand-alone kernel's rows, into ANOTHER buffer
+            check(_lib.lib().ic3_env_observe_at(raw._h, None, ptr(want), stream()))
+            tr.step_episode(t)
+            assert torch.equal(raw._obs, want), (workload, ep, t)
+            if ep == 1 and t == 5:
+                raw.observe()                      # another writer of the buffer: the next step rewrites every row
+        tr.end_episode()
+    assert getattr(tr.policy_net, 'mega_steps', 0) == 2 * a.max_steps
