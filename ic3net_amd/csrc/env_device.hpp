@@ -70,6 +70,29 @@ __device__ __forceinline__ bool padded_outside(int pr, int pc, int v, int dim)
     return pr < v || pr >= v + dim || pc < v || pc >= v + dim;  // np.pad(grid, vision, OUTSIDE_CLASS) PP:184
 }
 
+// reset(): PP:146-175 = sequential rejection sampling of total = N + nprey DISTINCT cells on the injected stream
+// (draw d of (episode ep, env gid): Philox domain DOMAIN_PP_RESET).  One lane per env — the draw sequence is serial.
+// Shared by pp_reset_kernel and by the in-launch restart of pp_step_lanes (auto-reset).
+__host__ __device__ inline void pp_place_entities(int32_t* rr, int32_t* cc, int total, int dim, uint32_t seed, uint32_t gid,
+                                                  uint32_t ep)
+{
+    const uint32_t ncell = (uint32_t)(dim * dim);
+    int m = 0;
+    uint32_t d = 0;
+    while (m < total) {
+        const uint32_t k = scale24(philox_x24(seed, gid, DOMAIN_PP_RESET, ep, 0u, d), ncell);
+        ++d;
+        const int kr = (int)(k / (uint32_t)dim), kc = (int)(k % (uint32_t)dim);
+        bool dup = false;
+        for (int j = 0; j < m; ++j) dup |= (rr[j] == kr) & (cc[j] == kc);   // own earlier writes (same lane)
+        if (!dup) {
+            rr[m] = kr;
+            cc[m] = kc;
+            ++m;
+        }
+    }
+}
+
 // step: PP:112-144 = _take_action for every predator (PP:212-252), then _get_reward (PP:254-290).  Called by ALL
 // lanes of a wave (ballots); lane (e, n) with n < G, G = pow2 >= rows lanes per env, groups aligned inside the wave.
 // `act_of()` returns the env action of (e, n) — only evaluated for lanes with e < E and n < rows.
@@ -165,23 +188,8 @@ __device__ __forceinline__ void pp_step_lanes(const PPState& s, const StepOut& o
             s.ar.acc_episodes[e] += 1;
             s.ar.acc_steps[e] += t_new;
             const uint32_t ep = (uint32_t)(s.ar.episode[e] + 1);
-            const uint32_t ncell = (uint32_t)(dim * dim);
-            int32_t* rr = s.loc_r + (size_t)e * total;
-            int32_t* cc = s.loc_c + (size_t)e * total;
-            int m = 0;
-            uint32_t d = 0;
-            while (m < total) {
-                const uint32_t k = scale24(philox_x24(s.ar.seed, s.ar.gid0 + (uint32_t)e, DOMAIN_PP_RESET, ep, 0u, d), ncell);
-                ++d;
-                const int kr = (int)(k / (uint32_t)dim), kc = (int)(k % (uint32_t)dim);
-                bool dup = false;
-                for (int j = 0; j < m; ++j) dup |= (rr[j] == kr) & (cc[j] == kc);
-                if (!dup) {
-                    rr[m] = kr;
-                    cc[m] = kc;
-                    ++m;
-                }
-            }
+            pp_place_entities(s.loc_r + (size_t)e * total, s.loc_c + (size_t)e * total, total, dim, s.ar.seed,
+                              s.ar.gid0 + (uint32_t)e, ep);
             for (int i = 0; i < N; ++i) s.reached[(size_t)e * N + i] = 0;
             s.over[e] = 0;
             s.success[e] = 0;
@@ -205,6 +213,17 @@ __device__ __forceinline__ int2 pp_tab_entry(const int32_t* sr, const int32_t* s
     for (int p = 0; p < N; ++p) npred += (sr[p] == gr) & (sc[p] == gc);             // PP:191-192
     for (int p = N; p < total; ++p) npr += (sr[p] == gr) & (sc[p] == gc);           // PP:194-195
     return make_int2(id, npred | (npr << 16));
+}
+
+// The non-zero entries of one window cell of the observation (PP:177-210): `cell` = first float of the cell's `vocab`
+// channels, d = its pp_tab_entry.  Channels: d.x one-hot (grid id or OUTSIDE), vocab-2 #prey, vocab-1 #predators (the
+// counts ADD to the one-hot when they share a channel, quirk Q3).  The rest of the cell is zero.
+__device__ __forceinline__ void pp_obs_patch(float* __restrict__ cell, int2 d, int vocab)
+{
+    const float npred = (float)(d.y & 0xffff), nprey = (float)(d.y >> 16);
+    cell[d.x] = 1.f + (d.x == vocab - 2 ? nprey : 0.f) + (d.x == vocab - 1 ? npred : 0.f);
+    if (d.x != vocab - 2 && nprey != 0.f) cell[vocab - 2] = nprey;
+    if (d.x != vocab - 1 && npred != 0.f) cell[vocab - 1] = npred;
 }
 
 // A table of float4 rows (H4 float4s each) behind a plain pointer or a buffer descriptor (32-bit offsets on the lane,
@@ -296,6 +315,20 @@ struct TJState {
     int h, w, v, vocab, outside, car_class, npath, hdr;
     uint32_t seed, gid0;
 };
+
+// reset() of one car slot (TJ:160-190); shared by tj_reset_kernel and the in-launch restart of tj_step_lanes
+__host__ __device__ inline void tj_reset_car(int32_t* alive, int32_t* wait, int32_t* loc_r, int32_t* loc_c, int32_t* last_act,
+                                             int32_t* route_loc, int32_t* route_id, int32_t* completed, size_t i)
+{
+    alive[i] = 0;       // TJ:171
+    wait[i] = 0;        // TJ:172
+    loc_r[i] = 0;       // TJ:187
+    loc_c[i] = 0;
+    last_act[i] = 0;    // TJ:188
+    route_loc[i] = -1;  // TJ:190
+    route_id[i] = -1;   // TJ:178
+    completed[i] = 0;
+}
 
 // step: TJ:206-252 = _take_action (TJ:540-581), _add_cars (TJ:369-393), _get_reward (TJ:585-595).  Called by all lanes
 // of a wave; G = pow2 >= max(N, 8) lanes per env.
@@ -405,14 +438,7 @@ __device__ __forceinline__ void tj_step_lanes(const TJState& s, const StepOut& o
         s.route_id[i] = rid;
         s.completed[i] = completed;
     } else {                                                              // reset(): TJ:160-190
-        s.alive[i] = 0;
-        s.wait[i] = 0;
-        s.loc_r[i] = 0;
-        s.loc_c[i] = 0;
-        s.last_act[i] = 0;
-        s.route_loc[i] = -1;
-        s.route_id[i] = -1;
-        s.completed[i] = 0;
+        tj_reset_car(s.alive, s.wait, s.loc_r, s.loc_c, s.last_act, s.route_loc, s.route_id, s.completed, i);
     }
     if (n == 0) {
         if (!restart) {

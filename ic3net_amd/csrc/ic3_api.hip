@@ -6,6 +6,7 @@
 #include <new>
 
 #include "ic3_common.hpp"
+#include "tj_curriculum.hpp"
 
 namespace ic3 {
 
@@ -269,19 +270,6 @@ int ic3_env_dims(const ic3_env* env, ic3_dims* out)
     return 0;
 }
 
-// traffic_junction_env.py:196-200 gating + :620-626 curriculum (host-side scalars; every env of the
-// handle sees the same epoch sequence, so they share one add_rate exactly like N reference instances).
-static double py_float_floordiv(double vx, double wx)
-{
-    double mod = fmod(vx, wx);
-    double div = (vx - mod) / wx;
-    if (mod != 0.0 && ((wx < 0) != (mod < 0))) div -= 1.0;
-    if (div == 0.0) return copysign(0.0, vx / wx);
-    double fl = floor(div);
-    if (div - fl > 0.5) fl += 1.0;
-    return fl;
-}
-
 int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
 {
     ic3::Range range_("ic3_env_reset");
@@ -291,16 +279,9 @@ int ic3_env_reset(ic3_env* env, int epoch, float* obs, ic3_stream stream)
     if (env->kind == IC3_ENV_PP) {
         rc = pp_reset(env, s);
     } else {
-        const ic3_tj_cfg& c = env->tj;
-        const double epoch_range = c.curr_end - c.curr_start, rate_range = c.add_rate_max - c.add_rate_min;
-        if (epoch >= 0 && epoch_range > 0 && rate_range > 0 && (double)epoch > env->epoch_last_update) {
-            if (c.curr_start <= (double)epoch && (double)epoch < c.curr_end) {
-                const double step = rate_range / epoch_range;
-                env->exact_rate = env->exact_rate + step;
-                env->add_rate = 0.01 * py_float_floordiv(env->exact_rate, 0.01);  // Python float `//`, quirk Q16
-            }
-            env->epoch_last_update = (double)epoch;
-        }
+        const ic3_tj_cfg& c = env->tj;   // curriculum: traffic_junction_env.py:196-200,620-626 (tj_curriculum.hpp)
+        tj_curriculum_update(c.add_rate_min, c.add_rate_max, c.curr_start, c.curr_end, epoch, env->exact_rate, env->add_rate,
+                             env->epoch_last_update);
         rc = tj_reset(env, s);
     }
     if (rc) return rc;

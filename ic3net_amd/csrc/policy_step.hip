@@ -909,12 +909,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
                 for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
                     const int2 d = ptab[sg];
-                    float* cell = orow0 + (size_t)sg * vocab;
-                    const float npred = (float)(d.y & 0xffff), nprey = (float)(d.y >> 16);
-                    // channels: d.x one-hot (grid id or OUTSIDE), vocab-2 #prey, vocab-1 #predators (counts add, quirk Q3)
-                    cell[d.x] = 1.f + (d.x == vocab - 2 ? nprey : 0.f) + (d.x == vocab - 1 ? npred : 0.f);
-                    if (d.x != vocab - 2 && nprey != 0.f) cell[vocab - 2] = nprey;
-                    if (d.x != vocab - 1 && npred != 0.f) cell[vocab - 1] = npred;
+                    pp_obs_patch(orow0 + (size_t)sg * vocab, d, vocab);   // (env_device.hpp)
                     if (a.obs_rec) rec[sg] = d;
                 }
             } else if constexpr (KIND == IC3_ENV_TJ) {

@@ -27,24 +27,8 @@ __global__ __launch_bounds__(256) void pp_reset_kernel(int32_t* __restrict__ loc
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int total = N + nprey;
-    const uint32_t ncell = (uint32_t)(dim * dim);
     const uint32_t ep = (uint32_t)(episode[e] + 1);
-    int32_t* r = loc_r + (size_t)e * total;
-    int32_t* c = loc_c + (size_t)e * total;
-    int n = 0;
-    uint32_t d = 0;
-    while (n < total) {
-        const uint32_t k = scale24(philox_x24(seed, gid0 + (uint32_t)e, DOMAIN_PP_RESET, ep, 0u, d), ncell);
-        ++d;
-        const int kr = (int)(k / (uint32_t)dim), kc = (int)(k % (uint32_t)dim);
-        bool dup = false;
-        for (int j = 0; j < n; ++j) dup |= (r[j] == kr) & (c[j] == kc);  // own earlier writes (same thread)
-        if (!dup) {
-            r[n] = kr;
-            c[n] = kc;
-            ++n;
-        }
-    }
+    pp_place_entities(loc_r + (size_t)e * total, loc_c + (size_t)e * total, total, dim, seed, gid0 + (uint32_t)e, ep);
     for (int i = 0; i < N; ++i) reached[(size_t)e * N + i] = 0;  // PP:155
     over[e] = 0;                                                  // PP:154
     success[e] = 0;

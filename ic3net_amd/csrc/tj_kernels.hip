@@ -8,6 +8,7 @@
 
 #include "enc_bwd.hpp"
 #include "env_device.hpp"
+#include "tj_curriculum.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -21,16 +22,7 @@ __global__ __launch_bounds__(256) void tj_reset_kernel(int32_t* __restrict__ ali
                                                        int32_t* __restrict__ tstep, int E, int N)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < E * N) {
-        alive[i] = 0;       // TJ:171
-        wait[i] = 0;        // TJ:172
-        loc_r[i] = 0;       // TJ:187
-        loc_c[i] = 0;
-        last_act[i] = 0;    // TJ:188
-        route_loc[i] = -1;  // TJ:190
-        route_id[i] = -1;   // TJ:178
-        completed[i] = 0;
-    }
+    if (i < E * N) tj_reset_car(alive, wait, loc_r, loc_c, last_act, route_loc, route_id, completed, (size_t)i);
     if (i < E) {
         cars[i] = 0;    // TJ:173
         failed[i] = 0;  // TJ:169
@@ -482,11 +474,7 @@ __global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
 int tj_reset(ic3_env* env, hipStream_t s)
 {
     const ic3_tj_cfg& c = env->tj;
-    // u <= add_rate  <=>  x24 <= floor(add_rate * 2^24)   (exact: power-of-two scaling in fp64)
-    double thr_d = __builtin_floor(env->add_rate * 16777216.0);
-    if (thr_d > 16777216.0) thr_d = 16777216.0;
-    if (thr_d < -1.0) thr_d = -1.0;
-    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, env->d_thr, (int32_t)thr_d);
+    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, env->d_thr, (int32_t)tj_rate_threshold(env->add_rate));
     const int n = c.E * c.N;
     hipLaunchKernelGGL(tj_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, env->f("alive"), env->f("wait"),
                        env->f("loc_r"), env->f("loc_c"), env->f("last_act"), env->f("route_loc"), env->f("route_id"),

@@ -1,0 +1,202 @@
+"""CPU: the PRODUCT's device functions compiled for the host (tests/host/) against golden vectors captured from the reference.
+
+ic3net_amd/csrc/env_device.hpp holds the Predator-Prey / Traffic-Junction step, window-table and observation-patch bodies that
+every launch geometry of libic3rollout runs.  tests/host/ic3_host_build.cpp compiles that header with a stand-in HIP runtime
+(64 lockstep host threads per wavefront) so the same code can be driven over the reference's own trajectories without a GPU,
+and — with IC3_HOST_ASAN=1 (tools/host_asan.sh) — under AddressSanitizer + UndefinedBehaviorSanitizer.
+Integer state bit-exact; rewards as float32(reference float64) bit-exact; observations bit-exact."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from golden_util import load, SparseObs, PP_FIXTURES, TJ_FIXTURES
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ASAN = os.environ.get("IC3_HOST_ASAN", "0") == "1"
+i32p = ctypes.POINTER(ctypes.c_int32)
+f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def hb():
+    target, so = ("asan", "libic3host_asan.so") if ASAN else ("all", "libic3host.so")
+    r = subprocess.run(["make", "-C", os.path.join(HERE, "host"), target], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lib = ctypes.CDLL(os.path.join(HERE, "host", so))
+    lib.hb_pp_create.restype = ctypes.c_void_p
+    lib.hb_pp_create.argtypes = [ctypes.c_int] * 7 + [ctypes.c_uint32] * 2
+    lib.hb_tj_create.restype = ctypes.c_void_p
+    lib.hb_tj_create.argtypes = [ctypes.c_int] * 5 + [ctypes.c_double] * 4 + [ctypes.c_uint32] * 2
+    for name in ("hb_pp_destroy", "hb_pp_reset", "hb_tj_destroy"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+        getattr(lib, name).restype = None
+    lib.hb_pp_step.argtypes = [ctypes.c_void_p, i32p, f32p, i32p]
+    lib.hb_pp_obs.argtypes = [ctypes.c_void_p, f32p]
+    lib.hb_pp_state.argtypes = [ctypes.c_void_p, i32p, i32p, i32p]
+    lib.hb_tj_obs_dim.argtypes = [ctypes.c_void_p]
+    lib.hb_tj_reset.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.hb_tj_step.argtypes = [ctypes.c_void_p, i32p, f32p, i32p, i32p, i32p]
+    lib.hb_tj_obs.argtypes = [ctypes.c_void_p, f32p]
+    lib.hb_tj_state.argtypes = [ctypes.c_void_p, i32p, i32p, ctypes.POINTER(ctypes.c_double)]
+    return lib
+
+
+class PP(object):
+    def __init__(self, lib, N, dim, vision, mode, stay, ec, seed, gid):
+        self.lib, self.N, self.total, self.rows = lib, N, N + 1, N + (1 if ec else 0)
+        self.obs_dim = (2 * vision + 1) ** 2 * (dim * dim + 4)
+        self.h = lib.hb_pp_create(N, 1, dim, vision, mode, int(stay), int(ec), seed, gid)
+        assert self.h
+
+    def close(self):
+        self.lib.hb_pp_destroy(self.h)
+
+    def reset(self):
+        self.lib.hb_pp_reset(self.h)
+        return self.obs()
+
+    def obs(self):
+        out = np.full((self.rows, self.obs_dim), np.nan, np.float32)
+        self.lib.hb_pp_obs(self.h, _p(out, f32p))
+        return out
+
+    def state(self):
+        loc = np.zeros((self.total, 2), np.int32)
+        reached = np.zeros(self.N, np.int32)
+        sc = np.zeros(4, np.int32)
+        self.lib.hb_pp_state(self.h, _p(loc, i32p), _p(reached, i32p), _p(sc, i32p))
+        return loc, reached, dict(over=int(sc[0]), success=int(sc[1]), episode=int(sc[2]), t=int(sc[3]))
+
+    def step(self, act):
+        act = np.ascontiguousarray(act, np.int32)
+        assert act.size == self.rows
+        rew = np.full(self.rows, np.nan, np.float32)
+        done = np.full(1, -1, np.int32)
+        err = self.lib.hb_pp_step(self.h, _p(act, i32p), _p(rew, f32p), _p(done, i32p))
+        return self.obs(), rew, int(done[0]), err
+
+
+@pytest.mark.parametrize("name", PP_FIXTURES)
+def test_pp_device_functions_on_the_host_match_reference_golden(hb, name):
+    fx = load(name)
+    N, dim, vision, mode, T, no_stay = [int(x) for x in fx["cfg"]]
+    nenv, nep = fx["nsteps"].shape
+    if ASAN:
+        nenv = min(nenv, 2)
+    ec = bool(int(fx["enemy_comm"]))
+    sp = SparseObs(fx["obs_coo"], N + (1 if ec else 0), int(fx["obs_dim"]))
+    for e in range(nenv):
+        env = PP(hb, N, dim, vision, mode, not no_stay, ec, int(fx["seed"]), int(fx["env_gid0"]) + e)
+        assert env.obs_dim == int(fx["obs_dim"])
+        for ep in range(nep):
+            obs = env.reset()
+            loc, reached, sc = env.state()
+            np.testing.assert_array_equal(loc, fx["init_loc"][e, ep])
+            np.testing.assert_array_equal(obs, sp.dense(e, ep, 0))
+            n = int(fx["nsteps"][e, ep])
+            for t in range(n):
+                obs, rew, done, err = env.step(fx["actions"][e, ep, t][:env.rows])
+                assert err == 0
+                loc, reached, sc = env.state()
+                np.testing.assert_array_equal(loc, fx["loc"][e, ep, t])
+                np.testing.assert_array_equal(reached, fx["reached"][e, ep, t])
+                np.testing.assert_array_equal(rew, fx["reward"][e, ep, t].astype(np.float32))
+                assert done == int(fx["done"][e, ep, t])
+                if fx["success"][e, ep, t] >= 0:
+                    assert sc["success"] == fx["success"][e, ep, t]
+                np.testing.assert_array_equal(obs, sp.dense(e, ep, t + 1))
+            if fx["done"][e, ep, n - 1]:     # frozen after done (the reference raises RuntimeError here)
+                obs2, rew, done, err = env.step(fx["actions"][e, ep, n - 1][:env.rows])
+                assert done == 1 and not rew.any()
+                np.testing.assert_array_equal(env.state()[0], loc)
+        env.close()
+
+
+def test_pp_bad_action_sets_the_error_flag(hb):
+    env = PP(hb, 3, 5, 1, 0, True, False, 1, 0)
+    env.reset()
+    assert env.step([0, 1, 2])[3] == 0
+    assert env.step([0, 5, 2])[3] == 0          # predator_prey_env.py:137 asserts `<= naction` (quirk Q2): 5 passes
+    assert env.step([0, 6, 2])[3] != 0
+    env.close()
+
+
+class TJ(object):
+    def __init__(self, lib, N, dim, vision, diff, scalar, rmin, rmax, cs, ce, seed, gid):
+        self.lib, self.N = lib, N
+        self.h = lib.hb_tj_create(N, dim, vision, diff, int(scalar), rmin, rmax, cs, ce, seed, gid)
+        assert self.h
+        self.obs_dim = lib.hb_tj_obs_dim(self.h)
+
+    def close(self):
+        self.lib.hb_tj_destroy(self.h)
+
+    def obs(self):
+        out = np.full((self.N, self.obs_dim), np.nan, np.float32)
+        self.lib.hb_tj_obs(self.h, _p(out, f32p))
+        return out
+
+    def reset(self, epoch):
+        self.lib.hb_tj_reset(self.h, epoch)
+        return self.obs()
+
+    def state(self):
+        cars = np.zeros((8, self.N), np.int32)
+        sc = np.zeros(5, np.int32)
+        rate = ctypes.c_double(0)
+        self.lib.hb_tj_state(self.h, _p(cars, i32p), _p(sc, i32p), ctypes.byref(rate))
+        st = dict(zip(("alive", "wait", "loc_r", "loc_c", "last_act", "route_loc", "route_id", "is_completed"), cars))
+        st["loc"] = np.stack([st["loc_r"], st["loc_c"]], -1)
+        st.update(cars_in_sys=int(sc[0]), has_failed=int(sc[1]), over=int(sc[2]), episode=int(sc[3]), t=int(sc[4]),
+                  add_rate=rate.value)
+        return st
+
+    def step(self, act):
+        act = np.ascontiguousarray(act, np.int32)
+        rew = np.full(self.N, np.nan, np.float32)
+        done = np.full(1, -1, np.int32)
+        alive = np.full(self.N, -1, np.int32)
+        comp = np.full(self.N, -1, np.int32)
+        err = self.lib.hb_tj_step(self.h, _p(act, i32p), _p(rew, f32p), _p(done, i32p), _p(alive, i32p), _p(comp, i32p))
+        return self.obs(), rew, int(done[0]), alive, comp, err
+
+
+@pytest.mark.parametrize("name", TJ_FIXTURES)
+def test_tj_device_functions_on_the_host_match_reference_golden(hb, name):
+    fx = load(name)
+    N, dim, vision, diff, T = [int(x) for x in fx["cfg"]]
+    nenv, nep = fx["epochs"].shape
+    if ASAN:
+        nenv, nep = min(nenv, 2), min(nep, 2)
+    sp = SparseObs(fx["obs_coo"], N, int(fx["obs_dim"]))
+    cur = fx["curriculum"]
+    has_curr = bool(cur[3] > cur[2])
+    rates = (float(cur[0]), float(cur[1]), float(cur[2]), float(cur[3])) if has_curr else \
+        (float(fx["add_rate"]), float(fx["add_rate"]), 0.0, 0.0)
+    scalar = "scalar" in fx.files and int(fx["scalar"])
+    for e in range(nenv):
+        env = TJ(hb, N, dim, vision, diff, scalar, *rates, int(fx["seed"]), int(fx["env_gid0"]) + e)
+        assert env.obs_dim == int(fx["obs_dim"])
+        for ep in range(nep):
+            obs = env.reset(int(fx["epochs"][e, ep]))
+            assert not obs.any()
+            for t in range(T):
+                obs, rew, done, alive, comp, err = env.step(fx["actions"][e, ep, t])
+                assert err == 0 and done == 0
+                st = env.state()
+                for k in ("alive", "wait", "loc", "last_act", "route_loc", "route_id", "is_completed", "cars_in_sys",
+                          "has_failed"):
+                    np.testing.assert_array_equal(st[k], fx[k][e, ep, t], err_msg="%s ep=%d t=%d" % (k, ep, t))
+                np.testing.assert_array_equal(alive, fx["alive"][e, ep, t])
+                np.testing.assert_array_equal(comp, fx["is_completed"][e, ep, t])
+                np.testing.assert_array_equal(rew, fx["reward"][e, ep, t].astype(np.float32))
+                assert st["add_rate"] == fx["add_rate_seen"][e, ep, t]
+                np.testing.assert_array_equal(obs, sp.dense(e, ep, t + 1))
+        env.close()
