@@ -133,10 +133,16 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     mask_zero = bool(args.comm_mask_zero)
     w_cat_t = fc['w_cat_t']                                               # (2H, 4H) = [W_ih | W_hh]^T
     z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    xh, comm, gates, dgates = z(R, 2 * H), z(E, N, H), z(R, 4 * H), z(R, 4 * H)   # xh = [inp | h_{t-1}]
+    xh, comm, dgates = z(R, 2 * H), z(E, N, H), z(R, 4 * H)   # xh = [inp | h_{t-1}]
     dxh, dcomm, dcomm_b, dh = z(R, 2 * H), z(R, H), z(E, N, H), z(R, H)           # dxh = [d inp | d h_{t-1}]
     inp, dinp = xh[:, :H], dxh[:, :H]
-    bias_parts, bsum = z(ops.LSTM_BWD_MAX_PARTIALS, 4 * H), z(4 * H)
+    # gate recompute + cell backward in one launch when the packed gate weights of the rollout kernel exist (hid 64/128/256);
+    # its bias partials accumulate over the episode's steps and are reduced once, behind the loop
+    fused_gates = fc.get('ps_l_wp') is not None and ops.lstm_gates_backward_supported(H)
+    if fused_gates:
+        bias_parts = torch.zeros(((R + 63) // 64, 4 * H), dtype=torch.float32, device=dev)
+    else:
+        gates, bias_parts, bsum = z(R, 4 * H), z(ops.LSTM_BWD_MAX_PARTIALS, 4 * H), z(4 * H)
     # the weight gradient dgates^T . [inp | h] has K = R: as NB products over row blocks (batched, then summed) the
     # library fills the chip (tools/exp/microbench_bptt_gemms.py: 118 instead of 83 TFLOP/s at R = 81920)
     NB = 8 if R % 8 == 0 and R >= 8192 else 1
@@ -159,15 +165,19 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         else:
             ops.comm_masked_mean_raw(h_prev.view(E, N, H), alive, gate, mode_avg, True, out=comm)
             inp.addmm_(comm.view(R, H), fc['c_wt'])
-        torch.addmm(fc['b_cat'], xh, w_cat_t, out=gates)                  # one K = 2H product, as in the rollout
+        if not fused_gates:
+            torch.addmm(fc['b_cat'], xh, w_cat_t, out=gates)              # one K = 2H product, as in the rollout
         # ---- heads (comm.py:228,239) -> LSTM cell
         d = d_out[t]
         torch.addmm(dh_rec, d, fc['w_heads'], out=dh)
         acc['w_heads'].addmm_(d.t(), h_t)
         acc['b_heads'].add_(d.sum(0))
-        parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)   # dc_rec <- dL/dc_{t-1}
-        torch.sum(parts, 0, out=bsum)
-        acc['b_cat'].add_(bsum)
+        if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
+            ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True)
+        else:
+            parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)
+            torch.sum(parts, 0, out=bsum)
+            acc['b_cat'].add_(bsum)
         # ---- [W_ih | W_hh] (torch.nn.LSTMCell): weight gradient and input gradient, one product each
         if NB > 1:                                                        # acc_t (2H, 4H) += sum_b xh_b^T . dgates_b
             torch.bmm(xh.view(NB, R // NB, 2 * H).transpose(1, 2), dgates.view(NB, R // NB, 4 * H), out=wpart)
@@ -186,6 +196,8 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         dwt, db = raw.encode_backward(dinp, rec.snaps[t], want_bias=True)    # db = sum of the d inp rows: both biases
         acc['wt'].add_(dwt)
         acc['enc_bias'].add_(db)
+    if fused_gates:
+        acc['b_cat'].add_(bias_parts.sum(0))
 
 
 def new_accumulators(net):

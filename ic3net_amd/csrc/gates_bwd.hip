@@ -1,0 +1,237 @@
+// gates_bwd.hip — update half (trainer.py:128-225 through torch.nn.LSTMCell's backward): the gate pre-activations of one
+// recorded step are RE-COMPUTED ([inp | h_prev] . [W_ih | W_hh]^T + b, comm.py:215) and turned into their gradient in the
+// same launch — ic3_lstm_gates_backward.
+//
+// What it replaces in ic3net_amd/bptt.py: a library GEMM writing gates (R x 4H: 168 MB at PP-hard E = 8192), the pointwise
+// ic3_lstm_cell_backward reading them back, and a reduction over its bias partials: 284 + 78 + 26 us per step there.
+// Here a workgroup owns 64 rows: their [inp | h_prev] rows go to LDS once (the A operand, as in policy_step_kernel), the
+// 2H x 4H weights stream from L2 in the k-major float4-over-the-four-gates layout of ic3_policy_pack through an 8-deep
+// register ring, v_mfma_f32_32x32x2_f32 accumulates all four gates of a (row, hidden column) in one lane — exact fp32 —
+// and the epilogue applies the cell's derivative with c_prev, dL/dh, dL/dc loaded straight into that lane: the
+// pre-activations never exist in memory.  Bound: MFMA (2 * R * 2H * 4H flop / 157.3 TFLOP/s = 137 us at R = 81920,
+// H = 128); HBM traffic per row: 2H + 3H floats in, 4H + H out (5 KB at H = 128 -> 0.42 GB per call, 52 us at 8 TB/s,
+// overlapped by the second workgroup of the CU).
+//
+// Layouts: accumulator register `reg` of row tile rt <-> tile row 32 rt + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5),
+// hidden column 32 wave + (lane & 31); gate order i, f, g, o (torch.nn.LSTMCell).  Rows past R read as zeros through the
+// buffer descriptors' range check (their gradient is exactly 0) and their stores are dropped by it.
+#include <hip/hip_runtime.h>
+
+#include "ic3_common.hpp"
+
+namespace ic3 {
+
+typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
+typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int gb_u32x4 __attribute__((ext_vector_type(4)));
+
+struct GatesBwdArgs {
+    const float* xh;       // [R][ldx] = [inp | h_prev]
+    const float* wq;       // ic3_policy_pack's lstm_wp: Wq[k][c] = float4 over the four gates
+    const float* bias;     // [4H] b_ih + b_hh
+    const float* c_prev;   // [R][H]
+    const float* dh;       // [R][H] dL/dh_t
+    const float* dc;       // [R][H] dL/dc_t arriving from step t + 1, or null (zeros)
+    float* dgates;         // [R][4H]
+    float* dc_prev;        // [R][H] (may be `dc`)
+    float* dbias;          // [tiles][4H] column sums of dgates per workgroup, or null
+    int ldx, R, accumulate;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gb_rsrc(const void* base, long long bytes)
+{
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ gb_f32x4 gb_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(gb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float gb_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void gb_store1(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+
+template <int H>
+__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kernel(const GatesBwdArgs a)
+{
+    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, KB = K / 8, K4 = K / 4, RING = 8;
+    static_assert(KB % 2 == 0 && KB >= 4, "K / 8 must be even");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                                      // [64][LDA]
+    gb_f32x4* const As4 = reinterpret_cast<gb_f32x4*>(smem);
+    float* const slb = As + 64 * LDA;                            // [4H]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int col = 32 * w + li;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int rows = (int)((a.R - r0) < 64 ? (a.R - r0) : 64);
+
+    // ---- A tile: 64 rows of [inp | h_prev] -> LDS (all loads issued, then the LDS writes) ------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t rx = gb_rsrc(a.xh + r0 * a.ldx, ((long long)(rows - 1) * a.ldx + K) * 4);
+        constexpr int PER = 64 * K4 / NT;                        // float4 per thread (16)
+        gb_f32x4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * NT, row = idx / K4, c4 = idx - row * K4;
+            v[i] = gb_load4(rx, (row * a.ldx + 4 * c4) * 4, 0);
+        }
+        if (tid < H) reinterpret_cast<gb_f32x4*>(slb)[tid] = reinterpret_cast<const gb_f32x4*>(a.bias)[tid];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * NT, row = idx / K4, c4 = idx - row * K4;
+            As4[row * LDA4 + c4] = v[i];
+        }
+    }
+    // ---- c_prev of this lane's 32 (row, column) elements: requested now, used behind the gate loop ----------------------
+    const int voff = (4 * lh * H + col) * 4;
+    float cold[2][16];
+    {
+        const __amdgpu_buffer_rsrc_t rc = gb_rsrc(a.c_prev + r0 * H, (long long)rows * H * 4);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                cold[rt][reg] = gb_load1(rc, voff, (32 * rt + (reg & 3) + 8 * (reg >> 2)) * H * 4);
+    }
+    gb_f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
+    // ---- gates = [inp | h] . [W_ih | W_hh]^T: k = 8 kb + 4 lh + j (A fragment and B slot agree) --------------------------
+    const __amdgpu_buffer_rsrc_t rgw = gb_rsrc(a.wq, (long long)K * 4 * H * 4);
+    const int glane = (4 * lh * H + col) * 16;
+    auto wq = [&](int kb, int j) { return gb_load4(rgw, glane, (8 * kb + j) * (H * 16)); };
+    gb_f32x4 wk[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
+    __syncthreads();
+    auto block = [&](auto sb_c, auto refill_c, int kb) {
+        constexpr int SB = decltype(sb_c)::value;
+        constexpr bool REFILL = decltype(refill_c)::value;
+        const gb_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+        const gb_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) {
+                acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], wk[SB + j][gt], acc[0][gt], 0, 0, 0);
+                acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], wk[SB + j][gt], acc[1][gt], 0, 0, 0);
+            }
+            if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    constexpr std::integral_constant<int, 0> s0{};
+    constexpr std::integral_constant<int, 4> s1{};
+#pragma unroll 1
+    for (int kb = 0; kb < KB - 2; kb += 2) {
+        block(s0, std::true_type{}, kb);
+        block(s1, std::true_type{}, kb + 1);
+    }
+    block(s0, std::false_type{}, KB - 2);
+    block(s1, std::false_type{}, KB - 1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the cell's derivative (torch.nn.LSTMCell): c' = f c + i g, h' = o tanh(c') -----------------------------------------
+    const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
+    const long long nrec = (long long)rows * H * 4;
+    const __amdgpu_buffer_rsrc_t rdh = gb_rsrc(a.dh + r0 * H, nrec);
+    const __amdgpu_buffer_rsrc_t rdc = gb_rsrc(a.dc ? a.dc + r0 * H : a.dh, a.dc ? nrec : 0);   // null: every load reads 0
+    const __amdgpu_buffer_rsrc_t rdp = gb_rsrc(a.dc_prev + r0 * H, nrec);
+    const __amdgpu_buffer_rsrc_t rdg = gb_rsrc(a.dgates + r0 * 4 * H, 4 * nrec);
+    const int goff = (4 * lh * 4 * H + col) * 4;
+    float si = 0.f, sf = 0.f, sg = 0.f, so = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        float dhv[16], dcv[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+            dhv[reg] = gb_load1(rdh, voff, lc * H * 4);
+            dcv[reg] = gb_load1(rdc, voff, lc * H * 4);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+            const float i = fast_sigmoid(acc[rt][0][reg] + bi), f = fast_sigmoid(acc[rt][1][reg] + bf);
+            const float gt = fast_tanh(acc[rt][2][reg] + bg), o = fast_sigmoid(acc[rt][3][reg] + bo);
+            const float c0 = cold[rt][reg];
+            const float tc = fast_tanh(f * c0 + i * gt);
+            const float dct = dcv[reg] + dhv[reg] * o * (1.0f - tc * tc);
+            const float di = dct * gt * i * (1.0f - i), df = dct * c0 * f * (1.0f - f);
+            const float dg = dct * i * (1.0f - gt * gt), dO = dhv[reg] * tc * o * (1.0f - o);
+            gb_store1(di, rdg, goff, lc * 4 * H * 4);
+            gb_store1(df, rdg, goff, lc * 4 * H * 4 + H * 4);
+            gb_store1(dg, rdg, goff, lc * 4 * H * 4 + 2 * H * 4);
+            gb_store1(dO, rdg, goff, lc * 4 * H * 4 + 3 * H * 4);
+            gb_store1(dct * f, rdp, voff, lc * H * 4);
+            si += di;
+            sf += df;
+            sg += dg;
+            so += dO;
+        }
+    }
+    if (a.dbias) {                                               // column sums over the tile's 64 rows: the two lane halves
+        si += __shfl_xor(si, 32);
+        sf += __shfl_xor(sf, 32);
+        sg += __shfl_xor(sg, 32);
+        so += __shfl_xor(so, 32);
+        if (lh == 0) {
+            float* d = a.dbias + (size_t)blockIdx.x * 4 * H + col;
+            if (a.accumulate) {
+                d[0] += si;
+                d[H] += sf;
+                d[2 * H] += sg;
+                d[3 * H] += so;
+            } else {
+                d[0] = si;
+                d[H] = sf;
+                d[2 * H] = sg;
+                d[3 * H] = so;
+            }
+        }
+    }
+}
+
+}  // namespace ic3
+
+extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H == 128 || H == 256; }
+
+extern "C" int ic3_lstm_gates_backward(const float* xh, int ldx, const float* lstm_wp, const float* bias, const float* c_prev,
+                                       const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
+                                       int accumulate, int R, int H, ic3_stream stream)
+{
+    using namespace ic3;
+    if (!xh || !lstm_wp || !bias || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
+        return fail(-22, "ic3_lstm_gates_backward: null argument");
+    if (!ic3_lstm_gates_backward_supported(H)) return fail(-38, "ic3_lstm_gates_backward: needs hid_size 64 / 128 / 256");
+    if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
+    if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
+        return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
+    const GatesBwdArgs a{ xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate };
+    const int tiles = (R + 63) / 64;
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define IC3_GB(h)                                                                                                       \
+    case h:                                                                                                             \
+        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<h>),                            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   /* per device: every call */ \
+        hipLaunchKernelGGL(lstm_gates_bwd_kernel<h>, dim3(tiles), dim3(2 * h), lds, s, a);                              \
+        break;
+    switch (H) {
+        IC3_GB(64)
+        IC3_GB(128)
+        IC3_GB(256)
+    }
+#undef IC3_GB
+    IC3_HIP(hipGetLastError());
+    return tiles;   // rows of dbias_partials written
+}

@@ -1122,9 +1122,9 @@ static void calibrate_tile_costs(const ic3_policy* p, int N, int cus, hipStream_
             tc.measured = true;
         }
     }
-    if (e0) hipEventDestroy(e0);
-    if (e1) hipEventDestroy(e1);
-    hipFree(scratch);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
     (void)EPTh;
 }
 

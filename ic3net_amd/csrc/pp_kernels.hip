@@ -252,8 +252,36 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_kernel(const int32_t* __res
     for (int i = threadIdx.x; i < (nslots + 1) * H; i += blockDim.x) dst[i] = Dl[i];
 }
 
+// Stage 1, row-parallel form (enc_bwd.hpp): slot 2*cell + 0 / 1 = predators / prey seen in window cell `cell`.
+__global__ __launch_bounds__(256) void pp_encode_bwd_rows_kernel(const int32_t* __restrict__ loc_r,
+                                                                 const int32_t* __restrict__ loc_c,
+                                                                 const float* __restrict__ g, int ldg,
+                                                                 float* __restrict__ Ppart, float* __restrict__ Dpart, int E,
+                                                                 int N, int nprey, int dim, int v, int H, int Hc, int rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int W = 2 * v + 1, total = N + nprey;
+    const int centre = v * W + v;
+    enc_bwd_rows(
+        g, ldg, E, rows, total, H, Hc, dim * dim, 2 * W * W, Ppart, Dpart, smf,
+        [&](size_t i) { return loc_r[i] | (loc_c[i] << 16); },
+        [&](const int32_t* ent, int a, size_t) { return (ent[a] & 0xffff) * dim + (ent[a] >> 16); },
+        [&](size_t, const int32_t* ent, int a, auto reg) {
+            reg(0, a < N ? 1.0f : 0.0f);                         // the observer itself, in its window's centre cell
+            reg(1, a < N ? 0.0f : 1.0f);
+            return (ent[a] & 0xffff) * dim + (ent[a] >> 16);
+        },
+        [&](const int32_t* ent, int a, int p, size_t) {          // PP:191-195: another entity standing inside the window
+            const int dy = (ent[p] & 0xffff) - (ent[a] & 0xffff) + v, dx = (ent[p] >> 16) - (ent[a] >> 16) + v;
+            return (p != a && (unsigned)dy < (unsigned)W && (unsigned)dx < (unsigned)W) ? 2 * (dy * W + dx) + (p >= N ? 1 : 0)
+                                                                                         : -1;
+        },
+        [&](int k) { return k == 0 ? 2 * centre : (k == 1 ? 2 * centre + 1 : -1); });
+}
+
 // Stage 2 for PP: dWt (zeroed by the caller) += P through the id map, class columns and dbias from the partials.
-__global__ __launch_bounds__(256) void pp_encode_bwd_expand_kernel(const float* __restrict__ P,
+// P = the sum of `np` partials of npos * H floats each.
+__global__ __launch_bounds__(256) void pp_encode_bwd_expand_kernel(const float* __restrict__ P, int np,
                                                                    const float* __restrict__ Dpart, int nwg,
                                                                    float* __restrict__ dWt, float* __restrict__ dbias,
                                                                    int dim, int v, int H)
@@ -262,17 +290,19 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_expand_kernel(const float* 
     const int OUTSIDE = dim * dim + 1;
     // partials: ENCB_SPLIT of them per thread, so that the reduction over workgroups is spread over many threads
     const int nsplit = (nwg + ENCB_SPLIT - 1) / ENCB_SPLIT;
-    const long long nA = (long long)WW * npos * H, nB = (long long)(nslots + 1) * H * nsplit;
+    const long long nP = (long long)npos * H, nA = enc_bwd_pfold_threads(nP), nB = (long long)(nslots + 1) * H * nsplit;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB;
          i += (long long)gridDim.x * blockDim.x) {
         if (i < nA) {
-            const int h = (int)(i % H);
-            const int pos = (int)((i / H) % npos), cell = (int)(i / ((long long)H * npos));
-            const float val = P[(size_t)pos * H + h];
-            if (val == 0.f) continue;
-            const int gr = pos / dim + cell / W - v, gc = pos % dim + cell % W - v;
-            const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
-            atomicAdd(dWt + ((size_t)cell * vocab + id) * H + h, val);
+            long long ip;
+            const float val = enc_bwd_pfold(P, np, (size_t)nP, i, nP, &ip);     // (whole wavefronts take this branch)
+            if (ip < 0 || val == 0.f) continue;
+            const int h = (int)(ip % H), pos = (int)(ip / H);
+            for (int cell = 0; cell < WW; ++cell) {
+                const int gr = pos / dim + cell / W - v, gc = pos % dim + cell % W - v;
+                const int id = (gr >= 0 && gr < dim && gc >= 0 && gc < dim) ? gr * dim + gc : OUTSIDE;
+                atomicAdd(dWt + ((size_t)cell * vocab + id) * H + h, val);
+            }
         } else {
             const long long j = i - nA;
             const int h = (int)(j % H), s = (int)((j / H) % (nslots + 1)), part = (int)(j / ((long long)H * (nslots + 1)));
@@ -299,7 +329,10 @@ int64_t pp_encode_bwd_work(const ic3_env* env, int H)
     const ic3_pp_cfg& c = env->pp;
     const int WW = (2 * c.vision + 1) * (2 * c.vision + 1);
     const int chunk = encode_bwd_chunk(c.E), nwg = (c.E + chunk - 1) / chunk;
-    return (int64_t)c.dim * c.dim * H + (int64_t)nwg * (2 * WW + 1) * H;
+    const EncBwdPlan pl = enc_bwd_plan(c.E, env->dims.N, c.N + c.nprey, H, c.dim * c.dim, 2 * WW);
+    const int64_t per_env_form = (int64_t)c.dim * c.dim * H + (int64_t)nwg * (2 * WW + 1) * H;
+    const int64_t row_form = pl.csplit ? (int64_t)pl.nrg * (c.dim * c.dim + 2 * WW + 1) * H : 0;
+    return std::max(per_env_form, row_form);
 }
 
 int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias,
@@ -310,24 +343,38 @@ int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     const int total = c.N + c.nprey, W = 2 * c.vision + 1, WW = W * W, nseg = rows * WW;
     const int tab_words = (((2 * total + 3) & ~3) + 2 * nseg + 3) & ~3;
     const size_t lds = ((size_t)tab_words + (size_t)rows * H + (size_t)(2 * WW + 1) * H) * sizeof(int32_t);
-    if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
-    if (lds > 64 * 1024)
-        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pp_encode_bwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int chunk = encode_bwd_chunk(c.E), nwg = (c.E + chunk - 1) / chunk;
     const int32_t* base = snap ? snap : env->state;
     const int32_t* loc_r = base + (env->f("loc_r") - env->state);
     const int32_t* loc_c = base + (env->f("loc_c") - env->state);
-    float* P = work;
-    float* Dpart = work + (size_t)c.dim * c.dim * H;
-    IC3_HIP(hipMemsetAsync(P, 0, (size_t)c.dim * c.dim * H * sizeof(float), s));
+    const int npos = c.dim * c.dim;
     IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)env->dims.obs_dim * H * sizeof(float), s));
-    hipLaunchKernelGGL(pp_encode_bwd_kernel, dim3(nwg), dim3(256), lds, s, loc_r, loc_c, g, ldg, P, Dpart, c.E, chunk, c.N,
-                       c.nprey, c.dim, c.vision, H, rows, tab_words);
     if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
-    const long long items = (long long)WW * c.dim * c.dim * H + encode_bwd_items_b(nwg, 2 * WW + 1, H);
+    const EncBwdPlan pl = enc_bwd_plan(c.E, rows, total, H, npos, 2 * WW);
+    float* P = work;
+    int np = 1, nwg;
+    float* Dpart;
+    if (pl.csplit) {                                   // rows in parallel, P and D of a column slice in LDS
+        np = nwg = pl.nrg;
+        Dpart = work + (size_t)pl.nrg * npos * H;
+        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pp_encode_bwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    pl.lds));
+        hipLaunchKernelGGL(pp_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, loc_r, loc_c, g, ldg, P,
+                           Dpart, c.E, c.N, c.nprey, c.dim, c.vision, H, H / pl.csplit, rows);
+    } else {                                           // the grid does not fit in LDS: one env at a time, P by global atomics
+        if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
+        if (lds > 64 * 1024)
+            IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pp_encode_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int chunk = encode_bwd_chunk(c.E);
+        nwg = (c.E + chunk - 1) / chunk;
+        Dpart = work + (size_t)npos * H;
+        IC3_HIP(hipMemsetAsync(P, 0, (size_t)npos * H * sizeof(float), s));
+        hipLaunchKernelGGL(pp_encode_bwd_kernel, dim3(nwg), dim3(256), lds, s, loc_r, loc_c, g, ldg, P, Dpart, c.E, chunk,
+                           c.N, c.nprey, c.dim, c.vision, H, rows, tab_words);
+    }
+    const long long items = enc_bwd_pfold_threads((long long)npos * H) + encode_bwd_items_b(nwg, 2 * WW + 1, H);
     const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
-    hipLaunchKernelGGL(pp_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, Dpart, nwg, dWt, dbias, c.dim,
+    hipLaunchKernelGGL(pp_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, np, Dpart, nwg, dWt, dbias, c.dim,
                        c.vision, H);
     IC3_HIP(hipGetLastError());
     return 0;

@@ -391,7 +391,43 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_kernel(const int32_t* __res
     for (int i = threadIdx.x; i < (nslots + 1) * H; i += blockDim.x) dst[i] = Dl[i];
 }
 
-__global__ __launch_bounds__(256) void tj_encode_bwd_expand_kernel(const float* __restrict__ P,
+// Stage 1, row-parallel form (enc_bwd.hpp): same slots; a live car's header scalars and the cars inside its window.
+__global__ __launch_bounds__(256) void tj_encode_bwd_rows_kernel(const int32_t* __restrict__ alive_s,
+                                                                 const int32_t* __restrict__ loc_r,
+                                                                 const int32_t* __restrict__ loc_c,
+                                                                 const int32_t* __restrict__ last_act_s,
+                                                                 const int32_t* __restrict__ route_id_s,
+                                                                 const float* __restrict__ g, int ldg,
+                                                                 float* __restrict__ Ppart, float* __restrict__ Dpart, int E,
+                                                                 int N, int h, int w, int v, int npath, int H, int Hc, int hdr)
+{
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int W = 2 * v + 1;
+    const int centre = v * W + v;
+    enc_bwd_rows(
+        g, ldg, E, N, N, H, Hc, h * w, hdr + W * W, Ppart, Dpart, smf,
+        [&](size_t i) { return loc_r[i] | (loc_c[i] << 16); },
+        [&](const int32_t* ent, int a, size_t row) { return alive_s[row] ? (ent[a] & 0xffff) * w + (ent[a] >> 16) : -1; },
+        [&](size_t row, const int32_t* ent, int a, auto reg) {
+            if (!alive_s[row]) return -1;                        // an all-zero obs row: bias only
+            const int r = ent[a] & 0xffff, c = ent[a] >> 16;
+            reg(0, (float)((double)last_act_s[row] / 1.0));                      // same expressions as the forward
+            reg(1, (float)((double)route_id_s[row] / (double)(npath - 1)));
+            if (hdr == 4) {
+                reg(2, (float)((double)r / (double)(h - 1)));
+                reg(3, (float)((double)c / (double)(w - 1)));
+            }
+            reg(4, 1.0f);                                        // the car itself, in its window's centre cell
+            return r * w + c;
+        },
+        [&](const int32_t* ent, int a, int p, size_t row) {      // another car slot standing inside a live car's window
+            const int dy = (ent[p] & 0xffff) - (ent[a] & 0xffff) + v, dx = (ent[p] >> 16) - (ent[a] >> 16) + v;
+            return (p != a && (unsigned)dy < (unsigned)W && (unsigned)dx < (unsigned)W && alive_s[row]) ? hdr + dy * W + dx : -1;
+        },
+        [&](int k) { return k < hdr ? k : (k == 4 ? hdr + centre : -1); });
+}
+
+__global__ __launch_bounds__(256) void tj_encode_bwd_expand_kernel(const float* __restrict__ P, int np,
                                                                    const float* __restrict__ Dpart, int nwg,
                                                                    const int32_t* __restrict__ grid,
                                                                    float* __restrict__ dWt, float* __restrict__ dbias,
@@ -400,17 +436,19 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_expand_kernel(const float* 
 {
     const int W = 2 * v + 1, WW = W * W, nslots = hdr + WW, npos = h * w;
     const int nsplit = (nwg + ENCB_SPLIT - 1) / ENCB_SPLIT;
-    const long long nA = (long long)WW * npos * H, nB = (long long)(nslots + 1) * H * nsplit;
+    const long long nP = (long long)npos * H, nA = enc_bwd_pfold_threads(nP), nB = (long long)(nslots + 1) * H * nsplit;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB;
          i += (long long)gridDim.x * blockDim.x) {
         if (i < nA) {
-            const int c = (int)(i % H);
-            const int pos = (int)((i / H) % npos), cell = (int)(i / ((long long)H * npos));
-            const float val = P[(size_t)pos * H + c];
-            if (val == 0.f) continue;
-            const int gr = pos / w + cell / W - v, gc = pos % w + cell % W - v;
-            const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
-            if (id >= 0) atomicAdd(dWt + ((size_t)hdr + (size_t)cell * vocab + id) * H + c, val);   // -1: scalar vocab, off-road
+            long long ip;
+            const float val = enc_bwd_pfold(P, np, (size_t)nP, i, nP, &ip);     // (whole wavefronts take this branch)
+            if (ip < 0 || val == 0.f) continue;
+            const int c = (int)(ip % H), pos = (int)(ip / H);
+            for (int cell = 0; cell < WW; ++cell) {
+                const int gr = pos / w + cell / W - v, gc = pos % w + cell % W - v;
+                const int id = (gr >= 0 && gr < h && gc >= 0 && gc < w) ? grid[gr * w + gc] : outside;
+                if (id >= 0) atomicAdd(dWt + ((size_t)hdr + (size_t)cell * vocab + id) * H + c, val);   // -1: scalar vocab, off-road
+            }
         } else {
             const long long j = i - nA;
             const int c = (int)(j % H), s = (int)((j / H) % (nslots + 1)), part = (int)(j / ((long long)H * (nslots + 1)));
@@ -435,7 +473,11 @@ int64_t tj_encode_bwd_work(const ic3_env* env, int H)
     const ic3_dims& d = env->dims;
     const int WW = d.window * d.window, hdr = env->tj.vocab_type ? 4 : 2;
     const int chunk = encode_bwd_chunk(env->tj.E), nwg = (env->tj.E + chunk - 1) / chunk;
-    return (int64_t)d.grid_h * d.grid_w * H + (int64_t)nwg * (hdr + WW + 1) * H;
+    const int npos = d.grid_h * d.grid_w;
+    const EncBwdPlan pl = enc_bwd_plan(env->tj.E, env->tj.N, env->tj.N, H, npos, hdr + WW);
+    const int64_t per_env_form = (int64_t)npos * H + (int64_t)nwg * (hdr + WW + 1) * H;
+    const int64_t row_form = pl.csplit ? (int64_t)pl.nrg * (npos + hdr + WW + 1) * H : 0;
+    return std::max(per_env_form, row_form);
 }
 
 int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias,
@@ -446,24 +488,39 @@ int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     const int WW = d.window * d.window, hdr = c.vocab_type ? 4 : 2;
     const int tab_words = (((7 * c.N + 3) & ~3) + c.N * WW + 3) & ~3;
     const size_t lds = ((size_t)tab_words + (size_t)c.N * H + (size_t)(hdr + WW + 1) * H) * sizeof(int32_t);
-    if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
-    if (lds > 64 * 1024)
-        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tj_encode_bwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int chunk = encode_bwd_chunk(c.E), nwg = (c.E + chunk - 1) / chunk;
     const int32_t* base = snap ? snap : env->state;
     auto fld = [&](const char* name) { return base + (env->f(name) - env->state); };
-    float* P = work;
-    float* Dpart = work + (size_t)d.grid_h * d.grid_w * H;
-    IC3_HIP(hipMemsetAsync(P, 0, (size_t)d.grid_h * d.grid_w * H * sizeof(float), s));
+    const int npos = d.grid_h * d.grid_w;
     IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)d.obs_dim * H * sizeof(float), s));
-    hipLaunchKernelGGL(tj_encode_bwd_kernel, dim3(nwg), dim3(256), lds, s, fld("alive"), fld("loc_r"), fld("loc_c"),
-                       fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, chunk, c.N, d.grid_h, d.grid_w, c.vision,
-                       d.npath, H, hdr, tab_words);
     if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
-    const long long items = (long long)WW * d.grid_h * d.grid_w * H + encode_bwd_items_b(nwg, hdr + WW + 1, H);
+    const EncBwdPlan pl = enc_bwd_plan(c.E, c.N, c.N, H, npos, hdr + WW);
+    float* P = work;
+    int np = 1, nwg;
+    float* Dpart;
+    if (pl.csplit) {                                   // rows in parallel, P and D of a column slice in LDS
+        np = nwg = pl.nrg;
+        Dpart = work + (size_t)pl.nrg * npos * H;
+        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tj_encode_bwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    pl.lds));
+        hipLaunchKernelGGL(tj_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, fld("alive"),
+                           fld("loc_r"), fld("loc_c"), fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, c.N, d.grid_h,
+                           d.grid_w, c.vision, d.npath, H, H / pl.csplit, hdr);
+    } else {
+        if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
+        if (lds > 64 * 1024)
+            IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tj_encode_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int chunk = encode_bwd_chunk(c.E);
+        nwg = (c.E + chunk - 1) / chunk;
+        Dpart = work + (size_t)npos * H;
+        IC3_HIP(hipMemsetAsync(P, 0, (size_t)npos * H * sizeof(float), s));
+        hipLaunchKernelGGL(tj_encode_bwd_kernel, dim3(nwg), dim3(256), lds, s, fld("alive"), fld("loc_r"), fld("loc_c"),
+                           fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, chunk, c.N, d.grid_h, d.grid_w, c.vision,
+                           d.npath, H, hdr, tab_words);
+    }
+    const long long items = enc_bwd_pfold_threads((long long)npos * H) + encode_bwd_items_b(nwg, hdr + WW + 1, H);
     const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
-    hipLaunchKernelGGL(tj_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, Dpart, nwg, env->d_grid, dWt, dbias,
+    hipLaunchKernelGGL(tj_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, np, Dpart, nwg, env->d_grid, dWt, dbias,
                        d.grid_h, d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, H, hdr);
     IC3_HIP(hipGetLastError());
     return 0;

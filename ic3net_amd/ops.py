@@ -108,6 +108,31 @@ def lstm_cell_backward(gates, c_prev, dh, dc, dgates, dc_prev, dbias_partials=No
     return dbias_partials[:n] if dbias_partials is not None else None
 
 
+def lstm_gates_backward_supported(H):
+    return bool(_lib.lib().ic3_lstm_gates_backward_supported(int(H)))
+
+
+def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None, accumulate=False):
+    """Gate recompute + LSTM cell backward in one launch (ic3_lstm_gates_backward): xh (R,2H) = [inp | h_prev] rows (unit
+    column stride), lstm_wp = policy_step_pack's 'ps_l_wp', bias (4H,) = b_ih + b_hh; c_prev, dh, dc (or None) (R,H) ->
+    dgates (R,4H), dc_prev (R,H; may alias dc).  dbias_partials: (ceil(R/64), 4H), written (or added to: `accumulate`)."""
+    _need_cuda(xh, "lstm_gates_backward")
+    R, H = c_prev.shape
+    assert xh.dtype == torch.float32 and xh.stride(1) == 1 and xh.shape == (R, 2 * H)
+    for t in (c_prev, dh, dgates, dc_prev, bias, lstm_wp):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    tiles = (R + 63) // 64
+    if dbias_partials is not None:
+        assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == (tiles, 4 * H)
+    n = _lib.lib().ic3_lstm_gates_backward(ptr(xh), xh.stride(0), ptr(lstm_wp), ptr(bias), ptr(c_prev), ptr(dh),
+                                           ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
+                                           ptr(dbias_partials) if dbias_partials is not None else None,
+                                           int(bool(accumulate)), R, H, stream())
+    if n < 0:
+        check(n)
+    return n
+
+
 def policy_heads(h, W, b, head_sizes, out=None):
     """h (R,H) rows (unit column stride), W (OT,H), b (OT,) -> out (R,OT) = [log_softmax heads | value]."""
     import ctypes as C

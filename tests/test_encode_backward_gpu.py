@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 CASES = [("pp", dict(N=10, dim=20, v=1, H=128, E=96)), ("pp", dict(N=3, dim=5, v=0, H=64, E=33)),
          ("pp", dict(N=32, dim=40, v=2, H=256, E=5)), ("pp", dict(N=4, dim=7, v=1, H=32, E=700)),
          ("pp", dict(N=5, dim=8, v=1, H=32, E=64, enemy_comm=True)),
+         ("pp", dict(N=4, dim=70, v=1, H=32, E=20)),       # 4900 grid cells: the per-env form (P does not fit in LDS)
          ("tj", dict(N=10, dim=14, v=1, diff="medium", H=128, E=64)), ("tj", dict(N=20, dim=18, v=0, diff="hard", H=128, E=32)),
          ("tj", dict(N=5, dim=6, v=1, diff="easy", H=32, E=17)), ("tj", dict(N=5, dim=6, v=1, diff="easy", H=32, E=1100)),
          ("tj", dict(N=10, dim=14, v=1, diff="medium", H=64, E=48, vocab_type="scalar"))]

@@ -1,0 +1,65 @@
+"""GPU: ic3_lstm_gates_backward (gate recompute + LSTM cell backward in one launch, update half) against fp64 autograd
+through torch.nn.LSTMCell's formula (comm.py:215) — and against the two-launch path it replaces (library GEMM +
+ic3_lstm_cell_backward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def reference(xh, w_ih, w_hh, b, c_prev, dh, dc):
+    H = c_prev.shape[1]
+    xh, c_prev = xh.double(), c_prev.double()
+    gates = (xh @ torch.cat([w_ih, w_hh], 1).double().t() + b.double()).requires_grad_(True)
+    c0 = c_prev.clone().requires_grad_(True)
+    i, f, g, o = gates[:, :H].sigmoid(), gates[:, H:2 * H].sigmoid(), gates[:, 2 * H:3 * H].tanh(), gates[:, 3 * H:].sigmoid()
+    c1 = f * c0 + i * g
+    h1 = o * c1.tanh()
+    loss = (h1 * dh.double()).sum() + ((c1 * dc.double()).sum() if dc is not None else 0)
+    loss.backward()
+    return gates.grad, c0.grad
+
+
+@pytest.mark.parametrize("H,R,pad", [(128, 640, 0), (128, 1000, 0), (64, 77, 8), (256, 333, 0), (128, 64 * 300 + 5, 4)])
+def test_gates_backward_matches_autograd(H, R, pad):
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(H + R)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    w_ih, w_hh, c_w = rn(4 * H, H) / H ** 0.5, rn(4 * H, H) / H ** 0.5, rn(H, H)
+    b = rn(4 * H)
+    wide = rn(R, 2 * H + pad)
+    xh = wide[:, :2 * H]                                      # row stride 2H + pad
+    c_prev, dh, dc = rn(R, H), rn(R, H), rn(R, H)
+    wp = ops.policy_step_pack(c_w, w_ih, w_hh)['ps_l_wp']
+    tiles = (R + 63) // 64
+    for with_dc in (True, False):
+        dgates = torch.full((R, 4 * H), float('nan'), device='cuda')
+        dcp = torch.full((R, H), float('nan'), device='cuda')
+        parts = torch.full((tiles, 4 * H), float('nan'), device='cuda')
+        n = ops.lstm_gates_backward(xh, wp, b, c_prev, dh, dc if with_dc else None, dgates, dcp, parts, False)
+        assert n == tiles
+        ref_dg, ref_dc = reference(xh, w_ih, w_hh, b, c_prev, dh, dc if with_dc else None)
+        assert float((dgates.double() - ref_dg).abs().max()) <= 2e-6 * max(1.0, float(ref_dg.abs().max()))
+        assert float((dcp.double() - ref_dc).abs().max()) <= 2e-6 * max(1.0, float(ref_dc.abs().max()))
+        torch.testing.assert_close(parts.double().sum(0), dgates.double().sum(0), atol=1e-4, rtol=1e-5)
+        # accumulate: the partial rows grow by the same sums; dc_prev written over dc (in place)
+        dc_io = (dc if with_dc else torch.zeros_like(dh)).clone()
+        before = parts.clone()
+        ops.lstm_gates_backward(xh, wp, b, c_prev, dh, dc_io, dgates, dc_io, parts, True)
+        torch.testing.assert_close(parts, 2 * before, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(dc_io, dcp, atol=0, rtol=0)
+    # the two-launch path it replaces
+    gates = torch.addmm(b, xh, torch.cat([w_ih, w_hh], 1).t())
+    dg2, dcp2 = torch.empty_like(dgates), torch.empty_like(dcp)
+    ops.lstm_cell_backward(gates.contiguous(), c_prev, dh, None, dg2, dcp2, None)
+    assert float((dgates - dg2).abs().max()) <= 2e-5 * max(1.0, float(dg2.abs().max()))
+
+
+def test_gates_backward_rejects_other_sizes():
+    from ic3net_amd import ops
+    assert ops.lstm_gates_backward_supported(128) and not ops.lstm_gates_backward_supported(96)
+    z = torch.zeros(8, 192, device='cuda')
+    with pytest.raises(Exception):
+        ops.lstm_gates_backward(z, torch.zeros(8 * 96 * 96, device='cuda'), torch.zeros(384, device='cuda'),
+                                torch.zeros(8, 96, device='cuda'), torch.zeros(8, 96, device='cuda'), None,
+                                torch.zeros(8, 384, device='cuda'), torch.zeros(8, 96, device='cuda'))
