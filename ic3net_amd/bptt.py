@@ -159,7 +159,8 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         alive, gate = rec.alive[t], rec.gate[t]
         # ---- the forward of step t again: enc + C.bias -> inp, comm, gate pre-activations (comm.py:119,181-215)
         raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp, loc_table=fc['loc_table'])
-        xh[:, H:].copy_(h_prev)
+        if not fused_gates:
+            xh[:, H:].copy_(h_prev)                                       # (the fused gate launch fills it)
         if mask_zero:
             comm.zero_()                                                  # comm.py:40-41: C sees zeros
         else:
@@ -173,7 +174,8 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         acc['w_heads'].addmm_(d.t(), h_t)
         acc['b_heads'].add_(d.sum(0))
         if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
-            ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True)
+            ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
+                                    h_prev=h_prev)
         else:
             parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)
             torch.sum(parts, 0, out=bsum)

@@ -26,7 +26,9 @@ typedef float gb_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int gb_u32x4 __attribute__((ext_vector_type(4)));
 
 struct GatesBwdArgs {
-    const float* xh;       // [R][ldx] = [inp | h_prev]
+    float* xh;             // [R][ldx] = [inp | h_prev]
+    const float* h_prev;   // or null.  [R][H]: the h half of a row is read from here and ALSO written into xh (the copy
+                           // the caller would otherwise make for the weight-gradient product that follows)
     const float* wq;       // ic3_policy_pack's lstm_wp: Wq[k][c] = float4 over the four gates
     const float* bias;     // [4H] b_ih + b_hh
     const float* c_prev;   // [R][H]
@@ -56,6 +58,22 @@ __device__ __forceinline__ void gb_store1(float v, __amdgpu_buffer_rsrc_t r, int
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
 }
 
+// The accumulators are pinned to AGPRs (tools/exp/ws_probe.hip: an fp32 MFMA stream with AGPR accumulators ran 153
+// instead of 141 TFLOP/s in isolation; this kernel: 266 instead of 280 us per call in tools/exp/microbench_gates_bwd.py,
+// no spills at 128 AGPR + 128 VGPR).  -DIC3_GB_AGPR=0 is the all-VGPR form.  policy_step_kernel cannot follow: its phases
+// around the loops need more than 128 VGPRs (97 spills with IC3_PS_AGPR=1).
+#ifndef IC3_GB_AGPR
+#define IC3_GB_AGPR 1
+#endif
+__device__ __forceinline__ void gb_mfma(gb_f32x16& acc, float x, float y)
+{
+#if IC3_GB_AGPR
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
+#else
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+#endif
+}
+
 template <int H>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kernel(const GatesBwdArgs a)
 {
@@ -74,11 +92,18 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     {
         const __amdgpu_buffer_rsrc_t rx = gb_rsrc(a.xh + r0 * a.ldx, ((long long)(rows - 1) * a.ldx + K) * 4);
         constexpr int PER = 64 * K4 / NT;                        // float4 per thread (16)
+        const __amdgpu_buffer_rsrc_t rhp = gb_rsrc(a.h_prev ? a.h_prev + r0 * H : a.xh, a.h_prev ? (long long)rows * H * 4 : 0);
+        const bool from_h = a.h_prev != nullptr;
         gb_f32x4 v[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = tid + i * NT, row = idx / K4, c4 = idx - row * K4;
-            v[i] = gb_load4(rx, (row * a.ldx + 4 * c4) * 4, 0);
+            if (from_h && c4 >= H / 4) {
+                v[i] = gb_load4(rhp, (row * H + 4 * c4 - H) * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gb_u32x4, v[i]), rx, (row * a.ldx + 4 * c4) * 4, 0, 0);
+            } else {
+                v[i] = gb_load4(rx, (row * a.ldx + 4 * c4) * 4, 0);
+            }
         }
         if (tid < H) reinterpret_cast<gb_f32x4*>(slb)[tid] = reinterpret_cast<const gb_f32x4*>(a.bias)[tid];
 #pragma unroll
@@ -122,8 +147,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt) {
-                acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], wk[SB + j][gt], acc[0][gt], 0, 0, 0);
-                acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], wk[SB + j][gt], acc[1][gt], 0, 0, 0);
+                gb_mfma(acc[0][gt], a0[j], wk[SB + j][gt]);
+                gb_mfma(acc[1][gt], a1[j], wk[SB + j][gt]);
             }
             if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
             __builtin_amdgcn_sched_barrier(0);
@@ -139,6 +164,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     block(s0, std::false_type{}, KB - 2);
     block(s1, std::false_type{}, KB - 1);
     __builtin_amdgcn_sched_barrier(0);
+#if IC3_GB_AGPR
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // (the asm MFMAs are opaque to the hazard recogniser)
+#endif
 
     // ---- the cell's derivative (torch.nn.LSTMCell): c' = f c + i g, h' = o tanh(c') -----------------------------------------
     const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
@@ -205,7 +233,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 
 extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
-extern "C" int ic3_lstm_gates_backward(const float* xh, int ldx, const float* lstm_wp, const float* bias, const float* c_prev,
+extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const float* bias, const float* c_prev,
                                        const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
                                        int accumulate, int R, int H, ic3_stream stream)
 {
@@ -216,14 +244,13 @@ extern "C" int ic3_lstm_gates_backward(const float* xh, int ldx, const float* ls
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
     if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
         return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
-    const GatesBwdArgs a{ xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate };
+    const GatesBwdArgs a{ xh, h_prev, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate };
     const int tiles = (R + 63) / 64;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define IC3_GB(h)                                                                                                       \
     case h:                                                                                                             \
-        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<h>),                            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   /* per device: every call */ \
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<h>), lds));                      \
         hipLaunchKernelGGL(lstm_gates_bwd_kernel<h>, dim3(tiles), dim3(2 * h), lds, s, a);                              \
         break;
     switch (H) {

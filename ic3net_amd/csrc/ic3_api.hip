@@ -3,6 +3,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "ic3_common.hpp"
@@ -48,6 +50,22 @@ Range::~Range()
 }
 
 void set_error(const std::string& msg) { g_err = msg; }
+
+hipError_t ensure_dynamic_lds(const void* func, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> have;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = have[{ func, dev }];
+    if (cur >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 int fail(int code, const std::string& msg)
 {
     g_err = msg;

@@ -96,6 +96,9 @@ namespace ic3 {
 
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+// hipFuncAttributeMaxDynamicSharedMemorySize of `func` raised to >= `bytes` on the CURRENT device.  The attribute is per
+// device; what has been set is remembered per (function, device), so the driver call happens once per pair, not per launch.
+hipError_t ensure_dynamic_lds(const void* func, size_t bytes);
 
 // roctx ranges around the launches of the hot loop (the reference's unused utils.Timer, utils.py:86-98):
 // `IC3_ROCTX=1 rocprofv3 --marker-trace --kernel-trace ...` shows reset / step / observe / encode / policy_step /

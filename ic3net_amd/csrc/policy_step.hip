@@ -1175,10 +1175,7 @@ static int plan_tiles(StepArgs& a, int H, const ic3_policy* p, hipStream_t s)
 template <int H, int KIND>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    // (hipFuncAttributeMaxDynamicSharedMemorySize is per device and cheap to set: no per-process cache)
-    if (lds > 64 * 1024)
-        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>), lds));   // per (kernel, device)
     // one workgroup per tile, dispatched in tile order (full tiles first, see plan_tiles): the hardware dispatcher
     // balances them over the CUs (a fixed resident set walking a strided tile list was measured slower)
     const int grid = tiles;

@@ -356,15 +356,12 @@ int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     if (pl.csplit) {                                   // rows in parallel, P and D of a column slice in LDS
         np = nwg = pl.nrg;
         Dpart = work + (size_t)pl.nrg * npos * H;
-        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pp_encode_bwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    pl.lds));
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(pp_encode_bwd_rows_kernel), (size_t)pl.lds));
         hipLaunchKernelGGL(pp_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, loc_r, loc_c, g, ldg, P,
                            Dpart, c.E, c.N, c.nprey, c.dim, c.vision, H, H / pl.csplit, rows);
     } else {                                           // the grid does not fit in LDS: one env at a time, P by global atomics
         if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
-        if (lds > 64 * 1024)
-            IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pp_encode_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(pp_encode_bwd_kernel), lds));
         const int chunk = encode_bwd_chunk(c.E);
         nwg = (c.E + chunk - 1) / chunk;
         Dpart = work + (size_t)npos * H;

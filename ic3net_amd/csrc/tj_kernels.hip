@@ -500,16 +500,13 @@ int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     if (pl.csplit) {                                   // rows in parallel, P and D of a column slice in LDS
         np = nwg = pl.nrg;
         Dpart = work + (size_t)pl.nrg * npos * H;
-        IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tj_encode_bwd_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    pl.lds));
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(tj_encode_bwd_rows_kernel), (size_t)pl.lds));
         hipLaunchKernelGGL(tj_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, fld("alive"),
                            fld("loc_r"), fld("loc_c"), fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, c.N, d.grid_h,
                            d.grid_w, c.vision, d.npath, H, H / pl.csplit, hdr);
     } else {
         if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
-        if (lds > 64 * 1024)
-            IC3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tj_encode_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(tj_encode_bwd_kernel), lds));
         const int chunk = encode_bwd_chunk(c.E);
         nwg = (c.E + chunk - 1) / chunk;
         Dpart = work + (size_t)npos * H;

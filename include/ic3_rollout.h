@@ -282,13 +282,14 @@ int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float*
                            float* dgates, float* dc_prev, float* dbias /* or NULL */, int R, int H, ic3_stream stream);
 /* The same gradient WITHOUT the pre-activations in memory (hid_size 64 / 128 / 256: ic3_lstm_gates_backward_supported):
  * one launch re-computes gates = [inp | h_prev] . [W_ih | W_hh]^T + bias on the fp32 matrix cores — xh [R][ldx] holds the
- * row [inp (H) | h_prev (H)] of comm.py:215's LSTMCell call, lstm_wp is ic3_policy_pack's packed weight, bias [4H] =
- * b_ih + b_hh — and applies the cell's derivative in the epilogue: dgates [R][4H], dc_prev [R][H] (may alias dc) as above.
+ * row [inp (H) | h_prev (H)] of comm.py:215's LSTMCell call (h_prev != NULL: [R][H], the h half is read from there and
+ * written into xh by the same launch), lstm_wp is ic3_policy_pack's packed weight, bias [4H] = b_ih + b_hh — and applies the cell's derivative in the epilogue: dgates [R][4H], dc_prev [R][H] (may alias dc) as above.
  * dbias_partials (or NULL): [ceil(R / 64)][4H]; row w receives the column sums of dgates over rows [64 w, 64 w + 64) —
  * written when accumulate == 0, ADDED to what the row holds when accumulate != 0 (a whole episode's bias gradient then
  * needs one reduction at its end).  Returns the number of partial rows, negative errno on error (-38: unsupported H). */
 int ic3_lstm_gates_backward_supported(int H);
-int ic3_lstm_gates_backward(const float* xh, int ldx, const float* lstm_wp, const float* bias, const float* c_prev,
+int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev /* or NULL */, const float* lstm_wp, const float* bias,
+                            const float* c_prev,
                             const float* dh, const float* dc /* or NULL */, float* dgates, float* dc_prev,
                             float* dbias_partials /* or NULL */, int accumulate, int R, int H, ic3_stream stream);
 

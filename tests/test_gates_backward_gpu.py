@@ -48,6 +48,12 @@ def test_gates_backward_matches_autograd(H, R, pad):
         ops.lstm_gates_backward(xh, wp, b, c_prev, dh, dc_io, dgates, dc_io, parts, True)
         torch.testing.assert_close(parts, 2 * before, atol=1e-6, rtol=1e-6)
         torch.testing.assert_close(dc_io, dcp, atol=0, rtol=0)
+    # h_prev given separately: same results, and the launch fills the h half of xh
+    xh2 = torch.cat([xh[:, :H], torch.full((R, H), float('nan'), device='cuda')], 1)
+    dg3, dcp3 = torch.empty_like(dgates), torch.empty_like(dcp)
+    ops.lstm_gates_backward(xh2, wp, b, c_prev, dh, None, dg3, dcp3, None, False, h_prev=xh[:, H:].contiguous())
+    torch.testing.assert_close(xh2, xh.contiguous(), atol=0, rtol=0)
+    torch.testing.assert_close(dg3, dgates, atol=0, rtol=0)
     # the two-launch path it replaces
     gates = torch.addmm(b, xh, torch.cat([w_ih, w_hh], 1).t())
     dg2, dcp2 = torch.empty_like(dgates), torch.empty_like(dcp)
