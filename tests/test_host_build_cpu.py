@@ -200,3 +200,39 @@ def test_tj_device_functions_on_the_host_match_reference_golden(hb, name):
                 assert st["add_rate"] == fx["add_rate_seen"][e, ep, t]
                 np.testing.assert_array_equal(obs, sp.dense(e, ep, t + 1))
         env.close()
+
+
+def test_host_build_reproduces_reference_checksum_sweep(hb):
+    """The 210-configuration checksum sweep recorded from the reference (tests/golden/make_golden_sweep.py: CRC32 of state,
+    reward and observation at every step), through the product's device functions on the host."""
+    from golden_util import crc_of, SWEEP_RATES
+    fx = load("sweep_checksums")
+    seed = int(fx["seed"])
+    step = 4 if ASAN else 1
+    for cfg, acts, crcs in list(zip(fx["pp_cfg"], fx["pp_act"], fx["pp_crc"]))[::step]:
+        N, dim, v, mode, ec, ns, gid = [int(x) for x in cfg]
+        env = PP(hb, N, dim, v, mode, not ns, bool(ec), seed, gid)
+        obs = env.reset()
+        loc = env.state()[0]
+        assert crc_of(loc[:N], loc[N:], obs) == crcs[0], cfg
+        over = False
+        for t in range(acts.shape[0]):
+            if over:
+                assert crcs[t + 1] == 0
+                continue
+            obs, rew, done, err = env.step(acts[t, :N + ec])
+            loc, reached, _ = env.state()
+            over = bool(done)
+            assert crc_of(loc[:N], reached, rew, obs, np.int32(int(over))) == crcs[t + 1], (cfg, t)
+        env.close()
+    for cfg, acts, crcs in list(zip(fx["tj_cfg"], fx["tj_act"], fx["tj_crc"]))[::step]:
+        N, dim, v, diff, rate_i, scalar, gid = [int(x) for x in cfg]
+        r = SWEEP_RATES[rate_i]
+        env = TJ(hb, N, dim, v, diff, scalar, r, r, 0.0, 0.0, seed, gid)
+        env.reset(0)
+        for t in range(acts.shape[0]):
+            obs, rew, _, _, _, err = env.step(acts[t, :N])
+            st = env.state()
+            got = crc_of(st["alive"], st["wait"], st["loc"], st["last_act"], st["route_loc"], st["route_id"], rew, obs)
+            assert got == crcs[t], (cfg, t)
+        env.close()
