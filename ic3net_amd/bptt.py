@@ -138,7 +138,7 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     inp, dinp = xh[:, :H], dxh[:, :H]
     # gate recompute + cell backward in one launch when the packed gate weights of the rollout kernel exist (hid 64/128/256);
     # its bias partials accumulate over the episode's steps and are reduced once, behind the loop
-    fused_gates = fc.get('ps_l_wp') is not None and ops.lstm_gates_backward_supported(H)
+    fused_gates = fc.get('ps_l_wp') is not None and ops.lstm_gates_backward_supported(H) and R * 4 * H * 4 < 2 ** 32
     if fused_gates:
         bias_parts = torch.zeros(((R + 63) // 64, 4 * H), dtype=torch.float32, device=dev)
     else:
