@@ -44,7 +44,7 @@ class Policy(C.Structure):
     _fields_ = [("H", C.c_int32), ("nheads", C.c_int32), ("head_sizes", C.c_int32 * 4), ("mode_avg", C.c_int32),
                 ("comm_zero", C.c_int32), ("enc_wt", C.c_void_p), ("enc_bias", C.c_void_p), ("loc_table", C.c_void_p),
                 ("c_wp", C.c_void_p), ("lstm_wp", C.c_void_p), ("lstm_bias", C.c_void_p), ("head_w", C.c_void_p),
-                ("head_b", C.c_void_p)]
+                ("head_b", C.c_void_p), ("pass_index", C.c_int32), ("inner_pass", C.c_int32)]
 
 
 class Episode(C.Structure):

@@ -121,7 +121,9 @@ class CommNetMLP(nn.Module):
         a = self.args
         if torch.is_grad_enabled() or not getattr(a, 'fused_policy', True):
             return False
-        if not (a.recurrent and self.comm_passes == 1 and self.hid_size % 4 == 0 and len(self.heads) <= 4):
+        if not (a.recurrent and self.hid_size % 4 == 0 and len(self.heads) <= 4):
+            return False
+        if self.comm_passes != 1 and not self._multi_pass_ok():   # comm_passes > 1: the one-launch kernels, once per pass
             return False
         if sum(int(o) for o in a.naction_heads) + 1 > 16:
             return False
@@ -142,8 +144,14 @@ class CommNetMLP(nn.Module):
     def _mega_wanted(self):
         return bool(getattr(self.args, 'mega_policy', True)) and self.hid_size in ops.POLICY_STEP_SIZES
 
+    def _multi_pass_ok(self):
+        """comm_passes > 1 on the fused path: ic3_policy_forward / ic3_policy_step once per communication pass
+        (ic3_policy.pass_index / inner_pass) — recurrent LSTM policies the one-launch kernels cover."""
+        a = self.args
+        return self._mega_wanted() and getattr(a, 'rnn_type', '') == 'LSTM' and self.nagents <= 64
+
     def _fused_cache(self):
-        ps = [self.encoder.weight, self.encoder.bias, self.C_modules[0].weight, self.C_modules[0].bias,
+        ps = [self.encoder.weight, self.encoder.bias] + [q for m in self.C_modules for q in (m.weight, m.bias)] + [
               self.f_module.weight_ih, self.f_module.weight_hh, self.f_module.bias_ih, self.f_module.bias_hh,
               self.value_head.weight, self.value_head.bias] + [p for hd in self.heads for p in (hd.weight, hd.bias)]
         key = tuple((p._version, p.data_ptr()) for p in ps)
@@ -161,6 +169,12 @@ class CommNetMLP(nn.Module):
                 if self._mega_wanted():
                     new.update(ops.policy_step_pack(self.C_modules[0].weight, self.f_module.weight_ih,
                                                     self.f_module.weight_hh))
+                    for i in range(1, self.comm_passes):         # comm_passes > 1: what pass i swaps in (C_modules[i])
+                        ci = self.C_modules[i]
+                        new['enc_bias_p%d' % i] = (self.encoder.bias + ci.bias).contiguous()
+                        new['enc_dbias_p%d' % i] = (ci.bias - self.C_modules[0].bias).contiguous()
+                        new['ps_c_wp_p%d' % i] = ops.policy_step_pack(ci.weight, self.f_module.weight_ih,
+                                                                     self.f_module.weight_hh)['ps_c_wp']
                 old = getattr(self, '_fc', None)
                 same = old is not None and old.keys() == new.keys() and all(
                     (old[k] is None) == (new[k] is None) and (new[k] is None or (old[k].shape == new[k].shape
@@ -208,8 +222,13 @@ class CommNetMLP(nn.Module):
                 self.obs_encoder(fc['wt'], fc['enc_bias'], out=enc, loc_table=fc['loc_table'])
             else:
                 torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)       # dense encoder GEMM
-            out = ops.policy_forward(fc, H, self.args.naction_heads, mode_avg, bool(self.args.comm_mask_zero), enc, batch,
-                                     n, h, c, alive, comm_action)
+            mz = bool(self.args.comm_mask_zero)
+            for i in range(self.comm_passes - 1):                 # comm.py:179: every pass but the last updates h, c only
+                ops.policy_forward(fc, H, self.args.naction_heads, mode_avg, mz, self._enc_of_pass(fc, mb, enc, i), batch, n,
+                                   h, c, alive, comm_action, pass_index=i, inner=True)
+            last = self.comm_passes - 1
+            out = ops.policy_forward(fc, H, self.args.naction_heads, mode_avg, mz, self._enc_of_pass(fc, mb, enc, last),
+                                     batch, n, h, c, alive, comm_action, pass_index=last)
             return self._split_out(out, batch, n) + ((h, c),)
         buf = getattr(self, '_fb', None)
         if buf is None or buf['xh'].shape[0] != R or buf['xh'].device != dev:
@@ -252,6 +271,17 @@ class CommNetMLP(nn.Module):
             out = ops.policy_heads(h_view, fc['w_heads'], fc['b_heads'], self.args.naction_heads)
         return self._split_out(out, batch, n) + ((h_view, c),)
 
+    @staticmethod
+    def _enc_of_pass(fc, mb, enc, i):
+        """encoder(x) + encoder.bias + C_modules[i].bias: `enc` carries pass 0's bias; later passes add the difference."""
+        if i == 0 or ('enc_dbias_p%d' % i) not in fc:
+            return enc
+        buf = mb.get('enc_p')
+        if buf is None or buf.shape != enc.shape:
+            buf = mb['enc_p'] = torch.empty_like(enc)
+        torch.add(enc, fc['enc_dbias_p%d' % i], out=buf)
+        return buf
+
     def _split_out(self, out, batch, n):
         """(R, OT) [log-probs of every head | value] -> ([ (E,N,A_k) ], value (R,1))"""
         OT = out.shape[1]
@@ -286,7 +316,7 @@ class CommNetMLP(nn.Module):
         a = self.args
         if not (self._mega_wanted() and getattr(a, 'fused_policy', True) and hasattr(env, '_h')):
             return False
-        if not (a.recurrent and getattr(a, 'rnn_type', '') == 'LSTM' and self.comm_passes == 1 and len(self.heads) <= 4):
+        if not (a.recurrent and getattr(a, 'rnn_type', '') == 'LSTM' and len(self.heads) <= 4):
             return False
         if sum(int(o) for o in a.naction_heads) + 1 > 16 or self.encoder.weight.dtype != torch.float32:
             return False
@@ -336,8 +366,11 @@ class CommNetMLP(nn.Module):
         heads = [int(a) for a in self.args.naction_heads]
         OT = sum(heads) + 1
         out = torch.empty((R, OT), dtype=torch.float32, device=dev)    # per call: a Transition keeps its action_out
-        ops.policy_step(env, fc, H, heads, mode_avg, bool(self.args.comm_mask_zero), h, c, alive_in, comm_in, out, action,
-                        reward, done, alive, is_completed, obs)
+        mz = bool(self.args.comm_mask_zero)
+        for i in range(self.comm_passes - 1):                     # comm.py:179: every pass but the last updates h, c only
+            ops.policy_step_pass(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, i)
+        ops.policy_step(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, out, action, reward, done, alive,
+                        is_completed, obs, pass_index=self.comm_passes - 1)
         self.mega_steps = getattr(self, 'mega_steps', 0) + 1
         return self._split_out(out, batch, n) + ((h, c),)
 

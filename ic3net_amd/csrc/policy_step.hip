@@ -155,6 +155,9 @@ struct StepArgs {
     // env
     int E, N, EPT, G;
     int auto_reset;             // env handle in auto-reset mode: an env with t == 0 starts an episode (h = c = 0, gate 0)
+    int inner;                  // comm_passes > 1 (comm.py:179): NOT the last communication pass of the step — the launch
+                                // ends behind the LSTM cell (h, c updated; no heads, draws, env.step, obs rows)
+    int keep_state;             // not the FIRST pass of the step: h, c hold the previous pass (an env at t == 0 keeps them)
     int tile_words;             // int32 words of one env-descriptor block in LDS
     uint32_t seed, gid0;
     const int32_t* episode;
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / H4, c4 = idx - row * H4;
-            As4[row * LDA4 + H4 + c4] = (autor && ((fmask >> row) & 1)) ? ps_f32x4{ 0.f, 0.f, 0.f, 0.f } : hv[i];
+            As4[row * LDA4 + H4 + c4] = (autor && !a.keep_state && ((fmask >> row) & 1)) ? ps_f32x4{ 0.f, 0.f, 0.f, 0.f } : hv[i];
         }
         __syncthreads();
         IC3_TR(3);
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
             // (cold[]: requested in front of the C product; every load this wave issued after them has been waited for
             // in the gate loop and loads return in order, so they have landed)
-            if (autor) {
+            if (autor && !a.keep_state) {
                 const unsigned long long fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
                                                  ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
 #pragma unroll
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         __syncthreads();
         IC3_TR(12);
-        if (ABL & 8) return;
+        if ((ABL & 8) || a.inner) return;   // (uniform)
 
         // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of
         //      16 rows per wave, the OT <= 16 output columns are the weight rows [0, 16) of the inp half (rows >= OT hold
@@ -1102,6 +1105,8 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
     a.a3 = sz[3];
     a.mode_avg = p->mode_avg;
     a.comm_zero = p->comm_zero;
+    a.inner = p->inner_pass != 0;
+    a.keep_state = p->pass_index > 0;
     return 0;
 }
 
@@ -1275,7 +1280,8 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
                                   const int32_t* alive_in, const int32_t* comm_in, float* out, ic3_stream stream)
 {
     ic3::Range range_("ic3_policy_forward");
-    if (!p || !enc || !h || !c || !out || E <= 0 || N <= 0) return fail(-22, "ic3_policy_forward: bad arguments");
+    if (!p || !enc || !h || !c || (!out && !p->inner_pass) || E <= 0 || N <= 0)
+        return fail(-22, "ic3_policy_forward: bad arguments");
     const int H = p->H;
     if ((H != 64 && H != 128 && H != 256) || N > 64)
         return fail(-38, "ic3_policy_forward: needs hid_size 64/128/256 and <= 64 agents per env");
@@ -1305,8 +1311,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
                                int32_t* done, int32_t* alive, int32_t* is_completed, ic3_stream stream)
 {
     ic3::Range range_("ic3_policy_step");
-    if (!env || !p || !h || !c || !out || !action || !reward || !done)
-        return fail(-22, "ic3_policy_step: null argument");
+    if (!env || !p || !h || !c) return fail(-22, "ic3_policy_step: null argument");
+    const bool inner = p->inner_pass != 0;                       // a non-final communication pass: h, c only
+    if (!inner && (!out || !action || !reward || !done)) return fail(-22, "ic3_policy_step: null argument");
+    if (inner) obs = nullptr;
     if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");
     if (!p->enc_wt || !p->enc_bias) return fail(-22, "ic3_policy_step: incomplete ic3_policy (encoder)");
     const int H = p->H;

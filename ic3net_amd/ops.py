@@ -172,39 +172,55 @@ def policy_step_supported(env, H):
     return H in POLICY_STEP_SIZES and _lib.lib().ic3_policy_step_supported(env._h, int(H)) > 0
 
 
-def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True):
+def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True, pass_index=0, inner=False):
+    """pass_index / inner: comm_passes > 1 — pass i uses C_modules[i] (cache keys '<name>_p<i>' for i > 0), every pass but
+    the last is an `inner` one (h, c only)."""
+    sfx = '' if pass_index == 0 else '_p%d' % pass_index
     pol = _lib.Policy()
+    pol.pass_index, pol.inner_pass = int(pass_index), int(bool(inner))
     pol.H, pol.nheads = int(H), len(head_sizes)
     for i, a in enumerate(head_sizes):
         pol.head_sizes[i] = int(a)
     pol.mode_avg, pol.comm_zero = int(bool(mode_avg)), int(bool(comm_zero))
     if encoder:
-        pol.enc_wt, pol.enc_bias = fc['wt'].data_ptr(), fc['enc_bias'].data_ptr()
+        pol.enc_wt, pol.enc_bias = fc['wt'].data_ptr(), fc['enc_bias' + sfx].data_ptr()
         pol.loc_table = fc['loc_table'].data_ptr() if fc.get('loc_table') is not None else None
-    pol.c_wp, pol.lstm_wp, pol.lstm_bias = fc['ps_c_wp'].data_ptr(), fc['ps_l_wp'].data_ptr(), fc['b_cat'].data_ptr()
+    pol.c_wp, pol.lstm_wp, pol.lstm_bias = fc['ps_c_wp' + sfx].data_ptr(), fc['ps_l_wp'].data_ptr(), fc['b_cat'].data_ptr()
     pol.head_w, pol.head_b = fc['w_heads'].data_ptr(), fc['b_heads'].data_ptr()
     return pol
 
 
-def policy_forward(fc, H, head_sizes, mode_avg, comm_zero, enc, E, N, h, c, alive_in, comm_in, out=None):
+def policy_forward(fc, H, head_sizes, mode_avg, comm_zero, enc, E, N, h, c, alive_in, comm_in, out=None, pass_index=0,
+                   inner=False):
     """The policy half of policy_step for a caller-supplied encoder output enc (E*N, H) = encoder(x) + C.bias
-    (ic3_policy_forward): communication block, C, LSTMCell, heads, log_softmax in one launch; h, c in place."""
+    (ic3_policy_forward): communication block, C, LSTMCell, heads, log_softmax in one launch; h, c in place.
+    inner=True: a non-final communication pass (comm_passes > 1) — h, c only, returns None."""
     import ctypes as C
     _need_cuda(enc, "policy_forward")
     R = E * N
     assert enc.is_contiguous() and enc.shape == (R, H) and h.is_contiguous() and c.is_contiguous()
     for m in (alive_in, comm_in):
         assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
-    if out is None:
+    if out is None and not inner:
         out = torch.empty((R, sum(head_sizes) + 1), dtype=torch.float32, device=enc.device)
-    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=False)
-    check(_lib.lib().ic3_policy_forward(C.byref(pol), ptr(enc), E, N, ptr(h), ptr(c), ptr(alive_in), ptr(comm_in), ptr(out),
-                                        stream()))
-    return out
+    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=False, pass_index=pass_index, inner=inner)
+    check(_lib.lib().ic3_policy_forward(C.byref(pol), ptr(enc), E, N, ptr(h), ptr(c), ptr(alive_in), ptr(comm_in),
+                                        None if inner else ptr(out), stream()))
+    return None if inner else out
+
+
+def policy_step_pass(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, comm_in, pass_index):
+    """A non-final communication pass of a comm_passes > 1 policy on the env's own state (ic3_policy_step with
+    ic3_policy.inner_pass): sparse encoder, communication block, C_modules[pass_index], LSTMCell — h, c in place."""
+    _need_cuda(h, "policy_step_pass")
+    import ctypes as C
+    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, pass_index=pass_index, inner=True)
+    check(_lib.lib().ic3_policy_step(env._h, C.byref(pol), ptr(h), ptr(c), ptr(alive_in), ptr(comm_in), None, None, None,
+                                     None, None, None, None, stream()))
 
 
 def policy_step(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, comm_in, out, action, reward, done,
-                alive=None, is_completed=None, obs=None):
+                alive=None, is_completed=None, obs=None, pass_index=0):
     """One whole rollout iteration (policy forward -> action draws -> env.step) in one launch — ic3_policy_step.
     `fc`: the policy's derived-weight cache (wt, enc_bias, loc_table, ps_c_wp, ps_l_wp, b_cat, w_heads, b_heads);
     h, c (E*N, H) contiguous, updated in place; out (E*N, OT); action (heads, E, N) int32."""
@@ -215,7 +231,7 @@ def policy_step(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, com
     assert action.numel() == len(head_sizes) * R and out.shape == (R, sum(head_sizes) + 1)
     for m in (alive_in, comm_in):
         assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
-    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero)
+    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, pass_index=pass_index)
     import ctypes as C
     check(_lib.lib().ic3_policy_step(env._h, C.byref(pol), ptr(h), ptr(c), ptr(alive_in), ptr(comm_in), ptr(out),
                                      ptr(action), ptr(obs), ptr(reward), ptr(done), ptr(alive), ptr(is_completed), stream()))

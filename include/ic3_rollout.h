@@ -371,6 +371,14 @@ typedef struct {
     const float* lstm_bias;
     const float* head_w;
     const float* head_b;
+    /* comm_passes > 1 (comm.py:179-218: the communication block + C_i + f_module run `comm_passes` times per step, each
+     * pass on the hidden state the previous one left).  One call = one pass: pass_index = i, c_wp / enc_bias = those of
+     * C_modules[i] (enc_bias = encoder.bias + C_i.bias); inner_pass != 0 for every pass but the last — such a call only
+     * updates h, c (out / action / obs / reward / done / alive / is_completed may be NULL, the env does not step).  The
+     * last pass is the ordinary call.  pass_index > 0 also tells an auto-reset handle that h, c are this step's, not
+     * the previous episode's.  Both 0: the one-pass policy of the BASELINE configs. */
+    int32_t pass_index;
+    int32_t inner_pass;
 } ic3_policy;
 
 int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */,

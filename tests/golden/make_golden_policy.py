@@ -179,8 +179,8 @@ def fullsize_case(name, env_name, N, H, steps, seed, heads, tj=None, pp=None, ga
         alive = np.stack(al).astype(np.float64) if tj is not None else None
     X = np.array(xs)                                                          # (steps, B, N, obs)
     nz = np.nonzero(X)
-    out = dict(cfg=np.array([N, obs_dim, H, steps, B, 1, 1, int(a.comm_mode == 'avg'), int(a.comm_mask_zero),
-                             int(bool(a.hard_attn)), 0, len(heads), 1], np.int32),
+    out = dict(cfg=np.array([N, obs_dim, H, steps, B, 1, int(a.comm_passes), int(a.comm_mode == 'avg'), int(a.comm_mask_zero),
+                             int(bool(a.hard_attn)), int(bool(a.share_weights)), len(heads), 1], np.int32),
                heads=np.array(heads, np.int32), x_nz=np.stack(nz).astype(np.int32), x_val=X[nz].astype(np.float32),
                alive=np.array(alives)[:, 0], comm_action=np.array(cas)[:, 0], value=np.array(outs_val),
                h=np.array(outs_h), c=np.array(outs_c))
@@ -212,6 +212,15 @@ def fullsize_main():
                   pp=dict(dim=5, vision=1), ic3net=True, recurrent=True, comm_mask_zero=True)
     fullsize_case('policy_h64_ic3net_b3', 'traffic_junction', 6, 64, 24, 46, [2, 2], B=3,
                   tj=dict(dim=6, vision=0, difficulty='easy', add_rate=0.4), ic3net=True, recurrent=True)
+
+
+def multipass_main():
+    """comm_passes > 1 on the recurrent policy (comm.py:179-218: every pass re-runs the communication block, its own
+    C_modules[i] — or the shared one — and the SAME LSTMCell on the state the previous pass left)."""
+    fullsize_case('policy_h64_ic3net_p2', 'traffic_junction', 6, 64, 24, 47, [2, 2], B=3,
+                  tj=dict(dim=6, vision=0, difficulty='easy', add_rate=0.4), ic3net=True, recurrent=True, comm_passes=2)
+    fullsize_case('policy_h128_commnet_p3share', 'predator_prey', 5, 128, 16, 48, [5], B=2,
+                  pp=dict(dim=8, vision=1), commnet=True, recurrent=True, comm_passes=3, share_weights=True)
 
 
 def baseline_case(name, kind, N, obs_dim, H, steps, seed, B=2, rnn_type='MLP'):
@@ -437,6 +446,8 @@ def trainer_fullsize_main():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':
         fullsize_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'multipass':
+        multipass_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         trainer_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':

@@ -11,7 +11,9 @@ POLICY_FIXTURES = ["policy_ic3net_small", "policy_ic3net_b3", "policy_commnet_re
                    # BASELINE configs 3-5 at full size + the H = 64 branches, on real env observations / alive masks
                    # (make_golden_policy.py fullsize)
                    "policy_tjmedium_closed", "policy_tjhard_closed", "policy_ppscaled_closed",
-                   "policy_h64_commnet_sum", "policy_h64_maskzero_b3", "policy_h64_ic3net_b3"]
+                   "policy_h64_commnet_sum", "policy_h64_maskzero_b3", "policy_h64_ic3net_b3",
+                   # comm_passes > 1 on the recurrent policy (make_golden_policy.py multipass): own C per pass / shared
+                   "policy_h64_ic3net_p2", "policy_h128_commnet_p3share"]
 
 
 def closed_form_weights(shapes, scale=0.05):
@@ -35,6 +37,11 @@ class PolicyCase(object):
         if closed:
             shapes = {str(n): eval(str(s)) for n, s in zip(fx["param_names"], fx["param_shapes"])}
             self.params = closed_form_weights(shapes)
+            if self.share:       # one C module under several state_dict names: load_state_dict copies them in order into
+                last = 'C_modules.%d.' % (self.comm_passes - 1)          # the same tensor — the last name wins
+                for k in list(self.params):
+                    if k.startswith('C_module.') or k.startswith('C_modules.'):
+                        self.params[k] = self.params[last + k.rsplit('.', 1)[1]]
             nz, val = fx["x_nz"], fx["x_val"]
             order = np.argsort(nz[0], kind='stable')
             self._nz, self._val = nz[:, order], val[order]

@@ -82,14 +82,14 @@ def test_tj_env_restarts_at_the_step_cap():
     assert s.auto_episodes == 2 * E and s.auto_success_sum == succ and s.auto_env_steps == 2 * E * cap
 
 
-def _trainer(E, T, seed, auto):
+def _trainer(E, T, seed, auto, passes=1):
     from ic3net_amd import data
     from ic3net_amd.action_utils import parse_action_args
     from ic3net_amd.comm import CommNetMLP
     from ic3net_amd.trainer import Trainer
     a = argparse.Namespace(
         batch_size=500, hid_size=64, recurrent=True, seed=seed, lrate=0.001, env_name='predator_prey', max_steps=T,
-        display=False, commnet=1, ic3net=True, nagents=2, comm_mode='avg', comm_passes=1, comm_mask_zero=False,
+        display=False, commnet=1, ic3net=True, nagents=2, comm_mode='avg', comm_passes=passes, comm_mask_zero=False,
         mean_ratio=0, rnn_type='LSTM', detach_gap=10, comm_init='uniform', hard_attn=1, comm_action_one=False,
         share_weights=False, nenvs=E, env_id_offset=400, store_states=False, gamma=1.0, normalize_rewards=False,
         entr=0, value_coeff=0.01, advantages_per_action=False, nenemies=1, dim=3, vision=1, moving_prey=False,
@@ -106,12 +106,14 @@ def _trainer(E, T, seed, auto):
     return Trainer(a, net, env), a, net
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_auto_reset_stream_equals_consecutive_reference_style_episodes(graph):
+@pytest.mark.parametrize("graph,passes", [(False, 1), (True, 1), (False, 2)])
+def test_auto_reset_stream_equals_consecutive_reference_style_episodes(graph, passes):
+    """passes = 2: comm_passes > 1 — ic3_policy_step once per communication pass; an env restarted inside the launch must
+    start from a zero state in the FIRST pass and keep the first pass's state in the second."""
     import oracle
     from oracle import philox, policy_ref
     E, T, seed, N = 30, 8, 17, 2
-    tr, a, net = _trainer(E, T, seed, True)
+    tr, a, net = _trainer(E, T, seed, True, passes)
     a.hip_graph = graph
     params = {k: v.detach().cpu().double().numpy() for k, v in net.state_dict().items()}
     orcs = [oracle.PPOracle(N, 3, 1, "mixed", seed=seed, env_gid=400 + e) for e in range(E)]
@@ -132,7 +134,7 @@ def test_auto_reset_stream_equals_consecutive_reference_style_episodes(graph):
             gate, tt = np.zeros(N), 0
             for t in range(T):
                 logp, value, hc = policy_ref.forward(params, obs[None].astype(np.float64), hc, None, gate,
-                                                     recurrent=True, hard_attn=True, nheads=2)
+                                                     recurrent=True, hard_attn=True, nheads=2, comm_passes=passes)
                 if e < 6:                                                  # fp64 numpy policy on 6 envs: 1e-5 (north_star)
                     for k in range(2):
                         assert np.abs(logp[k][0] - lp[k][t, e]).max() < 1e-5, (window, e, t, k)
@@ -165,7 +167,7 @@ def test_auto_reset_stream_equals_consecutive_reference_style_episodes(graph):
         total_eps += n_eps
         assert n_eps > E                                                   # episodes did end early and restart
     # run_batch counts the episodes actually played (stat normalisation main.py:219-225 divides by them)
-    tr2, a2, _ = _trainer(E, T, seed, True)
+    tr2, a2, _ = _trainer(E, T, seed, True, passes)
     a2.batch_size = 1
     batch, st = tr2.run_batch(0)
     assert st['num_episodes'] > E and st['num_steps'] == T * E

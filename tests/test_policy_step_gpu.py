@@ -21,8 +21,8 @@ pytestmark = pytest.mark.gpu
 from test_env_parity_gpu import make_pp, make_tj  # noqa: E402
 
 
-def policy_args(N, H, heads, hard_attn, mode='avg', mask_zero=False):
-    return argparse.Namespace(nagents=N, hid_size=H, comm_passes=1, recurrent=True, continuous=False,
+def policy_args(N, H, heads, hard_attn, mode='avg', mask_zero=False, passes=1):
+    return argparse.Namespace(nagents=N, hid_size=H, comm_passes=passes, recurrent=True, continuous=False,
                               naction_heads=list(heads), comm_mask_zero=mask_zero, share_weights=False,
                               comm_init='uniform', hard_attn=hard_attn, comm_mode=mode, rnn_type='LSTM', init_std=0.2)
 
@@ -55,10 +55,17 @@ def make_env(kind, kw, E, seed, offset):
 
 
 @pytest.mark.parametrize("kind,kw,H,hard_attn,E,T", CASES)
-@pytest.mark.parametrize("comm_mode", ["avg", "sum"])
+@pytest.mark.parametrize("comm_mode", ["avg", "sum", "avg-2passes"])
 def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_mode):
+    """("avg-2passes": comm_passes = 2 — the one-launch kernel once per communication pass against the generic
+    forward() of the same module, which is pinned to the reference by the multi-pass policy fixtures.)"""
     from ic3net_amd import ops
     from ic3net_amd.comm import CommNetMLP
+    passes = 1
+    if comm_mode == "avg-2passes":
+        if not ((kind == "pp" and kw['N'] in (10, 32) and E < 100) or (kind == "tj" and kw['N'] == 10)):
+            pytest.skip("comm_passes = 2 is covered on three shapes")
+        comm_mode, passes = "avg", 2
     if comm_mode == "sum" and not (kind == "pp" and kw['N'] in (10, 5)):
         pytest.skip("comm_mode='sum' is covered on two shapes")
     seed, offset = 13, 700
@@ -67,7 +74,7 @@ def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_
     nact = envA.dims.naction
     heads = [nact, 2] if hard_attn else [nact]
     torch.manual_seed(H + N)
-    netA = CommNetMLP(policy_args(N, H, heads, hard_attn, comm_mode), envA.obs_dim).cuda().float()
+    netA = CommNetMLP(policy_args(N, H, heads, hard_attn, comm_mode, passes=passes), envA.obs_dim).cuda().float()
     with torch.no_grad():                    # livelier logits than the default init
         for hd in netA.heads:
             hd.weight.mul_(4.0)

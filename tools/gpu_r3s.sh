@@ -1,0 +1,23 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/r3s
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_policy_gpu.py tests/test_policy_step_gpu.py tests/test_auto_reset_gpu.py tests/test_policy_step_onehop_gpu.py tests/test_trainer_gpu.py -m gpu -x -q -p no:cacheprovider > $O/pytest.log 2>&1
+tail -n 12 $O/pytest.log
+run() { name=$1; shift; timeout 300 env "$@" > $O/$name.json 2> $O/$name.err; python - $O/$name.json $name <<'PY'
+import json,sys
+try:
+    d=[json.loads(l) for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith('{')][-1]
+    r=d.get('roofline') or {}
+    t=d.get('timing') or {}
+    print("%-34s %.4f ms/step  %.1f M/s | kernel avg %.4f min %s med %s" % (sys.argv[2], d['ms_per_step'], d['value']/1e6, r.get('avg_launch_ms',0), t.get('launch_ms_min'), t.get('launch_ms_median')))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+}
+for W in pp_hard tj_hard tj_medium; do
+  B="python bench.py --no-cpu-baseline --steps 160 --warmup 16 --workload $W"
+  run warm_$W $B
+  run ${W}_a $B
+  run ${W}_b $B
+done
