@@ -1,6 +1,7 @@
-"""Throughput of the update path Trainer.train_batch (rollout + compute_grad + RMSprop), PP-hard:
-python tools/bench_train.py [nenvs] [updates] [native|autograd]   (default native: no-grad one-launch rollout + the
-explicit backward through time of ic3net_amd.bptt; autograd: the rollout keeps the autograd graph, rounds 1-2)."""
+"""Throughput of the update path Trainer.train_batch (rollout + compute_grad + RMSprop), PP-hard by default:
+python tools/bench_train.py [nenvs] [updates] [native|autograd] [workload] [dense_obs 0|1]   (default native: no-grad
+one-launch rollout + the explicit backward through time of ic3net_amd.bptt; autograd: the rollout keeps the autograd
+graph, rounds 1-2; dense_obs 0: the training rollout does not assemble observation rows nothing reads)."""
 import os
 import sys
 import time
@@ -14,7 +15,10 @@ def main():
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     updates = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     mode = sys.argv[3] if len(sys.argv) > 3 else 'native'
-    tr, a = bench.build_trainer('pp_hard', E, 0, 0, 0)
+    wl = sys.argv[4] if len(sys.argv) > 4 else 'pp_hard'
+    dense = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    tr, a = bench.build_trainer(wl, E, 0, 0, 0)
+    a.dense_obs = bool(dense)
     a.native_update = mode == 'native' 
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=E * a.max_steps)
@@ -39,9 +43,11 @@ def main():
         steps += st['num_steps']
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("train_batch [%s] PP-hard E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
-          "peak mem %.1f GB, gemm %s" % (mode, E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates, steps // updates,
-                                torch.cuda.max_memory_allocated() / 2 ** 30, 'TunableOp' if tune else 'default'))
+    label = wl + ("" if dense else " (no dense obs rows)")
+    print("train_batch [%s] %s E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
+          "peak mem %.1f GB, gemm %s" % (mode, label, E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates,
+                                         steps // updates, torch.cuda.max_memory_allocated() / 2 ** 30,
+                                         'TunableOp' if tune else 'default'))
 
 
 if __name__ == '__main__':
