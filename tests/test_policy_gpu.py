@@ -36,7 +36,6 @@ def test_policy_matches_reference(name, fused):
         from ic3net_amd import ops
         if not (pc.recurrent and pc.H in ops.POLICY_STEP_SIZES):
             pytest.skip("the one-launch policy kernel needs recurrent, H in {64,128,256}")
-        assert net._fused_ok([torch.zeros(1, device='cuda'), None]) or torch.is_grad_enabled()
     hid = net.init_hidden(pc.B) if pc.recurrent else None
     worst = 0.0
     with torch.no_grad():
