@@ -223,6 +223,7 @@ class CommNetMLP(nn.Module):
             else:
                 torch.addmm(fc['enc_bias'], x.reshape(R, -1), fc['wt'], out=enc)       # dense encoder GEMM
             mz = bool(self.args.comm_mask_zero)
+            self.mega_forwards = getattr(self, 'mega_forwards', 0) + 1
             for i in range(self.comm_passes - 1):                 # comm.py:179: every pass but the last updates h, c only
                 ops.policy_forward(fc, H, self.args.naction_heads, mode_avg, mz, self._enc_of_pass(fc, mb, enc, i), batch, n,
                                    h, c, alive, comm_action, pass_index=i, inner=True)

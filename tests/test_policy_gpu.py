@@ -57,6 +57,8 @@ def test_policy_matches_reference(name, fused):
                 worst = max(worst, np.abs(hid[0].cpu().numpy() - fx["h"][t]).max())
                 worst = max(worst, np.abs(hid[1].cpu().numpy() - fx["c"][t]).max())
     assert worst < TOL, worst
+    if fused == "mega":                                  # ... and it was the one-launch kernel that produced them
+        assert getattr(net, 'mega_forwards', 0) == pc.steps
 
 
 @pytest.mark.parametrize("E,N,H", [(64, 10, 128), (7, 3, 16), (33, 20, 128), (5, 32, 256), (3, 1, 64)])
