@@ -93,6 +93,10 @@ EXPORTS = {
     "ic3_comm_masked_mean": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
     "ic3_lstm_cell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
+    "ic3_commnet_forward_supported": (C.c_int, [C.c_int, C.c_int]),
+    "ic3_commnet_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ic3_commnet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 +
+                            [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "ic3_lstm_gates_backward_supported": (C.c_int, [C.c_int]),
     "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -79,6 +79,8 @@ class CommNetMLP(nn.Module):
         n, H = self.nagents, self.hid_size
         if self._fused_ok(x):
             return self._forward_fused(x, info)
+        if self._commnet_ok(x):
+            return self._forward_commnet(x, info)
         if self.args.recurrent:                                   # comm.py:117-122 (no tanh on this branch)
             x, (hidden_state, cell_state) = x
             x = self._encode(x)
@@ -128,6 +130,56 @@ class CommNetMLP(nn.Module):
         if sum(int(o) for o in a.naction_heads) + 1 > 16:
             return False
         return isinstance(x, (list, tuple)) and x[0].is_cuda and self.encoder.weight.dtype == torch.float32
+
+    def _commnet_ok(self, x):
+        """The non-recurrent module on the fused path: every communication pass in one ic3_commnet_forward launch."""
+        a = self.args
+        if torch.is_grad_enabled() or not getattr(a, 'fused_policy', True) or not getattr(a, 'mega_policy', True):
+            return False
+        if a.recurrent or getattr(self, 'continuous', False) or len(self.heads) > 4:
+            return False
+        if sum(int(o) for o in a.naction_heads) + 1 > 16 or not torch.is_tensor(x) or not x.is_cuda:
+            return False
+        return self.encoder.weight.dtype == torch.float32 and ops.commnet_forward_supported(self.hid_size, self.nagents)
+
+    def _commnet_cache(self):
+        ps = [self.encoder.weight, self.encoder.bias, self.value_head.weight, self.value_head.bias] + \
+            [q for m in list(self.C_modules) + list(self.f_modules) for q in (m.weight, m.bias)] + \
+            [q for hd in self.heads for q in (hd.weight, hd.bias)]
+        key = tuple((q._version, q.data_ptr()) for q in ps)
+        if getattr(self, '_cn_key', None) != key:
+            with torch.no_grad():
+                wt = self.encoder.weight.t().contiguous()
+                wp, bias = ops.commnet_pack([m.weight for m in self.C_modules], [m.weight for m in self.f_modules],
+                                            [m.bias for m in self.C_modules], [m.bias for m in self.f_modules])
+                self._cn = dict(wt=wt, enc_bias=self.encoder.bias.detach().contiguous(), wp=wp, bias=bias,
+                                loc_table=self.obs_table(wt) if self.obs_table is not None else None,
+                                w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
+                                b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
+            self._cn_key = key
+        return self._cn
+
+    def _forward_commnet(self, x, info):
+        n, H = self.nagents, self.hid_size
+        batch = x.size(0)
+        R, dev = batch * n, x.device
+        cn = self._commnet_cache()
+        alive = self._mask(info, 'alive_mask', batch, dev)
+        comm_action = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
+        mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
+        buf = getattr(self, '_cnb', None)
+        if buf is None or buf.shape[0] != R or buf.device != dev:
+            buf = self._cnb = torch.empty((R, H), dtype=torch.float32, device=dev)
+        if self._x_is_env_obs(x):
+            self.obs_encoder(cn['wt'], cn['enc_bias'], out=buf, loc_table=cn['loc_table'])
+        else:
+            torch.addmm(cn['enc_bias'], x.reshape(R, -1), cn['wt'], out=buf)             # dense encoder GEMM
+        out = ops.commnet_forward(buf, batch, n, cn['wp'], cn['bias'], cn['w_heads'], cn['b_heads'],
+                                  self.args.naction_heads, mode_avg, bool(self.args.comm_mask_zero), alive, comm_action)
+        self.commnet_forwards = getattr(self, 'commnet_forwards', 0) + 1
+        self.sampled = False
+        action, value = self._split_out(out, batch, n)
+        return action, value.reshape(batch, n, 1)                 # comm.py:228 on a (B, N, H) hidden state (shape quirk Q25)
 
     def _x_is_env_obs(self, x):
         """The sparse encoder evaluates encoder(obs(env's CURRENT integer state)) without reading x; that is only

@@ -108,6 +108,42 @@ def lstm_cell_backward(gates, c_prev, dh, dc, dgates, dc_prev, dbias_partials=No
     return dbias_partials[:n] if dbias_partials is not None else None
 
 
+def commnet_forward_supported(H, N):
+    return bool(_lib.lib().ic3_commnet_forward_supported(int(H), int(N)))
+
+
+def commnet_pack(c_weights, f_weights, c_biases, f_biases):
+    """Per-pass [C_i | F_i] in the layout ic3_commnet_forward streams + the summed biases: lists of (H,H) / (H,) tensors."""
+    _need_cuda(c_weights[0], "commnet_pack")
+    H, P, dev = c_weights[0].shape[0], len(c_weights), c_weights[0].device
+    wp = torch.empty((P, 2 * H * H), dtype=torch.float32, device=dev)
+    for i in range(P):
+        check(_lib.lib().ic3_commnet_pack(ptr(c_weights[i].detach().contiguous().float()),
+                                          ptr(f_weights[i].detach().contiguous().float()), ptr(wp[i]), H, stream()))
+    bias = torch.stack([(c_biases[i] + f_biases[i]).detach().float() for i in range(P)]).contiguous()
+    return wp, bias
+
+
+def commnet_forward(enc, E, N, wp, bias, head_w, head_b, head_sizes, mode_avg, comm_zero, alive_in, comm_in, out=None,
+                    h_out=None):
+    """The non-recurrent CommNet module after the encoder, every communication pass in one launch (ic3_commnet_forward):
+    enc (E*N, H) = encoder(obs) incl. bias -> out (E*N, OT) = [log-probs of every head | value]."""
+    import ctypes as C
+    _need_cuda(enc, "commnet_forward")
+    R, H = enc.shape
+    assert R == E * N and enc.is_contiguous() and enc.dtype == torch.float32
+    for m in (alive_in, comm_in):
+        assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+    OT = sum(int(a) for a in head_sizes) + 1
+    if out is None:
+        out = torch.empty((R, OT), dtype=torch.float32, device=enc.device)
+    sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
+    check(_lib.lib().ic3_commnet_forward(ptr(enc), E, N, H, wp.shape[0], ptr(wp), ptr(bias), ptr(head_w), ptr(head_b), sizes,
+                                         len(head_sizes), int(bool(mode_avg)), int(bool(comm_zero)), ptr(alive_in),
+                                         ptr(comm_in), ptr(out), ptr(h_out), stream()))
+    return out
+
+
 def lstm_gates_backward_supported(H):
     return bool(_lib.lib().ic3_lstm_gates_backward_supported(int(H)))
 

@@ -381,6 +381,21 @@ typedef struct {
     int32_t inner_pass;
 } ic3_policy;
 
+/* The NON-recurrent CommNet module after the encoder (comm.py:127-129,179-205,220-224,228-239), every communication pass
+ * in ONE launch:  x = tanh(enc);  h_0 = x;  h_{i+1} = tanh(x + f_modules[i](h_i) + C_modules[i](comm(h_i)));
+ * out [E*N][OT] = [log_softmax(heads_k(h)) ... | value_head(h)].  enc [E*N][H] = encoder(obs) including its bias
+ * (ic3_env_encode or a dense GEMM); wp = comm_passes blocks of 2*H*H floats, block i = ic3_commnet_pack(C_modules[i].weight,
+ * f_modules[i].weight); bias [comm_passes][H] = C_i.bias + f_i.bias; head_w / head_b / head_sizes as ic3_policy_heads;
+ * alive_in / comm_in as ic3_policy_step (NULL = everyone alive / talking); h_out [E*N][H] or NULL receives the final
+ * hidden state.  hid_size 64 / 128 / 256, <= 64 agents per env (ic3_commnet_forward_supported), else -ENOSYS. */
+int ic3_commnet_forward_supported(int H, int N);
+int ic3_commnet_pack(const float* C_weight /* [H][H] */, const float* f_weight /* [H][H] */, float* wp /* [2*H*H] */, int H,
+                     ic3_stream stream);
+int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, const float* wp, const float* bias,
+                        const float* head_w, const float* head_b, const int32_t* head_sizes, int nheads, int mode_avg,
+                        int comm_zero, const int32_t* alive_in, const int32_t* comm_in, float* out, float* h_out /* or NULL */,
+                        ic3_stream stream);
+
 int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */,
                     float* c_wp /* H*H */, float* lstm_wp /* 4H*2H */, int H, ic3_stream stream);
 int ic3_policy_step_supported(const ic3_env* env, int H); /* 0, or the LDS bytes per workgroup */

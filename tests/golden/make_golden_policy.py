@@ -223,6 +223,13 @@ def multipass_main():
                   pp=dict(dim=8, vision=1), commnet=True, recurrent=True, comm_passes=3, share_weights=True)
 
 
+def nonrec_main():
+    """The non-recurrent module (comm.py:127-129,220-224) at the hid sizes ic3_commnet_forward covers."""
+    policy_case('policy_h64_commnet_mlp2', 4, 29, 64, 5, 31, B=2, commnet=True, comm_passes=2)
+    policy_case('policy_h64_commnet_mlp3share', 5, 29, 64, 5, 32, B=3, commnet=True, comm_passes=3, share_weights=True)
+    policy_case('policy_h128_ic3net_mlp1', 6, 29, 128, 6, 33, B=2, ic3net=True)
+
+
 def baseline_case(name, kind, N, obs_dim, H, steps, seed, B=2, rnn_type='MLP'):
     """IC / IRIC baselines: the reference's models.MLP / models.RNN (models.py:8-97), free-running."""
     ref = rh.load_reference()
@@ -448,6 +455,8 @@ if __name__ == '__main__':
         fullsize_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'multipass':
         multipass_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'nonrec':
+        nonrec_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         trainer_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':

@@ -13,7 +13,9 @@ POLICY_FIXTURES = ["policy_ic3net_small", "policy_ic3net_b3", "policy_commnet_re
                    "policy_tjmedium_closed", "policy_tjhard_closed", "policy_ppscaled_closed",
                    "policy_h64_commnet_sum", "policy_h64_maskzero_b3", "policy_h64_ic3net_b3",
                    # comm_passes > 1 on the recurrent policy (make_golden_policy.py multipass): own C per pass / shared
-                   "policy_h64_ic3net_p2", "policy_h128_commnet_p3share"]
+                   "policy_h64_ic3net_p2", "policy_h128_commnet_p3share",
+                   # the non-recurrent module at hid 64 / 128 (make_golden_policy.py nonrec): 2 passes, 3 shared passes, gated
+                   "policy_h64_commnet_mlp2", "policy_h64_commnet_mlp3share", "policy_h128_ic3net_mlp1"]
 
 
 def closed_form_weights(shapes, scale=0.05):

@@ -25,7 +25,8 @@ def build(pc):
 def test_policy_matches_reference(name, fused):
     """"mega": the no-grad rollout fast path with everything after the encoder as ONE launch (ic3_policy_forward, the
     policy half of ic3_policy_step: communication block, C, LSTMCell, heads, log_softmax) where it applies (recurrent,
-    H in {64,128,256}; comm_passes > 1: one launch per communication pass); "chain": the same path as separate launches (one [inp|h] buffer, library GEMMs,
+    H in {64,128,256}; comm_passes > 1: one launch per communication pass; the non-recurrent module: ic3_commnet_forward,
+    every pass in one launch); "chain": the same path as separate launches (one [inp|h] buffer, library GEMMs,
     lstm_cell / policy_heads HIP kernels); False: the generic torch path + comm_masked_mean op."""
     pc = PolicyCase(name)
     fx = pc.fx
@@ -34,8 +35,8 @@ def test_policy_matches_reference(name, fused):
     net.args.mega_policy = (fused == "mega")
     if fused == "mega":
         from ic3net_amd import ops
-        if not (pc.recurrent and pc.H in ops.POLICY_STEP_SIZES):
-            pytest.skip("the one-launch policy kernel needs recurrent, H in {64,128,256}")
+        if pc.H not in ops.POLICY_STEP_SIZES:
+            pytest.skip("the one-launch policy kernels need H in {64,128,256}")
     hid = net.init_hidden(pc.B) if pc.recurrent else None
     worst = 0.0
     with torch.no_grad():
@@ -58,7 +59,7 @@ def test_policy_matches_reference(name, fused):
                 worst = max(worst, np.abs(hid[1].cpu().numpy() - fx["c"][t]).max())
     assert worst < TOL, worst
     if fused == "mega":                                  # ... and it was the one-launch kernel that produced them
-        assert getattr(net, 'mega_forwards', 0) == pc.steps
+        assert getattr(net, 'mega_forwards' if pc.recurrent else 'commnet_forwards', 0) == pc.steps
 
 
 @pytest.mark.parametrize("E,N,H", [(64, 10, 128), (7, 3, 16), (33, 20, 128), (5, 32, 256), (3, 1, 64)])

@@ -483,3 +483,51 @@ def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     for k in g1:
         scale = max(float(g2[k].abs().max()), 1e-6)
         np.testing.assert_allclose(g1[k].cpu().numpy() / scale, g2[k].cpu().numpy() / scale, rtol=0, atol=5e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("env_name,flags", [
+    ("predator_prey", dict(nagents=5, dim=8, vision=1, hid_size=64, commnet=True, comm_passes=2)),
+    ("traffic_junction", dict(nagents=6, dim=6, vision=1, hid_size=128, ic3net=True, add_rate_min=0.3, add_rate_max=0.3)),
+])
+def test_nonrecurrent_commnet_rollout_runs_on_the_one_launch_module(env_name, flags):
+    """recurrent = False at hid 64 / 128: the rollout's policy_net(x, info) is ONE ic3_commnet_forward launch behind the
+    sparse encoder; same transitions as the generic module path (args.fused_policy = False) on a twin env — log-probs and
+    values within fp32 rounding, hence (away from CDF edges) the same draws, rewards and masks; and one update runs."""
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    import copy
+    T, E = 12, 24
+    trs = []
+    for fused in (True, False):
+        a = build_args(env_name, dict(flags), flags['nagents'], T, E, 5)
+        a.env_id_offset = 0
+        env = data.init(env_name, a, False)
+        a.num_actions, a.dim_actions, a.num_inputs = [env.num_actions], env.dim_actions, env.observation_dim
+        if a.hard_attn and a.commnet:
+            a.num_actions, a.dim_actions = [env.num_actions, 2], env.dim_actions + 1
+        a.continuous = False
+        a.fused_policy = fused
+        parse_action_args(a)
+        torch.manual_seed(3)
+        net = CommNetMLP(a, a.num_inputs).cuda().float()
+        trs.append((trmod.Trainer(a, net, env), net, a))
+    (trA, netA, aA), (trB, netB, aB) = trs
+    epA, statA = trA.get_episode(0)
+    epB, statB = trB.get_episode(0)
+    assert getattr(netA, 'commnet_forwards', 0) == T and getattr(netB, 'commnet_forwards', 0) == 0
+    assert len(epA) == len(epB) == T
+    same = 0
+    for ta, tb in zip(epA, epB):
+        for k in range(len(ta.action_out)):
+            assert float((ta.action_out[k] - tb.action_out[k]).abs().max()) < 2e-5
+        assert float((ta.value - tb.value).abs().max()) < 2e-5
+        if not torch.equal(ta.action, tb.action):
+            break                                  # a draw on a CDF edge: the trajectories part ways (legitimately)
+        assert torch.equal(ta.reward, tb.reward) and torch.equal(ta.episode_mask, tb.episode_mask)
+        same += 1
+    assert same >= 3
+    aA.batch_size = E * T
+    before = netA.encoder.weight.detach().clone()
+    st = trA.train_batch(0)
+    assert np.isfinite(st['action_loss']) and not torch.equal(before, netA.encoder.weight)
