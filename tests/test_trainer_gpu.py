@@ -140,6 +140,9 @@ def test_run_batch_surface():
                               difficulty='medium', add_rate_min=0.2, add_rate_max=0.2)),
     ("traffic_junction", dict(nagents=5, dim=6, vision=0, hid_size=32, commnet=True, recurrent=True, detach_gap=10,
                               difficulty='easy', add_rate_min=0.1, add_rate_max=0.3, curr_start=0, curr_end=4)),
+    # the one-launch kernel, two communication passes (two launches per captured step)
+    ("predator_prey", dict(nagents=5, dim=10, vision=1, hid_size=64, ic3net=True, recurrent=True, detach_gap=10,
+                           comm_passes=2)),
 ])
 def test_hip_graph_replay_equals_eager(env_name, flags):
     """args.hip_graph: episode 0 eager, episode 1 captured, episodes 2.. replayed — every episode must be
