@@ -56,8 +56,9 @@ typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef IC3_PS_AGPR
 #define IC3_PS_AGPR 0   // the 128/128 VGPR/AGPR split spills (round 2: net slower, 0.57 vs 0.52 ms; round 3: the compiler keeps
-                        // the old cell state in scratch across the gate loop, 97 spills, also with the C product's
-                        // accumulators left to it) — gates_bwd.hip, which has no phases around its loop, does use AGPRs
+                        // the old cell state in scratch across the gate loop, 97 spills; with it requested inside a common
+                        // loop tail instead — commit 864dc03, profiles/r03/agpr_gate_loop.txt — 1 spill, -6 % without obs
+                        // rows, +1.5 % with them) — gates_bwd.hip, which has no phases around its loop, does use AGPRs
 #endif
 // Timing ablations are COMPILE-TIME only (tools/build_variant.sh abl1 -DIC3_PS_ABL=1 ...): a set bit removes a phase and
 // makes the results wrong, so no environment variable of the shipped library can do it.  Bits: 1 gate MFMA loop,
@@ -65,13 +66,6 @@ typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
 // stores issued but dropped.
 #ifndef IC3_PS_ABL
 #define IC3_PS_ABL 0
-#endif
-#ifndef IC3_PS_LATE_C
-#define IC3_PS_LATE_C (IC3_PS_AGPR ? 2 : 0)   // where the old cell state is requested.  0: in front of the C product (a quarter
-                                    // of a tile's life ahead of its use).  2: behind the first fill of the gate operand
-                                    // ring — 32 VGPRs fewer across the comm phase and the C product, what the AGPR build
-                                    // needs.  1: inside the last two K blocks, which then are common code without store
-                                    // slots (measured slower with obs rows: the loads queue behind the zero stores)
 #endif
 #ifndef IC3_PS_RING
 #define IC3_PS_RING 8   // float4 slots of the gate GEMM's B-operand ring (4: one K block, 8: two)
@@ -497,20 +491,19 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // stream — here the comm phase and the C product cover it — and behind the loop it would queue up behind the
         // zero stores (one counter, in order).  Rows >= `rows` read as zeros (range check).  32 registers held through
         // the loop.
-        const __amdgpu_buffer_rsrc_t rc_old = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
-        const int voff_old = (4 * lh * H + col) * 4;
-        auto load_cold = [&]() {
+        {
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
+            const int voff = (4 * lh * H + col) * 4;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 if (rt == 1 && !two) break;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-                    cold[rt][reg] = buf_load_b32(rc_old, voff_old + lc * H * 4, 0);
+                    cold[rt][reg] = buf_load_b32(rc, voff + lc * H * 4, 0);
                 }
             }
-        };
-        if (IC3_PS_LATE_C == 0) load_cold();
+        }
         if (g.obs_here) {
 #pragma unroll 1
             for (int i = 0; i < a.z3; ++i) zero_store();
@@ -611,7 +604,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         ps_f32x4 wk[RING];
 #pragma unroll
         for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
-        if (IC3_PS_LATE_C == 2) load_cold();                     // (behind the ring fill: the first MFMAs do not wait for it)
         __builtin_amdgcn_sched_barrier(0);
         // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------
 #pragma unroll
@@ -640,12 +632,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
         // `SB` = first ring slot of this K block, REFILL = the ring is refilled for block kb + RING / 4.  The compiler's
         // waits in front of each k sub-step come out exact: vmcnt(RING - 1 + stores issued since the slot's refill).
-        auto block = [&](auto two_c, auto s_c, auto sb_c, auto refill_c, int kb, auto loadc_c) {
+        auto block = [&](auto two_c, auto s_c, auto sb_c, auto refill_c, int kb) {
             constexpr bool TWO = decltype(two_c)::value;
             constexpr int S = decltype(s_c)::value;
             constexpr int SB = decltype(sb_c)::value;
             constexpr bool REFILL = decltype(refill_c)::value;
-            constexpr bool LOADC = decltype(loadc_c)::value;
             const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
             ps_f32x4 a1;
             if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
@@ -663,22 +654,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                     }
                 }
                 if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
-                if constexpr (LOADC) {                            // four old cell states into the ring slot just retired:
-#pragma unroll                                                   // row tile 0 in block KB - 2, row tile 1 in block KB - 1
-                    for (int q = 0; q < 4; ++q) {
-                        constexpr int rt = SB / 4;
-                        const int reg = 4 * j + q;
-                        if (TWO || rt == 0)
-                            cold[rt][reg] = buf_load_b32(rc_old, voff_old, (32 * rt + (reg & 3) + 8 * (reg >> 2)) * H * 4);
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // With IC3_PS_LATE_C the last two K blocks are COMMON code behind the store-slot variants (no store slots in
-        // them): the old cell state is requested there, into the ring slots that are no longer refilled — inside the
-        // variants the register allocator had to bring the 32 values to the same registers at the merge point of 24
-        // code paths and spilled some of them behind an s_waitcnt vmcnt(0).
         auto gate_loop = [&](auto two_c, auto s_c) {
             static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
             constexpr std::integral_constant<int, 0> s0{};
@@ -686,22 +664,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             if (!(ABL & 1)) {
 #pragma unroll 1
                 for (int kb = 0; kb < KB - 2; kb += 2) {
-                    block(two_c, s_c, s0, std::true_type{}, kb, std::false_type{});
-                    block(two_c, s_c, s1, std::true_type{}, kb + 1, std::false_type{});
+                    block(two_c, s_c, s0, std::true_type{}, kb);
+                    block(two_c, s_c, s1, std::true_type{}, kb + 1);
                 }
-                if constexpr (IC3_PS_LATE_C != 1) {
-                    block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2, std::false_type{});
-                    block(two_c, s_c, s1, std::false_type{}, KB - 1, std::false_type{});
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto gate_tail = [&](auto two_c) {
-            static_assert(IC3_PS_LATE_C != 1 || RING == 8, "late c loads: ring of two K blocks");
-            constexpr std::integral_constant<int, 0> none{};
-            if (!(ABL & 1)) {
-                block(two_c, none, std::integral_constant<int, 0>{}, std::false_type{}, KB - 2, std::true_type{});
-                block(two_c, none, std::integral_constant<int, 4>{}, std::false_type{}, KB - 1, std::true_type{});
+                block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2);
+                block(two_c, s_c, s1, std::false_type{}, KB - 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -720,7 +687,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             case 16: gate_loop(two_c, std::integral_constant<int, 16>{}); break;
             default: gate_loop(two_c, std::integral_constant<int, 0>{}); break;
             }
-            if constexpr (IC3_PS_LATE_C == 1) gate_tail(two_c);
         };
         if (two) gate_loop_s(std::true_type{});
         else gate_loop_s(std::false_type{});
@@ -1408,7 +1374,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
             }
         }
         a.zs = zs;
-        long long left = per_wave - (long long)zs * (KBv - (IC3_PS_LATE_C == 1 ? 2 : 0));   // (no slots in a common tail)
+        long long left = per_wave - (long long)zs * KBv;
         auto take = [&](int want) {
             const int n = (fused_obs && !incr_valid) ? (int)std::min<long long>(std::max<long long>(left, 0), std::max(want, 0)) : 0;
             left -= n;
