@@ -129,9 +129,6 @@ struct StepArgs {
     int zs;                     // stores per K block of the gate loop (one of ZS_SET; a block = 32 MFMAs of a full tile)
     int zf, zepi, zh;           // stores in front of the comm phase; per element of the cell epilogue (0..2); in front of the heads
     int z0, z3, zc;             // stores behind the loads of S0; behind the request of the old cell state; K blocks of the C product with a slot
-    int stagger, first_round;   // first-round workgroups that come second on their CU start `stagger` x 3.5 us late
-    int32_t* cu_slots;          // [16384] running count of workgroups per CU (parity = which of the two residents)
-    int32_t* cu_lock;           // [16384] or null: one gate loop at a time per CU (see the kernel)
     int zrest;                  // stores per wave issued behind the cell epilogue (what the other slots left)
     // recurrent state, masks, outputs
     float* h;                   // [R][H] in place
@@ -266,21 +263,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             a.trace[(size_t)blockIdx.x * 20 + 19] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
         }
 #endif
-        // The launch starts with two workgroups per CU in lockstep: every CU of the chip reaches its gate loop — and its
-        // obs zero stores — at the same moment, HBM takes ~5.3 TB/s of writes, and the first round's gate loops stretch
-        // to the time their stores need (round-3 phase trace: 76 us against 51 us two rounds later, when the residents
-        // of a CU have drifted apart).  The second resident of each CU therefore starts half a tile life late: the CU's
-        // store stream becomes continuous instead of bursty.  (Speed only; parity from a per-CU arrival count.)
-        if (tid == 0) {   // this CU's index (XCC, SE, SH, CU of HW_ID) for the per-CU words below
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            sfm[3] = (xcc & 15u) * 1024u + ((hw >> 13) & 7u) * 64u + ((hw >> 12) & 1u) * 32u + ((hw >> 8) & 15u);
-        }
-        if (a.stagger > 0 && a.cu_slots && (int)blockIdx.x < a.first_round) {
-            if (tid == 0) sfm[2] = (uint32_t)atomicAdd(&a.cu_slots[sfm[3]], 1);
-            __syncthreads();
-            if (sfm[2] & 1u)
-                for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-        }
+        // (Two experiments on the co-residency of the two workgroups of a CU were measured in round 3 and removed again:
+        //  a start stagger of the second resident, and a per-CU lock that lets one gate loop run at a time — the loops
+        //  did take turns, 36 us instead of 76, and the phases around them stretched by exactly what the loops gained:
+        //  an fp32 MFMA stream leaves the vector ALU to nobody.  profiles/r03/gate_lock.txt, pacing_sweep.txt.)
         const int N = a.N;
         const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
         const int total = a.pp.Np + a.pp.nprey;
@@ -615,17 +601,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 As[lr * LDA + col] = accC[rt][reg];
             }
         }
-        // Experiment (IC3_PS_GATELOCK=1, off by default): ONE gate loop at a time per CU — a spin on a per-CU word in
-        // global memory (both residents share an L2), held from here to the barrier behind the loop.  Two co-resident
-        // workgroups that start together run their gate loops together, each MFMA stream getting half of its SIMD; with
-        // the loops taking turns one workgroup streams MFMAs while the other runs its epilogue / heads / draws / env step
-        // and the front phases of its next tile.  Measured (round 3): the loops do take turns (36 us instead of 76) and
-        // the other phases stretch by exactly what the loops gain — an fp32 MFMA stream leaves the vector ALU to nobody,
-        // so the phases around it are not hidden behind it, they are starved by it.
-        if (a.cu_lock && tid == 0) {
-            int32_t* lk = a.cu_lock + sfm[3];
-            while (atomicCAS(lk, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
-        }
         __syncthreads();
         IC3_TR(8);
 
@@ -744,7 +719,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         if ((fmask >> (32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh)) & 1) cold[rt][reg] = 0.0f;
             }
             __syncthreads();   // every wave is done with the A tile
-            if (a.cu_lock && tid == 0) atomicExch(a.cu_lock + sfm[3], 0);   // the other resident's gate loop may start
             IC3_TR(11);
             // head / value weights -> rows [0, OT) of the inp half: requested now, written to LDS behind the element loop
             // (the compiler's wait there allows the >= 32 stores issued meanwhile to stay in flight)
@@ -1389,34 +1363,6 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.zepi = (!fused_obs || incr_valid) ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
         left -= 32LL * a.zepi;
         a.zrest = (fused_obs && !incr_valid) ? (int)(left > 0 ? left + 1 : 0) : 0;
-    }
-    {   // first-round stagger (see the kernel): per-device arrival counters, allocated once
-        static const int stagger_env = getenv("IC3_PS_STAGGER") ? atoi(getenv("IC3_PS_STAGGER")) : -1;
-        static int32_t* slots[64] = { nullptr };
-        static int32_t* locks[64] = { nullptr };
-        // (experiment, off: profiles/r03/gate_lock.txt — the loops do take turns, 36 instead of 76 us each, and the phases
-        //  around them stretch by the same amount: the SIMD issues one or the other, the launch takes the same time)
-        static const int lock_env = getenv("IC3_PS_GATELOCK") ? atoi(getenv("IC3_PS_GATELOCK")) : 0;
-        int dev = 0;
-        a.stagger = 0;
-        a.cu_lock = nullptr;
-        if (lock_env && H <= 128 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {   // two residents per CU
-            if (!locks[dev]) {
-                IC3_HIP(hipMalloc(&locks[dev], 16384 * sizeof(int32_t)));
-                IC3_HIP(hipMemset(locks[dev], 0, 16384 * sizeof(int32_t)));
-            }
-            a.cu_lock = locks[dev];
-        }
-        const int want = stagger_env >= 0 ? stagger_env : 0;
-        if (fused_obs && want > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-            if (!slots[dev]) {
-                IC3_HIP(hipMalloc(&slots[dev], 16384 * sizeof(int32_t)));
-                IC3_HIP(hipMemset(slots[dev], 0, 16384 * sizeof(int32_t)));
-            }
-            a.cu_slots = slots[dev];
-            a.stagger = want;
-            a.first_round = device_cus() * (H <= 128 ? 2 : 1);
-        }
     }
     hipStream_t s = (hipStream_t)stream;
     int rc;

@@ -340,7 +340,7 @@ def test_result_changing_environment_knobs_are_gone():
     base = run({})
     assert run({"IC3_PS_DEBUG": "63", "IC3_PS_ZMODE": "48", "IC3_PS_SKEW": "9", "IC3_PS_WGS": "1"}) == base
     assert run({"IC3_PS_ZS": "2", "IC3_PS_ZF": "9", "IC3_PS_ZFRAC": "40", "IC3_PS_HALF": "1", "IC3_PS_ZEPI": "0",
-                "IC3_PS_STAGGER": "3", "IC3_PS_Z0": "5", "IC3_PS_Z3": "5", "IC3_PS_ZC": "4", "IC3_PS_ZH": "6"}) == base
+                "IC3_PS_Z0": "5", "IC3_PS_Z3": "5", "IC3_PS_ZC": "4", "IC3_PS_ZH": "6"}) == base
 
 
 @pytest.mark.parametrize("workload,E", [("pp_hard", 29), ("tj_hard", 11), ("tj_medium", 16)])
