@@ -1382,8 +1382,12 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         if (tiles == trace_tiles) a.trace = trace_buf;
     }
 #endif
-    hipEvent_t ev0 = (hipEvent_t)env->ev_start, ev1 = (hipEvent_t)env->ev_stop;   // one-shot (ic3_env_set_step_events)
-    env->ev_start = env->ev_stop = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (!inner) {                                                // one-shot (ic3_env_set_step_events): the step's LAST launch
+        ev0 = (hipEvent_t)env->ev_start;
+        ev1 = (hipEvent_t)env->ev_stop;
+        env->ev_start = env->ev_stop = nullptr;
+    }
     if (H == 128)
         rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
     else if (H == 64)
