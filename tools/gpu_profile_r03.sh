@@ -13,7 +13,7 @@ timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests_gpu
 B="python bench.py --steps 160 --warmup 16 --no-cpu-baseline"
 timeout 600 python bench.py --steps 160 --warmup 16 > $O/bench_pp_hard.json 2> $O/bench_pp_hard.err
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_pp_hard_driver_args.json 2>/dev/null
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rccl 1 > $O/bench_pp_hard_driver_args_rccl_world1.json 2>/dev/null
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rccl 1 > $O/bench_pp_hard_driver_args_rccl_world1.json 2> $O/rccl_world1.err
 for w in tj_hard tj_medium pp_easy; do timeout 300 $B --workload $w > $O/bench_$w.json 2> /dev/null; done
 timeout 600 $B --workload pp_scaled --steps 24 --warmup 4 > $O/bench_pp_scaled.json 2> $O/bench_pp_scaled.err
 timeout 300 $B --auto-reset 1 > $O/bench_pp_hard_auto_reset.json 2>/dev/null
