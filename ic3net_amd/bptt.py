@@ -25,10 +25,10 @@ from . import ops
 
 
 def supported(args, net, raw):
-    """Recurrent LSTM CommNet / IC3Net, one communication pass, sparse encoder bound to this env."""
+    """Recurrent LSTM CommNet / IC3Net (any number of communication passes), sparse encoder bound to this env."""
     if not (getattr(args, 'recurrent', False) and getattr(args, 'rnn_type', '') == 'LSTM' and hasattr(net, 'f_module')):
         return False
-    if getattr(net, 'comm_passes', 1) != 1 or args.hid_size % 4 or not hasattr(raw, 'encode_at'):
+    if getattr(net, 'comm_passes', 1) < 1 or args.hid_size % 4 or not hasattr(raw, 'encode_at'):
         return False
     if getattr(net.obs_encoder, '__self__', None) is not raw or net.nagents != raw.nagents_env:
         return False
@@ -124,6 +124,8 @@ def loss_gradients(args, batch):
 def backward_episode(args, net, raw, rec, d_out, acc):
     """Backward through one recorded episode; parameter gradients are ADDED into `acc` (fp32 tensors keyed like the
     fused weight cache)."""
+    if net.comm_passes > 1:
+        return _backward_episode_multipass(args, net, raw, rec, d_out, acc)
     fc = net._fused_cache()
     T, R, H = rec.n, rec.hs.shape[1], rec.hs.shape[2]
     N = net.nagents
@@ -202,13 +204,94 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         acc['b_cat'].add_(bias_parts.sum(0))
 
 
+def _backward_episode_multipass(args, net, raw, rec, d_out, acc):
+    """comm_passes > 1 (comm.py:179-218): the step's passes are re-evaluated forward from the (h, c) that entered the step
+    — pass i: comm_i = mix(h_i), inp_i = enc + C_i(comm_i), (h_{i+1}, c_{i+1}) = LSTMCell(inp_i, (h_i, c_i)), every pass's
+    [inp | h], comm and c kept for the duration of the step — and then differentiated last pass first; the encoder sees
+    the sum of the passes' d inp.  Plain launch chain (library GEMMs + the pointwise kernels): this is f3 coverage."""
+    fc = net._fused_cache()
+    P = net.comm_passes
+    T, R, H = rec.n, rec.hs.shape[1], rec.hs.shape[2]
+    N = net.nagents
+    E = R // N
+    dev = rec.hs.device
+    mode_avg = getattr(args, 'comm_mode', 'avg') == 'avg'
+    mask_zero = bool(args.comm_mask_zero)
+    w_cat_t = fc['w_cat_t']
+    z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    c_wt = [m.weight.detach().t().contiguous() for m in net.C_modules]    # per pass C_i^T (H, H)
+    dbias = [(m.bias - net.C_modules[0].bias).detach() for m in net.C_modules]
+    xh = [z(R, 2 * H) for _ in range(P)]
+    comm = [z(E, N, H) for _ in range(P)]
+    cs = [z(R, H) for _ in range(P)]
+    enc, gates, dgates, dxh = z(R, H), z(R, 4 * H), z(R, 4 * H), z(R, 2 * H)
+    dcomm, dcomm_b, dh, denc = z(R, H), z(E, N, H), z(R, H), z(R, H)
+    bias_parts, bsum = z(ops.LSTM_BWD_MAX_PARTIALS, 4 * H), z(4 * H)
+    dinp = dxh[:, :H]
+    dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
+    dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
+    gap = int(getattr(args, 'detach_gap', 10000))
+    for t in reversed(range(T)):
+        if (t + 1) % gap == 0:
+            dh_rec.zero_()
+            dc_rec.zero_()
+        h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
+        alive, gate = rec.alive[t], rec.gate[t]
+        # ---- forward: enc (+ encoder.bias + C_0.bias), then the passes
+        raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=enc, loc_table=fc['loc_table'])
+        xh[0][:, H:].copy_(rec.hs[t])
+        cs[0].copy_(rec.cs[t])
+        for i in range(P):
+            inp_i = xh[i][:, :H]
+            torch.add(enc, dbias[i], out=inp_i) if i else inp_i.copy_(enc)
+            if mask_zero:
+                comm[i].zero_()
+            else:
+                ops.comm_masked_mean_raw(xh[i].view(E, N, 2 * H)[:, :, H:], alive, gate, mode_avg, True, out=comm[i])
+                inp_i.addmm_(comm[i].view(R, H), c_wt[i])
+            if i + 1 < P:
+                torch.addmm(fc['b_cat'], xh[i], w_cat_t, out=gates)
+                cs[i + 1].copy_(cs[i])
+                ops.lstm_cell_(gates, cs[i + 1], xh[i + 1][:, H:])
+        # ---- backward: heads on the last pass's h, then the passes in reverse
+        d = d_out[t]
+        torch.addmm(dh_rec, d, fc['w_heads'], out=dh)
+        acc['w_heads'].addmm_(d.t(), h_t)
+        acc['b_heads'].add_(d.sum(0))
+        denc.zero_()
+        for i in reversed(range(P)):
+            torch.addmm(fc['b_cat'], xh[i], w_cat_t, out=gates)
+            parts = ops.lstm_cell_backward(gates, cs[i], dh, dc_rec, dgates, dc_rec, bias_parts)   # dc_rec <- dL/dc_i
+            torch.sum(parts, 0, out=bsum)
+            acc['b_cat'].add_(bsum)
+            acc['w_cat_t'].addmm_(xh[i].t(), dgates)
+            torch.mm(dgates, w_cat_t.t(), out=dxh)
+            denc.add_(dinp)
+            acc['c_b'][i].add_(dinp.sum(0))
+            if not mask_zero:
+                acc['c_w_p'][i].addmm_(dinp.t(), comm[i].view(R, H))
+                torch.mm(dinp, c_wt[i].t(), out=dcomm)
+                ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dcomm_b)
+                torch.add(dxh[:, H:], dcomm_b.view(R, H), out=dh)         # dL/dh_i: what pass i - 1 (or step t - 1) receives
+            else:
+                dh.copy_(dxh[:, H:])
+        dh_rec.copy_(dh)
+        dwt, db = raw.encode_backward(denc, rec.snaps[t], want_bias=True)
+        acc['wt'].add_(dwt)
+        acc['enc_bias'].add_(db)
+
+
 def new_accumulators(net):
     fc = net._fused_cache()
     H = net.hid_size
     dev = fc['wt'].device
     z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-    return dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_cat_t=z(2 * H, 4 * H), b_cat=z(4 * H),
-                w_heads=z(*fc['w_heads'].shape), b_heads=z(fc['b_heads'].shape[0]))
+    acc = dict(wt=z(*fc['wt'].shape), enc_bias=z(H), c_w=z(H, H), w_cat_t=z(2 * H, 4 * H), b_cat=z(4 * H),
+               w_heads=z(*fc['w_heads'].shape), b_heads=z(fc['b_heads'].shape[0]))
+    if net.comm_passes > 1:                                               # per pass: C_i.weight, C_i.bias
+        acc['c_w_p'] = [z(H, H) for _ in range(net.comm_passes)]
+        acc['c_b'] = [z(H) for _ in range(net.comm_passes)]
+    return acc
 
 
 def assign_grads(net, acc):
@@ -217,8 +300,19 @@ def assign_grads(net, acc):
         p.grad = g.reshape(p.shape).contiguous()
     put(net.encoder.weight, acc['wt'].t())
     put(net.encoder.bias, acc['enc_bias'].clone())
-    put(net.C_modules[0].weight, acc['c_w'])
-    put(net.C_modules[0].bias, acc['enc_bias'].clone())                   # inp = enc + C(comm): both biases see d inp
+    if net.comm_passes > 1:
+        done = {}
+        for i, m in enumerate(net.C_modules):                             # share_weights: one module, the passes' sums
+            if id(m) in done:
+                m.weight.grad.add_(acc['c_w_p'][i])
+                m.bias.grad.add_(acc['c_b'][i])
+            else:
+                put(m.weight, acc['c_w_p'][i].clone())
+                put(m.bias, acc['c_b'][i].clone())
+                done[id(m)] = True
+    else:
+        put(net.C_modules[0].weight, acc['c_w'])
+        put(net.C_modules[0].bias, acc['enc_bias'].clone())               # inp = enc + C(comm): both biases see d inp
     H = net.hid_size
     put(net.f_module.weight_ih, acc['w_cat_t'][:H].t())
     put(net.f_module.weight_hh, acc['w_cat_t'][H:].t())

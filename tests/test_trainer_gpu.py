@@ -440,13 +440,17 @@ def test_store_states_holds_state_and_next_state(workload, E):
     assert torch.equal(got.reshape(fresh.shape), fresh)              # reset() assembled the observation of the new state
 
 
-@pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7)])
+@pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7), ("pp_hard_p2", 9), ("tj_medium_p3share", 7)])
 def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     """train_batch's default path at a BASELINE shape: the rollout is the one-launch kernel (ic3_policy_step, hid 128) and
     the gradients come from ic3net_amd.bptt — compared with loss.backward() through the autograd rollout replaying the
-    same actions (trainer.py:128-225 both ways; detach_gap cuts inside the episode, entropy term on)."""
+    same actions (trainer.py:128-225 both ways; detach_gap cuts inside the episode, entropy term on).
+    `_p2` / `_p3share`: comm_passes 2 (own C per pass) / 3 (shared C) — one launch per pass, multi-pass backward."""
     import bench
     from ic3net_amd import trainer as trmod
+    bench.WORKLOADS.setdefault("pp_hard_p2", ("predator_prey", dict(bench.WORKLOADS["pp_hard"][1], comm_passes=2)))
+    bench.WORKLOADS.setdefault("tj_medium_p3share", ("traffic_junction", dict(bench.WORKLOADS["tj_medium"][1], comm_passes=3,
+                                                                               share_weights=True)))
     T = 12
     extra = dict(gamma=0.95, normalize_rewards=True, entr=0.01, value_coeff=0.01, advantages_per_action=False,
                  batch_size=E * T, detach_gap=5)
