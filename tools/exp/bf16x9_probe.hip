@@ -200,6 +200,74 @@ __global__ __launch_bounds__(256) void gemm_bf16(const float* __restrict__ A, co
     store_c<RT>(C, r0, store ? (int)((size_t)R - r0 < (size_t)ROWS ? (size_t)R - r0 : (size_t)ROWS) : -1, w, li, lh, acc);
 }
 
+// ---- the same with the A tile left in fp32 in LDS (66 KB: two workgroups per CU, as policy_step_kernel has it) and split
+//      ON THE FLY: every wave reads 8 fp32 of its row per 16 k-steps and splits them in registers (4 x redundant across
+//      the waves of the workgroup, no LDS beyond what the fp32 kernel uses) -----------------------------------------------
+template <int ROWS, int NPROD>
+__global__ __launch_bounds__(256) void gemm_bf16_otf(const float* __restrict__ A, const u32x4* __restrict__ Wp,
+                                                     float* __restrict__ C, int R, int store)
+{
+    constexpr int RT = ROWS / 32, LDA = K + 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const size_t r0 = (size_t)blockIdx.x * ROWS;
+    for (int i = tid; i < ROWS * (K / 4); i += 256) {
+        const int row = i / (K / 4), c4 = i % (K / 4);
+        f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+        if (r0 + row < (size_t)R) v = *reinterpret_cast<const f32x4*>(A + (r0 + row) * K + 4 * c4);
+        *reinterpret_cast<f32x4*>(sm + row * LDA + 4 * c4) = v;
+    }
+    __syncthreads();
+    f32x16 acc[RT][4];
+    for (int rt = 0; rt < RT; ++rt)
+        for (int g = 0; g < 4; ++g)
+            for (int i = 0; i < 16; ++i) acc[rt][g][i] = 0.f;
+    constexpr size_t PLANE = (size_t)KB16 * (NC / 32) * 64;
+    const u32x4* wp = Wp + (size_t)(4 * w) * 64 + lane;
+    u32x4 b[2][3][4];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[0][pl][g] = wp[pl * PLANE + g * 64];
+    constexpr int PA[9] = { 2, 1, 2, 0, 2, 1, 0, 1, 0 };
+    constexpr int PB[9] = { 2, 2, 1, 2, 0, 1, 1, 0, 0 };
+#pragma unroll 2
+    for (int kb = 0; kb < KB16; ++kb) {
+        if (kb + 1 < KB16) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b[(kb + 1) & 1][pl][g] = wp[pl * PLANE + (size_t)(kb + 1) * (NC / 32) * 64 + g * 64];
+        }
+        u32x4 a[RT][3];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float* src = sm + (32 * rt + li) * LDA + 16 * kb + 8 * lh;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+            unsigned p[3][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                split3(x0[q], p[0][q], p[1][q], p[2][q]);
+                split3(x1[q], p[0][4 + q], p[1][4 + q], p[2][4 + q]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) a[rt][pl][d] = p[pl][2 * d] | (p[pl][2 * d + 1] << 16);
+        }
+#pragma unroll
+        for (int t = 9 - NPROD; t < 9; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[rt][PA[t]]),
+                                                                         __builtin_bit_cast(bf16x8, b[kb & 1][PB[t]][g]),
+                                                                         acc[rt][g], 0, 0, 0);
+    }
+    store_c<RT>(C, r0, store ? (int)((size_t)R - r0 < (size_t)ROWS ? (size_t)R - r0 : (size_t)ROWS) : -1, w, li, lh, acc);
+}
+
 #define CK(x)                                                                                  \
     do {                                                                                       \
         hipError_t e_ = (x);                                                                   \
@@ -294,6 +362,8 @@ int main(int argc, char** argv)
     RUN("bf16x9 32x32x16, 32-row tiles (3 WG/CU)", (gemm_bf16<32, 9>), 32, 3 * 32 * (K + 8) * 2);
     RUN("bf16x6 32x32x16, 64-row tiles (1 WG/CU)", (gemm_bf16<64, 6>), 64, 3 * 64 * (K + 8) * 2);
     RUN("bf16x6 32x32x16, 32-row tiles (3 WG/CU)", (gemm_bf16<32, 6>), 32, 3 * 32 * (K + 8) * 2);
+    RUN("bf16x9, fp32 A tile split on the fly, 64 rows", (gemm_bf16_otf<64, 9>), 64, 64 * (K + 4) * 4);
+    RUN("bf16x6, fp32 A tile split on the fly, 64 rows", (gemm_bf16_otf<64, 6>), 64, 64 * (K + 4) * 4);
 #undef ARG
     return 0;
 }
