@@ -254,6 +254,9 @@ def main():
                         'slot of the timed region is then a live transition')
     p.add_argument('--fused-obs', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_OBS', '1')),
                    help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
+    p.add_argument('--gate-split', type=int, default=0,
+                   help='EXPERIMENT, labelled in the output: 1 = the gate product of ic3_policy_step with every fp32 operand '
+                        'split exactly into three bf16 terms, nine exact products on the bf16 matrix cores')
     p.add_argument('--incremental-obs', type=int, default=0,
                    help='EXPERIMENT (labelled in the output, never the headline): ic3_policy_step maintains the obs rows '
                         'incrementally (clears what the previous step painted, paints the new entries) instead of '
@@ -308,6 +311,7 @@ def main():
     a.fused_obs = bool(o.fused_obs)
     a.auto_reset = bool(o.auto_reset)
     a.incremental_obs = bool(o.incremental_obs)
+    a.gate_split = bool(o.gate_split)
     T = a.max_steps
     raw_env = trainer.env.env
     live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
@@ -479,7 +483,8 @@ def main():
             "metric": "env-steps/sec (agents x envs x steps), rollout hot path",
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
             "ms_per_step": round(dt / o.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (gate product: exact bf16x9 split, EXPERIMENT)" if o.gate_split else "f32",
+            "data": "synthetic",
             "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
                        "envs_per_gpu": o.nenvs, "agents": N, "obs_dim": raw_env.obs_dim, "parallelism": "env-shard x%d" % world,
@@ -491,7 +496,9 @@ def main():
                        "auto_reset": bool(o.auto_reset),
                        "obs_rows": ("EXPERIMENT: maintained incrementally (not rewritten every step) - not the headline "
                                     "configuration" if o.incremental_obs else "rewritten every step"),
-                       "gemm": ("hand-written fp32 MFMA" if mega_live else
+                       "gemm": ("EXPERIMENT: gate product as nine exact bf16 split products (fp32 accumulation) - not the "
+                                "headline configuration" if (mega_live and o.gate_split) else
+                                "hand-written fp32 MFMA" if mega_live else
                                 "TunableOp-selected" if o.tune_gemm else "default heuristics")},
             "live_frac": round(live_frac, 6),
             "roofline": {"kernel": hbm_kernel, "bound": "hbm",

@@ -44,7 +44,8 @@ class Policy(C.Structure):
     _fields_ = [("H", C.c_int32), ("nheads", C.c_int32), ("head_sizes", C.c_int32 * 4), ("mode_avg", C.c_int32),
                 ("comm_zero", C.c_int32), ("enc_wt", C.c_void_p), ("enc_bias", C.c_void_p), ("loc_table", C.c_void_p),
                 ("c_wp", C.c_void_p), ("lstm_wp", C.c_void_p), ("lstm_bias", C.c_void_p), ("head_w", C.c_void_p),
-                ("head_b", C.c_void_p), ("pass_index", C.c_int32), ("inner_pass", C.c_int32)]
+                ("head_b", C.c_void_p), ("pass_index", C.c_int32), ("inner_pass", C.c_int32), ("gate_split", C.c_int32),
+                ("reserved_", C.c_int32), ("lstm_wp3", C.c_void_p)]
 
 
 class Episode(C.Structure):
@@ -93,6 +94,7 @@ EXPORTS = {
     "ic3_comm_masked_mean": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
     "ic3_lstm_cell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
+    "ic3_policy_pack_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_commnet_forward_supported": (C.c_int, [C.c_int, C.c_int]),
     "ic3_commnet_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_commnet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 +

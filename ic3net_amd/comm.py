@@ -221,6 +221,8 @@ class CommNetMLP(nn.Module):
                 if self._mega_wanted():
                     new.update(ops.policy_step_pack(self.C_modules[0].weight, self.f_module.weight_ih,
                                                     self.f_module.weight_hh))
+                    if getattr(self.args, 'gate_split', False):  # EXPERIMENT, off by default
+                        new['ps_l_wp3'] = ops.policy_pack_split(self.f_module.weight_ih, self.f_module.weight_hh)
                     for i in range(1, self.comm_passes):         # comm_passes > 1: what pass i swaps in (C_modules[i])
                         ci = self.C_modules[i]
                         new['enc_bias_p%d' % i] = (self.encoder.bias + ci.bias).contiguous()

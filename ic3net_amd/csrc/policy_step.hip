@@ -146,6 +146,7 @@ struct StepArgs {
     // env
     int E, N, EPT, G;
     int auto_reset;             // env handle in auto-reset mode: an env with t == 0 starts an episode (h = c = 0, gate 0)
+    const void* l_wp3;          // EXPERIMENT (gate_split): [W_ih | W_hh] as three bf16 planes in fragment order, or null
     int inner;                  // comm_passes > 1 (comm.py:179): NOT the last communication pass of the step — the launch
                                 // ends behind the LSTM cell (h, c updated; no heads, draws, env.step, obs rows)
     int keep_state;             // not the FIRST pass of the step: h, c hold the previous pass (an env at t == 0 keeps them)
@@ -160,6 +161,53 @@ struct StepArgs {
 
 // zero-store slots of one K block: 16 slots (one behind every pair of MFMAs of a full tile), S of them in use, evenly
 constexpr bool ps_zslot(int S, int i) { return S > 0 && ((i + 1) * S / 16) > (i * S / 16); }
+// the same for the split-product loop (SPLIT = 1): 36 slots per 16-k block (one behind every pair of bf16 MFMAs)
+constexpr bool ps_zslot36(int S, int i) { return S > 0 && ((i + 1) * S / 36) > (i * S / 36); }
+
+// ---- EXPERIMENT (ic3_policy.gate_split, off by default; DESIGN.md section 10, tools/exp/bf16x9_probe.hip): the gate
+// product with every fp32 operand split EXACTLY into three bf16 terms (x = x1 + x2 + x3, round-to-nearest-even splits,
+// exact residuals) and all nine cross products on v_mfma_f32_32x32x16_bf16 — each product exact in fp32, fp32
+// accumulation.  Weights: pre-split planes in fragment order (ic3_policy_pack_split); activations: the fp32 A tile stays
+// in LDS as it is and every wave splits the 8 values of its row per 16 k-steps in registers.
+typedef __bf16 ps_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned ps_bf16_rne(float x)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void ps_split3(float x, unsigned& x1, unsigned& x2, unsigned& x3)
+{
+    x1 = ps_bf16_rne(x);
+    const float r1 = x - __builtin_bit_cast(float, x1 << 16);
+    x2 = ps_bf16_rne(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, x2 << 16);
+    x3 = ps_bf16_rne(r2);
+}
+// 8 consecutive fp32 of one row -> the three bf16 A fragments of a 32x32x16 MFMA.  Pairwise through v_cvt_pk_bf16_f32
+// (round-to-nearest-even in hardware, the pair comes out packed): 9 vector instructions per pair.
+typedef float ps_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ps_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ps_split_pair(ps_f32x2 x, unsigned& p1, unsigned& p2, unsigned& p3)
+{
+    const ps_bf16x2 h1 = __builtin_convertvector(x, ps_bf16x2);
+    const ps_f32x2 r1 = x - __builtin_convertvector(h1, ps_f32x2);
+    const ps_bf16x2 h2 = __builtin_convertvector(r1, ps_bf16x2);
+    const ps_f32x2 r2 = r1 - __builtin_convertvector(h2, ps_f32x2);
+    const ps_bf16x2 h3 = __builtin_convertvector(r2, ps_bf16x2);
+    p1 = __builtin_bit_cast(unsigned, h1);
+    p2 = __builtin_bit_cast(unsigned, h2);
+    p3 = __builtin_bit_cast(unsigned, h3);
+}
+__device__ __forceinline__ void ps_split_frag(ps_f32x4 x0, ps_f32x4 x1, ps_u32x4 (&out)[3])
+{
+    unsigned p[3][4];
+    ps_split_pair(ps_f32x2{ x0[0], x0[1] }, p[0][0], p[1][0], p[2][0]);
+    ps_split_pair(ps_f32x2{ x0[2], x0[3] }, p[0][1], p[1][1], p[2][1]);
+    ps_split_pair(ps_f32x2{ x1[0], x1[1] }, p[0][2], p[1][2], p[2][2]);
+    ps_split_pair(ps_f32x2{ x1[2], x1[3] }, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = ps_u32x4{ p[pl][0], p[pl][1], p[pl][2], p[pl][3] };
+}
 
 // Geometry of one tile, derived from the kernel arguments and the tile index only — the phases behind the gate loop
 // derive it AGAIN from a re-read copy of the arguments instead of keeping ~40 scalars (and the 40 argument pointers)
@@ -212,7 +260,7 @@ __device__ __forceinline__ void reload_args(StepArgs& a)
     for (int i = 0; i < (int)(sizeof(StepArgs) / 4); ++i) dst[i] = kp[i];
 }
 
-template <int H, int KIND>
+template <int H, int KIND, int SPLIT = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(const StepArgs a_in)
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
@@ -477,7 +525,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // stream — here the comm phase and the C product cover it — and behind the loop it would queue up behind the
         // zero stores (one counter, in order).  Rows >= `rows` read as zeros (range check).  32 registers held through
         // the loop.
-        {
+        if constexpr (!SPLIT) {
             const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
             const int voff = (4 * lh * H + col) * 4;
 #pragma unroll
@@ -577,94 +625,208 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
-        // gate weights in the layout Wq[k][c] = float4 (W[c][k], W[H+c][k], W[2H+c][k], W[3H+c][k]) of ic3_policy_pack:
-        // ONE 16-byte load per lane feeds a k-step of all four gates.  The operand ring is IC3_PS_RING float4 deep (8 = two
-        // K blocks = 32 registers, what round 2 held as two buffers of four float4 per gate); a slot is refilled right
-        // behind the 8 MFMAs that read it, RING - 1 k sub-steps (56 MFMAs) ahead of its next use — with the obs zero stores
-        // in flight the L2 answers slower than an idle one, a ring of 4 (24 MFMAs ahead) ran the gate loop 5 % slower.
-        constexpr int RING = IC3_PS_RING;
-        static_assert(RING == 4 || RING == 8, "operand ring: one or two K blocks");
-        const __amdgpu_buffer_rsrc_t rgw = make_rsrc(a.l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
-        const int glane = (4 * lh * H + col) * 16;               // k = 8 kb + 4 lh + j (must match the A fragments)
-        auto wq = [&](int kb, int j) { return buf_load_b128(rgw, glane, (8 * kb + j) * (H * 16)); };
-        ps_f32x4 wk[RING];
+        if constexpr (SPLIT != 0) {
+            // ---- EXPERIMENT (gate_split): the gate product as nine exact bf16 x bf16 products per 16 k-steps -----------
+            // B: pre-split weight planes Wp[plane][kb16][gate][wave][lane] (16 bytes = the 8 bf16 of k = 16 kb + 8 lh + i,
+            // column 32 w + li of the gate); ONE 16-k block in registers (48 VGPRs), a plane refilled for the next block
+            // right behind its last product of this one (products grouped by weight plane).  A: this wave's rows of the
+            // fp32 tile, 8 values per row and block, split in registers.  The old cell state is requested in the last
+            // block, into the plane registers that are no longer refilled (the block is common code without store slots).
+            constexpr int KB16 = K / 16;
+            const __amdgpu_buffer_rsrc_t rg3 = make_rsrc(a.l_wp3, (uint32_t)((size_t)3 * K * 4 * H * 2));
+            const int g3lane = (w * 64 + lane) * 16;
+            constexpr int GSTRIDE = NW * 64 * 16;
+            auto wq3 = [&](int pl, int kb, int gt) {
+                return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
+            };
+            ps_u32x4 bq[3][4];
 #pragma unroll
-        for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------
+            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            if (rt == 1 && !two) break;
+                for (int gt = 0; gt < 4; ++gt) bq[pl][gt] = wq3(pl, 0, gt);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- S7: inp = enc + C.bias + C(comm) -> inp half --------------------------------------------------------
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                As[lr * LDA + col] = accC[rt][reg];
+            for (int rt = 0; rt < 2; ++rt) {
+                if (rt == 1 && !two) break;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    As[lr * LDA + col] = accC[rt][reg];
+                }
             }
-        }
-        __syncthreads();
-        IC3_TR(8);
-
-        // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
-        // `SB` = first ring slot of this K block, REFILL = the ring is refilled for block kb + RING / 4.  The compiler's
-        // waits in front of each k sub-step come out exact: vmcnt(RING - 1 + stores issued since the slot's refill).
-        auto block = [&](auto two_c, auto s_c, auto sb_c, auto refill_c, int kb) {
-            constexpr bool TWO = decltype(two_c)::value;
-            constexpr int S = decltype(s_c)::value;
-            constexpr int SB = decltype(sb_c)::value;
-            constexpr bool REFILL = decltype(refill_c)::value;
-            const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-            ps_f32x4 a1;
-            if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    mfma_acc(acc[0][gt], a0[j], wk[SB + j][gt]);
-                    if constexpr (TWO) mfma_acc(acc[1][gt], a1[j], wk[SB + j][gt]);
-                    // a store slot is two instructions that wait for nothing: it rides in the 64-cycle shadow of an MFMA
-                    if (ps_zslot(S, 4 * j + gt)) {                // (folded after unrolling)
-                        __builtin_amdgcn_sched_barrier(0);        // pinned between the MFMAs it follows / precedes
-                        zero_store();
-                        __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            IC3_TR(8);
+            const __amdgpu_buffer_rsrc_t rc_old = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
+            const int voff_old = (4 * lh * H + col) * 4;
+            auto block3 = [&](auto two_c, auto s_c, auto refill_c, auto loadc_c, int kb) {
+                constexpr bool TWO = decltype(two_c)::value;
+                constexpr int S = decltype(s_c)::value;
+                constexpr bool REFILL = decltype(refill_c)::value;
+                constexpr bool LOADC = decltype(loadc_c)::value;
+                ps_u32x4 ap[2][3];
+                {
+                    const ps_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
+                    ps_split_frag(s0[0], s0[1], ap[0]);
+                    if constexpr (TWO) {
+                        const ps_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
+                        ps_split_frag(s1[0], s1[1], ap[1]);
                     }
                 }
-                if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto gate_loop = [&](auto two_c, auto s_c) {
-            static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
-            constexpr std::integral_constant<int, 0> s0{};
-            constexpr std::integral_constant<int, RING == 8 ? 4 : 0> s1{};
-            if (!(ABL & 1)) {
-#pragma unroll 1
-                for (int kb = 0; kb < KB - 2; kb += 2) {
-                    block(two_c, s_c, s0, std::true_type{}, kb);
-                    block(two_c, s_c, s1, std::true_type{}, kb + 1);
+#pragma unroll
+                for (int pb = 0; pb < 3; ++pb) {
+#pragma unroll
+                    for (int pa = 2; pa >= 0; --pa) {                 // least significant activation term first
+#pragma unroll
+                        for (int gt = 0; gt < 4; ++gt) {
+                            acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(ps_bf16x8, ap[0][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[0][gt], 0, 0, 0);
+                            if constexpr (TWO)
+                                acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(ps_bf16x8, ap[1][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[1][gt], 0, 0, 0);
+                            if (ps_zslot36(S, (pb * 3 + (2 - pa)) * 4 + gt)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                zero_store();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                    if constexpr (REFILL) {
+#pragma unroll
+                        for (int gt = 0; gt < 4; ++gt) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                    }
+                    if constexpr (LOADC) {                            // 11 + 11 + 10 old cell states behind the three plane groups
+#pragma unroll
+                        for (int q = 0; q < 11; ++q) {
+                            const int idx = 11 * pb + q;
+                            if (idx < 32) {
+                                const int rt = idx >> 4, reg = idx & 15;
+                                if (TWO || rt == 0)
+                                    cold[rt][reg] = buf_load_b32(rc_old, voff_old, (32 * rt + (reg & 3) + 8 * (reg >> 2)) * H * 4);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2);
-                block(two_c, s_c, s1, std::false_type{}, KB - 1);
-            }
+            };
+            auto gate_loop3 = [&](auto two_c, auto s_c) {
+                if (!(ABL & 1)) {
+#pragma unroll 1
+                    for (int kb = 0; kb < KB16 - 1; ++kb) block3(two_c, s_c, std::true_type{}, std::false_type{}, kb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto gate_loop3_s = [&](auto two_c) {
+                switch (g.obs_here ? a.zs : 0) {   // workgroup-uniform; a 16-k block carries twice the slots of an 8-k block
+                case 1: gate_loop3(two_c, std::integral_constant<int, 2>{}); break;
+                case 2: gate_loop3(two_c, std::integral_constant<int, 4>{}); break;
+                case 3: gate_loop3(two_c, std::integral_constant<int, 6>{}); break;
+                case 4: gate_loop3(two_c, std::integral_constant<int, 8>{}); break;
+                case 5: gate_loop3(two_c, std::integral_constant<int, 10>{}); break;
+                case 6: gate_loop3(two_c, std::integral_constant<int, 12>{}); break;
+                case 7: gate_loop3(two_c, std::integral_constant<int, 14>{}); break;
+                case 8: gate_loop3(two_c, std::integral_constant<int, 16>{}); break;
+                case 10: gate_loop3(two_c, std::integral_constant<int, 20>{}); break;
+                case 12: gate_loop3(two_c, std::integral_constant<int, 24>{}); break;
+                case 16: gate_loop3(two_c, std::integral_constant<int, 32>{}); break;
+                default: gate_loop3(two_c, std::integral_constant<int, 0>{}); break;
+                }
+                if (!(ABL & 1))   // the last block: common code, no store slots, requests the old cell state
+                    block3(two_c, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, KB16 - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (two) gate_loop3_s(std::true_type{});
+            else gate_loop3_s(std::false_type{});
+        } else {
+            // gate weights in the layout Wq[k][c] = float4 (W[c][k], W[H+c][k], W[2H+c][k], W[3H+c][k]) of ic3_policy_pack:
+            // ONE 16-byte load per lane feeds a k-step of all four gates.  The operand ring is IC3_PS_RING float4 deep (8 = two
+            // K blocks = 32 registers, what round 2 held as two buffers of four float4 per gate); a slot is refilled right
+            // behind the 8 MFMAs that read it, RING - 1 k sub-steps (56 MFMAs) ahead of its next use — with the obs zero stores
+            // in flight the L2 answers slower than an idle one, a ring of 4 (24 MFMAs ahead) ran the gate loop 5 % slower.
+            constexpr int RING = IC3_PS_RING;
+            static_assert(RING == 4 || RING == 8, "operand ring: one or two K blocks");
+            const __amdgpu_buffer_rsrc_t rgw = make_rsrc(a.l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
+            const int glane = (4 * lh * H + col) * 16;               // k = 8 kb + 4 lh + j (must match the A fragments)
+            auto wq = [&](int kb, int j) { return buf_load_b128(rgw, glane, (8 * kb + j) * (H * 16)); };
+            ps_f32x4 wk[RING];
+    #pragma unroll
+            for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
             __builtin_amdgcn_sched_barrier(0);
-        };
-        auto gate_loop_s = [&](auto two_c) {
-            switch (g.obs_here ? a.zs : 0) {   // workgroup-uniform
-            case 1: gate_loop(two_c, std::integral_constant<int, 1>{}); break;
-            case 2: gate_loop(two_c, std::integral_constant<int, 2>{}); break;
-            case 3: gate_loop(two_c, std::integral_constant<int, 3>{}); break;
-            case 4: gate_loop(two_c, std::integral_constant<int, 4>{}); break;
-            case 5: gate_loop(two_c, std::integral_constant<int, 5>{}); break;
-            case 6: gate_loop(two_c, std::integral_constant<int, 6>{}); break;
-            case 7: gate_loop(two_c, std::integral_constant<int, 7>{}); break;
-            case 8: gate_loop(two_c, std::integral_constant<int, 8>{}); break;
-            case 10: gate_loop(two_c, std::integral_constant<int, 10>{}); break;
-            case 12: gate_loop(two_c, std::integral_constant<int, 12>{}); break;
-            case 16: gate_loop(two_c, std::integral_constant<int, 16>{}); break;
-            default: gate_loop(two_c, std::integral_constant<int, 0>{}); break;
+            // ---- S7: inp = enc + C.bias + C(comm) -> inp half ------------------------------------------------------------
+    #pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (rt == 1 && !two) break;
+    #pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    As[lr * LDA + col] = accC[rt][reg];
+                }
             }
-        };
-        if (two) gate_loop_s(std::true_type{});
-        else gate_loop_s(std::false_type{});
+            __syncthreads();
+            IC3_TR(8);
+
+            // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
+            // `SB` = first ring slot of this K block, REFILL = the ring is refilled for block kb + RING / 4.  The compiler's
+            // waits in front of each k sub-step come out exact: vmcnt(RING - 1 + stores issued since the slot's refill).
+            auto block = [&](auto two_c, auto s_c, auto sb_c, auto refill_c, int kb) {
+                constexpr bool TWO = decltype(two_c)::value;
+                constexpr int S = decltype(s_c)::value;
+                constexpr int SB = decltype(sb_c)::value;
+                constexpr bool REFILL = decltype(refill_c)::value;
+                const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+                ps_f32x4 a1;
+                if constexpr (TWO) a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+    #pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        mfma_acc(acc[0][gt], a0[j], wk[SB + j][gt]);
+                        if constexpr (TWO) mfma_acc(acc[1][gt], a1[j], wk[SB + j][gt]);
+                        // a store slot is two instructions that wait for nothing: it rides in the 64-cycle shadow of an MFMA
+                        if (ps_zslot(S, 4 * j + gt)) {                // (folded after unrolling)
+                            __builtin_amdgcn_sched_barrier(0);        // pinned between the MFMAs it follows / precedes
+                            zero_store();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto gate_loop = [&](auto two_c, auto s_c) {
+                static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
+                constexpr std::integral_constant<int, 0> s0{};
+                constexpr std::integral_constant<int, RING == 8 ? 4 : 0> s1{};
+                if (!(ABL & 1)) {
+    #pragma unroll 1
+                    for (int kb = 0; kb < KB - 2; kb += 2) {
+                        block(two_c, s_c, s0, std::true_type{}, kb);
+                        block(two_c, s_c, s1, std::true_type{}, kb + 1);
+                    }
+                    block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2);
+                    block(two_c, s_c, s1, std::false_type{}, KB - 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto gate_loop_s = [&](auto two_c) {
+                switch (g.obs_here ? a.zs : 0) {   // workgroup-uniform
+                case 1: gate_loop(two_c, std::integral_constant<int, 1>{}); break;
+                case 2: gate_loop(two_c, std::integral_constant<int, 2>{}); break;
+                case 3: gate_loop(two_c, std::integral_constant<int, 3>{}); break;
+                case 4: gate_loop(two_c, std::integral_constant<int, 4>{}); break;
+                case 5: gate_loop(two_c, std::integral_constant<int, 5>{}); break;
+                case 6: gate_loop(two_c, std::integral_constant<int, 6>{}); break;
+                case 7: gate_loop(two_c, std::integral_constant<int, 7>{}); break;
+                case 8: gate_loop(two_c, std::integral_constant<int, 8>{}); break;
+                case 10: gate_loop(two_c, std::integral_constant<int, 10>{}); break;
+                case 12: gate_loop(two_c, std::integral_constant<int, 12>{}); break;
+                case 16: gate_loop(two_c, std::integral_constant<int, 16>{}); break;
+                default: gate_loop(two_c, std::integral_constant<int, 0>{}); break;
+                }
+            };
+            if (two) gate_loop_s(std::true_type{});
+            else gate_loop_s(std::false_type{});
+        }
         IC3_TR(9);
         mfma_settle();
         IC3_TR(10);
@@ -968,6 +1130,34 @@ __global__ void policy_pack_gates_kernel(const float* __restrict__ w_ih, const f
     }
 }
 
+// EXPERIMENT (gate_split): Wp[plane][kb16][gate][wave][lane] = 8 x bf16 { W_plane[gate * H + 32 wave + li][16 kb16 + 8 lh + i] },
+// W = [w_ih | w_hh] (4H x 2H), the three planes an exact split of every weight
+__global__ void policy_pack_split_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                         ps_u32x4* __restrict__ Wp, int H)
+{
+    const int NWv = H / 32, KB16 = 2 * H / 16;
+    const long long per = (long long)KB16 * 4 * NWv * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long long rest = i >> 6;
+        const int wv = (int)(rest % NWv);
+        rest /= NWv;
+        const int gt = (int)(rest & 3), kb = (int)(rest >> 2);
+        const int li = lane & 31, lh = lane >> 5;
+        const size_t row = (size_t)gt * H + 32 * wv + li;
+        unsigned p[3][8];
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * kb + 8 * lh + q;
+            ps_split3(k < H ? w_ih[row * H + k] : w_hh[row * H + (k - H)], p[0][q], p[1][q], p[2][q]);
+        }
+        for (int pl = 0; pl < 3; ++pl) {
+            ps_u32x4 v;
+            for (int d = 0; d < 4; ++d) v[d] = p[pl][2 * d] | (p[pl][2 * d + 1] << 16);
+            Wp[(size_t)pl * per + i] = v;
+        }
+    }
+}
+
 static int device_cus()
 {
     static int cus[64] = { 0 };   // per device (a process may drive several GPUs)
@@ -1011,7 +1201,7 @@ static double tiles_cost(const TileCosts& tc, int k_full, int k_half)
     return c + (k_half / 2) * tc.half_pair + (k_half & 1) * tc.lone_half;
 }
 
-template <int H, int KIND>
+template <int H, int KIND, int SPLIT = 0>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0 = nullptr,
                        hipEvent_t ev1 = nullptr);
 // words of the small LDS arrays behind the A tile: sm, sscale, sact, rmask [64 each], sfm [4], sep, sts [64 each], shb [16], slb [4H]
@@ -1047,6 +1237,7 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
     a.comm_zero = p->comm_zero;
     a.inner = p->inner_pass != 0;
     a.keep_state = p->pass_index > 0;
+    a.l_wp3 = (p->gate_split && p->lstm_wp3) ? p->lstm_wp3 : nullptr;
     return 0;
 }
 
@@ -1156,17 +1347,17 @@ static int plan_tiles(StepArgs& a, int H, const ic3_policy* p, hipStream_t s)
     return a.ntiles;
 }
 
-template <int H, int KIND>
+template <int H, int KIND, int SPLIT>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND>), lds));   // per (kernel, device)
+    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND, SPLIT>), lds));   // per (kernel, device)
     // one workgroup per tile, dispatched in tile order (full tiles first, see plan_tiles): the hardware dispatcher
     // balances them over the CUs (a fixed resident set walking a strided tile list was measured slower)
     const int grid = tiles;
     if (ev0 || ev1) {   // timed launch: the dispatch itself stamps the events (no separate record packets around it)
-        hipExtLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, ev0, ev1, 0, a);
+        hipExtLaunchKernelGGL((policy_step_kernel<H, KIND, SPLIT>), dim3(grid), dim3(2 * H), lds, s, ev0, ev1, 0, a);
     } else {
-        hipLaunchKernelGGL((policy_step_kernel<H, KIND>), dim3(grid), dim3(2 * H), lds, s, a);
+        hipLaunchKernelGGL((policy_step_kernel<H, KIND, SPLIT>), dim3(grid), dim3(2 * H), lds, s, a);
     }
     IC3_HIP(hipGetLastError());
     return 0;
@@ -1188,6 +1379,16 @@ extern "C" int ic3_policy_pack(const float* c_weight, const float* w_ih, const f
     return 0;
 }
 
+
+extern "C" int ic3_policy_pack_split(const float* w_ih, const float* w_hh, void* lstm_wp3, int H, ic3_stream stream)
+{
+    if (!w_ih || !w_hh || !lstm_wp3 || H <= 0 || (H % 32))
+        return fail(-22, "ic3_policy_pack_split: H must be a positive multiple of 32");
+    hipLaunchKernelGGL(policy_pack_split_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh,
+                       reinterpret_cast<ps_u32x4*>(lstm_wp3), H);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
 
 // LDS bytes of one workgroup (0 = unsupported shape); *tile_words_out = int32 words of one env-descriptor block
 static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_words_out)
@@ -1348,7 +1549,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
             }
         }
         a.zs = zs;
-        long long left = per_wave - (long long)zs * KBv;
+        long long left = per_wave - (long long)zs * (KBv - (a.l_wp3 ? 2 : 0));   // (split loop: no slots in its last 16-k block)
         auto take = [&](int want) {
             const int n = (fused_obs && !incr_valid) ? (int)std::min<long long>(std::max<long long>(left, 0), std::max(want, 0)) : 0;
             left -= n;
@@ -1388,7 +1589,14 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         ev1 = (hipEvent_t)env->ev_stop;
         env->ev_start = env->ev_stop = nullptr;
     }
-    if (H == 128)
+    if (a.l_wp3) {   // EXPERIMENT: the gate product on the bf16 matrix cores with exact split products
+        if (H == 128)
+            rc = pp ? launch_step<128, IC3_ENV_PP, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ, 1>(a, tiles, lds, s, ev0, ev1);
+        else if (H == 64)
+            rc = pp ? launch_step<64, IC3_ENV_PP, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<64, IC3_ENV_TJ, 1>(a, tiles, lds, s, ev0, ev1);
+        else
+            rc = pp ? launch_step<256, IC3_ENV_PP, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<256, IC3_ENV_TJ, 1>(a, tiles, lds, s, ev0, ev1);
+    } else if (H == 128)
         rc = pp ? launch_step<128, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
     else if (H == 64)
         rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);

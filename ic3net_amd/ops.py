@@ -208,6 +208,16 @@ def policy_step_supported(env, H):
     return H in POLICY_STEP_SIZES and _lib.lib().ic3_policy_step_supported(env._h, int(H)) > 0
 
 
+def policy_pack_split(w_ih, w_hh):
+    """EXPERIMENT (ic3_policy.gate_split): [W_ih | W_hh] as three exact bf16 planes in MFMA fragment order."""
+    _need_cuda(w_ih, "policy_pack_split")
+    H = w_ih.shape[1]
+    wp3 = torch.empty((3 * 2 * H * 4 * H,), dtype=torch.bfloat16, device=w_ih.device)
+    check(_lib.lib().ic3_policy_pack_split(ptr(w_ih.detach().contiguous().float()), ptr(w_hh.detach().contiguous().float()),
+                                           ptr(wp3), H, stream()))
+    return wp3
+
+
 def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True, pass_index=0, inner=False):
     """pass_index / inner: comm_passes > 1 — pass i uses C_modules[i] (cache keys '<name>_p<i>' for i > 0), every pass but
     the last is an `inner` one (h, c only)."""
@@ -223,6 +233,8 @@ def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True, pass_in
         pol.loc_table = fc['loc_table'].data_ptr() if fc.get('loc_table') is not None else None
     pol.c_wp, pol.lstm_wp, pol.lstm_bias = fc['ps_c_wp' + sfx].data_ptr(), fc['ps_l_wp'].data_ptr(), fc['b_cat'].data_ptr()
     pol.head_w, pol.head_b = fc['w_heads'].data_ptr(), fc['b_heads'].data_ptr()
+    if fc.get('ps_l_wp3') is not None:                           # EXPERIMENT: exact split products on the bf16 matrix cores
+        pol.gate_split, pol.lstm_wp3 = 1, fc['ps_l_wp3'].data_ptr()
     return pol
 
 

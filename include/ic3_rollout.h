@@ -379,6 +379,13 @@ typedef struct {
      * the previous episode's.  Both 0: the one-pass policy of the BASELINE configs. */
     int32_t pass_index;
     int32_t inner_pass;
+    /* EXPERIMENT, off by default: gate_split != 0 with lstm_wp3 = ic3_policy_pack_split's buffer
+     * runs the gate product of ic3_policy_step with every fp32 operand split exactly into three bf16 terms and all nine
+     * cross products on the bf16 matrix cores (products exact in fp32, fp32 accumulation; results differ from the fp32
+     * path by summation order only).  Ignored by ic3_policy_forward. */
+    int32_t gate_split;
+    int32_t reserved_;
+    const void* lstm_wp3;
 } ic3_policy;
 
 /* The NON-recurrent CommNet module after the encoder (comm.py:127-129,179-205,220-224,228-239), every communication pass
@@ -398,6 +405,8 @@ int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, 
 
 int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */,
                     float* c_wp /* H*H */, float* lstm_wp /* 4H*2H */, int H, ic3_stream stream);
+int ic3_policy_pack_split(const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */, void* lstm_wp3 /* 3 * 2H * 4H * 2 bytes */,
+                          int H, ic3_stream stream);
 int ic3_policy_step_supported(const ic3_env* env, int H); /* 0, or the LDS bytes per workgroup */
 /* The policy half alone, for callers that bring their own encoder output (a dense observation that is not an env's
  * current state, comm.py:119 evaluated as a GEMM): enc [E*N][H] = encoder(x) + C.bias -> out [E*N][OT] as above, h / c

@@ -30,13 +30,14 @@ def _oracle_env(a, seed, gid):
                            a.curr_end, seed=seed, env_gid=gid, vocab_type=a.vocab_type)
 
 
-def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True):
+def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True, gate_split=False):
     """Plays T lock-step iterations through Trainer.step_episode (the one-launch path) and replays the envs in
     `check_envs` through the fp64 policy + the oracle env on the kernel's actions.  Returns the worst policy error."""
     import bench
     from oracle import policy_ref
     tr, a = bench.build_trainer(workload, E, seed, offset, 0)
     a.max_steps = T
+    a.gate_split = gate_split        # EXPERIMENT (DESIGN.md section 10): exact bf16 split products in the gate GEMM
     tr.begin_episode(0)
     raw = tr.env.env
     N, H = a.nagents, a.hid_size
@@ -91,6 +92,14 @@ def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True):
                                           ("pp_scaled", 3, 20)])
 def test_policy_step_full_episode_vs_fp64_reference_policy(workload, E, T):
     worst = _free_run(workload, E, T, seed=5, offset=300, check_envs=list(range(E)))
+    assert worst < TOL, worst
+
+
+@pytest.mark.parametrize("workload,E,T", [("pp_hard", 13, 80), ("tj_hard", 7, 80), ("pp_scaled", 3, 20)])
+def test_gate_split_experiment_full_episode_vs_fp64_reference_policy(workload, E, T):
+    """The opt-in gate_split mode (nine exact bf16 x bf16 products per fp32 product, fp32 accumulation) against the same
+    fp64 policy + oracle env at the same 1e-5: hid 128 and 256, full episodes."""
+    worst = _free_run(workload, E, T, seed=5, offset=300, check_envs=list(range(E)), gate_split=True)
     assert worst < TOL, worst
 
 
