@@ -55,7 +55,19 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, size_t floats_total,
         for (int i = 0; i < 8; ++i)
             for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
         float a = (float)lane * 1e-3f, b = (float)w * 1e-3f;
-        if (mode & 16) {          // accumulators pinned to AGPRs
+        if (mode & 4096) {        // bf16 MFMA stream (v_mfma_f32_32x32x16_bf16, 32 cycles each): twice the count, same duration
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 ua = { 0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u };
+            const u32x4 ub = { 0x3c003c00u + (unsigned)w, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u };
+            const bf16x8 xa = __builtin_bit_cast(bf16x8, ua), xb = __builtin_bit_cast(bf16x8, ub);
+            for (int it = 0; it < mfma_blocks; ++it) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, acc[i], 0, 0, 0);
+            }
+        } else if (mode & 16) {          // accumulators pinned to AGPRs
             for (int it = 0; it < mfma_blocks; ++it) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -222,7 +234,15 @@ int main(int argc, char** argv)
         { "same wave: store per 1 mfma", 1, 1, 4, 4, 1 },
         { "same wave: store per 2 mfma", 1, 1, 4, 4, 2 },
         { "same wave: store per 4 mfma", 1, 1, 4, 4, 4 },
-        { "same wave: store per 8 mfma", 1, 1, 4, 4, 8 } };
+        { "same wave: store per 8 mfma", 1, 1, 4, 4, 8 },
+        // round 3: the same questions for a bf16 MFMA stream (flops column: fp32-MFMA-equivalent count x 1, i.e. 64 x 32-cycle
+        // instructions per block instead of 32 x 64-cycle ones; multiply by 8 for bf16 flops)
+        { "bf16 mfma only", 1, 0, 4, 4096, 1 },
+        { "bf16 mfma + VALU helper", 1, 1, 4, 4096 + 64, 256 },
+        { "bf16 mfma + VALU helper prio 3", 1, 1, 4, 4096 + 64 + 1, 256 },
+        { "bf16 mfma + stores (4 waves)", 1, 1, 4, 4096, 1 },
+        { "bf16 mfma + LOAD stream", 1, 1, 4, 4096 + 8, 1 },
+        { "bf16 mfma + L2-chase helper", 1, 1, 4, 4096 + 128, 8 } };
     for (auto& c : cfg) {
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
