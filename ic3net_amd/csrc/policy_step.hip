@@ -640,11 +640,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
             };
             ps_u32x4 bq[3][4];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) bq[pl][gt] = wq3(pl, 0, gt);
-            __builtin_amdgcn_sched_barrier(0);
             // ---- S7: inp = enc + C.bias + C(comm) -> inp half --------------------------------------------------------
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -710,6 +705,15 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             };
             auto gate_loop3 = [&](auto two_c, auto s_c) {
+                // (the first block's planes are requested inside the store-slot variant, behind an opaque zero: in front of
+                //  the switch the compiler copies / spills the 12 fragments into every variant's own registers)
+                int zo = 0;
+                asm volatile("" : "+s"(zo));
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt)
+                        bq[pl][gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16) * 4 + gt) * GSTRIDE + zo, 0);
                 if (!(ABL & 1)) {
 #pragma unroll 1
                     for (int kb = 0; kb < KB16 - 1; ++kb) block3(two_c, s_c, std::true_type{}, std::false_type{}, kb);
