@@ -100,7 +100,7 @@ EXPORTS = {
     "ic3_commnet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 +
                             [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "ic3_lstm_gates_backward_supported": (C.c_int, [C.c_int]),
-    "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_policy_heads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

@@ -177,7 +177,7 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         acc['b_heads'].add_(d.sum(0))
         if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
-                                    h_prev=h_prev)
+                                    h_prev=h_prev, lstm_wp3=fc.get('ps_l_wp3'))
         else:
             parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)
             torch.sum(parts, 0, out=bsum)

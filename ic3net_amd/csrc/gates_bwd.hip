@@ -30,6 +30,7 @@ struct GatesBwdArgs {
     const float* h_prev;   // or null.  [R][H]: the h half of a row is read from here and ALSO written into xh (the copy
                            // the caller would otherwise make for the weight-gradient product that follows)
     const float* wq;       // ic3_policy_pack's lstm_wp: Wq[k][c] = float4 over the four gates
+    const void* wq3;       // EXPERIMENT (gate_split, policy_step.hip): ic3_policy_pack_split's three bf16 planes, or null
     const float* bias;     // [4H] b_ih + b_hh
     const float* c_prev;   // [R][H]
     const float* dh;       // [R][H] dL/dh_t
@@ -74,7 +75,43 @@ __device__ __forceinline__ void gb_mfma(gb_f32x16& acc, float x, float y)
 #endif
 }
 
-template <int H>
+// EXPERIMENT (SPLIT = 1, the update half's twin of policy_step_kernel's gate_split): the recompute as nine exact
+// bf16 x bf16 products per 16 k-steps on v_mfma_f32_32x32x16_bf16 — the same loop: weight planes in fragment order, one
+// 16-k block of them in registers, activations split per wave from the fp32 LDS tile through v_cvt_pk_bf16_f32.
+typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gb_split_pair(gb_f32x2 x, unsigned& p1, unsigned& p2, unsigned& p3)
+{
+    const gb_bf16x2 h1 = __builtin_convertvector(x, gb_bf16x2);
+    const gb_f32x2 r1 = x - __builtin_convertvector(h1, gb_f32x2);
+    const gb_bf16x2 h2 = __builtin_convertvector(r1, gb_bf16x2);
+    const gb_f32x2 r2 = r1 - __builtin_convertvector(h2, gb_f32x2);
+    const gb_bf16x2 h3 = __builtin_convertvector(r2, gb_bf16x2);
+    p1 = __builtin_bit_cast(unsigned, h1);
+    p2 = __builtin_bit_cast(unsigned, h2);
+    p3 = __builtin_bit_cast(unsigned, h3);
+}
+__device__ __forceinline__ void gb_split_frag(gb_f32x4 x0, gb_f32x4 x1, gb_u32x4 (&out)[3])
+{
+    unsigned p[3][4];
+    gb_split_pair(gb_f32x2{ x0[0], x0[1] }, p[0][0], p[1][0], p[2][0]);
+    gb_split_pair(gb_f32x2{ x0[2], x0[3] }, p[0][1], p[1][1], p[2][1]);
+    gb_split_pair(gb_f32x2{ x1[0], x1[1] }, p[0][2], p[1][2], p[2][2]);
+    gb_split_pair(gb_f32x2{ x1[2], x1[3] }, p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = gb_u32x4{ p[pl][0], p[pl][1], p[pl][2], p[pl][3] };
+}
+__device__ __forceinline__ void gb_mfma_bf16(gb_f32x16& acc, gb_u32x4 x, gb_u32x4 y)
+{
+#if IC3_GB_AGPR
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
+#else
+    typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, x), __builtin_bit_cast(gb_bf16x8, y), acc, 0, 0, 0);
+#endif
+}
+
+template <int H, int SPLIT = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kernel(const GatesBwdArgs a)
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, KB = K / 8, K4 = K / 4, RING = 8;
@@ -115,8 +152,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     // ---- c_prev of this lane's 32 (row, column) elements: requested now, used behind the gate loop ----------------------
     const int voff = (4 * lh * H + col) * 4;
     float cold[2][16];
-    {
-        const __amdgpu_buffer_rsrc_t rc = gb_rsrc(a.c_prev + r0 * H, (long long)rows * H * 4);
+    const __amdgpu_buffer_rsrc_t rc = gb_rsrc(a.c_prev + r0 * H, (long long)rows * H * 4);
+    if constexpr (SPLIT == 0) {   // (split loop: 48 plane + 24 activation registers next to them — requested behind the loop there)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -130,40 +167,85 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
-    // ---- gates = [inp | h] . [W_ih | W_hh]^T: k = 8 kb + 4 lh + j (A fragment and B slot agree) --------------------------
-    const __amdgpu_buffer_rsrc_t rgw = gb_rsrc(a.wq, (long long)K * 4 * H * 4);
-    const int glane = (4 * lh * H + col) * 16;
-    auto wq = [&](int kb, int j) { return gb_load4(rgw, glane, (8 * kb + j) * (H * 16)); };
-    gb_f32x4 wk[RING];
+    if constexpr (SPLIT != 0) {
+        constexpr int KB16 = K / 16, NWv = H / 32;
+        const __amdgpu_buffer_rsrc_t rg3 = gb_rsrc(a.wq3, (long long)3 * K * 4 * H * 2);
+        const int g3lane = (w * 64 + lane) * 16;
+        constexpr int GSTRIDE = NWv * 64 * 16;
+        auto wq3 = [&](int pl, int kb, int gt) {
+            return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
+        };
+        gb_u32x4 bq[3][4];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
-    __syncthreads();
-    auto block = [&](auto sb_c, auto refill_c, int kb) {
-        constexpr int SB = decltype(sb_c)::value;
-        constexpr bool REFILL = decltype(refill_c)::value;
-        const gb_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
-        const gb_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt) {
-                gb_mfma(acc[0][gt], a0[j], wk[SB + j][gt]);
-                gb_mfma(acc[1][gt], a1[j], wk[SB + j][gt]);
+            for (int gt = 0; gt < 4; ++gt) bq[pl][gt] = wq3(pl, 0, gt);
+        __syncthreads();
+        auto block3 = [&](auto refill_c, int kb) {
+            constexpr bool REFILL = decltype(refill_c)::value;
+            gb_u32x4 ap[2][3];
+            {
+                const gb_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
+                const gb_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
+                gb_split_frag(s0[0], s0[1], ap[0]);
+                gb_split_frag(s1[0], s1[1], ap[1]);
             }
-            if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    constexpr std::integral_constant<int, 0> s0{};
-    constexpr std::integral_constant<int, 4> s1{};
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+#pragma unroll
+                for (int pa = 2; pa >= 0; --pa)
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        gb_mfma_bf16(acc[0][gt], ap[0][pa], bq[pb][gt]);
+                        gb_mfma_bf16(acc[1][gt], ap[1][pa], bq[pb][gt]);
+                    }
+                if constexpr (REFILL) {
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
 #pragma unroll 1
-    for (int kb = 0; kb < KB - 2; kb += 2) {
-        block(s0, std::true_type{}, kb);
-        block(s1, std::true_type{}, kb + 1);
+        for (int kb = 0; kb < KB16 - 1; ++kb) block3(std::true_type{}, kb);
+        block3(std::false_type{}, KB16 - 1);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // ---- gates = [inp | h] . [W_ih | W_hh]^T: k = 8 kb + 4 lh + j (A fragment and B slot agree) --------------------------
+        const __amdgpu_buffer_rsrc_t rgw = gb_rsrc(a.wq, (long long)K * 4 * H * 4);
+        const int glane = (4 * lh * H + col) * 16;
+        auto wq = [&](int kb, int j) { return gb_load4(rgw, glane, (8 * kb + j) * (H * 16)); };
+        gb_f32x4 wk[RING];
+    #pragma unroll
+        for (int i = 0; i < RING; ++i) wk[i] = wq(i >> 2, i & 3);
+        __syncthreads();
+        auto block = [&](auto sb_c, auto refill_c, int kb) {
+            constexpr int SB = decltype(sb_c)::value;
+            constexpr bool REFILL = decltype(refill_c)::value;
+            const gb_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh];
+            const gb_f32x4 a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+    #pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    gb_mfma(acc[0][gt], a0[j], wk[SB + j][gt]);
+                    gb_mfma(acc[1][gt], a1[j], wk[SB + j][gt]);
+                }
+                if constexpr (REFILL) wk[SB + j] = wq(kb + RING / 4, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        constexpr std::integral_constant<int, 0> s0{};
+        constexpr std::integral_constant<int, 4> s1{};
+    #pragma unroll 1
+        for (int kb = 0; kb < KB - 2; kb += 2) {
+            block(s0, std::true_type{}, kb);
+            block(s1, std::true_type{}, kb + 1);
+        }
+        block(s0, std::false_type{}, KB - 2);
+        block(s1, std::false_type{}, KB - 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    block(s0, std::false_type{}, KB - 2);
-    block(s1, std::false_type{}, KB - 1);
-    __builtin_amdgcn_sched_barrier(0);
 #if IC3_GB_AGPR
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // (the asm MFMAs are opaque to the hazard recogniser)
 #endif
@@ -185,6 +267,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
             dhv[reg] = gb_load1(rdh, voff, lc * H * 4);
             dcv[reg] = gb_load1(rdc, voff, lc * H * 4);
+            if constexpr (SPLIT != 0) cold[rt][reg] = gb_load1(rc, voff, lc * H * 4);
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -233,7 +316,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 
 extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
-extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const float* bias, const float* c_prev,
+extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias, const float* c_prev,
                                        const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
                                        int accumulate, int R, int H, ic3_stream stream)
 {
@@ -244,14 +327,19 @@ extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, 
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
     if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
         return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
-    const GatesBwdArgs a{ xh, h_prev, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate };
+    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate };
     const int tiles = (R + 63) / 64;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define IC3_GB(h)                                                                                                       \
     case h:                                                                                                             \
-        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<h>), lds));                      \
-        hipLaunchKernelGGL(lstm_gates_bwd_kernel<h>, dim3(tiles), dim3(2 * h), lds, s, a);                              \
+        if (lstm_wp3) {                                                                                                 \
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<h, 1>), lds));               \
+            hipLaunchKernelGGL((lstm_gates_bwd_kernel<h, 1>), dim3(tiles), dim3(2 * h), lds, s, a);                     \
+        } else {                                                                                                        \
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<h, 0>), lds));               \
+            hipLaunchKernelGGL((lstm_gates_bwd_kernel<h, 0>), dim3(tiles), dim3(2 * h), lds, s, a);                     \
+        }                                                                                                               \
         break;
     switch (H) {
         IC3_GB(64)

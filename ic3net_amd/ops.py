@@ -149,7 +149,7 @@ def lstm_gates_backward_supported(H):
 
 
 def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None, accumulate=False,
-                        h_prev=None):
+                        h_prev=None, lstm_wp3=None):
     """Gate recompute + LSTM cell backward in one launch (ic3_lstm_gates_backward): xh (R,2H) = [inp | h_prev] rows (unit
     column stride; with h_prev (R,H) given the launch fills the h half of xh from it), lstm_wp = policy_step_pack's 'ps_l_wp', bias (4H,) = b_ih + b_hh; c_prev, dh, dc (or None) (R,H) ->
     dgates (R,4H), dc_prev (R,H; may alias dc).  dbias_partials: (ceil(R/64), 4H), written (or added to: `accumulate`)."""
@@ -164,6 +164,7 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
     if h_prev is not None:
         assert h_prev.is_contiguous() and h_prev.dtype == torch.float32 and tuple(h_prev.shape) == (R, H)
     n = _lib.lib().ic3_lstm_gates_backward(ptr(xh), xh.stride(0), ptr(h_prev) if h_prev is not None else None, ptr(lstm_wp),
+                                           ptr(lstm_wp3) if lstm_wp3 is not None else None,   # EXPERIMENT gate_split
                                            ptr(bias), ptr(c_prev), ptr(dh),
                                            ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
                                            ptr(dbias_partials) if dbias_partials is not None else None,

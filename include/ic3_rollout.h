@@ -288,7 +288,9 @@ int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float*
  * written when accumulate == 0, ADDED to what the row holds when accumulate != 0 (a whole episode's bias gradient then
  * needs one reduction at its end).  Returns the number of partial rows, negative errno on error (-38: unsupported H). */
 int ic3_lstm_gates_backward_supported(int H);
-int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev /* or NULL */, const float* lstm_wp, const float* bias,
+int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev /* or NULL */, const float* lstm_wp,
+                            const void* lstm_wp3 /* NULL, or ic3_policy_pack_split's planes: the gate_split EXPERIMENT */,
+                            const float* bias,
                             const float* c_prev,
                             const float* dh, const float* dc /* or NULL */, float* dgates, float* dc_prev,
                             float* dbias_partials /* or NULL */, int accumulate, int R, int H, ic3_stream stream);

@@ -48,6 +48,15 @@ def test_gates_backward_matches_autograd(H, R, pad):
         ops.lstm_gates_backward(xh, wp, b, c_prev, dh, dc_io, dgates, dc_io, parts, True)
         torch.testing.assert_close(parts, 2 * before, atol=1e-6, rtol=1e-6)
         torch.testing.assert_close(dc_io, dcp, atol=0, rtol=0)
+    # EXPERIMENT gate_split: the recompute as nine exact bf16 split products per fp32 product — same bars
+    wp3 = ops.policy_pack_split(w_ih, w_hh)
+    dg4, dcp4 = torch.full_like(dgates, float('nan')), torch.full_like(dcp, float('nan'))
+    parts4 = torch.full((tiles, 4 * H), float('nan'), device='cuda')
+    ops.lstm_gates_backward(xh, wp, b, c_prev, dh, None, dg4, dcp4, parts4, False, lstm_wp3=wp3)
+    ref_dg, ref_dc = reference(xh, w_ih, w_hh, b, c_prev, dh, None)
+    assert float((dg4.double() - ref_dg).abs().max()) <= 2e-6 * max(1.0, float(ref_dg.abs().max()))
+    assert float((dcp4.double() - ref_dc).abs().max()) <= 2e-6 * max(1.0, float(ref_dc.abs().max()))
+    torch.testing.assert_close(parts4.double().sum(0), dg4.double().sum(0), atol=1e-4, rtol=1e-5)
     # h_prev given separately: same results, and the launch fills the h half of xh
     xh2 = torch.cat([xh[:, :H], torch.full((R, H), float('nan'), device='cuda')], 1)
     dg3, dcp3 = torch.empty_like(dgates), torch.empty_like(dcp)

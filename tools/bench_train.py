@@ -17,8 +17,10 @@ def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else 'native'
     wl = sys.argv[4] if len(sys.argv) > 4 else 'pp_hard'
     dense = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    split = int(sys.argv[6]) if len(sys.argv) > 6 else 0      # EXPERIMENT gate_split (rollout + recompute)
     tr, a = bench.build_trainer(wl, E, 0, 0, 0)
     a.dense_obs = bool(dense)
+    a.gate_split = bool(split)
     a.native_update = mode == 'native' 
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=E * a.max_steps)
@@ -43,7 +45,7 @@ def main():
         steps += st['num_steps']
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    label = wl + ("" if dense else " (no dense obs rows)")
+    label = wl + ("" if dense else " (no dense obs rows)") + (" EXPERIMENT gate_split" if split else "")
     print("train_batch [%s] %s E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
           "peak mem %.1f GB, gemm %s" % (mode, label, E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates,
                                          steps // updates, torch.cuda.max_memory_allocated() / 2 ** 30,
