@@ -191,20 +191,17 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
                 gb_split_frag(s1[0], s1[1], ap[1]);
             }
 #pragma unroll
-            for (int pb = 0; pb < 3; ++pb) {
+            for (int pb = 0; pb < 3; ++pb)
 #pragma unroll
-                for (int pa = 2; pa >= 0; --pa)
+                for (int gt = 0; gt < 4; ++gt) {                     // the six products of one weight fragment, then its refill
 #pragma unroll
-                    for (int gt = 0; gt < 4; ++gt) {
+                    for (int pa = 2; pa >= 0; --pa) {
                         gb_mfma_bf16(acc[0][gt], ap[0][pa], bq[pb][gt]);
                         gb_mfma_bf16(acc[1][gt], ap[1][pa], bq[pb][gt]);
                     }
-                if constexpr (REFILL) {
-#pragma unroll
-                    for (int gt = 0; gt < 4; ++gt) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                    if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         };
 #pragma unroll 1
         for (int kb = 0; kb < KB16 - 1; ++kb) block3(std::true_type{}, kb);

@@ -671,24 +671,24 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb) {
 #pragma unroll
-                    for (int pa = 2; pa >= 0; --pa) {                 // least significant activation term first
+                    for (int gt = 0; gt < 4; ++gt) {
+                        // the six products of ONE weight fragment back to back (three activation terms, least significant
+                        // first, two row tiles), then its refill: 11 fragments x 6 MFMAs of lead instead of 2 plane groups
 #pragma unroll
-                        for (int gt = 0; gt < 4; ++gt) {
+                        for (int pa = 2; pa >= 0; --pa) {
                             acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 __builtin_bit_cast(ps_bf16x8, ap[0][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[0][gt], 0, 0, 0);
                             if constexpr (TWO)
                                 acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                     __builtin_bit_cast(ps_bf16x8, ap[1][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[1][gt], 0, 0, 0);
-                            if (ps_zslot36(S, (pb * 3 + (2 - pa)) * 4 + gt)) {
+                            if (ps_zslot36(S, (pb * 4 + gt) * 3 + (2 - pa))) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 zero_store();
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
-                    }
-                    if constexpr (REFILL) {
-#pragma unroll
-                        for (int gt = 0; gt < 4; ++gt) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                        if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (LOADC) {                            // 11 + 11 + 10 old cell states behind the three plane groups
 #pragma unroll
