@@ -9,6 +9,12 @@
 
 #include "ic3_rollout.h"
 
+// The dynamic LDS of a kernel has one spelling, so that tests/host (the same sources behind the same C ABI on a CPU, under
+// ASan / UBSan) can give it storage.
+#ifndef IC3_DYNAMIC_LDS
+#define IC3_DYNAMIC_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 namespace ic3 {
 
 // Random stream contract: x24 = Philox4x32-10((draw, t, episode, domain), (seed, env_gid))[0] >> 8

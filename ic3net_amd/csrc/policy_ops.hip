@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
                                                            float* __restrict__ out, int R, int H4, int OT, int nheads,
                                                            int a0, int a1, int a2, int a3)
 {
-    extern __shared__ __attribute__((aligned(16))) float sW[];  // [OT][4*H4]
+    IC3_DYNAMIC_LDS(float, sW);  // [OT][4*H4]
     for (int i = threadIdx.x; i < OT * H4; i += blockDim.x)
         reinterpret_cast<f32x4*>(sW)[i] = reinterpret_cast<const f32x4*>(W)[i];
     __syncthreads();
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void lstm_cell_heads_kernel(const float* __res
                                                               const int32_t* __restrict__ tstep, uint32_t seed,
                                                               uint32_t gid0, int N, int32_t* __restrict__ action)
 {
-    extern __shared__ __attribute__((aligned(16))) float sW[];  // [OT][4*H4] weights, then [RPB][OT] logits
+    IC3_DYNAMIC_LDS(float, sW);  // [OT][4*H4] weights, then [RPB][OT] logits
     constexpr int RPB = 256 / H4;                               // rows per workgroup
     float* sZ = sW + OT * 4 * H4;
     for (int i = threadIdx.x; i < OT * H4; i += blockDim.x)

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(THREADS) void pp_obs_kernel(const int32_t* __restri
                                                      const int32_t* __restrict__ loc_c, float* __restrict__ obs,
                                                      int N, int nprey, int dim, int v, int rows)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int e = blockIdx.x;
     const int W = 2 * v + 1, nseg = rows * W * W;
     const int vocab = dim * dim + 4;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void pp_encode_kernel(const int32_t* __restric
                                                         f32x4* __restrict__ out, int ldo4, int N, int nprey, int dim,
                                                         int v, int H4, int rows, const f32x4* __restrict__ loc_table)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int e = blockIdx.x;
     const int WW = (2 * v + 1) * (2 * v + 1);
     const int vocab = dim * dim + 4;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_kernel(const int32_t* __res
                                                             float* __restrict__ Dpart, int E, int chunk, int N, int nprey,
                                                             int dim, int v, int H, int rows, int tab_words)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int WW = (2 * v + 1) * (2 * v + 1), nslots = 2 * WW;
     float* gl = reinterpret_cast<float*>(smem + tab_words);
     float* Dl = gl + rows * H;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_rows_kernel(const int32_t* 
                                                                  float* __restrict__ Ppart, float* __restrict__ Dpart, int E,
                                                                  int N, int nprey, int dim, int v, int H, int Hc, int rows)
 {
-    extern __shared__ __attribute__((aligned(16))) float smf[];
+    IC3_DYNAMIC_LDS(float, smf);
     const int W = 2 * v + 1, total = N + nprey;
     const int centre = v * W + v;
     enc_bwd_rows(

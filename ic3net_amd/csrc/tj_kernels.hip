@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void tj_obs_kernel(const int32_t* __restrict__
     // hdr = 2 ('bool' vocab: [last_act, route]) or 4 ('scalar' vocab: + p_norm = (r/(h-1), c/(w-1)), TJ:344,361).
     // In scalar mode the uploaded grid is (road ? 0 : -1), vocab = 2, car_class = 1, outside = -1, so the one-hot
     // formula below yields exactly the reference's (road, #cars) pair per window cell (TJ:331-332).
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int e = blockIdx.x;
     const int W = 2 * v + 1, WW = W * W, nseg = N * WW, obs_dim = hdr + WW * vocab;
     int32_t* sr = smem;          // [N]
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024) void tj_obs_vec4_kernel(const int32_t* __rest
                                                            int N, int h, int w, int v, int vocab, int outside,
                                                            int car_class, int npath, int hdr)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int e = blockIdx.x, NT = blockDim.x;
     const int W = 2 * v + 1, WW = W * W, nseg = N * WW, obs_dim = hdr + WW * vocab;
     int32_t* sr = smem;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void tj_encode_kernel(TJState st, const f32x4*
                                                         const f32x4* __restrict__ bias, f32x4* __restrict__ out, int ldo4,
                                                         int H4, const f32x4* __restrict__ loc_table)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int e = blockIdx.x;
     const int N = st.N, W = 2 * st.v + 1, WW = W * W, nseg = N * WW;
     const TJTile t = tj_tile_at(smem, N);
@@ -311,14 +311,12 @@ TJState tj_state_of(const ic3_env* env)
     return st;
 }
 
-int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
-              hipStream_t s)
+// The read-only launches (observation rows, sparse encoder): the car fields come from env->view when a snapshot is set
+// (ic3_env_observe_at / ic3_env_encode_at), from the live state otherwise.
+static TJState tj_view_state_of(const ic3_env* env)
 {
-    const ic3_tj_cfg& c = env->tj;
-    const int WW = env->dims.window * env->dims.window;
-    const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
     TJState st = tj_state_of(env);
-    if (env->view) {   // ic3_env_encode_at: the car fields the encoder reads come from the snapshot
+    if (env->view) {
         st.alive = const_cast<int32_t*>(env->fv("alive"));
         st.loc_r = const_cast<int32_t*>(env->fv("loc_r"));
         st.loc_c = const_cast<int32_t*>(env->fv("loc_c"));
@@ -327,6 +325,16 @@ int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc
         st.route_loc = const_cast<int32_t*>(env->fv("route_loc"));
         st.wait = const_cast<int32_t*>(env->fv("wait"));
     }
+    return st;
+}
+
+int tj_encode(ic3_env* env, const float* Wt, const float* bias, const float* loc_table, float* out, int ldo, int H,
+              hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const int WW = env->dims.window * env->dims.window;
+    const size_t lds = (size_t)(((7 * c.N + 3) & ~3) + 2 * c.N * WW) * sizeof(int32_t);
+    const TJState st = tj_view_state_of(env);
     hipLaunchKernelGGL(tj_encode_kernel, dim3(c.E), dim3(256), lds, s, st, reinterpret_cast<const f32x4*>(Wt),
                        reinterpret_cast<const f32x4*>(bias), reinterpret_cast<f32x4*>(out), ldo / 4, H / 4,
                        reinterpret_cast<const f32x4*>(loc_table));
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_kernel(const int32_t* __res
                                                             float* __restrict__ Dpart, int E, int chunk, int N, int h,
                                                             int w, int v, int npath, int H, int hdr, int tab_words)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int W = 2 * v + 1, WW = W * W, nseg = N * WW, nslots = hdr + WW;
     int32_t* sr = smem;
     int32_t* sc = sr + N;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_rows_kernel(const int32_t* 
                                                                  float* __restrict__ Ppart, float* __restrict__ Dpart, int E,
                                                                  int N, int h, int w, int v, int npath, int H, int Hc, int hdr)
 {
-    extern __shared__ __attribute__((aligned(16))) float smf[];
+    IC3_DYNAMIC_LDS(float, smf);
     const int W = 2 * v + 1;
     const int centre = v * W + v;
     enc_bwd_rows(
@@ -557,7 +565,7 @@ int tj_step(ic3_env* env, const int32_t* actions, float* reward, int32_t* done, 
 // element-wise dword kernel and no per-element evaluation.  Same bytes, same values (tests: bit-equal to the oracle).
 __global__ __launch_bounds__(1024) void tj_obs_fill_kernel(TJState st, float* __restrict__ obs, int obs_dim, int WW)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    IC3_DYNAMIC_LDS(int32_t, smem);
     const int e = blockIdx.x, NT = blockDim.x, tid = threadIdx.x, N = st.N;
     const TJTile t = tj_tile_at(smem, N);
     const int L = N * obs_dim;
@@ -591,7 +599,7 @@ int tj_observe(ic3_env* env, float* obs, hipStream_t s)
     static const int fill = getenv("IC3_TJ_OBS_FILL") ? atoi(getenv("IC3_TJ_OBS_FILL")) : 1;
     const bool big = (long long)c.N * d.obs_dim >= 8192 && d.obs_dim >= 8;
     if (fill == 2 && big) {   // experiment: zero fill + patch for large chunks too, 1024 threads per env
-        hipLaunchKernelGGL(tj_obs_fill_kernel, dim3(c.E), dim3(1024), lds, s, tj_state_of(env), obs, d.obs_dim, WW);
+        hipLaunchKernelGGL(tj_obs_fill_kernel, dim3(c.E), dim3(1024), lds, s, tj_view_state_of(env), obs, d.obs_dim, WW);
         IC3_HIP(hipGetLastError());
         return 0;
     }
@@ -607,7 +615,7 @@ int tj_observe(ic3_env* env, float* obs, hipStream_t s)
     // small rows: zero fill + patches, 256 threads per env (TJ-medium: 5.66 TB/s = 0.71 of peak; the element-wise dword
     // kernel below, kept as IC3_TJ_OBS_FILL=0, reached 4.35)
     if (fill) {
-        hipLaunchKernelGGL(tj_obs_fill_kernel, dim3(c.E), dim3(256), lds, s, tj_state_of(env), obs, d.obs_dim, WW);
+        hipLaunchKernelGGL(tj_obs_fill_kernel, dim3(c.E), dim3(256), lds, s, tj_view_state_of(env), obs, d.obs_dim, WW);
         IC3_HIP(hipGetLastError());
         return 0;
     }

@@ -2,8 +2,8 @@
 //
 // ic3net_amd/csrc/env_device.hpp holds the bodies of the Predator-Prey / Traffic-Junction step, window tables and
 // observation patches that every launch geometry of libic3rollout runs (pp/tj_step_kernel, policy_step_kernel).  This file
-// includes that header — through tests/host/shim/hip/hip_runtime.h, which stands in for the HIP runtime with 64 lockstep
-// host threads per wavefront — together with the product's host-side table builder (tj_tables.cpp) and curriculum
+// includes that header — through tests/host/shim/hip/hip_runtime.h, which stands in for the HIP runtime with 64
+// cooperatively scheduled lane fibers per wavefront — together with the product's host-side table builder (tj_tables.cpp) and curriculum
 // (tj_curriculum.hpp), and wraps ONE environment behind a small C interface so that tests/test_host_build_cpu.py can drive
 // the reference's golden trajectories (tests/golden/) through it on a CPU, also under ASan / UBSan (tools/host_asan.sh).
 // It never calls into oracle/, and nothing under ic3net_amd/ loads it: it is not a CPU path of the product

@@ -4,21 +4,39 @@
 // (tests/host/ic3_host_build.cpp, tests/test_host_build_cpu.py, tools/host_asan.sh).  Not a CPU fallback of the product:
 // nothing under ic3net_amd/ loads it.
 //
-// Execution model: one 64-lane wavefront = 64 host threads running the same device function in lockstep where the code
-// asks for it — __ballot / __shfl exchange through a shared array between two barriers (the device code calls them from
-// all lanes of a wave, uniformly: that is what makes it valid on the GPU too).
+// Execution model: a lane is a FIBER (ucontext), all lanes of a wavefront / workgroup are scheduled cooperatively on the
+// calling thread, round-robin, each running until it returns or waits in a barrier.  __ballot / __shfl exchange through a
+// per-wave array between two barriers over the wave's lanes (the device code calls them from all lanes of a wave,
+// uniformly: that is what makes it valid on the GPU too); a lane that returns leaves the barriers like an exited hardware
+// lane.  No OS threads, no real atomics: runs are deterministic, a barrier nobody can complete aborts with a message
+// instead of hanging, and a launch costs context switches instead of futex traffic.
+//
+// Whole kernels (tests/host/ic3_host_abi.cpp: the product's .hip sources behind the same C ABI, `device = -1`):
+// hipLaunchKernelGGL runs the grid one workgroup at a time, a workgroup = blockDim lanes (wavefronts of 64 as above,
+// __syncthreads = a barrier over the workgroup's lanes).  `__shared__` arrays become function-local statics (one workgroup
+// runs at a time), the dynamic LDS of a launch is one 160 KB buffer refilled with a poison pattern before every workgroup
+// (LDS is not zeroed on the GPU either).  hipMalloc / hipMemcpy / hipMemset work on host memory, streams are ignored
+// (every call is synchronous).
 #pragma once
 
-#include <atomic>
-#include <barrier>
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <tuple>
+#include <type_traits>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <thread>
 #include <vector>
 
+#ifndef __HIPCC__
+#define __HIPCC__ 1   // (ic3_common.hpp guards its device-only helpers with it)
+#endif
 #define __device__
 #define __host__
 #define __global__
@@ -27,7 +45,7 @@
 
 typedef void* hipStream_t;
 typedef int hipError_t;
-enum { hipSuccess = 0 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101 };
 inline const char* hipGetErrorString(hipError_t) { return "host build"; }
 
 struct int2 {
@@ -37,34 +55,200 @@ inline int2 make_int2(int x, int y) { return int2{ x, y }; }
 struct ic3_host_dim3 {
     unsigned x, y, z;
 };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define IC3_HOST_ASAN_FIBERS 1
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#endif
+#endif
 
 namespace ic3_host {
+void yield();
+// a barrier over `expected` lanes; a lane that drops out lowers the count for this and every later phase
+struct Barrier {
+    int expected, arrived = 0;
+    unsigned phase = 0;
+    explicit Barrier(int n) : expected(n) {}
+    void arrive_and_wait();
+    void arrive_and_drop();
+};
 struct Wave {
-    std::barrier<> bar{ 64 };
+    Barrier bar;
+    explicit Wave(int lanes = 64) : bar(lanes) {}
     long long vals[64];
     int active[64];   // a lane that has returned contributes 0 to later ballots (like an exited hardware lane)
 };
-inline thread_local int tl_lane = 0;
-inline thread_local Wave* tl_wave = nullptr;
-inline thread_local ic3_host_dim3 tl_tid{ 0, 0, 0 };
+struct Block {
+    Barrier bar;
+    explicit Block(int n) : bar(n) {}
+};
+inline int tl_lane = 0;
+inline Wave* tl_wave = nullptr;
+inline Block* tl_block = nullptr;
+inline ic3_host_dim3 tl_tid{ 0, 0, 0 }, tl_bid{ 0, 0, 0 }, tl_bdim{ 64, 1, 1 }, tl_gdim{ 1, 1, 1 };
+constexpr size_t LDS_BYTES = 160 * 1024;
+inline void* dynamic_lds()
+{
+    alignas(64) static unsigned char buf[LDS_BYTES];
+    return buf;
+}
+
+// The cooperative scheduler.  run(n, fn) plays fn(0) .. fn(n - 1) as n fibers until all have returned.
+class Fibers {
+public:
+    static constexpr size_t STACK = 256 * 1024;
+    struct Fiber {
+        ucontext_t ctx;
+        char* stack = nullptr;
+        void* fake = nullptr;   // (ASan) fake-stack handle while switched out
+        bool done = false;
+        int lane = 0;           // the per-lane registers of the shim, saved / restored around a switch
+        Wave* wave = nullptr;
+        ic3_host_dim3 tid{ 0, 0, 0 };
+    };
+    static Fibers& get()
+    {
+        static Fibers* f = new Fibers();
+        return *f;
+    }
+    void run(int n, const std::function<void(int)>& fn)
+    {
+        if (cur_ >= 0) die("nested launch from device code");
+        while ((int)fibers_.size() < n) {
+            fibers_.emplace_back(new Fiber());
+            void* p = mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_STACK, -1, 0);
+            if (p == MAP_FAILED) die("mmap of a fiber stack failed");
+            fibers_.back()->stack = (char*)p;
+        }
+        job_ = &fn;
+        for (int i = 0; i < n; ++i) {
+            Fiber& f = *fibers_[i];
+            f.done = false;
+            f.fake = nullptr;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack;
+            f.ctx.uc_stack.ss_size = STACK;
+            f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        int left = n;
+        while (left > 0) {
+            const unsigned long long before = progress_;
+            for (int i = 0; i < n; ++i) {
+                Fiber& f = *fibers_[i];
+                if (f.done) continue;
+                cur_ = i;
+                tl_lane = f.lane;
+                tl_wave = f.wave;
+                tl_tid = f.tid;
+                switch_to(f);
+                f.lane = tl_lane;
+                f.wave = tl_wave;
+                f.tid = tl_tid;
+                cur_ = -1;
+                if (f.done) { --left; ++progress_; }
+            }
+            if (left > 0 && progress_ == before)
+                die("no lane can make progress: a barrier (__syncthreads / __shfl / __ballot) that not all live lanes reach");
+        }
+        job_ = nullptr;
+    }
+    void yield_current()
+    {
+        if (cur_ < 0) die("barrier outside a launch");
+        Fiber& f = *fibers_[cur_];
+#ifdef IC3_HOST_ASAN_FIBERS
+        __sanitizer_start_switch_fiber(&f.fake, main_bottom_, main_size_);
+#endif
+        swapcontext(&f.ctx, &main_);
+#ifdef IC3_HOST_ASAN_FIBERS
+        __sanitizer_finish_switch_fiber(f.fake, nullptr, nullptr);
+#endif
+    }
+    void progressed() { ++progress_; }
+    [[noreturn]] static void die(const char* what)
+    {
+        std::fprintf(stderr, "ic3 host shim: %s\n", what);
+        std::abort();
+    }
+
+private:
+    void switch_to(Fiber& f)
+    {
+#ifdef IC3_HOST_ASAN_FIBERS
+        void* fake = nullptr;
+        __sanitizer_start_switch_fiber(&fake, f.stack, STACK);
+#endif
+        swapcontext(&main_, &f.ctx);
+#ifdef IC3_HOST_ASAN_FIBERS
+        __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+    }
+    static void trampoline()
+    {
+        Fibers& s = get();
+#ifdef IC3_HOST_ASAN_FIBERS
+        __sanitizer_finish_switch_fiber(nullptr, &s.main_bottom_, &s.main_size_);
+#endif
+        const int id = s.cur_;
+        (*s.job_)(id);
+        Fiber& f = *s.fibers_[id];
+        f.done = true;
+#ifdef IC3_HOST_ASAN_FIBERS
+        __sanitizer_start_switch_fiber(nullptr, s.main_bottom_, s.main_size_);   // (this fiber's fake stack is released)
+#endif
+        swapcontext(&f.ctx, &s.main_);
+        die("a finished fiber was resumed");
+    }
+    std::vector<std::unique_ptr<Fiber>> fibers_;
+    const std::function<void(int)>* job_ = nullptr;
+    ucontext_t main_;
+    [[maybe_unused]] const void* main_bottom_ = nullptr;   // (ASan) bounds of the scheduler's own stack
+    [[maybe_unused]] size_t main_size_ = 0;
+    int cur_ = -1;
+    unsigned long long progress_ = 0;
+};
+inline void yield() { Fibers::get().yield_current(); }
+inline void Barrier::arrive_and_wait()
+{
+    const unsigned mine = phase;
+    if (++arrived >= expected) {
+        arrived = 0;
+        ++phase;
+        Fibers::get().progressed();
+        return;
+    }
+    while (phase == mine) yield();
+}
+inline void Barrier::arrive_and_drop()
+{
+    --expected;
+    if (expected > 0 && arrived >= expected) {   // the lanes already waiting were only waiting for this one
+        arrived = 0;
+        ++phase;
+        Fibers::get().progressed();
+    }
+}
 
 // runs fn(lane) on 64 lockstep lanes
 inline void run_wave(const std::function<void(int)>& fn)
 {
     Wave w;
     for (int l = 0; l < 64; ++l) w.active[l] = 1;
-    std::vector<std::thread> th;
-    th.reserve(64);
-    for (int l = 0; l < 64; ++l)
-        th.emplace_back([&, l]() {
-            tl_lane = l;
-            tl_wave = &w;
-            tl_tid = ic3_host_dim3{ (unsigned)l, 0, 0 };
-            fn(l);
-            w.active[l] = 0;
-            w.bar.arrive_and_drop();   // a lane that returns leaves the barrier (all cross-lane ops are behind it)
-        });
-    for (auto& t : th) t.join();
+    Fibers::get().run(64, [&](int l) {
+        tl_lane = l;
+        tl_wave = &w;
+        tl_tid = ic3_host_dim3{ (unsigned)l, 0, 0 };
+        fn(l);
+        w.active[l] = 0;
+        w.bar.arrive_and_drop();   // a lane that returns leaves the barrier (all cross-lane ops are behind it)
+    });
 }
 inline long long exchange(long long v, int src)
 {
@@ -78,6 +262,13 @@ inline long long exchange(long long v, int src)
 }  // namespace ic3_host
 
 #define threadIdx (ic3_host::tl_tid)
+#define blockIdx (ic3_host::tl_bid)
+#define blockDim (ic3_host::tl_bdim)
+#define gridDim (ic3_host::tl_gdim)
+#define __shared__ static
+// (ic3_common.hpp's spelling of `extern __shared__ T name[]`)
+#define IC3_DYNAMIC_LDS(T, name) T* const name = reinterpret_cast<T*>(ic3_host::dynamic_lds())
+inline void __syncthreads() { ic3_host::tl_block->bar.arrive_and_wait(); }
 
 inline unsigned long long __ballot(int pred)
 {
@@ -138,3 +329,125 @@ inline ic3_host_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc
     if ((uint64_t)off + 16 <= r.bytes) std::memcpy(&v, r.base + off, 16);
     return v;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// whole kernels: launches, the HIP runtime calls of the C ABI, the remaining device intrinsics
+// ---------------------------------------------------------------------------------------------------------------------
+namespace ic3_host {
+template <class... P, class... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, A&&... args)
+{
+    std::tuple<std::decay_t<P>...> params{ static_cast<std::decay_t<P>>(std::forward<A>(args))... };
+    const int nt = (int)(block.x * block.y * block.z);
+    if (nt <= 0 || lds_bytes > LDS_BYTES) std::abort();
+    const int nwaves = (nt + 63) / 64;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                std::memset(dynamic_lds(), 0xCD, lds_bytes);   // poison: what a kernel reads it must have written
+                Block blk(nt);
+                std::vector<std::unique_ptr<Wave>> waves;
+                for (int w = 0; w < nwaves; ++w) {
+                    const int lanes = std::min(64, nt - 64 * w);
+                    waves.emplace_back(new Wave(lanes));
+                    for (int l = 0; l < 64; ++l) waves[w]->active[l] = l < lanes;
+                }
+                Fibers::get().run(nt, [&](int t) {
+                        Wave* w = waves[t >> 6].get();
+                        tl_lane = t & 63;
+                        tl_wave = w;
+                        tl_block = &blk;
+                        tl_tid = ic3_host_dim3{ (unsigned)t % block.x, ((unsigned)t / block.x) % block.y,
+                                                (unsigned)t / (block.x * block.y) };
+                        tl_bid = ic3_host_dim3{ bx, by, bz };
+                        tl_bdim = ic3_host_dim3{ block.x, block.y, block.z };
+                        tl_gdim = ic3_host_dim3{ grid.x, grid.y, grid.z };
+                        std::apply(kernel, params);
+                        w->active[t & 63] = 0;
+                        w->bar.arrive_and_drop();
+                        blk.bar.arrive_and_drop();
+                    });
+            }
+}
+}  // namespace ic3_host
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    ic3_host::launch(kernel, grid, block, lds, stream, ##__VA_ARGS__)
+
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+template <class T>
+inline hipError_t hipMalloc(T** p, size_t bytes)
+{
+    *p = (T*)std::malloc(bytes ? bytes : 1);   // (uninitialised, like device memory; ASan / UBSan watch its bounds)
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int device) { return device == -1 ? hipSuccess : hipErrorInvalidDevice; }   // the host "device"
+inline hipError_t hipGetDevice(int* device) { *device = -1; return hipSuccess; }
+template <class F>
+inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+struct ic3_host_event {
+    std::chrono::steady_clock::time_point t;
+};
+typedef ic3_host_event* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new ic3_host_event{ std::chrono::steady_clock::now() }; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
+{
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
+template <class T>
+inline T ic3_host_shfl_any(T v, int src)
+{
+    static_assert(sizeof(T) <= 8, "shuffle of up to 8 bytes");
+    long long raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    raw = ic3_host::exchange(raw, src);
+    std::memcpy(&v, &raw, sizeof(T));
+    return v;
+}
+inline double __shfl(double v, int src) { return ic3_host_shfl_any(v, src); }
+inline unsigned __shfl(unsigned v, int src) { return ic3_host_shfl_any(v, src); }
+template <class T>
+inline T __shfl_down(T v, int d) { return __shfl(v, ic3_host::tl_lane + d < 64 ? ic3_host::tl_lane + d : ic3_host::tl_lane); }
+template <class T>
+inline T __shfl_up(T v, int d) { return __shfl(v, ic3_host::tl_lane - d >= 0 ? ic3_host::tl_lane - d : ic3_host::tl_lane); }
+
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class F, class I>
+inline F ic3_host_atomic_add_fp(F* p, F v)
+{
+    I old, want;
+    F cur;
+    __atomic_load((I*)p, &old, __ATOMIC_RELAXED);
+    do {
+        std::memcpy(&cur, &old, sizeof(F));
+        const F next = cur + v;
+        std::memcpy(&want, &next, sizeof(F));
+    } while (!__atomic_compare_exchange((I*)p, &old, &want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return cur;
+}
+inline float atomicAdd(float* p, float v) { return ic3_host_atomic_add_fp<float, uint32_t>(p, v); }
+inline double atomicAdd(double* p, double v) { return ic3_host_atomic_add_fp<double, uint64_t>(p, v); }
+inline int atomicMax(int* p, int v)
+{
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
+inline float __builtin_amdgcn_logf(float x) { return std::log2(x); }   // v_log_f32: base 2

@@ -578,3 +578,40 @@ def test_hip_reproduces_reference_checksum_sweep():
             got = crc_of(st["alive"][0], st["wait"][0], loc, st["last_act"][0], st["route_loc"][0], st["route_id"][0],
                          rew.cpu().numpy()[0], obs.cpu().numpy()[0])
             assert got == crcs[t], (cfg, t)
+
+
+@pytest.mark.parametrize("kind", ["pp", "tj_zero_fill_rows", "tj_vec4_rows"])
+def test_observe_at_reads_the_snapshot_not_the_live_state(kind):
+    """ic3_env_observe_at: the rows of the state in `snap` whatever the handle's live state has become since (every launch
+    geometry of the observation kernels; found by tests/test_host_abi_cpu.py — the Traffic-Junction zero-fill geometry read
+    the live state)."""
+    if kind == "pp":
+        env = make_pp(5, 10, 1, "mixed", 6, seed=3)
+    elif kind == "tj_zero_fill_rows":
+        env = make_tj(6, 8, 1, "medium", 6, seed=3, add_rate_min=0.5, add_rate_max=0.5)
+        assert env.nagents_env * env.obs_dim < 8192
+    else:
+        env = make_tj(20, 18, 1, "hard", 4, seed=3, add_rate_min=0.5, add_rate_max=0.5)
+        assert env.nagents_env * env.obs_dim >= 8192
+    rng = np.random.default_rng(4)
+    E, N, A = env.nenvs, env.nagents_env, env.dims.naction
+    env.reset(0)
+    for _ in range(6):
+        env.step(rng.integers(0, A, (E, N)))
+    want = env.observe().clone()
+    snap = env.snapshot()
+    for _ in range(3):
+        env.step(rng.integers(0, A, (E, N)))
+    assert not torch.equal(env.observe(), want)                        # the live state has moved on
+    assert torch.equal(env.observe_timed(snap), want)
+    assert not torch.equal(env.observe(), want)
+
+
+def test_gpu_library_refuses_the_host_device():
+    """device = -1 is the host build's (tests/host/libic3rollout_host.so); the product has no CPU path."""
+    import ctypes as C
+    from ic3net_amd import _lib
+    cfg = _lib.PPCfg(2, 3, 1, 5, 0, 0, 1, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert _lib.lib().ic3_pp_create(C.byref(cfg), -1, C.byref(h)) < 0
+    assert b"hipSetDevice" in _lib.lib().ic3_last_error()

@@ -2,7 +2,7 @@
 
 ic3net_amd/csrc/env_device.hpp holds the Predator-Prey / Traffic-Junction step, window-table and observation-patch bodies that
 every launch geometry of libic3rollout runs.  tests/host/ic3_host_build.cpp compiles that header with a stand-in HIP runtime
-(64 lockstep host threads per wavefront) so the same code can be driven over the reference's own trajectories without a GPU,
+(64 cooperatively scheduled lane fibers per wavefront) so the same code can be driven over the reference's own trajectories without a GPU,
 and — with IC3_HOST_ASAN=1 (tools/host_asan.sh) — under AddressSanitizer + UndefinedBehaviorSanitizer.
 Integer state bit-exact; rewards as float32(reference float64) bit-exact; observations bit-exact."""
 import ctypes
