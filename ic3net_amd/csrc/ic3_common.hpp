@@ -116,11 +116,15 @@ struct Range {
     bool on;
 };
 
+// A failed runtime call is reported through the return code + ic3_last_error(); the runtime's own "last error" is read
+// back so that the caller's next HIP call (torch's, say) does not trip over it.
 #define IC3_HIP(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \
-        if (_e != hipSuccess)                                                                             \
+        if (_e != hipSuccess) {                                                                           \
+            (void)hipGetLastError();                                                                      \
             return ic3::fail(-5 /*EIO*/, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+        }                                                                                                 \
     } while (0)
 
 // LSTM nonlinearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each), shared by the

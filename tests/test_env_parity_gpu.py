@@ -595,7 +595,7 @@ def test_observe_at_reads_the_snapshot_not_the_live_state(kind):
         assert env.nagents_env * env.obs_dim >= 8192
     rng = np.random.default_rng(4)
     E, N, A = env.nenvs, env.nagents_env, env.dims.naction
-    env.reset(0)
+    env.reset() if kind == "pp" else env.reset(0)
     for _ in range(6):
         env.step(rng.integers(0, A, (E, N)))
     want = env.observe().clone()
@@ -615,3 +615,5 @@ def test_gpu_library_refuses_the_host_device():
     h = C.c_void_p()
     assert _lib.lib().ic3_pp_create(C.byref(cfg), -1, C.byref(h)) < 0
     assert b"hipSetDevice" in _lib.lib().ic3_last_error()
+    torch.cuda.synchronize()                                           # the refusal leaves no sticky runtime error behind
+    assert torch.zeros(4, device='cuda').sum().item() == 0
