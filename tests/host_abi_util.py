@@ -152,6 +152,18 @@ class HostEnv(object):
             buf[off:off + cnt] = np.asarray(val, np.int32).reshape(-1)
         check(self.lib.ic3_env_set_state(self._h, p(buf), buf.nbytes, None))
 
+    def reset_to(self, state, epoch=-1):
+        """ic3_env_reset_to with a FULL state dump (dict as from get_state, or the raw int32 buffer)."""
+        if isinstance(state, dict):
+            buf = self.raw_state()
+            for name, val in state.items():
+                off, cnt = self._field(name)
+                buf[off:off + cnt] = np.asarray(val, np.int32).reshape(-1)
+            state = buf
+        obs = self._obs_buf()
+        check(self.lib.ic3_env_reset_to(self._h, int(epoch), p(state), state.nbytes, p(obs), None))
+        return obs
+
     def snapshot(self):
         snap = np.empty(self.dims.state_words, np.int32)
         check(self.lib.ic3_env_snapshot(self._h, p(snap), None))

@@ -337,3 +337,243 @@ def test_sanitizer_sees_a_kernel_writing_past_its_buffer():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "survived" not in r.stdout
     assert "AddressSanitizer" in r.stderr and "heap-buffer-overflow" in r.stderr, r.stderr[-2000:]
+
+
+def test_randomized_config_sweep_vs_oracle():
+    """The GPU suite's randomized sweep (tests/test_env_parity_gpu.py, same seed, same 40 + 30 configurations) through the
+    host ABI: random Predator-Prey and Traffic-Junction configurations (odd / even dims -> both obs store paths, vision 0..2, every lane-group size, all modes
+    / difficulties / vocab types, enemy_comm, big rows -> the 1024-lane obs geometries) for a few steps each, env by env
+    against the oracle.  Under the sanitizers this is the bounds check of every launch geometry of the env kernels."""
+    import oracle
+    rs = np.random.RandomState(2024)
+    for trial in range(40):
+        dim = int(rs.randint(2, 13))
+        N = int(rs.randint(1, min(12, dim * dim - 1) + 1))
+        v = int(rs.randint(0, 3))
+        mode = ["mixed", "cooperative", "competitive"][rs.randint(3)]
+        ec = bool(rs.rand() < 0.3)
+        no_stay = bool(rs.rand() < 0.2)
+        E = int(rs.randint(1, 20))
+        seed, off = int(rs.randint(1 << 30)), int(rs.randint(1 << 20))
+        env = HostEnv.pp(N, dim, v, mode, E, seed=seed, offset=off, no_stay=no_stay, enemy_comm=ec)
+        orcs = [oracle.PPOracle(N, dim, v, mode, stay=not no_stay, seed=seed, env_gid=off + e, enemy_comm=ec)
+                for e in range(E)]
+        R = N + (1 if ec else 0)
+        obs = env.reset()
+        for e, o in enumerate(orcs):
+            np.testing.assert_array_equal(obs[e], o.reset(), err_msg="pp reset trial %d" % trial)
+        for t in range(6):
+            act = rs.randint(0, 4 if no_stay else 5, size=(E, R))
+            obs, rew, done, _ = env.step(act)
+            for e, o in enumerate(orcs):
+                if o.over.value:
+                    assert done[e] == 1
+                    continue
+                oo, orew, od = o.step(act[e])
+                np.testing.assert_array_equal(obs[e], oo, err_msg="pp obs trial %d" % trial)
+                np.testing.assert_array_equal(rew[e], orew.astype(np.float32), err_msg="pp reward trial %d" % trial)
+                assert done[e] == int(od)
+        env.close()
+    tj_dims = {"easy": [6, 8, 10], "medium": [6, 8, 10, 14], "hard": [9, 12, 15, 18]}
+    for trial in range(30):
+        diff = ["easy", "medium", "hard"][rs.randint(3)]
+        dim = int(tj_dims[diff][rs.randint(len(tj_dims[diff]))])
+        v = int(rs.randint(0, 3))
+        if diff != "hard" and dim < 4 + v:
+            v = 0
+        N = int(rs.randint(1, 25))
+        rate = float([0.05, 0.3, 0.7, 1.0][rs.randint(4)])
+        vt = "scalar" if rs.rand() < 0.3 else "bool"
+        E = int(rs.randint(1, 12))
+        seed, off = int(rs.randint(1 << 30)), int(rs.randint(1 << 20))
+        env = HostEnv.tj(N, dim, v, diff, E, seed=seed, offset=off, add_rate_min=rate, add_rate_max=rate, vocab_type=vt)
+        orcs = [oracle.TJOracle(N, dim, v, diff, add_rate_min=rate, add_rate_max=rate, seed=seed, env_gid=off + e,
+                                vocab_type=vt) for e in range(E)]
+        env.reset(0)
+        for o in orcs:
+            o.reset(0)
+        for t in range(10):
+            act = (rs.rand(E, N) < 0.4).astype(np.int32)
+            obs, rew, done, info = env.step(act)
+            st = env.get_state()
+            for e, o in enumerate(orcs):
+                oo, orew, _ = o.step(act[e])
+                np.testing.assert_array_equal(st["alive"][e], o.alive, err_msg="tj alive trial %d" % trial)
+                np.testing.assert_array_equal(st["route_id"][e], o.route_id)
+                np.testing.assert_array_equal(obs[e], oo, err_msg="tj obs trial %d (%s dim %d v %d N %d %s)" %
+                                              (trial, diff, dim, v, N, vt))
+                np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+        env.close()
+
+
+def test_reset_to_a_given_state():
+    """ic3_env_reset_to (SURVEY 8(b2) `init_state_or_null`): reset into a recorded state, and stepping from there reproduces
+    the recorded trajectory."""
+    envA = HostEnv.pp(5, 8, 1, "mixed", 6, seed=3)
+    envA.reset()
+    rs = np.random.RandomState(0)
+    for _ in range(3):
+        envA.step(rs.randint(0, 5, size=(6, 5)))
+    snap = envA.raw_state()
+    obs_snap = envA.observe()
+    acts = rs.randint(0, 5, size=(4, 6, 5))
+    want = [envA.step(a)[:3] for a in acts]
+    envB = HostEnv.pp(5, 8, 1, "mixed", 6, seed=3)
+    envB.reset()                                              # a different state (fresh episode) ...
+    obs = envB.reset_to(snap)                                 # ... replaced by the recorded one
+    np.testing.assert_array_equal(obs, obs_snap)
+    np.testing.assert_array_equal(envB.raw_state(), snap)
+    for a, (o, r, d) in zip(acts, want):
+        o2, r2, d2, _ = envB.step(a)
+        np.testing.assert_array_equal(o2, o)
+        np.testing.assert_array_equal(r2, r)
+        np.testing.assert_array_equal(d2, d)
+    with pytest.raises(ValueError, match="size mismatch"):
+        envB.reset_to(snap[:-1].copy())
+    tj = HostEnv.tj(5, 6, 1, "easy", 3, seed=1, add_rate_min=0.5, add_rate_max=0.5)
+    tj.reset(0)
+    tj.step(np.zeros((3, 5), np.int32))
+    st = tj.raw_state()
+    o1 = tj.observe()
+    tj.step(np.ones((3, 5), np.int32))
+    np.testing.assert_array_equal(tj.reset_to(st, epoch=0), o1)
+
+
+def test_max_agents_per_env_vs_oracle():
+    """N = 64 (one env per wavefront, the full 64-bit ballot mask) for PP, and N = 48 cars for TJ-hard; N = 65 is refused."""
+    import oracle
+    E = 3
+    env = HostEnv.pp(64, 10, 1, "cooperative", E, seed=8, offset=3)
+    orcs = [oracle.PPOracle(64, 10, 1, "cooperative", seed=8, env_gid=3 + e) for e in range(E)]
+    obs = env.reset()
+    for e, o in enumerate(orcs):
+        np.testing.assert_array_equal(obs[e], o.reset())
+    rs = np.random.RandomState(1)
+    for t in range(6):
+        act = rs.randint(0, 5, size=(E, 64))
+        obs, rew, done, _ = env.step(act)
+        for e, o in enumerate(orcs):
+            oo, orew, od = o.step(act[e])
+            np.testing.assert_array_equal(obs[e], oo)
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+    tj = HostEnv.tj(48, 18, 1, "hard", E, seed=8, offset=3, add_rate_min=0.9, add_rate_max=0.9)
+    torcs = [oracle.TJOracle(48, 18, 1, "hard", add_rate_min=0.9, add_rate_max=0.9, seed=8, env_gid=3 + e)
+             for e in range(E)]
+    tj.reset(0)
+    for o in torcs:
+        o.reset(0)
+    for t in range(15):
+        act = (rs.rand(E, 48) < 0.5).astype(np.int32)
+        obs, rew, done, info = tj.step(act)
+        st = tj.get_state()
+        for e, o in enumerate(torcs):
+            oo, orew, _ = o.step(act[e])
+            np.testing.assert_array_equal(st["alive"][e], o.alive)
+            np.testing.assert_array_equal(st["route_id"][e], o.route_id)
+            np.testing.assert_array_equal(obs[e], oo)
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+    with pytest.raises(ValueError):
+        HostEnv.pp(65, 10, 1, "mixed", 2)                    # N > 64 is rejected, not mis-simulated
+    with pytest.raises(NotImplementedError):                  # predator_prey_env.py:84-85
+        from ic3net_amd import _lib as binding
+        cfg = binding.PPCfg(2, 3, 1, 5, 0, 0, 1, 1, 0, 0, 0)
+        check(host_lib().ic3_pp_create(C.byref(cfg), -1, C.byref(C.c_void_p())))
+
+
+def test_kernels_reproduce_reference_checksum_sweep():
+    """The 210-configuration checksum sweep recorded from the reference (tests/golden/make_golden_sweep.py), through the
+    product's kernels on the host (one handle per configuration, E = 1 like the reference)."""
+    from golden_util import crc_of, SWEEP_RATES
+    fx = load("sweep_checksums")
+    seed = int(fx["seed"])
+    for cfg, acts, crcs in zip(fx["pp_cfg"], fx["pp_act"], fx["pp_crc"]):
+        N, dim, v, mode, ec, ns, gid = [int(x) for x in cfg]
+        env = HostEnv.pp(N, dim, v, MODES[mode], 1, seed=seed, offset=gid, no_stay=bool(ns), enemy_comm=bool(ec))
+        obs = env.reset()[0]
+        st = env.get_state()
+        loc = np.stack([st["loc_r"][0], st["loc_c"][0]], -1)
+        assert crc_of(loc[:N], loc[N:], obs) == crcs[0], cfg
+        over = False
+        for t in range(acts.shape[0]):
+            if over:
+                assert crcs[t + 1] == 0
+                continue
+            obs, rew, done, _ = env.step(acts[t:t + 1, :N + ec])
+            st = env.get_state()
+            loc = np.stack([st["loc_r"][0], st["loc_c"][0]], -1)
+            over = bool(done[0])
+            got = crc_of(loc[:N], st["reached"][0], rew[0], obs[0], np.int32(int(over)))
+            assert got == crcs[t + 1], (cfg, t)
+        env.close()
+    for cfg, acts, crcs in zip(fx["tj_cfg"], fx["tj_act"], fx["tj_crc"]):
+        N, dim, v, diff, rate_i, scalar, gid = [int(x) for x in cfg]
+        r = SWEEP_RATES[rate_i]
+        env = HostEnv.tj(N, dim, v, DIFFS[diff], 1, seed=seed, offset=gid, add_rate_min=r, add_rate_max=r,
+                         vocab_type='scalar' if scalar else 'bool')
+        env.reset(0)
+        for t in range(acts.shape[0]):
+            obs, rew, _, _ = env.step(acts[t:t + 1, :N])
+            st = env.get_state()
+            loc = np.stack([st["loc_r"][0], st["loc_c"][0]], -1)
+            got = crc_of(st["alive"][0], st["wait"][0], loc, st["last_act"][0], st["route_loc"][0], st["route_id"][0],
+                         rew[0], obs[0])
+            assert got == crcs[t], (cfg, t)
+        env.close()
+
+
+@pytest.mark.parametrize("H", [4, 16, 64, 256])
+def test_cell_backward_and_fused_cell_heads_draws(H):
+    """ic3_lstm_cell_backward (torch.nn.LSTMCell's derivative + per-workgroup bias partials) against the closed form, and
+    ic3_lstm_cell_heads (cell + heads + log_softmax + the draws of every head in one launch, comm.py:215-239 +
+    action_utils.py:32-36) against ic3_lstm_cell -> ic3_policy_heads -> ic3_env_sample_actions on the same inputs."""
+    lib = host_lib()
+    rng = np.random.default_rng(H)
+    env = HostEnv.pp(5, 8, 1, "mixed", 7, seed=21, offset=5)
+    env.reset()
+    env.step(rng.integers(0, 5, (7, 5)), with_obs=False)               # t = 1, episode 0: the draw counters of the env
+    R = env.E * env.N
+    gates = rng.standard_normal((R, 4 * H)).astype(np.float32)
+    c_prev = rng.standard_normal((R, H)).astype(np.float32)
+    dh = rng.standard_normal((R, H)).astype(np.float32)
+    dc = rng.standard_normal((R, H)).astype(np.float32)
+    dgates = np.full((R, 4 * H), np.nan, np.float32)
+    dc_prev = np.full((R, H), np.nan, np.float32)
+    parts = np.full((2048, 4 * H), np.nan, np.float32)
+    nb = check(lib.ic3_lstm_cell_backward(p(gates), p(c_prev), p(dh), p(dc), p(dgates), p(dc_prev), p(parts), R, H, None))
+    g64 = gates.astype(np.float64)
+    sig = lambda x: 1 / (1 + np.exp(-x))
+    i, f, g, o = sig(g64[:, :H]), sig(g64[:, H:2 * H]), np.tanh(g64[:, 2 * H:3 * H]), sig(g64[:, 3 * H:])
+    c = f * c_prev + i * g
+    tc = np.tanh(c)
+    dct = dc + dh * o * (1 - tc * tc)
+    want = np.concatenate([dct * g * i * (1 - i), dct * c_prev * f * (1 - f), dct * i * (1 - g * g), dh * tc * o * (1 - o)], 1)
+    np.testing.assert_allclose(dgates, want, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dc_prev, dct * f, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(parts[:nb].astype(np.float64).sum(0), want.sum(0), rtol=0, atol=1e-4)
+
+    heads = np.array([5, 2], np.int32)
+    OT = 8
+    W = (rng.standard_normal((OT, H)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(OT).astype(np.float32)
+    c1, c2 = c_prev.copy(), c_prev.copy()
+    h1 = np.full((R, 2 * H), np.nan, np.float32)                       # h written into the right half of an [x | h] row
+    h2 = np.full((R, H), np.nan, np.float32)
+    out1 = np.full((R, OT), np.nan, np.float32)
+    out2 = np.full((R, OT), np.nan, np.float32)
+    act1 = np.full((2, env.E, env.N), -1, np.int32)
+    act2 = np.full((2, env.E, env.N), -1, np.int32)
+    check(lib.ic3_lstm_cell_heads(p(gates), p(c1), C.c_void_p(h1.ctypes.data + 4 * H), 2 * H, R, H, p(W), p(b), p(heads), 2,
+                                  p(out1), env._h, p(act1), None))
+    check(lib.ic3_lstm_cell(p(gates), p(c2), p(h2), H, R, H, None))
+    check(lib.ic3_policy_heads(p(h2), H, p(W), p(b), p(heads), 2, p(out2), R, H, None))
+    np.testing.assert_array_equal(c1, c2)
+    np.testing.assert_array_equal(h1[:, H:], h2)
+    assert np.isnan(h1[:, :H]).all()
+    np.testing.assert_allclose(out1, out2, rtol=0, atol=2e-6)
+    off = 0
+    for k, A in enumerate(heads):
+        lp = np.ascontiguousarray(out1[:, off:off + A])
+        check(lib.ic3_env_sample_actions(env._h, p(lp), int(A), int(A), k, p(act2[k]), None, None))
+        off += A
+    np.testing.assert_array_equal(act1, act2)
+    env.close()
