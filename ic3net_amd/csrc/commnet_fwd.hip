@@ -36,7 +36,7 @@ template <int H>
 __global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const CommnetArgs a)
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, H4 = H / 4, KB = K / 8, BM = 64;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    IC3_DYNAMIC_LDS(float, smem);
     float* const As = smem;                                      // [BM][LDA]: cols [0,H) comm, [H,2H) h
     cn_f32x4* const As4 = reinterpret_cast<cn_f32x4*>(smem);
     float* const sm = As + BM * LDA;                             // [BM] m_j = alive_j * comm_action_j

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, KB = K / 8, K4 = K / 4, RING = 8;
     static_assert(KB % 2 == 0 && KB >= 4, "K / 8 must be even");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    IC3_DYNAMIC_LDS(float, smem);
     float* const As = smem;                                      // [64][LDA]
     gb_f32x4* const As4 = reinterpret_cast<gb_f32x4*>(smem);
     float* const slb = As + 64 * LDA;                            // [4H]

@@ -14,6 +14,13 @@
 #ifndef IC3_DYNAMIC_LDS
 #define IC3_DYNAMIC_LDS(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #endif
+// Likewise the compiler fences of the hand-scheduled kernels: the value is opaque to the optimiser from here on and lives
+// in a scalar / vector register; wait for every outstanding vector-memory operation of the wave.
+#ifndef IC3_OPAQUE_SGPR
+#define IC3_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
+#define IC3_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#define IC3_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 namespace ic3 {
 

@@ -253,7 +253,7 @@ __device__ __forceinline__ void reload_args(StepArgs& a)
 {
     typedef const __attribute__((address_space(4))) int* KWords;
     KWords kp = (KWords)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
+    IC3_OPAQUE_SGPR(kp);
     static_assert(sizeof(StepArgs) % 4 == 0, "StepArgs is a whole number of dwords");
     int* dst = reinterpret_cast<int*>(&a);
 #pragma unroll
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
     constexpr int ABL = IC3_PS_ABL;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    IC3_DYNAMIC_LDS(float, smem);
     float* const As = smem;                                      // [BM][LDA]: cols [0,H) enc / comm / inp, [H,2H) h / h'
     ps_f32x4* const As4 = reinterpret_cast<ps_f32x4*>(smem);
     float* const sm = As + BM * LDA;                             // [BM] m_j = alive_j * comm_action_j
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     float cold[2][16];
     __amdgpu_buffer_rsrc_t zr;                                   // descriptor of the tile's obs slice (see below)
     ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
-    asm volatile("" : "+v"(zv));                                 // keep it in registers (no re-materialisation per store)
+    IC3_OPAQUE_VGPR(zv);                                        // keep it in registers (no re-materialisation per store)
     int zlane, zso;                                              // lane offset; running byte offset of this wave's next chunk (SGPR)
     auto zero_store = [&]() {
 #ifdef IC3_PS_PLAIN_STORES
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 // (the first block's planes are requested inside the store-slot variant, behind an opaque zero: in front of
                 //  the switch the compiler copies / spills the 12 fragments into every variant's own registers)
                 int zo = 0;
-                asm volatile("" : "+s"(zo));
+                IC3_OPAQUE_SGPR(zo);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         StepArgs a;
         reload_args(a);
         int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        IC3_OPAQUE_VGPR(tid);
         const TileGeom g = tile_geom<KIND>(a, blockIdx.x);
         const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
         const int col = 32 * w + li;
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         if (obs_here && !(ABL & 32)) {
             // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
             // first non-zero entry goes out to the same lines
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            IC3_WAIT_VMEM();
             __syncthreads();
             IC3_TR(16);
             float* orow0 = a.obs + g.ob0;
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         if (d.x != vocab - 2 && (d.y >> 16) != 0) cell[vocab - 2] = 0.f;
                         if (d.x != vocab - 1 && (d.y & 0xffff) != 0) cell[vocab - 1] = 0.f;
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a cleared word may be painted again by another thread
+                    IC3_WAIT_VMEM();   // a cleared word may be painted again by another thread
                     __syncthreads();
                 }
                 for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                             if (d.x != a.tj.car_class && d.y != 0) cell[a.tj.car_class] = 0.f;
                         }
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    IC3_WAIT_VMEM();
                     __syncthreads();
                 }
                 for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {

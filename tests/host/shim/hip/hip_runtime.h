@@ -83,6 +83,7 @@ struct Wave {
     explicit Wave(int lanes = 64) : bar(lanes) {}
     long long vals[64];
     int active[64];   // a lane that has returned contributes 0 to later ballots (like an exited hardware lane)
+    alignas(16) unsigned char wide[64][32];   // operands of an emulated MFMA (up to 2 x 16 bytes per lane)
 };
 struct Block {
     Barrier bar;
@@ -92,6 +93,7 @@ inline int tl_lane = 0;
 inline Wave* tl_wave = nullptr;
 inline Block* tl_block = nullptr;
 inline ic3_host_dim3 tl_tid{ 0, 0, 0 }, tl_bid{ 0, 0, 0 }, tl_bdim{ 64, 1, 1 }, tl_gdim{ 1, 1, 1 };
+inline const void* tl_kernarg = nullptr;   // the first kernel parameter of the running launch (__builtin_amdgcn_kernarg_segment_ptr)
 constexpr size_t LDS_BYTES = 160 * 1024;
 inline void* dynamic_lds()
 {
@@ -268,6 +270,10 @@ inline long long exchange(long long v, int src)
 #define __shared__ static
 // (ic3_common.hpp's spelling of `extern __shared__ T name[]`)
 #define IC3_DYNAMIC_LDS(T, name) T* const name = reinterpret_cast<T*>(ic3_host::dynamic_lds())
+// (ic3_common.hpp's compiler fences of the hand-scheduled kernels)
+#define IC3_OPAQUE_SGPR(x) asm volatile("" : "+r"(x))
+#define IC3_OPAQUE_VGPR(x) asm volatile("" : "+m"(x))
+#define IC3_WAIT_VMEM() asm volatile("" ::: "memory")
 inline void __syncthreads() { ic3_host::tl_block->bar.arrive_and_wait(); }
 
 inline unsigned long long __ballot(int pred)
@@ -322,11 +328,11 @@ inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, 
     return __amdgpu_buffer_rsrc_t{ (const char*)p, (uint32_t)bytes };
 }
 typedef unsigned int ic3_host_u32x4 __attribute__((ext_vector_type(4)));
+inline void ic3_host_buf_read(__amdgpu_buffer_rsrc_t r, int voff, int soff, void* out, int dwords);
 inline ic3_host_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int)
 {
-    ic3_host_u32x4 v = { 0, 0, 0, 0 };
-    const uint32_t off = (uint32_t)voff + (uint32_t)soff;
-    if ((uint64_t)off + 16 <= r.bytes) std::memcpy(&v, r.base + off, 16);
+    ic3_host_u32x4 v;
+    ic3_host_buf_read(r, voff, soff, &v, 4);
     return v;
 }
 
@@ -338,6 +344,7 @@ template <class... P, class... A>
 inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, A&&... args)
 {
     std::tuple<std::decay_t<P>...> params{ static_cast<std::decay_t<P>>(std::forward<A>(args))... };
+    if constexpr (sizeof...(P) > 0) tl_kernarg = &std::get<0>(params);
     const int nt = (int)(block.x * block.y * block.z);
     if (nt <= 0 || lds_bytes > LDS_BYTES) std::abort();
     const int nwaves = (nt + 63) / 64;
@@ -451,3 +458,152 @@ inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned 
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 inline float __builtin_amdgcn_logf(float x) { return std::log2(x); }   // v_log_f32: base 2
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the matrix-core kernels (policy_step.hip, gates_bwd.hip, commnet_fwd.hip): MFMA as a cross-lane operation with the
+// hardware's operand / result layouts, raw buffer loads / stores with the descriptor's range check (per dword, VGPR +
+// SGPR offset, unsigned — tools/exp/buf_probe.hip), the scalar helpers
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float ic3_host_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ic3_host_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ic3_host_bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace ic3_host {
+// every live lane of the wave deposits `bytes` at wide[lane], then all read; two barriers like exchange()
+template <class F>
+inline void wave_gather(const void* mine, size_t bytes, F&& use)
+{
+    Wave* w = tl_wave;
+    std::memcpy(w->wide[tl_lane], mine, bytes);
+    w->bar.arrive_and_wait();
+    use(w->wide);
+    w->bar.arrive_and_wait();
+}
+}  // namespace ic3_host
+
+// v_mfma_f32_32x32x2_f32: A[i][k] in lane 32 k + i, B[k][j] in lane 32 k + j; D[i][j]: lane 32 ((i / 4) % 2) + j, register 4 (i / 8) + i % 4
+inline ic3_host_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, ic3_host_f32x16 c, int, int, int)
+{
+    const float ab[2] = { a, b };
+    const int lane = ic3_host::tl_lane, j = lane & 31, hi = lane >> 5;
+    ic3_host::wave_gather(ab, sizeof(ab), [&](unsigned char (*wide)[32]) {
+        for (int r = 0; r < 16; ++r) {
+            const int i = 8 * (r >> 2) + 4 * hi + (r & 3);
+            float acc = c[r];
+            for (int k = 0; k < 2; ++k) {
+                float av, bv;
+                std::memcpy(&av, wide[32 * k + i], 4);
+                std::memcpy(&bv, wide[32 * k + j] + 4, 4);
+                acc += av * bv;
+            }
+            c[r] = acc;
+        }
+    });
+    return c;
+}
+// v_mfma_f32_16x16x4_f32: A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j; D[i][j]: lane 16 (i / 4) + j, register i % 4
+inline ic3_host_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, ic3_host_f32x4 c, int, int, int)
+{
+    const float ab[2] = { a, b };
+    const int lane = ic3_host::tl_lane, j = lane & 15, q = lane >> 4;
+    ic3_host::wave_gather(ab, sizeof(ab), [&](unsigned char (*wide)[32]) {
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            float acc = c[r];
+            for (int k = 0; k < 4; ++k) {
+                float av, bv;
+                std::memcpy(&av, wide[16 * k + i], 4);
+                std::memcpy(&bv, wide[16 * k + j] + 4, 4);
+                acc += av * bv;
+            }
+            c[r] = acc;
+        }
+    });
+    return c;
+}
+// v_mfma_f32_32x32x16_bf16: A[i][8 h + e] = element e of lane 32 h + i, B[8 h + e][j] = element e of lane 32 h + j; D as 32x32x2
+inline ic3_host_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(ic3_host_bf16x8 a, ic3_host_bf16x8 b, ic3_host_f32x16 c, int, int, int)
+{
+    unsigned char ab[32];
+    std::memcpy(ab, &a, 16);
+    std::memcpy(ab + 16, &b, 16);
+    const int lane = ic3_host::tl_lane, j = lane & 31, hi = lane >> 5;
+    auto bf = [](const unsigned char* p) {
+        uint16_t u;
+        std::memcpy(&u, p, 2);
+        const uint32_t w = (uint32_t)u << 16;
+        float f;
+        std::memcpy(&f, &w, 4);
+        return f;
+    };
+    ic3_host::wave_gather(ab, sizeof(ab), [&](unsigned char (*wide)[32]) {
+        for (int r = 0; r < 16; ++r) {
+            const int i = 8 * (r >> 2) + 4 * hi + (r & 3);
+            float acc = c[r];
+            for (int h = 0; h < 2; ++h)
+                for (int e = 0; e < 8; ++e) acc += bf(wide[32 * h + i] + 2 * e) * bf(wide[32 * h + j] + 16 + 2 * e);
+            c[r] = acc;
+        }
+    });
+    return c;
+}
+
+inline void ic3_host_buf_read(__amdgpu_buffer_rsrc_t r, int voff, int soff, void* out, int dwords)
+{
+    std::memset(out, 0, 4 * (size_t)dwords);
+    const uint32_t off = (uint32_t)voff + (uint32_t)soff;
+    for (int d = 0; d < dwords; ++d)
+        if ((uint64_t)off + 4 * d + 4 <= r.bytes) std::memcpy((char*)out + 4 * d, r.base + off + 4 * d, 4);
+}
+inline void ic3_host_buf_write(__amdgpu_buffer_rsrc_t r, int voff, int soff, const void* in, int dwords)
+{
+    const uint32_t off = (uint32_t)voff + (uint32_t)soff;
+    for (int d = 0; d < dwords; ++d)   // out-of-range dwords are dropped, like the hardware does
+        if ((uint64_t)off + 4 * d + 4 <= r.bytes) std::memcpy(const_cast<char*>(r.base) + off + 4 * d, (const char*)in + 4 * d, 4);
+}
+inline int __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    int v;
+    ic3_host_buf_read(r, voff, soff, &v, 1);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b32(int v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    ic3_host_buf_write(r, voff, soff, &v, 1);
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(ic3_host_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    ic3_host_buf_write(r, voff, soff, &v, 4);
+}
+inline int __builtin_amdgcn_readfirstlane(int v)
+{
+    ic3_host::Wave* w = ic3_host::tl_wave;
+    int first = 0;
+    while (first < 63 && !w->active[first]) ++first;
+    return __shfl(v, first);
+}
+inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void* __builtin_amdgcn_kernarg_segment_ptr() { return const_cast<void*>(ic3_host::tl_kernarg); }
+inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
+
+// what the launch helpers of the matrix-core kernels ask the runtime
+struct hipDeviceProp_t {
+    int multiProcessorCount;
+};
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int)
+{
+    prop->multiProcessorCount = 2;   // two "CUs": small tile plans still mix full and half tiles
+    return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone, hipStreamCaptureStatusActive };
+// every stream reports "being captured": the product then skips its on-device timing calibration (calibrate_tile_costs)
+// and plans tiles with its documented fallback costs — timing a host emulation would mean nothing
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st)
+{
+    *st = hipStreamCaptureStatusActive;
+    return hipSuccess;
+}

@@ -213,3 +213,54 @@ class HostEnv(object):
         db = np.full((H,), np.nan, np.float32) if want_bias else None
         check(self.lib.ic3_env_encode_backward(self._h, p(snap), p(g2), H, H, p(dwt), p(db), p(work), None))
         return dwt, db
+
+
+class HostPolicy(object):
+    """The derived weights ic3_policy_step streams (ic3net_amd.comm._fused_cache / ops._policy_struct on numpy buffers),
+    from a state_dict-shaped dict of float64 arrays (the same dict oracle.policy_ref.forward takes)."""
+
+    def __init__(self, env, params, H, head_sizes, mode_avg=True, comm_zero=False, gate_split=False, use_table=True):
+        from ic3net_amd import _lib as binding
+        lib = host_lib()
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self.H, self.heads = H, [int(a) for a in head_sizes]
+        self.OT = sum(self.heads) + 1
+        self.wt = f32(params['encoder.weight'].T)
+        self.enc_bias = f32(params['encoder.bias'] + params['C_modules.0.bias'])
+        self.loc_table = env.encode_table(self.wt) if use_table else None
+        self.c_w, self.w_ih, self.w_hh = f32(params['C_modules.0.weight']), f32(params['f_module.weight_ih']), f32(params['f_module.weight_hh'])
+        self.c_wp = np.full((H * H,), np.nan, np.float32)
+        self.l_wp = np.full((4 * H * 2 * H,), np.nan, np.float32)
+        check(lib.ic3_policy_pack(p(self.c_w), p(self.w_ih), p(self.w_hh), p(self.c_wp), p(self.l_wp), H, None))
+        self.b_cat = f32(params['f_module.bias_ih'] + params['f_module.bias_hh'])
+        self.w_heads = f32(np.concatenate([params['heads.%d.weight' % k] for k in range(len(self.heads))] + [params['value_head.weight']], 0))
+        self.b_heads = f32(np.concatenate([params['heads.%d.bias' % k] for k in range(len(self.heads))] + [params['value_head.bias']], 0))
+        pol = binding.Policy()
+        pol.H, pol.nheads = H, len(self.heads)
+        for i, a in enumerate(self.heads):
+            pol.head_sizes[i] = a
+        pol.mode_avg, pol.comm_zero = int(mode_avg), int(comm_zero)
+        pol.enc_wt, pol.enc_bias = self.wt.ctypes.data, self.enc_bias.ctypes.data
+        pol.loc_table = self.loc_table.ctypes.data if self.loc_table is not None else None
+        pol.c_wp, pol.lstm_wp, pol.lstm_bias = self.c_wp.ctypes.data, self.l_wp.ctypes.data, self.b_cat.ctypes.data
+        pol.head_w, pol.head_b = self.w_heads.ctypes.data, self.b_heads.ctypes.data
+        if gate_split:                                          # EXPERIMENT (DESIGN.md section 10)
+            self.l_wp3 = np.zeros((3 * 2 * H * 4 * H,), np.uint16)
+            check(lib.ic3_policy_pack_split(p(self.w_ih), p(self.w_hh), p(self.l_wp3), H, None))
+            pol.gate_split, pol.lstm_wp3 = 1, self.l_wp3.ctypes.data
+        self.struct = pol
+
+    def step(self, env, h, c, alive_in, comm_in, with_obs=True):
+        """ic3_policy_step: h, c (E*N, H) updated in place.  Returns out (E*N, OT), action (heads, E, N), obs, reward, done,
+        alive, is_completed."""
+        E, N = env.E, env.N
+        out = np.full((E * N, self.OT), np.nan, np.float32)
+        action = np.full((len(self.heads), E, N), -1, np.int32)
+        obs = env._obs_buf() if with_obs else None
+        rew = np.full((E, N), np.nan, np.float32)
+        done = np.full((E,), -1, np.int32)
+        alive = np.full((E, N), -1, np.int32)
+        comp = np.full((E, N), -1, np.int32)
+        check(env.lib.ic3_policy_step(env._h, C.byref(self.struct), p(h), p(c), p(alive_in), p(comm_in), p(out), p(action),
+                                      p(obs), p(rew), p(done), p(alive), p(comp), None))
+        return out, action, obs, rew, done, alive, comp
