@@ -107,10 +107,11 @@ __device__ __forceinline__ void pp_step_lanes(const PPState& s, const StepOut& o
     const int gbase = lane & ~(G - 1);
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gbase);
 
-    int r = 0, c = 0, pr = -1, pc = -1, rch = 0, act = 4, was_over = 1;
+    int r = 0, c = 0, pr = -1, pc = -1, rch = 0, act = 4, was_over = 1, t_old = 0;
     if (in_env) {
         act = act_of();
         was_over = s.over[e];
+        t_old = s.tstep[e];   // read by every lane in front of the ballots; lane 0 writes it behind them
         if (act > s.naction) atomicOr(o.err, 1);  // PP:137 (<=, quirk Q2; checked on every entry of `action`)
     }
     if (valid) {
@@ -154,7 +155,7 @@ __device__ __forceinline__ void pp_step_lanes(const PPState& s, const StepOut& o
     }
     // env-uniform: every lane of the group evaluates the same values
     const int ov_new = live ? ((n_reached == N && mode == IC3_PP_MIXED) ? 1 : 0) : was_over;   // PP:273-274
-    const int t_new = s.tstep[e] + (live ? 1 : 0);
+    const int t_new = t_old + (live ? 1 : 0);
     const bool restart = s.ar.max_steps > 0 && live && (ov_new || t_new >= s.ar.max_steps);
     float rew = 0.0f;
     if (live) {

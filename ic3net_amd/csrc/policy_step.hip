@@ -1043,10 +1043,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             if constexpr (KIND == IC3_ENV_PP) {
                 const int2* ptab = reinterpret_cast<const int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
                 const int vocab = a.pp.dim * a.pp.dim + 4;
-                int2* rec = reinterpret_cast<int2*>(a.obs_rec) + (size_t)e0 * nsegE;
+                const size_t rec0 = (size_t)e0 * nsegE;              // the tile's first record (a.obs_rec may be null)
                 if (a.obs_incr) {
                     for (int sg = tid; sg < nenv * nsegE; sg += NT) {
-                        const int2 d = rec[sg];
+                        const int2 d = reinterpret_cast<const int2*>(a.obs_rec)[rec0 + sg];
                         float* cell = orow0 + (size_t)sg * vocab;
                         cell[d.x] = 0.f;
                         if (d.x != vocab - 2 && (d.y >> 16) != 0) cell[vocab - 2] = 0.f;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 for (int sg = tid; sg < nenv * nsegE; sg += NT) {   // descriptors of the INPUT state (S1)
                     const int2 d = ptab[sg];
                     pp_obs_patch(orow0 + (size_t)sg * vocab, d, vocab);   // (env_device.hpp)
-                    if (a.obs_rec) rec[sg] = d;
+                    if (a.obs_rec) reinterpret_cast<int2*>(a.obs_rec)[rec0 + sg] = d;
                 }
             } else if constexpr (KIND == IC3_ENV_TJ) {
                 const int obs_dim = a.obs_dim;

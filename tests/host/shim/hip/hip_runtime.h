@@ -104,7 +104,11 @@ inline void* dynamic_lds()
 // The cooperative scheduler.  run(n, fn) plays fn(0) .. fn(n - 1) as n fibers until all have returned.
 class Fibers {
 public:
+#ifdef IC3_HOST_ASAN_FIBERS
+    static constexpr size_t STACK = 2048 * 1024;   // (unoptimised, instrumented frames of the big kernels)
+#else
     static constexpr size_t STACK = 256 * 1024;
+#endif
     struct Fiber {
         ucontext_t ctx;
         char* stack = nullptr;

@@ -219,16 +219,17 @@ class HostPolicy(object):
     """The derived weights ic3_policy_step streams (ic3net_amd.comm._fused_cache / ops._policy_struct on numpy buffers),
     from a state_dict-shaped dict of float64 arrays (the same dict oracle.policy_ref.forward takes)."""
 
-    def __init__(self, env, params, H, head_sizes, mode_avg=True, comm_zero=False, gate_split=False, use_table=True):
+    def __init__(self, env, params, H, head_sizes, mode_avg=True, comm_zero=False, gate_split=False, use_table=True,
+                 pass_index=0, inner=False):
         from ic3net_amd import _lib as binding
         lib = host_lib()
         f32 = lambda a: np.ascontiguousarray(a, np.float32)
         self.H, self.heads = H, [int(a) for a in head_sizes]
         self.OT = sum(self.heads) + 1
         self.wt = f32(params['encoder.weight'].T)
-        self.enc_bias = f32(params['encoder.bias'] + params['C_modules.0.bias'])
-        self.loc_table = env.encode_table(self.wt) if use_table else None
-        self.c_w, self.w_ih, self.w_hh = f32(params['C_modules.0.weight']), f32(params['f_module.weight_ih']), f32(params['f_module.weight_hh'])
+        self.enc_bias = f32(params['encoder.bias'] + params['C_modules.%d.bias' % pass_index])
+        self.loc_table = env.encode_table(self.wt) if (use_table and env is not None) else None
+        self.c_w, self.w_ih, self.w_hh = f32(params['C_modules.%d.weight' % pass_index]), f32(params['f_module.weight_ih']), f32(params['f_module.weight_hh'])
         self.c_wp = np.full((H * H,), np.nan, np.float32)
         self.l_wp = np.full((4 * H * 2 * H,), np.nan, np.float32)
         check(lib.ic3_policy_pack(p(self.c_w), p(self.w_ih), p(self.w_hh), p(self.c_wp), p(self.l_wp), H, None))
@@ -240,6 +241,7 @@ class HostPolicy(object):
         for i, a in enumerate(self.heads):
             pol.head_sizes[i] = a
         pol.mode_avg, pol.comm_zero = int(mode_avg), int(comm_zero)
+        pol.pass_index, pol.inner_pass = int(pass_index), int(inner)
         pol.enc_wt, pol.enc_bias = self.wt.ctypes.data, self.enc_bias.ctypes.data
         pol.loc_table = self.loc_table.ctypes.data if self.loc_table is not None else None
         pol.c_wp, pol.lstm_wp, pol.lstm_bias = self.c_wp.ctypes.data, self.l_wp.ctypes.data, self.b_cat.ctypes.data
@@ -249,6 +251,16 @@ class HostPolicy(object):
             check(lib.ic3_policy_pack_split(p(self.w_ih), p(self.w_hh), p(self.l_wp3), H, None))
             pol.gate_split, pol.lstm_wp3 = 1, self.l_wp3.ctypes.data
         self.struct = pol
+
+    def inner_pass(self, env, h, c, alive_in, comm_in):
+        """A non-final communication pass (comm_passes > 1, ic3_policy.inner_pass): h, c only."""
+        check(env.lib.ic3_policy_step(env._h, C.byref(self.struct), p(h), p(c), p(alive_in), p(comm_in), *([None] * 8)))
+
+    def forward(self, enc, E, N, h, c, alive_in, comm_in):
+        """ic3_policy_forward: the policy half for a caller-supplied enc (E*N, H) = encoder(x) + C.bias."""
+        out = np.full((E * N, self.OT), np.nan, np.float32)
+        check(host_lib().ic3_policy_forward(C.byref(self.struct), p(enc), E, N, p(h), p(c), p(alive_in), p(comm_in), p(out), None))
+        return out
 
     def step(self, env, h, c, alive_in, comm_in, with_obs=True):
         """ic3_policy_step: h, c (E*N, H) updated in place.  Returns out (E*N, OT), action (heads, E, N), obs, reward, done,

@@ -575,3 +575,71 @@ def test_cell_backward_and_fused_cell_heads_draws(H):
         off += A
     np.testing.assert_array_equal(act1, act2)
     env.close()
+
+
+def test_auto_reset_env_restarts_inside_the_step_launch():
+    """ic3_env_set_auto_reset through ic3_env_step (tests/test_auto_reset_gpu.py): a Predator-Prey env restarts when its
+    episode is over or the step cap is reached, a Traffic-Junction env at the cap; the per-env stream, cut at `done`, equals
+    consecutive oracle episodes, and the finished episodes' statistics accumulate in ic3_stats.auto_*."""
+    import oracle
+    E, N, dim, v, cap = 20, 2, 3, 1, 5
+    env = HostEnv.pp(N, dim, v, "mixed", E, seed=21, offset=90)
+    check(env.lib.ic3_env_set_auto_reset(env._h, cap))
+    env.reset()
+    orcs = [oracle.PPOracle(N, dim, v, "mixed", seed=21, env_gid=90 + e) for e in range(E)]
+    for o in orcs:
+        o.reset()
+    tcount = np.zeros(E, int)
+    rs = np.random.RandomState(3)
+    ends = succ = steps = 0
+    for t in range(23):
+        act = rs.randint(0, 5, size=(E, N)).astype(np.int32)
+        obs, rew, done, _ = env.step(act)
+        st = env.get_state()
+        for e, o in enumerate(orcs):
+            oo, orew, od = o.step(act[e])
+            tcount[e] += 1
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+            end = bool(od) or tcount[e] == cap
+            assert int(done[e]) == int(end), (t, e)
+            if end:
+                ends += 1
+                succ += int(o.success.value)
+                steps += tcount[e]
+                oo = o.reset()                                    # next episode: same draws as the in-kernel restart
+                tcount[e] = 0
+            np.testing.assert_array_equal(obs[e], oo)            # the observation after the step is the new episode's
+            np.testing.assert_array_equal(np.stack([st['loc_r'][e], st['loc_c'][e]], -1), o.loc)
+            assert st['t'][e] == tcount[e] and st['episode'][e] == o.episode
+    s = env.stats()
+    assert ends > E and s.auto_episodes == ends and s.auto_success_sum == succ and s.auto_env_steps == steps
+    check(env.lib.ic3_env_set_auto_reset(env._h, 0))              # back to lock-step: finished envs freeze again
+    env.reset()
+    assert env.stats().auto_episodes == 0
+    env.close()
+
+    E, N, cap = 8, 5, 4
+    tj = HostEnv.tj(N, 6, 1, "easy", E, seed=5, offset=7, add_rate_min=0.6, add_rate_max=0.6)
+    check(tj.lib.ic3_env_set_auto_reset(tj._h, cap))
+    tj.reset(0)
+    torcs = [oracle.TJOracle(N, 6, 1, "easy", add_rate_min=0.6, add_rate_max=0.6, seed=5, env_gid=7 + e) for e in range(E)]
+    for o in torcs:
+        o.reset(0)
+    rs = np.random.RandomState(1)
+    succ = 0
+    for t in range(11):
+        act = (rs.rand(E, N) < 0.3).astype(np.int32)
+        obs, rew, done, info = tj.step(act)
+        for e, o in enumerate(torcs):
+            oo, orew, _ = o.step(act[e])
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+            np.testing.assert_array_equal(info['alive_mask'][e], o.alive)   # info of the finishing step: the old episode's
+            end = (t + 1) % cap == 0
+            assert int(done[e]) == int(end)
+            if end:
+                succ += 1 - int(o.has_failed.value)
+                oo = o.reset(0)
+            np.testing.assert_array_equal(obs[e], oo)
+    s = tj.stats()
+    assert s.auto_episodes == 2 * E and s.auto_success_sum == succ and s.auto_env_steps == 2 * E * cap
+    tj.close()

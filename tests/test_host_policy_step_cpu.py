@@ -10,6 +10,8 @@ env on the kernel's own actions at the north_star's 1e-5, rewards and the dense 
 bit (/root/reference/trainer.py:43-108).  With IC3_HOST_ASAN=1 (tools/host_asan.sh) every LDS / global index the kernel
 forms is bounds-checked.  What this does NOT see: the hardware's own behaviour (waitcnt, hazards, occupancy) — that is the
 GPU suite's."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -115,3 +117,351 @@ def free_run(name, seed=5, offset=300, gate_split=False, use_table=True, E=None,
 @pytest.mark.parametrize("name", ["pp_easy", "pp_hard", "tj_medium", "tj_hard", "pp_scaled"])
 def test_policy_step_free_run_vs_fp64_reference_policy(name):
     assert free_run(name) < TOL
+
+
+@pytest.mark.parametrize("name", ["pp_hard", "tj_hard", "pp_scaled"])
+def test_gate_split_experiment_free_run(name):
+    """The opt-in gate_split mode (ic3_policy.gate_split: nine exact bf16 x bf16 products per fp32 product on
+    v_mfma_f32_32x32x16_bf16, fp32 accumulation) against the same fp64 policy at the same 1e-5."""
+    assert free_run(name, gate_split=True, T=4) < TOL
+
+
+def test_variants_without_location_table_and_with_sum_mode():
+    """loc_table = NULL (the encoder gathers every window cell's row) and comm_mode = 'sum' (comm.py:194-196 skipped)."""
+    assert free_run("pp_easy", use_table=False, T=5) < TOL
+    assert free_run("tj_medium", use_table=False, mode_avg=False, T=5, E=4) < TOL
+
+
+def test_two_communication_passes_one_launch_per_pass():
+    """comm_passes = 2 on the recurrent policy (comm.py:179-218): pass 0 is an inner pass (ic3_policy.inner_pass: sparse
+    encoder, communication block, C_modules[0], LSTMCell — h, c only), pass 1 the ordinary call with C_modules[1]."""
+    from oracle import policy_ref
+    import oracle
+    w = WORKLOADS['pp_easy']
+    E, N, H, heads, T = 5, w['N'], w['H'], w['heads'], 4
+    env = make_env(w, E, 8, 40)
+    P = make_params(env.obs_dim, H, heads, seed=2, comm_passes=2)
+    pols = [HostPolicy(env, P, H, heads, pass_index=0, inner=True), HostPolicy(env, P, H, heads, pass_index=1)]
+    env.reset()
+    h = np.zeros((E * N, H), np.float32)
+    c = np.zeros((E * N, H), np.float32)
+    gate = np.zeros((E, N), np.int32)
+    orcs = [oracle.PPOracle(N, w['dim'], w['vision'], 'mixed', seed=8, env_gid=40 + e) for e in range(E)]
+    obs_o = [o.reset() for o in orcs]
+    hcs = [(np.zeros((N, H)), np.zeros((N, H))) for _ in range(E)]
+    for t in range(T):
+        pols[0].inner_pass(env, h, c, None, gate)
+        out, act, obs, rew, done, alive, comp = pols[1].step(env, h, c, None, gate)
+        for e, o in enumerate(orcs):
+            np.testing.assert_array_equal(obs[e], obs_o[e])
+            logp, val, hcs[e] = policy_ref.forward(P, obs_o[e][None].astype(np.float64), hcs[e], None, gate[e].astype(np.float64),
+                                                   recurrent=True, comm_passes=2, hard_attn=True, nheads=2)
+            o3 = out.reshape(E, N, -1)[e]
+            err = max(np.abs(logp[0][0] - o3[:, :5]).max(), np.abs(logp[1][0] - o3[:, 5:7]).max(),
+                      np.abs(val.reshape(-1) - o3[:, 7]).max(), np.abs(hcs[e][0] - h.reshape(E, N, H)[e]).max(),
+                      np.abs(hcs[e][1] - c.reshape(E, N, H)[e]).max())
+            assert err < TOL, (t, e, err)
+            obs_o[e], orew, _ = o.step(act[0, e])
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+        gate = np.ascontiguousarray(act[1])
+    env.close()
+
+
+@pytest.mark.parametrize("H,N,E", [(64, 3, 11), (128, 10, 7), (256, 20, 2)])
+def test_policy_forward_on_a_caller_supplied_encoder_output(H, N, E):
+    """ic3_policy_forward (the kernel's KIND 0: no env, enc = encoder(x) + C.bias from the caller) with random alive / talk
+    masks, incl. envs with 0 and 1 agents alive (comm.py:194: the division only when more than one is alive)."""
+    from oracle import policy_ref
+    heads = [2, 2]
+    obs_dim = 12
+    P = make_params(obs_dim, H, heads, seed=H)
+    pol = HostPolicy(None, P, H, heads, use_table=False)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((E, N, obs_dim))
+    enc = np.ascontiguousarray((x @ P['encoder.weight'].T + P['encoder.bias'] + P['C_modules.0.bias']).reshape(E * N, H), np.float32)
+    h0 = (rng.standard_normal((E * N, H)) * 0.5).astype(np.float32)
+    c0 = (rng.standard_normal((E * N, H)) * 0.5).astype(np.float32)
+    alive = (rng.random((E, N)) < 0.7).astype(np.int32)
+    alive[0] = 0
+    if E > 1:
+        alive[1] = 0
+        alive[1, N // 2] = 1
+    gate = (rng.random((E, N)) < 0.6).astype(np.int32)
+    h, c = h0.copy(), c0.copy()
+    out = pol.forward(enc, E, N, h, c, alive, gate).reshape(E, N, -1)
+    for e in range(E):
+        Pe = dict(P)
+        # the caller's enc already holds encoder(x) + C.bias: feed the reference the same numbers through its own encoder
+        logp, val, hc = policy_ref.forward(Pe, x[e][None], (h0.reshape(E, N, H)[e].astype(np.float64),
+                                                            c0.reshape(E, N, H)[e].astype(np.float64)),
+                                           alive[e].astype(np.float64), gate[e].astype(np.float64), recurrent=True, hard_attn=True,
+                                           nheads=2)
+        err = max(np.abs(logp[0][0] - out[e][:, :2]).max(), np.abs(logp[1][0] - out[e][:, 2:4]).max(),
+                  np.abs(val.reshape(-1) - out[e][:, 4]).max(), np.abs(hc[0] - h.reshape(E, N, H)[e]).max(),
+                  np.abs(hc[1] - c.reshape(E, N, H)[e]).max())
+        assert err < 2e-5, (e, err)     # (enc itself is rounded to fp32 here before the kernel sees it)
+
+
+def test_incremental_obs_rows_are_the_same_rows():
+    """EXPERIMENT ic3_env_set_incremental_obs: the launch clears what it painted last step instead of zero-filling; the
+    rows must be bit-identical to the default's, step after step, on the same buffer."""
+    w = WORKLOADS['pp_hard']
+    E, N, H, heads = 5, w['N'], w['H'], w['heads']
+    outs = []
+    for incr in (0, 1):
+        env = make_env(w, E, 3, 70)
+        check(env.lib.ic3_env_set_incremental_obs(env._h, incr))
+        P = make_params(env.obs_dim, H, heads, seed=4)
+        pol = HostPolicy(env, P, H, heads)
+        env.reset()
+        h = np.zeros((E * N, H), np.float32)
+        c = np.zeros((E * N, H), np.float32)
+        gate = np.zeros((E, N), np.int32)
+        obs = np.full((E, N, env.obs_dim), np.nan, np.float32)       # ONE buffer for the whole run (the caller's promise)
+        rows = []
+        for t in range(4):
+            out = np.full((E * N, pol.OT), np.nan, np.float32)
+            act = np.full((2, E, N), -1, np.int32)
+            rew, done = np.zeros((E, N), np.float32), np.zeros((E,), np.int32)
+            check(env.lib.ic3_policy_step(env._h, C.byref(pol.struct), p(h), p(c), None, p(gate), p(out), p(act), p(obs), p(rew),
+                                          p(done), None, None, None))
+            rows.append((obs.copy(), out.copy(), act.copy(), rew.copy()))
+            gate = np.ascontiguousarray(act[1])
+        outs.append(rows)
+        env.close()
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_auto_reset_stream_restarts_policy_and_env_inside_the_launch():
+    """ic3_env_set_auto_reset: an env whose episode ends (episode_over, or the step cap) starts its next episode inside the
+    same ic3_policy_step launch, and the launch treats an env at t = 0 as an episode start (h = c = 0, no alive mask, gate 0:
+    trainer.py:38-46, quirks Q21 / Q22).  Per env the stream must equal consecutive oracle episodes under the kernel's
+    actions with the fp64 policy restarted at every episode start (tests/test_auto_reset_gpu.py)."""
+    import oracle
+    from oracle import policy_ref
+    E, N, dim, v, cap, H, heads, T = 9, 2, 3, 1, 5, 64, [5, 2], 14
+    env = HostEnv.pp(N, dim, v, "mixed", E, seed=21, offset=90)
+    check(env.lib.ic3_env_set_auto_reset(env._h, cap))
+    P = make_params(env.obs_dim, H, heads, seed=9)
+    pol = HostPolicy(env, P, H, heads)
+    env.reset()
+    orcs = [oracle.PPOracle(N, dim, v, "mixed", seed=21, env_gid=90 + e) for e in range(E)]
+    obs_o = [o.reset() for o in orcs]
+    hcs = [(np.zeros((N, H)), np.zeros((N, H))) for _ in range(E)]
+    gates = [np.zeros(N) for _ in range(E)]
+    tcount = np.zeros(E, int)
+    h = np.zeros((E * N, H), np.float32)
+    c = np.zeros((E * N, H), np.float32)
+    gate = np.zeros((E, N), np.int32)
+    ends = 0
+    for t in range(T):
+        out, act, obs, rew, done, alive, comp = pol.step(env, h, c, None, gate)
+        for e, o in enumerate(orcs):
+            np.testing.assert_array_equal(obs[e], obs_o[e])
+            logp, val, hcs[e] = policy_ref.forward(P, obs_o[e][None].astype(np.float64), hcs[e], None, gates[e], recurrent=True,
+                                                   hard_attn=True, nheads=2)
+            o3 = out.reshape(E, N, -1)[e]
+            err = max(np.abs(logp[0][0] - o3[:, :5]).max(), np.abs(logp[1][0] - o3[:, 5:7]).max(),
+                      np.abs(val.reshape(-1) - o3[:, 7]).max(), np.abs(hcs[e][0] - h.reshape(E, N, H)[e]).max())
+            assert err < TOL, (t, e, err)
+            oo, orew, od = o.step(act[0, e])
+            tcount[e] += 1
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+            end = bool(od) or tcount[e] == cap
+            assert int(done[e]) == int(end), (t, e)
+            gates[e] = act[1, e].astype(np.float64)
+            if end:                                               # the next launch starts this env's next episode
+                ends += 1
+                oo = o.reset()
+                tcount[e] = 0
+                hcs[e] = (np.zeros((N, H)), np.zeros((N, H)))
+                gates[e] = np.zeros(N)
+            obs_o[e] = oo
+        gate = np.ascontiguousarray(act[1])                       # (the launch itself ignores it for envs at t = 0)
+    s = env.stats()
+    assert ends > E and s.auto_episodes == ends
+    env.close()
+
+
+PLAN_WORKER = r"""
+import sys, zlib
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from test_host_policy_step_cpu import WORKLOADS, make_env, make_params
+from host_abi_util import HostPolicy
+w = WORKLOADS['pp_hard']
+E, N, H, heads = 13, w['N'], w['H'], w['heads']
+env = make_env(w, E, 6, 10)
+pol = HostPolicy(env, make_params(env.obs_dim, H, heads, seed=6), H, heads)
+env.reset()
+h = np.zeros((E * N, H), np.float32); c = np.zeros((E * N, H), np.float32)
+gate = np.zeros((E, N), np.int32)
+crc = 0
+for t in range(3):
+    res = pol.step(env, h, c, None, gate)
+    for a in res + (h, c):
+        crc = zlib.crc32(np.ascontiguousarray(a).tobytes(), crc)
+    gate = np.ascontiguousarray(res[1][1])
+print("CRC", crc)
+"""
+
+
+def test_results_do_not_depend_on_the_tile_plan():
+    """IC3_PS_HALF = 0 / 1 forces plan A (ceil(E / EPT) tiles of up to two 32-row MFMA tiles) / plan B (full tiles + half
+    tiles): 13 PP-hard envs are 3 tiles one way, 2 full + 1 half the other (the host runtime reports 2 CUs).  Everything the
+    launches produce must be bit-identical (tests/test_policy_step_plans_gpu.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    crcs = []
+    for plan in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", PLAN_WORKER, here, os.path.dirname(here)], capture_output=True, text=True,
+                           env=dict(os.environ, IC3_PS_HALF=plan))
+        assert r.returncode == 0, r.stderr[-3000:]
+        crcs.append([l for l in r.stdout.splitlines() if l.startswith("CRC")][-1])
+    assert crcs[0] == crcs[1], crcs
+
+
+@pytest.mark.parametrize("H,N,E,passes", [(64, 3, 9, 1), (128, 10, 5, 2), (256, 5, 3, 3)])
+def test_commnet_forward_nonrecurrent_module(H, N, E, passes):
+    """ic3_commnet_forward: the non-recurrent CommNet module behind the encoder, every communication pass in one launch
+    (comm.py:127-129,179-205,220-224,228-239), against oracle.policy_ref with recurrent = False."""
+    from oracle import policy_ref
+    lib = host_lib()
+    heads = [2]
+    obs_dim = 9
+    P = make_params(obs_dim, H, heads, seed=H + passes, comm_passes=passes)
+    rng = np.random.default_rng(passes)
+    for i in range(passes):
+        P['f_modules.%d.weight' % i] = (rng.standard_normal((H, H)) * 0.1).astype(np.float32).astype(np.float64)
+        P['f_modules.%d.bias' % i] = (rng.standard_normal(H) * 0.1).astype(np.float32).astype(np.float64)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    wp = np.full((passes, 2 * H * H), np.nan, np.float32)
+    for i in range(passes):
+        cw, fw = f32(P['C_modules.%d.weight' % i]), f32(P['f_modules.%d.weight' % i])
+        check(lib.ic3_commnet_pack(p(cw), p(fw), C.c_void_p(wp.ctypes.data + i * 2 * H * H * 4), H, None))
+    bias = f32(np.stack([P['C_modules.%d.bias' % i] + P['f_modules.%d.bias' % i] for i in range(passes)]))
+    head_w = f32(np.concatenate([P['heads.0.weight'], P['value_head.weight']], 0))
+    head_b = f32(np.concatenate([P['heads.0.bias'], P['value_head.bias']], 0))
+    x = rng.standard_normal((E, N, obs_dim))
+    enc = f32((x @ P['encoder.weight'].T + P['encoder.bias']).reshape(E * N, H))
+    alive = (rng.random((E, N)) < 0.8).astype(np.int32)
+    alive[0] = 0
+    out = np.full((E * N, 3), np.nan, np.float32)
+    h_out = np.full((E * N, H), np.nan, np.float32)
+    sizes = np.array(heads, np.int32)
+    check(lib.ic3_commnet_forward(p(enc), E, N, H, passes, p(wp), p(bias), p(head_w), p(head_b), p(sizes), 1, 1, 0, p(alive), None,
+                                  p(out), p(h_out), None))
+    for e in range(E):
+        logp, val, hh = policy_ref.forward(P, x[e][None], None, alive[e].astype(np.float64), None, recurrent=False,
+                                           comm_passes=passes, hard_attn=False, nheads=1)
+        o3 = out.reshape(E, N, -1)[e]
+        err = max(np.abs(logp[0][0] - o3[:, :2]).max(), np.abs(val.reshape(-1) - o3[:, 2]).max(),
+                  np.abs(hh.reshape(N, H) - h_out.reshape(E, N, H)[e]).max())
+        assert err < 2e-5, (e, err)
+
+
+@pytest.mark.parametrize("H,R,split", [(64, 100, False), (128, 70, False), (128, 70, True), (256, 65, True)])
+def test_gates_backward_recompute_and_cell_derivative(H, R, split):
+    """ic3_lstm_gates_backward (gates_bwd.hip): gates = [inp | h_prev] . [W_ih | W_hh]^T + bias re-computed on the matrix cores
+    and torch.nn.LSTMCell's derivative applied in the epilogue, against the closed form in float64; bias partials per 64 rows,
+    written then accumulated; h_prev given separately fills the h half of xh (tests/test_gates_backward_gpu.py)."""
+    lib = host_lib()
+    rng = np.random.default_rng(H + R)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    w_ih, w_hh = f32(rng.standard_normal((4 * H, H)) / H ** 0.5), f32(rng.standard_normal((4 * H, H)) / H ** 0.5)
+    c_w = f32(rng.standard_normal((H, H)))
+    b = f32(rng.standard_normal(4 * H))
+    pad = 8
+    wide = f32(rng.standard_normal((R, 2 * H + pad)))
+    c_prev, dh, dc = [f32(rng.standard_normal((R, H))) for _ in range(3)]
+    c_wp = np.empty(H * H, np.float32)
+    l_wp = np.empty(4 * H * 2 * H, np.float32)
+    check(lib.ic3_policy_pack(p(c_w), p(w_ih), p(w_hh), p(c_wp), p(l_wp), H, None))
+    wp3 = None
+    if split:
+        wp3 = np.zeros(3 * 2 * H * 4 * H, np.uint16)
+        check(lib.ic3_policy_pack_split(p(w_ih), p(w_hh), p(wp3), H, None))
+    tiles = (R + 63) // 64
+    xh = wide[:, :2 * H].astype(np.float64)
+    g = xh @ np.concatenate([w_ih, w_hh], 1).T.astype(np.float64) + b
+    sig = lambda z: 1 / (1 + np.exp(-z))
+    i, f, gg, o = sig(g[:, :H]), sig(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), sig(g[:, 3 * H:])
+    cn = f * c_prev + i * gg
+    tc = np.tanh(cn)
+    for with_dc in (True, False):
+        dct = (dc if with_dc else 0) + dh * o * (1 - tc * tc)
+        want = np.concatenate([dct * gg * i * (1 - i), dct * c_prev * f * (1 - f), dct * i * (1 - gg * gg), dh * tc * o * (1 - o)], 1)
+        dgates = np.full((R, 4 * H), np.nan, np.float32)
+        dcp = np.full((R, H), np.nan, np.float32)
+        parts = np.full((tiles, 4 * H), np.nan, np.float32)
+        n = check(lib.ic3_lstm_gates_backward(p(wide), 2 * H + pad, None, p(l_wp), p(wp3), p(b), p(c_prev), p(dh),
+                                              p(dc) if with_dc else None, p(dgates), p(dcp), p(parts), 0, R, H, None))
+        assert n == tiles
+        # (4e-6, the GPU test has 2e-6: the emulated MFMA adds its k terms to the accumulator one at a time in fp32)
+        assert np.abs(dgates - want).max() <= 4e-6 * max(1.0, np.abs(want).max())
+        assert np.abs(dcp - dct * f).max() <= 4e-6 * max(1.0, np.abs(dct * f).max())
+        np.testing.assert_allclose(parts.astype(np.float64).sum(0), want.sum(0), rtol=1e-5, atol=1e-4)
+        before = parts.copy()
+        dc_io = (dc if with_dc else np.zeros_like(dh)).copy()
+        check(lib.ic3_lstm_gates_backward(p(wide), 2 * H + pad, None, p(l_wp), p(wp3), p(b), p(c_prev), p(dh), p(dc_io), p(dgates),
+                                          p(dc_io), p(parts), 1, R, H, None))
+        np.testing.assert_allclose(parts, 2 * before, rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(dc_io, dcp)                  # dc_prev written over dc (in place)
+    xh2 = np.ascontiguousarray(np.concatenate([wide[:, :H], np.full((R, H), np.nan, np.float32)], 1))
+    h_prev = np.ascontiguousarray(wide[:, H:2 * H])
+    dg3 = np.full((R, 4 * H), np.nan, np.float32)
+    dcp3 = np.full((R, H), np.nan, np.float32)
+    check(lib.ic3_lstm_gates_backward(p(xh2), 2 * H, p(h_prev), p(l_wp), p(wp3), p(b), p(c_prev), p(dh), None, p(dg3), p(dcp3), None,
+                                      0, R, H, None))
+    np.testing.assert_array_equal(xh2, wide[:, :2 * H])
+    np.testing.assert_array_equal(dg3, dgates)
+
+
+def test_auto_reset_stream_traffic_junction():
+    """The same for Traffic-Junction: every env restarts at the step cap (quirk Q12: TJ never sets episode_over); the alive
+    mask of the previous step is ignored for an env at t = 0."""
+    import oracle
+    from oracle import policy_ref
+    E, N, cap, H, heads, T = 5, 5, 4, 64, [2, 2], 10
+    env = HostEnv.tj(N, 6, 1, "easy", E, seed=5, offset=7, add_rate_min=0.6, add_rate_max=0.6)
+    check(env.lib.ic3_env_set_auto_reset(env._h, cap))
+    P = make_params(env.obs_dim, H, heads, seed=12)
+    pol = HostPolicy(env, P, H, heads)
+    env.reset(0)
+    orcs = [oracle.TJOracle(N, 6, 1, "easy", add_rate_min=0.6, add_rate_max=0.6, seed=5, env_gid=7 + e) for e in range(E)]
+    obs_o = [o.reset(0) for o in orcs]
+    hcs = [(np.zeros((N, H)), np.zeros((N, H))) for _ in range(E)]
+    gates = [np.zeros(N) for _ in range(E)]
+    alives = [None] * E
+    h = np.zeros((E * N, H), np.float32)
+    c = np.zeros((E * N, H), np.float32)
+    gate = np.zeros((E, N), np.int32)
+    alive_in = None
+    for t in range(T):
+        out, act, obs, rew, done, alive, comp = pol.step(env, h, c, alive_in, gate)
+        end = (t + 1) % cap == 0
+        for e, o in enumerate(orcs):
+            np.testing.assert_array_equal(obs[e], obs_o[e])
+            logp, val, hcs[e] = policy_ref.forward(P, obs_o[e][None].astype(np.float64), hcs[e], alives[e], gates[e],
+                                                   recurrent=True, hard_attn=True, nheads=2)
+            o3 = out.reshape(E, N, -1)[e]
+            err = max(np.abs(logp[0][0] - o3[:, :2]).max(), np.abs(logp[1][0] - o3[:, 2:4]).max(),
+                      np.abs(val.reshape(-1) - o3[:, 4]).max(), np.abs(hcs[e][0] - h.reshape(E, N, H)[e]).max())
+            assert err < TOL, (t, e, err)
+            oo, orew, _ = o.step(act[0, e])
+            np.testing.assert_array_equal(rew[e], orew.astype(np.float32))
+            np.testing.assert_array_equal(alive[e], o.alive)
+            assert int(done[e]) == int(end)
+            alives[e], gates[e] = o.alive.astype(np.float64), act[1, e].astype(np.float64)
+            if end:
+                oo = o.reset(0)
+                hcs[e] = (np.zeros((N, H)), np.zeros((N, H)))
+                alives[e], gates[e] = None, np.zeros(N)
+            obs_o[e] = oo
+        alive_in, gate = alive, np.ascontiguousarray(act[1])
+    assert env.stats().auto_episodes == 2 * E
+    env.close()
