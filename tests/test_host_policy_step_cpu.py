@@ -61,11 +61,11 @@ def make_oracle(w, seed, gid):
     return oracle.TJOracle(w['N'], w['dim'], w['vision'], w['difficulty'], w['rate'], w['rate'], 0, 0, seed=seed, env_gid=gid)
 
 
-def free_run(name, seed=5, offset=300, gate_split=False, use_table=True, E=None, T=None, mode_avg=True):
+def free_run(name, seed=5, offset=300, gate_split=False, use_table=True, E=None, T=None, mode_avg=True, w=None):
     """T lock-step iterations of ic3_policy_step on E envs, replayed env by env through the fp64 policy + the oracle env on
     the kernel's actions (tests/test_policy_step_onehop_gpu.py::_free_run).  Returns the worst policy error."""
     from oracle import policy_ref
-    w = WORKLOADS[name]
+    w = w or WORKLOADS[name]
     E, T = E or w['E'], T or w['T']
     N, H, heads = w['N'], w['H'], w['heads']
     nheads = len(heads)
@@ -465,3 +465,32 @@ def test_auto_reset_stream_traffic_junction():
         alive_in, gate = alive, np.ascontiguousarray(act[1])
     assert env.stats().auto_episodes == 2 * E
     env.close()
+
+
+def test_randomized_shapes_sweep():
+    """Random small configurations of both envs through the one-launch kernel (every lane-group size G = 1 .. 32, envs per
+    tile from 2 to 64, partial last tiles, full + half tile plans, odd and even grids, vision 0 .. 2, one or two heads, IC3Net
+    and CommNet gating, hid 64 / 128) for a few steps each against the fp64 policy + oracle env."""
+    rs = np.random.RandomState(77)
+    tj_dims = {"easy": [6, 8], "medium": [6, 8, 10], "hard": [9, 12]}
+    ran = 0
+    for trial in range(14):
+        H = int(rs.choice([64, 64, 128]))
+        hard = bool(rs.rand() < 0.6)
+        if rs.rand() < 0.5:
+            dim = int(rs.randint(3, 9))
+            w = dict(env='pp', N=int(rs.randint(1, min(20, dim * dim - 1) + 1)), dim=dim, vision=int(rs.randint(0, 3)), H=H,
+                     heads=[5, 2] if hard else [5], hard_attn=hard)
+        else:
+            diff = ["easy", "medium", "hard"][rs.randint(3)]
+            w = dict(env='tj', N=int(rs.randint(1, 21)), dim=int(rs.choice(tj_dims[diff])), vision=int(rs.randint(0, 2)),
+                     difficulty=diff, H=H, heads=[2, 2] if hard else [2], hard_attn=hard, rate=float(rs.choice([0.3, 0.7])))
+        E = int(rs.randint(1, 1 + max(2, 150 // w['N'])))
+        seed, offset = int(rs.randint(1 << 20)), int(rs.randint(1 << 16))
+        try:
+            worst = free_run('trial %d' % trial, seed=seed, offset=offset, E=E, T=3, w=w)
+        except NotImplementedError:           # an env tile that does not fit in LDS: the launch chain's case, not this kernel's
+            continue
+        ran += 1
+        assert worst < TOL, (trial, w, E, worst)
+    assert ran >= 10, ran
