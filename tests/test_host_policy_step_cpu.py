@@ -494,3 +494,31 @@ def test_randomized_shapes_sweep():
         ran += 1
         assert worst < TOL, (trial, w, E, worst)
     assert ran >= 10, ran
+
+
+def test_step_events_are_stamped_by_the_launch():
+    """ic3_event_create / ic3_env_set_step_events / ic3_event_elapsed_ms (bench.py's per-launch timing): the armed pair is
+    consumed by exactly the next ic3_policy_step (one shot)."""
+    lib = host_lib()
+    w = WORKLOADS['pp_easy']
+    env = make_env(w, 3, 1, 0)
+    pol = HostPolicy(env, make_params(env.obs_dim, w['H'], w['heads'], seed=1), w['H'], w['heads'])
+    env.reset()
+    h = np.zeros((3 * w['N'], w['H']), np.float32)
+    c = np.zeros_like(h)
+    gate = np.zeros((3, w['N']), np.int32)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    check(lib.ic3_event_create(C.byref(e0)))
+    check(lib.ic3_event_create(C.byref(e1)))
+    check(lib.ic3_env_set_step_events(env._h, e0, e1))
+    pol.step(env, h, c, None, gate)
+    ms = C.c_float(-1.0)
+    check(lib.ic3_event_elapsed_ms(e0, e1, C.byref(ms)))
+    first = ms.value
+    assert first > 0.0
+    pol.step(env, h, c, None, gate)                            # not armed again: the pair keeps the first launch's stamps
+    check(lib.ic3_event_elapsed_ms(e0, e1, C.byref(ms)))
+    assert ms.value == first
+    check(lib.ic3_event_destroy(e0))
+    check(lib.ic3_event_destroy(e1))
+    env.close()
