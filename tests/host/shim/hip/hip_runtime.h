@@ -143,10 +143,15 @@ public:
             f.ctx.uc_link = nullptr;
             makecontext(&f.ctx, (void (*)())trampoline, 0);
         }
+        // IC3_HOST_SCHED=reverse walks the lanes from the highest to the lowest: code whose result depends on which lane
+        // runs first between two cross-lane operations (a wave-lockstep assumption) gives different results under the two
+        // orders (tests/test_host_policy_step_cpu.py::test_results_do_not_depend_on_the_lane_schedule)
+        static const bool reverse = std::getenv("IC3_HOST_SCHED") && !std::strcmp(std::getenv("IC3_HOST_SCHED"), "reverse");
         int left = n;
         while (left > 0) {
             const unsigned long long before = progress_;
-            for (int i = 0; i < n; ++i) {
+            for (int k = 0; k < n; ++k) {
+                const int i = reverse ? n - 1 - k : k;
                 Fiber& f = *fibers_[i];
                 if (f.done) continue;
                 cur_ = i;
