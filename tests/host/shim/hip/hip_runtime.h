@@ -146,12 +146,21 @@ public:
         // IC3_HOST_SCHED=reverse walks the lanes from the highest to the lowest: code whose result depends on which lane
         // runs first between two cross-lane operations (a wave-lockstep assumption) gives different results under the two
         // orders (tests/test_host_policy_step_cpu.py::test_results_do_not_depend_on_the_lane_schedule)
-        static const bool reverse = std::getenv("IC3_HOST_SCHED") && !std::strcmp(std::getenv("IC3_HOST_SCHED"), "reverse");
+        // ("shuffle": a different pseudo-random order in every round)
+        static const char* sched = std::getenv("IC3_HOST_SCHED");
+        static const bool reverse = sched && !std::strcmp(sched, "reverse"), shuffle = sched && !std::strcmp(sched, "shuffle");
+        std::vector<int> order(n);
+        for (int k = 0; k < n; ++k) order[k] = reverse ? n - 1 - k : k;
         int left = n;
         while (left > 0) {
             const unsigned long long before = progress_;
+            if (shuffle)
+                for (int k = n - 1; k > 0; --k) {
+                    rng_ = rng_ * 6364136223846793005ull + 1442695040888963407ull;
+                    std::swap(order[k], order[(int)((rng_ >> 33) % (unsigned long long)(k + 1))]);
+                }
             for (int k = 0; k < n; ++k) {
-                const int i = reverse ? n - 1 - k : k;
+                const int i = order[k];
                 Fiber& f = *fibers_[i];
                 if (f.done) continue;
                 cur_ = i;
@@ -223,7 +232,7 @@ private:
     [[maybe_unused]] const void* main_bottom_ = nullptr;   // (ASan) bounds of the scheduler's own stack
     [[maybe_unused]] size_t main_size_ = 0;
     int cur_ = -1;
-    unsigned long long progress_ = 0;
+    unsigned long long progress_ = 0, rng_ = 0x9E3779B97F4A7C15ull;
 };
 inline void yield() { Fibers::get().yield_current(); }
 inline void Barrier::arrive_and_wait()
