@@ -15,8 +15,8 @@
 // hipLaunchKernelGGL runs the grid one workgroup at a time, a workgroup = blockDim lanes (wavefronts of 64 as above,
 // __syncthreads = a barrier over the workgroup's lanes).  `__shared__` arrays become function-local statics (one workgroup
 // runs at a time), the dynamic LDS of a launch is one 160 KB buffer refilled with a poison pattern before every workgroup
-// (LDS is not zeroed on the GPU either).  hipMalloc / hipMemcpy / hipMemset work on host memory, streams are ignored
-// (every call is synchronous).
+// (LDS is not zeroed on the GPU either).  hipMalloc / hipMemcpy / hipMemset work on host memory (allocations poisoned the
+// same way), streams are ignored (every call is synchronous).
 #pragma once
 
 #include <sys/mman.h>
@@ -403,7 +403,8 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 template <class T>
 inline hipError_t hipMalloc(T** p, size_t bytes)
 {
-    *p = (T*)std::malloc(bytes ? bytes : 1);   // (uninitialised, like device memory; ASan / UBSan watch its bounds)
+    *p = (T*)std::malloc(bytes ? bytes : 1);   // (ASan / UBSan watch its bounds)
+    if (*p) std::memset(*p, 0xCD, bytes);      // poison: device memory is not zeroed either; what is read must have been written
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
