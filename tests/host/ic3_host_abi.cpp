@@ -13,3 +13,30 @@
 // this is not a CPU path of the product.  This translation unit only anchors the library (every symbol comes from the
 // product's sources).
 #include "ic3_common.hpp"
+
+// ---- self-tests of the stand-in runtime's guards (tests/test_host_abi_cpu.py runs them in subprocesses: both must abort) ----
+namespace {
+__global__ void selftest_lds_overrun_kernel(int words)
+{
+    IC3_DYNAMIC_LDS(int32_t, smem);
+    if (threadIdx.x == 0) smem[words] = 1;   // the first word BEHIND what the launch asked for
+}
+__global__ void selftest_barrier_kernel()
+{
+    // every lane waits for a partner value that only arrives through a shuffle the odd lanes never reach
+    if ((threadIdx.x & 1) == 0) (void)__shfl((int)threadIdx.x, 1);
+    else
+        for (;;) __syncthreads();
+}
+}  // namespace
+
+extern "C" int ic3_host_selftest_lds_overrun(void)
+{
+    hipLaunchKernelGGL(selftest_lds_overrun_kernel, dim3(1), dim3(64), 64 * sizeof(int32_t), nullptr, 64);
+    return 0;   // not reached: the runtime aborts behind the workgroup ("wrote past the dynamic LDS")
+}
+extern "C" int ic3_host_selftest_stuck_barrier(void)
+{
+    hipLaunchKernelGGL(selftest_barrier_kernel, dim3(1), dim3(64), 0, nullptr);
+    return 0;   // not reached: "no lane can make progress"
+}

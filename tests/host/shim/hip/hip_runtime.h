@@ -358,6 +358,15 @@ inline ic3_host_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc
 // whole kernels: launches, the HIP runtime calls of the C ABI, the remaining device intrinsics
 // ---------------------------------------------------------------------------------------------------------------------
 namespace ic3_host {
+#ifdef IC3_HOST_ASAN_FIBERS
+extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t size);
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+inline void lds_guard(void* p, size_t n) { __asan_poison_memory_region(p, n); }
+inline void lds_unguard(void* p, size_t n) { __asan_unpoison_memory_region(p, n); }
+#else
+inline void lds_guard(void*, size_t) {}
+inline void lds_unguard(void*, size_t) {}
+#endif
 template <class... P, class... A>
 inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds_bytes, hipStream_t, A&&... args)
 {
@@ -369,7 +378,12 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds_bytes
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
-                std::memset(dynamic_lds(), 0xCD, lds_bytes);   // poison: what a kernel reads it must have written
+                // poison: what a kernel reads it must have written; and what lies behind the bytes the launch asked for must
+                // stay untouched (checked behind the workgroup; under ASan every access there is reported at once)
+                unsigned char* const lds = static_cast<unsigned char*>(dynamic_lds());
+                lds_unguard(lds + lds_bytes, LDS_BYTES - lds_bytes);
+                std::memset(lds, 0xCD, LDS_BYTES);
+                lds_guard(lds + lds_bytes, LDS_BYTES - lds_bytes);
                 Block blk(nt);
                 std::vector<std::unique_ptr<Wave>> waves;
                 for (int w = 0; w < nwaves; ++w) {
@@ -392,6 +406,9 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds_bytes
                         w->bar.arrive_and_drop();
                         blk.bar.arrive_and_drop();
                     });
+                lds_unguard(lds + lds_bytes, LDS_BYTES - lds_bytes);
+                for (size_t b = lds_bytes; b < LDS_BYTES; ++b)
+                    if (lds[b] != 0xCD) Fibers::die("a workgroup wrote past the dynamic LDS its launch asked for");
             }
 }
 }  // namespace ic3_host

@@ -643,3 +643,22 @@ def test_auto_reset_env_restarts_inside_the_step_launch():
     s = tj.stats()
     assert s.auto_episodes == 2 * E and s.auto_success_sum == succ and s.auto_env_steps == 2 * E * cap
     tj.close()
+
+
+@pytest.mark.parametrize("which,message", [("ic3_host_selftest_lds_overrun", "wrote past the dynamic LDS"),
+                                           ("ic3_host_selftest_stuck_barrier", "no lane can make progress")])
+def test_runtime_guards_fire(which, message):
+    """Negative controls of the stand-in runtime (kernels in tests/host/ic3_host_abi.cpp): a workgroup that writes behind the
+    dynamic LDS its launch asked for, and a barrier that not every live lane reaches, end the process with a message
+    instead of corrupting memory / hanging."""
+    import os
+    import subprocess
+    import sys
+    code = ("from host_abi_util import host_lib\n"
+            "host_lib().%s()\n"
+            "print('survived')\n" % which)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([here, os.path.dirname(here)]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "survived" not in r.stdout
+    assert message in r.stderr or "AddressSanitizer" in r.stderr, r.stderr[-2000:]
