@@ -1,8 +1,11 @@
-// TEST INFRASTRUCTURE — a stand-in for <hip/hip_runtime.h> that lets the PRODUCT's wave-level device functions
-// (ic3net_amd/csrc/env_device.hpp: pp/tj_step_lanes, window tables, obs patches) compile for the host, so that they can be
-// driven over the reference's golden trajectories on a CPU and under AddressSanitizer / UndefinedBehaviorSanitizer
-// (tests/host/ic3_host_build.cpp, tests/test_host_build_cpu.py, tools/host_asan.sh).  Not a CPU fallback of the product:
-// nothing under ic3net_amd/ loads it.
+// TEST INFRASTRUCTURE — a stand-in for <hip/hip_runtime.h> that lets the PRODUCT's device code compile for the host: the
+// wave-level functions of ic3net_amd/csrc/env_device.hpp behind tests/host/ic3_host_build.cpp, and every .hip source of the
+// library — whole kernels, launches, the matrix-core builtins — behind the library's own C ABI (tests/host/Makefile ->
+// libic3rollout_host.so), so that the reference's golden trajectories and ic3_policy_step free runs can be driven through
+// the real kernel sources on a CPU, deterministically and under AddressSanitizer / UndefinedBehaviorSanitizer
+// (tests/test_host_build_cpu.py, test_host_abi_cpu.py, test_host_policy_step_cpu.py, tools/host_asan.sh).  Not a CPU
+// fallback of the product: nothing under ic3net_amd/ loads it, and it says nothing about the hardware itself (wait counts,
+// hazards, occupancy, timing).
 //
 // Execution model: a lane is a FIBER (ucontext), all lanes of a wavefront / workgroup are scheduled cooperatively on the
 // calling thread, round-robin, each running until it returns or waits in a barrier.  __ballot / __shfl exchange through a
@@ -22,16 +25,17 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <chrono>
-#include <cstdio>
-#include <memory>
-#include <tuple>
-#include <type_traits>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <tuple>
+#include <type_traits>
 #include <vector>
 
 #ifndef __HIPCC__
