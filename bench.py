@@ -8,8 +8,10 @@ workload configs[1] "Predator-Prey hard": 10 agents, dim 20, vision 1, max_steps
          8192 parallel envs per GPU (weak scaling: every rank owns 8192 envs, global env ids rank*8192 + e).
 A "step" = one lock-step iteration of the hot loop over all envs of the rank.
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
-         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Launch:  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: bench.py starts the N
+                                                                     ranks itself through torch.distributed.run)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                bench.py --gpus N --steps K --warmup W               (the driver's form: one rank per GPU over RCCL)
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -261,6 +263,10 @@ def main():
                    help='EXPERIMENT (labelled in the output, never the headline): ic3_policy_step maintains the obs rows '
                         'incrementally (clears what the previous step painted, paints the new entries) instead of '
                         'zero-filling them every step; the rows are bit-identical, the HBM traffic is not')
+    p.add_argument('--prefill-obs', type=int, default=int(os.environ.get('IC3_BENCH_PREFILL_OBS', '0')),
+                   help='1: the zero background of the obs rows is written by ic3_obs_prefill on a second stream, one step '
+                        'ahead on the other of two obs buffers (the policy launch then only patches); 0: zero stores '
+                        'issued from inside the policy launch')
     p.add_argument('--rccl', type=int, default=int(os.environ.get('IC3_BENCH_RCCL', '0')),
                    help='1: bring up the RCCL process group even for one rank (world_size 1) so that the timing barrier '
                         'and the MAX / SUM reductions of the N > 1 path run on device tensors over RCCL')
@@ -269,12 +275,27 @@ def main():
                         'during the eager warm-up episode (seconds; selections are kept in memory)')
     o = p.parse_args()
 
+    if o.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
+        # reference's one worker per process: multi_processing.py:41-72) and hand over — rank 0 of the children prints
+        # the ONE JSON line.  Exactly what the driver's torch.distributed.run command line does.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(o.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if 'IC3_BENCH_DEVICE' in os.environ:      # test hook: several ranks on one GPU (exercises the world>1 control flow)
         local_rank = int(os.environ['IC3_BENCH_DEVICE'])
-    assert world == o.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert world == o.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node == --gpus, " \
+                            "or without a launcher (bench.py then starts the ranks itself)" % (world, o.gpus)
 
     cpu = None
     if rank == 0 and world == 1 and not o.no_cpu_baseline:
@@ -312,6 +333,7 @@ def main():
     a.auto_reset = bool(o.auto_reset)
     a.incremental_obs = bool(o.incremental_obs)
     a.gate_split = bool(o.gate_split)
+    a.prefill_obs = bool(o.prefill_obs)
     T = a.max_steps
     raw_env = trainer.env.env
     live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
@@ -392,6 +414,7 @@ def main():
     if o.time_kernels and mega_live:
         raw_env.step_timer = []               # the launch of every step is event-timed and issued eagerly
         raw_env.dispatch_events = bool(o.dispatch_events)   # events stamped by the dispatch, not recorded around it
+        raw_env.fill_timer = []               # ... and the fill launch on the second stream (args.prefill_obs)
     gc.disable()                              # (like timeit: no collector pause in the warm-up + timed steps)
     t_in_ep = run(o.warmup, 0)                # W untimed warm-up steps, in the measured configuration
 
@@ -401,6 +424,8 @@ def main():
         raw_env.obs_timer = []
         if raw_env.step_timer is not None:
             raw_env.step_timer = []
+        if getattr(raw_env, 'fill_timer', None) is not None:
+            raw_env.fill_timer = []
         live0 = live_done[0] + raw_env.device_stats().live_env_steps  # (synchronises) finished episodes + the running one
         barrier()
         torch.cuda.synchronize()
@@ -414,6 +439,7 @@ def main():
         obs_ms = [s_.elapsed_time(e_) for s_, e_ in raw_env.obs_timer]
         step_all = [(s_.elapsed_time(e_), t_) for s_, e_, t_ in (raw_env.step_timer or [])]
         live = live_done[0] + raw_env.device_stats().live_env_steps - live0
+        fill_ms[:] = [s_.elapsed_time(e_) for s_, e_, _t in (getattr(raw_env, 'fill_timer', None) or [])]
         return t_in_ep, dt, host_dt, obs_ms, step_all, live
 
     # One 6 ms sample (the driver's 20 steps) can be hit by a clock ramp or a host hiccup.  The region is therefore
@@ -421,6 +447,7 @@ def main():
     # (GPU-bound loop: wall = launches + a few us of gaps per step).  A region whose two clocks disagree by more than
     # 10 % is measured again (at most 3 attempts, each EXACTLY o.steps steps); the attempt count is reported.
     attempts = []
+    fill_ms = []
     for attempt in range(3):
         t_in_ep, dt, host_dt, obs_ms, step_all, live_steps = timed_region(t_in_ep)
         launch_sum = sum(ms for ms, _ in step_all) + sum(obs_ms)
@@ -510,6 +537,7 @@ def main():
                          "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms)},
             "cpu_baseline": cpu,
             "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms) if step_ms else None,
+            "fill_launch_ms": round(sum(fill_ms) / len(fill_ms), 4) if fill_ms else None,
             "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),
             "ms_per_step_ranks": [round(x, 4) for x in rank_ms],
             "collectives": backend,
@@ -519,6 +547,7 @@ def main():
                        "launch_ms_max": round(max(step_ms), 4) if step_ms else None},
         }
         if not attempts[-1]["consistent"]:
+            out["timing_inconsistent"] = True     # no attempt had wall clock and device clock agree: not a valid headline
             sys.stderr.write("bench.py: wall clock and event-timed launches disagree by more than 10 %% in all %d "
                              "attempts: %r\n" % (len(attempts), attempts))
         print(json.dumps(out))

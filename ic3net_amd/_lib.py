@@ -9,6 +9,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("IC3_ROLLOUT_LIB") or os.path.join(_HERE, "csrc", "libic3rollout.so")   # (override: A/B builds)
 
+ABI_VERSION = 400        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
 ENV_PP, ENV_TJ = 1, 2
 PP_MODES = {"mixed": 0, "cooperative": 1, "competitive": 2}
 TJ_DIFFICULTY = {"easy": 0, "medium": 1, "hard": 2}
@@ -41,26 +42,35 @@ class Stats(C.Structure):
 
 class Policy(C.Structure):
     """ic3_policy (include/ic3_rollout.h): host struct of device pointers for ic3_policy_step."""
-    _fields_ = [("H", C.c_int32), ("nheads", C.c_int32), ("head_sizes", C.c_int32 * 4), ("mode_avg", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("H", C.c_int32), ("nheads", C.c_int32), ("head_sizes", C.c_int32 * 4), ("mode_avg", C.c_int32),
                 ("comm_zero", C.c_int32), ("enc_wt", C.c_void_p), ("enc_bias", C.c_void_p), ("loc_table", C.c_void_p),
                 ("c_wp", C.c_void_p), ("lstm_wp", C.c_void_p), ("lstm_bias", C.c_void_p), ("head_w", C.c_void_p),
                 ("head_b", C.c_void_p), ("pass_index", C.c_int32), ("inner_pass", C.c_int32), ("gate_split", C.c_int32),
                 ("reserved_", C.c_int32), ("lstm_wp3", C.c_void_p)]
 
+    def __init__(self, *a, **kw):             # positional arguments start at the field behind struct_size
+        super().__init__(*((0,) + a if a else a), **kw)
+        self.struct_size = C.sizeof(self)
+
 
 class Episode(C.Structure):
     """ic3_episode (include/ic3_rollout.h): episode buffers in, masks and reduced statistics out."""
-    _fields_ = [("n", C.c_int32), ("E", C.c_int32), ("N", C.c_int32), ("auto_reset", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("n", C.c_int32), ("E", C.c_int32), ("N", C.c_int32), ("auto_reset", C.c_int32),
                 ("forced_last", C.c_int32), ("gate_ones", C.c_int32), ("done", C.c_void_p), ("alive", C.c_void_p),
                 ("is_completed", C.c_void_p), ("reward", C.c_void_p), ("gate", C.c_void_p), ("gate_stride", C.c_int64),
                 ("live", C.c_void_p), ("alive_mask", C.c_void_p), ("episode_mask", C.c_void_p),
                 ("episode_mini_mask", C.c_void_p), ("live_after", C.c_void_p), ("stats", C.c_void_p),
                 ("scratch", C.c_void_p), ("counter", C.c_void_p)]
 
+    def __init__(self, *a, **kw):             # positional arguments start at the field behind struct_size
+        super().__init__(*((0,) + a if a else a), **kw)
+        self.struct_size = C.sizeof(self)
+
 
 EXPORTS = {
     # name: (restype, argtypes)
     "ic3_version": (C.c_int, []),
+    "ic3_abi_check": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t]),
     "ic3_last_error": (C.c_char_p, []),
     "ic3_pp_create": (C.c_int, [C.POINTER(PPCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "ic3_tj_create": (C.c_int, [C.POINTER(TJCfg), C.c_int, C.POINTER(C.c_void_p)]),
@@ -113,6 +123,8 @@ EXPORTS = {
     "ic3_policy_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_policy_forward": (C.c_int, [C.POINTER(Policy), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "ic3_policy_step": (C.c_int, [C.c_void_p, C.POINTER(Policy)] + [C.c_void_p] * 12),
+    "ic3_obs_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ic3_obs_set_prefilled": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ic3_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ic3_event_destroy": (C.c_int, [C.c_void_p]),
     "ic3_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
@@ -142,6 +154,11 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        # the boundary checks itself: same header version, same struct layouts (a stale .so would read garbage otherwise)
+        if l.ic3_version() != ABI_VERSION or l.ic3_abi_check(ABI_VERSION, C.sizeof(Policy), C.sizeof(Episode)) != 0:
+            raise IC3Error("%s is version %d, this binding needs %d with sizeof(ic3_policy) = %d, sizeof(ic3_episode) = %d: %s"
+                           % (SO_PATH, l.ic3_version(), ABI_VERSION, C.sizeof(Policy), C.sizeof(Episode),
+                              l.ic3_last_error().decode("utf-8", "replace")))
         _lib = l
     return _lib
 

@@ -30,6 +30,9 @@ def supported(args, net, raw):
         return False
     if getattr(net, 'comm_passes', 1) < 1 or args.hid_size % 4 or not hasattr(raw, 'encode_at'):
         return False
+    h4 = args.hid_size // 4
+    if h4 > 64 or h4 & (h4 - 1):        # ic3_lstm_cell_backward (the non-fused step): H/4 a power of two <= 64;
+        return False                    # other sizes keep the autograd update
     if getattr(net.obs_encoder, '__self__', None) is not raw or net.nagents != raw.nagents_env:
         return False
     return net.encoder.weight.is_cuda and net.encoder.weight.dtype == torch.float32

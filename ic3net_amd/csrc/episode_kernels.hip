@@ -173,6 +173,9 @@ int ic3_episode_finalize(const ic3_episode* ep, ic3_stream stream)
 {
     Range range("ic3_episode_finalize");
     if (!ep) return fail(-22, "ic3_episode_finalize: null argument");
+    if (ep->struct_size != sizeof(ic3_episode))
+        return fail(-22, "ic3_episode_finalize: ic3_episode.struct_size is " + std::to_string(ep->struct_size) + ", this library's is " +
+                             std::to_string(sizeof(ic3_episode)) + " (built against another ic3_rollout.h?)");
     const ic3_episode& a = *ep;
     if (a.E <= 0 || a.N <= 0 || a.n < 0) return fail(-22, "ic3_episode_finalize: bad sizes");
     if (a.N > EF_THREADS) return fail(-22, "ic3_episode_finalize: more than 256 agents per env");

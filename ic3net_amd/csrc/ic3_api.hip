@@ -161,6 +161,18 @@ using namespace ic3;
 extern "C" {
 
 int ic3_version(void) { return IC3_VERSION; }
+
+int ic3_abi_check(int version, size_t sizeof_policy, size_t sizeof_episode)
+{
+    if (version != IC3_VERSION)
+        return fail(-22, "ic3_abi_check: the caller was built against ic3_rollout.h version " + std::to_string(version) +
+                             ", this library is version " + std::to_string(IC3_VERSION));
+    if (sizeof_policy != sizeof(ic3_policy) || sizeof_episode != sizeof(ic3_episode))
+        return fail(-22, "ic3_abi_check: struct sizes differ (ic3_policy " + std::to_string(sizeof_policy) + " vs " +
+                             std::to_string(sizeof(ic3_policy)) + ", ic3_episode " + std::to_string(sizeof_episode) + " vs " +
+                             std::to_string(sizeof(ic3_episode)) + ")");
+    return 0;
+}
 const char* ic3_last_error(void) { return g_err.c_str(); }
 
 int ic3_pp_create(const ic3_pp_cfg* cfg, int device, ic3_env** out)

@@ -91,7 +91,13 @@ struct ic3_env {
     int32_t* obs_rec = nullptr;
     const float* painted_obs = nullptr;
     bool painted_valid = false;
-    void touch_obs(const float* obs) { if (obs && obs == painted_obs) painted_valid = false; }   // another writer of that buffer
+    int fill_nap = 0;                       // ic3_obs_prefill: sleep quanta between two stores of a fill wave (pacing)
+    const float* prefilled_obs = nullptr;   // ic3_obs_prefill: this buffer holds zero rows — the next ic3_policy_step on it only patches
+    void touch_obs(const float* obs)        // another writer of that buffer
+    {
+        if (obs && obs == painted_obs) painted_valid = false;
+        if (obs && obs == prefilled_obs) prefilled_obs = nullptr;
+    }
     // Traffic-Junction constant tables (device + host copies)
     int32_t* d_grid = nullptr;       // [h*w] road ids
     int32_t* d_route_off = nullptr;  // [npath+1]

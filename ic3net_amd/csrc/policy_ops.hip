@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict_
 // read 4H floats per row again; 2048 workgroups adding into the same 4H words with atomics cost more than they saved).
 template <int H4>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
-                                                            const float* __restrict__ dh, const float* __restrict__ dc,
-                                                            float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                                            const float* __restrict__ dh, const float* dc,
+                                                            float* __restrict__ dgates, float* dc_prev,   // (dc_prev may alias dc)
                                                             float* __restrict__ dbias, int R)
 {
     constexpr int RL = 256 / H4;                                  // row lanes of a workgroup

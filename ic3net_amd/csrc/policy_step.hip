@@ -140,6 +140,8 @@ struct StepArgs {
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
     int32_t* obs_rec;           // incremental mode (ic3_env_set_incremental_obs): what the rows of `obs` hold painted, per env
     int obs_incr;               // 1: `obs` still holds exactly what obs_rec describes -> clear those entries, no zero fill
+    int obs_prefilled;          // 1: ic3_obs_prefill zero-filled `obs` (a launch of its own, ordered in front by the caller):
+                                //    this launch only patches the non-zero entries in
     int obs_dim;                // floats per observation row
     int ntiles;                 // workgroups = tiles: n_full tiles of EPT envs, then half tiles of EPTh envs
     int n_full, EPTh;
@@ -243,7 +245,8 @@ __device__ __forceinline__ TileGeom tile_geom(const StepArgs& a, int tile_id)
     g.c_hi = (g.mis + g.onb) >> 6;
     g.zend = g.obs_here ? max(0, (64 * g.c_hi - g.mis) * 16) : 0;   // bytes of the body up to the last full chunk
     if (IC3_PS_ABL & 64) g.zend = 0;   // ablation: every zero store is issued and dropped by the range check (no HBM traffic)
-    if (a.obs_incr) g.zend = 0;        // incremental rows: nothing to zero-fill (the host also sets every slot count to 0)
+    if (a.obs_incr || a.obs_prefilled) g.zend = 0;   // incremental / prefilled rows: nothing to zero-fill here (the host
+                                                     // also sets every slot count to 0)
     return g;
 }
 
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             if (tid < a.OT * H4) As4[(tid / H4) * LDA4 + tid % H4] = hw0;
             if (tid + NT < a.OT * H4) As4[((tid + NT) / H4) * LDA4 + (tid + NT) % H4] = hw1;
-            if (obs_here && !a.obs_incr) {
+            if (obs_here && !a.obs_incr && !a.obs_prefilled) {
 #pragma unroll 1
                 for (int i = 0; i < a.zrest; ++i) zero_store();     // obs-dominated shapes
                 // ragged chunks: chunk 0 when the body starts inside it, chunk c_hi when the body ends inside it; the
@@ -1211,8 +1214,17 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, 
 // words of the small LDS arrays behind the A tile: sm, sscale, sact, rmask [64 each], sfm [4], sep, sts [64 each], shb [16], slb [4H]
 static size_t ps_lds_small(int H) { return 6 * 64 + 4 + 16 + 4 * (size_t)H; }
 
+static int check_policy_struct(const ic3_policy* p, const char* who)
+{
+    if (p && p->struct_size != sizeof(ic3_policy))
+        return fail(-22, std::string(who) + ": ic3_policy.struct_size is " + std::to_string(p->struct_size) + ", this library's is " +
+                             std::to_string(sizeof(ic3_policy)) + " (built against another ic3_rollout.h?)");
+    return 0;
+}
+
 static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
 {
+    if (int rc = check_policy_struct(p, who)) return rc;
     if (!p->c_wp || !p->lstm_wp || !p->lstm_bias || !p->head_w || !p->head_b)
         return fail(-22, std::string(who) + ": incomplete ic3_policy");
     if (p->nheads < 1 || p->nheads > 4) return fail(-22, std::string(who) + ": 1..4 action heads");
@@ -1425,6 +1437,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
                                   const int32_t* alive_in, const int32_t* comm_in, float* out, ic3_stream stream)
 {
     ic3::Range range_("ic3_policy_forward");
+    if (int src = check_policy_struct(p, "ic3_policy_forward")) return src;   // before any other field is read
     if (!p || !enc || !h || !c || (!out && !p->inner_pass) || E <= 0 || N <= 0)
         return fail(-22, "ic3_policy_forward: bad arguments");
     const int H = p->H;
@@ -1456,6 +1469,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
                                int32_t* done, int32_t* alive, int32_t* is_completed, ic3_stream stream)
 {
     ic3::Range range_("ic3_policy_step");
+    if (int src = check_policy_struct(p, "ic3_policy_step")) return src;      // before any other field is read
     if (!env || !p || !h || !c) return fail(-22, "ic3_policy_step: null argument");
     const bool inner = p->inner_pass != 0;                       // a non-final communication pass: h, c only
     if (!inner && (!out || !action || !reward || !done)) return fail(-22, "ic3_policy_step: null argument");
@@ -1503,9 +1517,13 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     const int tiles = plan_tiles(a, H, p, (hipStream_t)stream);
     // incremental obs rows (opt-in): the buffer must be the one the previous call painted, untouched since
     const bool incr = fused_obs && env->obs_rec != nullptr;
-    const bool incr_valid = incr && env->painted_valid && env->painted_obs == obs;
+    // rows zero-filled by ic3_obs_prefill (a launch of its own, beside the previous step): patches only.  One use per fill.
+    const bool prefilled = fused_obs && !incr && env->prefilled_obs == obs;
+    if (obs && env->prefilled_obs == obs) env->prefilled_obs = nullptr;
+    const bool incr_valid = (incr && env->painted_valid && env->painted_obs == obs) || prefilled;   // (no zero fill in the launch)
     a.obs_rec = incr ? env->obs_rec : nullptr;
-    a.obs_incr = incr_valid ? 1 : 0;
+    a.obs_incr = (incr_valid && !prefilled) ? 1 : 0;
+    a.obs_prefilled = prefilled ? 1 : 0;
     if (incr) {
         env->painted_obs = obs;
         env->painted_valid = true;

@@ -58,33 +58,60 @@ class Random(nn.Module):                                   # models.py:37-56
         return out, v
 
 
+class _TanhRecurrence(object):
+    """rnn_type 'MLP' (models.py:86-88): next = tanh(affine2(prev) + enc), hidden state (E, N, H)."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def step(self, enc, state):
+        nxt = torch.tanh(self.owner.affine2(state) + enc)
+        return nxt, nxt
+
+    def blank(self, envs):
+        raise AttributeError("init_hidden() belongs to the LSTM variant; the Trainer starts this one from zeros (trainer.py:41)")
+
+
+class _LSTMRecurrence(object):
+    """rnn_type 'LSTM' (models.py:75-84): one LSTMCell over the E*N agent rows; the state handed back is a fresh pair
+    (the Trainer detaches / stores it), the features keep the (E, N, H) view."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def step(self, enc, state):
+        o = self.owner
+        envs = enc.shape[0]
+        h, c = o.lstm_unit(enc.reshape(envs * o.nagents, o.hid_size), state)
+        return h.view(envs, o.nagents, o.hid_size), (h.clone(), c.clone())
+
+    def blank(self, envs):
+        w = self.owner.affine1.weight
+        rows = envs * self.owner.nagents
+        return tuple(torch.zeros(rows, self.owner.hid_size, requires_grad=True, device=w.device, dtype=w.dtype)
+                     for _ in range(2))
+
+
 class RNN(MLP):
+    """IRIC baseline (models.py:59-97).  Parameter names follow the reference's checkpoints: `affine1`, `heads.k`,
+    `value_head`, and `affine2` (rnn_type 'MLP') or `lstm_unit` (rnn_type 'LSTM').  The recurrence itself is a small
+    strategy object chosen once, so forward() has one shape: encode -> recur -> heads."""
+
     def __init__(self, args, num_inputs):
-        super(RNN, self).__init__(args, num_inputs)
-        self.nagents = self.args.nagents
-        self.hid_size = self.args.hid_size
-        if self.args.rnn_type == 'LSTM':                   # models.py:64-66
-            del self.affine2
+        super(RNN, self).__init__(args, num_inputs)      # (creates affine2 too: the reference's constructor draws its
+        self.nagents = args.nagents                      #  weights from the global generator before the LSTM's, so a
+        self.hid_size = args.hid_size                    #  seeded default init comes out the same)
+        if args.rnn_type == 'LSTM':
+            self._modules.pop('affine2')                 # not part of this variant's state_dict (models.py:64-66)
             self.lstm_unit = nn.LSTMCell(self.hid_size, self.hid_size)
-
-    def forward(self, x, info={}):                         # models.py:68-92
-        x, prev_hid = x
-        encoded_x = self._affine1(x)
-        if self.args.rnn_type == 'LSTM':
-            batch_size = encoded_x.size(0)
-            encoded_x = encoded_x.reshape(batch_size * self.nagents, self.hid_size)
-            next_hid, cell_state = self.lstm_unit(encoded_x, prev_hid)
-            ret = (next_hid.clone(), cell_state.clone())
-            next_hid = next_hid.view(batch_size, self.nagents, self.hid_size)
+            self._recur = _LSTMRecurrence(self)
         else:
-            next_hid = torch.tanh(self.affine2(prev_hid) + encoded_x)
-            ret = next_hid
-        action, v = self._outputs(next_hid)
-        return action, v, ret
+            self._recur = _TanhRecurrence(self)
 
-    def init_hidden(self, batch_size):                     # models.py:94-97
-        p = self.affine1.weight
-        return tuple((torch.zeros(batch_size * self.nagents, self.hid_size, requires_grad=True, device=p.device,
-                                  dtype=p.dtype),
-                      torch.zeros(batch_size * self.nagents, self.hid_size, requires_grad=True, device=p.device,
-                                  dtype=p.dtype)))
+    def forward(self, x, info={}):
+        obs, state = x
+        feat, state = self._recur.step(self._affine1(obs), state)
+        return self._outputs(feat) + (state,)
+
+    def init_hidden(self, batch_size):
+        return self._recur.blank(batch_size)

@@ -30,7 +30,15 @@
 extern "C" {
 #endif
 
-#define IC3_VERSION 200 /* 0.2.0 */
+/* Version of THIS header.  The structs the caller fills (ic3_policy, ic3_episode) have grown between versions, so the
+ * boundary checks itself: ic3_version() returns the library's value, ic3_abi_check() compares the caller's version and
+ * struct sizes with the library's, and both structs start with `struct_size` (= sizeof, set by the caller) — an entry
+ * point handed a struct of another size refuses it with -EINVAL before reading any other field. */
+#define IC3_VERSION 400 /* 0.4.0 (round 4: struct_size handshake, ic3_obs_prefill) */
+
+/* 0 when `version` == IC3_VERSION of the library and the two sizes are the library's sizeof(ic3_policy) /
+ * sizeof(ic3_episode); -EINVAL (with a message naming the mismatch) otherwise.  A binding calls it once after loading. */
+int ic3_abi_check(int version, size_t sizeof_policy, size_t sizeof_episode);
 
 typedef struct ic3_env ic3_env; /* opaque */
 typedef void* ic3_stream;       /* hipStream_t */
@@ -238,6 +246,7 @@ int ic3_env_stats(ic3_env* env, ic3_stats* host_out, ic3_stream stream);
  * counter: reserved (may be NULL).  Two launches (derivations + block partials, then a one-block fixed-order
  * reduction); asynchronous on `stream`. */
 typedef struct ic3_episode {
+    uint32_t struct_size;         /* sizeof(ic3_episode) of the caller's header (checked: -EINVAL on mismatch) */
     int32_t n, E, N;
     int32_t auto_reset, forced_last, gate_ones;
     const int32_t* done;          /* [n][E] */
@@ -360,6 +369,7 @@ int ic3_env_sample_actions(const ic3_env* env, const float* logp, int ld, int A,
  * Returns -ENOSYS when ic3_policy_step_supported(env, H) == 0 (H not in {64,128,256}, > 64 agents, or an env tile
  * that does not fit in LDS): use the separate entry points then. */
 typedef struct {
+    uint32_t struct_size;   /* sizeof(ic3_policy) of the caller's header (checked: -EINVAL on mismatch) */
     int32_t H;
     int32_t nheads;
     int32_t head_sizes[4];
@@ -418,6 +428,20 @@ int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, int N, floa
 int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, float* c, const int32_t* alive_in,
                     const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward, int32_t* done,
                     int32_t* alive, int32_t* is_completed, ic3_stream stream);
+
+/* The zero background of the dense observation rows as a launch of its own: zero-fills obs [E][N][obs_dim] on `stream`
+ * and marks the buffer — the NEXT ic3_policy_step that is handed this buffer only patches the non-zero entries of the
+ * rows in (instead of zero-filling its tiles' slices from inside the matrix work) and clears the mark.  Meant to run on a
+ * second stream BESIDE the policy launch of the previous step, on the other one of two obs buffers (the reference
+ * allocates a fresh observation every step: predator_prey_env.py:188-190, env_wrappers.py:88-100); the caller orders the
+ * fill in front of the ic3_policy_step that consumes it (event / stream wait).  Every row is still rewritten every step.
+ * Any other writer of the buffer through this handle (ic3_env_observe, ic3_env_step with obs) drops the mark.
+ * obs must be 16-byte aligned (-EINVAL otherwise). */
+int ic3_obs_prefill(ic3_env* env, float* obs, ic3_stream stream);
+/* The mark by itself (host state of the handle, no launch): `obs` holds zero rows — or, with NULL, no buffer does.  For a
+ * caller that replays captured launches (hipGraph): the handle only sees the calls made while capturing, so before it
+ * issues ic3_policy_step eagerly again the caller states what its replays left behind. */
+int ic3_obs_set_prefilled(ic3_env* env, const float* obs);
 
 /* Synthetic uniform actions in [0, naction) for env-only benchmarks (DOMAIN_BENCH). */
 int ic3_random_actions(int32_t* action, int naction, uint32_t seed, uint32_t env_id_offset, uint32_t episode,

@@ -292,6 +292,10 @@ def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, **flags):
     rh.finish_args(a, env)
     torch.manual_seed(seed)
     net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    if closed_form:       # BASELINE shapes: weights from the index alone (both sides regenerate them, no 4 MB blobs)
+        sd = net.state_dict()
+        cw = closed_form_weights({k: tuple(v.shape) for k, v in sd.items()})
+        net.load_state_dict({k: torch.from_numpy(cw[k]) for k in sd})
     tr = ref['trainer'].Trainer(a, net, env)
     N, nh = a.nagents, len(a.naction_heads)
     rs = np.random.RandomState(seed)
@@ -352,7 +356,7 @@ def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, **flags):
     print(name, 'nsteps', rec['nsteps'].tolist(), 'stat keys', sorted(stats))
 
 
-def grad_case(name, env_name, T, nenv, nep, seed, **flags):
+def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, **flags):
     """F5b: the reference run_batch + compute_grad (trainer.py:128-225) over nenv*nep taped episodes played one
     after the other in ONE batch (what a single reference process does), fp64.  Records the loss terms and every
     parameter gradient (before the /num_steps of train_batch), plus the weights and the action tape."""
@@ -363,6 +367,10 @@ def grad_case(name, env_name, T, nenv, nep, seed, **flags):
     rh.finish_args(a, env)
     torch.manual_seed(seed)
     net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    if closed_form:       # BASELINE shapes: weights from the index alone (both sides regenerate them, no 4 MB blobs)
+        sd = net.state_dict()
+        cw = closed_form_weights({k: tuple(v.shape) for k, v in sd.items()})
+        net.load_state_dict({k: torch.from_numpy(cw[k]) for k in sd})
     tr = ref['trainer'].Trainer(a, net, env)
     N, nh = a.nagents, len(a.naction_heads)
     rs = np.random.RandomState(seed)
@@ -412,10 +420,16 @@ def grad_case(name, env_name, T, nenv, nep, seed, **flags):
     out = dict(tape=tape.astype(np.int32), nsteps=nsteps, cfg=np.array([N, T, nenv, nep, nh, seed], np.int32),
                flags=np.array(repr(sorted(flags.items()))), action_loss=s['action_loss'], value_loss=s['value_loss'],
                entropy=s.get('entropy', 0.0), num_steps=stats['num_steps'])
-    for k, v in net.state_dict().items():
-        out['w:' + k] = v.detach().numpy().copy()
+    if closed_form:
+        out['param_names'] = np.array(list(net.state_dict().keys()))
+        out['param_shapes'] = np.array([repr(tuple(v.shape)) for v in net.state_dict().values()])
+    else:
+        for k, v in net.state_dict().items():
+            out['w:' + k] = v.detach().numpy().copy()
     for k, p in net.named_parameters():
-        out['g:' + k] = np.zeros(0) if p.grad is None else p.grad.detach().numpy().copy()
+        g = np.zeros(0) if p.grad is None else p.grad.detach().numpy().copy()
+        # (full-size fixtures keep the gradients as float32: the test's bar is 3e-4 of the largest entry)
+        out['g:' + k] = g.astype(np.float32) if closed_form else g
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     print(name, 'steps', stats['num_steps'], 'losses', s)
 
@@ -442,6 +456,17 @@ def trainer_main():
     trainer_fullsize_main()
 
 
+def grad_fullsize_main():
+    """F5b at BASELINE shapes (round-3 verdict item 4): the reference's compute_grad for PP-hard (configs[1]: 10 agents,
+    dim 20, vision 1, hid 128, 80 steps, detach_gap 10; env 0 is steered onto the prey and ends early) and TJ-hard
+    (configs[3]: 20 agents, dim 18, hid 128, 80 steps) on closed-form weights."""
+    grad_case('grad_pp_hard_ic3net', 'predator_prey', 80, 3, 1, 41, closed_form=True, nagents=10, dim=20, vision=1,
+              hid_size=128, ic3net=True, recurrent=True, detach_gap=10, entr=0.01, value_coeff=0.01)
+    grad_case('grad_tj_hard_ic3net', 'traffic_junction', 80, 2, 1, 42, closed_form=True, nagents=20, dim=18, vision=1,
+              hid_size=128, ic3net=True, recurrent=True, detach_gap=10, add_rate_min=0.05, add_rate_max=0.05,
+              difficulty='hard', entr=0.01, value_coeff=0.01)
+
+
 def trainer_fullsize_main():
     """F5 at BASELINE shapes: PP-hard (configs[1]) and TJ-hard (configs[3]), IC3Net recurrent hid 128, 80 steps."""
     trainer_case('trainer_pp_hard', 'predator_prey', 80, 2, 1, 25, greedy=True, nagents=10, dim=20, vision=1,
@@ -459,6 +484,8 @@ if __name__ == '__main__':
         nonrec_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         trainer_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_fullsize':
+        grad_fullsize_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':
         trainer_fullsize_main()
     else:

@@ -625,6 +625,7 @@ inline int __builtin_amdgcn_readfirstlane(int v)
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
 inline void* __builtin_amdgcn_kernarg_segment_ptr() { return const_cast<void*>(ic3_host::tl_kernarg); }
 inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }

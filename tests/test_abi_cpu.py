@@ -24,7 +24,36 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), s
     assert set(syms) == set(_lib.EXPORTS), set(syms) ^ set(_lib.EXPORTS)
-    assert l.ic3_version() == 200
+    hdr = int(re.search(r"#define\s+IC3_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "ic3_rollout.h")).read()).group(1))
+    assert l.ic3_version() == hdr == _lib.ABI_VERSION
+
+
+def test_abi_handshake_refuses_other_versions_and_struct_sizes():
+    """include/ic3_rollout.h: a binding built against another header version hands the library structs of another size
+    (ic3_policy grew in rounds 2 and 3).  ic3_abi_check names the mismatch, and every entry point that takes a struct
+    refuses one whose struct_size is not the library's with -EINVAL BEFORE it reads anything else (no GPU needed to
+    see that: the check comes first)."""
+    import ctypes as C
+    from ic3net_amd import _lib
+    l = _lib.lib()
+    assert l.ic3_abi_check(_lib.ABI_VERSION, C.sizeof(_lib.Policy), C.sizeof(_lib.Episode)) == 0
+    assert l.ic3_abi_check(200, C.sizeof(_lib.Policy), C.sizeof(_lib.Episode)) == -22
+    assert b"version 200" in l.ic3_last_error()
+    assert l.ic3_abi_check(_lib.ABI_VERSION, C.sizeof(_lib.Policy) - 16, C.sizeof(_lib.Episode)) == -22
+    assert b"struct sizes differ" in l.ic3_last_error()
+    pol = _lib.Policy()
+    assert pol.struct_size == C.sizeof(_lib.Policy)
+    pol.struct_size -= 16                        # round 2's ic3_policy: no gate_split / lstm_wp3
+    fake = C.c_void_p(64)                        # never dereferenced
+    assert l.ic3_policy_forward(C.byref(pol), fake, 1, 1, fake, fake, None, None, fake, None) == -22
+    assert b"struct_size" in l.ic3_last_error()
+    assert l.ic3_policy_step(fake, C.byref(pol), *([fake] * 12)) == -22
+    assert b"struct_size" in l.ic3_last_error()
+    ep = _lib.Episode(4, 2, 3, 0, 0, 0)
+    assert (ep.struct_size, ep.n, ep.E, ep.N) == (C.sizeof(_lib.Episode), 4, 2, 3)
+    ep.struct_size = 0
+    assert l.ic3_episode_finalize(C.byref(ep), None) == -22
+    assert b"struct_size" in l.ic3_last_error()
 
 
 def test_product_tj_tables_match_reference():

@@ -49,6 +49,23 @@ def test_bench_two_ranks_share_one_device():
     assert d["cpu_baseline"] is None and d["roofline"]["bound"] == "hbm"
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (WORLD_SIZE unset): bench.py starts the two ranks itself
+    (round 3: it died on an assert) and rank 0 prints the one line with per-rank times."""
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IC3_BENCH_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "4", "--nenvs", "512",
+                        "--no-cpu-baseline"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["ms_per_step_ranks"]) == 2 and d["collectives"] == "gloo"   # (nccl on 2 real GPUs)
+    assert d["config"]["parallelism"] == "env-shard x2"
+    assert d["value"] == pytest.approx(10 * 1024 * 12 / (d["ms_per_step"] * 12 * 1e-3), rel=1e-3)
+
+
 PP = ['--env_name', 'predator_prey', '--nagents', '3', '--nprocesses', '1', '--num_epochs', '2', '--epoch_size', '1',
       '--hid_size', '64', '--detach_gap', '10', '--lrate', '0.001', '--dim', '5', '--max_steps', '20', '--ic3net',
       '--vision', '0', '--recurrent', '--dist_backend', 'gloo', '--device', '0',

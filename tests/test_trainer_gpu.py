@@ -197,7 +197,9 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
 
 
 GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_commnet_norm", "predator_prey"),
-                 ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction")]
+                 ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction"),
+                 # BASELINE shapes (hid 128, 80 steps, detach_gap 10), closed-form weights: configs[1] and configs[3]
+                 ("grad_pp_hard_ic3net", "predator_prey"), ("grad_tj_hard_ic3net", "traffic_junction")]
 
 
 @pytest.mark.parametrize("native", [False, True])
@@ -226,7 +228,12 @@ def test_compute_grad_matches_reference(name, env_name, native):
         a.recurrent, a.rnn_type = True, 'LSTM'
     parse_action_args(a)
     net = CommNetMLP(a, a.num_inputs)
-    net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
+    if "param_names" in fx.files:                     # full-size fixture: weights from the index alone
+        from policy_util import closed_form_weights
+        shapes = {str(n): eval(str(sh)) for n, sh in zip(fx["param_names"], fx["param_shapes"])}
+        net.load_state_dict({k: torch.from_numpy(v).float() for k, v in closed_form_weights(shapes).items()})
+    else:
+        net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
     net = net.cuda()
     tr = trmod.Trainer(a, net, env)
     tape = fx["tape"]

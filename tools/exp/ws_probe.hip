@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -173,6 +174,17 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, size_t floats_total,
             int idx = lane;
             for (int it = 0; it < every * 64; ++it) idx = tab[idx & 16383] + lane;
             if (idx == 123456789) sink[1] = (float)idx;
+        } else if (mode & 8192) {   // round 4: a store stream WITHOUT vector ALU work (descriptor + scalar offset), non-temporal
+            typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+            const unsigned int mine = (unsigned int)(per_cu * 16);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(base), 0, mine, 0x00020000);
+            u32x4s z = { 0u, 0u, 0u, 0u };
+            asm volatile("" : "+v"(z));
+            const int voff = lane * 16;
+            int so = __builtin_amdgcn_readfirstlane(sw) * 1024;
+            const int step = nsw * 1024;
+#pragma unroll 1
+            for (; so < (int)mine; so += step) __builtin_amdgcn_raw_buffer_store_b128(z, r, voff, so, 2);
         } else if (mode & 8) {
             f32x4 acc = { 0.f, 0.f, 0.f, 0.f };
             for (size_t q = (size_t)sw * 64 + lane; q < per_cu; q += (size_t)nsw * 64) acc += base[q];
@@ -242,8 +254,15 @@ int main(int argc, char** argv)
         { "bf16 mfma + VALU helper prio 3", 1, 1, 4, 4096 + 64 + 1, 256 },
         { "bf16 mfma + stores (4 waves)", 1, 1, 4, 4096, 1 },
         { "bf16 mfma + LOAD stream", 1, 1, 4, 4096 + 8, 1 },
-        { "bf16 mfma + L2-chase helper", 1, 1, 4, 4096 + 128, 8 } };
+        { "bf16 mfma + L2-chase helper", 1, 1, 4, 4096 + 128, 8 },
+        // round 4: helper waves whose store loop holds no vector ALU instruction
+        { "VALU-free stores only (4 waves)", 0, 1, 4, 8192, 1 },
+        { "fp32 mfma + VALU-free stores", 1, 1, 4, 8192, 1 },
+        { "bf16 mfma + VALU-free stores", 1, 1, 4, 4096 + 8192, 1 },
+        { "fp32 mfma + VALU-free stores, 1 wave", 1, 1, 1, 8192, 1 },
+        { "split by CU: VALU-free both", 1, 1, 4, 2 + 8192, 1 } };
     for (auto& c : cfg) {
+        if (argc > 1 && !strstr(c.name, argv[1]) && strcmp(c.name, "mfma only") && strcmp(c.name, "bf16 mfma only")) continue;
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             hipEventRecord(e0);
