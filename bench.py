@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (f32 in / f32 acc), same guide
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak (no sparsity), same guide
 
 
 WORKLOADS = {
@@ -214,18 +215,30 @@ def cpu_baseline(workload, envs_per_proc=256, episodes=1, seed=0, budget_s=10.0)
     return out
 
 
-def mfma_roofline(a, nenvs, step_ms):
+def mfma_roofline(a, nenvs, step_ms, gate_split=False):
     """The MFMA-bound kernel of the step: policy_step_kernel.  Algorithmic flops per launch = the two dense layers of
-    comm.py (C: H x H, LSTMCell: 2H x 4H) plus the heads, 2 flops per multiply-add, for E*N rows."""
+    comm.py (C: H x H, LSTMCell: 2H x 4H) plus the heads, 2 flops per multiply-add, for E*N rows: `achieved` / `frac` are
+    these fp32-EQUIVALENT flops against the fp32 matrix peak whatever the gate product runs on.  With the split gate product
+    (nine bf16 x bf16 products per fp32 product) `bf16_issued` reports what the bf16 matrix cores were actually asked for:
+    9 x the gate product's flops against the dense bf16 peak."""
     R, H = nenvs * a.nagents, a.hid_size
     OT = sum(int(x) for x in a.naction_heads) + 1
-    flops = 2.0 * R * (2 * H * 4 * H + H * H + H * OT)
+    gate = 2.0 * R * (2 * H * 4 * H)
+    flops = gate + 2.0 * R * (H * H + H * OT)
     avg = sum(step_ms) / len(step_ms)
     tf = flops / (avg * 1e-3) / 1e12
-    return {"kernel": "policy_step_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
-            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops,
-            "avg_launch_ms": round(avg, 4), "launches": len(step_ms),
-            "hbm_bytes_per_launch_algorithmic": R * (4 * H + OT + 2 * len(a.naction_heads) + 1) * 4}
+    out = {"kernel": "policy_step_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+           "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops,
+           "flops_counted": "fp32-equivalent (2 per multiply-add of comm.py's dense layers)",
+           "avg_launch_ms": round(avg, 4), "launches": len(step_ms),
+           "hbm_bytes_per_launch_algorithmic": R * (4 * H + OT + 2 * len(a.naction_heads) + 1) * 4}
+    if gate_split:
+        btf = 9.0 * gate / (avg * 1e-3) / 1e12
+        out["bf16_issued"] = {"flops_per_launch": 9.0 * gate, "achieved": round(btf, 1), "peak": MFMA_BF16_PEAK_TF,
+                              "unit": "TFLOP/s", "frac": round(btf / MFMA_BF16_PEAK_TF, 4),
+                              "note": "gate product only: 9 bf16 x bf16 products per fp32 product on "
+                                      "v_mfma_f32_32x32x16_bf16; the C product and the heads stay on the fp32 instruction"}
+    return out
 
 
 def main():
@@ -256,9 +269,10 @@ def main():
                         'slot of the timed region is then a live transition')
     p.add_argument('--fused-obs', type=int, default=int(os.environ.get('IC3_BENCH_FUSED_OBS', '1')),
                    help='next_state rows stored by the policy+step launch itself (0: separate obs-assembly launch)')
-    p.add_argument('--gate-split', type=int, default=0,
-                   help='EXPERIMENT, labelled in the output: 1 = the gate product of ic3_policy_step with every fp32 operand '
-                        'split exactly into three bf16 terms, nine exact products on the bf16 matrix cores')
+    p.add_argument('--gate-split', type=int, default=1,
+                   help='1 (default): the gate product of ic3_policy_step with every fp32 operand split exactly into three '
+                        'bf16 terms, all nine cross products on the bf16 matrix cores, fp32 accumulation (exact products: '
+                        'fp32-class arithmetic, DESIGN.md); 0: the fp32 matrix instruction')
     p.add_argument('--incremental-obs', type=int, default=0,
                    help='EXPERIMENT (labelled in the output, never the headline): ic3_policy_step maintains the obs rows '
                         'incrementally (clears what the previous step painted, paints the new entries) instead of '
@@ -488,29 +502,54 @@ def main():
         live_frac = live_steps / float(E_total * o.steps)
         obs_bytes = o.nenvs * N * raw_env.obs_dim * 4          # algorithmic bytes of one obs-assembly launch
         fused_obs = bool(step_ms) and not obs_ms and not o.no_dense_obs    # next_state rows stored by policy_step_kernel
-        hbm_kernel = "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel"
-        hbm_bytes = obs_bytes
-        hbm_ms = obs_ms
-        if fused_obs:
+        # The HBM-bound kernel of the step and ITS launches inside the timed region.  Nothing is reported from launches
+        # outside the per-step path (round 3's graph-mode line fell back to the two reset launches of pp_obs_kernel), and a
+        # fraction is only formed over bytes the timed launches really wrote.
+        state_bytes = mfma_roofline(a, o.nenvs, step_ms or [1.0])["hbm_bytes_per_launch_algorithmic"]
+        per_step_obs = len(obs_ms) >= max(1, o.steps // 2)
+        roof_note = None
+        if fused_obs and fill_ms:
+            hbm_kernel = "obs_fill_kernel (zero background of the obs rows, second stream, beside policy_step_kernel)"
+            hbm_bytes, hbm_ms = obs_bytes, fill_ms
+        elif fused_obs and o.incremental_obs:
+            hbm_kernel, hbm_bytes, hbm_ms = "policy_step_kernel", None, step_ms
+            roof_note = "EXPERIMENT --incremental-obs: the launch does not rewrite the rows, so no fraction is formed over them"
+        elif fused_obs:
             hbm_kernel = "policy_step_kernel (policy + draws + env.step + obs assembly in one launch)"
-            hbm_bytes = obs_bytes + mfma_roofline(a, o.nenvs, step_ms)["hbm_bytes_per_launch_algorithmic"]
-            hbm_ms = step_ms
+            hbm_bytes, hbm_ms = obs_bytes + state_bytes, step_ms
+        elif step_ms and o.no_dense_obs:
+            hbm_kernel, hbm_bytes, hbm_ms = "policy_step_kernel (no obs rows: diagnostic)", state_bytes, step_ms
+        elif per_step_obs:
+            hbm_kernel = "pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_kernel"
+            hbm_bytes, hbm_ms = obs_bytes, obs_ms
+        else:
+            hbm_kernel, hbm_bytes, hbm_ms = None, None, []
+            roof_note = ("launches replayed as hipGraphs are not event-timed: run with --time-kernels 1 for the roofline "
+                         "of the step's launch")
         avg_ms = sum(hbm_ms) / max(len(hbm_ms), 1)
-        achieved = hbm_bytes / (avg_ms * 1e-3) / 1e9 if hbm_ms else 0.0
+        achieved = hbm_bytes / (avg_ms * 1e-3) / 1e9 if (hbm_ms and hbm_bytes) else None
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'obs_traffic.json')
-        if os.path.exists(tf):
+        if os.path.exists(tf) and hbm_kernel and not o.incremental_obs and not fill_ms:
             try:
                 tab = json.load(open(tf))
                 key = o.workload + ('_fused' if fused_obs else '')
                 traffic = tab.get(key) if o.nenvs == tab.get('_nenvs', 8192) else None   # measured at that size
             except Exception:
                 traffic = None
+        roofline = None if hbm_kernel is None else {
+            "kernel": hbm_kernel, "bound": "hbm", "achieved": round(achieved, 1) if achieved is not None else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved is not None else None, "traffic": traffic,
+            "traffic_source": "rocprofv3 PMC passes of this command, profiles/obs_traffic.json (not re-measured in this "
+                              "run)" if traffic is not None else None,
+            "bytes_per_launch": hbm_bytes, "obs_bytes_per_launch": obs_bytes if not o.no_dense_obs else 0,
+            "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms), "note": roof_note}
         out = {
             "metric": "env-steps/sec (agents x envs x steps), rollout hot path",
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,
             "ms_per_step": round(dt / o.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (gate product: exact bf16x9 split, EXPERIMENT)" if o.gate_split else "f32",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "Predator-Prey hard: 10 agents, dim 20, vision 1, max_steps 80, IC3Net recurrent "
                                    "hid 128, %d envs per GPU" % o.nenvs if o.workload == 'pp_hard' else o.workload,
@@ -522,21 +561,21 @@ def main():
                        "policy": "one launch per step (ic3_policy_step)" if mega_live else "launch chain",
                        "auto_reset": bool(o.auto_reset),
                        "obs_rows": ("EXPERIMENT: maintained incrementally (not rewritten every step) - not the headline "
-                                    "configuration" if o.incremental_obs else "rewritten every step"),
-                       "gemm": ("EXPERIMENT: gate product as nine exact bf16 split products (fp32 accumulation) - not the "
-                                "headline configuration" if (mega_live and o.gate_split) else
-                                "hand-written fp32 MFMA" if mega_live else
+                                    "configuration" if o.incremental_obs else
+                                    "rewritten every step (EXPERIMENT --prefill-obs: zeros by ic3_obs_prefill on a second "
+                                    "stream, non-zero entries by the policy launch)" if (o.prefill_obs and fill_ms) else
+                                    "rewritten every step"),
+                       "gemm": ("hand-written MFMA; gate product [inp|h].[W_ih|W_hh]^T: every fp32 operand split exactly into 3 "
+                                "bf16 terms, all 9 cross products on v_mfma_f32_32x32x16_bf16 (each product exact in fp32), fp32 "
+                                "accumulation - fp32-class arithmetic (error vs fp64 = the fp32 instruction's, "
+                                "tests/test_gate_split_gpu.py; --gate-split 0 selects v_mfma_f32_32x32x2_f32); C product and "
+                                "heads: fp32 MFMA" if (mega_live and o.gate_split) else
+                                "hand-written fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mega_live else
                                 "TunableOp-selected" if o.tune_gemm else "default heuristics")},
             "live_frac": round(live_frac, 6),
-            "roofline": {"kernel": hbm_kernel, "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": "rocprofv3 PMC passes of this command, profiles/obs_traffic.json (not re-measured "
-                                           "in this run)" if traffic is not None else None,
-                         "bytes_per_launch": hbm_bytes, "obs_bytes_per_launch": obs_bytes,
-                         "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms)},
+            "roofline": roofline, "roofline_note": roof_note if roofline is None else None,
             "cpu_baseline": cpu,
-            "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms) if step_ms else None,
+            "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms, bool(mega_live and o.gate_split)) if step_ms else None,
             "fill_launch_ms": round(sum(fill_ms) / len(fill_ms), 4) if fill_ms else None,
             "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),
             "ms_per_step_ranks": [round(x, 4) for x in rank_ms],

@@ -120,6 +120,7 @@ EXPORTS = {
     "ic3_env_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
     "ic3_policy_pack": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
+    "ic3_gate_product_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_policy_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_policy_forward": (C.c_int, [C.POINTER(Policy), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "ic3_policy_step": (C.c_int, [C.c_void_p, C.POINTER(Policy)] + [C.c_void_p] * 12),

@@ -20,6 +20,7 @@
 #define IC3_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
 #define IC3_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #define IC3_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define IC3_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")   // at most n vector-memory operations in flight
 #endif
 
 namespace ic3 {

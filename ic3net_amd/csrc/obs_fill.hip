@@ -27,7 +27,7 @@ typedef unsigned int of_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT_STORES>
 __global__ __launch_bounds__(64) void obs_fill_kernel(float* __restrict__ base, unsigned int nblocks, unsigned int last_bytes,
-                                                      int U, unsigned int start_stride, unsigned int trip_stride, int nap)
+                                                      int U, unsigned int start_stride, unsigned int trip_stride, int nap, int depth)
 {
     // One wave per workgroup.  The 16-byte aligned body is `nblocks` blocks of 1 KiB (the last one holds last_bytes).  Trip
     // u of wave b covers block b * start_stride + u * trip_stride: (U, 1) = a contiguous slice per wave, (1, gridDim.x) =
@@ -49,6 +49,22 @@ __global__ __launch_bounds__(64) void obs_fill_kernel(float* __restrict__ base, 
             reinterpret_cast<char*>(base) + ((unsigned long long)bi << 10), 0, mine, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(z, r, voff, 0, NT_STORES ? 2 : 0);   // past `mine`: dropped by the range check
         bi += trip_stride;
+        // CLOSED-LOOP pacing: at most `depth` stores of this wave in flight.  Left to itself a wave keeps 64 of them
+        // outstanding (the counter's range) — 64 MB across the chip, ~20 us of queue in front of every L2 channel, and the
+        // policy launch's loads wait in those queues (measured: 4 x slower).
+        switch (depth) {
+        case 0: IC3_WAIT_VMEM_N(0); break;
+        case 1: IC3_WAIT_VMEM_N(1); break;
+        case 2: IC3_WAIT_VMEM_N(2); break;
+        case 3: IC3_WAIT_VMEM_N(3); break;
+        case 4: IC3_WAIT_VMEM_N(4); break;
+        case 6: IC3_WAIT_VMEM_N(6); break;
+        case 8: IC3_WAIT_VMEM_N(8); break;
+        case 12: IC3_WAIT_VMEM_N(12); break;
+        case 16: IC3_WAIT_VMEM_N(16); break;
+        case 32: IC3_WAIT_VMEM_N(32); break;
+        default: break;
+        }
 #pragma unroll 1
         for (int q = 0; q < nap; ++q) __builtin_amdgcn_s_sleep(1);
     }
@@ -87,6 +103,7 @@ extern "C" int ic3_obs_prefill(ic3_env* env, float* obs, ic3_stream stream)
     static const int waves_env = getenv("IC3_FILL_WAVES") ? atoi(getenv("IC3_FILL_WAVES")) : 400;
     static const int mode = getenv("IC3_FILL_MODE") ? atoi(getenv("IC3_FILL_MODE")) : 0;
     static const int nap_env = getenv("IC3_FILL_NAP") ? atoi(getenv("IC3_FILL_NAP")) : -1;
+    static const int depth = getenv("IC3_FILL_DEPTH") ? atoi(getenv("IC3_FILL_DEPTH")) : 4;
     static const int plain = getenv("IC3_FILL_PLAIN") ? atoi(getenv("IC3_FILL_PLAIN")) : 0;
     env->touch_obs(obs);
     if (bytes16) {
@@ -109,10 +126,10 @@ extern "C" int ic3_obs_prefill(ic3_env* env, float* obs, ic3_stream stream)
         const int nap = nap_env >= 0 ? nap_env : env->fill_nap;
         if (plain)
             hipLaunchKernelGGL((obs_fill_kernel<0>), dim3((unsigned)grid), dim3(64), 0, s, obs, (unsigned int)blocks, last_bytes,
-                               (int)U, start_stride, trip_stride, nap);
+                               (int)U, start_stride, trip_stride, nap, depth);
         else
             hipLaunchKernelGGL((obs_fill_kernel<1>), dim3((unsigned)grid), dim3(64), 0, s, obs, (unsigned int)blocks, last_bytes,
-                               (int)U, start_stride, trip_stride, nap);
+                               (int)U, start_stride, trip_stride, nap, depth);
     }
     if (floats & 3)
         hipLaunchKernelGGL(obs_fill_tail_kernel, dim3(1), dim3(64), 0, s, obs + (floats & ~3ull), (int)(floats & 3));

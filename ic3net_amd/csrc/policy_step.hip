@@ -1108,6 +1108,86 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 }
 
+// ---- ic3_gate_product_probe: the gate product ALONE (pre-activations without the bias), through the operand layouts, the
+// activation split and the per-accumulator order of matrix instructions of policy_step_kernel's two gate loops — (k ascending;
+// fp32: one v_mfma_f32_32x32x2_f32 per k; split: per 16-k block weight plane outer, then gate, then the activation terms
+// least significant first) — without their prefetch rings and store slots.  What the arithmetic of the two modes IS can be
+// measured with it on operands no rollout produces (edge magnitudes, tests/test_gate_split_gpu.py).
+template <int H, int SPLIT>
+__global__ __launch_bounds__(2 * H) void gate_product_probe_kernel(const float* __restrict__ xh, const ps_f32x4* l_wp, const void* l_wp3,
+                                                                   float* __restrict__ gates, int R)
+{
+    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, KB = K / 8, KB16 = K / 16;
+    IC3_DYNAMIC_LDS(float, smem);
+    ps_f32x4* const As4 = reinterpret_cast<ps_f32x4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5, col = 32 * w + li;
+    const size_t r0 = (size_t)blockIdx.x * BM;
+    for (int idx = tid; idx < BM * (K / 4); idx += NT) {
+        const int row = idx / (K / 4), c4 = idx - row * (K / 4);
+        ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+        if (r0 + row < (size_t)R) v = *reinterpret_cast<const ps_f32x4*>(xh + (r0 + row) * K + 4 * c4);
+        As4[row * LDA4 + c4] = v;
+    }
+    __syncthreads();
+    ps_f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
+    if constexpr (SPLIT != 0) {
+        const __amdgpu_buffer_rsrc_t rg3 = make_rsrc(l_wp3, (uint32_t)((size_t)3 * K * 4 * H * 2));
+        const int g3lane = (w * 64 + lane) * 16;
+        constexpr int GSTRIDE = NW * 64 * 16;
+#pragma unroll 1
+        for (int kb = 0; kb < KB16; ++kb) {
+            ps_u32x4 ap[2][3];
+            const ps_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
+            ps_split_frag(s0[0], s0[1], ap[0]);
+            const ps_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
+            ps_split_frag(s1[0], s1[1], ap[1]);
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    const ps_u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pb * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
+#pragma unroll
+                    for (int pa = 2; pa >= 0; --pa)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+                            acc[rt][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(ps_bf16x8, ap[rt][pa]), __builtin_bit_cast(ps_bf16x8, bq), acc[rt][gt], 0, 0, 0);
+                }
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rgw = make_rsrc(l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
+        const int glane = (4 * lh * H + col) * 16;
+#pragma unroll 1
+        for (int kb = 0; kb < KB; ++kb) {
+            const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh], a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const ps_f32x4 wk = buf_load_b128(rgw, glane, (8 * kb + j) * (H * 16));
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt) {
+                    acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], wk[gt], acc[0][gt], 0, 0, 0);
+                    acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], wk[gt], acc[1][gt], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const size_t row = r0 + 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (row < (size_t)R) gates[row * 4 * H + (size_t)gt * H + col] = acc[rt][gt][reg];
+            }
+}
+
 // Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
 __global__ void policy_pack_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb, float* __restrict__ Wp,
                                    int C, int Ka, int Kb)
@@ -1459,6 +1539,11 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     hipStream_t s = (hipStream_t)stream;
     const int tiles = plan_tiles(a, H, p, s);
     const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H)) * sizeof(float);
+    if (a.l_wp3) {   // the gate product as exact bf16 split products (ic3_policy.gate_split), as in ic3_policy_step
+        if (H == 128) return launch_step<128, 0, 1>(a, tiles, lds, s);
+        if (H == 64) return launch_step<64, 0, 1>(a, tiles, lds, s);
+        return launch_step<256, 0, 1>(a, tiles, lds, s);
+    }
     if (H == 128) return launch_step<128, 0>(a, tiles, lds, s);
     if (H == 64) return launch_step<64, 0>(a, tiles, lds, s);
     return launch_step<256, 0>(a, tiles, lds, s);
@@ -1640,4 +1725,32 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     }
 #endif
     return rc;
+}
+
+template <int H>
+static int launch_gate_probe(const float* xh, const float* lstm_wp, const void* lstm_wp3, float* gates, int R, hipStream_t s)
+{
+    const size_t lds = (size_t)64 * (2 * H + 4) * sizeof(float);
+    const dim3 grid((R + 63) / 64), block(2 * H);
+    if (lstm_wp3) {
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&gate_product_probe_kernel<H, 1>), lds));
+        hipLaunchKernelGGL((gate_product_probe_kernel<H, 1>), grid, block, lds, s, xh, (const ps_f32x4*)nullptr, lstm_wp3, gates, R);
+    } else {
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&gate_product_probe_kernel<H, 0>), lds));
+        hipLaunchKernelGGL((gate_product_probe_kernel<H, 0>), grid, block, lds, s, xh, reinterpret_cast<const ps_f32x4*>(lstm_wp),
+                           (const void*)nullptr, gates, R);
+    }
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_gate_product_probe(const float* xh, const float* lstm_wp, const void* lstm_wp3, float* gates, int R, int H,
+                                      ic3_stream stream)
+{
+    if (!xh || !gates || (!lstm_wp && !lstm_wp3) || R <= 0) return fail(-22, "ic3_gate_product_probe: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 128) return launch_gate_probe<128>(xh, lstm_wp, lstm_wp3, gates, R, s);
+    if (H == 64) return launch_gate_probe<64>(xh, lstm_wp, lstm_wp3, gates, R, s);
+    if (H == 256) return launch_gate_probe<256>(xh, lstm_wp, lstm_wp3, gates, R, s);
+    return fail(-38, "ic3_gate_product_probe: hid_size 64 / 128 / 256");
 }

@@ -419,6 +419,12 @@ int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H
                     float* c_wp /* H*H */, float* lstm_wp /* 4H*2H */, int H, ic3_stream stream);
 int ic3_policy_pack_split(const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */, void* lstm_wp3 /* 3 * 2H * 4H * 2 bytes */,
                           int H, ic3_stream stream);
+/* Diagnostic: the gate product of the LSTM cell ALONE — gates [R][4H] = xh [R][2H] . [W_ih | W_hh]^T, no bias — through the
+ * operand layouts, activation split and per-accumulator instruction order of ic3_policy_step's gate loops: lstm_wp3 == NULL:
+ * the fp32 matrix instruction on ic3_policy_pack's lstm_wp; lstm_wp3 != NULL: the exact bf16 split products on
+ * ic3_policy_pack_split's planes.  For measuring what the two arithmetic modes do on operands no rollout produces. */
+int ic3_gate_product_probe(const float* xh, const float* lstm_wp, const void* lstm_wp3, float* gates, int R, int H,
+                           ic3_stream stream);
 int ic3_policy_step_supported(const ic3_env* env, int H); /* 0, or the LDS bytes per workgroup */
 /* The policy half alone, for callers that bring their own encoder output (a dense observation that is not an env's
  * current state, comm.py:119 evaluated as a GEMM): enc [E*N][H] = encoder(x) + C.bias -> out [E*N][OT] as above, h / c

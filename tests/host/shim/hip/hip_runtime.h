@@ -296,6 +296,7 @@ inline long long exchange(long long v, int src)
 #define IC3_OPAQUE_SGPR(x) asm volatile("" : "+r"(x))
 #define IC3_OPAQUE_VGPR(x) asm volatile("" : "+m"(x))
 #define IC3_WAIT_VMEM() asm volatile("" ::: "memory")
+#define IC3_WAIT_VMEM_N(n) asm volatile("" ::: "memory")
 inline void __syncthreads() { ic3_host::tl_block->bar.arrive_and_wait(); }
 
 inline unsigned long long __ballot(int pred)

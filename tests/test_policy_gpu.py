@@ -20,10 +20,12 @@ def build(pc):
     return net.cuda().float()
 
 
-@pytest.mark.parametrize("fused", ["mega", "chain", False])
+@pytest.mark.parametrize("fused", ["mega", "mega-fp32", "chain", False])
 @pytest.mark.parametrize("name", POLICY_FIXTURES)
 def test_policy_matches_reference(name, fused):
-    """"mega": the no-grad rollout fast path with everything after the encoder as ONE launch (ic3_policy_forward, the
+    """"mega" / "mega-fp32": the two arithmetic modes of the gate product (the default exact bf16 split products /
+    args.gate_split = False: the fp32 matrix instruction) — both run every fixture.
+    "mega": the no-grad rollout fast path with everything after the encoder as ONE launch (ic3_policy_forward, the
     policy half of ic3_policy_step: communication block, C, LSTMCell, heads, log_softmax) where it applies (recurrent,
     H in {64,128,256}; comm_passes > 1: one launch per communication pass; the non-recurrent module: ic3_commnet_forward,
     every pass in one launch); "chain": the same path as separate launches (one [inp|h] buffer, library GEMMs,
@@ -32,6 +34,9 @@ def test_policy_matches_reference(name, fused):
     fx = pc.fx
     net = build(pc)
     net.args.fused_policy = bool(fused)
+    net.args.gate_split = fused != "mega-fp32"
+    if fused == "mega-fp32":
+        fused = "mega"
     net.args.mega_policy = (fused == "mega")
     if fused == "mega":
         from ic3net_amd import ops

@@ -55,17 +55,17 @@ def make_env(kind, kw, E, seed, offset):
 
 
 @pytest.mark.parametrize("kind,kw,H,hard_attn,E,T", CASES)
-@pytest.mark.parametrize("comm_mode", ["avg", "sum", "avg-2passes", "avg-split"])
+@pytest.mark.parametrize("comm_mode", ["avg", "sum", "avg-2passes", "avg-fp32", "sum-fp32", "avg-2passes-fp32"])
 def test_policy_step_equals_the_launch_chain(kind, kw, H, hard_attn, E, T, comm_mode):
     """("avg-2passes": comm_passes = 2 — the one-launch kernel once per communication pass against the generic
-    forward() of the same module, which is pinned to the reference by the multi-pass policy fixtures.)"""
+    forward() of the same module, which is pinned to the reference by the multi-pass policy fixtures.  "-fp32": the gate
+    product on the fp32 matrix instruction (args.gate_split = False) instead of the default exact bf16 split products —
+    both arithmetic modes run every shape at the same tolerances.)"""
     from ic3net_amd import ops
     from ic3net_amd.comm import CommNetMLP
-    passes, split = 1, False
-    if comm_mode == "avg-split":      # EXPERIMENT (gate_split): exact bf16 split products in the gate GEMM, same tolerances
-        if not ((kind == "pp" and kw['N'] in (10, 32, 5, 64)) or (kind == "tj" and kw['N'] in (10, 20) and E < 100)):
-            pytest.skip("gate_split is covered on six shapes (hid 64 / 128 / 256, half tiles)")
-        comm_mode, split = "avg", True
+    passes, split = 1, True
+    if comm_mode.endswith("-fp32"):
+        comm_mode, split = comm_mode[:-5], False
     if comm_mode == "avg-2passes":
         if not ((kind == "pp" and kw['N'] in (10, 32) and E < 100) or (kind == "tj" and kw['N'] == 10)):
             pytest.skip("comm_passes = 2 is covered on three shapes")

@@ -30,14 +30,14 @@ def _oracle_env(a, seed, gid):
                            a.curr_end, seed=seed, env_gid=gid, vocab_type=a.vocab_type)
 
 
-def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True, gate_split=False):
+def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True, gate_split=True):
     """Plays T lock-step iterations through Trainer.step_episode (the one-launch path) and replays the envs in
     `check_envs` through the fp64 policy + the oracle env on the kernel's actions.  Returns the worst policy error."""
     import bench
     from oracle import policy_ref
     tr, a = bench.build_trainer(workload, E, seed, offset, 0)
     a.max_steps = T
-    a.gate_split = gate_split        # EXPERIMENT (DESIGN.md section 10): exact bf16 split products in the gate GEMM
+    a.gate_split = gate_split        # True (the default): exact bf16 split products in the gate GEMM; False: fp32 MFMA
     tr.begin_episode(0)
     raw = tr.env.env
     N, H = a.nagents, a.hid_size
@@ -88,26 +88,23 @@ def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True, gate_spl
     return worst
 
 
+@pytest.mark.parametrize("gate_split", [True, False], ids=["bf16x9", "fp32"])
 @pytest.mark.parametrize("workload,E,T", [("pp_hard", 13, 80), ("tj_hard", 7, 80), ("tj_medium", 13, 40),
                                           ("pp_scaled", 3, 20)])
-def test_policy_step_full_episode_vs_fp64_reference_policy(workload, E, T):
-    worst = _free_run(workload, E, T, seed=5, offset=300, check_envs=list(range(E)))
+def test_policy_step_full_episode_vs_fp64_reference_policy(workload, E, T, gate_split):
+    """Both arithmetic modes of the gate product — the default (nine exact bf16 x bf16 products per fp32 product, fp32
+    accumulation) and the fp32 matrix instruction — against the same fp64 policy + oracle env at the same 1e-5: hid 128
+    and 256, full episodes."""
+    worst = _free_run(workload, E, T, seed=5, offset=300, check_envs=list(range(E)), gate_split=gate_split)
     assert worst < TOL, worst
 
 
-@pytest.mark.parametrize("workload,E,T", [("pp_hard", 13, 80), ("tj_hard", 7, 80), ("pp_scaled", 3, 20)])
-def test_gate_split_experiment_full_episode_vs_fp64_reference_policy(workload, E, T):
-    """The opt-in gate_split mode (nine exact bf16 x bf16 products per fp32 product, fp32 accumulation) against the same
-    fp64 policy + oracle env at the same 1e-5: hid 128 and 256, full episodes."""
-    worst = _free_run(workload, E, T, seed=5, offset=300, check_envs=list(range(E)), gate_split=True)
-    assert worst < TOL, worst
-
-
-def test_policy_step_at_benchmark_size_pp_hard():
+@pytest.mark.parametrize("gate_split", [True, False], ids=["bf16x9", "fp32"])
+def test_policy_step_at_benchmark_size_pp_hard(gate_split):
     """E = 8192 through the auto-selected tile plan (1280 full tiles of 6 envs + 171 half tiles of 3): envs of the first
     full tile, the last full tile, the first / a middle / the last half tile."""
     envs = [0, 5, 7674, 7679, 7680, 7682, 7935, 8189, 8191]
-    worst = _free_run("pp_hard", 8192, 3, seed=9, offset=0, check_envs=envs)
+    worst = _free_run("pp_hard", 8192, 3, seed=9, offset=0, check_envs=envs, gate_split=gate_split)
     assert worst < TOL, worst
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Round-4 experiment: what the policy launch costs in its obs modes, with and without a fill launch beside it.
    python tools/exp/prefill_probe.py MODE [workload] [gate_split]
-MODE: noobs | fused | patch_nofill (rows marked prefilled by ic3_obs_set_prefilled, NO fill launch at all) |
+MODE: noobs | fused | patch_longfill (patch_nofill + ONE slow fill launch of a third buffer beside each episode) | patch_nofill (rows marked prefilled by ic3_obs_set_prefilled, NO fill launch at all) |
       patch_fill (ic3_obs_prefill of the other buffer on a second stream beside every launch; IC3_FILL_* pace it)
 Prints the median / min launch time of ic3_policy_step (dispatch-stamped events) and the wall time per step."""
 import os
@@ -37,12 +37,17 @@ for ep in range(3):
     if ep == 1:
         torch.cuda.synchronize()
         wall0 = time.perf_counter()
+    if mode == 'patch_longfill':              # ONE slow fill launch (IC3_FILL_NAP large) running beside the whole episode
+        side.wait_stream(main)
+        third = torch.empty_like(pair[0]) if ep == 0 else third
+        raw.prefill(third, side)
     for t in range(T):
         e0, e1 = DispatchEvent(), DispatchEvent()
         raw.set_step_events(e0, e1)
-        if mode in ('patch_nofill', 'patch_fill'):
+        if mode in ('patch_nofill', 'patch_fill', 'patch_longfill'):
             raw._obs = pair[t & 1]
-            if mode == 'patch_nofill':
+            tr._state = raw._obs
+            if mode in ('patch_nofill', 'patch_longfill'):
                 raw.mark_prefilled(raw._obs)
             else:
                 side.wait_stream(main)

@@ -34,7 +34,7 @@ bench)
   timeout 600 python bench.py "$@" > $O/$N.json 2> $O/$N.err; summ $O/$N.json $N ;;
 matrix)
   WL=$1; shift; [ "$1" == "--" ] && shift
-  timeout 300 python bench.py --no-cpu-baseline --steps 40 > /dev/null 2>&1    # warm the box
+  [ -z "$NOWARM" ] && timeout 300 python bench.py --no-cpu-baseline --steps 40 > /dev/null 2>&1    # warm the box
   for rep in $(seq 1 ${REPS:-1}); do for w in $WL; do i=0; for A in "$@"; do i=$((i+1))
     n=${w}_a${i}_r${rep}
     timeout 300 env $ENVPRE python bench.py --no-cpu-baseline --workload $w $A > $O/$n.json 2> $O/$n.err
