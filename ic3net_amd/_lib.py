@@ -111,6 +111,10 @@ EXPORTS = {
                             [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "ic3_lstm_gates_backward_supported": (C.c_int, [C.c_int]),
     "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_heads_grad_scratch_floats": (C.c_size_t, [C.c_int]),
+    "ic3_heads_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "ic3_env_set_hidden_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_lstm_cell_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_policy_heads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

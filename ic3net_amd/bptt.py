@@ -43,19 +43,30 @@ class EpisodeRecord(object):
     step, the masks of the communication block."""
 
     def __init__(self, T, R, H, state_words, device):
-        self.hs = torch.empty((T, R, H), dtype=torch.float32, device=device)
-        self.cs = torch.empty((T, R, H), dtype=torch.float32, device=device)
+        self.hs = torch.empty((T + 1, R, H), dtype=torch.float32, device=device)     # slot t: h entering step t; slot T: h_T
+        self.cs = torch.empty((T + 1, R, H), dtype=torch.float32, device=device)
         self.snaps = torch.empty((T, state_words), dtype=torch.int32, device=device)
         self.alive = [None] * T
         self.gate = [None] * T
         self.h_last = None
         self.n = 0
 
+    def start(self):
+        """Zero state of step 0, held in the record itself: a rollout that reads (h, c) from slot t and lets the step launch
+        write slot t + 1 (ic3_env_set_hidden_out) records the recurrent state without a single copy."""
+        self.hs[0].zero_()
+        self.cs[0].zero_()
+        return (self.hs[0], self.cs[0])
+
+    def slot(self, t):
+        return (self.hs[t], self.cs[t])
+
     def record(self, t, net, raw, prev_hid, info):
         h, c = prev_hid
         R, H = self.hs.shape[1:]
-        self.hs[t].copy_(h.detach().reshape(R, H))
-        self.cs[t].copy_(c.detach().reshape(R, H))
+        if h.data_ptr() != self.hs[t].data_ptr():              # (in-place rollouts hand slot t itself)
+            self.hs[t].copy_(h.detach().reshape(R, H))
+            self.cs[t].copy_(c.detach().reshape(R, H))
         raw.snapshot(out=self.snaps[t])
         E = R // net.nagents
         self.alive[t] = net._mask(info, 'alive_mask', E, self.hs.device)
@@ -63,7 +74,11 @@ class EpisodeRecord(object):
         self.n = t + 1
 
     def finish(self, prev_hid):
-        self.h_last = prev_hid[0].detach().reshape(self.hs.shape[1:]).clone()
+        h = prev_hid[0]
+        if self.n < self.hs.shape[0] and h.data_ptr() == self.hs[self.n].data_ptr():
+            self.h_last = self.hs[self.n]
+        else:
+            self.h_last = h.detach().reshape(self.hs.shape[1:]).clone()
 
 
 def loss_gradients(args, batch):
@@ -151,7 +166,7 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     # the weight gradient dgates^T . [inp | h] has K = R: as NB products over row blocks (batched, then summed) the
     # library fills the chip (tools/exp/microbench_bptt_gemms.py: 118 instead of 83 TFLOP/s at R = 81920)
     NB = 8 if R % 8 == 0 and R >= 8192 else 1
-    wpart = z(NB, 2 * H, 4 * H) if NB > 1 else None
+    wpart = torch.zeros((NB, 2 * H, 4 * H), dtype=torch.float32, device=dev) if NB > 1 else None
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
@@ -175,20 +190,20 @@ def backward_episode(args, net, raw, rec, d_out, acc):
             torch.addmm(fc['b_cat'], xh, w_cat_t, out=gates)              # one K = 2H product, as in the rollout
         # ---- heads (comm.py:228,239) -> LSTM cell
         d = d_out[t]
-        torch.addmm(dh_rec, d, fc['w_heads'], out=dh)
-        acc['w_heads'].addmm_(d.t(), h_t)
-        acc['b_heads'].add_(d.sum(0))
+        torch.addmm(dh_rec, d, fc['w_heads'], out=dh)                     # dL/dh_t = what step t + 1 sent back + the heads' share
         if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
+            # (the heads' own weight gradient is one pass over the whole episode behind the loop: ic3_heads_grad)
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
                                     h_prev=h_prev, lstm_wp3=fc.get('ps_l_wp3'))
         else:
+            acc['w_heads'].addmm_(d.t(), h_t)
+            acc['b_heads'].add_(d.sum(0))
             parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)
             torch.sum(parts, 0, out=bsum)
             acc['b_cat'].add_(bsum)
         # ---- [W_ih | W_hh] (torch.nn.LSTMCell): weight gradient and input gradient, one product each
-        if NB > 1:                                                        # acc_t (2H, 4H) += sum_b xh_b^T . dgates_b
-            torch.bmm(xh.view(NB, R // NB, 2 * H).transpose(1, 2), dgates.view(NB, R // NB, 4 * H), out=wpart)
-            acc['w_cat_t'].add_(wpart.sum(0))
+        if NB > 1:                            # wpart_b (2H, 4H) += xh_b^T . dgates_b; the NB partials are summed behind the loop
+            wpart.baddbmm_(xh.view(NB, R // NB, 2 * H).transpose(1, 2), dgates.view(NB, R // NB, 4 * H))
         else:
             acc['w_cat_t'].addmm_(xh.t(), dgates)                         # (2H, R) x (R, 4H)
         torch.mm(dgates, w_cat_t.t(), out=dxh)                            # (R, 4H) x (4H, 2H) -> [d inp | d h_{t-1}]
@@ -203,8 +218,19 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         dwt, db = raw.encode_backward(dinp, rec.snaps[t], want_bias=True)    # db = sum of the d inp rows: both biases
         acc['wt'].add_(dwt)
         acc['enc_bias'].add_(db)
+    if NB > 1:
+        acc['w_cat_t'].add_(wpart.sum(0))
     if fused_gates:
         acc['b_cat'].add_(bias_parts.sum(0))
+        # heads + value head: dW += sum_t d_t^T h_t, db += sum_t sum_rows d_t — h_t of step t is the state ENTERING step t + 1
+        if rec.h_last is not None and rec.h_last.data_ptr() == rec.hs[T].data_ptr():
+            ops.heads_grad(d_out[:T].reshape(T * R, -1), rec.hs[1:T + 1].reshape(T * R, H), acc['w_heads'], acc['b_heads'],
+                           acc.setdefault('_work', {}))
+        else:
+            if T > 1:
+                ops.heads_grad(d_out[:T - 1].reshape((T - 1) * R, -1), rec.hs[1:T].reshape((T - 1) * R, H), acc['w_heads'],
+                               acc['b_heads'], acc.setdefault('_work', {}))
+            ops.heads_grad(d_out[T - 1], rec.h_last, acc['w_heads'], acc['b_heads'], acc.setdefault('_work', {}))
 
 
 def _backward_episode_multipass(args, net, raw, rec, d_out, acc):

@@ -405,7 +405,7 @@ class CommNetMLP(nn.Module):
         mb['c'].zero_()
         return (mb['h'], mb['c'])
 
-    def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None):
+    def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, hidden_out=None):
         """action_out, value, (h, c) = forward(x, info); `action` (heads, E, N) int32 <- select_action (Philox draws
         positioned by the env's own counters); env.step(action[0]) -> reward (E,N) f32, done (E,) i32, alive /
         is_completed (E,N) i32.  trainer.py:49-67 in one launch.  `obs` (E,N,obs_dim), when given, receives the dense
@@ -422,10 +422,18 @@ class CommNetMLP(nn.Module):
             mb = self._mb = dict(h=torch.empty((R, H), dtype=torch.float32, device=dev),
                                  c=torch.empty((R, H), dtype=torch.float32, device=dev))
         h, c = mb['h'], mb['c']
-        if hidden_state.data_ptr() != h.data_ptr():            # fresh hidden state from the caller (t = 0)
-            h.copy_(hidden_state.detach().reshape(R, H))
-        if cell_state.data_ptr() != c.data_ptr():
-            c.copy_(cell_state.detach().reshape(R, H))
+        if hidden_out is not None and self.comm_passes == 1:
+            # the caller keeps the state ENTERING every step (the update half's episode record): read it where it is, write
+            # h', c' into the next slot (ic3_env_set_hidden_out) — no copies
+            h, c = hidden_state, cell_state
+            assert h.is_contiguous() and c.is_contiguous() and tuple(h.shape) == (R, H) and h.dtype == torch.float32
+            env.set_hidden_out(hidden_out[0], hidden_out[1])
+        else:
+            hidden_out = None
+            if hidden_state.data_ptr() != h.data_ptr():        # fresh hidden state from the caller (t = 0)
+                h.copy_(hidden_state.detach().reshape(R, H))
+            if cell_state.data_ptr() != c.data_ptr():
+                c.copy_(cell_state.detach().reshape(R, H))
         alive_in = self._mask(info, 'alive_mask', batch, dev)
         comm_in = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
         mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
@@ -438,7 +446,7 @@ class CommNetMLP(nn.Module):
         ops.policy_step(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, out, action, reward, done, alive,
                         is_completed, obs, pass_index=self.comm_passes - 1)
         self.mega_steps = getattr(self, 'mega_steps', 0) + 1
-        return self._split_out(out, batch, n) + ((h, c),)
+        return self._split_out(out, batch, n) + ((h, c) if hidden_out is None else tuple(hidden_out),)
 
     def _encode(self, x):
         """self.encoder(x) (comm.py:51,119); during no-grad rollouts optionally via the env's sparse gather."""

@@ -5,6 +5,8 @@
 #include <type_traits>
 
 #include "env_device.hpp"
+#include <algorithm>
+
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -573,6 +575,122 @@ extern "C" int ic3_random_actions(int32_t* action, int naction, uint32_t seed, u
     const int rows = E * N;
     hipLaunchKernelGGL(ic3::random_actions_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, action,
                        naction, seed, env_id_offset, episode, t, E, N);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+
+namespace ic3 {
+
+// ---- ic3_heads_grad: the weight / bias gradient of the heads + value head over a WHOLE episode in one pass ------------------
+// (trainer.py:128-225 through comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o], m over all
+// M = T * R (step, row) pairs.  Per step this was a K = R library GEMM with an 8 x 128 result (+ two reduction launches);
+// as ONE product its K = 6.5 M (PP-hard) is a shape the library tunes for minutes.  HBM-bound: every h row is read once
+// (M * H * 4 bytes: 3.4 GB per PP-hard update = 0.6 ms).  A workgroup of H threads... 256 threads walk a contiguous range of
+// rows: thread (c, half) keeps OT partial sums of column c for the rows of its half; the d rows of 64 rows go through
+// LDS (broadcast reads).  Partials [grid][OT][H] are reduced by a second small launch in a fixed order (reproducible).
+constexpr int HG_ROWS = 64;
+template <int H>
+__global__ __launch_bounds__(256) void heads_grad_kernel(const float* __restrict__ d, const float* __restrict__ h, long long M, int OT,
+                                                         float* __restrict__ partial /* [grid][17][H] */)
+{
+    constexpr int HALVES = 256 / H;                              // row lanes per workgroup (H = 64: 4, 128: 2, 256: 1)
+    __shared__ float sd[HG_ROWS * 16];
+    const int c = threadIdx.x % H, half = threadIdx.x / H;
+    float acc[16], bsum[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = bsum[o] = 0.0f;
+    const long long per = (M + gridDim.x - 1) / gridDim.x;
+    const long long m0 = (long long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+    for (long long base = m0; base < m1; base += HG_ROWS) {
+        const int n = (int)((m1 - base) < HG_ROWS ? (m1 - base) : HG_ROWS);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < HG_ROWS * 16; idx += 256) {
+            const int row = idx >> 4, o = idx & 15;
+            sd[idx] = (row < n && o < OT) ? d[(base + row) * OT + o] : 0.0f;
+        }
+        __syncthreads();
+        for (int row = half; row < n; row += HALVES) {
+            const float hv = h[(base + row) * H + c];
+            const f32x4* dr = reinterpret_cast<const f32x4*>(sd + row * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 d4 = dr[q];
+                acc[4 * q] += d4[0] * hv;
+                acc[4 * q + 1] += d4[1] * hv;
+                acc[4 * q + 2] += d4[2] * hv;
+                acc[4 * q + 3] += d4[3] * hv;
+                if (c == 0) {
+                    bsum[4 * q] += d4[0];
+                    bsum[4 * q + 1] += d4[1];
+                    bsum[4 * q + 2] += d4[2];
+                    bsum[4 * q + 3] += d4[3];
+                }
+            }
+        }
+    }
+    // fold the row lanes of the workgroup (fixed order), one partial per workgroup
+    __shared__ float fold[256][17];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 16; ++o) fold[threadIdx.x][o] = acc[o];
+    __syncthreads();
+    if (half == 0) {
+        float* out = partial + (size_t)blockIdx.x * 17 * H;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float v = fold[c][o];
+            for (int q = 1; q < HALVES; ++q) v += fold[q * H + c][o];
+            out[o * H + c] = v;
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) fold[half][o] = bsum[o];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float v = 0.0f;
+        for (int q = 0; q < HALVES; ++q) v += fold[q][threadIdx.x];
+        partial[(size_t)blockIdx.x * 17 * H + 16 * H + threadIdx.x] = v;
+    }
+}
+
+__global__ void heads_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int H, int OT, float* __restrict__ dW,
+                                         float* __restrict__ db)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < OT * H) {
+        float v = 0.0f;
+        for (int p = 0; p < nparts; ++p) v += partial[(size_t)p * 17 * H + i];
+        dW[i] += v;
+    } else if (i < OT * H + OT) {
+        const int o = i - OT * H;
+        float v = 0.0f;
+        for (int p = 0; p < nparts; ++p) v += partial[(size_t)p * 17 * H + 16 * H + o];
+        db[o] += v;
+    }
+}
+
+}  // namespace ic3
+
+extern "C" size_t ic3_heads_grad_scratch_floats(int H) { return (size_t)1024 * 17 * (size_t)H; }
+
+extern "C" int ic3_heads_grad(const float* d, const float* h, long long M, int H, int OT, float* dW, float* db, float* scratch,
+                              ic3_stream stream)
+{
+    using namespace ic3;
+    if (!d || !h || !dW || !db || !scratch || M <= 0 || OT < 1 || OT > 16) return fail(-22, "ic3_heads_grad: bad arguments");
+    if (H != 64 && H != 128 && H != 256) return fail(-38, "ic3_heads_grad: hid_size 64 / 128 / 256");
+    hipStream_t s = (hipStream_t)stream;
+    int grid = (int)std::min<long long>(1024, (M + HG_ROWS - 1) / HG_ROWS);
+    if (H == 64) hipLaunchKernelGGL((heads_grad_kernel<64>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
+    else if (H == 128) hipLaunchKernelGGL((heads_grad_kernel<128>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
+    else hipLaunchKernelGGL((heads_grad_kernel<256>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
+    IC3_HIP(hipGetLastError());
+    const int n = OT * H + OT;
+    hipLaunchKernelGGL(heads_grad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, grid, H, OT, dW, db);
     IC3_HIP(hipGetLastError());
     return 0;
 }

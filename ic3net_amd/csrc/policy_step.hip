@@ -131,8 +131,10 @@ struct StepArgs {
     int z0, z3, zc;             // stores behind the loads of S0; behind the request of the old cell state; K blocks of the C product with a slot
     int zrest;                  // stores per wave issued behind the cell epilogue (what the other slots left)
     // recurrent state, masks, outputs
-    float* h;                   // [R][H] in place
-    float* c;                   // [R][H] in place
+    float* h;                   // [R][H] read ...
+    float* c;                   // [R][H]
+    float* h_out;               // ... and written here (= h, c unless ic3_env_set_hidden_out)
+    float* c_out;
     const int32_t* alive_in;    // [R] or null (t = 0: everyone alive, quirk Q21)
     const int32_t* comm_in;     // [R] or null (gate sampled at t-1, quirk Q22)
     float* out;                 // [R][OT] log-probs | value
@@ -872,8 +874,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             // of a 64-bit address pair each, and the hardware range check (num_records = the tile's valid rows) stands
             // in for the `row < rows` predicates — an out-of-range store is dropped.
             const uint32_t nrec = (ABL & 16) ? 0u : (uint32_t)rows * H * 4u;
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c + r0 * H), 0, nrec, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h + r0 * H), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c_out + r0 * H), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h_out + r0 * H), 0, nrec, 0x00020000);
             const int voff = (4 * lh * H + col) * 4;
             const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
             // (cold[]: requested in front of the C product; every load this wave issued after them has been waited for
@@ -1354,8 +1356,8 @@ static double time_tile_mix(const ic3_policy* p, int N, int n_full, int n_half, 
     a.G = 1;
     const size_t R = (size_t)a.E * N;
     a.enc_in = scratch;
-    a.h = scratch + R * H;
-    a.c = scratch + 2 * R * H;
+    a.h = a.h_out = scratch + R * H;
+    a.c = a.c_out = scratch + 2 * R * H;
     a.out = scratch + 3 * R * H;
     const size_t lds = ((size_t)64 * (2 * H + 4) + ps_lds_small(H)) * sizeof(float);
     double best = 1e30;
@@ -1527,8 +1529,8 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     int rc = fill_policy(a, p, "ic3_policy_forward");
     if (rc) return rc;
     a.enc_in = enc;
-    a.h = h;
-    a.c = c;
+    a.h = a.h_out = h;
+    a.c = a.c_out = c;
     a.alive_in = alive_in;
     a.comm_in = comm_in;
     a.out = out;
@@ -1575,8 +1577,13 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     StepArgs a{};
     int frc = fill_policy(a, p, "ic3_policy_step");
     if (frc) return frc;
-    a.h = h;
-    a.c = c;
+    a.h = a.h_out = h;
+    a.c = a.c_out = c;
+    if (!inner && env->h_out && env->c_out) {                    // one-shot (ic3_env_set_hidden_out): the step's LAST launch
+        a.h_out = env->h_out;
+        a.c_out = env->c_out;
+    }
+    if (!inner) env->h_out = env->c_out = nullptr;
     a.alive_in = alive_in;
     a.comm_in = comm_in;
     a.out = out;
@@ -1753,4 +1760,12 @@ extern "C" int ic3_gate_product_probe(const float* xh, const float* lstm_wp, con
     if (H == 64) return launch_gate_probe<64>(xh, lstm_wp, lstm_wp3, gates, R, s);
     if (H == 256) return launch_gate_probe<256>(xh, lstm_wp, lstm_wp3, gates, R, s);
     return fail(-38, "ic3_gate_product_probe: hid_size 64 / 128 / 256");
+}
+
+extern "C" int ic3_env_set_hidden_out(ic3_env* env, float* h_out, float* c_out)
+{
+    if (!env || (h_out == nullptr) != (c_out == nullptr)) return fail(-22, "ic3_env_set_hidden_out: h_out and c_out come together");
+    env->h_out = h_out;
+    env->c_out = c_out;
+    return 0;
 }

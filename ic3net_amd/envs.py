@@ -254,6 +254,10 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_set_auto_reset(self._h, int(max_steps)))
         self.auto_max_steps = int(max_steps)
 
+    def set_hidden_out(self, h_out, c_out):
+        """One-shot (ic3_env_set_hidden_out): the next ic3_policy_step writes h', c' there instead of in place."""
+        check(_lib.lib().ic3_env_set_hidden_out(self._h, ptr(h_out), ptr(c_out)))
+
     def set_step_events(self, start, stop):
         """Arm the next ic3_policy_step launch on this handle: the dispatch stamps `start` / `stop` (DispatchEvent)."""
         check(_lib.lib().ic3_env_set_step_events(self._h, start.handle, stop.handle))

@@ -164,7 +164,7 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
     if h_prev is not None:
         assert h_prev.is_contiguous() and h_prev.dtype == torch.float32 and tuple(h_prev.shape) == (R, H)
     n = _lib.lib().ic3_lstm_gates_backward(ptr(xh), xh.stride(0), ptr(h_prev) if h_prev is not None else None, ptr(lstm_wp),
-                                           ptr(lstm_wp3) if lstm_wp3 is not None else None,   # EXPERIMENT gate_split
+                                           ptr(lstm_wp3) if lstm_wp3 is not None else None,   # split gate product
                                            ptr(bias), ptr(c_prev), ptr(dh),
                                            ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
                                            ptr(dbias_partials) if dbias_partials is not None else None,
@@ -172,6 +172,21 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
     if n < 0:
         check(n)
     return n
+
+
+def heads_grad(d, h, dW, db, work=None):
+    """dW (OT,H) += d^T . h, db (OT,) += column sums of d over all M rows of d (M,OT) / h (M,H) — ic3_heads_grad: the heads'
+    weight gradient of a whole episode in one pass."""
+    _need_cuda(d, "heads_grad")
+    M, OT = d.shape
+    H = h.shape[1]
+    assert d.is_contiguous() and h.is_contiguous() and h.shape[0] == M and d.dtype == h.dtype == torch.float32
+    assert dW.is_contiguous() and tuple(dW.shape) == (OT, H) and db.is_contiguous() and db.numel() == OT
+    work = work if work is not None else dict()
+    key = ('heads_grad', H, str(d.device))
+    if key not in work:
+        work[key] = torch.empty((int(_lib.lib().ic3_heads_grad_scratch_floats(H)),), dtype=torch.float32, device=d.device)
+    check(_lib.lib().ic3_heads_grad(ptr(d), ptr(h), M, H, OT, ptr(dW), ptr(db), ptr(work[key]), stream()))
 
 
 def policy_heads(h, W, b, head_sizes, out=None):

@@ -145,6 +145,12 @@ class Trainer(object):
                 self._graphs.clear()
                 self._episodes_played = min(self._episodes_played, 1)   # next episode re-captures
 
+    def _rec_inplace(self):
+        """The recorded rollout of a native update reads / writes (h, c) in the episode record (no copies) when every
+        step of the episode goes through ic3_policy_step with ONE communication pass."""
+        raw = getattr(self.env, 'env', None)
+        return raw is not None and self._mega_expected(raw) and getattr(self.policy_net, 'comm_passes', 1) == 1
+
     def _mega_expected(self, raw):
         """Will step_episode go through ic3_policy_step?  (no autograd, default sampling, a policy that supports the
         env: the same conditions _step_body tests, evaluated before the episode starts)"""
@@ -165,7 +171,8 @@ class Trainer(object):
 
     def _use_graph(self):
         a = self.args
-        return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
+        return bool(getattr(a, 'hip_graph', False)) and not getattr(self, '_graph_broken', False) \
+            and not getattr(a, 'store_states', False) \
             and not getattr(a, 'rollout_grad', False) and self._records is None and self.clock.env is not None \
             and not getattr(self, '_should_display', False) \
             and getattr(self.clock.env, 'step_timer', None) is None      # event-timed launches stay eager
@@ -192,6 +199,25 @@ class Trainer(object):
             try:
                 with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                     self._step_body(t, observe=in_graph_obs)
+            except Exception as exc:
+                # A capture the runtime invalidated (seen once per long test session on ROCm 7.2: "operation failed due
+                # to a previous error during capture" at an arbitrary step): nothing of the step has executed.  Graphs are
+                # a launch-overhead optimisation only — restore the step's inputs, play this and all later steps eagerly
+                # (same results), and say so.
+                import warnings
+                raw.obs_timer = timer
+                torch.cuda.synchronize()
+                self._state, self._info, self._prev_hid = saved
+                self._pf_ready = pf_before
+                self._graphs.clear()
+                self._graph_broken = True
+                st = torch.cuda.memory_stats()
+                warnings.warn("hipGraph capture of rollout step %d failed (%s: %s); continuing with eager launches "
+                              "[reserved %.2f GB, allocated %.2f GB]"
+                              % (t, type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '',
+                                 st.get('reserved_bytes.all.current', 0) / 2 ** 30,
+                                 st.get('allocated_bytes.all.current', 0) / 2 ** 30))
+                return self.step_episode(t)
             finally:
                 raw.obs_timer = timer
             self._graph_gen = getattr(self.policy_net, 'cache_generation', 0)
@@ -238,7 +264,10 @@ class Trainer(object):
                 state = state.clone()          # the env reuses its obs buffer; autograd keeps the encoder input
             if args.recurrent:                                     # trainer.py:49-60
                 if args.rnn_type == 'LSTM' and t == 0:
-                    if getattr(self, '_mega_prev', False) and not torch.is_grad_enabled() \
+                    if self._rec is not None and not torch.is_grad_enabled() and self._rec_inplace():
+                        # native update on the one-launch path: the episode record itself holds the recurrent state
+                        self._prev_hid = self._rec.start()
+                    elif getattr(self, '_mega_prev', False) and not torch.is_grad_enabled() \
                             and hasattr(self.policy_net, 'zero_hidden'):
                         # the previous step went through the one-launch path: hand it its own buffers, zeroed
                         self._prev_hid = self.policy_net.zero_hidden(state.shape[0], state.device)
@@ -338,9 +367,13 @@ class Trainer(object):
             if ft is not None:
                 f1.record(side)
                 ft.append((f0, f1, t))
+        rec_out = None
+        if self._rec is not None and self._prev_hid[0].data_ptr() == self._rec.hs[t].data_ptr():
+            rec_out = self._rec.slot(t + 1)                        # the launch writes the next slot of the episode record
         action_out, value, prev_hid = self.policy_net.step_env(
             raw, [state, self._prev_hid], info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
-            alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None)
+            alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None,
+            hidden_out=rec_out)
         if prefill:
             main.wait_stream(side)
             self._pf_ready = (t + 1) & 1

@@ -298,11 +298,18 @@ int ic3_lstm_cell_backward(const float* gates, const float* c_prev, const float*
  * needs one reduction at its end).  Returns the number of partial rows, negative errno on error (-38: unsupported H). */
 int ic3_lstm_gates_backward_supported(int H);
 int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev /* or NULL */, const float* lstm_wp,
-                            const void* lstm_wp3 /* NULL, or ic3_policy_pack_split's planes: the gate_split EXPERIMENT */,
+                            const void* lstm_wp3 /* NULL (fp32 instruction), or ic3_policy_pack_split's planes (exact bf16 split products) */,
                             const float* bias,
                             const float* c_prev,
                             const float* dh, const float* dc /* or NULL */, float* dgates, float* dc_prev,
                             float* dbias_partials /* or NULL */, int accumulate, int R, int H, ic3_stream stream);
+/* The weight / bias gradient of the heads + value head over a whole episode in one pass (trainer.py:128-225 through
+ * comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o] over the M = steps x rows pairs
+ * (d [M][OT], h [M][H]: h_t of every step, i.e. the recorded hidden states shifted by one step).  scratch:
+ * ic3_heads_grad_scratch_floats(H) floats.  Fixed-order reduction (reproducible).  hid_size 64 / 128 / 256. */
+size_t ic3_heads_grad_scratch_floats(int H);
+int ic3_heads_grad(const float* d, const float* h, long long M, int H, int OT, float* dW, float* db, float* scratch,
+                   ic3_stream stream);
 
 /* Action heads + value head + log_softmax (comm.py:228,239) in one pass: out[r][:] =
  * [log_softmax(W_0 h_r + b_0) | ... | log_softmax(W_{k-1} h_r + b_{k-1}) | w_v h_r + b_v], OT = sum A_k + 1 <= 16.
@@ -391,10 +398,11 @@ typedef struct {
      * the previous episode's.  Both 0: the one-pass policy of the BASELINE configs. */
     int32_t pass_index;
     int32_t inner_pass;
-    /* EXPERIMENT, off by default: gate_split != 0 with lstm_wp3 = ic3_policy_pack_split's buffer
-     * runs the gate product of ic3_policy_step with every fp32 operand split exactly into three bf16 terms and all nine
-     * cross products on the bf16 matrix cores (products exact in fp32, fp32 accumulation; results differ from the fp32
-     * path by summation order only).  Ignored by ic3_policy_forward. */
+    /* gate_split != 0 with lstm_wp3 = ic3_policy_pack_split's buffer: the gate product [inp | h] . [W_ih | W_hh]^T with every
+     * fp32 operand split EXACTLY into three bf16 terms and all nine cross products on the bf16 matrix cores (each product
+     * exact in fp32, fp32 accumulation: fp32-class arithmetic — measured error against fp64 = the fp32 matrix instruction's,
+     * DESIGN.md section 0; what ic3net_amd passes by default).  0: the fp32 matrix instruction.  Honoured by ic3_policy_step
+     * and ic3_policy_forward. */
     int32_t gate_split;
     int32_t reserved_;
     const void* lstm_wp3;
@@ -425,6 +433,11 @@ int ic3_policy_pack_split(const float* w_ih /* [4H][H] */, const float* w_hh /* 
  * ic3_policy_pack_split's planes.  For measuring what the two arithmetic modes do on operands no rollout produces. */
 int ic3_gate_product_probe(const float* xh, const float* lstm_wp, const void* lstm_wp3, float* gates, int R, int H,
                            ic3_stream stream);
+/* One-shot: the NEXT ic3_policy_step on this handle (its final communication pass) reads the LSTM state from its h / c
+ * arguments as always but writes the new state to h_out / c_out [E*N][H] instead of updating h / c in place — a caller that
+ * keeps the state ENTERING every step of an episode (the update half, trainer.py:128-225: backward through time over
+ * recorded (h, c)) lets the launch write slot t + 1 of its record directly instead of copying 2 x E*N*H floats per step. */
+int ic3_env_set_hidden_out(ic3_env* env, float* h_out, float* c_out);
 int ic3_policy_step_supported(const ic3_env* env, int H); /* 0, or the LDS bytes per workgroup */
 /* The policy half alone, for callers that bring their own encoder output (a dense observation that is not an env's
  * current state, comm.py:119 evaluated as a GEMM): enc [E*N][H] = encoder(x) + C.bias -> out [E*N][OT] as above, h / c

@@ -70,6 +70,25 @@ def test_gates_backward_matches_autograd(H, R, pad):
     assert float((dgates - dg2).abs().max()) <= 2e-5 * max(1.0, float(dg2.abs().max()))
 
 
+@pytest.mark.parametrize("H,M,OT", [(128, 5000, 8), (64, 333, 3), (256, 70000, 16), (128, 64 * 1024 * 3 + 17, 5)])
+def test_heads_grad_over_an_episode(H, M, OT):
+    """ic3_heads_grad: dW += d^T h, db += column sums of d over all (step, row) pairs, against a float64 product."""
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(H + M)
+    d = torch.randn(M, OT, device='cuda', generator=gen)
+    h = torch.randn(M, H, device='cuda', generator=gen)
+    dW = torch.ones((OT, H), device='cuda')                      # (accumulates on top of what is there)
+    db = torch.full((OT,), 2.0, device='cuda')
+    ops.heads_grad(d, h, dW, db)
+    refW = 1.0 + d.double().t() @ h.double()
+    refb = 2.0 + d.double().sum(0)
+    tol = 2e-6 * M ** 0.5 * 8
+    assert float((dW.double() - refW).abs().max()) <= tol and float((db.double() - refb).abs().max()) <= tol
+    dW2, db2 = torch.ones_like(dW), torch.full_like(db, 2.0)
+    ops.heads_grad(d, h, dW2, db2)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)         # fixed-order reduction: reproducible
+
+
 def test_gates_backward_rejects_other_sizes():
     from ic3net_amd import ops
     assert ops.lstm_gates_backward_supported(128) and not ops.lstm_gates_backward_supported(96)

@@ -501,6 +501,54 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
     np.testing.assert_array_equal(dg3, dgates)
 
 
+@pytest.mark.parametrize("H,R,OT", [(64, 100, 3), (128, 70, 8)])
+def test_heads_grad_over_an_episode(H, R, OT):
+    """ic3_heads_grad accumulates d^T h and the column sums of d over all rows (float64 check)."""
+    lib = host_lib()
+    rng = np.random.default_rng(H + R + OT)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    d = f32(rng.standard_normal((R, OT)))
+    dW, db = np.ones((OT, H), np.float32), np.full(OT, 2.0, np.float32)
+    scratch = np.empty(int(lib.ic3_heads_grad_scratch_floats(H)), np.float32)
+    hrows = f32(rng.standard_normal((R, H)))
+    check(lib.ic3_heads_grad(p(d), p(hrows), R, H, OT, p(dW), p(db), p(scratch), None))
+    np.testing.assert_allclose(dW, 1.0 + d.astype(np.float64).T @ hrows.astype(np.float64), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(db, 2.0 + d.astype(np.float64).sum(0), rtol=0, atol=1e-4)
+
+
+def test_hidden_out_writes_the_next_slot_and_leaves_the_input_alone():
+    """ic3_env_set_hidden_out: the next ic3_policy_step reads (h, c) from its arguments and writes h', c' to the given buffers —
+    same values as the in-place call, inputs untouched, one-shot."""
+    w = WORKLOADS['pp_easy']
+    E, N, H, heads = 7, w['N'], w['H'], w['heads']
+    res = []
+    for use_out in (False, True):
+        env = make_env(w, E, 3, 70)
+        P = make_params(env.obs_dim, H, heads, seed=4)
+        pol = HostPolicy(env, P, H, heads)
+        env.reset()
+        rng = np.random.default_rng(1)
+        h = (rng.standard_normal((E * N, H)) * 0.3).astype(np.float32)
+        c = (rng.standard_normal((E * N, H)) * 0.3).astype(np.float32)
+        h0, c0 = h.copy(), c.copy()
+        ho, co = np.full_like(h, np.nan), np.full_like(c, np.nan)
+        gate = np.ones((E, N), np.int32)
+        if use_out:
+            check(env.lib.ic3_env_set_hidden_out(env._h, p(ho), p(co)))
+        out, act, obs, rew, done, alive, comp = pol.step(env, h, c, None, gate)
+        if use_out:
+            np.testing.assert_array_equal(h, h0)
+            np.testing.assert_array_equal(c, c0)
+            res.append((ho.copy(), co.copy(), out.copy()))
+            out2, *_ = pol.step(env, h, c, None, gate)            # one-shot: this call updates h, c in place again
+            assert not np.array_equal(h, h0)
+        else:
+            res.append((h.copy(), c.copy(), out.copy()))
+        env.close()
+    for x, y in zip(*res):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_auto_reset_stream_traffic_junction():
     """The same for Traffic-Junction: every env restarts at the step cap (quirk Q12: TJ never sets episode_over); the alive
     mask of the previous step is ignored for an env at t = 0."""

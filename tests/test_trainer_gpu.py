@@ -545,3 +545,32 @@ def test_nonrecurrent_commnet_rollout_runs_on_the_one_launch_module(env_name, fl
     before = netA.encoder.weight.detach().clone()
     st = trA.train_batch(0)
     assert np.isfinite(st['action_loss']) and not torch.equal(before, netA.encoder.weight)
+
+
+def test_native_update_records_the_recurrent_state_in_place():
+    """train_batch on the one-launch path: the step launch reads (h, c) from slot t of the episode record and writes slot
+    t + 1 (ic3_env_set_hidden_out) — the record equals the one a copying rollout makes, bit for bit, and so do the grads."""
+    import bench
+    from ic3net_amd import bptt
+    grads = []
+    for inplace in (True, False):
+        tr, a = bench.build_trainer('pp_hard', 12, 3, 0, 0)
+        a.max_steps, a.batch_size = 12, 12 * 12
+        a.entr, a.value_coeff, a.gamma, a.normalize_rewards, a.advantages_per_action = 0.01, 0.01, 1.0, False, False
+        if not inplace:
+            tr._rec_inplace = lambda: False
+        assert tr._native_update()
+        tr._records = []
+        batch, stats = tr.run_batch(0)
+        rec = tr._records[0]
+        assert rec.n == 12 and (rec.h_last.data_ptr() == rec.hs[12].data_ptr()) == inplace
+        tr.optimizer.zero_grad()
+        tr.compute_grad_native(batch, tr._records)
+        tr._records = None
+        grads.append(({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None},
+                      rec.hs[:12].clone(), rec.cs[:12].clone(), rec.h_last.clone()))
+    for x, y in zip(grads[0][1:], grads[1][1:]):
+        assert torch.equal(x, y)
+    for k in grads[0][0]:      # (the heads' gradient is one pass over the episode in place, two passes otherwise: summation order)
+        g0, g1 = grads[0][0][k], grads[1][0][k]
+        assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k

@@ -17,7 +17,7 @@ def main():
     mode = sys.argv[3] if len(sys.argv) > 3 else 'native'
     wl = sys.argv[4] if len(sys.argv) > 4 else 'pp_hard'
     dense = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-    split = int(sys.argv[6]) if len(sys.argv) > 6 else 0      # EXPERIMENT gate_split (rollout + recompute)
+    split = int(sys.argv[6]) if len(sys.argv) > 6 else 1      # gate product: 1 exact bf16 split products (default), 0 fp32 MFMA
     tr, a = bench.build_trainer(wl, E, 0, 0, 0)
     a.dense_obs = bool(dense)
     a.gate_split = bool(split)
@@ -45,7 +45,7 @@ def main():
         steps += st['num_steps']
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    label = wl + ("" if dense else " (no dense obs rows)") + (" EXPERIMENT gate_split" if split else "")
+    label = wl + ("" if dense else " (no dense obs rows)") + ("" if split else " (fp32 MFMA gate product)")
     print("train_batch [%s] %s E=%d: %.0f env-steps/s = %.2f M agent-steps/s (%.2f s per update of %d env-steps), "
           "peak mem %.1f GB, gemm %s" % (mode, label, E, steps / dt, a.nagents * steps / dt / 1e6, dt / updates,
                                          steps // updates, torch.cuda.max_memory_allocated() / 2 ** 30,

@@ -52,6 +52,48 @@ pmc)
   cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $GRAFT_REPO_ROOT/$O/$N -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/$O/$N.json 2> $GRAFT_REPO_ROOT/$O/$N.err
   cd $GRAFT_REPO_ROOT; python tools/collect_pmc.py $O/$N $C > $O/${N}_${C}.txt 2>&1; cat $O/${N}_${C}.txt | tail -12
   rm -rf $O/$N ;;
+evidence)
+  # the round's evidence in one call: bench lines of every BASELINE workload (default path), the fp32-instruction and
+  # hipGraph variants of the headline, rocprofv3 kernel stats, PMC HBM passes and SQ counter passes -> gpurun_out/evidence/
+  B="python bench.py --no-cpu-baseline"
+  timeout 300 $B --steps 40 > /dev/null 2>&1
+  timeout 600 python bench.py > $O/bench_pp_hard.json 2> $O/bench_pp_hard.err; summ $O/bench_pp_hard.json "pp_hard (default command)"
+  timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_pp_hard_driver_args.json 2>/dev/null; summ $O/bench_pp_hard_driver_args.json "pp_hard --steps 20 --warmup 5"
+  for w in tj_hard tj_medium pp_easy; do timeout 300 $B --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; summ $O/bench_$w.json $w; done
+  timeout 600 $B --workload pp_scaled --steps 40 > $O/bench_pp_scaled.json 2> $O/bench_pp_scaled.err; summ $O/bench_pp_scaled.json pp_scaled
+  timeout 300 $B --gate-split 0 > $O/bench_pp_hard_fp32_instruction.json 2>/dev/null; summ $O/bench_pp_hard_fp32_instruction.json "pp_hard --gate-split 0"
+  for w in tj_hard tj_medium; do timeout 300 $B --workload $w --gate-split 0 > $O/bench_${w}_fp32_instruction.json 2>/dev/null; summ $O/bench_${w}_fp32_instruction.json "$w --gate-split 0"; done
+  timeout 300 $B --time-kernels 0 > $O/bench_pp_hard_graph.json 2>/dev/null; summ $O/bench_pp_hard_graph.json "pp_hard hipGraph replay"
+  timeout 300 $B --no-dense-obs > $O/bench_pp_hard_no_obs_diagnostic.json 2>/dev/null; summ $O/bench_pp_hard_no_obs_diagnostic.json "pp_hard --no-dense-obs (diagnostic)"
+  timeout 300 $B --auto-reset 1 > $O/bench_pp_hard_auto_reset.json 2>/dev/null; summ $O/bench_pp_hard_auto_reset.json "pp_hard --auto-reset 1"
+  timeout 300 $B --rccl 1 --steps 20 --warmup 5 > $O/bench_pp_hard_rccl_world1.json 2>/dev/null; summ $O/bench_pp_hard_rccl_world1.json "pp_hard --rccl 1 (one-rank RCCL group)"
+  cd /tmp
+  S="--no-cpu-baseline --steps 40 --warmup 8"
+  R=$GRAFT_REPO_ROOT
+  for w in pp_hard tj_hard tj_medium pp_scaled; do
+    st="$S"; [ $w == pp_scaled ] && st="--no-cpu-baseline --steps 10 --warmup 4"
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_$w -- python $R/bench.py $st --workload $w > /dev/null 2>&1
+    f=$(find $R/$O/kt_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/$O/bench_${w}_kernel_stats.csv
+    for c in WRITE_SIZE FETCH_SIZE; do
+      timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/pmc_${c}_$w -- python $R/bench.py $st --workload $w > /dev/null 2>&1
+      python $R/tools/collect_pmc.py $R/$O/pmc_${c}_$w $c > $R/$O/pmc_${c}_$w.csv 2>&1; rm -rf $R/$O/pmc_${c}_$w
+    done
+    rm -rf $R/$O/kt_$w
+  done
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_graph -- python $R/bench.py $S --time-kernels 0 > /dev/null 2>&1
+  f=$(find $R/$O/kt_graph -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/collect_gaps.py $f > $R/$O/launch_gaps_graph.txt 2>&1
+  rm -rf $R/$O/kt_graph
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/kt_eager -- python $R/bench.py $S > /dev/null 2>&1
+  f=$(find $R/$O/kt_eager -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/collect_gaps.py $f > $R/$O/launch_gaps_eager.txt 2>&1
+  rm -rf $R/$O/kt_eager
+  i=0
+  for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$O/sq_$i -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > /dev/null 2>&1
+    for c in $grp; do python $R/tools/collect_pmc.py $R/$O/sq_$i $c | grep policy_step_kernel | head -1; done >> $R/$O/sq_counters.csv
+    rm -rf $R/$O/sq_$i
+  done
+  cd $R; cat $O/sq_counters.csv; head -3 $O/launch_gaps_graph.txt $O/launch_gaps_eager.txt; grep policy_step $O/pmc_*pp_hard.csv ;;
 sh)
   bash -c "$*" 2>&1 | grep -v amdgpu.ids | tee -a $O/log.txt | tail -40 ;;
 esac
