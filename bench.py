@@ -41,6 +41,11 @@ WORKLOADS = {
     "tj_hard": ("traffic_junction", dict(nagents=20, dim=18, vision=1, max_steps=80, hid_size=128, ic3net=True,
                                          recurrent=True, detach_gap=10, difficulty='hard', add_rate_min=0.05,
                                          add_rate_max=0.05)),
+    # the NON-recurrent CommNet module (comm.py:127-129,220-224) on the TJ-medium env, two communication
+    # passes — one launch per step through ic3_commnet_step
+    "tj_medium_commnet_mlp": ("traffic_junction", dict(nagents=10, dim=14, vision=1, max_steps=40, hid_size=128, commnet=True,
+                                                       recurrent=False, comm_passes=2, difficulty='medium', add_rate_min=0.05,
+                                                       add_rate_max=0.05)),
     "pp_scaled": ("predator_prey", dict(nagents=32, dim=40, vision=2, max_steps=80, hid_size=256, ic3net=True,
                                         recurrent=True, detach_gap=10, mode='mixed')),
 }
@@ -70,13 +75,14 @@ def make_args(env_name, flags, nenvs, seed, env_id_offset, device):
     return a
 
 
-def build_trainer(workload, nenvs, seed, env_id_offset, device):
+def build_trainer(workload, nenvs, seed, env_id_offset, device, **overrides):
     import torch
     from ic3net_amd import data
     from ic3net_amd.action_utils import parse_action_args
     from ic3net_amd.comm import CommNetMLP
     from ic3net_amd.trainer import Trainer
     env_name, flags = WORKLOADS[workload]
+    flags = dict(flags, **overrides)
     a = make_args(env_name, flags, nenvs, seed, env_id_offset, device)
     env = data.init(env_name, a, False)
     a.num_actions = [env.num_actions]     # main.py:134-152
@@ -223,16 +229,18 @@ def mfma_roofline(a, nenvs, step_ms, gate_split=False):
     9 x the gate product's flops against the dense bf16 peak."""
     R, H = nenvs * a.nagents, a.hid_size
     OT = sum(int(x) for x in a.naction_heads) + 1
-    gate = 2.0 * R * (2 * H * 4 * H)
-    flops = gate + 2.0 * R * (H * H + H * OT)
+    rec = bool(getattr(a, 'recurrent', True))
+    gate = 2.0 * R * (2 * H * 4 * H) if rec else 0.0
+    # non-recurrent module (comm.py:220-224): per communication pass one [comm | h] . [C_i | F_i]^T product (2H x H)
+    flops = gate + 2.0 * R * (H * H + H * OT) if rec else 2.0 * R * (int(a.comm_passes) * 2 * H * H + H * OT)
     avg = sum(step_ms) / len(step_ms)
     tf = flops / (avg * 1e-3) / 1e12
-    out = {"kernel": "policy_step_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+    out = {"kernel": "policy_step_kernel" if rec else "commnet_forward_kernel<H, env> (ic3_commnet_step)", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops,
            "flops_counted": "fp32-equivalent (2 per multiply-add of comm.py's dense layers)",
            "avg_launch_ms": round(avg, 4), "launches": len(step_ms),
-           "hbm_bytes_per_launch_algorithmic": R * (4 * H + OT + 2 * len(a.naction_heads) + 1) * 4}
-    if gate_split:
+           "hbm_bytes_per_launch_algorithmic": R * ((4 * H if rec else 0) + OT + 2 * len(a.naction_heads) + 1) * 4}
+    if gate_split and rec:
         btf = 9.0 * gate / (avg * 1e-3) / 1e12
         out["bf16_issued"] = {"flops_per_launch": 9.0 * gate, "achieved": round(btf, 1), "peak": MFMA_BF16_PEAK_TF,
                               "unit": "TFLOP/s", "frac": round(btf / MFMA_BF16_PEAK_TF, 4),
@@ -424,7 +432,8 @@ def main():
             raw_env.obs_timer = []
     else:
         run(T, 0)                             # no graphs: one untimed eager episode (first-use set-up, clocks)
-    mega_live = bool(o.mega) and getattr(trainer.policy_net, 'mega_steps', 0) > 0   # the one-launch path is in use
+    mega_live = bool(o.mega) and (getattr(trainer.policy_net, 'mega_steps', 0) > 0 or
+                                  getattr(trainer.policy_net, 'commnet_steps', 0) > 0)   # the one-launch path is in use
     if o.time_kernels and mega_live:
         raw_env.step_timer = []               # the launch of every step is event-timed and issued eagerly
         raw_env.dispatch_events = bool(o.dispatch_events)   # events stamped by the dispatch, not recorded around it
@@ -515,7 +524,8 @@ def main():
             hbm_kernel, hbm_bytes, hbm_ms = "policy_step_kernel", None, step_ms
             roof_note = "EXPERIMENT --incremental-obs: the launch does not rewrite the rows, so no fraction is formed over them"
         elif fused_obs:
-            hbm_kernel = "policy_step_kernel (policy + draws + env.step + obs assembly in one launch)"
+            hbm_kernel = ("policy_step_kernel" if a.recurrent else "commnet_forward_kernel<H, env>") + \
+                " (policy + draws + env.step + obs assembly in one launch)"
             hbm_bytes, hbm_ms = obs_bytes + state_bytes, step_ms
         elif step_ms and o.no_dense_obs:
             hbm_kernel, hbm_bytes, hbm_ms = "policy_step_kernel (no obs rows: diagnostic)", state_bytes, step_ms
@@ -558,7 +568,8 @@ def main():
                                   "eager, event-timed: policy+step launch, obs launch" if step_ms else
                                   "hipGraph replay" if o.graph else "eager"),
                        "dense_obs": not o.no_dense_obs, "overlap_obs": bool(o.overlap_obs),
-                       "policy": "one launch per step (ic3_policy_step)" if mega_live else "launch chain",
+                       "policy": ("one launch per step (%s)" % ("ic3_policy_step" if a.recurrent else "ic3_commnet_step"))
+                       if mega_live else "launch chain",
                        "auto_reset": bool(o.auto_reset),
                        "obs_rows": ("EXPERIMENT: maintained incrementally (not rewritten every step) - not the headline "
                                     "configuration" if o.incremental_obs else
@@ -569,7 +580,7 @@ def main():
                                 "bf16 terms, all 9 cross products on v_mfma_f32_32x32x16_bf16 (each product exact in fp32), fp32 "
                                 "accumulation - fp32-class arithmetic (error vs fp64 = the fp32 instruction's, "
                                 "tests/test_gate_split_gpu.py; --gate-split 0 selects v_mfma_f32_32x32x2_f32); C product and "
-                                "heads: fp32 MFMA" if (mega_live and o.gate_split) else
+                                "heads: fp32 MFMA" if (mega_live and o.gate_split and a.recurrent) else
                                 "hand-written fp32 MFMA (v_mfma_f32_32x32x2_f32)" if mega_live else
                                 "TunableOp-selected" if o.tune_gemm else "default heuristics")},
             "live_frac": round(live_frac, 6),

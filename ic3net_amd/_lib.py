@@ -109,6 +109,9 @@ EXPORTS = {
     "ic3_commnet_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_commnet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 +
                             [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "ic3_commnet_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
+    "ic3_commnet_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int] +
+                         [C.c_void_p] * 10),
     "ic3_lstm_gates_backward_supported": (C.c_int, [C.c_int]),
     "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_heads_grad_scratch_floats": (C.c_size_t, [C.c_int]),

@@ -184,6 +184,37 @@ class CommNetMLP(nn.Module):
         action, value = self._split_out(out, batch, n)
         return action, value.reshape(batch, n, 1)                 # comm.py:228 on a (B, N, H) hidden state (shape quirk Q25)
 
+    def commnet_step_ok(self, env, x):
+        """True when step_env_commnet() may replace forward + select_action + env.step for this input (the non-recurrent
+        module, the env's own observation, a handle that is not in auto-reset mode)."""
+        if not self._commnet_ok(x) or not hasattr(env, '_h'):
+            return False
+        if getattr(self.obs_encoder, '__self__', None) is not env or not self._x_is_env_obs(x):
+            return False
+        if x.shape[0] != env.nenvs or self.nagents != env.nagents_env:
+            return False
+        return ops.commnet_step_supported(env, self.hid_size)
+
+    def step_env_commnet(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, out=None):
+        """trainer.py:61-67 for the non-recurrent module in ONE launch (ic3_commnet_step): action_out, value =
+        forward(x, info); `action` (heads, E, N) int32 <- the draws; env.step(action[0]) -> reward / done / alive /
+        is_completed; `obs`, when given, receives the dense observation of the state this call acts on."""
+        n, H = self.nagents, self.hid_size
+        batch = x.size(0)
+        R, dev = batch * n, x.device
+        cn = self._commnet_cache()
+        alive_in = self._mask(info, 'alive_mask', batch, dev)
+        comm_in = self._mask(info, 'comm_action', batch, dev) if self.args.hard_attn else None
+        mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
+        heads = [int(a) for a in self.args.naction_heads]
+        if out is None:
+            out = torch.empty((R, sum(heads) + 1), dtype=torch.float32, device=dev)
+        ops.commnet_step(env, cn, H, heads, mode_avg, bool(self.args.comm_mask_zero), alive_in, comm_in, out, action, reward,
+                         done, alive, is_completed, obs)
+        self.commnet_steps = getattr(self, 'commnet_steps', 0) + 1
+        action_out, value = self._split_out(out, batch, n)
+        return action_out, value.reshape(batch, n, 1)
+
     def _x_is_env_obs(self, x):
         """The sparse encoder evaluates encoder(obs(env's CURRENT integer state)) without reading x; that is only
         the answer when x IS that observation, i.e. the env's own obs buffer (which env.reset/step keep in sync with
@@ -405,7 +436,8 @@ class CommNetMLP(nn.Module):
         mb['c'].zero_()
         return (mb['h'], mb['c'])
 
-    def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, hidden_out=None):
+    def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, hidden_out=None,
+                 out=None):
         """action_out, value, (h, c) = forward(x, info); `action` (heads, E, N) int32 <- select_action (Philox draws
         positioned by the env's own counters); env.step(action[0]) -> reward (E,N) f32, done (E,) i32, alive /
         is_completed (E,N) i32.  trainer.py:49-67 in one launch.  `obs` (E,N,obs_dim), when given, receives the dense
@@ -439,7 +471,10 @@ class CommNetMLP(nn.Module):
         mode_avg = hasattr(self.args, 'comm_mode') and self.args.comm_mode == 'avg'
         heads = [int(a) for a in self.args.naction_heads]
         OT = sum(heads) + 1
-        out = torch.empty((R, OT), dtype=torch.float32, device=dev)    # per call: a Transition keeps its action_out
+        if out is None:
+            out = torch.empty((R, OT), dtype=torch.float32, device=dev)   # per call: a Transition keeps its action_out
+        else:                        # the caller's buffer (hipGraph mode: nothing is allocated inside a captured step)
+            assert out.is_contiguous() and tuple(out.shape) == (R, OT) and out.dtype == torch.float32
         mz = bool(self.args.comm_mask_zero)
         for i in range(self.comm_passes - 1):                     # comm.py:179: every pass but the last updates h, c only
             ops.policy_step_pass(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, i)

@@ -10,8 +10,18 @@
 // in registers in the MFMA C/D layout, tanh on the hardware transcendental unit (|error| <= ~2e-7, bar 1e-5).
 // This is f3 coverage ("other policy variants"), not the headline path: one resident workgroup per CU at
 // H >= 128, no store pacing, plain loops.
+//
+// Round 4 — ic3_commnet_step: the WHOLE rollout iteration of trainer.py:43-108 for the non-recurrent module as one launch
+// (KIND = IC3_ENV_PP / IC3_ENV_TJ instantiations of the same kernel): window descriptors of the tile's envs in LDS ->
+// the dense observation rows of the state acted on (pp/tj_obs_store_run: every element evaluated and stored once) -> sparse
+// encoder gather (comm.py:119) -> tanh -> the communication passes above -> heads, log_softmax -> Philox inverse-CDF draws
+// (action_utils.py:32-36, the counters of ic3_env_sample_actions) -> env.step (pp/tj_step_lanes: the device functions the
+// stand-alone step kernels and policy_step_kernel run).  Five launches per step before (encode, this kernel's policy part,
+// draws, step, obs).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
+#include "env_device.hpp"
 #include "ic3_common.hpp"
 
 namespace ic3 {
@@ -30,9 +40,22 @@ struct CommnetArgs {
     float* out;                // [R][OT]
     float* h_out;              // [R][H] or null: the final hidden state (tests)
     int E, N, EPT, passes, mode_avg, comm_zero, nheads, OT, a0, a1, a2, a3;
+    // ic3_commnet_step (KIND != 0): the env side of the iteration
+    const cn_f32x4* Wt;        // encoder.weight^T [obs_dim][H/4]
+    const cn_f32x4* enc_bias;  // encoder.bias [H/4]
+    const cn_f32x4* loc_table; // ic3_env_encode_table or null
+    float* obs;                // [E][N][obs_dim] or null: rows of the state acted on
+    int32_t* action;           // [nheads][R]
+    int obs_dim, G, tile_words;
+    uint32_t seed, gid0;
+    const int32_t* episode;
+    const int32_t* tstep;
+    StepOut so;
+    PPState pp;
+    TJState tj;
 };
 
-template <int H>
+template <int H, int KIND = 0>
 __global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const CommnetArgs a)
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, H4 = H / 4, KB = K / 8, BM = 64;
@@ -43,10 +66,22 @@ __global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const Commnet
     float* const sscale = sm + BM;                               // [BM] per-env 1 / (n_alive - 1)
     int32_t* const sal = reinterpret_cast<int32_t*>(sscale + BM);   // [BM] alive flags
     float* const zl = reinterpret_cast<float*>(sal + BM);        // [BM][16] logits
+    int32_t* const sact = reinterpret_cast<int32_t*>(zl + BM * 16);   // [BM] env action (head 0) of every row      (KIND != 0)
+    uint32_t* const rmask = reinterpret_cast<uint32_t*>(sact + BM);   // [BM] window cells of a row that carry a count
+    int32_t* const sep = reinterpret_cast<int32_t*>(rmask + BM); // [BM] episode counters of the tile's envs (Philox key)
+    int32_t* const sts = sep + BM;                               // [BM] step counters
+    int32_t* const tile = sts + BM;                              // env descriptors of the tile's envs
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li, N = a.N;
     const int e0 = blockIdx.x * a.EPT, nenv = min(a.EPT, a.E - e0), rows = nenv * N;
     const size_t r0 = (size_t)e0 * N;
+    const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
+    const int total = a.pp.Np + a.pp.nprey;
+    const int nsegE = N * WW;
+    const int tjw = tj_tile_words(N, WW);
+    const float invN = 1.0f / (float)N;
+    (void)total;
+    (void)tjw;
 
     // ---- masks and per-env scale (comm.py:102-107,175-177,194-196) ---------------------------------------------------------
     if (tid < BM) {
@@ -56,6 +91,77 @@ __global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const Commnet
         sm[tid] = in ? (float)(al * cm) : 0.f;
         sal[tid] = al;
     }
+    if constexpr (KIND != 0) {
+        // ---- window descriptors of the tile's envs (positions, then the per-cell table), Philox counters ----------------------
+        if (tid < BM) {
+            rmask[tid] = (WW <= 32) ? 0u : ~0u;
+            if (tid < nenv) {
+                sep[tid] = a.episode[e0 + tid];
+                sts[tid] = a.tstep[e0 + tid];
+            }
+        }
+        int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
+        if constexpr (KIND == IC3_ENV_PP) {
+            int32_t* psr = tile;
+            int32_t* psc = tile + a.EPT * total;
+            for (int i = tid; i < nenv * total; i += NT) {
+                psr[i] = a.pp.loc_r[(size_t)e0 * total + i];
+                psc[i] = a.pp.loc_c[(size_t)e0 * total + i];
+            }
+        } else {
+            for (int i = tid; i < nenv * N; i += NT) {
+                const int el = div_small(i, invN);
+                tj_tile_load_car(tj_tile_at(tile + el * tjw, N), a.tj, e0 + el, i - el * N);
+            }
+        }
+        __syncthreads();
+        const float inv_nsegE = 1.0f / (float)max(nsegE, 1), inv_WW = 1.0f / (float)max(WW, 1);
+        for (int sg = tid; sg < nenv * nsegE; sg += NT) {
+            const int el = div_small(sg, inv_nsegE), q = sg - el * nsegE;
+            int2 d;
+            if constexpr (KIND == IC3_ENV_PP) {
+                d = pp_tab_entry(tile + el * total, tile + a.EPT * total + el * total, q, a.pp.Np, total, a.pp.dim, a.pp.v);
+                ptab[sg] = d;
+            } else {
+                const TJTile t = tj_tile_at(tile + el * tjw, N);
+                d = tj_tab_entry(t, a.tj, q);
+                t.tab[q] = d;
+            }
+            if (d.y != 0 && WW <= 32) {
+                const int ag = div_small(q, inv_WW);
+                atomicOr(&rmask[el * N + ag], 1u << (q - ag * WW));
+            }
+        }
+        __syncthreads();
+        // ---- the dense observation rows of the state this step acts on (trainer.py:49), every element stored once ------------
+        if (a.obs) {
+            if constexpr (KIND == IC3_ENV_PP) {
+                const int vocab = a.pp.dim * a.pp.dim + 4;
+                if ((vocab & 3) == 0) pp_obs_store_run(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
+                else pp_obs_store_run_scalar(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
+            } else {
+                tj_obs_store_run(tile, tjw, a.tj, a.obs, e0, nenv, tid, NT, 0, 1);
+            }
+        }
+        // ---- x = tanh(encoder(obs)) as a sparse gather (comm.py:119,127-129) -> h half ------------------------------------------
+        const PtrRows encW = { a.Wt }, encL = { a.loc_table };
+        for (int idx = tid; idx < BM * H4; idx += NT) {
+            const int row = idx / H4, c4 = idx - row * H4;
+            cn_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+            if (row < rows) {
+                const int el = div_small(row, invN), aa = row - el * N;
+                if constexpr (KIND == IC3_ENV_PP) {
+                    v = pp_encode_row_t(tile + el * total, tile + a.EPT * total + el * total, ptab + el * nsegE, aa, c4, H4, WW,
+                                        a.pp.dim * a.pp.dim + 4, a.pp.dim, encW, a.enc_bias, encL, rmask[row]);
+                } else {
+                    v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, a.enc_bias, encL, rmask[row]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
+            }
+            As4[row * LDA4 + H4 + c4] = v;
+        }
+    } else {
     // ---- x = tanh(enc) -> h half (comm.py:127-129) ---------------------------------------------------------------------------
     for (int idx = tid; idx < BM * H4; idx += NT) {
         const int row = idx / H4, c4 = idx - row * H4;
@@ -66,6 +172,7 @@ __global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const Commnet
             for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
         }
         As4[row * LDA4 + H4 + c4] = v;
+    }
     }
     __syncthreads();
     for (int el = tid; el < nenv; el += NT) {
@@ -185,6 +292,38 @@ __global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const Commnet
         for (int o = 0; o < A; ++o) sum += __builtin_amdgcn_exp2f(1.4426950408889634f * (z[off + o] - mx));
         const float lse = mx + 0.6931471805599453f * __builtin_amdgcn_logf(sum);
         for (int o = 0; o < A; ++o) orow[off + o] = z[off + o] - lse;
+        if constexpr (KIND != 0) {          // the draw of this (row, head): same counters and arithmetic as sample_actions_env_kernel
+            const int el = div_small(tr, invN), n = tr - el * N;
+            const uint32_t x = philox_x24(a.seed, a.gid0 + (uint32_t)(e0 + el), DOMAIN_SAMPLE, (uint32_t)sep[el],
+                                          (uint32_t)sts[el], (uint32_t)(hd * N + n));
+            const float u = (float)x * (1.0f / 16777216.0f);
+            float cdf = 0.0f;
+            int act = A - 1;
+            for (int o = 0; o < A - 1; ++o) {
+                cdf += expf(z[off + o] - lse);
+                if (u < cdf) {
+                    act = o;
+                    break;
+                }
+            }
+            a.action[(size_t)hd * ((size_t)a.E * N) + r0 + tr] = act;
+            if (hd == 0) sact[tr] = act;
+        }
+    }
+    if constexpr (KIND != 0) {
+        // ---- env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) -------------------------------------
+        __syncthreads();
+        const int lgG = __builtin_ctz(a.G);
+        for (int base = 0; base < a.EPT * a.G; base += NT) {
+            const int lt = base + tid;
+            const int el = lt >> lgG, n = lt - (el << lgG);
+            const int e = el < nenv ? e0 + el : a.E;
+            if constexpr (KIND == IC3_ENV_PP) {
+                pp_step_lanes(a.pp, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+            } else {
+                tj_step_lanes(a.tj, a.so, e, n, a.E, a.G, [&]() { return sact[el * N + n]; });
+            }
+        }
     }
 }
 
@@ -255,12 +394,12 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
     a.a2 = sz[2];
     a.a3 = sz[3];
     const int tiles = (E + a.EPT - 1) / a.EPT;
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + 64 * 16) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + 64 * 16 + 4 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define IC3_CN(h)                                                                                                 \
     case h:                                                                                                       \
-        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h>), lds));               \
-        hipLaunchKernelGGL(commnet_forward_kernel<h>, dim3(tiles), dim3(2 * h), lds, s, a);                       \
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h, 0>), lds));               \
+        hipLaunchKernelGGL((commnet_forward_kernel<h, 0>), dim3(tiles), dim3(2 * h), lds, s, a);                       \
         break;
     switch (H) {
         IC3_CN(64)
@@ -268,6 +407,120 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
         IC3_CN(256)
     }
 #undef IC3_CN
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+static size_t commnet_step_tile_words(const ic3_env* env)
+{
+    const int N = env->dims.N, EPT = 64 / N, WW = env->dims.window * env->dims.window;
+    size_t w;
+    if (env->kind == IC3_ENV_PP) w = (size_t)((2 * EPT * (env->pp.N + env->pp.nprey) + 3) & ~3) + (size_t)2 * EPT * N * WW;
+    else w = (size_t)EPT * (((7 * N + 3) & ~3) + 2 * N * WW);
+    return (w + 3) & ~(size_t)3;
+}
+
+static size_t commnet_step_lds(const ic3_env* env, int H)
+{
+    return ((size_t)64 * (2 * H + 4) + 3 * 64 + 64 * 16 + 4 * 64 + commnet_step_tile_words(env)) * sizeof(float);
+}
+
+extern "C" int ic3_commnet_step_supported(const ic3_env* env, int H)
+{
+    if (!env || !ic3_commnet_forward_supported(H, env->dims.N) || env->auto_max_steps > 0) return 0;
+    const size_t lds = commnet_step_lds(env, H);
+    return lds <= 160 * 1024 ? (int)lds : 0;
+}
+
+extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* enc_bias, const float* loc_table, int H,
+                                int comm_passes, const float* wp, const float* bias, const float* head_w, const float* head_b,
+                                const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
+                                const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward, int32_t* done,
+                                int32_t* alive, int32_t* is_completed, ic3_stream stream)
+{
+    using namespace ic3;
+    ic3::Range range_("ic3_commnet_step");
+    if (!env || !enc_wt || !enc_bias || !wp || !bias || !head_w || !head_b || !head_sizes || !out || !action || !reward || !done ||
+        comm_passes < 1)
+        return fail(-22, "ic3_commnet_step: bad arguments");
+    if (env->resets == 0) return fail(-22, "ic3_commnet_step: reset() has not been called");
+    if (nheads < 1 || nheads > 4) return fail(-22, "ic3_commnet_step: 1..4 action heads");
+    const int lds = ic3_commnet_step_supported(env, H);
+    if (!lds)
+        return fail(-38, "ic3_commnet_step: needs hid_size 64/128/256, <= 64 agents per env, an env tile that fits in LDS and a "
+                         "handle that is not in auto-reset mode (use ic3_env_encode + ic3_commnet_forward + ic3_env_sample_actions "
+                         "+ ic3_env_step)");
+    CommnetArgs a{};
+    a.wp = wp;
+    a.bias = bias;
+    a.head_w = head_w;
+    a.head_b = head_b;
+    a.alive_in = alive_in;
+    a.comm_in = comm_in;
+    a.out = out;
+    a.E = env->dims.E;
+    a.N = env->dims.N;
+    a.EPT = 64 / a.N;
+    a.passes = comm_passes;
+    a.mode_avg = mode_avg;
+    a.comm_zero = comm_zero;
+    a.nheads = nheads;
+    int sz[4] = { 0, 0, 0, 0 };
+    a.OT = 1;
+    for (int i = 0; i < nheads; ++i) {
+        sz[i] = head_sizes[i];
+        if (sz[i] < 1) return fail(-22, "ic3_commnet_step: empty action head");
+        a.OT += sz[i];
+    }
+    if (a.OT > 16) return fail(-22, "ic3_commnet_step: more than 15 actions in total");
+    a.a0 = sz[0];
+    a.a1 = sz[1];
+    a.a2 = sz[2];
+    a.a3 = sz[3];
+    a.Wt = reinterpret_cast<const cn_f32x4*>(enc_wt);
+    a.enc_bias = reinterpret_cast<const cn_f32x4*>(enc_bias);
+    a.loc_table = reinterpret_cast<const cn_f32x4*>(loc_table);
+    a.obs = obs;
+    a.obs_dim = env->dims.obs_dim;
+    a.action = action;
+    a.tile_words = (int)commnet_step_tile_words(env);
+    a.episode = env->f("episode");
+    a.tstep = env->f("t");
+    a.so = StepOut{ reward, done, alive, is_completed, env->d_err };
+    const bool pp = env->kind == IC3_ENV_PP;
+    if (pp) {
+        a.pp = pp_state_of(env);
+        a.G = group_lanes(a.N);
+        a.seed = env->pp.seed;
+        a.gid0 = env->pp.env_id_offset;
+    } else {
+        a.tj = tj_state_of(env);
+        a.G = tj_group(a.N);
+        a.seed = env->tj.seed;
+        a.gid0 = env->tj.env_id_offset;
+    }
+    env->touch_obs(obs);
+    const int tiles = (a.E + a.EPT - 1) / a.EPT;
+    hipStream_t s = (hipStream_t)stream;
+    // one-shot (ic3_env_set_step_events): the dispatch itself stamps the caller's events
+    hipEvent_t ev0 = (hipEvent_t)env->ev_start, ev1 = (hipEvent_t)env->ev_stop;
+    env->ev_start = env->ev_stop = nullptr;
+#define IC3_CS(h)                                                                                                          \
+    case h:                                                                                                                \
+        if (pp) {                                                                                                          \
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h, IC3_ENV_PP>), lds));        \
+            hipExtLaunchKernelGGL((commnet_forward_kernel<h, IC3_ENV_PP>), dim3(tiles), dim3(2 * h), lds, s, ev0, ev1, 0, a); \
+        } else {                                                                                                           \
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h, IC3_ENV_TJ>), lds));        \
+            hipExtLaunchKernelGGL((commnet_forward_kernel<h, IC3_ENV_TJ>), dim3(tiles), dim3(2 * h), lds, s, ev0, ev1, 0, a); \
+        }                                                                                                                  \
+        break;
+    switch (H) {
+        IC3_CS(64)
+        IC3_CS(128)
+        IC3_CS(256)
+    }
+#undef IC3_CS
     IC3_HIP(hipGetLastError());
     return 0;
 }

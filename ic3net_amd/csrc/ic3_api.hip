@@ -42,6 +42,11 @@ bool roctx_on()
 
 Range::Range(const char* name) : on(roctx_on())
 {
+    // Every launching entry point starts with a Range: drop whatever error another user of the runtime left in the thread's
+    // "last error" slot (e.g. torch reading the return code of a failed hipStreamEndCapture without clearing it), so that the
+    // hipGetLastError() check behind OUR launch reports our launch and nothing else.  (The reverse direction — not leaving
+    // our own failures behind for the caller's next call — is IC3_HIP's.)
+    (void)hipGetLastError();
     if (on) g_push(name);
 }
 Range::~Range()

@@ -144,6 +144,31 @@ def commnet_forward(enc, E, N, wp, bias, head_w, head_b, head_sizes, mode_avg, c
     return out
 
 
+def commnet_step_supported(env, H):
+    return _lib.lib().ic3_commnet_step_supported(env._h, int(H)) > 0
+
+
+def commnet_step(env, cn, H, head_sizes, mode_avg, comm_zero, alive_in, comm_in, out, action, reward, done, alive=None,
+                 is_completed=None, obs=None):
+    """One whole rollout iteration of the NON-recurrent module (sparse encoder -> communication passes -> heads -> draws ->
+    env.step, + the dense obs rows of the state acted on) in one launch — ic3_commnet_step.  `cn`: the module's derived
+    weights (wt, enc_bias, loc_table, wp, bias, w_heads, b_heads)."""
+    import ctypes as C
+    _need_cuda(out, "commnet_step")
+    R = out.shape[0]
+    assert out.is_contiguous() and action.is_contiguous() and action.dtype == torch.int32
+    assert action.numel() == len(head_sizes) * R and out.shape[1] == sum(int(a) for a in head_sizes) + 1
+    for m in (alive_in, comm_in):
+        assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+    sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
+    check(_lib.lib().ic3_commnet_step(env._h, ptr(cn['wt']), ptr(cn['enc_bias']), ptr(cn['loc_table']), int(H),
+                                      cn['wp'].shape[0], ptr(cn['wp']), ptr(cn['bias']), ptr(cn['w_heads']), ptr(cn['b_heads']),
+                                      sizes, len(head_sizes), int(bool(mode_avg)), int(bool(comm_zero)), ptr(alive_in),
+                                      ptr(comm_in), ptr(out), ptr(action), ptr(obs), ptr(reward), ptr(done), ptr(alive),
+                                      ptr(is_completed), stream()))
+    return out
+
+
 def lstm_gates_backward_supported(H):
     return bool(_lib.lib().ic3_lstm_gates_backward_supported(int(H)))
 

@@ -12,6 +12,7 @@ Differences forced by batching:
   * `state` / `next_state` are only materialised in the Transition when args.store_states is set (the
     env reuses one (E,N,obs_dim) buffer; PP-hard is 1.19 GB per step at E = 8192).
 """
+import gc
 from collections import namedtuple
 from inspect import signature
 
@@ -171,8 +172,7 @@ class Trainer(object):
 
     def _use_graph(self):
         a = self.args
-        return bool(getattr(a, 'hip_graph', False)) and not getattr(self, '_graph_broken', False) \
-            and not getattr(a, 'store_states', False) \
+        return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
             and not getattr(a, 'rollout_grad', False) and self._records is None and self.clock.env is not None \
             and not getattr(self, '_should_display', False) \
             and getattr(self.clock.env, 'step_timer', None) is None      # event-timed launches stay eager
@@ -196,30 +196,24 @@ class Trainer(object):
                 self._graph_pool = torch.cuda.graph_pool_handle()
             # thread_local: calls made by other threads (e.g. an RCCL watchdog) must not invalidate the capture
             timer, raw.obs_timer = raw.obs_timer, None        # no event records inside a capture
+            # No Python garbage collection INSIDE a capture: a cycle collected there may own device resources of something
+            # long dead (another Trainer's graphs, tensors, events) and releasing them (hipFree, hipGraphDestroy, ...) from
+            # the capturing thread invalidates the capture — "operation failed due to a previous error during capture" at an
+            # arbitrary step of a long-lived process, after which the process is not recoverable (round 4: the GPU suite at
+            # step 53 / 66 of one test, depending on how much the tests before it had allocated).  torch.cuda.graph itself
+            # stopped collecting in its __enter__ (torch 2.10: only under torch.compiler.config.force_cudagraph_gc), so
+            # collect once in front of an episode's first capture and keep the collector off while capturing.
+            if not self._graphs:
+                gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
             try:
                 with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                     self._step_body(t, observe=in_graph_obs)
-            except Exception as exc:
-                # A capture the runtime invalidated (seen once per long test session on ROCm 7.2: "operation failed due
-                # to a previous error during capture" at an arbitrary step): nothing of the step has executed.  Graphs are
-                # a launch-overhead optimisation only — restore the step's inputs, play this and all later steps eagerly
-                # (same results), and say so.
-                import warnings
-                raw.obs_timer = timer
-                torch.cuda.synchronize()
-                self._state, self._info, self._prev_hid = saved
-                self._pf_ready = pf_before
-                self._graphs.clear()
-                self._graph_broken = True
-                st = torch.cuda.memory_stats()
-                warnings.warn("hipGraph capture of rollout step %d failed (%s: %s); continuing with eager launches "
-                              "[reserved %.2f GB, allocated %.2f GB]"
-                              % (t, type(exc).__name__, str(exc).splitlines()[0] if str(exc) else '',
-                                 st.get('reserved_bytes.all.current', 0) / 2 ** 30,
-                                 st.get('allocated_bytes.all.current', 0) / 2 ** 30))
-                return self.step_episode(t)
             finally:
                 raw.obs_timer = timer
+                if gc_was_on:
+                    gc.enable()
             self._graph_gen = getattr(self.policy_net, 'cache_generation', 0)
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
                                        outputs=(self._state, self._info, self._prev_hid, self._step_out[t]),
@@ -281,6 +275,7 @@ class Trainer(object):
                 if fuse_draw and self.clock.env is raw and getattr(self.policy_net, 'mega_ok', None) is not None \
                         and self.policy_net.mega_ok(raw, [state, self._prev_hid]):
                     return self._step_body_mega(t, observe)
+                self._refresh_skipped_reset_obs(raw, t)
                 if self._auto_reset():
                     raise NotImplementedError("args.auto_reset needs the one-launch rollout step (ic3_policy_step: "
                                               "recurrent CommNet/IC3Net, hid_size 64/128/256, no autograd): per-env "
@@ -297,6 +292,13 @@ class Trainer(object):
                         else prev_hid.detach()
                 self._prev_hid = prev_hid
             else:
+                raw = self.env.env
+                if not torch.is_grad_enabled() and self.clock.env is raw and self.clock.env is not None \
+                        and select_action is _select_action_default and not store \
+                        and getattr(self.policy_net, 'commnet_step_ok', None) is not None \
+                        and self.policy_net.commnet_step_ok(raw, state):
+                    return self._step_body_commnet(t, observe)
+                self._refresh_skipped_reset_obs(raw, t)
                 action_out, value = self.policy_net(state, info)
             if getattr(self.policy_net, 'sampled', False):                               # drawn by the policy launch
                 self.policy_net.sampled = False
@@ -370,10 +372,11 @@ class Trainer(object):
         rec_out = None
         if self._rec is not None and self._prev_hid[0].data_ptr() == self._rec.hs[t].data_ptr():
             rec_out = self._rec.slot(t + 1)                        # the launch writes the next slot of the episode record
+        out_buf = self._static_out(t, state)
         action_out, value, prev_hid = self.policy_net.step_env(
             raw, [state, self._prev_hid], info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
             alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None,
-            hidden_out=rec_out)
+            hidden_out=rec_out, out=out_buf)
         if prefill:
             main.wait_stream(side)
             self._pf_ready = (t + 1) & 1
@@ -398,6 +401,59 @@ class Trainer(object):
         if getattr(self, '_should_display', False):                # trainer.py:101-102
             self.env.display()
         self._step_out[t] = (cur_state, action_out, value, next_state.clone() if store else None)
+        self._state = next_state
+        self._info = info
+        self._nsteps = t + 1
+
+    def _static_out(self, t, state):
+        """hipGraph mode: the launch's [log-probs | value] rows of every step index live in one static buffer — no
+        allocation inside a captured step (a pool that has to grow mid-capture invalidated the capture of step 53 in long
+        test sessions on ROCm 7.2: "operation failed due to a previous error during capture").  Eager mode: None (a fresh
+        tensor per call, a Transition keeps its action_out)."""
+        if not self._use_graph():
+            return None
+        args = self.args
+        OT = sum(int(o) for o in args.naction_heads) + 1
+        shape = (args.max_steps, state.shape[0] * args.nagents, OT)
+        ob = self._static.get('out')
+        if ob is None or tuple(ob.shape) != shape:
+            ob = self._static['out'] = torch.empty(shape, dtype=torch.float32, device=state.device)
+        return ob[t]
+
+    def _refresh_skipped_reset_obs(self, raw, t):
+        """begin_episode skipped the reset obs launch because it EXPECTED step 0 on the one-launch path (which writes the
+        rows itself); step 0 turned out to take another path: assemble the observation of the reset state now, before
+        anything reads it."""
+        if t == 0 and getattr(raw, 'skip_reset_obs', False) and hasattr(raw, 'observe'):
+            raw.observe()
+            raw.skip_reset_obs = False
+
+    def _step_body_commnet(self, t, observe):
+        """The iteration of _step_body for the NON-recurrent CommNet module through CommNetMLP.step_env_commnet
+        (ic3_commnet_step): sparse encoder, communication passes, heads, the draws of every head, env.step and the dense obs
+        rows of the state acted on are ONE launch."""
+        args, buf, state, info = self.args, self._buf, self._state, self._info
+        raw = self.env.env
+        timer = getattr(raw, 'step_timer', None)                   # bench: HIP events stamped by the dispatch of the launch
+        if timer is not None:
+            from .envs import DispatchEvent
+            e0, e1 = DispatchEvent(), DispatchEvent()
+            raw.set_step_events(e0, e1)
+            timer.append((e0, e1, t))
+        action_out, value = self.policy_net.step_env_commnet(
+            raw, state, info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t], alive=buf['alive'][t],
+            is_completed=buf['is_completed'][t], obs=raw._obs if observe else None, out=self._static_out(t, state))
+        self._mega_last = True                                     # (the reset obs launch may be skipped: step 0 writes the rows)
+        next_state = self.env._flatten_obs(raw._obs) if hasattr(self.env, '_flatten_obs') else raw._obs
+        if raw.dims.kind == 2:                                     # TJ:244-247
+            info = {'alive_mask': buf['alive'][t], 'is_completed': buf['is_completed'][t]}
+        else:
+            info = {'alive_mask_device': buf['alive'][t]}
+        if args.hard_attn and args.commnet:                        # trainer.py:70-71 (gate for the NEXT step)
+            info['comm_action'] = buf['action'][t][-1] if not args.comm_action_one else self._ones_comm
+        if getattr(self, '_should_display', False):                # trainer.py:101-102
+            self.env.display()
+        self._step_out[t] = (None, action_out, value, None)
         self._state = next_state
         self._info = info
         self._nsteps = t + 1

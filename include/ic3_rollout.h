@@ -423,6 +423,21 @@ int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, 
                         int comm_zero, const int32_t* alive_in, const int32_t* comm_in, float* out, float* h_out /* or NULL */,
                         ic3_stream stream);
 
+/* The whole rollout iteration of trainer.py:43-108 for the NON-recurrent module as ONE launch — what ic3_policy_step is for
+ * the recurrent policy: the sparse encoder on the env's integer state (enc_wt [obs_dim][H] = encoder.weight^T, enc_bias [H] =
+ * encoder.bias, loc_table = ic3_env_encode_table(enc_wt) or NULL), ic3_commnet_forward's passes / heads / log_softmax (same
+ * wp / bias / head_* arguments), the action draws of every head (action [nheads][E][N], Philox counters of
+ * ic3_env_sample_actions), env.step with head 0 (reward / done / alive / is_completed as ic3_env_step) and, when obs != NULL,
+ * the dense observation rows [E][N][obs_dim] of the state this call ACTS ON (bit-identical to ic3_env_observe before the
+ * call).  -ENOSYS when ic3_commnet_step_supported(env, H) == 0 (hid_size not 64/128/256, > 64 agents, a tile that does
+ * not fit in LDS, or a handle in auto-reset mode). */
+int ic3_commnet_step_supported(const ic3_env* env, int H);
+int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* enc_bias, const float* loc_table /* or NULL */, int H,
+                     int comm_passes, const float* wp, const float* bias, const float* head_w, const float* head_b,
+                     const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
+                     const int32_t* comm_in, float* out, int32_t* action, float* obs /* or NULL */, float* reward, int32_t* done,
+                     int32_t* alive, int32_t* is_completed, ic3_stream stream);
+
 int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */,
                     float* c_wp /* H*H */, float* lstm_wp /* 4H*2H */, int H, ic3_stream stream);
 int ic3_policy_pack_split(const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */, void* lstm_wp3 /* 3 * 2H * 4H * 2 bytes */,

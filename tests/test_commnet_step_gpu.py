@@ -1,0 +1,90 @@
+"""ic3_commnet_step — one rollout iteration of the NON-recurrent CommNet module as ONE launch (trainer.py:43-108 through
+comm.py:127-129,179-205,220-224) — pinned in one hop: free-running episodes through the Trainer against
+oracle.policy_ref (numpy float64, recurrent = False; pinned by the non-recurrent policy fixtures recorded from the reference)
+driven by the C oracle env on the kernel's own actions at the north_star's 1e-5; rewards and the dense observation rows
+written by the same launch bit for bit; the draws bit-identical to ic3_env_sample_actions on the kernel's log-probs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _oracle_env(a, seed, gid):
+    import oracle
+    if a.env_name == 'predator_prey':
+        return oracle.PPOracle(a.nagents, a.dim, a.vision, a.mode, seed=seed, env_gid=gid)
+    return oracle.TJOracle(a.nagents, a.dim, a.vision, a.difficulty, a.add_rate_min, a.add_rate_max, a.curr_start,
+                           a.curr_end, seed=seed, env_gid=gid, vocab_type=a.vocab_type)
+
+
+@pytest.mark.parametrize("workload,over,E,T", [
+    ("tj_medium_commnet_mlp", dict(), 13, 40),
+    ("tj_hard", dict(recurrent=False, comm_passes=1), 7, 30),             # IC3Net gating (hard_attn, comm_action_one)
+    ("pp_hard", dict(recurrent=False, comm_passes=2), 13, 30),            # gated IC3Net-style, two passes
+    ("pp_easy", dict(recurrent=False, commnet=True, ic3net=False, comm_passes=3, share_weights=True, hid_size=64), 9, 20),
+])
+def test_commnet_step_full_episode_vs_fp64_reference_policy(workload, over, E, T):
+    import bench
+    from ic3net_amd import ops
+    from oracle import policy_ref
+    seed, offset = 5, 300
+    tr, a = bench.build_trainer(workload, E, seed, offset, 0, **over)
+    a.max_steps = T
+    assert not a.recurrent
+    tr.begin_episode(0)
+    raw = tr.env.env
+    N, nheads = a.nagents, len(a.naction_heads)
+    params = {k: v.detach().cpu().double().numpy() for k, v in tr.policy_net.state_dict().items()}
+    rec = []
+    for t in range(T):
+        tr.step_episode(t)
+        _, action_out, value, _ = tr._step_out[t]
+        rec.append(dict(logp=[ao.cpu().numpy() for ao in action_out], value=value.reshape(E, N).cpu().numpy(),
+                        act=tr._buf['action'][t].cpu().numpy(), rew=tr._buf['reward'][t].cpu().numpy(),
+                        obs=raw._obs.cpu().numpy()))
+    assert getattr(tr.policy_net, 'commnet_steps', 0) == T, "the one-launch path did not run"
+    assert getattr(tr.policy_net, 'commnet_forwards', 0) == 0
+    import oracle
+    from oracle import philox
+    tj = a.env_name == 'traffic_junction'
+    worst = 0.0
+    for e in range(E):
+        o = _oracle_env(a, seed, offset + e)
+        obs = o.reset(0) if tj else o.reset()
+        alive, gate = None, np.zeros(N)
+        for t in range(T):
+            r = rec[t]
+            np.testing.assert_array_equal(r['obs'][e], obs, err_msg="obs rows env %d step %d" % (e, t))
+            logp, val, _ = policy_ref.forward(params, obs[None].astype(np.float64), None, alive, gate if a.hard_attn else None,
+                                              recurrent=False, comm_passes=a.comm_passes, comm_mode_avg=(a.comm_mode == 'avg'),
+                                              hard_attn=bool(a.hard_attn), nheads=nheads)
+            for hd in range(nheads):
+                worst = max(worst, np.abs(logp[hd][0] - r['logp'][hd][e]).max())
+                for n in range(N):   # the draw = the oracle's inverse-CDF on the kernel's own log-probs at this stream position
+                    want = oracle.sample_one(r['logp'][hd][e, n], philox.x24(seed, offset + e, philox.DOMAIN_SAMPLE, 0, t, hd * N + n))
+                    if want != r['act'][hd, e, n]:
+                        u = philox.x24(seed, offset + e, philox.DOMAIN_SAMPLE, 0, t, hd * N + n) / 2.0 ** 24
+                        assert np.abs(np.cumsum(np.exp(r['logp'][hd][e, n].astype(np.float64))) - u).min() < 1e-6
+            worst = max(worst, np.abs(val.reshape(-1) - r['value'][e]).max())
+            assert worst < TOL, (workload, e, t, worst)
+            obs, orew, done = o.step(r['act'][0, e])
+            np.testing.assert_array_equal(r['rew'][e], np.asarray(orew).astype(np.float32))
+            if done:
+                break
+            if tj:
+                alive = o.alive.astype(np.float64)
+            if a.hard_attn:
+                gate = np.ones(N) if a.comm_action_one else r['act'][nheads - 1, e].astype(np.float64)
+    assert worst < TOL
+
+
+def test_commnet_step_refuses_what_it_does_not_cover():
+    import bench
+    from ic3net_amd import ops
+    tr, a = bench.build_trainer("tj_medium_commnet_mlp", 8, 1, 0, 0)
+    raw = tr.env.env
+    assert ops.commnet_step_supported(raw, 128) and not ops.commnet_step_supported(raw, 96)
+    raw.set_auto_reset(5)
+    assert not ops.commnet_step_supported(raw, 128)      # (episode starts inside the launch: ic3_policy_step only)

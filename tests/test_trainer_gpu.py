@@ -504,8 +504,8 @@ def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     ("traffic_junction", dict(nagents=6, dim=6, vision=1, hid_size=128, ic3net=True, add_rate_min=0.3, add_rate_max=0.3)),
 ])
 def test_nonrecurrent_commnet_rollout_runs_on_the_one_launch_module(env_name, flags):
-    """recurrent = False at hid 64 / 128: the rollout's policy_net(x, info) is ONE ic3_commnet_forward launch behind the
-    sparse encoder; same transitions as the generic module path (args.fused_policy = False) on a twin env — log-probs and
+    """recurrent = False at hid 64 / 128: one rollout iteration is ONE launch (ic3_commnet_step, round 4; round 3: the policy
+    in one ic3_commnet_forward launch, five launches per step); same transitions as the generic module path (args.fused_policy = False) on a twin env — log-probs and
     values within fp32 rounding, hence (away from CDF edges) the same draws, rewards and masks; and one update runs."""
     from ic3net_amd import data, trainer as trmod
     from ic3net_amd.action_utils import parse_action_args
@@ -529,7 +529,9 @@ def test_nonrecurrent_commnet_rollout_runs_on_the_one_launch_module(env_name, fl
     (trA, netA, aA), (trB, netB, aB) = trs
     epA, statA = trA.get_episode(0)
     epB, statB = trB.get_episode(0)
-    assert getattr(netA, 'commnet_forwards', 0) == T and getattr(netB, 'commnet_forwards', 0) == 0
+    # ONE launch per step: ic3_commnet_step (sparse encoder, passes, heads, draws, env.step, obs rows) — and nothing else
+    assert getattr(netA, 'commnet_steps', 0) == T and getattr(netA, 'commnet_forwards', 0) == 0
+    assert getattr(netB, 'commnet_steps', 0) == 0 and getattr(netB, 'commnet_forwards', 0) == 0
     assert len(epA) == len(epB) == T
     same = 0
     for ta, tb in zip(epA, epB):

@@ -15,7 +15,7 @@ mkdir -p $O
 summ() { python - "$1" "$2" <<'PY'
 import json,sys
 try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d=json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1])
     r=d.get('roofline') or {}; m=d.get('roofline_mfma') or {}; t=d.get('timing') or {}
     print("%-44s %.4f ms/step %7.1f M/s | launch %.4f (min %s med %s) fill %s | hbm %.3f mfma %.3f | ok=%s" % (
         sys.argv[2], d['ms_per_step'], d['value']/1e6, (m or r).get('avg_launch_ms',0), t.get('launch_ms_min'),
@@ -80,12 +80,6 @@ evidence)
     done
     rm -rf $R/$O/kt_$w
   done
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_graph -- python $R/bench.py $S --time-kernels 0 > /dev/null 2>&1
-  f=$(find $R/$O/kt_graph -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/collect_gaps.py $f > $R/$O/launch_gaps_graph.txt 2>&1
-  rm -rf $R/$O/kt_graph
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/kt_eager -- python $R/bench.py $S > /dev/null 2>&1
-  f=$(find $R/$O/kt_eager -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/collect_gaps.py $f > $R/$O/launch_gaps_eager.txt 2>&1
-  rm -rf $R/$O/kt_eager
   i=0
   for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM"; do
     i=$((i+1))
@@ -93,7 +87,7 @@ evidence)
     for c in $grp; do python $R/tools/collect_pmc.py $R/$O/sq_$i $c | grep policy_step_kernel | head -1; done >> $R/$O/sq_counters.csv
     rm -rf $R/$O/sq_$i
   done
-  cd $R; cat $O/sq_counters.csv; head -3 $O/launch_gaps_graph.txt $O/launch_gaps_eager.txt; grep policy_step $O/pmc_*pp_hard.csv ;;
+  cd $R; cat $O/sq_counters.csv; grep policy_step $O/pmc_*pp_hard.csv ;;
 sh)
   bash -c "$*" 2>&1 | grep -v amdgpu.ids | tee -a $O/log.txt | tail -40 ;;
 esac
