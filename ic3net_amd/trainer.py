@@ -14,6 +14,7 @@ Differences forced by batching:
 """
 import gc
 from collections import namedtuple
+from collections.abc import Sequence
 from inspect import signature
 
 import torch
@@ -26,6 +27,44 @@ from .utils import merge_stat
 
 Transition = namedtuple('Transition', ('state', 'action', 'action_out', 'value', 'episode_mask', 'episode_mini_mask',
                                        'next_state', 'reward', 'misc'))
+
+
+class LazyEpisode(Sequence):
+    """The list of Transitions get_episode returns (trainer.py:26-126), materialised on access: len(), indexing (also
+    negative / slices), iteration, item assignment and `batch += episode` behave like the list they stand for."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._items = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if i not in self._items:
+            self._items[i] = self._make(i)
+        return self._items[i]
+
+    def __setitem__(self, i, value):
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        self._items[i] = value
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
 
 
 class Trainer(object):
@@ -538,14 +577,18 @@ class Trainer(object):
         alive_mask, episode_mini_mask, live = m['alive_mask'], m['episode_mini_mask'], m['live']
         episode_mask = m['episode_mask'].unsqueeze(2).expand(n, E, N)                          # trainer.py:92-96
         done_t = (m['episode_mask'] == 0) if self._auto_reset() else None
-        episode = []
-        for t in range(n):
-            cur_state, action_out, value, next_state = self._step_out[t]
+        step_out = self._step_out
+
+        def transition(t):
+            cur_state, action_out, value, next_state = step_out[t]
             misc = {'alive_mask': alive_mask[t], 'live': live[t]}
             if done_t is not None:
                 misc['done'] = done_t[t]                           # (E,) this transition ends its env's episode
-            episode.append(Transition(cur_state, action[t], action_out, value, episode_mask[t], episode_mini_mask[t],
-                                      next_state, reward[t], misc))
+            return Transition(cur_state, action[t], action_out, value, episode_mask[t], episode_mini_mask[t], next_state,
+                              reward[t], misc)
+        # The n Transition tuples (~10 tensor views each) are built when they are READ: a rollout loop that only wants the
+        # statistics (bench.py, soak runs, evaluation) does not pay ~1 ms of host time per episode during which the GPU idles
+        episode = LazyEpisode(n, transition)
         stat = dict()
         enemy = bool(getattr(args, 'enemy_comm', False))
         rts = None
