@@ -534,8 +534,8 @@ def main():
             hbm_bytes, hbm_ms = obs_bytes, obs_ms
         else:
             hbm_kernel, hbm_bytes, hbm_ms = None, None, []
-            roof_note = ("launches replayed as hipGraphs are not event-timed: run with --time-kernels 1 for the roofline "
-                         "of the step's launch")
+            roof_note = ("the step's launches were not event-timed (--time-kernels 0: hipGraph replays, or plain eager "
+                         "launches): run with --time-kernels 1 for the roofline of the step's launch")
         avg_ms = sum(hbm_ms) / max(len(hbm_ms), 1)
         achieved = hbm_bytes / (avg_ms * 1e-3) / 1e9 if (hbm_ms and hbm_bytes) else None
         traffic = None

@@ -25,7 +25,16 @@ from . import ops
 
 
 def supported(args, net, raw):
-    """Recurrent LSTM CommNet / IC3Net (any number of communication passes), sparse encoder bound to this env."""
+    """Recurrent LSTM CommNet / IC3Net (any number of communication passes), or the NON-recurrent CommNet module (round 4:
+    `_backward_episode_commnet`), with the sparse encoder bound to this env."""
+    if not getattr(args, 'recurrent', False):
+        if not (hasattr(net, 'f_modules') and hasattr(net, '_commnet_cache')) or getattr(net, 'continuous', False):
+            return False                                          # (models.MLP / RNN: the autograd update)
+        if not hasattr(raw, 'encode_at') or not ops.commnet_forward_supported(args.hid_size, net.nagents):
+            return False
+        if getattr(net.obs_encoder, '__self__', None) is not raw or net.nagents != raw.nagents_env:
+            return False
+        return net.encoder.weight.is_cuda and net.encoder.weight.dtype == torch.float32
     if not (getattr(args, 'recurrent', False) and getattr(args, 'rnn_type', '') == 'LSTM' and hasattr(net, 'f_module')):
         return False
     if getattr(net, 'comm_passes', 1) < 1 or args.hid_size % 4 or not hasattr(raw, 'encode_at'):
@@ -42,9 +51,14 @@ class EpisodeRecord(object):
     """What one batched episode leaves behind for the backward pass: (h, c) entering every step, the env state of every
     step, the masks of the communication block."""
 
-    def __init__(self, T, R, H, state_words, device):
-        self.hs = torch.empty((T + 1, R, H), dtype=torch.float32, device=device)     # slot t: h entering step t; slot T: h_T
-        self.cs = torch.empty((T + 1, R, H), dtype=torch.float32, device=device)
+    def __init__(self, T, R, H, state_words, device, recurrent=True):
+        self.recurrent = recurrent
+        if recurrent:
+            self.hs = torch.empty((T + 1, R, H), dtype=torch.float32, device=device)     # slot t: h entering step t; slot T: h_T
+            self.cs = torch.empty((T + 1, R, H), dtype=torch.float32, device=device)
+        else:                                  # the non-recurrent module carries no state between steps: env snapshots + masks only
+            self.hs = self.cs = None
+            self.rows, self.device = R, device
         self.snaps = torch.empty((T, state_words), dtype=torch.int32, device=device)
         self.alive = [None] * T
         self.gate = [None] * T
@@ -62,18 +76,24 @@ class EpisodeRecord(object):
         return (self.hs[t], self.cs[t])
 
     def record(self, t, net, raw, prev_hid, info):
-        h, c = prev_hid
-        R, H = self.hs.shape[1:]
-        if h.data_ptr() != self.hs[t].data_ptr():              # (in-place rollouts hand slot t itself)
-            self.hs[t].copy_(h.detach().reshape(R, H))
-            self.cs[t].copy_(c.detach().reshape(R, H))
+        if self.recurrent:
+            h, c = prev_hid
+            R, H = self.hs.shape[1:]
+            if h.data_ptr() != self.hs[t].data_ptr():          # (in-place rollouts hand slot t itself)
+                self.hs[t].copy_(h.detach().reshape(R, H))
+                self.cs[t].copy_(c.detach().reshape(R, H))
+            dev = self.hs.device
+        else:
+            R, dev = self.rows, self.device
         raw.snapshot(out=self.snaps[t])
         E = R // net.nagents
-        self.alive[t] = net._mask(info, 'alive_mask', E, self.hs.device)
-        self.gate[t] = net._mask(info, 'comm_action', E, self.hs.device) if net.args.hard_attn else None
+        self.alive[t] = net._mask(info, 'alive_mask', E, dev)
+        self.gate[t] = net._mask(info, 'comm_action', E, dev) if net.args.hard_attn else None
         self.n = t + 1
 
     def finish(self, prev_hid):
+        if not self.recurrent:
+            return
         h = prev_hid[0]
         if self.n < self.hs.shape[0] and h.data_ptr() == self.hs[self.n].data_ptr():
             self.h_last = self.hs[self.n]
@@ -142,6 +162,8 @@ def loss_gradients(args, batch):
 def backward_episode(args, net, raw, rec, d_out, acc):
     """Backward through one recorded episode; parameter gradients are ADDED into `acc` (fp32 tensors keyed like the
     fused weight cache)."""
+    if not rec.recurrent:
+        return _backward_episode_commnet(args, net, raw, rec, d_out, acc)
     if net.comm_passes > 1:
         return _backward_episode_multipass(args, net, raw, rec, d_out, acc)
     fc = net._fused_cache()
@@ -310,7 +332,77 @@ def _backward_episode_multipass(args, net, raw, rec, d_out, acc):
         acc['enc_bias'].add_(db)
 
 
+def _backward_episode_commnet(args, net, raw, rec, d_out, acc):
+    """The NON-recurrent module (comm.py:127-129,179-205,220-224):  x = tanh(encoder(obs));  h_0 = x;
+    h_{i+1} = tanh(x + f_i(h_i) + C_i(comm(h_i)));  [logits | value] = W_heads h_P + b.  No state crosses a step, so every
+    recorded step is differentiated on its own: the forward is re-evaluated from the env snapshot (sparse encoder, the masked
+    mean, library GEMMs for the H x H layers), then
+        dz_i = dh_{i+1} (1 - h_{i+1}^2);   dx += dz_i;   dF_i += dz_i^T h_i;   dC_i += dz_i^T comm_i;
+        dh_i = dz_i F_i + mix(dz_i C_i)            (the mixing matrix of the communication block is symmetric)
+    and finally d enc = (dx + dh_0)(1 - x^2) through ic3_env_encode_backward on the snapshot."""
+    cn = net._commnet_cache()
+    P = net.comm_passes
+    T, R, H = rec.n, rec.rows, net.hid_size
+    N = net.nagents
+    E = R // N
+    dev = rec.device
+    mode_avg = getattr(args, 'comm_mode', 'avg') == 'avg'
+    mask_zero = bool(args.comm_mask_zero)
+    z = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    Cw = [m.weight.detach() for m in net.C_modules]               # (H, H): y = v C^T
+    Fw = [m.weight.detach() for m in net.f_modules]
+    bias = cn['bias']                                             # (P, H) = C_i.bias + f_i.bias
+    x, enc = z(R, H), z(R, H)
+    hs = [z(R, H) for _ in range(P + 1)]
+    comm = [z(E, N, H) for _ in range(P)]
+    dz, dh, dx, tmp, mixed = z(R, H), z(R, H), z(R, H), z(R, H), z(E, N, H)
+    w_heads = cn['w_heads']
+    for t in reversed(range(T)):
+        alive, gate = rec.alive[t], rec.gate[t]
+        # ---- forward of step t again
+        raw.encode_at(rec.snaps[t], cn['wt'], cn['enc_bias'], out=enc, loc_table=cn['loc_table'])
+        torch.tanh(enc, out=x)
+        hs[0].copy_(x)
+        for i in range(P):
+            if mask_zero:
+                comm[i].zero_()
+            else:
+                ops.comm_masked_mean_raw(hs[i].view(E, N, H), alive, gate, mode_avg, True, out=comm[i])
+            torch.addmm(bias[i], hs[i], Fw[i].t(), out=tmp)       # f_i(h_i) + both biases
+            tmp.addmm_(comm[i].view(R, H), Cw[i].t())             # + C_i(comm_i)
+            torch.add(tmp, x, out=tmp)
+            torch.tanh(tmp, out=hs[i + 1])
+        # ---- backward: heads, then the passes last to first
+        d = d_out[t]
+        acc['w_heads'].addmm_(d.t(), hs[P])
+        acc['b_heads'].add_(d.sum(0))
+        torch.mm(d, w_heads, out=dh)
+        dx.zero_()
+        for i in reversed(range(P)):
+            torch.addcmul(dh, dh, hs[i + 1] * hs[i + 1], value=-1.0, out=dz)      # dh (1 - h^2)
+            dx.add_(dz)
+            acc['f_w'][i].addmm_(dz.t(), hs[i])
+            acc['cf_b'][i].add_(dz.sum(0))
+            torch.mm(dz, Fw[i], out=dh)
+            if not mask_zero:
+                acc['c_w_p'][i].addmm_(dz.t(), comm[i].view(R, H))
+                torch.mm(dz, Cw[i], out=tmp)
+                ops.comm_masked_mean_raw(tmp.view(E, N, H), alive, gate, mode_avg, True, out=mixed)
+                dh.add_(mixed.view(R, H))
+        dx.add_(dh)                                               # h_0 = x
+        torch.addcmul(dx, dx, x * x, value=-1.0, out=tmp)         # through x = tanh(enc)
+        dwt, db = raw.encode_backward(tmp, rec.snaps[t], want_bias=True)
+        acc['wt'].add_(dwt)
+        acc['enc_bias'].add_(db)
+
+
 def new_accumulators(net):
+    if not getattr(net.args, 'recurrent', False):                 # the non-recurrent module
+        cn = net._commnet_cache()
+        H, P, dev = net.hid_size, net.comm_passes, cn['wt'].device
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+        return dict(wt=z(*cn['wt'].shape), enc_bias=z(H), w_heads=z(*cn['w_heads'].shape), b_heads=z(cn['b_heads'].shape[0]),
+                    c_w_p=[z(H, H) for _ in range(P)], f_w=[z(H, H) for _ in range(P)], cf_b=[z(H) for _ in range(P)])
     fc = net._fused_cache()
     H = net.hid_size
     dev = fc['wt'].device
@@ -329,6 +421,26 @@ def assign_grads(net, acc):
         p.grad = g.reshape(p.shape).contiguous()
     put(net.encoder.weight, acc['wt'].t())
     put(net.encoder.bias, acc['enc_bias'].clone())
+    if 'f_w' in acc:                                              # the non-recurrent module: C_i, f_i per pass (+ shared modules)
+        done = {}
+        for mods, wkey in ((net.C_modules, 'c_w_p'), (net.f_modules, 'f_w')):
+            for i, m in enumerate(mods):
+                if id(m) in done:                                 # share_weights: one module, the passes' sums
+                    m.weight.grad.add_(acc[wkey][i])
+                    m.bias.grad.add_(acc['cf_b'][i])
+                else:
+                    put(m.weight, acc[wkey][i].clone())
+                    put(m.bias, acc['cf_b'][i].clone())
+                    done[id(m)] = True
+        off = 0
+        for hd in net.heads:
+            A = hd.weight.shape[0]
+            put(hd.weight, acc['w_heads'][off:off + A])
+            put(hd.bias, acc['b_heads'][off:off + A])
+            off += A
+        put(net.value_head.weight, acc['w_heads'][off:off + 1])
+        put(net.value_head.bias, acc['b_heads'][off:off + 1])
+        return
     if net.comm_passes > 1:
         done = {}
         for i, m in enumerate(net.C_modules):                             # share_weights: one module, the passes' sums

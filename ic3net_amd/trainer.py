@@ -171,7 +171,8 @@ class Trainer(object):
         self._rec = None
         if self._records is not None:                              # native update: what the backward pass needs later
             raw1 = self.env.env
-            self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size, raw1.dims.state_words, dev)
+            self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size, raw1.dims.state_words, dev,
+                                           recurrent=bool(getattr(args, 'recurrent', False)))
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
         if self._use_graph() and self._graphs and getattr(self.policy_net, '_fc', None) is not None:
@@ -332,6 +333,8 @@ class Trainer(object):
                 self._prev_hid = prev_hid
             else:
                 raw = self.env.env
+                if self._rec is not None:                          # native update: env snapshot + masks of step t
+                    self._rec.record(t, self.policy_net, raw, None, info)
                 if not torch.is_grad_enabled() and self.clock.env is raw and self.clock.env is not None \
                         and select_action is _select_action_default and not store \
                         and getattr(self.policy_net, 'commnet_step_ok', None) is not None \

@@ -467,6 +467,16 @@ def grad_fullsize_main():
               difficulty='hard', entr=0.01, value_coeff=0.01)
 
 
+def grad_nonrec_main():
+    """F5b for the NON-recurrent module (comm.py:127-129,220-224): the reference's compute_grad with
+    recurrent = False — CommNet with two communication passes, and the gated (IC3Net-style) module with shared weights."""
+    grad_case('grad_pp_medium_commnet_mlp2', 'predator_prey', 20, 3, 1, 43, closed_form=True, nagents=5, dim=10, vision=1,
+              hid_size=64, commnet=True, recurrent=False, comm_passes=2, entr=0.01, value_coeff=0.01)
+    grad_case('grad_tj_easy_ic3net_mlp2share', 'traffic_junction', 20, 3, 1, 44, closed_form=True, nagents=5, dim=6, vision=1,
+              hid_size=64, ic3net=True, recurrent=False, comm_passes=2, share_weights=True, add_rate_min=0.3, add_rate_max=0.3,
+              difficulty='easy', entr=0.01, value_coeff=0.01)
+
+
 def trainer_fullsize_main():
     """F5 at BASELINE shapes: PP-hard (configs[1]) and TJ-hard (configs[3]), IC3Net recurrent hid 128, 80 steps."""
     trainer_case('trainer_pp_hard', 'predator_prey', 80, 2, 1, 25, greedy=True, nagents=10, dim=20, vision=1,
@@ -484,6 +494,8 @@ if __name__ == '__main__':
         nonrec_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer':
         trainer_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_nonrec':
+        grad_nonrec_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_fullsize':
         grad_fullsize_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':

@@ -199,7 +199,9 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
 GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_commnet_norm", "predator_prey"),
                  ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction"),
                  # BASELINE shapes (hid 128, 80 steps, detach_gap 10), closed-form weights: configs[1] and configs[3]
-                 ("grad_pp_hard_ic3net", "predator_prey"), ("grad_tj_hard_ic3net", "traffic_junction")]
+                 ("grad_pp_hard_ic3net", "predator_prey"), ("grad_tj_hard_ic3net", "traffic_junction"),
+                 # the NON-recurrent module (comm.py:127-129,220-224): CommNet with two passes; gated, shared weights
+                 ("grad_pp_medium_commnet_mlp2", "predator_prey"), ("grad_tj_easy_ic3net_mlp2share", "traffic_junction")]
 
 
 @pytest.mark.parametrize("native", [False, True])
@@ -447,17 +449,21 @@ def test_store_states_holds_state_and_next_state(workload, E):
     assert torch.equal(got.reshape(fresh.shape), fresh)              # reset() assembled the observation of the new state
 
 
-@pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7), ("pp_hard_p2", 9), ("tj_medium_p3share", 7)])
+@pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7), ("pp_hard_p2", 9), ("tj_medium_p3share", 7),
+                                        ("tj_medium_commnet_mlp", 7), ("pp_hard_mlp", 9)])
 def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     """train_batch's default path at a BASELINE shape: the rollout is the one-launch kernel (ic3_policy_step, hid 128) and
     the gradients come from ic3net_amd.bptt — compared with loss.backward() through the autograd rollout replaying the
     same actions (trainer.py:128-225 both ways; detach_gap cuts inside the episode, entropy term on).
-    `_p2` / `_p3share`: comm_passes 2 (own C per pass) / 3 (shared C) — one launch per pass, multi-pass backward."""
+    `_p2` / `_p3share`: comm_passes 2 (own C per pass) / 3 (shared C) — one launch per pass, multi-pass backward.
+    `tj_medium_commnet_mlp` / `pp_hard_mlp`: the NON-recurrent module (round 4): rollout = ic3_commnet_step, gradients =
+    bptt._backward_episode_commnet."""
     import bench
     from ic3net_amd import trainer as trmod
     bench.WORKLOADS.setdefault("pp_hard_p2", ("predator_prey", dict(bench.WORKLOADS["pp_hard"][1], comm_passes=2)))
     bench.WORKLOADS.setdefault("tj_medium_p3share", ("traffic_junction", dict(bench.WORKLOADS["tj_medium"][1], comm_passes=3,
                                                                                share_weights=True)))
+    bench.WORKLOADS.setdefault("pp_hard_mlp", ("predator_prey", dict(bench.WORKLOADS["pp_hard"][1], recurrent=False)))
     T = 12
     extra = dict(gamma=0.95, normalize_rewards=True, entr=0.01, value_coeff=0.01, advantages_per_action=False,
                  batch_size=E * T, detach_gap=5)
@@ -467,7 +473,7 @@ def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     assert tr._native_update()
     tr._records = []
     batch, _ = tr.run_batch(0)
-    assert getattr(tr.policy_net, 'mega_steps', 0) == T, "the one-launch rollout did not run"
+    assert getattr(tr.policy_net, 'mega_steps' if a.recurrent else 'commnet_steps', 0) == T, "the one-launch rollout did not run"
     tr.optimizer.zero_grad()
     s1 = tr.compute_grad_native(batch, tr._records)
     tr._records = None
