@@ -56,7 +56,7 @@ struct CommnetArgs {
 };
 
 template <int H, int KIND = 0>
-__global__ __launch_bounds__(2 * H, 1) void commnet_forward_kernel(const CommnetArgs a)
+__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_kernel(const CommnetArgs a)
 {
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, H4 = H / 4, KB = K / 8, BM = 64;
     IC3_DYNAMIC_LDS(float, smem);

@@ -1559,6 +1559,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     if (int src = check_policy_struct(p, "ic3_policy_step")) return src;      // before any other field is read
     if (!env || !p || !h || !c) return fail(-22, "ic3_policy_step: null argument");
     const bool inner = p->inner_pass != 0;                       // a non-final communication pass: h, c only
+    // one-shot outputs armed on the handle (ic3_env_set_hidden_out): consumed by this call whatever becomes of it
+    float* const armed_h = env->h_out;
+    float* const armed_c = env->c_out;
+    if (!inner) env->h_out = env->c_out = nullptr;
     if (!inner && (!out || !action || !reward || !done)) return fail(-22, "ic3_policy_step: null argument");
     if (inner) obs = nullptr;
     if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");
@@ -1579,11 +1583,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     if (frc) return frc;
     a.h = a.h_out = h;
     a.c = a.c_out = c;
-    if (!inner && env->h_out && env->c_out) {                    // one-shot (ic3_env_set_hidden_out): the step's LAST launch
-        a.h_out = env->h_out;
-        a.c_out = env->c_out;
+    if (!inner && armed_h && armed_c) {                          // (ic3_env_set_hidden_out): the step's LAST launch
+        a.h_out = armed_h;
+        a.c_out = armed_c;
     }
-    if (!inner) env->h_out = env->c_out = nullptr;
     a.alive_in = alive_in;
     a.comm_in = comm_in;
     a.out = out;

@@ -582,3 +582,27 @@ def test_native_update_records_the_recurrent_state_in_place():
     for k in grads[0][0]:      # (the heads' gradient is one pass over the episode in place, two passes otherwise: summation order)
         g0, g1 = grads[0][0][k], grads[1][0][k]
         assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k
+
+
+def test_native_update_is_not_taken_where_it_does_not_apply():
+    """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
+    episode (the explicit backward would cross the cut) — train_batch must not take the native path there (the autograd
+    rollout then raises its explicit NotImplementedError, as before round 3); and hid sizes ic3_lstm_cell_backward does not
+    take (H / 4 not a power of two <= 64) keep the autograd update instead of failing inside it."""
+    import bench
+    from ic3net_amd import bptt
+    tr, a = bench.build_trainer('pp_hard', 8, 1, 0, 0)
+    assert tr._native_update()
+    a.auto_reset = True
+    assert not tr._native_update()
+    a.batch_size = 8 * a.max_steps
+    with pytest.raises(NotImplementedError):
+        tr.train_batch(0)
+    for hid, ok in ((96, False), (100, False), (128, True), (32, True)):
+        tr2, a2 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=hid)
+        assert bptt.supported(a2, tr2.policy_net, tr2.env.env) == ok, hid
+    tr3, a3 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=96)      # ... and the update itself runs (autograd path)
+    a3.batch_size = 8 * a3.max_steps
+    a3.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False)
+    st = tr3.train_batch(0)
+    assert np.isfinite(st['action_loss'])

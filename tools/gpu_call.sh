@@ -59,7 +59,7 @@ evidence)
   timeout 300 $B --steps 40 > /dev/null 2>&1
   timeout 600 python bench.py > $O/bench_pp_hard.json 2> $O/bench_pp_hard.err; summ $O/bench_pp_hard.json "pp_hard (default command)"
   timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_pp_hard_driver_args.json 2>/dev/null; summ $O/bench_pp_hard_driver_args.json "pp_hard --steps 20 --warmup 5"
-  for w in tj_hard tj_medium pp_easy; do timeout 300 $B --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; summ $O/bench_$w.json $w; done
+  for w in tj_hard tj_medium pp_easy tj_medium_commnet_mlp; do timeout 300 $B --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; summ $O/bench_$w.json $w; done
   timeout 600 $B --workload pp_scaled --steps 40 > $O/bench_pp_scaled.json 2> $O/bench_pp_scaled.err; summ $O/bench_pp_scaled.json pp_scaled
   timeout 300 $B --gate-split 0 > $O/bench_pp_hard_fp32_instruction.json 2>/dev/null; summ $O/bench_pp_hard_fp32_instruction.json "pp_hard --gate-split 0"
   for w in tj_hard tj_medium; do timeout 300 $B --workload $w --gate-split 0 > $O/bench_${w}_fp32_instruction.json 2>/dev/null; summ $O/bench_${w}_fp32_instruction.json "$w --gate-split 0"; done
@@ -70,7 +70,7 @@ evidence)
   cd /tmp
   S="--no-cpu-baseline --steps 40 --warmup 8"
   R=$GRAFT_REPO_ROOT
-  for w in pp_hard tj_hard tj_medium pp_scaled; do
+  for w in pp_hard tj_hard tj_medium pp_scaled tj_medium_commnet_mlp; do
     st="$S"; [ $w == pp_scaled ] && st="--no-cpu-baseline --steps 10 --warmup 4"
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_$w -- python $R/bench.py $st --workload $w > /dev/null 2>&1
     f=$(find $R/$O/kt_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/$O/bench_${w}_kernel_stats.csv
