@@ -448,10 +448,10 @@ class Trainer(object):
         self._nsteps = t + 1
 
     def _static_out(self, t, state):
-        """hipGraph mode: the launch's [log-probs | value] rows of every step index live in one static buffer — no
-        allocation inside a captured step (a pool that has to grow mid-capture invalidated the capture of step 53 in long
-        test sessions on ROCm 7.2: "operation failed due to a previous error during capture").  Eager mode: None (a fresh
-        tensor per call, a Transition keeps its action_out)."""
+        """hipGraph mode: the launch's [log-probs | value] rows of every step index live in one static buffer, so a captured
+        step allocates nothing (allocator traffic inside a capture is avoidable risk — it is what moved the failing step of
+        the garbage-collection problem described in step_episode from 53 to 66).  Eager mode: None (a fresh tensor per
+        call, a Transition keeps its action_out)."""
         if not self._use_graph():
             return None
         args = self.args

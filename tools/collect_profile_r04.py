@@ -113,5 +113,15 @@ for f, title in (('sq_counters.csv', 'SQ counters of policy_step_kernel<128, PP,
     p = os.path.join(dst, f)
     if os.path.exists(p):
         out += ["", "**%s**" % title, "", "```"] + open(p).read().strip().splitlines() + ["```"]
+out += ["", "**Other files of the round**", "",
+        "* `prefill_experiment.txt` — the obs zero fill as a launch of its own beside the policy launch (`ic3_obs_prefill`): "
+        "`tools/exp/ws_probe.hip` (a store stream without vector-ALU work beside an MFMA stream: free), every fill geometry tried, "
+        "`tools/exp/prefill_probe.py` (what the policy launch costs in its obs modes), a rocprofv3 timeline: slower than the "
+        "in-launch fill in every form (DESIGN.md section 10).",
+        "* `split_pacing_sweep.txt` — the speed-only pacing knobs of the in-launch fill re-swept with the split gate product.",
+        "* `train_batch.txt`, `train_profile.txt` — `tools/bench_train.py` lines and the kernel table of one PP-hard update.",
+        "* `host_asan.txt` — the product's `.hip` sources on the host under ASan + UBSan (`tools/host_asan.sh`), incl. round 4's "
+        "`obs_fill.hip`, `ic3_commnet_step`, `ic3_heads_grad`, `ic3_env_set_hidden_out`.",
+        "* `tests_gpu_summary.txt` — tail of `pytest -m gpu` on the final code."]
 open(os.path.join(dst, 'README.md'), 'w').write("\n".join(out) + "\n")
 print("\n".join(out[:20]))
