@@ -24,12 +24,28 @@ import torch
 from . import ops
 
 
+def _is_baseline(net):
+    from . import models
+    return isinstance(net, models.MLP)
+
+
 def supported(args, net, raw):
     """Recurrent LSTM CommNet / IC3Net (any number of communication passes), or the NON-recurrent CommNet module (round 4:
     `_backward_episode_commnet`), with the sparse encoder bound to this env."""
+    if _is_baseline(net):
+        # IC / IRIC baselines (models.MLP / models.RNN, no communication): round 4, _backward_episode_baseline
+        if args.hid_size % 4 or not hasattr(raw, 'encode_at') or getattr(net, 'continuous', False):
+            return False
+        if getattr(net.obs_encoder, '__self__', None) is not raw or args.nagents != raw.nagents_env:
+            return False
+        if getattr(args, 'recurrent', False) and getattr(args, 'rnn_type', 'MLP') == 'LSTM':
+            h4 = args.hid_size // 4
+            if h4 > 64 or h4 & (h4 - 1):                          # ic3_lstm_cell_backward
+                return False
+        return net.affine1.weight.is_cuda and net.affine1.weight.dtype == torch.float32
     if not getattr(args, 'recurrent', False):
         if not (hasattr(net, 'f_modules') and hasattr(net, '_commnet_cache')) or getattr(net, 'continuous', False):
-            return False                                          # (models.MLP / RNN: the autograd update)
+            return False
         if not hasattr(raw, 'encode_at') or not ops.commnet_forward_supported(args.hid_size, net.nagents):
             return False
         if getattr(net.obs_encoder, '__self__', None) is not raw or net.nagents != raw.nagents_env:
@@ -77,24 +93,26 @@ class EpisodeRecord(object):
 
     def record(self, t, net, raw, prev_hid, info):
         if self.recurrent:
-            h, c = prev_hid
+            h, c = prev_hid if isinstance(prev_hid, (tuple, list)) else (prev_hid, None)   # (models.RNN, rnn_type MLP: h only)
             R, H = self.hs.shape[1:]
             if h.data_ptr() != self.hs[t].data_ptr():          # (in-place rollouts hand slot t itself)
                 self.hs[t].copy_(h.detach().reshape(R, H))
-                self.cs[t].copy_(c.detach().reshape(R, H))
+                if c is not None:
+                    self.cs[t].copy_(c.detach().reshape(R, H))
             dev = self.hs.device
         else:
             R, dev = self.rows, self.device
         raw.snapshot(out=self.snaps[t])
-        E = R // net.nagents
-        self.alive[t] = net._mask(info, 'alive_mask', E, dev)
-        self.gate[t] = net._mask(info, 'comm_action', E, dev) if net.args.hard_attn else None
+        if hasattr(net, '_mask'):                              # the communication block's masks (CommNetMLP)
+            E = R // net.nagents
+            self.alive[t] = net._mask(info, 'alive_mask', E, dev)
+            self.gate[t] = net._mask(info, 'comm_action', E, dev) if net.args.hard_attn else None
         self.n = t + 1
 
     def finish(self, prev_hid):
         if not self.recurrent:
             return
-        h = prev_hid[0]
+        h = prev_hid[0] if isinstance(prev_hid, (tuple, list)) else prev_hid
         if self.n < self.hs.shape[0] and h.data_ptr() == self.hs[self.n].data_ptr():
             self.h_last = self.hs[self.n]
         else:
@@ -162,6 +180,8 @@ def loss_gradients(args, batch):
 def backward_episode(args, net, raw, rec, d_out, acc):
     """Backward through one recorded episode; parameter gradients are ADDED into `acc` (fp32 tensors keyed like the
     fused weight cache)."""
+    if _is_baseline(net):
+        return _backward_episode_baseline(args, net, raw, rec, d_out, acc)
     if not rec.recurrent:
         return _backward_episode_commnet(args, net, raw, rec, d_out, acc)
     if net.comm_passes > 1:
@@ -396,7 +416,95 @@ def _backward_episode_commnet(args, net, raw, rec, d_out, acc):
         acc['enc_bias'].add_(db)
 
 
+def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
+    """The IC / IRIC baselines of models.py:8-97 (no communication), differentiated by hand over the recorded rollout:
+      MLP  (models.py:23-34)   x1 = tanh(affine1(obs));  h = tanh(affine2(x1) + x1)         every step on its own
+      RNN  (models.py:68-92)   rnn_type 'MLP':  h_t = tanh(affine2(h_{t-1}) + affine1(obs))
+                               rnn_type 'LSTM': (h_t, c_t) = LSTMCell(affine1(obs), (h_{t-1}, c_{t-1}))
+    heads / value on h.  affine1 is the sparse encoder (ic3_env_encode_at on the step's snapshot, ic3_env_encode_backward);
+    the recurrent gradient is cut where the Trainer detaches the hidden state (trainer.py:56-60)."""
+    T, H = rec.n, args.hid_size
+    R = rec.rows if not rec.recurrent else rec.hs.shape[1]
+    dev = net.affine1.weight.device
+    z = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    wt = net.affine1.weight.detach().t().contiguous()
+    b1 = net.affine1.bias.detach()
+    w_heads = torch.cat([hd.weight for hd in net.heads] + [net.value_head.weight], 0).detach().contiguous()
+    enc, dh, dz = z(R, H), z(R, H), z(R, H)
+    recurrent = rec.recurrent
+    lstm = recurrent and getattr(args, 'rnn_type', 'MLP') == 'LSTM'
+    gap = int(getattr(args, 'detach_gap', 10000))
+    if recurrent:
+        dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
+    if lstm:
+        cell = net.lstm_unit
+        w_ih, w_hh = cell.weight_ih.detach(), cell.weight_hh.detach()
+        b_cat = (cell.bias_ih + cell.bias_hh).detach()
+        gates, dgates = z(R, 4 * H), z(R, 4 * H)
+        parts, bsum = z(ops.LSTM_BWD_MAX_PARTIALS, 4 * H), z(4 * H)
+        dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
+    elif recurrent:
+        A2 = net.affine2.weight.detach()
+    else:
+        A2, b2 = net.affine2.weight.detach(), net.affine2.bias.detach()
+        x1, hcur = z(R, H), z(R, H)
+    for t in reversed(range(T)):
+        d = d_out[t]
+        raw.encode_at(rec.snaps[t], wt, b1, out=enc)              # affine1(obs_t)
+        if not recurrent:                                         # ---- MLP
+            torch.tanh(enc, out=x1)
+            torch.addmm(b2, x1, A2.t(), out=hcur)
+            hcur.add_(x1)
+            torch.tanh(hcur, out=hcur)
+            acc['w_heads'].addmm_(d.t(), hcur)
+            acc['b_heads'].add_(d.sum(0))
+            torch.mm(d, w_heads, out=dh)
+            torch.addcmul(dh, dh, hcur * hcur, value=-1.0, out=dz)                # through the outer tanh
+            acc['a2_w'].addmm_(dz.t(), x1)
+            acc['a2_b'].add_(dz.sum(0))
+            torch.addmm(dz, dz, A2, out=dh)                                       # d x1 = dz A2 + dz (the skip)
+            torch.addcmul(dh, dh, x1 * x1, value=-1.0, out=dz)                    # through x1 = tanh(enc)
+        else:
+            if (t + 1) % gap == 0:                                # (h_t, c_t) were handed on detached
+                dh_rec.zero_()
+                if lstm:
+                    dc_rec.zero_()
+            h_prev = rec.hs[t]
+            h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
+            acc['w_heads'].addmm_(d.t(), h_t)
+            acc['b_heads'].add_(d.sum(0))
+            torch.addmm(dh_rec, d, w_heads, out=dh)
+            if lstm:                                              # ---- RNN, LSTM cell
+                torch.addmm(b_cat, enc, w_ih.t(), out=gates)
+                gates.addmm_(h_prev, w_hh.t())
+                p_ = ops.lstm_cell_backward(gates, rec.cs[t], dh, dc_rec, dgates, dc_rec, parts)   # dc_rec <- dL/dc_{t-1}
+                torch.sum(p_, 0, out=bsum)
+                acc['l_b'].add_(bsum)
+                acc['l_w_ih'].addmm_(dgates.t(), enc)
+                acc['l_w_hh'].addmm_(dgates.t(), h_prev)
+                torch.mm(dgates, w_ih, out=dz)                    # d enc
+                torch.mm(dgates, w_hh, out=dh_rec)                # dL/dh_{t-1}
+            else:                                                 # ---- RNN, tanh recurrence
+                torch.addcmul(dh, dh, h_t * h_t, value=-1.0, out=dz)
+                acc['a2_w'].addmm_(dz.t(), h_prev)
+                acc['a2_b'].add_(dz.sum(0))
+                torch.mm(dz, A2, out=dh_rec)
+        dwt, db = raw.encode_backward(dz, rec.snaps[t], want_bias=True)
+        acc['wt'].add_(dwt)
+        acc['a1_b'].add_(db)
+
+
 def new_accumulators(net):
+    if _is_baseline(net):
+        H, dev = net.args.hid_size, net.affine1.weight.device
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+        OT = sum(hd.weight.shape[0] for hd in net.heads) + 1
+        acc = dict(wt=z(net.affine1.weight.shape[1], H), a1_b=z(H), w_heads=z(OT, H), b_heads=z(OT), baseline=True)
+        if hasattr(net, 'lstm_unit'):
+            acc.update(l_w_ih=z(4 * H, H), l_w_hh=z(4 * H, H), l_b=z(4 * H))
+        else:
+            acc.update(a2_w=z(H, H), a2_b=z(H))
+        return acc
     if not getattr(net.args, 'recurrent', False):                 # the non-recurrent module
         cn = net._commnet_cache()
         H, P, dev = net.hid_size, net.comm_passes, cn['wt'].device
@@ -419,6 +527,26 @@ def assign_grads(net, acc):
     """accumulators -> .grad of the reference's parameters (state_dict names of comm.py)."""
     def put(p, g):
         p.grad = g.reshape(p.shape).contiguous()
+    if acc.get('baseline'):                                       # models.MLP / models.RNN
+        put(net.affine1.weight, acc['wt'].t())
+        put(net.affine1.bias, acc['a1_b'])
+        if 'l_b' in acc:
+            put(net.lstm_unit.weight_ih, acc['l_w_ih'])
+            put(net.lstm_unit.weight_hh, acc['l_w_hh'])
+            put(net.lstm_unit.bias_ih, acc['l_b'].clone())
+            put(net.lstm_unit.bias_hh, acc['l_b'].clone())
+        else:
+            put(net.affine2.weight, acc['a2_w'])
+            put(net.affine2.bias, acc['a2_b'])
+        off = 0
+        for hd in net.heads:
+            A = hd.weight.shape[0]
+            put(hd.weight, acc['w_heads'][off:off + A])
+            put(hd.bias, acc['b_heads'][off:off + A])
+            off += A
+        put(net.value_head.weight, acc['w_heads'][off:off + 1])
+        put(net.value_head.bias, acc['b_heads'][off:off + 1])
+        return
     put(net.encoder.weight, acc['wt'].t())
     put(net.encoder.bias, acc['enc_bias'].clone())
     if 'f_w' in acc:                                              # the non-recurrent module: C_i, f_i per pass (+ shared modules)

@@ -606,3 +606,60 @@ def test_native_update_is_not_taken_where_it_does_not_apply():
     a3.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False)
     st = tr3.train_batch(0)
     assert np.isfinite(st['action_loss'])
+
+
+@pytest.mark.parametrize("kind,rnn_type,env_name", [("mlp", "MLP", "predator_prey"), ("rnn", "MLP", "traffic_junction"),
+                                                    ("rnn", "LSTM", "predator_prey")])
+def test_native_update_of_the_baselines_matches_autograd(kind, rnn_type, env_name):
+    """IC / IRIC baselines (models.py:8-97): the graph-free update (bptt._backward_episode_baseline, round 4) against
+    loss.backward() through the autograd rollout replaying the same actions — detach_gap cuts inside the episode, entropy
+    term and reward normalisation on."""
+    from ic3net_amd import bptt, data, models, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    T, E = 12, 9
+    flags = dict(nagents=3, dim=5, vision=1, hid_size=32, recurrent=(kind == "rnn"), rnn_type=rnn_type, detach_gap=5,
+                 mean_ratio=0.5, gamma=0.95, normalize_rewards=True, entr=0.01, value_coeff=0.01)
+    if env_name == "traffic_junction":
+        flags.update(nagents=5, dim=6, difficulty='easy', add_rate_min=0.4, add_rate_max=0.4)
+
+    def make():
+        a = build_args(env_name, dict(flags), flags['nagents'], T, E, 7)
+        a.env_id_offset = 0
+        env = data.init(env_name, a, False)
+        a.num_actions, a.dim_actions, a.num_inputs = [env.num_actions], env.dim_actions, env.observation_dim
+        a.continuous = False
+        a.batch_size = E * T
+        parse_action_args(a)
+        torch.manual_seed(0)
+        net = (models.RNN if kind == "rnn" else models.MLP)(a, a.num_inputs).cuda()
+        return trmod.Trainer(a, net, env), a
+    tr, a = make()
+    assert bptt.supported(a, tr.policy_net, tr.env.env) and tr._native_update()
+    tr._records = []
+    batch, _ = tr.run_batch(0)
+    tr.optimizer.zero_grad()
+    s1 = tr.compute_grad_native(batch, tr._records)
+    tr._records = None
+    g1 = {k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None}
+    tape = torch.stack(batch.action).clone()
+    tr2, a2 = make()
+
+    def taped(args, action_out, clock, out=None):
+        out.copy_(tape[clock.t])
+        return out
+    orig = trmod.select_action
+    trmod.select_action = taped
+    try:
+        a2.rollout_grad = True
+        batch2, _ = tr2.run_batch(0)
+        tr2.optimizer.zero_grad()
+        s2 = tr2.compute_grad(batch2)
+    finally:
+        trmod.select_action = orig
+    for k in ("action_loss", "value_loss", "entropy"):
+        np.testing.assert_allclose(s1[k], s2[k], rtol=2e-4, atol=1e-4, err_msg=k)
+    g2 = {k: p.grad for k, p in tr2.policy_net.named_parameters() if p.grad is not None}
+    assert set(g1) == set(g2)
+    for k in g1:
+        scale = max(float(g2[k].abs().max()), 1e-6)
+        np.testing.assert_allclose(g1[k].cpu().numpy() / scale, g2[k].cpu().numpy() / scale, rtol=0, atol=5e-4, err_msg=k)
