@@ -107,13 +107,15 @@ extern "C" int ic3_obs_prefill(ic3_env* env, float* obs, ic3_stream stream)
     static const int plain = getenv("IC3_FILL_PLAIN") ? atoi(getenv("IC3_FILL_PLAIN")) : 0;
     env->touch_obs(obs);
     if (bytes16) {
-        static int cus = 0;
-        if (!cus) {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            IC3_HIP(hipGetDevice(&dev));
-            IC3_HIP(hipGetDeviceProperties(&prop, dev));
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        static int cus_of[64] = { 0 };                               // per device (a process may drive several GPUs)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!cus_of[dev]) {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                    cus_of[dev] = prop.multiProcessorCount;
+            }
+            if (cus_of[dev]) cus = cus_of[dev];
         }
         const unsigned long long blocks = (bytes16 + 1023ull) / 1024ull;
         if (blocks > 0x7fffffffull) return fail(-22, "ic3_obs_prefill: buffer too large for one launch");
