@@ -153,7 +153,8 @@ __device__ __forceinline__ float fast_sigmoid(float x)
 }
 __device__ __forceinline__ float fast_tanh(float x)
 {
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+    // (an explicit fma: which of mul + sub / fma the compiler picks must not depend on the code around the call)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)), 1.0f);
 }
 #endif
 

@@ -43,13 +43,28 @@ typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
 // The asm is opaque to the hazard recogniser: whoever reads the accumulator afterwards calls mfma_settle() first.
 // -DIC3_PS_TRACE: wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries into a device buffer;
 // the 40th ic3_policy_step call of the process dumps it to $IC3_PS_TRACE_OUT (tools/build_variant.sh trace -DIC3_PS_TRACE)
+// -DIC3_PS_TRACE_EPI (with IC3_PS_TRACE): slots 12..14 are three stamps INSIDE the cell epilogue (old cell state there and
+// first element done; element loop done; head weights in LDS + the remaining zero stores issued), slot 15 its closing
+// barrier; the heads / draws / env step stamps are dropped (tools/analyze_trace.py --epi).
 #ifdef IC3_PS_TRACE
-#define IC3_TR(k)                                                                                       \
+#ifdef IC3_PS_TRACE_EPI
+__device__ constexpr int ps_trace_slot(int k) { return k == 12 ? 15 : (k >= 13 && k <= 15) ? -1 : k; }
+#define IC3_TRE(j) IC3_TR_RAW(12 + (j))
+#else
+__device__ constexpr int ps_trace_slot(int k) { return k; }
+#define IC3_TRE(j) do { } while (0)
+#endif
+#define IC3_TR_RAW(k)                                                                                   \
     do {                                                                                                \
         if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 20 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+#define IC3_TR(k)                                                                                       \
+    do {                                                                                                \
+        if constexpr (ps_trace_slot(k) >= 0) IC3_TR_RAW(ps_trace_slot(k));                              \
+    } while (0)
 #else
 #define IC3_TR(k) do { } while (0)
+#define IC3_TRE(j) do { } while (0)
 #endif
 #ifndef IC3_PS_ENC_UNROLL
 #define IC3_PS_ENC_UNROLL 2   // rows of the sparse encoder gather in flight per thread
@@ -896,26 +911,41 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const __amdgpu_buffer_rsrc_t rhw = make_rsrc(a.head_w, (uint32_t)(a.OT * H * sizeof(float)));
             const ps_f32x4 hw0 = buf_load_b128(rhw, tid * 16, 0), hw1 = buf_load_b128(rhw, (tid + NT) * 16, 0);
             static_assert(16 * H4 <= 2 * NT, "head weights: two float4 per thread");
+            // The element loop, one copy per number of zero-store slots per element (workgroup-uniform): with the slot count
+            // a compile-time constant the 16 elements of a row tile are ONE basic block, and the scheduler overlaps the
+            // transcendental chains (exp -> rcp -> exp -> rcp) of neighbouring elements instead of running them end to end.
+            auto cell = [&](auto ze_c) {
+                constexpr int ZE = decltype(ze_c)::value;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                if (rt == 1 && !two) break;              // half tile: rows 32..63 are padding (their h' is never read)
+                for (int rt = 0; rt < 2; ++rt) {
+                    if (rt == 1 && !two) break;          // half tile: rows 32..63 are padding (their h' is never read)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
-                    const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
-                    const float c1 = fast_sigmoid(gf) * cold[rt][reg] + fast_sigmoid(gi) * fast_tanh(gg);
-                    const float h1 = fast_sigmoid(go) * fast_tanh(c1);
-                    if (obs_here) {                    // what the gate loop left of the zero fill goes out between the
-                        if (a.zepi > 0) zero_store();  // transcendental work of the cell (<= 2 x 32 slots, then the rest)
-                        if (a.zepi > 1) zero_store();
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                        const float gi = acc[rt][0][reg] + bi, gf = acc[rt][1][reg] + bf;
+                        const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
+                        // (explicit fma: the three copies of this loop must round alike — a*b + c*d left to the compiler
+                        //  comes out as fma(a, b, c*d), fma(c, d, a*b) or two products and a sum depending on the schedule)
+                        const float ig = fast_sigmoid(gi) * fast_tanh(gg);
+                        const float c1 = __builtin_fmaf(fast_sigmoid(gf), cold[rt][reg], ig);
+                        const float h1 = fast_sigmoid(go) * fast_tanh(c1);
+                        // what the gate loop left of the zero fill goes out between the transcendental work of the cell
+                        // (<= 2 x 32 slots, then the rest)
+                        if constexpr (ZE > 0) zero_store();
+                        if constexpr (ZE > 1) zero_store();
+                        const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
+                        As[lr * LDA + H + col] = h1;
+                        if (rt == 0 && reg == 0) IC3_TRE(0);
                     }
-                    const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
-                    As[lr * LDA + H + col] = h1;
                 }
-            }
+            };
+            const int ze = obs_here ? a.zepi : 0;
+            if (ze <= 0) cell(std::integral_constant<int, 0>{});
+            else if (ze == 1) cell(std::integral_constant<int, 1>{});
+            else cell(std::integral_constant<int, 2>{});
+            IC3_TRE(1);
             if (tid < a.OT * H4) As4[(tid / H4) * LDA4 + tid % H4] = hw0;
             if (tid + NT < a.OT * H4) As4[((tid + NT) / H4) * LDA4 + (tid + NT) % H4] = hw1;
             if (obs_here && !a.obs_incr && !a.obs_prefilled) {
@@ -933,6 +963,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 if (tid < g.ohead) a.obs[g.ob0 + tid] = 0.f;
                 if (tid < otail) a.obs[g.ob0 + g.ohead + 4 * (long long)g.onb + tid] = 0.f;
             }
+            IC3_TRE(2);
         }
         __syncthreads();
         IC3_TR(12);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-tile phase timeline of policy_step_kernel from an IC3_PS_TRACE build (see policy_step.hip):
-python tools/analyze_trace.py trace.csv  — s_memrealtime ticks are 10 ns."""
+python tools/analyze_trace.py trace.csv [--epi]  — s_memrealtime ticks are 10 ns.  --epi: a -DIC3_PS_TRACE_EPI build (three
+stamps inside the cell epilogue instead of the heads / draws / env step stamps)."""
 import sys
 
 import numpy as np
@@ -11,7 +12,14 @@ NAMES = ["start", "S0 loads", "S1 desc", "S2 enc + S4 h->LDS", "S3 enc->acc+c ld
          "S12 env step", "patch wait", "patches"]
 
 
-def main(path):
+NAMES_EPI = NAMES[:12] + ["S9a c_old there, 1st element", "S9b elements", "S9c head W->LDS, rest of fill", "S9d barrier",
+                         "S10-12 heads, draws, env step, patch wait", "patches"]
+
+
+def main(path, epi=False):
+    global NAMES
+    if epi:
+        NAMES = NAMES_EPI
     d = np.loadtxt(path, delimiter=',', dtype=np.int64)
     t = d[:, 1:19].astype(np.float64) * 0.01          # us
     hw, xcc = d[:, 19], d[:, 20]
@@ -56,4 +64,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], '--epi' in sys.argv[2:])
