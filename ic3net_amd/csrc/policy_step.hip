@@ -217,6 +217,17 @@ __device__ __forceinline__ void ps_split_pair(ps_f32x2 x, unsigned& p1, unsigned
     p2 = __builtin_bit_cast(unsigned, h2);
     p3 = __builtin_bit_cast(unsigned, h3);
 }
+// The same split in stages, for the gate loop's software pipeline: the most significant plane of a pair, then
+// `r -= float(h)` and the next plane of what is left (ps_split_pair = ps_hi_pair, ps_next_pair, ps_next_pair).
+__device__ __forceinline__ unsigned ps_hi_pair(ps_f32x2 x)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, ps_bf16x2));
+}
+__device__ __forceinline__ unsigned ps_next_pair(ps_f32x2& r, unsigned h)
+{
+    r = r - __builtin_convertvector(__builtin_bit_cast(ps_bf16x2, h), ps_f32x2);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(r, ps_bf16x2));
+}
 __device__ __forceinline__ void ps_split_frag(ps_f32x4 x0, ps_f32x4 x1, ps_u32x4 (&out)[3])
 {
     unsigned p[3][4];
@@ -679,36 +690,77 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 constexpr int S = decltype(s_c)::value;
                 constexpr bool REFILL = decltype(refill_c)::value;
                 constexpr bool LOADC = decltype(loadc_c)::value;
+                // Activation split in three stages around the products of the FIRST weight plane group: the most significant
+                // plane of the 8 (4) value pairs, then that group's products pass by pass (most significant activation
+                // plane first) with the next plane of two (one) pairs computed behind each pair of MFMAs — 4 vector
+                // instructions per pair in the shadow of a 32-cycle MFMA instead of 72 (36) in front of the block's first.
+                // The other two groups run fragment by fragment, least significant activation plane first, as before.
+                constexpr int NRT = TWO ? 2 : 1;
                 ps_u32x4 ap[2][3];
+                ps_f32x2 xr[2][4];                                   // the raw values, then what the planes so far leave
                 {
                     const ps_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
-                    ps_split_frag(s0[0], s0[1], ap[0]);
+                    const ps_f32x4 x0 = s0[0], x1 = s0[1];
+                    xr[0][0] = ps_f32x2{ x0[0], x0[1] }, xr[0][1] = ps_f32x2{ x0[2], x0[3] };
+                    xr[0][2] = ps_f32x2{ x1[0], x1[1] }, xr[0][3] = ps_f32x2{ x1[2], x1[3] };
                     if constexpr (TWO) {
                         const ps_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
-                        ps_split_frag(s1[0], s1[1], ap[1]);
+                        const ps_f32x4 y0 = s1[0], y1 = s1[1];
+                        xr[1][0] = ps_f32x2{ y0[0], y0[1] }, xr[1][1] = ps_f32x2{ y0[2], y0[3] };
+                        xr[1][2] = ps_f32x2{ y1[0], y1[1] }, xr[1][3] = ps_f32x2{ y1[2], y1[3] };
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ap[rt][0][q] = ps_hi_pair(xr[rt][q]);
+                }
+                auto products = [&](int pa, int pb, int gt) {
+                    acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(ps_bf16x8, ap[0][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[0][gt], 0, 0, 0);
+                    if constexpr (TWO)
+                        acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(ps_bf16x8, ap[1][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[1][gt], 0, 0, 0);
+                };
+                auto slot = [&](int i) {                              // (folded after unrolling)
+                    if (ps_zslot36(S, i)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        zero_store();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+#pragma unroll
+                for (int pa = 0; pa < 3; ++pa) {                      // weight plane group 0, activation planes 0, 1, 2
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) {
+                        products(pa, 0, gt);
+                        slot(pa * 4 + gt);
+                        if (pa < 2) {
+#pragma unroll
+                            for (int j = 0; j < NRT; ++j) {
+                                const int rt = (gt * NRT + j) >> 2, q = (gt * NRT + j) & 3;
+                                ap[rt][pa + 1][q] = ps_next_pair(xr[rt][q], ap[rt][pa][q]);
+                            }
+                        } else if constexpr (REFILL) {
+                            bq[0][gt] = wq3(0, kb + 1, gt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb) {
+                    if (pb > 0) {
 #pragma unroll
-                    for (int gt = 0; gt < 4; ++gt) {
-                        // the six products of ONE weight fragment back to back (three activation terms, least significant
-                        // first, two row tiles), then its refill: 11 fragments x 6 MFMAs of lead instead of 2 plane groups
+                        for (int gt = 0; gt < 4; ++gt) {
+                            // the six products of ONE weight fragment back to back (three activation terms, least
+                            // significant first, two row tiles), then its refill: 11 fragments x 6 MFMAs of lead
 #pragma unroll
-                        for (int pa = 2; pa >= 0; --pa) {
-                            acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(ps_bf16x8, ap[0][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[0][gt], 0, 0, 0);
-                            if constexpr (TWO)
-                                acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(ps_bf16x8, ap[1][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[1][gt], 0, 0, 0);
-                            if (ps_zslot36(S, (pb * 4 + gt) * 3 + (2 - pa))) {
-                                __builtin_amdgcn_sched_barrier(0);
-                                zero_store();
-                                __builtin_amdgcn_sched_barrier(0);
+                            for (int pa = 2; pa >= 0; --pa) {
+                                products(pa, pb, gt);
+                                slot((pb * 4 + gt) * 3 + (2 - pa));
                             }
+                            if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt);
-                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (LOADC) {                            // 11 + 11 + 10 old cell states behind the three plane groups
 #pragma unroll
@@ -1180,8 +1232,22 @@ __global__ __launch_bounds__(2 * H) void gate_product_probe_kernel(const float* 
             ps_split_frag(s0[0], s0[1], ap[0]);
             const ps_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
             ps_split_frag(s1[0], s1[1], ap[1]);
+            // (product order of block3: weight plane group 0 pass by pass, most significant activation plane first; groups
+            //  1 and 2 fragment by fragment, least significant activation plane first)
+            ps_u32x4 bq0[4];
 #pragma unroll
-            for (int pb = 0; pb < 3; ++pb)
+            for (int gt = 0; gt < 4; ++gt)
+                bq0[gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, (kb * 4 + gt) * GSTRIDE, 0);
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc[rt][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(ps_bf16x8, ap[rt][pa]), __builtin_bit_cast(ps_bf16x8, bq0[gt]), acc[rt][gt], 0, 0, 0);
+#pragma unroll
+            for (int pb = 1; pb < 3; ++pb)
 #pragma unroll
                 for (int gt = 0; gt < 4; ++gt) {
                     const ps_u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pb * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
