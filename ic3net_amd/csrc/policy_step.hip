@@ -66,6 +66,15 @@ __device__ constexpr int ps_trace_slot(int k) { return k; }
 #define IC3_TR(k) do { } while (0)
 #define IC3_TRE(j) do { } while (0)
 #endif
+// Wave priority: 3 in the phases in front of the gate loop (short dependent chains of loads, LDS exchanges and barriers
+// whose every instruction is on the tile's critical path), 0 from the gate loop on — the co-resident workgroup's MFMA
+// stream gives up an issue slot now and then, the phases stop queueing behind it (measured on one box, round 4:
+// TJ-hard +2.3 %, TJ-medium +1.7 %, PP-hard +0.6 %; also raising the epilogue or the phases behind it: no further gain;
+// the reverse: -1.5 %).  IC3_PS_PRIO_MASK (variant builds): 1 = front, 2 = cell epilogue, 4 = behind the epilogue.
+#ifndef IC3_PS_PRIO_MASK
+#define IC3_PS_PRIO_MASK 1
+#endif
+#define IC3_PRIO_AT(bit) __builtin_amdgcn_s_setprio(((IC3_PS_PRIO_MASK) & (bit)) ? 3 : 0)
 #ifndef IC3_PS_ENC_UNROLL
 #define IC3_PS_ENC_UNROLL 2   // rows of the sparse encoder gather in flight per thread
 #endif
@@ -225,7 +234,12 @@ __device__ __forceinline__ unsigned ps_hi_pair(ps_f32x2 x)
 }
 __device__ __forceinline__ unsigned ps_next_pair(ps_f32x2& r, unsigned h)
 {
+#ifdef IC3_PS_SCALAR_SUB   // variant build: two v_sub_f32 instead of one v_pk_add_f32 (needs -fno-slp-vectorize to stay that way)
+    r[0] = r[0] - __builtin_bit_cast(float, h << 16);
+    r[1] = r[1] - __builtin_bit_cast(float, h & 0xffff0000u);
+#else
     r = r - __builtin_convertvector(__builtin_bit_cast(ps_bf16x2, h), ps_f32x2);
+#endif
     return __builtin_bit_cast(unsigned, __builtin_convertvector(r, ps_bf16x2));
 }
 __device__ __forceinline__ void ps_split_frag(ps_f32x4 x0, ps_f32x4 x1, ps_u32x4 (&out)[3])
@@ -336,6 +350,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const StepArgs& a = a_in;
         const int tid = threadIdx.x;
         IC3_TR(0);
+        IC3_PRIO_AT(1);
 #ifdef IC3_PS_TRACE
         if (a.trace && tid == 0) {
             a.trace[(size_t)blockIdx.x * 20 + 18] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             __syncthreads();
             IC3_TR(8);
+            IC3_PRIO_AT(0);
             const __amdgpu_buffer_rsrc_t rc_old = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
             const int voff_old = (4 * lh * H + col) * 4;
             auto block3 = [&](auto two_c, auto s_c, auto refill_c, auto loadc_c, int kb) {
@@ -749,6 +765,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb) {
                     if (pb > 0) {
+#ifdef IC3_PS_PAIRFRAG   // variant build: two fragments at a time — an accumulator comes round every fourth MFMA, not every second
+#pragma unroll
+                        for (int gt = 0; gt < 4; gt += 2) {
+#pragma unroll
+                            for (int pa = 2; pa >= 0; --pa) {
+                                products(pa, pb, gt);
+                                slot((pb * 4 + gt) * 3 + 2 * (2 - pa));
+                                products(pa, pb, gt + 1);
+                                slot((pb * 4 + gt) * 3 + 2 * (2 - pa) + 1);
+                            }
+                            if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt), bq[pb][gt + 1] = wq3(pb, kb + 1, gt + 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#else
 #pragma unroll
                         for (int gt = 0; gt < 4; ++gt) {
                             // the six products of ONE weight fragment back to back (three activation terms, least
@@ -761,6 +791,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                             if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+#endif
                     }
                     if constexpr (LOADC) {                            // 11 + 11 + 10 old cell states behind the three plane groups
 #pragma unroll
@@ -840,6 +871,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             __syncthreads();
             IC3_TR(8);
+            IC3_PRIO_AT(0);
 
             // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
             // `SB` = first ring slot of this K block, REFILL = the ring is refilled for block kb + RING / 4.  The compiler's
@@ -904,6 +936,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             else gate_loop_s(std::false_type{});
         }
         IC3_TR(9);
+        IC3_PRIO_AT(2);
         mfma_settle();
         IC3_TR(10);
     }
@@ -1019,6 +1052,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         __syncthreads();
         IC3_TR(12);
+        IC3_PRIO_AT(4);
         if ((ABL & 8) || a.inner) return;   // (uniform)
 
         // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of

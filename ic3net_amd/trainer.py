@@ -369,6 +369,17 @@ class Trainer(object):
             self._info = info
             self._nsteps = t + 1
 
+    @staticmethod
+    def _step_timer(raw):
+        """The list the one-launch step appends its (start, stop, t) HIP events to, or None: `raw.step_timer` on every
+        `raw.step_timer_every`-th call (bench.py: stamping both events costs ~10 us per launch, so it samples)."""
+        timer = getattr(raw, 'step_timer', None)
+        if timer is None:
+            return None
+        tick = getattr(raw, '_step_timer_tick', 0)
+        raw._step_timer_tick = tick + 1
+        return timer if tick % max(1, int(getattr(raw, 'step_timer_every', 1))) == 0 else None
+
     def _step_body_mega(self, t, observe):
         """The same iteration as _step_body through CommNetMLP.step_env (ic3_policy_step): policy forward, the action
         draws of every head and env.step are ONE launch; the obs-assembly launch follows when `observe`."""
@@ -376,7 +387,7 @@ class Trainer(object):
         raw = self.env.env
         store = bool(getattr(args, 'store_states', False))
         cur_state = state.clone() if store else None
-        timer = getattr(raw, 'step_timer', None)                   # bench: HIP events around the one launch
+        timer = self._step_timer(raw)                              # bench: HIP events around the one launch
         stamped = timer is not None and getattr(raw, 'dispatch_events', False)
         if stamped:                                                # ... stamped by the dispatch itself
             from .envs import DispatchEvent
@@ -476,7 +487,7 @@ class Trainer(object):
         rows of the state acted on are ONE launch."""
         args, buf, state, info = self.args, self._buf, self._state, self._info
         raw = self.env.env
-        timer = getattr(raw, 'step_timer', None)                   # bench: HIP events stamped by the dispatch of the launch
+        timer = self._step_timer(raw)                              # bench: HIP events stamped by the dispatch of the launch
         if timer is not None:
             from .envs import DispatchEvent
             e0, e1 = DispatchEvent(), DispatchEvent()
