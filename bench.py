@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6300.0     # MI355X_MICROARCH.md, HBM section: ~6.3 TB/s achievable (context, not the roofline's peak)
+HBM_WRITE_STREAM_GBS = 5300.0   # a store stream alone on this chip, measured three ways in round 4 (see roofline.achievable.source)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (f32 in / f32 acc), same guide
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak (no sparsity), same guide
 
@@ -560,6 +562,20 @@ def main():
                               "run)" if traffic is not None else None,
             "bytes_per_launch": hbm_bytes, "obs_bytes_per_launch": obs_bytes if not o.no_dense_obs else 0,
             "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms), "note": roof_note}
+        if roofline is not None and fused_obs and achieved is not None and not fill_ms and not o.incremental_obs:
+            # context next to `frac` (which stays algorithmic bytes / the 8 TB/s spec peak): what this chip was measured to
+            # take.  The guide's achievable figure is a read stream; the launch is ~94 % writes, and a store stream alone
+            # (tools/exp/ws_probe.hip, ic3_obs_prefill alone, the obs-dominated pp_scaled launch) tops out at 5.3 TB/s.
+            R_ = o.nenvs * N
+            written = obs_bytes + R_ * ((2 * a.hid_size if a.recurrent else 0) + sum(int(x) for x in a.naction_heads) + 1
+                                        + 2 * len(a.naction_heads) + 1) * 4
+            roofline["achievable"] = {
+                "hbm_achievable_GBps_guide": HBM_ACHIEVABLE_GBS, "frac_of_guide_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+                "written_bytes_per_launch": written,
+                "write_stream_ceiling_GBps_measured": HBM_WRITE_STREAM_GBS,
+                "written_frac_of_write_ceiling": round(written / (avg_ms * 1e-3) / 1e9 / HBM_WRITE_STREAM_GBS, 4),
+                "source": "MI355X_MICROARCH.md (8 TB/s spec, ~6.3 TB/s achievable); write stream alone 5.3 TB/s: "
+                          "profiles/r04/prefill_experiment.txt section 1, profiles/r04/bench_pp_scaled.json"}
         out = {
             "metric": "env-steps/sec (agents x envs x steps), rollout hot path",
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,

@@ -55,9 +55,18 @@ struct CommnetArgs {
     TJState tj;
 };
 
+// Wave priority (policy_step.hip: the phases around a matrix product are dependent chains on the tile's critical path, the
+// product is throughput work): 3 outside the [comm | h] product, 0 inside.  -DIC3_CN_NO_PRIO: variant build without it.
+#ifdef IC3_CN_NO_PRIO
+#define CN_PRIO(p) do { } while (0)
+#else
+#define CN_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 template <int H, int KIND = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_kernel(const CommnetArgs a)
 {
+    CN_PRIO(3);
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, H4 = H / 4, KB = K / 8, BM = 64;
     IC3_DYNAMIC_LDS(float, smem);
     float* const As = smem;                                      // [BM][LDA]: cols [0,H) comm, [H,2H) h
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
         cn_f32x4 cb[2][CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) cb[0][k] = wp[(size_t)k * H * 2];
+        CN_PRIO(0);                                              // (the phases around the product run at priority 3)
 #pragma unroll 1
         for (int ch = 0; ch < KB / CH; ch += 2) {
 #pragma unroll
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                 }
             }
         }
+        CN_PRIO(3);
         __syncthreads();                                         // every wave has read the old h
         // ---- h' = tanh(x + F h + C comm + biases) -> h half (comm.py:222-224) ------------------------------------------------
         const float b = a.bias[pass * H + col];
