@@ -75,6 +75,9 @@ __device__ constexpr int ps_trace_slot(int k) { return k; }
 #define IC3_PS_PRIO_MASK 1
 #endif
 #define IC3_PRIO_AT(bit) __builtin_amdgcn_s_setprio(((IC3_PS_PRIO_MASK) & (bit)) ? 3 : 0)
+#ifndef IC3_PS_ZSTORE_AUX
+#define IC3_PS_ZSTORE_AUX 2   // cache policy of the obs zero stores: nt (variant builds: 3 = sc0 nt, 18 = sc1 nt, 19 = sc0 sc1 nt)
+#endif
 #ifndef IC3_PS_ENC_UNROLL
 #define IC3_PS_ENC_UNROLL 2   // rows of the sparse encoder gather in flight per thread
 #endif
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #ifdef IC3_PS_PLAIN_STORES
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, 0);
 #else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, 2);   // nt
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, IC3_PS_ZSTORE_AUX);
 #endif
         zso += NW * 1024;
     };
