@@ -481,7 +481,9 @@ def main():
         t_in_ep, dt, host_dt, obs_ms, step_all, live_steps = timed_region(t_in_ep)
         # (every N-th step launch is event-timed: the launches of the region = their mean x the steps)
         launch_sum = (sum(ms for ms, _ in step_all) / len(step_all) * o.steps if step_all else 0.0) + sum(obs_ms)
-        consistent = (not step_all) or abs(dt * 1e3 - launch_sum) <= 0.10 * dt * 1e3
+        # (tolerance: 10 % of the wall time, or the 15 us per step that the gap between two dependent launches can cost —
+        #  the larger; a 70 us launch such as PP-easy's is otherwise flagged for its launch gaps alone)
+        consistent = (not step_all) or abs(dt * 1e3 - launch_sum) <= max(0.10 * dt * 1e3, 0.015 * o.steps)
         attempts.append(dict(ms_per_step=round(dt / o.steps * 1e3, 4), launches_ms=round(launch_sum / o.steps, 4),
                              consistent=bool(consistent)))
         all_ok = consistent
@@ -621,7 +623,7 @@ def main():
         }
         if not attempts[-1]["consistent"]:
             out["timing_inconsistent"] = True     # no attempt had wall clock and device clock agree: not a valid headline
-            sys.stderr.write("bench.py: wall clock and event-timed launches disagree by more than 10 %% in all %d "
+            sys.stderr.write("bench.py: wall clock and event-timed launches disagree by more than max(10 %%, 15 us per step) in all %d "
                              "attempts: %r\n" % (len(attempts), attempts))
         print(json.dumps(out))
     if use_dist:

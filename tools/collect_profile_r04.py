@@ -119,6 +119,11 @@ out += ["", "**Other files of the round**", "",
         "`tools/exp/prefill_probe.py` (what the policy launch costs in its obs modes), a rocprofv3 timeline: slower than the "
         "in-launch fill in every form (DESIGN.md section 10).",
         "* `split_pacing_sweep.txt` — the speed-only pacing knobs of the in-launch fill re-swept with the split gate product.",
+        "* `ab_runs.txt` — the second half of the round: variant libraries A/B on one box per call (cell epilogue, staged "
+        "activation split, wave priority by phase, what had no effect, what stamping HIP events on every launch costs).",
+        "* `phase_trace_pp_hard.txt`, `phase_trace_tj_hard.txt` — per-tile phase timeline of the final kernel "
+        "(`tools/build_variant.sh trace -DIC3_PS_TRACE`, `tools/analyze_trace.py`); `phase_trace_epilogue_*.txt`: the "
+        "`-DIC3_PS_TRACE_EPI` build's stamps inside the cell epilogue.",
         "* `train_batch.txt`, `train_profile.txt` — `tools/bench_train.py` lines and the kernel table of one PP-hard update.",
         "* `host_asan.txt` — the product's `.hip` sources on the host under ASan + UBSan (`tools/host_asan.sh`), incl. round 4's "
         "`obs_fill.hip`, `ic3_commnet_step`, `ic3_heads_grad`, `ic3_env_set_hidden_out`.",
