@@ -95,7 +95,11 @@ class EpisodeRecord(object):
         if self.recurrent:
             h, c = prev_hid if isinstance(prev_hid, (tuple, list)) else (prev_hid, None)   # (models.RNN, rnn_type MLP: h only)
             R, H = self.hs.shape[1:]
-            if h.data_ptr() != self.hs[t].data_ptr():          # (in-place rollouts hand slot t itself)
+            if h.shape[-1] != H:                               # a zero-padded twin's record, an (R, hid_size) state
+                self._put(self.hs[t], h)
+                if c is not None:
+                    self._put(self.cs[t], c)
+            elif h.data_ptr() != self.hs[t].data_ptr():        # (in-place rollouts hand slot t itself)
                 self.hs[t].copy_(h.detach().reshape(R, H))
                 if c is not None:
                     self.cs[t].copy_(c.detach().reshape(R, H))
@@ -109,11 +113,20 @@ class EpisodeRecord(object):
             self.gate[t] = net._mask(info, 'comm_action', E, dev) if net.args.hard_attn else None
         self.n = t + 1
 
+    @staticmethod
+    def _put(slot, x):
+        """slot (R, wide) <- x (R, narrower), zero beyond"""
+        slot.zero_()
+        slot[:, :x.shape[-1]].copy_(x.detach().reshape(slot.shape[0], x.shape[-1]))
+
     def finish(self, prev_hid):
         if not self.recurrent:
             return
         h = prev_hid[0] if isinstance(prev_hid, (tuple, list)) else prev_hid
-        if self.n < self.hs.shape[0] and h.data_ptr() == self.hs[self.n].data_ptr():
+        if h.shape[-1] != self.hs.shape[2]:
+            self.h_last = torch.empty_like(self.hs[0])
+            self._put(self.h_last, h)
+        elif self.n < self.hs.shape[0] and h.data_ptr() == self.hs[self.n].data_ptr():
             self.h_last = self.hs[self.n]
         else:
             self.h_last = h.detach().reshape(self.hs.shape[1:]).clone()

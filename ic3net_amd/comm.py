@@ -19,6 +19,24 @@ from . import ops
 DEFAULT_GATE_SPLIT = True     # (tests run the policy parity set in both modes by flipping this)
 
 
+class _PaddedArgs(object):
+    """The args of a policy, read live, with another hid_size (CommNetMLP._twin)."""
+
+    def __init__(self, base, hid_size):
+        object.__setattr__(self, '_base', base)
+        object.__setattr__(self, '_hid_size', int(hid_size))
+
+    def __getattr__(self, k):                                    # (only reached for names not set on the proxy itself)
+        return getattr(object.__getattribute__(self, '_base'), k)
+
+    def __setattr__(self, k, v):
+        setattr(object.__getattribute__(self, '_base'), k, v)
+
+    @property
+    def hid_size(self):
+        return object.__getattribute__(self, '_hid_size')
+
+
 class CommNetMLP(nn.Module):
     def __init__(self, args, num_inputs):
         super(CommNetMLP, self).__init__()
@@ -80,6 +98,9 @@ class CommNetMLP(nn.Module):
 
     def forward(self, x, info={}):
         n, H = self.nagents, self.hid_size
+        tw = self._twin_for(x)
+        if tw is not None:
+            return self._forward_twin(tw, x, info)
         if self._fused_ok(x):
             return self._forward_fused(x, info)
         if self._commnet_ok(x):
@@ -109,6 +130,147 @@ class CommNetMLP(nn.Module):
         if self.args.recurrent:
             return action, value_head, (hidden_state.clone(), cell_state.clone())
         return action, value_head
+
+    # ------------------------------------------------------------------------------------------
+    # Hidden sizes the one-launch kernels are not built for (they exist for 64 / 128 / 256; main.py:34 takes any int):
+    # during no-grad rollouts the policy runs as its ZERO-PADDED TWIN at the next such size.  Exact, not approximate: a
+    # padded hidden unit has zero encoder / C / LSTM weights and biases, so its gate pre-activations are 0, its cell
+    # state stays 0.5 * 0 + 0.5 * tanh(0) = 0, its output o * tanh(0) = 0, and the zero columns of the weights that read
+    # it contribute nothing to any real unit, head or value.  The twin is a CommNetMLP of its own (not a submodule: its
+    # tensors are derived data like the packed weights of _fused_cache, refreshed in place when a parameter's version
+    # changes); callers keep seeing (R, hid_size) hidden states — views of the twin's (R, padded) buffers.  The update
+    # half of such a policy takes the autograd path (bptt.supported() is False for it).
+    # ------------------------------------------------------------------------------------------
+    def _twin(self):
+        a = self.args
+        Hp = ops.padded_hidden(self.hid_size)
+        if Hp is None or not (getattr(a, 'pad_hidden', True) and getattr(a, 'fused_policy', True)
+                              and getattr(a, 'mega_policy', True)) or len(self.heads) > 4:
+            return None
+        if a.recurrent and getattr(a, 'rnn_type', '') != 'LSTM':
+            return None
+        if not self.encoder.weight.is_cuda or self.encoder.weight.dtype != torch.float32:
+            return None
+        tw = self._padded_twin(Hp)
+        tw.obs_encoder, tw.obs_table, tw.obs_env, tw.sample_into = self.obs_encoder, self.obs_table, self.obs_env, self.sample_into
+        return tw
+
+    def _padded_twin(self, Hp):
+        """The twin at hidden size Hp, its parameters up to date with this policy's (any device)."""
+        a = self.args
+        box = self.__dict__.get('_twin_box')
+        dev, dt = self.encoder.weight.device, self.encoder.weight.dtype
+        if box is None or box[0].encoder.weight.device != dev or box[0].encoder.weight.dtype != dt or box[0].hid_size != Hp:
+            tw = CommNetMLP(_PaddedArgs(a, Hp), self.encoder.in_features).to(device=dev, dtype=dt)
+            for q in tw.parameters():
+                q.requires_grad_(False)
+                q.zero_()
+            box = self.__dict__['_twin_box'] = [tw, None]        # (a list: not registered as a submodule)
+        tw = box[0]
+        key = tuple((q._version, q.data_ptr()) for q in self.parameters())
+        if box[1] != key:
+            H = self.hid_size
+            with torch.no_grad():
+                mine, theirs = dict(self.named_parameters()), dict(tw.named_parameters())
+                assert mine.keys() == theirs.keys()
+                for name, src in mine.items():
+                    dst = theirs[name]
+                    if name.startswith('hidd_encoder.'):
+                        continue                                  # unused by forward (quirk Q18)
+                    if a.recurrent and name.startswith('f_module.'):       # LSTMCell: four gate blocks of H rows
+                        if src.dim() == 2:
+                            dst.view(4, Hp, Hp)[:, :H, :H].copy_(src.view(4, H, H))
+                        else:
+                            dst.view(4, Hp)[:, :H].copy_(src.view(4, H))
+                    elif name.startswith('heads.') or name.startswith('value_head.'):
+                        if src.dim() == 2:
+                            dst[:, :H].copy_(src)
+                        else:
+                            dst.copy_(src)
+                    elif name.startswith('encoder.'):
+                        dst[:H].copy_(src)
+                    elif src.dim() == 2:                          # C_module(s), the non-recurrent f_module(s): H x H
+                        dst[:H, :H].copy_(src)
+                    else:
+                        dst[:H].copy_(src)
+            box[1] = key
+        return tw
+
+    def _twin_for(self, x):
+        if torch.is_grad_enabled():
+            return None
+        x0 = x[0] if isinstance(x, (list, tuple)) else x
+        if not (torch.is_tensor(x0) and x0.is_cuda):
+            return None
+        return self._twin()
+
+    def _twin_done(self, tw):
+        """mirror what callers read off the policy after a call"""
+        for k in ('mega_steps', 'mega_forwards', 'commnet_steps', 'commnet_forwards', 'cache_generation'):
+            if k in tw.__dict__:
+                self.__dict__[k] = tw.__dict__[k]
+        self.sampled = tw.sampled
+        if getattr(tw, '_fc', None) is not None:
+            self.__dict__['_fc'] = tw._fc
+
+    def _twin_hidden(self, tw, hidden_state, cell_state, R):
+        """The caller's hidden state as the twin takes it: (h, c, wide).  A state that already has the twin's width (the
+        native update's episode record, trainer.py) passes through (wide = True); an (R, hid_size) state goes into the
+        twin's (R, padded) buffers — without a copy when it is the views a previous call returned."""
+        H, Hp = self.hid_size, tw.hid_size
+        if hidden_state.shape[-1] == Hp:
+            return hidden_state, cell_state, True
+        mb = getattr(tw, '_mb', None)
+        dev = hidden_state.device
+        if mb is None or mb['h'].shape[0] != R or mb['h'].device != dev:
+            mb = tw._mb = dict(h=torch.zeros((R, Hp), dtype=torch.float32, device=dev),
+                               c=torch.zeros((R, Hp), dtype=torch.float32, device=dev))
+        for src, k in ((hidden_state, 'h'), (cell_state, 'c')):
+            buf = mb[k]
+            if src.data_ptr() == buf.data_ptr() and tuple(src.shape) == (R, H) and src.stride() == (Hp, 1):
+                continue
+            buf.zero_()
+            buf[:, :H].copy_(src.detach().reshape(R, H))
+        return mb['h'], mb['c'], False
+
+    def _twin_state_out(self, hc, wide):
+        return tuple(hc) if wide else (hc[0][:, :self.hid_size], hc[1][:, :self.hid_size])
+
+    def kernel_module(self):
+        """The module the one-launch kernels and the native update (bptt) run: this policy, or its zero-padded twin."""
+        tw = self._twin()
+        return self if tw is None else tw
+
+    def unpad_grads(self):
+        """After a native update on the twin: p.grad of every parameter <- its region of the twin's gradient (the padded
+        rows / columns of the twin's gradients are exactly zero)."""
+        tw = self.__dict__['_twin_box'][0]
+        H, Hp = self.hid_size, tw.hid_size
+        theirs = dict(tw.named_parameters())
+        for name, p in self.named_parameters():
+            g = theirs[name].grad
+            if g is None or name.startswith('hidd_encoder.'):
+                p.grad = None
+            elif self.args.recurrent and name.startswith('f_module.'):
+                p.grad = (g.view(4, Hp, Hp)[:, :H, :H] if g.dim() == 2 else g.view(4, Hp)[:, :H]).reshape(p.shape).clone()
+            elif name.startswith('heads.') or name.startswith('value_head.'):
+                p.grad = (g[:, :H] if g.dim() == 2 else g).clone()
+            elif name.startswith('encoder.'):
+                p.grad = g[:H].clone()
+            else:
+                p.grad = (g[:H, :H] if g.dim() == 2 else g[:H]).clone()
+            theirs[name].grad = None
+
+    def _forward_twin(self, tw, x, info):
+        if self.args.recurrent:
+            x0, (hidden_state, cell_state) = x
+            hp, cp, wide = self._twin_hidden(tw, hidden_state, cell_state, x0.size(0) * self.nagents)
+            action, value, hc = tw([x0, (hp, cp)], info)
+            self._twin_done(tw)
+            return action, value, self._twin_state_out(hc, wide)
+        out = tw(x, info)
+        self._twin_done(tw)
+        return out
 
     # ------------------------------------------------------------------------------------------
     # Fused rollout path (no autograd): the same math as forward() for the recurrent LSTM policy with one
@@ -187,6 +349,9 @@ class CommNetMLP(nn.Module):
     def commnet_step_ok(self, env, x):
         """True when step_env_commnet() may replace forward + select_action + env.step for this input (the non-recurrent
         module, the env's own observation, a handle that is not in auto-reset mode)."""
+        tw = self._twin_for(x)
+        if tw is not None:
+            return tw.commnet_step_ok(env, x)
         if not self._commnet_ok(x) or not hasattr(env, '_h'):
             return False
         if getattr(self.obs_encoder, '__self__', None) is not env or not self._x_is_env_obs(x):
@@ -199,6 +364,11 @@ class CommNetMLP(nn.Module):
         """trainer.py:61-67 for the non-recurrent module in ONE launch (ic3_commnet_step): action_out, value =
         forward(x, info); `action` (heads, E, N) int32 <- the draws; env.step(action[0]) -> reward / done / alive /
         is_completed; `obs`, when given, receives the dense observation of the state this call acts on."""
+        tw = self._twin_for(x)
+        if tw is not None:
+            r = tw.step_env_commnet(env, x, info, action, reward, done, alive, is_completed, obs, out)
+            self._twin_done(tw)
+            return r
         n, H = self.nagents, self.hid_size
         batch = x.size(0)
         R, dev = batch * n, x.device
@@ -244,6 +414,11 @@ class CommNetMLP(nn.Module):
         return self._mega_wanted() and getattr(a, 'rnn_type', '') == 'LSTM' and self.nagents <= 64
 
     def _fused_cache(self):
+        tw = self._twin() if not torch.is_grad_enabled() else None
+        if tw is not None:                                       # (the Trainer refreshes derived weights before replays)
+            fc = tw._fused_cache()
+            self._twin_done(tw)
+            return fc
         ps = [self.encoder.weight, self.encoder.bias] + [q for m in self.C_modules for q in (m.weight, m.bias)] + [
               self.f_module.weight_ih, self.f_module.weight_hh, self.f_module.bias_ih, self.f_module.bias_hh,
               self.value_head.weight, self.value_head.bias] + [p for hd in self.heads for p in (hd.weight, hd.bias)]
@@ -396,6 +571,10 @@ class CommNetMLP(nn.Module):
     # ------------------------------------------------------------------------------------------
     def mega_ok(self, env, x):
         """True when step_env() may replace forward + select_action + env.step for this input."""
+        tw = self._twin_for(x)
+        if tw is not None:
+            hp, cp, _ = self._twin_hidden(tw, x[1][0], x[1][1], x[0].size(0) * self.nagents)
+            return tw.mega_ok(env, [x[0], (hp, cp)])
         if not (self._mega_wanted() and self._fused_ok(x) and hasattr(env, '_h')):
             return False
         if getattr(self.obs_encoder, '__self__', None) is not env or not self._x_is_env_obs(x[0]):
@@ -411,6 +590,9 @@ class CommNetMLP(nn.Module):
         """mega_ok() without an input: the conditions that do not depend on the tensors of a step (the Trainer asks
         before an episode starts whether that episode will run on the one-launch path)."""
         a = self.args
+        tw = self._twin()
+        if tw is not None:
+            return tw.mega_supported(env)
         if not (self._mega_wanted() and getattr(a, 'fused_policy', True) and hasattr(env, '_h')):
             return False
         if not (a.recurrent and getattr(a, 'rnn_type', '') == 'LSTM' and len(self.heads) <= 4):
@@ -428,6 +610,10 @@ class CommNetMLP(nn.Module):
         """init_hidden() for the one-launch rollout path: the persistent (h, c) buffers step_env() updates in place,
         zeroed — two fills instead of two allocations + fills + two copies at every episode start."""
         R, H = batch_size * self.nagents, self.hid_size
+        tw = self._twin()
+        if tw is not None:
+            h, c = tw.zero_hidden(batch_size, device)
+            return (h[:, :H], c[:, :H])
         mb = getattr(self, '_mb', None)
         if mb is None or mb['h'].shape[0] != R or mb['h'].device != device:
             mb = self._mb = dict(h=torch.empty((R, H), dtype=torch.float32, device=device),
@@ -444,6 +630,14 @@ class CommNetMLP(nn.Module):
         observation of the state this call ACTS ON (the reference's `state` argument of policy_net at this step),
         assembled by the same launch; the observation of the new state is what the next call writes (or env.observe())."""
         n, H = self.nagents, self.hid_size
+        tw = self._twin_for(x)
+        if tw is not None:
+            hp, cp, wide = self._twin_hidden(tw, x[1][0], x[1][1], x[0].size(0) * n)
+            assert hidden_out is None or wide, "an in-place episode record has the twin's width (Trainer._kernel_net)"
+            action_out, value, hc = tw.step_env(env, [x[0], (hp, cp)], info, action, reward, done, alive,
+                                                is_completed, obs, hidden_out, out)
+            self._twin_done(tw)
+            return action_out, value, self._twin_state_out(hc, wide)
         x, (hidden_state, cell_state) = x
         batch = x.size(0)
         R = batch * n

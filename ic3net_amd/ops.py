@@ -232,6 +232,18 @@ def policy_heads(h, W, b, head_sizes, out=None):
 POLICY_STEP_SIZES = (64, 128, 256)
 
 
+def padded_hidden(H):
+    """The next hidden size the one-launch kernels are built for, or None (H is one of them, or larger than all):
+    comm.CommNetMLP runs other sizes zero-padded to it (exact: a padded unit's pre-activations, state and output are 0)."""
+    H = int(H)
+    if H in POLICY_STEP_SIZES or H < 1:
+        return None
+    for s in POLICY_STEP_SIZES:
+        if H < s:
+            return s
+    return None
+
+
 def policy_step_pack(c_weight, w_ih, w_hh):
     """C.weight (H,H) and [W_ih | W_hh] (4H, 2H) in the layout ic3_policy_step streams (ic3_policy_pack)."""
     _need_cuda(c_weight, "policy_step_pack")

@@ -171,8 +171,9 @@ class Trainer(object):
         self._rec = None
         if self._records is not None:                              # native update: what the backward pass needs later
             raw1 = self.env.env
-            self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size, raw1.dims.state_words, dev,
-                                           recurrent=bool(getattr(args, 'recurrent', False)))
+            knet = self._kernel_net()                             # (a zero-padded twin records its own, wider, state)
+            self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size if knet is self.policy_net else knet.hid_size,
+                                           raw1.dims.state_words, dev, recurrent=bool(getattr(args, 'recurrent', False)))
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
         if self._use_graph() and self._graphs and getattr(self.policy_net, '_fc', None) is not None:
@@ -185,6 +186,12 @@ class Trainer(object):
             if gen != self._graph_gen:
                 self._graphs.clear()
                 self._episodes_played = min(self._episodes_played, 1)   # next episode re-captures
+
+    def _kernel_net(self):
+        """The module the one-launch kernels and the native update run: the policy itself, or — for a hidden size they are
+        not built for — its zero-padded twin (comm.CommNetMLP.kernel_module)."""
+        km = getattr(self.policy_net, 'kernel_module', None)
+        return km() if km is not None else self.policy_net
 
     def _rec_inplace(self):
         """The recorded rollout of a native update reads / writes (h, c) in the episode record (no copies) when every
@@ -779,22 +786,28 @@ class Trainer(object):
             # the recurrent gradient would cross the cut — not handled by bptt; the autograd rollout then raises the
             # explicit NotImplementedError of _step_body (as before round 3)
             return False
-        return bool(getattr(self.args, 'native_update', True)) and raw is not None and hasattr(raw, '_h') \
-            and bptt.supported(self.args, self.policy_net, raw)
+        if not (bool(getattr(self.args, 'native_update', True)) and raw is not None and hasattr(raw, '_h')):
+            return False
+        knet = self._kernel_net()
+        return bptt.supported(self.args if knet is self.policy_net else knet.args, knet, raw)
 
     def compute_grad_native(self, batch, records):
         """compute_grad() without an autograd graph: losses and dL/d(logits, value) from the batch, then
         bptt.backward_episode over every recorded episode; fills p.grad like loss.backward() would."""
         stat, d_out = bptt.loss_gradients(self.args, batch)
-        acc = bptt.new_accumulators(self.policy_net)
+        knet = self._kernel_net()
+        kargs = self.args if knet is self.policy_net else knet.args
+        acc = bptt.new_accumulators(knet)
         t0 = 0
         raw = self.env.env
         with torch.no_grad():
             for rec in records:
-                bptt.backward_episode(self.args, self.policy_net, raw, rec, d_out[t0:t0 + rec.n], acc)
+                bptt.backward_episode(kargs, knet, raw, rec, d_out[t0:t0 + rec.n], acc)
                 t0 += rec.n
             assert t0 == d_out.shape[0], "recorded steps do not match the batch"
-            bptt.assign_grads(self.policy_net, acc)
+            bptt.assign_grads(knet, acc)
+            if knet is not self.policy_net:
+                self.policy_net.unpad_grads()                      # the twin's gradients -> the policy's own parameters
         return stat
 
     def train_batch(self, epoch):

@@ -450,7 +450,8 @@ def test_store_states_holds_state_and_next_state(workload, E):
 
 
 @pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7), ("pp_hard_p2", 9), ("tj_medium_p3share", 7),
-                                        ("tj_medium_commnet_mlp", 7), ("pp_hard_mlp", 9)])
+                                        ("tj_medium_commnet_mlp", 7), ("pp_hard_mlp", 9),
+                                        ("pp_hard_h100", 9), ("tj_medium_h48_p2", 7), ("tj_medium_commnet_mlp_h100", 7)])
 def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     """train_batch's default path at a BASELINE shape: the rollout is the one-launch kernel (ic3_policy_step, hid 128) and
     the gradients come from ic3net_amd.bptt — compared with loss.backward() through the autograd rollout replaying the
@@ -464,6 +465,13 @@ def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     bench.WORKLOADS.setdefault("tj_medium_p3share", ("traffic_junction", dict(bench.WORKLOADS["tj_medium"][1], comm_passes=3,
                                                                                share_weights=True)))
     bench.WORKLOADS.setdefault("pp_hard_mlp", ("predator_prey", dict(bench.WORKLOADS["pp_hard"][1], recurrent=False)))
+    # hidden sizes the kernels are not built for (main.py:34: any int): the policy's zero-padded twin at 128 / 64 runs the
+    # one-launch rollout AND the explicit backward; its gradients, cut back, against autograd through the policy itself
+    bench.WORKLOADS.setdefault("pp_hard_h100", ("predator_prey", dict(bench.WORKLOADS["pp_hard"][1], hid_size=100)))
+    bench.WORKLOADS.setdefault("tj_medium_h48_p2", ("traffic_junction", dict(bench.WORKLOADS["tj_medium"][1], hid_size=48,
+                                                                              comm_passes=2)))
+    bench.WORKLOADS.setdefault("tj_medium_commnet_mlp_h100", ("traffic_junction",
+                                                              dict(bench.WORKLOADS["tj_medium_commnet_mlp"][1], hid_size=100)))
     T = 12
     extra = dict(gamma=0.95, normalize_rewards=True, entr=0.01, value_coeff=0.01, advantages_per_action=False,
                  batch_size=E * T, detach_gap=5)
@@ -601,11 +609,19 @@ def test_native_update_is_not_taken_where_it_does_not_apply():
     for hid, ok in ((96, False), (100, False), (128, True), (32, True)):
         tr2, a2 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=hid)
         assert bptt.supported(a2, tr2.policy_net, tr2.env.env) == ok, hid
-    tr3, a3 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=96)      # ... and the update itself runs (autograd path)
-    a3.batch_size = 8 * a3.max_steps
-    a3.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False)
-    st = tr3.train_batch(0)
-    assert np.isfinite(st['action_loss'])
+        # (round 4, later: such a policy runs as its zero-padded twin at 128 / 64 — comm.CommNetMLP._twin — and the twin's
+        #  size IS one the backward takes; without the twin the update stays on autograd)
+        assert tr2._native_update()
+        a2.pad_hidden = False
+        assert tr2._native_update() == ok, hid
+    for pad in (False, True):                                             # ... and the update itself runs either way
+        tr3, a3 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=96)
+        a3.pad_hidden = pad
+        a3.batch_size = 8 * a3.max_steps
+        a3.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False)
+        st = tr3.train_batch(0)
+        assert np.isfinite(st['action_loss'])
+        assert (getattr(tr3.policy_net, 'mega_steps', 0) > 0) == pad     # the one-launch rollout ran for the twin only
 
 
 @pytest.mark.parametrize("kind,rnn_type,env_name", [("mlp", "MLP", "predator_prey"), ("rnn", "MLP", "traffic_junction"),
