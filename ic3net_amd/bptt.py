@@ -222,6 +222,10 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     # library fills the chip (tools/exp/microbench_bptt_gemms.py: 118 instead of 83 TFLOP/s at R = 81920)
     NB = 8 if R % 8 == 0 and R >= 8192 else 1
     wpart = torch.zeros((NB, 2 * H, 4 * H), dtype=torch.float32, device=dev) if NB > 1 else None
+    # C.weight's gradient d inp^T . comm has an H x H result over K = R: a single product is 24 workgroups of split-K; as
+    # NBC products over row blocks, summed behind the loop, it fills the chip too
+    NBC = 32 if R % 32 == 0 and R >= 8192 and not mask_zero else 1
+    cpart = torch.zeros((NBC, H, H), dtype=torch.float32, device=dev) if NBC > 1 else None
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
@@ -264,7 +268,10 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         torch.mm(dgates, w_cat_t.t(), out=dxh)                            # (R, 4H) x (4H, 2H) -> [d inp | d h_{t-1}]
         # ---- inp = encoder(obs) + C(comm) (+ both biases)
         if not mask_zero:
-            acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
+            if NBC > 1:
+                cpart.baddbmm_(dinp.view(NBC, R // NBC, H).transpose(1, 2), comm.view(NBC, R // NBC, H))
+            else:
+                acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
             torch.mm(dinp, fc['c_wt'].t(), out=dcomm)                     # d comm = d inp . C.weight
             ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dcomm_b)
             torch.add(dxh[:, H:], dcomm_b.view(R, H), out=dh_rec)         # dL/dh_{t-1}: what step t - 1 receives
@@ -275,6 +282,8 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         acc['enc_bias'].add_(db)
     if NB > 1:
         acc['w_cat_t'].add_(wpart.sum(0))
+    if NBC > 1:
+        acc['c_w'].add_(cpart.sum(0))
     if fused_gates:
         acc['b_cat'].add_(bias_parts.sum(0))
         # heads + value head: dW += sum_t d_t^T h_t, db += sum_t sum_rows d_t — h_t of step t is the state ENTERING step t + 1

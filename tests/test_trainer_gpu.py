@@ -451,7 +451,8 @@ def test_store_states_holds_state_and_next_state(workload, E):
 
 @pytest.mark.parametrize("workload,E", [("pp_hard", 9), ("tj_medium", 7), ("pp_hard_p2", 9), ("tj_medium_p3share", 7),
                                         ("tj_medium_commnet_mlp", 7), ("pp_hard_mlp", 9),
-                                        ("pp_hard_h100", 9), ("tj_medium_h48_p2", 7), ("tj_medium_commnet_mlp_h100", 7)])
+                                        ("pp_hard_h100", 9), ("tj_medium_h48_p2", 7), ("tj_medium_commnet_mlp_h100", 7),
+                                        ("pp_hard", 1024)])     # 10 240 rows: the weight gradients as batched row-block products
 def test_native_update_on_the_one_launch_rollout_matches_autograd(workload, E):
     """train_batch's default path at a BASELINE shape: the rollout is the one-launch kernel (ic3_policy_step, hid 128) and
     the gradients come from ic3net_amd.bptt — compared with loss.backward() through the autograd rollout replaying the
