@@ -196,6 +196,49 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
                 np.testing.assert_array_equal(e[4][k], g[4][k], err_msg=k)
 
 
+@pytest.mark.parametrize("hid", [64, 32])
+def test_graph_replay_follows_weight_updates(hid):
+    """Replayed step graphs hold the ADDRESSES of the derived weight tensors (packed layouts; for hid 32 the zero-padded
+    twin's parameters and ITS packed layouts): after the parameters change in place (optimizer.step, checkpoint load) the
+    next episode must play the new weights — begin_episode refreshes the derived tensors in place."""
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    flags = dict(nagents=5, dim=10, vision=1, hid_size=hid, ic3net=True, recurrent=True, detach_gap=10)
+
+    def run(graph):
+        a = build_args("predator_prey", dict(flags), 5, 12, 64, 5)
+        a.env_id_offset = 0
+        a.hip_graph = graph
+        env = data.init("predator_prey", a, False)
+        a.num_actions = [env.num_actions, 2]
+        a.dim_actions = env.dim_actions + 1
+        a.num_inputs = env.observation_dim
+        a.recurrent, a.rnn_type = True, 'LSTM'
+        parse_action_args(a)
+        torch.manual_seed(11)
+        net = CommNetMLP(a, a.num_inputs).cuda()
+        tr = trmod.Trainer(a, net, env)
+        out = []
+        for ep in range(6):
+            if ep == 3:
+                with torch.no_grad():
+                    for q in net.parameters():
+                        q.mul_(0.5).add_(0.01)
+            episode, _ = tr.get_episode(ep)
+            out.append(([t.action.clone() for t in episode], [t.value.clone() for t in episode]))
+        return out, tr
+
+    eager, _ = run(False)
+    graphed, tr = run(True)
+    assert len(tr._graphs) == 12 and getattr(tr.policy_net, 'mega_steps', 0) > 0
+    assert not all(torch.equal(x, y) for x, y in zip(eager[2][1], eager[3][1]))     # the update does change the episode
+    for ep, (e, g) in enumerate(zip(eager, graphed)):
+        for i in range(2):
+            for x, y in zip(e[i], g[i]):
+                assert torch.equal(x, y), (ep, i)
+
+
 GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_commnet_norm", "predator_prey"),
                  ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction"),
                  # BASELINE shapes (hid 128, 80 steps, detach_gap 10), closed-form weights: configs[1] and configs[3]
