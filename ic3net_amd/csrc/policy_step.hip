@@ -75,6 +75,9 @@ __device__ constexpr int ps_trace_slot(int k) { return k; }
 #define IC3_PS_PRIO_MASK 1
 #endif
 #define IC3_PRIO_AT(bit) __builtin_amdgcn_s_setprio(((IC3_PS_PRIO_MASK) & (bit)) ? 3 : 0)
+#ifndef IC3_PS_WLOAD_AUX
+#define IC3_PS_WLOAD_AUX 0    // cache policy of the split loop's weight fragment loads (variant builds: 2 = nt, 16 = sc1, 17 = sc0 sc1)
+#endif
 #ifndef IC3_PS_ZSTORE_AUX
 #define IC3_PS_ZSTORE_AUX 2   // cache policy of the obs zero stores: nt (variant builds: 3 = sc0 nt, 18 = sc1 nt, 19 = sc0 sc1 nt)
 #endif
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int g3lane = (w * 64 + lane) * 16;
             constexpr int GSTRIDE = NW * 64 * 16;
             auto wq3 = [&](int pl, int kb, int gt) {
-                return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
+                return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, IC3_PS_WLOAD_AUX);
             };
             ps_u32x4 bq[3][4];
             // ---- S7: inp = enc + C.bias + C(comm) -> inp half --------------------------------------------------------
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int gt = 0; gt < 4; ++gt)
-                        bq[pl][gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16) * 4 + gt) * GSTRIDE + zo, 0);
+                        bq[pl][gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16) * 4 + gt) * GSTRIDE + zo, IC3_PS_WLOAD_AUX);
                 if (!(ABL & 1)) {
 #pragma unroll 1
                     for (int kb = 0; kb < KB16 - 1; ++kb) block3(two_c, s_c, std::true_type{}, std::false_type{}, kb);
