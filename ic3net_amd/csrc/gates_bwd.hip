@@ -30,7 +30,7 @@ struct GatesBwdArgs {
     const float* h_prev;   // or null.  [R][H]: the h half of a row is read from here and ALSO written into xh (the copy
                            // the caller would otherwise make for the weight-gradient product that follows)
     const float* wq;       // ic3_policy_pack's lstm_wp: Wq[k][c] = float4 over the four gates
-    const void* wq3;       // EXPERIMENT (gate_split, policy_step.hip): ic3_policy_pack_split's three bf16 planes, or null
+    const void* wq3;       // gate_split (policy_step.hip; the default): ic3_policy_pack_split's three bf16 planes, or null = fp32 instruction
     const float* bias;     // [4H] b_ih + b_hh
     const float* c_prev;   // [R][H]
     const float* dh;       // [R][H] dL/dh_t
@@ -75,7 +75,7 @@ __device__ __forceinline__ void gb_mfma(gb_f32x16& acc, float x, float y)
 #endif
 }
 
-// EXPERIMENT (SPLIT = 1, the update half's twin of policy_step_kernel's gate_split): the recompute as nine exact
+// SPLIT = 1 (the default; the update half's twin of policy_step_kernel's gate_split): the recompute as nine exact
 // bf16 x bf16 products per 16 k-steps on v_mfma_f32_32x32x16_bf16 — the same loop: weight planes in fragment order, one
 // 16-k block of them in registers, activations split per wave from the fp32 LDS tile through v_cvt_pk_bf16_f32.
 typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));

@@ -180,7 +180,7 @@ struct StepArgs {
     // env
     int E, N, EPT, G;
     int auto_reset;             // env handle in auto-reset mode: an env with t == 0 starts an episode (h = c = 0, gate 0)
-    const void* l_wp3;          // EXPERIMENT (gate_split): [W_ih | W_hh] as three bf16 planes in fragment order, or null
+    const void* l_wp3;          // gate_split (the default): [W_ih | W_hh] as three bf16 planes in fragment order; null = fp32 instruction
     int inner;                  // comm_passes > 1 (comm.py:179): NOT the last communication pass of the step — the launch
                                 // ends behind the LSTM cell (h, c updated; no heads, draws, env.step, obs rows)
     int keep_state;             // not the FIRST pass of the step: h, c hold the previous pass (an env at t == 0 keeps them)
@@ -198,7 +198,7 @@ constexpr bool ps_zslot(int S, int i) { return S > 0 && ((i + 1) * S / 16) > (i 
 // the same for the split-product loop (SPLIT = 1): 36 slots per 16-k block (one behind every pair of bf16 MFMAs)
 constexpr bool ps_zslot36(int S, int i) { return S > 0 && ((i + 1) * S / 36) > (i * S / 36); }
 
-// ---- EXPERIMENT (ic3_policy.gate_split, off by default; DESIGN.md section 10, tools/exp/bf16x9_probe.hip): the gate
+// ---- ic3_policy.gate_split (the default since round 4; DESIGN.md section 0, tools/exp/bf16x9_probe.hip): the gate
 // product with every fp32 operand split EXACTLY into three bf16 terms (x = x1 + x2 + x3, round-to-nearest-even splits,
 // exact residuals) and all nine cross products on v_mfma_f32_32x32x16_bf16 — each product exact in fp32, fp32
 // accumulation.  Weights: pre-split planes in fragment order (ic3_policy_pack_split); activations: the fp32 A tile stays
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
         if constexpr (SPLIT != 0) {
-            // ---- EXPERIMENT (gate_split): the gate product as nine exact bf16 x bf16 products per 16 k-steps -----------
+            // ---- gate_split: the gate product as nine exact bf16 x bf16 products per 16 k-steps ---------------------------
             // B: pre-split weight planes Wp[plane][kb16][gate][wave][lane] (16 bytes = the 8 bf16 of k = 16 kb + 8 lh + i,
             // column 32 w + li of the gate); ONE 16-k block in registers (48 VGPRs), a plane refilled for the next block
             // right behind its last product of this one (products grouped by weight plane).  A: this wave's rows of the
@@ -1356,7 +1356,7 @@ __global__ void policy_pack_gates_kernel(const float* __restrict__ w_ih, const f
     }
 }
 
-// EXPERIMENT (gate_split): Wp[plane][kb16][gate][wave][lane] = 8 x bf16 { W_plane[gate * H + 32 wave + li][16 kb16 + 8 lh + i] },
+// gate_split: Wp[plane][kb16][gate][wave][lane] = 8 x bf16 { W_plane[gate * H + 32 wave + li][16 kb16 + 8 lh + i] },
 // W = [w_ih | w_hh] (4H x 2H), the three planes an exact split of every weight
 __global__ void policy_pack_split_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                          ps_u32x4* __restrict__ Wp, int H)
@@ -1843,7 +1843,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         ev1 = (hipEvent_t)env->ev_stop;
         env->ev_start = env->ev_stop = nullptr;
     }
-    if (a.l_wp3) {   // EXPERIMENT: the gate product on the bf16 matrix cores with exact split products
+    if (a.l_wp3) {   // gate_split: the gate product on the bf16 matrix cores with exact split products
         if (H == 128)
             rc = pp ? launch_step<128, IC3_ENV_PP, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ, 1>(a, tiles, lds, s, ev0, ev1);
         else if (H == 64)

@@ -262,7 +262,7 @@ def policy_step_supported(env, H):
 
 
 def policy_pack_split(w_ih, w_hh):
-    """EXPERIMENT (ic3_policy.gate_split): [W_ih | W_hh] as three exact bf16 planes in MFMA fragment order."""
+    """ic3_policy.gate_split (the default): [W_ih | W_hh] as three exact bf16 planes in MFMA fragment order."""
     _need_cuda(w_ih, "policy_pack_split")
     H = w_ih.shape[1]
     wp3 = torch.empty((3 * 2 * H * 4 * H,), dtype=torch.bfloat16, device=w_ih.device)
@@ -286,7 +286,7 @@ def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True, pass_in
         pol.loc_table = fc['loc_table'].data_ptr() if fc.get('loc_table') is not None else None
     pol.c_wp, pol.lstm_wp, pol.lstm_bias = fc['ps_c_wp' + sfx].data_ptr(), fc['ps_l_wp'].data_ptr(), fc['b_cat'].data_ptr()
     pol.head_w, pol.head_b = fc['w_heads'].data_ptr(), fc['b_heads'].data_ptr()
-    if fc.get('ps_l_wp3') is not None:                           # EXPERIMENT: exact split products on the bf16 matrix cores
+    if fc.get('ps_l_wp3') is not None:                           # gate_split: exact split products on the bf16 matrix cores
         pol.gate_split, pol.lstm_wp3 = 1, fc['ps_l_wp3'].data_ptr()
     return pol
 
