@@ -241,7 +241,10 @@ def mfma_roofline(a, nenvs, step_ms, gate_split=False):
            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops,
            "flops_counted": "fp32-equivalent (2 per multiply-add of comm.py's dense layers)",
            "avg_launch_ms": round(avg, 4), "launches": len(step_ms),
-           "hbm_bytes_per_launch_algorithmic": R * ((4 * H if rec else 0) + OT + 2 * len(a.naction_heads) + 1) * 4}
+           "hbm_bytes_per_launch_algorithmic": R * ((4 * H if rec else 0) + OT + 2 * len(a.naction_heads) + 1) * 4,
+           "clock_context": "peaks are 2.4 GHz figures; under this launch the shader clock is lower (power-limited): 1.72 GHz "
+                            "while PP-hard's gate loops run, 1.91 GHz on TJ-hard - profiles/r04/shader_clock.txt "
+                            "(IC3_PS_TRACE_CLK build; not re-measured in this run)"}
     if gate_split and rec:
         btf = 9.0 * gate / (avg * 1e-3) / 1e12
         out["bf16_issued"] = {"flops_per_launch": 9.0 * gate, "achieved": round(btf, 1), "peak": MFMA_BF16_PEAK_TF,

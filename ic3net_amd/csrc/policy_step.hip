@@ -46,13 +46,22 @@ typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
 // -DIC3_PS_TRACE_EPI (with IC3_PS_TRACE): slots 12..14 are three stamps INSIDE the cell epilogue (old cell state there and
 // first element done; element loop done; head weights in LDS + the remaining zero stores issued), slot 15 its closing
 // barrier; the heads / draws / env step stamps are dropped (tools/analyze_trace.py --epi).
+// -DIC3_PS_TRACE_CLK (with IC3_PS_TRACE): slots 13 / 14 hold s_memtime (SHADER clock cycles) at the start / end of the gate
+// loop instead of the heads / draws stamps — with the 100 MHz stamps of slots 8 / 9 that is the clock the loop ran at
+// (tools/analyze_trace.py --clk).
 #ifdef IC3_PS_TRACE
-#ifdef IC3_PS_TRACE_EPI
+#ifdef IC3_PS_TRACE_CLK
+__device__ constexpr int ps_trace_slot(int k) { return (k == 13 || k == 14) ? -1 : k; }
+#define IC3_TRE(j) do { } while (0)
+#define IC3_TRC(j) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 20 + 13 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(IC3_PS_TRACE_EPI)
 __device__ constexpr int ps_trace_slot(int k) { return k == 12 ? 15 : (k >= 13 && k <= 15) ? -1 : k; }
 #define IC3_TRE(j) IC3_TR_RAW(12 + (j))
+#define IC3_TRC(j) do { } while (0)
 #else
 __device__ constexpr int ps_trace_slot(int k) { return k; }
 #define IC3_TRE(j) do { } while (0)
+#define IC3_TRC(j) do { } while (0)
 #endif
 #define IC3_TR_RAW(k)                                                                                   \
     do {                                                                                                \
@@ -65,6 +74,7 @@ __device__ constexpr int ps_trace_slot(int k) { return k; }
 #else
 #define IC3_TR(k) do { } while (0)
 #define IC3_TRE(j) do { } while (0)
+#define IC3_TRC(j) do { } while (0)
 #endif
 // Wave priority: 3 in the phases in front of the gate loop (short dependent chains of loads, LDS exchanges and barriers
 // whose every instruction is on the tile's critical path), 0 from the gate loop on — the co-resident workgroup's MFMA
@@ -704,6 +714,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             __syncthreads();
             IC3_TR(8);
+            IC3_TRC(0);
             IC3_PRIO_AT(0);
             const __amdgpu_buffer_rsrc_t rc_old = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
             const int voff_old = (4 * lh * H + col) * 4;
@@ -877,6 +888,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             __syncthreads();
             IC3_TR(8);
+            IC3_TRC(0);
             IC3_PRIO_AT(0);
 
             // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
@@ -941,6 +953,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             if (two) gate_loop_s(std::true_type{});
             else gate_loop_s(std::false_type{});
         }
+        IC3_TRC(1);
         IC3_TR(9);
         IC3_PRIO_AT(2);
         mfma_settle();

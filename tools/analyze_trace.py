@@ -16,6 +16,24 @@ NAMES_EPI = NAMES[:12] + ["S9a c_old there, 1st element", "S9b elements", "S9c h
                          "S10-12 heads, draws, env step, patch wait", "patches"]
 
 
+def clk(path):
+    """-DIC3_PS_TRACE_CLK build: shader clock of every gate loop = s_memtime cycles / s_memrealtime time"""
+    d = np.loadtxt(path, delimiter=',', dtype=np.int64)
+    us = (d[:, 10] - d[:, 9]).astype(np.float64) * 0.01          # slots 9 - 8 (column 0 is the tile index)
+    cyc = (d[:, 15] - d[:, 14]).astype(np.float64)               # slots 14 - 13
+    ok = (us > 1) & (cyc > 0)
+    ghz = cyc[ok] / us[ok] / 1e3
+    t0 = d[:, 1].min()
+    start = (d[ok, 9] - t0) * 0.01
+    print("gate loops: %d; shader clock while they ran: mean %.3f GHz, p10 %.3f, p50 %.3f, p90 %.3f" % (
+        ok.sum(), ghz.mean(), np.percentile(ghz, 10), np.percentile(ghz, 50), np.percentile(ghz, 90)))
+    print("loop duration: mean %.1f us = %.0f cycles (p10 %.0f, p90 %.0f cycles)" % (
+        us[ok].mean(), cyc[ok].mean(), np.percentile(cyc[ok], 10), np.percentile(cyc[ok], 90)))
+    last = start > np.percentile(start, 97)
+    print("last 3 %% of the loops by start time (CUs draining): %.1f us = %.0f cycles at %.3f GHz" % (
+        us[ok][last].mean(), cyc[ok][last].mean(), ghz[last].mean()))
+
+
 def main(path, epi=False):
     global NAMES
     if epi:
@@ -64,4 +82,7 @@ def main(path, epi=False):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], '--epi' in sys.argv[2:])
+    if '--clk' in sys.argv[2:]:
+        clk(sys.argv[1])
+    else:
+        main(sys.argv[1], '--epi' in sys.argv[2:])

@@ -119,6 +119,8 @@ out += ["", "**Other files of the round**", "",
         "`tools/exp/prefill_probe.py` (what the policy launch costs in its obs modes), a rocprofv3 timeline: slower than the "
         "in-launch fill in every form (DESIGN.md section 10).",
         "* `split_pacing_sweep.txt` — the speed-only pacing knobs of the in-launch fill re-swept with the split gate product.",
+        "* `shader_clock.txt` — the shader clock while the gate loops run (`-DIC3_PS_TRACE_CLK` build): 1.72 GHz on PP-hard, "
+        "1.91 GHz on TJ-hard; `tcp_tcc_counters_tj_hard.csv` — L1 / L2 PMC counters of the TJ-hard launch (179 cycles per L1 -> L2 read).",
         "* `ab_runs.txt` — the second half of the round: variant libraries A/B on one box per call (cell epilogue, staged "
         "activation split, wave priority by phase, what had no effect, what stamping HIP events on every launch costs).",
         "* `phase_trace_pp_hard.txt`, `phase_trace_tj_hard.txt` — per-tile phase timeline of the final kernel "
