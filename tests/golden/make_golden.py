@@ -12,6 +12,7 @@ import sys
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('IC3_GOLDEN_OUT', HERE)   # where the fixtures are written (tests/test_golden_recipes_cpu.py: a tmp dir)
 sys.path.insert(0, HERE)
 
 import zlib
@@ -98,7 +99,7 @@ def pp_fixture(name, N, dim, vision, mode, T, nenv=3, nep=2, greedy_env=None, no
                     except RuntimeError:
                         pass
                     break
-    np.savez_compressed(os.path.join(HERE, name + '.npz'),
+    np.savez_compressed(os.path.join(OUT, name + '.npz'),
                         cfg=np.array([N, dim, vision, {'mixed': 0, 'cooperative': 1, 'competitive': 2}[mode], T, int(no_stay)], np.int32),
                         enemy_comm=int(enemy_comm),
                         seed=SEED, env_gid0=100, obs_dim=env.observation_dim, init_loc=init_loc, actions=actions,
@@ -128,7 +129,7 @@ def tj_tables_fixture():
             out[key + '_meta'] = np.array([env.dims[0], env.dims[1], env.vocab_size, env.OUTSIDE_CLASS,
                                            env.CAR_CLASS, env.BASE, env.npath, len(env.routes),
                                            len(env.routes[0]), a_obs_dim(a, env)], np.int32)
-    np.savez_compressed(os.path.join(HERE, 'tj_tables.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, 'tj_tables.npz'), **out)
     print('tj_tables', len(out) // 5, 'configs')
 
 
@@ -191,7 +192,7 @@ def tj_fixture(name, N, dim, vision, difficulty, add_rate, T, nenv=2, nep=2, bra
                 add_rate_seen[e, ep, t] = raw.stat['add_rate']
                 assert not d
                 assert raw.stat['success'] == 1 - raw.has_failed
-    np.savez_compressed(os.path.join(HERE, name + '.npz'),
+    np.savez_compressed(os.path.join(OUT, name + '.npz'),
                         cfg=np.array([N, dim, vision, {'easy': 0, 'medium': 1, 'hard': 2}[difficulty], T], np.int32),
                         add_rate=add_rate, curriculum=np.array(curriculum if curriculum else [0, 0, 0, 0], np.float64),
                         scalar=int(vocab_type == 'scalar'),

@@ -22,6 +22,7 @@ import numpy as np
 import ref_harness as rh
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('IC3_GOLDEN_OUT', HERE)   # where the fixtures are written (tests/test_golden_recipes_cpu.py: a tmp dir)
 
 
 def main():
@@ -31,7 +32,7 @@ def main():
     import torch
     _load = torch.load
     torch.load = lambda f, *a, **kw: _load(f, *a, **dict(dict(weights_only=False), **kw))   # torch>=2.6 default
-    ck = os.path.join(HERE, 'ref_ckpt_pp_easy.pt')
+    ck = os.path.join(OUT, 'ref_ckpt_pp_easy.pt')
     argv = ['main.py', '--env_name', 'predator_prey', '--nagents', '3', '--nprocesses', '1', '--num_epochs', '3',
             '--epoch_size', '2', '--batch_size', '60', '--hid_size', '16', '--detach_gap', '10', '--lrate', '0.001',
             '--dim', '5', '--max_steps', '20', '--ic3net', '--vision', '0', '--recurrent', '--seed', '5', '--save', ck]
@@ -45,7 +46,7 @@ def main():
         torch.load = _load
     text = buf.getvalue()
     text = text[text.index('Epoch 1\t'):]          # drop the Namespace / model dump in front
-    path = os.path.join(HERE, 'ref_stdout_pp_easy.txt')
+    path = os.path.join(OUT, 'ref_stdout_pp_easy.txt')
     with open(path, 'w') as f:
         f.write(text)
     # plot_script.read_file on the reference's own output
@@ -57,7 +58,7 @@ def main():
     # (the non-scalar branch needs a tab in the line: only the 'Epoch ...\tReward [...]' line has one)
     for term, scalar in (('Epoch', False), ('Success', True), ('Steps-taken', True)):
         expect[term] = ns['read_file']([], path, scalar, term)
-    json.dump(expect, open(os.path.join(HERE, 'ref_plot_expect.json'), 'w'), indent=1)
+    json.dump(expect, open(os.path.join(OUT, 'ref_plot_expect.json'), 'w'), indent=1)
     d = _load(ck, weights_only=False)
     print('wrote', ck, os.path.getsize(ck), 'bytes; log epochs', d['log']['epoch'].data, 'plot', expect)
 

@@ -11,6 +11,7 @@ import ref_harness as rh
 from oracle import philox
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('IC3_GOLDEN_OUT', HERE)   # where the fixtures are written (tests/test_golden_recipes_cpu.py: a tmp dir)
 
 
 def closed_form_weights(shapes, scale=0.05):
@@ -101,7 +102,7 @@ def policy_case(name, N, obs_dim, H, steps, seed, B=1, closed_form=False, **flag
         out['c'] = np.array(outs_c)
     out['param_names'] = np.array(sorted(sd.keys()))
     out['param_shapes'] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
-    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, 'params', len(sd), 'steps', steps)
 
 
@@ -189,9 +190,9 @@ def fullsize_case(name, env_name, N, H, steps, seed, heads, tj=None, pp=None, ga
     out['param_names'] = np.array(sorted(shapes))
     out['param_shapes'] = np.array([str(shapes[k]) for k in sorted(shapes)])
     n_alive = [int(v.sum()) for v in np.array(alives).reshape(steps, -1, N)[:, 0] if v[0] >= 0]
-    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, 'obs_dim', obs_dim, 'steps', steps, 'n_alive seen', sorted(set(n_alive)),
-          os.path.getsize(os.path.join(HERE, name + '.npz')) // 1024, 'KB')
+          os.path.getsize(os.path.join(OUT, name + '.npz')) // 1024, 'KB')
 
 
 def fullsize_main():
@@ -263,7 +264,7 @@ def baseline_case(name, kind, N, obs_dim, H, steps, seed, B=2, rnn_type='MLP'):
                param_names=np.array(sorted(sd)), param_shapes=np.array([str(tuple(sd[k].shape)) for k in sorted(sd)]))
     for k, v in sd.items():
         out['w:' + k] = v
-    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, sorted(sd))
 
 
@@ -282,7 +283,7 @@ def main():
     policy_case('policy_pphard_closed', 10, 3636, 128, 80, 9, ic3net=True, recurrent=True, closed_form=True)
 
 
-def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, **flags):
+def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, closed_form=False, **flags):
     """F5: the reference Trainer.get_episode with `select_action` replaced by an action tape and the env RNG
     injected; one reference episode per (env, episode).  Records per-transition fields + the stat dict."""
     ref = rh.load_reference()
@@ -352,7 +353,7 @@ def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, **flags):
         out['stat:' + k] = v
     out['cfg'] = np.array([N, T, nenv, nep, nh, seed], np.int32)
     out['flags'] = np.array(repr(sorted(flags.items())))
-    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, 'nsteps', rec['nsteps'].tolist(), 'stat keys', sorted(stats))
 
 
@@ -430,7 +431,7 @@ def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, **flags):
         g = np.zeros(0) if p.grad is None else p.grad.detach().numpy().copy()
         # (full-size fixtures keep the gradients as float32: the test's bar is 3e-4 of the largest entry)
         out['g:' + k] = g.astype(np.float32) if closed_form else g
-    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
     print(name, 'steps', stats['num_steps'], 'losses', s)
 
 

@@ -13,6 +13,7 @@ import sys
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('IC3_GOLDEN_OUT', HERE)   # where the fixtures are written (tests/test_golden_recipes_cpu.py: a tmp dir)
 sys.path.insert(0, HERE)
 
 import numpy as np  # noqa: E402
@@ -98,7 +99,7 @@ def main():
     out = []
     pp_cases(ref, out)
     tj_cases(ref, out)
-    path = os.path.join(HERE, 'render_fixture.json')
+    path = os.path.join(OUT, 'render_fixture.json')
     with open(path, 'w') as f:
         json.dump(out, f, separators=(',', ':'))
     print("wrote %s: %d views, %d draw calls" % (path, len(out), sum(len(o['cells']) for o in out)))

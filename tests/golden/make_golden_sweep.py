@@ -10,6 +10,7 @@ import zlib
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('IC3_GOLDEN_OUT', HERE)   # where the fixtures are written (tests/test_golden_recipes_cpu.py: a tmp dir)
 sys.path.insert(0, HERE)
 import numpy as np
 
@@ -96,7 +97,7 @@ def main():
         tj_cfg.append([N, dim, v, diff, rate_i, scalar, gid])
         tj_act.append(acts)
         tj_crc.append(crcs)
-    np.savez_compressed(os.path.join(HERE, 'sweep_checksums.npz'), seed=SEED,
+    np.savez_compressed(os.path.join(OUT, 'sweep_checksums.npz'), seed=SEED,
                         pp_cfg=np.array(pp_cfg, np.int32), pp_act=np.array(pp_act, np.int32),
                         pp_crc=np.array(pp_crc, np.uint32), tj_cfg=np.array(tj_cfg, np.int32),
                         tj_act=np.array(tj_act, np.int32), tj_crc=np.array(tj_crc, np.uint32))
