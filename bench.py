@@ -25,8 +25,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_ACHIEVABLE_GBS = 6300.0     # MI355X_MICROARCH.md, HBM section: ~6.3 TB/s achievable (context, not the roofline's peak)
-HBM_WRITE_STREAM_GBS = 5300.0   # a store stream alone on this chip, measured three ways in round 4 (see roofline.achievable.source)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (f32 in / f32 acc), same guide
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak (no sparsity), same guide
 
@@ -241,10 +239,7 @@ def mfma_roofline(a, nenvs, step_ms, gate_split=False):
            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops,
            "flops_counted": "fp32-equivalent (2 per multiply-add of comm.py's dense layers)",
            "avg_launch_ms": round(avg, 4), "launches": len(step_ms),
-           "hbm_bytes_per_launch_algorithmic": R * ((4 * H if rec else 0) + OT + 2 * len(a.naction_heads) + 1) * 4,
-           "clock_context": "peaks are 2.4 GHz figures; under this launch the shader clock is lower (power-limited): 1.72 GHz "
-                            "while PP-hard's gate loops run, 1.91 GHz on TJ-hard - profiles/r04/shader_clock.txt "
-                            "(IC3_PS_TRACE_CLK build; not re-measured in this run)"}
+           "hbm_bytes_per_launch_algorithmic": R * ((4 * H if rec else 0) + OT + 2 * len(a.naction_heads) + 1) * 4}
     if gate_split and rec:
         btf = 9.0 * gate / (avg * 1e-3) / 1e12
         out["bf16_issued"] = {"flops_per_launch": 9.0 * gate, "achieved": round(btf, 1), "peak": MFMA_BF16_PEAK_TF,
@@ -497,6 +492,14 @@ def main():
         if all_ok:
             break
     gc.enable()
+    # the store stream alone, same run: the stand-alone obs-assembly kernel on the same rows (rank 0, default configuration)
+    store_ref_ms = []
+    if rank == 0 and step_all and not o.no_dense_obs and not o.incremental_obs and not o.prefill_obs:
+        raw_env.obs_timer = []
+        for _ in range(12):
+            raw_env.observe_timed()
+        torch.cuda.synchronize()
+        store_ref_ms = [s_.elapsed_time(e_) for s_, e_ in raw_env.obs_timer][2:]
     rank_ms = [dt / o.steps * 1e3]
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -567,20 +570,24 @@ def main():
                               "run)" if traffic is not None else None,
             "bytes_per_launch": hbm_bytes, "obs_bytes_per_launch": obs_bytes if not o.no_dense_obs else 0,
             "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms), "note": roof_note}
-        if roofline is not None and fused_obs and achieved is not None and not fill_ms and not o.incremental_obs:
-            # context next to `frac` (which stays algorithmic bytes / the 8 TB/s spec peak): what this chip was measured to
-            # take.  The guide's achievable figure is a read stream; the launch is ~94 % writes, and a store stream alone
-            # (tools/exp/ws_probe.hip, ic3_obs_prefill alone, the obs-dominated pp_scaled launch) tops out at 5.3 TB/s.
+        if roofline is not None and fused_obs and achieved is not None and not fill_ms and not o.incremental_obs and store_ref_ms:
+            # context next to `frac` (which stays algorithmic bytes / the 8 TB/s spec peak), MEASURED IN THIS RUN: the stand-alone
+            # obs-assembly kernel (ic3_env_observe: nothing but the same obs rows, zeros + non-zero entries) event-timed right
+            # behind the timed region — the store stream this chip takes when nothing else runs beside it.
             R_ = o.nenvs * N
             written = obs_bytes + R_ * ((2 * a.hid_size if a.recurrent else 0) + sum(int(x) for x in a.naction_heads) + 1
                                         + 2 * len(a.naction_heads) + 1) * 4
-            roofline["achievable"] = {
-                "hbm_achievable_GBps_guide": HBM_ACHIEVABLE_GBS, "frac_of_guide_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-                "written_bytes_per_launch": written,
-                "write_stream_ceiling_GBps_measured": HBM_WRITE_STREAM_GBS,
-                "written_frac_of_write_ceiling": round(written / (avg_ms * 1e-3) / 1e9 / HBM_WRITE_STREAM_GBS, 4),
-                "source": "MI355X_MICROARCH.md (8 TB/s spec, ~6.3 TB/s achievable); write stream alone 5.3 TB/s: "
-                          "profiles/r04/prefill_experiment.txt section 1, profiles/r04/bench_pp_scaled.json"}
+            ref_ms = sum(store_ref_ms) / len(store_ref_ms)
+            ref_gbs = obs_bytes / (ref_ms * 1e-3) / 1e9
+            roofline["store_stream_reference"] = {
+                "kernel": ("pp_obs_kernel" if a.env_name == 'predator_prey' else "tj_obs_fill/vec4_kernel") +
+                          " (ic3_env_observe alone, the same obs rows)",
+                "bytes_per_launch": obs_bytes, "launches": len(store_ref_ms), "avg_launch_ms": round(ref_ms, 4),
+                "min_launch_ms": round(min(store_ref_ms), 4), "GBps": round(ref_gbs, 1),
+                "written_bytes_per_step_launch": written,
+                "step_launch_write_rate_GBps": round(written / (avg_ms * 1e-3) / 1e9, 1),
+                "step_launch_write_rate_over_reference": round(written / (avg_ms * 1e-3) / 1e9 / ref_gbs, 4),
+                "measured": "in this run, HIP events, behind the timed region"}
         out = {
             "metric": "env-steps/sec (agents x envs x steps), rollout hot path",
             "value": round(value, 1), "unit": "agent-steps/s", "n_gpus": world, "steps": o.steps, "warmup": o.warmup,

@@ -66,6 +66,29 @@ def test_bench_launches_its_own_ranks():
     assert d["value"] == pytest.approx(10 * 1024 * 12 / (d["ms_per_step"] * 12 * 1e-3), rel=1e-3)
 
 
+def test_bench_gpus_8_self_launch_on_one_device():
+    """Round-4 verdict item 8: the driver's 8-GPU command, `python bench.py --gpus 8 --steps K --warmup W`, kept runnable on a
+    one-GPU box: bench.py starts the EIGHT ranks itself (WORLD_SIZE unset), the IC3_BENCH_DEVICE hook puts them on one GPU
+    (gloo stands in for RCCL, which refuses duplicate devices), 256 envs per rank.  One JSON line from rank 0: eight per-rank
+    times, value = agents x (sum of all ranks' envs) x steps / the MAX-over-ranks time, weak scaling."""
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IC3_BENCH_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "10", "--warmup", "3", "--nenvs", "256"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert len(d["ms_per_step_ranks"]) == 8 and d["collectives"] == "gloo"
+    assert d["ms_per_step"] == pytest.approx(max(d["ms_per_step_ranks"]), rel=1e-3)          # MAX over ranks
+    assert d["config"]["parallelism"] == "env-shard x8" and d["config"]["envs_per_gpu"] == 256
+    assert d["live_frac"] == pytest.approx(1.0)
+    assert d["value"] == pytest.approx(10 * 8 * 256 * 10 / (d["ms_per_step"] * 10 * 1e-3), rel=1e-3)
+    assert d["cpu_baseline"] is None                              # rank 0 at N = 1 only
+
+
 PP = ['--env_name', 'predator_prey', '--nagents', '3', '--nprocesses', '1', '--num_epochs', '2', '--epoch_size', '1',
       '--hid_size', '64', '--detach_gap', '10', '--lrate', '0.001', '--dim', '5', '--max_steps', '20', '--ic3net',
       '--vision', '0', '--recurrent', '--dist_backend', 'gloo', '--device', '0',

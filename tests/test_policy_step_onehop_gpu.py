@@ -30,12 +30,12 @@ def _oracle_env(a, seed, gid):
                            a.curr_end, seed=seed, env_gid=gid, vocab_type=a.vocab_type)
 
 
-def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True, gate_split=True):
+def _free_run(workload, E, T, seed, offset, check_envs, check_obs=True, gate_split=True, **overrides):
     """Plays T lock-step iterations through Trainer.step_episode (the one-launch path) and replays the envs in
     `check_envs` through the fp64 policy + the oracle env on the kernel's actions.  Returns the worst policy error."""
     import bench
     from oracle import policy_ref
-    tr, a = bench.build_trainer(workload, E, seed, offset, 0)
+    tr, a = bench.build_trainer(workload, E, seed, offset, 0, **overrides)
     a.max_steps = T
     a.gate_split = gate_split        # True (the default): exact bf16 split products in the gate GEMM; False: fp32 MFMA
     tr.begin_episode(0)
@@ -105,6 +105,27 @@ def test_policy_step_at_benchmark_size_pp_hard(gate_split):
     full tile, the last full tile, the first / a middle / the last half tile."""
     envs = [0, 5, 7674, 7679, 7680, 7682, 7935, 8189, 8191]
     worst = _free_run("pp_hard", 8192, 3, seed=9, offset=0, check_envs=envs, gate_split=gate_split)
+    assert worst < TOL, worst
+
+
+@pytest.mark.parametrize("gate_split", [True, False], ids=["bf16x9", "fp32"])
+@pytest.mark.parametrize("workload,T,envs", [
+    # N = 20 -> 3 envs per 60-row tile; plan B: 2560 full tiles (envs 0..7679) + 512 half tiles of ONE env each, plan A: 2731
+    # tiles of 3 (the last one holds 2 envs) — the spot envs sit on the first / last full tile and the first / a middle /
+    # the last half tile under either plan
+    ("tj_hard", 6, [0, 2, 3, 7677, 7679, 7680, 7681, 7935, 8191]),
+    # N = 10 -> the PP-hard plan (1280 full tiles of 6 envs + 171 half tiles of 3) on the TJ env, CommNet (no gate head)
+    ("tj_medium", 6, [0, 5, 7674, 7679, 7680, 7682, 7935, 8189, 8191]),
+    # N = 32, hid 256 -> 2 envs per tile, one workgroup per CU, no half tiles; 42 GB of obs rows per step
+    ("pp_scaled", 2, [0, 1, 2, 4095, 4096, 4097, 8190, 8191]),
+])
+def test_policy_step_at_benchmark_size_other_workloads(workload, T, envs, gate_split):
+    """Round-4 verdict item 3: the E = 8192 launch geometries that the TJ-hard / TJ-medium / PP-scaled bench lines are measured
+    on (their tile plans differ from PP-hard's), in one hop against oracle.policy_ref + the oracle env, both gate-product modes."""
+    # (TJ: cars enter at rate 0.5 instead of the workload's 0.05 so that the few steps played see alive cars; the launch
+    #  geometry does not depend on it)
+    more_cars = dict(add_rate_min=0.5, add_rate_max=0.5) if workload.startswith('tj') else {}
+    worst = _free_run(workload, 8192, T, seed=11, offset=0, check_envs=envs, gate_split=gate_split, **more_cars)
     assert worst < TOL, worst
 
 
