@@ -80,6 +80,19 @@ class EpisodeRecord(object):
         self.gate = [None] * T
         self.h_last = None
         self.n = 0
+        self.stream = None     # collection mode (Trainer._run_batch_streams): per-slot cuts of the recurrence, see backward_episode
+
+    def start_from(self, h, c):
+        """Collection mode: this window continues the streams of the previous one — the state it ended with is the state
+        entering slot 0 (an env that starts an episode there is zeroed inside the step launch, and again in the backward)."""
+        R, H = self.hs.shape[1:]
+        if h.shape[-1] != H:
+            self._put(self.hs[0], h)
+            self._put(self.cs[0], c)
+        else:
+            self.hs[0].copy_(h.detach().reshape(R, H))
+            self.cs[0].copy_(c.detach().reshape(R, H))
+        return (self.hs[0], self.cs[0])
 
     def start(self):
         """Zero state of step 0, held in the record itself: a rollout that reads (h, c) from slot t and lets the step launch
@@ -190,9 +203,18 @@ def loss_gradients(args, batch):
     return stat, d_out
 
 
-def backward_episode(args, net, raw, rec, d_out, acc):
+def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     """Backward through one recorded episode; parameter gradients are ADDED into `acc` (fp32 tensors keyed like the
-    fused weight cache)."""
+    fused weight cache).
+
+    Collection mode (`rec.stream`, Trainer._run_batch_streams: the record is a WINDOW of consecutive slots of E streams of
+    episodes; recurrent policy, one communication pass): `fresh[t]` marks the envs that start an episode at slot t — their
+    rows of (h, c) entering the slot are zero, nobody is dead and the gate is 0 (trainer.py:38-51, quirks Q21 / Q22), as
+    the step launch had it — and `keep[t]` the envs whose state leaving slot t reaches slot t + 1 with its gradient (no
+    episode end, not a detach point of the env's own step count: trainer.py:56-60); `carry` = (dL/dh, dL/dc) arriving at
+    the window's last slot from the next window, and the pair leaving the window's first slot is returned."""
+    if rec.stream is not None:
+        assert rec.recurrent and net.comm_passes == 1 and not _is_baseline(net), "collection mode: recurrent policy, one pass"
     if _is_baseline(net):
         return _backward_episode_baseline(args, net, raw, rec, d_out, acc)
     if not rec.recurrent:
@@ -229,13 +251,32 @@ def backward_episode(args, net, raw, rec, d_out, acc):
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
+    stream = rec.stream
+    if stream is not None:
+        if carry is not None:
+            dh_rec.copy_(carry[0])
+            dc_rec.copy_(carry[1])
+        _heads_grad_episode(rec, d_out, acc, T, R, H)                     # (reads h_t of every slot: before rows are zeroed)
+        fresh_rows = stream['fresh'].to(torch.float32).repeat_interleave(N, dim=1)     # (T, R)
+        keep_rows = stream['keep'].to(torch.float32).repeat_interleave(N, dim=1).unsqueeze(2)   # (T, R, 1)
+        ones_mask = torch.ones((E, N), dtype=torch.int32, device=dev)
+        zeros_mask = torch.zeros((E, N), dtype=torch.int32, device=dev)
     for t in reversed(range(T)):
-        if (t + 1) % gap == 0:                                            # trainer.py:56-60: (h_t, c_t) handed on detached
+        if stream is not None:
+            dh_rec.mul_(keep_rows[t])                                     # the cuts of the env's OWN episode / detach points
+            dc_rec.mul_(keep_rows[t])
+        elif (t + 1) % gap == 0:                                          # trainer.py:56-60: (h_t, c_t) handed on detached
             dh_rec.zero_()
             dc_rec.zero_()
         h_prev, c_prev = rec.hs[t], rec.cs[t]
         h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
         alive, gate = rec.alive[t], rec.gate[t]
+        if stream is not None:
+            fr = stream['fresh'][t].unsqueeze(1)                          # (E, 1) the env starts an episode at this slot
+            h_prev.mul_((1.0 - fresh_rows[t]).unsqueeze(1))               # in place: the record is not read again
+            c_prev.mul_((1.0 - fresh_rows[t]).unsqueeze(1))
+            alive = torch.where(fr, ones_mask, alive) if alive is not None else None
+            gate = torch.where(fr, zeros_mask, gate) if gate is not None else None
         # ---- the forward of step t again: enc + C.bias -> inp, comm, gate pre-activations (comm.py:119,181-215)
         raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp, loc_table=fc['loc_table'])
         if not fused_gates:
@@ -255,8 +296,9 @@ def backward_episode(args, net, raw, rec, d_out, acc):
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
                                     h_prev=h_prev, lstm_wp3=fc.get('ps_l_wp3'))
         else:
-            acc['w_heads'].addmm_(d.t(), h_t)
-            acc['b_heads'].add_(d.sum(0))
+            if stream is None:
+                acc['w_heads'].addmm_(d.t(), h_t)
+                acc['b_heads'].add_(d.sum(0))
             parts = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, bias_parts)
             torch.sum(parts, 0, out=bsum)
             acc['b_cat'].add_(bsum)
@@ -286,15 +328,27 @@ def backward_episode(args, net, raw, rec, d_out, acc):
         acc['c_w'].add_(cpart.sum(0))
     if fused_gates:
         acc['b_cat'].add_(bias_parts.sum(0))
-        # heads + value head: dW += sum_t d_t^T h_t, db += sum_t sum_rows d_t — h_t of step t is the state ENTERING step t + 1
-        if rec.h_last is not None and rec.h_last.data_ptr() == rec.hs[T].data_ptr():
-            ops.heads_grad(d_out[:T].reshape(T * R, -1), rec.hs[1:T + 1].reshape(T * R, H), acc['w_heads'], acc['b_heads'],
-                           acc.setdefault('_work', {}))
-        else:
-            if T > 1:
-                ops.heads_grad(d_out[:T - 1].reshape((T - 1) * R, -1), rec.hs[1:T].reshape((T - 1) * R, H), acc['w_heads'],
-                               acc['b_heads'], acc.setdefault('_work', {}))
-            ops.heads_grad(d_out[T - 1], rec.h_last, acc['w_heads'], acc['b_heads'], acc.setdefault('_work', {}))
+        if stream is None:
+            _heads_grad_episode(rec, d_out, acc, T, R, H)
+    return (dh_rec, dc_rec)       # dL/d(h, c) entering the record's first slot (collection mode: the previous window's carry)
+
+
+def _heads_grad_episode(rec, d_out, acc, T, R, H):
+    """heads + value head over a whole record: dW += sum_t d_t^T h_t, db += sum_t sum_rows d_t — h_t of step t is the state
+    ENTERING step t + 1 (slot t + 1 of the record).  ONE pass (ic3_heads_grad) for up to 16 output columns, a library product
+    otherwise."""
+    def grad(d, h):
+        if d.shape[-1] <= ops.HEADS_GRAD_MAX_OT:
+            ops.heads_grad(d, h, acc['w_heads'], acc['b_heads'], acc.setdefault('_work', {}))
+        else:                                                             # (more than 15 actions in total)
+            acc['w_heads'].addmm_(d.t(), h)
+            acc['b_heads'].add_(d.sum(0))
+    if rec.h_last is not None and rec.h_last.data_ptr() == rec.hs[T].data_ptr():
+        grad(d_out[:T].reshape(T * R, -1), rec.hs[1:T + 1].reshape(T * R, H))
+    else:
+        if T > 1:
+            grad(d_out[:T - 1].reshape((T - 1) * R, -1), rec.hs[1:T].reshape((T - 1) * R, H))
+        grad(d_out[T - 1], rec.h_last)
 
 
 def _backward_episode_multipass(args, net, raw, rec, d_out, acc):

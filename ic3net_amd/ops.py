@@ -199,6 +199,9 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
     return n
 
 
+HEADS_GRAD_MAX_OT = 16      # ic3_heads_grad: at most 16 output columns (the heads' actions in total + the value)
+
+
 def heads_grad(d, h, dW, db, work=None):
     """dW (OT,H) += d^T . h, db (OT,) += column sums of d over all M rows of d (M,OT) / h (M,H) — ic3_heads_grad: the heads'
     weight gradient of a whole episode in one pass."""

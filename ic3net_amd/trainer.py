@@ -120,6 +120,12 @@ class Trainer(object):
         reset; one get_episode() call is then a WINDOW of max_steps steps over E streams of consecutive episodes."""
         return bool(getattr(self.args, 'auto_reset', False))
 
+    def _stream_continues(self):
+        """Collection mode (run_batch under args.auto_reset): every window after the batch's first one continues the E
+        running streams of consecutive episodes."""
+        st = getattr(self, '_stream', None)
+        return bool(st and st.get('cont'))
+
     def begin_episode(self, epoch):
         args = self.args
         raw0 = getattr(self.env, 'env', None)
@@ -138,9 +144,12 @@ class Trainer(object):
                                        and self._fused_obs() and self._dense_obs())
         self._mega_prev = bool(getattr(self, '_mega_last', False))     # (zero_hidden hands the launch its own buffers)
         self._mega_last = False
+        cont = self._stream_continues()
         if self._reset_takes_epoch is None:                        # (inspect.signature costs ~0.1 ms: once)
             self._reset_takes_epoch = 'epoch' in signature(self.env.reset).parameters
-        if self._reset_takes_epoch:                                # trainer.py:28-32
+        if cont:                                                   # collection mode, not the batch's first window: the E
+            state = self._state                                    # streams run on (no reset; h, c, masks carried over)
+        elif self._reset_takes_epoch:                              # trainer.py:28-32
             state = self.env.reset(epoch)
         else:
             state = self.env.reset()
@@ -151,10 +160,11 @@ class Trainer(object):
         T, N, nh = args.max_steps, args.nagents, len(args.naction_heads)
         self._state = state
         self.clock.episode += 1
-        self._info = dict()
-        # trainer.py:41; an LSTM policy replaces it by init_hidden() at t = 0 (trainer.py:50-51), so not allocated then
         lstm = bool(getattr(args, 'recurrent', False)) and getattr(args, 'rnn_type', '') == 'LSTM'
-        self._prev_hid = None if lstm else torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)
+        if not cont:
+            self._info = dict()
+            # trainer.py:41; an LSTM policy replaces it by init_hidden() at t = 0 (trainer.py:50-51), so not allocated then
+            self._prev_hid = None if lstm else torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)
         self._nsteps = 0
         # Episode buffers [T, ...]: the env / sampling kernels write step t's outputs straight into slice t, so the
         # hot loop launches no bookkeeping kernels; masks and statistics are derived once in end_episode().
@@ -299,12 +309,18 @@ class Trainer(object):
         store = bool(getattr(args, 'store_states', False))
         self.clock.t = t
         with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):
-            if t == 0 and args.hard_attn and args.commnet:         # trainer.py:45-46 (quirk Q22)
+            cont = t == 0 and self._stream_continues()            # collection mode: the window continues E running streams
+            if t == 0 and args.hard_attn and args.commnet and not cont:   # trainer.py:45-46 (quirk Q22)
                 info['comm_action'] = self._zeros_comm
             if torch.is_grad_enabled() and getattr(self.policy_net, 'obs_env', None) is None:
                 state = state.clone()          # the env reuses its obs buffer; autograd keeps the encoder input
             if args.recurrent:                                     # trainer.py:49-60
-                if args.rnn_type == 'LSTM' and t == 0:
+                if args.rnn_type == 'LSTM' and t == 0 and cont:
+                    if self._rec is not None and self._rec_inplace():
+                        # (h, c) the previous window ended with -> slot 0 of this window's record (fresh rows are zeroed
+                        # inside the launch: an env whose t == 0 starts an episode)
+                        self._prev_hid = self._rec.start_from(*self._prev_hid)
+                elif args.rnn_type == 'LSTM' and t == 0:
                     if self._rec is not None and not torch.is_grad_enabled() and self._rec_inplace():
                         # native update on the one-launch path: the episode record itself holds the recurrent state
                         self._prev_hid = self._rec.start()
@@ -703,7 +719,122 @@ class Trainer(object):
                     episode_mini_mask=mini, live_after=live[-1] * not_done[-1], stats=stats,
                     read_stats=lambda: stats.cpu().numpy())
 
+    def _run_batch_streams(self, epoch):
+        """run_batch in COLLECTION MODE (args.auto_reset) — trainer.py:227-242 as E parallel streams: the reference plays
+        whole episodes one after the other until the batch holds batch_size steps; here every env plays whole episodes one
+        after the other (an env that finishes restarts inside the step launch), window after window of max_steps slots,
+        until the batch holds batch_size slots.  The reference never sees part of an episode, so what is still running
+        when the batch closes is DISCARDED: a slot counts (misc['live'], alive_mask, every statistic) only if its episode
+        ends inside the batch.  What the update then sees is exactly a set of complete reference episodes — per env the
+        consecutive ones that fit — with episode_mask cutting the return scan at every episode end
+        (trainer.py:163-175), the recurrent state and its gradient cut there too (bptt.backward_episode)."""
+        args = self.args
+        E, T, N = self.env.nenvs, args.max_steps, args.nagents
+        self.stats = dict()
+        wins, slots = [], 0
+        try:
+            while slots < args.batch_size:
+                if args.batch_size - slots <= T * E:
+                    self.last_step = True
+                self._stream = dict(cont=bool(wins))
+                self.begin_episode(epoch)
+                for t in range(T):
+                    self.step_episode(t)
+                wins.append(self._end_window())
+                slots += T * E
+        finally:
+            self._stream = None
+            self.last_step = False
+        done_all = torch.cat([w['done'] for w in wins]).to(torch.bool)                 # (slots, E): the step ends the env's episode
+        # complete[t, e] = an episode end at or after slot t: the slot's episode ends inside the batch
+        complete = torch.flip(torch.cummax(torch.flip(done_all.to(torch.int32), [0]), 0).values, [0]).to(torch.float32)
+        gated = bool(args.hard_attn and args.commnet)
+        rsum = torch.zeros(N, dtype=torch.float64, device=done_all.device)
+        csum = torch.zeros(N, dtype=torch.float64, device=done_all.device)
+        batch = []
+        for k, w in enumerate(wins):
+            cw = complete[k * T:(k + 1) * T]
+            w['live'].mul_(cw)                                     # (in place: the window's lazy Transitions read these)
+            w['alive_mask'].mul_(cw.unsqueeze(2))
+            rsum += (w['reward'] * cw.unsqueeze(2)).double().sum((0, 1))
+            if gated:
+                g = torch.ones_like(w['reward']) if args.comm_action_one else w['gate'].to(torch.float32)
+                csum += (g * cw.unsqueeze(2)).double().sum((0, 1))
+            batch += w['episode']
+        # the cuts of the recurrence, for the backward pass: fresh[t] = the env starts an episode at slot t; keep[t] = the
+        # state leaving slot t reaches slot t + 1 of the SAME episode with its gradient (no episode end, no detach point of
+        # the env's own step counter: trainer.py:56-60)
+        ntot = done_all.shape[0]
+        fresh = torch.ones_like(done_all)
+        fresh[1:] = done_all[:-1]
+        idx = torch.arange(ntot, device=done_all.device).unsqueeze(1).expand(ntot, E)
+        tstep = idx - torch.cummax(torch.where(fresh, idx, torch.zeros_like(idx)), 0).values
+        gap = int(getattr(args, 'detach_gap', 10000))
+        keep = ~(done_all | ((tstep + 1) % gap == 0))
+        if self._records is not None:
+            for k, rec in enumerate(self._records):
+                rec.stream = dict(fresh=fresh[k * T:(k + 1) * T], keep=keep[k * T:(k + 1) * T], first=(k == 0),
+                                  last=(k == len(wins) - 1))
+        nsteps = float(complete.sum().item())                     # (synchronises, like the per-episode statistics read)
+        st = dict(num_steps=nsteps, steps_taken=nsteps)
+        enemy = bool(getattr(args, 'enemy_comm', False))
+        rs = rsum.cpu().numpy()
+        st['reward'] = rs[:args.nfriendly].copy()
+        if enemy:
+            st['enemy_reward'] = rs[args.nfriendly:].copy()
+        if gated:
+            cs = csum.cpu().numpy()
+            st['comm_action'] = cs[:args.nfriendly].copy()
+            if enemy:
+                st['enemy_comm'] = cs[args.nfriendly:].copy()
+        # env statistics (env_wrappers.get_stat) of the FINISHED episodes only: the device counters of the in-launch restarts
+        raw = self.env.env
+        ds = raw.device_stats()
+        n_ep = float(ds.auto_episodes)
+        if raw.dims.kind != 1 or raw.mode != 'competitive':
+            st['success'] = ds.auto_success_sum
+        if raw.dims.kind == 2:
+            st['add_rate'] = ds.add_rate * n_ep
+        merge_stat(st, self.stats)
+        self.stats['num_episodes'] = n_ep
+        self.stats['num_steps'] = nsteps
+        return Transition(*zip(*batch)), self.stats
+
+    def _end_window(self):
+        """end_episode of a collection window: masks of the max_steps slots just played (no cut at the window's end: the
+        streams run on) — statistics and the complete-episode mask are formed over the whole batch by _run_batch_streams."""
+        args = self.args
+        if getattr(self, '_side', None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        n, buf = self._nsteps, self._buf
+        E, N = buf['reward'].shape[1:]
+        has_info = self.env.env.dims.kind == 2
+        reward, action, done = buf['reward'][:n], buf['action'][:n], buf['done'][:n]
+        gated = bool(args.hard_attn and args.commnet)
+        gate = action[:, -1] if gated and not args.comm_action_one else None
+        m = ops.episode_finalize(done, reward, buf['alive'][:n] if has_info else None,
+                                 buf['is_completed'][:n] if has_info else None, gate, gated and bool(args.comm_action_one),
+                                 True, False, work=self._fin_work)
+        alive_mask, episode_mini_mask, live = m['alive_mask'], m['episode_mini_mask'], m['live']
+        episode_mask = m['episode_mask'].unsqueeze(2).expand(n, E, N)
+        done_t = m['episode_mask'] == 0
+        step_out = self._step_out
+
+        def transition(t):
+            cur_state, action_out, value, next_state = step_out[t]
+            return Transition(cur_state, action[t], action_out, value, episode_mask[t], episode_mini_mask[t], next_state,
+                              reward[t], {'alive_mask': alive_mask[t], 'live': live[t], 'done': done_t[t]})
+        self._live = m['live_after']
+        self._episodes_played += 1
+        if self._rec is not None:
+            self._rec.finish(self._prev_hid)
+            self._records.append(self._rec)
+            self._rec = None
+        return dict(episode=LazyEpisode(n, transition), done=done, reward=reward, gate=gate, live=live, alive_mask=alive_mask)
+
     def run_batch(self, epoch):                                    # trainer.py:227-242
+        if self._auto_reset():
+            return self._run_batch_streams(epoch)
         batch = []
         self.stats = dict()
         self.stats['num_episodes'] = 0
@@ -781,15 +912,18 @@ class Trainer(object):
         """args.native_update (default): the update runs on a NO-GRAD rollout + an explicit backward through time
         (ic3net_amd.bptt) when the policy is the recurrent CommNet / IC3Net; otherwise through autograd."""
         raw = getattr(self.env, 'env', None)
-        if self._auto_reset():
-            # episode cuts inside a window: the recorded (h, c) / masks of a restarted env are the previous episode's and
-            # the recurrent gradient would cross the cut — not handled by bptt; the autograd rollout then raises the
-            # explicit NotImplementedError of _step_body (as before round 3)
-            return False
         if not (bool(getattr(self.args, 'native_update', True)) and raw is not None and hasattr(raw, '_h')):
             return False
         knet = self._kernel_net()
-        return bptt.supported(self.args if knet is self.policy_net else knet.args, knet, raw)
+        if not bptt.supported(self.args if knet is self.policy_net else knet.args, knet, raw):
+            return False
+        if self._auto_reset():
+            # collection mode: episode cuts inside the windows — handled by bptt.backward_episode for the recurrent policy
+            # with one communication pass on the one-launch rollout (the launch restarts finished envs itself); other
+            # policies keep the explicit NotImplementedError of _step_body
+            return bool(getattr(self.args, 'recurrent', False)) and getattr(knet, 'comm_passes', 1) == 1 \
+                and not bptt._is_baseline(knet) and self._mega_expected(raw)
+        return True
 
     def compute_grad_native(self, batch, records):
         """compute_grad() without an autograd graph: losses and dL/d(logits, value) from the batch, then
@@ -801,9 +935,21 @@ class Trainer(object):
         t0 = 0
         raw = self.env.env
         with torch.no_grad():
-            for rec in records:
-                bptt.backward_episode(kargs, knet, raw, rec, d_out[t0:t0 + rec.n], acc)
-                t0 += rec.n
+            if records and getattr(records[0], 'stream', None) is not None:
+                # collection mode: the windows are consecutive slots of the same E streams — last window first, the gradient
+                # of the recurrent state handed from a window's first slot to the previous window's last one
+                offs = [0]
+                for rec in records:
+                    offs.append(offs[-1] + rec.n)
+                assert offs[-1] == d_out.shape[0], "recorded steps do not match the batch"
+                carry = None
+                for k in reversed(range(len(records))):
+                    carry = bptt.backward_episode(kargs, knet, raw, records[k], d_out[offs[k]:offs[k + 1]], acc, carry=carry)
+                t0 = offs[-1]
+            else:
+                for rec in records:
+                    bptt.backward_episode(kargs, knet, raw, rec, d_out[t0:t0 + rec.n], acc)
+                    t0 += rec.n
             assert t0 == d_out.shape[0], "recorded steps do not match the batch"
             bptt.assign_grads(knet, acc)
             if knet is not self.policy_net:

@@ -435,6 +435,111 @@ def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, **flags):
     print(name, 'steps', stats['num_steps'], 'losses', s)
 
 
+def grad_stream_case(name, env_name, T, nenv, nwin, seed, closed_form=False, **flags):
+    """F5c — collection mode: the reference's run_batch + compute_grad (trainer.py:227-242,128-225) over, per env, the
+    consecutive WHOLE episodes that fit in nwin * T slots (`while: get_episode()` of one reference process per env, the batch
+    their concatenation) — what one auto-reset rollout of nwin windows holds here, the unfinished tail of every stream
+    discarded.  Actions are SAMPLED, not taped: the reference's own log-probs (float32) through the build's Philox
+    inverse-CDF draw (oracle.sample_one, counters = env, the env's episode and step: what ic3_policy_step draws), so that the
+    one-launch rollout — which samples inside the launch — plays the same episodes."""
+    import oracle
+    ref = rh.load_reference()
+    torch.set_default_dtype(torch.float64)
+    a = rh.make_args(env_name, max_steps=T, seed=seed, **flags)
+    env = rh.make_env(env_name, a)
+    rh.finish_args(a, env)
+    torch.manual_seed(seed)
+    net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    if closed_form:
+        sd = net.state_dict()
+        cw = closed_form_weights({k: tuple(v.shape) for k, v in sd.items()})
+        net.load_state_dict({k: torch.from_numpy(cw[k]) for k in sd})
+    tr = ref['trainer'].Trainer(a, net, env)
+    N, nh = a.nagents, len(a.naction_heads)
+    cursor = {}
+    trmod = ref['trainer']
+    played = []
+
+    def sampled_select(args, action_out):
+        e, ep, t = cursor['e'], cursor['ep'], cursor['t']
+        cursor['t'] += 1
+        if env_name == 'traffic_junction':
+            ref['rnd'].begin(cursor['st'], philox.DOMAIN_TJ_ADD, ep, t)
+        act = np.zeros((nh, N), np.int64)
+        for h in range(nh):
+            lp = action_out[h].detach().numpy().reshape(N, -1).astype(np.float32)
+            for n in range(N):
+                act[h, n] = oracle.sample_one(lp[n], philox.x24(seed, 400 + e, philox.DOMAIN_SAMPLE, ep, t, h * N + n))
+        played.append((e, ep, t, act.copy()))
+        return torch.from_numpy(act).view(nh, 1, N, 1)
+    trmod.select_action = sampled_select
+    batch = []
+    stats = dict(num_episodes=0)
+    streams = [philox.Stream(seed, 400 + e) for e in range(nenv)]
+    envs = [rh.make_env(env_name, a) for e in range(nenv)]
+    lengths = []
+    for e in range(nenv):
+        tr.env = envs[e]
+        slots, ep, lens = 0, 0, []
+        while True:
+            cursor.update(e=e, ep=ep, t=0, st=streams[e])
+            ref['rnd'].begin(streams[e], philox.DOMAIN_PP_RESET, ep, 0)
+            n0 = len(played)
+            episode, stat = tr.get_episode(ep)
+            if slots + len(episode) > nwin * T:          # does not end inside the batch: discarded
+                del played[n0:]
+                break
+            slots += len(episode)
+            lens.append(len(episode))
+            ref['utils'].merge_stat(stat, stats)
+            stats['num_episodes'] += 1
+            batch += episode
+            ep += 1
+        lengths.append(lens)
+    trmod.select_action = ref['action_utils'].select_action
+    stats['num_steps'] = len(batch)
+    batch = trmod.Transition(*zip(*batch))
+    tr.optimizer.zero_grad()
+    s = tr.compute_grad(batch)
+    maxep = max(len(l) for l in lengths)
+    ep_len = np.zeros((nenv, maxep), np.int32)
+    for e, l in enumerate(lengths):
+        ep_len[e, :len(l)] = l
+    acts = np.full((nenv, nwin * T, nh, N), -1, np.int32)     # per env, slot by slot (diagnostics for a diverging draw)
+    off = {}
+    for e, ep, t, act in played:
+        base = int(ep_len[e, :ep].sum())
+        acts[e, base + t] = act
+    out = dict(cfg=np.array([N, T, nenv, nwin, nh, seed], np.int32), flags=np.array(repr(sorted(flags.items()))),
+               ep_len=ep_len, actions=acts, action_loss=s['action_loss'], value_loss=s['value_loss'],
+               entropy=s.get('entropy', 0.0), num_steps=stats['num_steps'], num_episodes=stats['num_episodes'],
+               reward=np.asarray(stats['reward'], np.float64), success=float(stats.get('success', 0)))
+    if closed_form:
+        out['param_names'] = np.array(list(net.state_dict().keys()))
+        out['param_shapes'] = np.array([repr(tuple(v.shape)) for v in net.state_dict().values()])
+    else:
+        for k, v in net.state_dict().items():
+            out['w:' + k] = v.detach().numpy().copy()
+    for k, p in net.named_parameters():
+        g = np.zeros(0) if p.grad is None else p.grad.detach().numpy().copy()
+        out['g:' + k] = g.astype(np.float32) if closed_form else g
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'steps', stats['num_steps'], 'episodes', stats['num_episodes'], 'lengths', lengths, 'losses', s)
+
+
+def grad_stream_main():
+    """Collection-mode fixtures (round-4 verdict item 5): a tiny Predator-Prey grid on which sampled policies DO end episodes
+    early (cuts inside the windows, a different number of episodes per env, detach points of the env's own step counter), and
+    Traffic-Junction (episodes of exactly max_steps: the cuts fall on the window borders; alive masks and the gate head)."""
+    grad_stream_case('gradstream_pp_tiny_ic3net', 'predator_prey', 12, 6, 3, 51, nagents=2, dim=3, vision=1, hid_size=16,
+                     ic3net=True, recurrent=True, detach_gap=5, entr=0.01, value_coeff=0.01, mode='mixed')
+    grad_stream_case('gradstream_pp_tiny_commnet', 'predator_prey', 10, 5, 2, 52, nagents=2, dim=3, vision=0, hid_size=16,
+                     commnet=True, recurrent=True, detach_gap=4, normalize_rewards=True, mean_ratio=0.5, gamma=0.9,
+                     mode='mixed')
+    grad_stream_case('gradstream_tj_easy_ic3net', 'traffic_junction', 10, 4, 2, 53, nagents=5, dim=6, vision=0, hid_size=16,
+                     ic3net=True, recurrent=True, detach_gap=4, add_rate_min=0.3, add_rate_max=0.3, difficulty='easy')
+
+
 def trainer_main():
     grad_case('grad_pp_easy_ic3net', 'predator_prey', 20, 4, 2, 31, nagents=3, dim=5, vision=0, hid_size=16,
               ic3net=True, recurrent=True, detach_gap=10, entr=0.01, value_coeff=0.01)
@@ -499,6 +604,8 @@ if __name__ == '__main__':
         grad_nonrec_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_fullsize':
         grad_fullsize_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream':
+        grad_stream_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':
         trainer_fullsize_main()
     else:

@@ -35,11 +35,12 @@ RECIPES = {
     'trainer': ['make_golden_policy.py', 'trainer'],          # (runs trainer_fullsize too)
     'grad_nonrec': ['make_golden_policy.py', 'grad_nonrec'],
     'grad_fullsize': ['make_golden_policy.py', 'grad_fullsize'],
+    'grad_stream': ['make_golden_policy.py', 'grad_stream'],
     'render': ['make_golden_render.py'],
     'ckpt': ['make_golden_ckpt.py'],
 }
 # every committed data fixture must come out of one of the recipes above
-EXPECTED_MIN_NPZ = 59
+EXPECTED_MIN_NPZ = 62
 
 
 @pytest.fixture(scope='module')

@@ -317,6 +317,91 @@ def test_compute_grad_matches_reference(name, env_name, native):
         np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=3e-4, err_msg=pname)
 
 
+STREAM_FIXTURES = [("gradstream_pp_tiny_ic3net", "predator_prey"), ("gradstream_pp_tiny_commnet", "predator_prey"),
+                   ("gradstream_tj_easy_ic3net", "traffic_junction")]
+
+
+@pytest.mark.parametrize("name,env_name", STREAM_FIXTURES)
+def test_collection_mode_grad_matches_reference(name, env_name):
+    """train_batch in COLLECTION MODE (args.auto_reset; round-4 verdict item 5) against the reference in one hop: the
+    fixture is the reference's run_batch + compute_grad (trainer.py:227-242,128-225) over, per env, the consecutive whole
+    episodes that fit in nwin * max_steps slots — episodes of different lengths (Predator-Prey 'mixed' ends when every
+    predator sits on the prey), a different number per env — with the actions drawn from the reference's own log-probs by
+    the Philox inverse-CDF draw of ic3_policy_step.  Here: ONE auto-reset rollout of nwin windows on the one-launch kernel
+    (envs restart inside the launch), the unfinished tails discarded, and the native backward with the recurrence cut at
+    every episode end and at every detach point of an env's own step counter."""
+    from ic3net_amd import data, trainer as trmod
+    from ic3net_amd.action_utils import parse_action_args
+    from ic3net_amd.comm import CommNetMLP
+    fx = load(name)
+    N, T, nenv, nwin, nh, seed = [int(x) for x in fx["cfg"]]
+    flags = dict(ast.literal_eval(str(fx["flags"])))
+    a = build_args(env_name, flags, N, T, nenv, seed)
+    a.env_id_offset = 400
+    a.auto_reset = True
+    env = data.init(env_name, a, False)
+    a.num_actions = [env.num_actions]
+    a.dim_actions = env.dim_actions
+    a.num_inputs = env.observation_dim
+    if a.hard_attn and a.commnet:
+        a.num_actions = [*a.num_actions, 2]
+        a.dim_actions = env.dim_actions + 1
+    if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
+        a.recurrent, a.rnn_type = True, 'LSTM'
+    parse_action_args(a)
+    net = CommNetMLP(a, a.num_inputs)
+    net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
+    net = net.cuda()
+    tr = trmod.Trainer(a, net, env)
+    a.batch_size = nenv * T * nwin                      # slots: exactly nwin windows
+    assert tr._native_update(), "collection mode must take the native update"
+    tr._records = []
+    try:
+        batch, stats = tr.run_batch(0)
+        assert len(tr._records) == nwin and len(batch.reward) == nwin * T
+        # the slots that count are the reference's batch: the same episodes, step for step
+        ep_len = fx["ep_len"]
+        act = torch.stack(batch.action).cpu().numpy()               # (slots, heads, E, N)
+        live = torch.stack([m['live'] for m in batch.misc]).cpu().numpy()
+        for e in range(nenv):
+            n_ref = int(ep_len[e].sum())
+            assert live[:, e].sum() == n_ref and live[:n_ref, e].all(), (e, live[:, e], ep_len[e])
+            np.testing.assert_array_equal(act[:n_ref, :, e], fx["actions"][e, :n_ref], err_msg="env %d: a draw diverged" % e)
+        assert stats['num_steps'] == int(fx["num_steps"]) and stats['num_episodes'] == int(fx["num_episodes"])
+        np.testing.assert_allclose(stats['reward'], fx["reward"], rtol=1e-5, atol=1e-5)
+        if env_name != 'predator_prey' or a.mode != 'competitive':
+            assert stats['success'] == pytest.approx(float(fx["success"]))
+        tr.optimizer.zero_grad()
+        s = tr.compute_grad_native(batch, tr._records)
+    finally:
+        tr._records = None
+    for k in ("action_loss", "value_loss", "entropy"):
+        np.testing.assert_allclose(s[k], float(fx[k]), rtol=2e-4, atol=1e-3, err_msg=k)
+    for pname, p in net.named_parameters():
+        g = fx["g:" + pname]
+        if g.size == 0:
+            assert p.grad is None, pname
+            continue
+        scale = max(np.abs(g).max(), 1e-6)
+        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=3e-4, err_msg=pname)
+
+
+def test_collection_mode_train_batch_runs_at_a_baseline_shape():
+    """train_batch under args.auto_reset end to end (PP-hard shape, fewer envs, two windows per update): runs, updates the
+    parameters, counts only whole episodes."""
+    import bench
+    tr, a = bench.build_trainer("pp_hard", 48, 3, 0, 0, max_steps=20)
+    a.auto_reset = True
+    a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0.01, value_coeff=0.01, advantages_per_action=False,
+                      batch_size=2 * 48 * 20)
+    before = tr.policy_net.encoder.weight.detach().clone()
+    st = tr.train_batch(0)
+    assert st['num_steps'] == 2 * 48 * 20 and st['num_episodes'] == 2 * 48      # a random-init PP-hard policy never ends early
+    assert np.isfinite(st['action_loss']) and not torch.equal(before, tr.policy_net.encoder.weight)
+    st = tr.train_batch(1)
+    assert np.isfinite(st['value_loss'])
+
+
 def test_train_batch_updates_parameters():
     from ic3net_amd import data, trainer as trmod
     from ic3net_amd.action_utils import parse_action_args
