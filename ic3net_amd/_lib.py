@@ -92,6 +92,9 @@ EXPORTS = {
     "ic3_env_encode_backward_work": (C.c_int64, [C.c_void_p, C.c_int]),
     "ic3_env_encode_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    "ic3_env_encode_backward_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                     C.c_void_p]),
+    "ic3_env_encode_backward_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ic3_env_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ic3_env_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -102,6 +105,8 @@ EXPORTS = {
     "ic3_tj_get_add_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ic3_env_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     "ic3_comm_masked_mean": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
+    "ic3_comm_masked_mean_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                                 + [C.c_int] * 5 + [C.c_void_p]),
     "ic3_lstm_cell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
     "ic3_policy_pack_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -139,6 +144,8 @@ EXPORTS = {
     "ic3_env_set_step_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_episode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ic3_episode_finalize": (C.c_int, [C.POINTER(Episode), C.c_void_p]),
+    "ic3_returns_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_int, C.c_void_p]),
 }

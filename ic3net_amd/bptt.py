@@ -145,6 +145,24 @@ class EpisodeRecord(object):
             self.h_last = h.detach().reshape(self.hs.shape[1:]).clone()
 
 
+def _returns(args, rewards, episode_masks, episode_mini_masks):
+    """trainer.py:162-171: the reversed scan of the cooperative and the per-agent returns and their mix — one launch
+    (ic3_returns_scan) on the GPU for up to 256 agents, the reference's loop otherwise."""
+    T, E, n = rewards.shape
+    if rewards.is_cuda and n <= 256 and rewards.dtype == torch.float32:
+        return ops.returns_scan(rewards, episode_masks, episode_mini_masks, args.gamma, args.mean_ratio)
+    coop_returns = torch.empty_like(rewards)
+    ncoop_returns = torch.empty_like(rewards)
+    prev_coop = torch.zeros_like(rewards[0])
+    prev_ncoop = torch.zeros_like(rewards[0])
+    for i in reversed(range(T)):
+        coop_returns[i] = rewards[i] + args.gamma * prev_coop * episode_masks[i]
+        ncoop_returns[i] = rewards[i] + args.gamma * prev_ncoop * episode_masks[i] * episode_mini_masks[i]
+        prev_coop = coop_returns[i]
+        prev_ncoop = ncoop_returns[i]
+    return args.mean_ratio * coop_returns.mean(dim=2, keepdim=True) + (1 - args.mean_ratio) * ncoop_returns
+
+
 def loss_gradients(args, batch):
     """trainer.py:128-218 up to the losses: returns (stat, d_out) with d_out (T, R, OT) = dL/d[logits of every head |
     value] of every transition (the log-softmax is folded in: gradients w.r.t. its INPUT)."""
@@ -160,16 +178,7 @@ def loss_gradients(args, batch):
     alive_masks = torch.stack([m['alive_mask'] for m in batch.misc])      # (T, E, N), already x live
     live = torch.stack([m['live'] for m in batch.misc]).unsqueeze(2).expand(T, E, n)
 
-    coop_returns = torch.empty_like(rewards)
-    ncoop_returns = torch.empty_like(rewards)
-    prev_coop = torch.zeros_like(rewards[0])
-    prev_ncoop = torch.zeros_like(rewards[0])
-    for i in reversed(range(T)):                                          # trainer.py:162-170
-        coop_returns[i] = rewards[i] + args.gamma * prev_coop * episode_masks[i]
-        ncoop_returns[i] = rewards[i] + args.gamma * prev_ncoop * episode_masks[i] * episode_mini_masks[i]
-        prev_coop = coop_returns[i]
-        prev_ncoop = ncoop_returns[i]
-    returns = args.mean_ratio * coop_returns.mean(dim=2, keepdim=True) + (1 - args.mean_ratio) * ncoop_returns
+    returns = _returns(args, rewards, episode_masks, episode_mini_masks)  # trainer.py:162-171
     advantages = returns - values                                         # trainer.py:173-174 (values carry no graph here)
     if args.normalize_rewards:                                            # trainer.py:176-177 (live entries only)
         cnt = live.sum()
@@ -231,7 +240,7 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     w_cat_t = fc['w_cat_t']                                               # (2H, 4H) = [W_ih | W_hh]^T
     z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     xh, comm, dgates = z(R, 2 * H), z(E, N, H), z(R, 4 * H)   # xh = [inp | h_{t-1}]
-    dxh, dcomm, dcomm_b, dh = z(R, 2 * H), z(R, H), z(E, N, H), z(R, H)           # dxh = [d inp | d h_{t-1}]
+    dxh, dcomm = z(R, 2 * H), z(R, H)                                      # dxh = [d inp | d h_{t-1}]
     inp, dinp = xh[:, :H], dxh[:, :H]
     # gate recompute + cell backward in one launch when the packed gate weights of the rollout kernel exist (hid 64/128/256);
     # its bias partials accumulate over the episode's steps and are reduced once, behind the loop
@@ -251,6 +260,7 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)         # dL/dh_t, dL/dc_t arriving from step t + 1
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
+    enc_acc = None        # None: no state accumulated yet; True: partial sums hold the steps so far; False: per-step form
     stream = rec.stream
     if stream is not None:
         if carry is not None:
@@ -290,7 +300,9 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
             torch.addmm(fc['b_cat'], xh, w_cat_t, out=gates)              # one K = 2H product, as in the rollout
         # ---- heads (comm.py:228,239) -> LSTM cell
         d = d_out[t]
-        torch.addmm(dh_rec, d, fc['w_heads'], out=dh)                     # dL/dh_t = what step t + 1 sent back + the heads' share
+        # dL/dh_t = what step t + 1 sent back + the heads' share — in place (addmm with another `out` first copies R x H floats);
+        # dh_rec is rewritten with dL/dh_{t-1} at the end of the iteration, after the cell backward has consumed it
+        dh = dh_rec.addmm_(d, fc['w_heads'])
         if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
             # (the heads' own weight gradient is one pass over the whole episode behind the loop: ic3_heads_grad)
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
@@ -315,11 +327,20 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
             else:
                 acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
             torch.mm(dinp, fc['c_wt'].t(), out=dcomm)                     # d comm = d inp . C.weight
-            ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dcomm_b)
-            torch.add(dxh[:, H:], dcomm_b.view(R, H), out=dh_rec)         # dL/dh_{t-1}: what step t - 1 receives
+            # dL/dh_{t-1} (what step t - 1 receives) = d h of the gate product + the communication block's share, one pass
+            ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dh_rec.view(E, N, H), addend=dxh[:, H:])
         else:
             dh_rec.copy_(dxh[:, H:])
-        dwt, db = raw.encode_backward(dinp, rec.snaps[t], want_bias=True)    # db = sum of the d inp rows: both biases
+        # encoder: the first stage per step adds to partial sums, the expansion into (obs_dim, H) runs once behind the loop
+        if enc_acc is not False:
+            enc_acc = raw.encode_backward_accumulate(dinp, rec.snaps[t], first=(enc_acc is None)) \
+                if hasattr(raw, 'encode_backward_accumulate') else False
+        if enc_acc is False:
+            dwt, db = raw.encode_backward(dinp, rec.snaps[t], want_bias=True)    # db = sum of the d inp rows: both biases
+            acc['wt'].add_(dwt)
+            acc['enc_bias'].add_(db)
+    if enc_acc:
+        dwt, db = raw.encode_backward_finish(H, want_bias=True)
         acc['wt'].add_(dwt)
         acc['enc_bias'].add_(db)
     if NB > 1:

@@ -137,7 +137,7 @@ template <class StageFn, class KeyFn, class RowFn, class PairFn, class RegSlotFn
 __device__ __forceinline__ void enc_bwd_rows(const float* __restrict__ g, int ldg, int E, int rows_env, int total, int H,
                                              int Hc, int npos, int nslots, float* __restrict__ Ppart,
                                              float* __restrict__ Dpart, float* sm, StageFn stage, KeyFn key_fn, RowFn row_fn,
-                                             PairFn pair_fn, RegSlotFn reg_slot)
+                                             PairFn pair_fn, RegSlotFn reg_slot, int accumulate = 0)
 {
     const int C4 = Hc >> 2, RL = 256 / C4;
     const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4;
@@ -228,12 +228,16 @@ __device__ __forceinline__ void enc_bwd_rows(const float* __restrict__ g, int ld
     float* Pg = Ppart + (size_t)blockIdx.x * npos * H + col0;
     for (int i = threadIdx.x; i < npos * C4; i += 256) {
         const int pos = i / C4, k = i - pos * C4;
-        *reinterpret_cast<encb_f32x4*>(Pg + (size_t)pos * H + 4 * k) = Pl4[i];
+        // accumulate (ic3_env_encode_backward_accumulate): the workgroup's partial of the previous calls + this call's — the
+        // expand stage is linear in the partials, so a whole episode's states need it ONCE
+        encb_f32x4* dst = reinterpret_cast<encb_f32x4*>(Pg + (size_t)pos * H + 4 * k);
+        *dst = accumulate ? *dst + Pl4[i] : Pl4[i];
     }
     float* Dg = Dpart + (size_t)blockIdx.x * (nslots + 1) * H + col0;
     for (int i = threadIdx.x; i < (nslots + 1) * C4; i += 256) {
         const int s = i / C4, k = i - s * C4;
-        *reinterpret_cast<encb_f32x4*>(Dg + (size_t)s * H + 4 * k) = reinterpret_cast<const encb_f32x4*>(Dl)[i];
+        encb_f32x4* dst = reinterpret_cast<encb_f32x4*>(Dg + (size_t)s * H + 4 * k);
+        *dst = accumulate ? *dst + reinterpret_cast<const encb_f32x4*>(Dl)[i] : reinterpret_cast<const encb_f32x4*>(Dl)[i];
     }
 }
 

@@ -155,11 +155,73 @@ __global__ __launch_bounds__(EF_THREADS) void episode_reduce_kernel(ic3_episode 
     }
 }
 
+// ic3_returns_scan — the reversed return scan of compute_grad (/root/reference/trainer.py:162-171) over T slots of E envs x N
+// agents in ONE launch (as a Python loop over the slots it is ~9 tensor ops per slot: 720 launches per 80-step update):
+//   coop[t]  = reward[t] + gamma * coop[t + 1]  * episode_mask[t]
+//   ncoop[t] = reward[t] + gamma * ncoop[t + 1] * episode_mask[t] * episode_mini_mask[t]
+//   returns[t][e][n] = mean_ratio * mean_n coop[t][e][:] + (1 - mean_ratio) * ncoop[t][e][n]
+// One thread per (env, agent) walks the slots backwards (coalesced across the (env, agent) index); the mean over an env's
+// agents goes through LDS (the block holds whole envs).  Slots are read in batches so that several loads are in flight.
+__global__ __launch_bounds__(EF_THREADS) void returns_scan_kernel(const float* __restrict__ reward, const float* __restrict__ emask,
+                                                                  const float* __restrict__ mini, float gamma, float mean_ratio,
+                                                                  float* __restrict__ returns, int T, int E, int N, int epb)
+{
+    __shared__ float sh[EF_THREADS];
+    const int tid = threadIdx.x;
+    const int el = tid / N, ag = tid - el * N;
+    const int e = blockIdx.x * epb + el;
+    const bool valid = el < epb && e < E;
+    const size_t EN = (size_t)E * N, en = valid ? (size_t)e * N + ag : 0;
+    const int ec = valid ? e : 0;
+    const float invN = 1.0f / (float)N;
+    float coop = 0.0f, ncoop = 0.0f;
+    constexpr int TB = 4;
+    for (int t1 = T; t1 > 0; t1 -= TB) {
+        float rw[TB], em[TB], mm[TB];
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const int t = max(t1 - 1 - k, 0);
+            rw[k] = reward[(size_t)t * EN + en];
+            em[k] = emask[(size_t)t * E + ec];
+            mm[k] = mini[(size_t)t * EN + en];
+        }
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const int t = t1 - 1 - k;
+            if (t < 0) break;                                       // (uniform)
+            coop = rw[k] + gamma * coop * em[k];
+            ncoop = rw[k] + gamma * ncoop * em[k] * mm[k];
+            float mean = 0.0f;
+            if (mean_ratio != 0.0f) {                               // (uniform)
+                __syncthreads();
+                sh[tid] = valid ? coop : 0.0f;
+                __syncthreads();
+                for (int j = 0; j < N; ++j) mean += sh[el * N + j];   // fixed order
+                mean *= invN;
+            }
+            if (valid) returns[(size_t)t * EN + en] = mean_ratio * mean + (1.0f - mean_ratio) * ncoop;
+        }
+    }
+}
+
 }  // namespace ic3
 
 using namespace ic3;
 
 extern "C" {
+
+int ic3_returns_scan(const float* reward, const float* episode_mask, const float* episode_mini_mask, float gamma, float mean_ratio,
+                     float* returns, int T, int E, int N, ic3_stream stream)
+{
+    Range range("ic3_returns_scan");
+    if (!reward || !episode_mask || !episode_mini_mask || !returns) return fail(-22, "ic3_returns_scan: null argument");
+    if (T <= 0 || E <= 0 || N <= 0 || N > EF_THREADS) return fail(-22, "ic3_returns_scan: bad sizes (1..256 agents per env)");
+    const int epb = EF_THREADS / N;
+    hipLaunchKernelGGL(returns_scan_kernel, dim3((E + epb - 1) / epb), dim3(EF_THREADS), 0, (hipStream_t)stream, reward, episode_mask,
+                       episode_mini_mask, gamma, mean_ratio, returns, T, E, N, epb);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
 
 size_t ic3_episode_scratch_bytes(int E, int N)
 {

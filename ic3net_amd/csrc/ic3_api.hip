@@ -438,6 +438,26 @@ int ic3_env_encode_backward(ic3_env* env, const int32_t* snap, const float* grad
                                    : tj_encode_bwd(env, snap, grad_out, ldg, H, dWt, dbias, work, (hipStream_t)stream);
 }
 
+int ic3_env_encode_backward_accumulate(ic3_env* env, const int32_t* snap, const float* grad_out, int ldg, int H, float* work,
+                                       int first, ic3_stream stream)
+{
+    if (!env || !grad_out || !work) return fail(-22, "ic3_env_encode_backward_accumulate: null argument");
+    if (ldg <= 0) ldg = H;
+    if (H <= 0 || (H & 3) || (ldg & 3) || ldg < H)
+        return fail(-22, "ic3_env_encode_backward_accumulate: H and ldg must be positive multiples of 4");
+    const int mode = first ? 1 : 2;
+    return env->kind == IC3_ENV_PP ? pp_encode_bwd(env, snap, grad_out, ldg, H, nullptr, nullptr, work, (hipStream_t)stream, mode)
+                                   : tj_encode_bwd(env, snap, grad_out, ldg, H, nullptr, nullptr, work, (hipStream_t)stream, mode);
+}
+
+int ic3_env_encode_backward_finish(ic3_env* env, int H, float* dWt, float* dbias, float* work, ic3_stream stream)
+{
+    if (!env || !dWt || !work) return fail(-22, "ic3_env_encode_backward_finish: null argument");
+    if (H <= 0 || (H & 3)) return fail(-22, "ic3_env_encode_backward_finish: H must be a positive multiple of 4");
+    return env->kind == IC3_ENV_PP ? pp_encode_bwd(env, nullptr, nullptr, H, H, dWt, dbias, work, (hipStream_t)stream, 3)
+                                   : tj_encode_bwd(env, nullptr, nullptr, H, H, dWt, dbias, work, (hipStream_t)stream, 3);
+}
+
 int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,
                  int32_t* is_completed, ic3_stream stream)
 {

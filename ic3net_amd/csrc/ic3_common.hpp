@@ -177,10 +177,11 @@ int tj_encode_table(ic3_env* env, const float* Wt, int H, float* table, hipStrea
 // sparse-encoder backward (enc_bwd.hpp)
 int64_t pp_encode_bwd_work(const ic3_env* env, int H);
 int64_t tj_encode_bwd_work(const ic3_env* env, int H);
+// mode 0: both stages; 1 / 2: stage 1 writing / adding to the partials in `work`; 3: stage 2 alone
 int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias, float* work,
-                  hipStream_t s);
+                  hipStream_t s, int mode = 0);
 int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias, float* work,
-                  hipStream_t s);
+                  hipStream_t s, int mode = 0);
 // tj_tables.cpp (host)
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
                                                                const int32_t* __restrict__ alive,
                                                                const int32_t* __restrict__ comm_action,
                                                                float* __restrict__ out, int E, int N, int H4,
-                                                               int mode_avg, int mask_self)
+                                                               int mode_avg, int mask_self,
+                                                               const float* __restrict__ addend = nullptr, int lda = 0)
 {
     const int per_block = blockDim.x / H4;
     const int e = blockIdx.x * per_block + threadIdx.x / H4;
@@ -37,8 +38,12 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
     for (int j = 0; j < N; ++j) n_alive += alive ? alive[(size_t)e * N + j] : 1;   // comm.py:102-107, quirk Q21
     const float scale = (mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;  // comm.py:194-196, Q23
     f32x4* oe = reinterpret_cast<f32x4*>(out + (size_t)e * N * H4 * 4) + k;
+    // ic3_comm_masked_mean_add: out = addend + the block's output (addend rows may be a strided column slice)
+    auto add = [&](int j) {
+        return addend ? *reinterpret_cast<const f32x4*>(addend + ((size_t)e * N + j) * lda + 4 * k) : f32x4{ 0.f, 0.f, 0.f, 0.f };
+    };
     if (!mask_self) {  // comm_mask_zero: comm.py:40-41 -> all-zero communication
-        for (int j = 0; j < N; ++j) oe[(size_t)j * H4] = f32x4{ 0.f, 0.f, 0.f, 0.f };
+        for (int j = 0; j < N; ++j) oe[(size_t)j * H4] = add(j);
         return;
     }
     f32x4 S = { 0.f, 0.f, 0.f, 0.f };
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
             if (i < N) S += mm[i] * hv[i];
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-            if (j < N) oe[(size_t)j * H4] = mm[j] * (S - mm[j] * hv[j]) * scale;
+            if (j < N) oe[(size_t)j * H4] = addend ? add(j) + mm[j] * (S - mm[j] * hv[j]) * scale : mm[j] * (S - mm[j] * hv[j]) * scale;
         return;
     }
     for (int i = 0; i < N; ++i) {
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
         const float m = (float)((alive ? alive[(size_t)e * N + j] : 1) *
                                 (comm_action ? comm_action[(size_t)e * N + j] : 1));
         const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + j) * ldh + 4 * k);
-        oe[(size_t)j * H4] = m * (S - m * hv) * scale;
+        oe[(size_t)j * H4] = addend ? add(j) + m * (S - m * hv) * scale : m * (S - m * hv) * scale;
     }
 }
 
@@ -431,31 +436,50 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* __restrict
 
 }  // namespace ic3
 
-extern "C" int ic3_comm_masked_mean(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, float* out,
-                                    int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream)
+static int comm_masked_mean_launch(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, const float* addend,
+                                   int lda, float* out, int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream,
+                                   const char* who)
 {
-    if (!h || !out || E <= 0 || N <= 0 || H <= 0) return ic3::fail(-22, "ic3_comm_masked_mean: bad arguments");
+    if (!h || !out || E <= 0 || N <= 0 || H <= 0) return ic3::fail(-22, std::string(who) + ": bad arguments");
     if (ldh <= 0) ldh = H;
-    if ((H & 3) == 0 && (ldh & 3) == 0 && H / 4 <= 256) {
+    if (lda <= 0) lda = H;
+    if ((H & 3) == 0 && (ldh & 3) == 0 && (lda & 3) == 0 && H / 4 <= 256) {
         const int H4 = H / 4, per_block = 256 / H4;
         const dim3 grid((E + per_block - 1) / per_block);
         hipStream_t s = (hipStream_t)stream;
         if (N <= 16)
             hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<16>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
-                               H4, mode_avg, mask_self);
+                               H4, mode_avg, mask_self, addend, lda);
         else if (N <= 32)
             hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<32>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
-                               H4, mode_avg, mask_self);
+                               H4, mode_avg, mask_self, addend, lda);
         else
             hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<0>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
-                               H4, mode_avg, mask_self);
+                               H4, mode_avg, mask_self, addend, lda);
     } else {
+        if (addend) return ic3::fail(-38, std::string(who) + ": H, ldh and lda must be multiples of 4");
         const int threads = H >= 256 ? 256 : ((H + 63) / 64) * 64;
         hipLaunchKernelGGL(ic3::comm_masked_mean_scalar_kernel, dim3(E), dim3(threads), 0, (hipStream_t)stream, h, ldh,
                            alive, comm_action, out, N, H, mode_avg, mask_self);
     }
     IC3_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int ic3_comm_masked_mean(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, float* out,
+                                    int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream)
+{
+    return comm_masked_mean_launch(h, ldh, alive, comm_action, nullptr, 0, out, E, N, H, mode_avg, mask_self, stream,
+                                   "ic3_comm_masked_mean");
+}
+
+extern "C" int ic3_comm_masked_mean_add(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action,
+                                        const float* addend, int lda, float* out, int E, int N, int H, int mode_avg,
+                                        int mask_self, ic3_stream stream)
+{
+    if (!addend) return ic3::fail(-22, "ic3_comm_masked_mean_add: null addend");
+    return comm_masked_mean_launch(h, ldh, alive, comm_action, addend, lda, out, E, N, H, mode_avg, mask_self, stream,
+                                   "ic3_comm_masked_mean_add");
 }
 
 extern "C" int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream)

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_rows_kernel(const int32_t* 
                                                                  const int32_t* __restrict__ loc_c,
                                                                  const float* __restrict__ g, int ldg,
                                                                  float* __restrict__ Ppart, float* __restrict__ Dpart, int E,
-                                                                 int N, int nprey, int dim, int v, int H, int Hc, int rows)
+                                                                 int N, int nprey, int dim, int v, int H, int Hc, int rows,
+                                                                 int accumulate)
 {
     IC3_DYNAMIC_LDS(float, smf);
     const int W = 2 * v + 1, total = N + nprey;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_rows_kernel(const int32_t* 
             return (p != a && (unsigned)dy < (unsigned)W && (unsigned)dx < (unsigned)W) ? 2 * (dy * W + dx) + (p >= N ? 1 : 0)
                                                                                          : -1;
         },
-        [&](int k) { return k == 0 ? 2 * centre : (k == 1 ? 2 * centre + 1 : -1); });
+        [&](int k) { return k == 0 ? 2 * centre : (k == 1 ? 2 * centre + 1 : -1); }, accumulate);
 }
 
 // Stage 2 for PP: dWt (zeroed by the caller) += P through the id map, class columns and dbias from the partials.
@@ -335,8 +336,10 @@ int64_t pp_encode_bwd_work(const ic3_env* env, int H)
     return std::max(per_env_form, row_form);
 }
 
+// mode 0: both stages (ic3_env_encode_backward); 1 / 2: stage 1 writing / adding to the partials in `work`
+// (ic3_env_encode_backward_accumulate); 3: stage 2 alone (ic3_env_encode_backward_finish)
 int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias,
-                  float* work, hipStream_t s)
+                  float* work, hipStream_t s, int mode)
 {
     const ic3_pp_cfg& c = env->pp;
     const int rows = env->dims.N;
@@ -347,18 +350,25 @@ int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     const int32_t* loc_r = base + (env->f("loc_r") - env->state);
     const int32_t* loc_c = base + (env->f("loc_c") - env->state);
     const int npos = c.dim * c.dim;
-    IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)env->dims.obs_dim * H * sizeof(float), s));
-    if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
     const EncBwdPlan pl = enc_bwd_plan(c.E, rows, total, H, npos, 2 * WW);
+    if (mode && !pl.csplit) return fail(-38, "ic3_env_encode_backward_accumulate: this configuration takes the per-env form (use ic3_env_encode_backward)");
+    if (mode == 0 || mode == 3) {
+        IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)env->dims.obs_dim * H * sizeof(float), s));
+        if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
+    }
     float* P = work;
     int np = 1, nwg;
     float* Dpart;
     if (pl.csplit) {                                   // rows in parallel, P and D of a column slice in LDS
         np = nwg = pl.nrg;
         Dpart = work + (size_t)pl.nrg * npos * H;
-        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(pp_encode_bwd_rows_kernel), (size_t)pl.lds));
-        hipLaunchKernelGGL(pp_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, loc_r, loc_c, g, ldg, P,
-                           Dpart, c.E, c.N, c.nprey, c.dim, c.vision, H, H / pl.csplit, rows);
+        if (mode != 3) {
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(pp_encode_bwd_rows_kernel), (size_t)pl.lds));
+            hipLaunchKernelGGL(pp_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, loc_r, loc_c, g, ldg, P,
+                               Dpart, c.E, c.N, c.nprey, c.dim, c.vision, H, H / pl.csplit, rows, mode == 2 ? 1 : 0);
+            IC3_HIP(hipGetLastError());
+        }
+        if (mode == 1 || mode == 2) return 0;
     } else {                                           // the grid does not fit in LDS: one env at a time, P by global atomics
         if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
         IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(pp_encode_bwd_kernel), lds));

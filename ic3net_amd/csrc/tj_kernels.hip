@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_rows_kernel(const int32_t* 
                                                                  const int32_t* __restrict__ route_id_s,
                                                                  const float* __restrict__ g, int ldg,
                                                                  float* __restrict__ Ppart, float* __restrict__ Dpart, int E,
-                                                                 int N, int h, int w, int v, int npath, int H, int Hc, int hdr)
+                                                                 int N, int h, int w, int v, int npath, int H, int Hc, int hdr,
+                                                                 int accumulate)
 {
     IC3_DYNAMIC_LDS(float, smf);
     const int W = 2 * v + 1;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_rows_kernel(const int32_t* 
             const int dy = (ent[p] & 0xffff) - (ent[a] & 0xffff) + v, dx = (ent[p] >> 16) - (ent[a] >> 16) + v;
             return (p != a && (unsigned)dy < (unsigned)W && (unsigned)dx < (unsigned)W && alive_s[row]) ? hdr + dy * W + dx : -1;
         },
-        [&](int k) { return k < hdr ? k : (k == 4 ? hdr + centre : -1); });
+        [&](int k) { return k < hdr ? k : (k == 4 ? hdr + centre : -1); }, accumulate);
 }
 
 __global__ __launch_bounds__(256) void tj_encode_bwd_expand_kernel(const float* __restrict__ P, int np,
@@ -488,8 +489,9 @@ int64_t tj_encode_bwd_work(const ic3_env* env, int H)
     return std::max(per_env_form, row_form);
 }
 
+// mode: see pp_encode_bwd
 int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias,
-                  float* work, hipStream_t s)
+                  float* work, hipStream_t s, int mode)
 {
     const ic3_tj_cfg& c = env->tj;
     const ic3_dims& d = env->dims;
@@ -499,19 +501,26 @@ int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     const int32_t* base = snap ? snap : env->state;
     auto fld = [&](const char* name) { return base + (env->f(name) - env->state); };
     const int npos = d.grid_h * d.grid_w;
-    IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)d.obs_dim * H * sizeof(float), s));
-    if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
     const EncBwdPlan pl = enc_bwd_plan(c.E, c.N, c.N, H, npos, hdr + WW);
+    if (mode && !pl.csplit) return fail(-38, "ic3_env_encode_backward_accumulate: this configuration takes the per-env form (use ic3_env_encode_backward)");
+    if (mode == 0 || mode == 3) {
+        IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)d.obs_dim * H * sizeof(float), s));
+        if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
+    }
     float* P = work;
     int np = 1, nwg;
     float* Dpart;
     if (pl.csplit) {                                   // rows in parallel, P and D of a column slice in LDS
         np = nwg = pl.nrg;
         Dpart = work + (size_t)pl.nrg * npos * H;
-        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(tj_encode_bwd_rows_kernel), (size_t)pl.lds));
-        hipLaunchKernelGGL(tj_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, fld("alive"),
-                           fld("loc_r"), fld("loc_c"), fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, c.N, d.grid_h,
-                           d.grid_w, c.vision, d.npath, H, H / pl.csplit, hdr);
+        if (mode != 3) {
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(tj_encode_bwd_rows_kernel), (size_t)pl.lds));
+            hipLaunchKernelGGL(tj_encode_bwd_rows_kernel, dim3(pl.nrg, pl.csplit), dim3(256), pl.lds, s, fld("alive"),
+                               fld("loc_r"), fld("loc_c"), fld("last_act"), fld("route_id"), g, ldg, P, Dpart, c.E, c.N, d.grid_h,
+                               d.grid_w, c.vision, d.npath, H, H / pl.csplit, hdr, mode == 2 ? 1 : 0);
+            IC3_HIP(hipGetLastError());
+        }
+        if (mode == 1 || mode == 2) return 0;
     } else {
         if (lds > 160 * 1024) return fail(-22, "ic3_env_encode_backward: configuration needs more than 160 KB of LDS");
         IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(tj_encode_bwd_kernel), lds));

@@ -247,6 +247,43 @@ class _BatchedEnv(object):
                                                  ptr(dwt), ptr(dbias) if want_bias else None, ptr(work), stream()))
         return dwt, dbias
 
+    def _encb_work(self, H):
+        key = ('encb', H)
+        if not hasattr(self, '_scratch'):
+            self._scratch = {}
+        work = self._scratch.get(key)
+        if work is None:
+            n = _lib.lib().ic3_env_encode_backward_work(self._h, H)
+            if n < 0:
+                check(int(n))
+            work = self._scratch[key] = torch.empty((n,), dtype=torch.float32, device=self.device)
+        return work
+
+    def encode_backward_accumulate(self, grad_out, snap, first):
+        """encode_backward over several states with ONE expansion at the end (ic3_env_encode_backward_accumulate): adds this
+        state's share to the partial sums (writes them when `first`).  Returns False when the configuration has no
+        partial-sums form — use encode_backward() per state then."""
+        self._require()
+        H = grad_out.shape[-1]
+        g = grad_out.reshape(-1, H) if grad_out.is_contiguous() else grad_out
+        if g.dtype != torch.float32 or g.dim() != 2 or g.stride(1) != 1 or g.shape[0] != self.nenvs * self.nagents_env:
+            raise ValueError("encode_backward_accumulate: grad_out must be float32 (E*N, H) with unit inner stride")
+        rc = _lib.lib().ic3_env_encode_backward_accumulate(self._h, ptr(snap) if snap is not None else None, ptr(g), g.stride(0),
+                                                           H, ptr(self._encb_work(H)), int(bool(first)), stream())
+        if rc == -38:
+            return False
+        check(rc)
+        return True
+
+    def encode_backward_finish(self, H, want_bias=True):
+        """(dWt (obs_dim, H), dbias (H,)) of everything accumulated since the `first` encode_backward_accumulate call."""
+        self._require()
+        dwt = torch.empty((self.obs_dim, H), dtype=torch.float32, device=self.device)
+        dbias = torch.empty((H,), dtype=torch.float32, device=self.device) if want_bias else None
+        check(_lib.lib().ic3_env_encode_backward_finish(self._h, H, ptr(dwt), ptr(dbias) if want_bias else None,
+                                                        ptr(self._encb_work(H)), stream()))
+        return dwt, dbias
+
     def set_auto_reset(self, max_steps):
         """max_steps > 0: an env whose episode ends (episode_over, or max_steps steps played) starts its next episode
         inside the same step launch (ic3_env_set_auto_reset); 0: lock-step episodes (finished envs freeze)."""

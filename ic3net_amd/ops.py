@@ -64,13 +64,19 @@ def _rows(t, H):
     return t, H
 
 
-def comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self, out=None):
-    """The kernel launch without autograd: h (E,N,H) rows may be a strided column slice; `out` (E,N,H) contiguous."""
+def comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self, out=None, addend=None):
+    """The kernel launch without autograd: h (E,N,H) rows may be a strided column slice; `out` (E,N,H) contiguous.
+    `addend` (E*N,H) / (E,N,H) rows (a strided column slice is fine): out = addend + comm(h) (ic3_comm_masked_mean_add)."""
     _need_cuda(h, "comm_masked_mean")
     E, N, H = h.shape
     hk, ldh = _rows(h, H)
     if out is None:
         out = torch.empty((E, N, H), dtype=torch.float32, device=h.device)
+    if addend is not None:
+        ak, lda = _rows(addend, H)
+        check(_lib.lib().ic3_comm_masked_mean_add(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(ak), lda, ptr(out), E, N, H,
+                                                  int(mode_avg), int(mask_self), stream()))
+        return out
     check(_lib.lib().ic3_comm_masked_mean(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(out), E, N, H,
                                           int(mode_avg), int(mask_self), stream()))
     return out
@@ -379,6 +385,19 @@ def episode_finalize(done, reward, alive=None, is_completed=None, gate=None, gat
                       ptr(res['live_after']), ptr(res['stats']), ptr(work['scratch']), ptr(work['counter']))
     check(_lib.lib().ic3_episode_finalize(C.byref(ep), stream()))
     return res
+
+
+def returns_scan(rewards, episode_masks, episode_mini_masks, gamma, mean_ratio):
+    """trainer.py:162-171: returns (T, E, N) = mean_ratio * mean over agents of the cooperative returns + (1 - mean_ratio) *
+    the per-agent returns, both scanned backwards over the T slots with episode_mask (and episode_mini_mask) cutting the
+    recursion — ic3_returns_scan, one launch instead of ~9 tensor ops per slot.  episode_masks (T, E) or (T, E, N) expanded."""
+    _need_cuda(rewards, "returns_scan")
+    T, E, N = rewards.shape
+    em = episode_masks[:, :, 0] if episode_masks.dim() == 3 else episode_masks
+    rewards, em, mm = rewards.contiguous().float(), em.contiguous().float(), episode_mini_masks.contiguous().float()
+    out = torch.empty_like(rewards)
+    check(_lib.lib().ic3_returns_scan(ptr(rewards), ptr(em), ptr(mm), float(gamma), float(mean_ratio), ptr(out), T, E, N, stream()))
+    return out
 
 
 def lstm_cell_heads_ok(H):

@@ -874,16 +874,7 @@ class Trainer(object):
         alive_masks = torch.stack([m['alive_mask'] for m in batch.misc])      # (T, E, N), already x live
         live = torch.stack([m['live'] for m in batch.misc]).unsqueeze(2).expand(T, E, n)      # (T, E, N)
 
-        coop_returns = torch.empty_like(rewards)
-        ncoop_returns = torch.empty_like(rewards)
-        prev_coop = torch.zeros_like(rewards[0])
-        prev_ncoop = torch.zeros_like(rewards[0])
-        for i in reversed(range(T)):                                          # trainer.py:162-170
-            coop_returns[i] = rewards[i] + args.gamma * prev_coop * episode_masks[i]
-            ncoop_returns[i] = rewards[i] + args.gamma * prev_ncoop * episode_masks[i] * episode_mini_masks[i]
-            prev_coop = coop_returns[i]
-            prev_ncoop = ncoop_returns[i]
-        returns = args.mean_ratio * coop_returns.mean(dim=2, keepdim=True) + (1 - args.mean_ratio) * ncoop_returns
+        returns = bptt._returns(args, rewards, episode_masks, episode_mini_masks)   # trainer.py:162-171
         advantages = returns - values.detach()                                # trainer.py:173-174
         if args.normalize_rewards:                                            # trainer.py:176-177 (live entries only)
             cnt = live.sum()
@@ -964,11 +955,18 @@ class Trainer(object):
         prev = getattr(self.args, 'rollout_grad', False)
         self.args.rollout_grad = not native             # autograd path: the rollout keeps the graph, like the reference
         self._records = [] if native else None
+        # The native update reads env snapshots, never the dense observation rows (the sparse encoder and its backward work
+        # from the integer state): the training rollout does not assemble them unless someone asks for the states
+        # (args.store_states) or for the rows themselves (args.train_dense_obs) — 1.19 GB of stores per PP-hard step
+        prev_dense = getattr(self.args, 'dense_obs', True)
+        if native and not getattr(self.args, 'train_dense_obs', False):
+            self.args.dense_obs = False                 # (_dense_obs() keeps them when store_states / no sparse encoder)
         try:
             batch, stat = self.run_batch(epoch)
             records = self._records
         finally:
             self.args.rollout_grad = prev
+            self.args.dense_obs = prev_dense
             self._records = None
             self._rec = None
         self.optimizer.zero_grad()

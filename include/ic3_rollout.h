@@ -192,6 +192,16 @@ int ic3_env_snapshot(const ic3_env* env, int32_t* snap /* device, dims.state_wor
 int64_t ic3_env_encode_backward_work(const ic3_env* env, int H);
 int ic3_env_encode_backward(ic3_env* env, const int32_t* snap, const float* grad_out, int ldg, int H, float* dWt,
                             float* dbias, float* work, ic3_stream stream);
+/* The same gradient over SEVERAL states (the steps of an episode) with the expansion done once: the operation is linear in
+ * what its first stage collects (per grid position / per shared column the sum of the grad_out rows standing there), so a
+ * backward pass through time calls _accumulate once per step — `first` != 0 on the first call: the partial sums in `work`
+ * are written, otherwise added to — and _finish once at the end, which overwrites dWt / dbias like ic3_env_encode_backward
+ * would for the sum over all the accumulated states.  Same `work` (ic3_env_encode_backward_work floats) in every call of
+ * the sequence.  -38 when the configuration's first stage does not run in its partial-sums form (grids too large for LDS):
+ * the caller then uses ic3_env_encode_backward per step. */
+int ic3_env_encode_backward_accumulate(ic3_env* env, const int32_t* snap, const float* grad_out, int ldg, int H, float* work,
+                                       int first, ic3_stream stream);
+int ic3_env_encode_backward_finish(ic3_env* env, int H, float* dWt, float* dbias /* or NULL */, float* work, ic3_stream stream);
 
 /* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
 int ic3_env_check(ic3_env* env, ic3_stream stream);
@@ -266,6 +276,13 @@ typedef struct ic3_episode {
 } ic3_episode;
 size_t ic3_episode_scratch_bytes(int E, int N);
 int ic3_episode_finalize(const ic3_episode* ep, ic3_stream stream);
+/* The reversed return scan of compute_grad — replaces the loop trainer.py:162-171 and the mix of trainer.py:171 — over T
+ * slots (the batch's transitions in time order, [T][E][N] step-major like the episode buffers) in one launch:
+ *   coop[t] = reward[t] + gamma * coop[t+1] * episode_mask[t];   ncoop[t] = reward[t] + gamma * ncoop[t+1] * episode_mask[t] *
+ *   episode_mini_mask[t];   returns[t][e][n] = mean_ratio * mean_n coop[t][e][:] + (1 - mean_ratio) * ncoop[t][e][n]
+ * reward, episode_mini_mask, returns [T][E][N] f32; episode_mask [T][E] f32.  N <= 256. */
+int ic3_returns_scan(const float* reward, const float* episode_mask, const float* episode_mini_mask, float gamma, float mean_ratio,
+                     float* returns, int T, int E, int N, ic3_stream stream);
 
 /* CommNetMLP communication block, comm.py:181-205, in closed form per env (SURVEY B.5 i):
  *   m_j = alive_j * comm_action_j ; out_j = m_j * (sum_i m_i h_i - m_j h_j) [ / (n_alive - 1) if mode_avg && n_alive > 1 ]
@@ -275,6 +292,12 @@ int ic3_episode_finalize(const ic3_episode* ep, ic3_stream stream);
 int ic3_comm_masked_mean(const float* h, int ldh /* h row stride in floats, 0 = H */, const int32_t* alive,
                          const int32_t* comm_action, float* out, int E, int N, int H, int mode_avg, int mask_self,
                          ic3_stream stream);
+/* The same block with an addend: out = addend + comm(h) — the backward of the communication block is the block itself applied
+ * to the gradient (its mixing matrix is symmetric), and what it is added to (dL/dh of the recurrent path) comes along in the
+ * same pass.  addend [E*N][H] rows with stride lda floats (0 = H; may be a column slice of a wider buffer).  H, ldh, lda
+ * multiples of 4. */
+int ic3_comm_masked_mean_add(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, const float* addend,
+                             int lda, float* out, int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream);
 
 /* Pointwise half of torch.nn.LSTMCell (comm.py:61,215; gate order i,f,g,o): gates [R][4H] already hold
  * W_ih x + b_ih + W_hh h + b_hh (two fp32 MFMA GEMMs, or one over [x | h]).  c [R][H] is updated in place,

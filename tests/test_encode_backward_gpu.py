@@ -56,6 +56,40 @@ def test_encode_backward_equals_dense(kind, c):
         assert float((dwt2.double() - ref2).abs().max()) <= 2e-6 * max(1.0, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("kind,c", CASES)
+def test_encode_backward_accumulated_over_states_equals_the_sum(kind, c):
+    """ic3_env_encode_backward_accumulate / _finish: the gradient over several states (snapshots of different steps) with one
+    expansion at the end equals the sum of the per-state dense products; the configuration whose first stage has no
+    partial-sums form (the 4900-cell grid) reports it and the caller keeps the per-state calls."""
+    env, nact = build(kind, c, seed=2)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    H, R = c['H'], env.nenvs * env.nagents_env
+    ref = None
+    refb = torch.zeros(H, dtype=torch.float64, device='cuda')
+    ok = None
+    for k, steps in enumerate((0, 3, 4)):
+        play(env, nact, steps, gen)
+        snap = env.snapshot()
+        obs = env.observe().reshape(R, -1).double()
+        wide = torch.randn(R, 2 * H, device='cuda', generator=gen)
+        g = wide[:, :H]                                            # a strided column slice, as bptt hands d inp
+        play(env, nact, 1, gen)                                    # the live state moves on: the snapshot is what counts
+        ok = env.encode_backward_accumulate(g, snap, first=(k == 0))
+        if not ok:
+            break
+        r = obs.t() @ g.double()
+        ref = r if ref is None else ref + r
+        refb += g.double().sum(0)
+    if kind == "pp" and c['dim'] == 70:
+        assert ok is False
+        return
+    assert ok is True
+    dwt, db = env.encode_backward_finish(H)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((dwt.double() - ref).abs().max()) <= 4e-6 * scale
+    torch.testing.assert_close(db.double(), refb, atol=4e-6 * max(1.0, (3 * R) ** 0.5), rtol=0)
+
+
 def test_snapshot_is_the_state_of_the_forward():
     env, nact = build("pp", CASES[0][1])
     gen = torch.Generator(device='cuda').manual_seed(5)

@@ -114,6 +114,49 @@ def test_comm_masked_mean_backward():
     torch.testing.assert_close(h.grad, h2.grad, atol=1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("E,N,H,avg", [(37, 10, 128, True), (9, 20, 64, False), (5, 40, 32, True)])
+def test_comm_masked_mean_add_is_the_block_plus_the_addend(E, N, H, avg):
+    """ic3_comm_masked_mean_add: out = addend + comm(h) with the addend a strided column slice (bptt's [d inp | d h] buffer)."""
+    from ic3net_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(1)
+    h = torch.randn(E, N, H, device='cuda', generator=g)
+    alive = (torch.rand(E, N, device='cuda', generator=g) < 0.8).int()
+    gate = (torch.rand(E, N, device='cuda', generator=g) < 0.6).int()
+    wide = torch.randn(E * N, 2 * H, device='cuda', generator=g)
+    for al, ga in ((alive, gate), (None, gate), (alive, None)):
+        base = ops.comm_masked_mean_raw(h, al, ga, avg, True)
+        out = ops.comm_masked_mean_raw(h, al, ga, avg, True, addend=wide[:, H:])
+        assert torch.equal(out.view(E * N, H), wide[:, H:] + base.view(E * N, H))
+    out = ops.comm_masked_mean_raw(h, alive, gate, avg, False, addend=wide[:, H:])     # comm_mask_zero: the addend alone
+    assert torch.equal(out.view(E * N, H), wide[:, H:])
+
+
+@pytest.mark.parametrize("T,E,N,gamma,ratio", [(20, 33, 3, 1.0, 0.0), (40, 17, 10, 0.95, 0.5), (7, 300, 5, 0.9, 1.0),
+                                                (13, 5, 64, 1.0, 0.3)])
+def test_returns_scan_matches_the_reference_loop(T, E, N, gamma, ratio):
+    """ic3_returns_scan against the loop of /root/reference/trainer.py:162-171 in float64 (episode cuts inside the batch,
+    per-agent mini masks)."""
+    from ic3net_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(T)
+    rew = torch.randn(T, E, N, device='cuda', generator=g)
+    em = (torch.rand(T, E, device='cuda', generator=g) < 0.85).float()
+    mm = (torch.rand(T, E, N, device='cuda', generator=g) < 0.8).float()
+    out = ops.returns_scan(rew, em, mm, gamma, ratio)
+    r, e, m = rew.double().cpu(), em.double().cpu().unsqueeze(2), mm.double().cpu()
+    coop = torch.zeros(T, E, N, dtype=torch.float64)
+    ncoop = torch.zeros(T, E, N, dtype=torch.float64)
+    pc = torch.zeros(E, N, dtype=torch.float64)
+    pn = torch.zeros(E, N, dtype=torch.float64)
+    for i in reversed(range(T)):
+        coop[i] = r[i] + gamma * pc * e[i]
+        ncoop[i] = r[i] + gamma * pn * e[i] * m[i]
+        pc, pn = coop[i], ncoop[i]
+    ref = ratio * coop.mean(2, keepdim=True) + (1 - ratio) * ncoop
+    torch.testing.assert_close(out.double().cpu(), ref, atol=2e-5 * float(ref.abs().max()), rtol=0)
+    out3 = ops.returns_scan(rew, em.unsqueeze(2).expand(T, E, N), mm, gamma, ratio)       # the expanded mask of a Transition
+    assert torch.equal(out, out3)
+
+
 def test_sample_actions_vs_oracle_and_distribution():
     import oracle
     from oracle import philox

@@ -723,18 +723,24 @@ def test_native_update_records_the_recurrent_state_in_place():
 
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
-    episode (the explicit backward would cross the cut) — train_batch must not take the native path there (the autograd
-    rollout then raises its explicit NotImplementedError, as before round 3); and hid sizes ic3_lstm_cell_backward does not
-    take (H / 4 not a power of two <= 64) keep the autograd update instead of failing inside it."""
+    episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)
+    for the recurrent policy with one communication pass; a policy with several passes per step has no such backward and
+    train_batch must not take the native path (the autograd rollout then raises its explicit NotImplementedError); and hid
+    sizes ic3_lstm_cell_backward does not take (H / 4 not a power of two <= 64) keep the autograd update instead of failing
+    inside it."""
     import bench
     from ic3net_amd import bptt
     tr, a = bench.build_trainer('pp_hard', 8, 1, 0, 0)
     assert tr._native_update()
     a.auto_reset = True
-    assert not tr._native_update()
-    a.batch_size = 8 * a.max_steps
+    assert tr._native_update()
+    trp, ap = bench.build_trainer('pp_hard', 8, 1, 0, 0, comm_passes=2)
+    assert trp._native_update()
+    ap.auto_reset = True
+    assert not trp._native_update()
+    ap.batch_size = 8 * ap.max_steps
     with pytest.raises(NotImplementedError):
-        tr.train_batch(0)
+        trp.train_batch(0)
     for hid, ok in ((96, False), (100, False), (128, True), (32, True)):
         tr2, a2 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=hid)
         assert bptt.supported(a2, tr2.policy_net, tr2.env.env) == ok, hid
