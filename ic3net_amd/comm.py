@@ -139,7 +139,8 @@ class CommNetMLP(nn.Module):
     # it contribute nothing to any real unit, head or value.  The twin is a CommNetMLP of its own (not a submodule: its
     # tensors are derived data like the packed weights of _fused_cache, refreshed in place when a parameter's version
     # changes); callers keep seeing (R, hid_size) hidden states — views of the twin's (R, padded) buffers.  The update
-    # half of such a policy takes the autograd path (bptt.supported() is False for it).
+    # half runs on the twin as well (Trainer._kernel_net: the no-grad rollout records the twin's state, bptt differentiates
+    # the twin, unpad_grads() cuts its gradients back to this policy's parameters — the padded entries are exactly 0).
     # ------------------------------------------------------------------------------------------
     def _twin(self):
         a = self.args
@@ -244,7 +245,11 @@ class CommNetMLP(nn.Module):
     def unpad_grads(self):
         """After a native update on the twin: p.grad of every parameter <- its region of the twin's gradient (the padded
         rows / columns of the twin's gradients are exactly zero)."""
-        tw = self.__dict__['_twin_box'][0]
+        box = self.__dict__.get('_twin_box')
+        if not box or box[0] is None:
+            raise RuntimeError("unpad_grads(): this policy has no zero-padded twin (nothing ran on one: hid_size %d is a size "
+                               "the kernels take as it is, or args.pad_hidden is off)" % self.hid_size)
+        tw = box[0]
         H, Hp = self.hid_size, tw.hid_size
         theirs = dict(tw.named_parameters())
         for name, p in self.named_parameters():

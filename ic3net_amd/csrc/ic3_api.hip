@@ -1,6 +1,7 @@
 // ic3_api.hip — C ABI entry points of libic3rollout.so (declared in include/ic3_rollout.h).
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -45,8 +46,13 @@ Range::Range(const char* name) : on(roctx_on())
     // Every launching entry point starts with a Range: drop whatever error another user of the runtime left in the thread's
     // "last error" slot (e.g. torch reading the return code of a failed hipStreamEndCapture without clearing it), so that the
     // hipGetLastError() check behind OUR launch reports our launch and nothing else.  (The reverse direction — not leaving
-    // our own failures behind for the caller's next call — is IC3_HIP's.)
-    (void)hipGetLastError();
+    // our own failures behind for the caller's next call — is IC3_HIP's.)  The slot is only cleared when it holds something
+    // (peek first), and what is dropped is kept for ic3_last_error()'s reader under IC3_DEBUG_ERRORS.
+    if (const hipError_t pending = hipPeekAtLastError(); pending != hipSuccess) {
+        static const bool log_dropped = getenv("IC3_DEBUG_ERRORS") != nullptr;
+        if (log_dropped) fprintf(stderr, "libic3rollout: %s entered with a pending HIP error of another caller: %s (cleared)\n", name, hipGetErrorString(pending));
+        (void)hipGetLastError();
+    }
     if (on) g_push(name);
 }
 Range::~Range()

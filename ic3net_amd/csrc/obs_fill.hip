@@ -17,6 +17,7 @@
 // round 4: fp32 MFMA stream alone 0.486 ms, this store loop alone 0.225 ms (1.19 GB), both on the same CUs 0.477 ms;
 // helper waves WITH vector address arithmetic (round 2's probe) were starved by the MFMA stream: 0.690 ms.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "ic3_common.hpp"
@@ -107,15 +108,18 @@ extern "C" int ic3_obs_prefill(ic3_env* env, float* obs, ic3_stream stream)
     static const int plain = getenv("IC3_FILL_PLAIN") ? atoi(getenv("IC3_FILL_PLAIN")) : 0;
     env->touch_obs(obs);
     if (bytes16) {
-        static int cus_of[64] = { 0 };                               // per device (a process may drive several GPUs)
-        int dev = 0, cus = 256;
+        static std::atomic<int> cus_of[64];                          // per device (a process may drive several GPUs); zero-initialised,
+        int dev = 0, cus = 256;                                      // written once per device with the same value by whoever gets there
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-            if (!cus_of[dev]) {
+            int known = cus_of[dev].load(std::memory_order_relaxed);
+            if (!known) {
                 hipDeviceProp_t prop;
-                if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                    cus_of[dev] = prop.multiProcessorCount;
+                if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+                    known = prop.multiProcessorCount;
+                    cus_of[dev].store(known, std::memory_order_relaxed);
+                }
             }
-            if (cus_of[dev]) cus = cus_of[dev];
+            if (known) cus = known;
         }
         const unsigned long long blocks = (bytes16 + 1023ull) / 1024ull;
         if (blocks > 0x7fffffffull) return fail(-22, "ic3_obs_prefill: buffer too large for one launch");

@@ -39,8 +39,9 @@ _FLAGS = [
     ('share_weights', 'flag', False),
 ]
 # engine flags (new)
-_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', 'flag', False), ('tune_gemm', 'flag', False),
+_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', int, 1), ('tune_gemm', 'flag', False),
                  ('dist_backend', str, 'nccl')]     # 'nccl' = RCCL over xGMI; 'gloo' for several ranks on one GPU (tests)
+# hip_graph 1 (default): rollouts that feed no update (evaluation, --display off) replay ONE hipGraph per episode; 0 = eager
 
 
 def build_parser(argv):

@@ -436,6 +436,7 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { s
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int device) { return device == -1 ? hipSuccess : hipErrorInvalidDevice; }   // the host "device"
 inline hipError_t hipGetDevice(int* device) { *device = -1; return hipSuccess; }
 template <class F>

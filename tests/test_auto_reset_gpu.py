@@ -166,8 +166,17 @@ def test_auto_reset_stream_equals_consecutive_reference_style_episodes(graph, pa
         assert stat['success'] == succ
         total_eps += n_eps
         assert n_eps > E                                                   # episodes did end early and restart
-    # run_batch counts the episodes actually played (stat normalisation main.py:219-225 divides by them)
+    # run_batch (collection mode, round 5): the batch holds WHOLE episodes only — a slot counts iff its episode ends inside the
+    # batch — and counts the episodes that ended (stat normalisation main.py:219-225 divides by them)
     tr2, a2, _ = _trainer(E, T, seed, True, passes)
-    a2.batch_size = 1
+    a2.batch_size = 2 * T * E                                              # two windows of T slots: the streams run on across them
     batch, st = tr2.run_batch(0)
-    assert st['num_episodes'] > E and st['num_steps'] == T * E
+    done = torch.stack([m['done'] for m in batch.misc]).cpu().numpy()      # (2T, E)
+    live = torch.stack([m['live'] for m in batch.misc]).cpu().numpy()
+    assert done.shape == (2 * T, E)
+    for e in range(E):
+        ends = np.nonzero(done[:, e])[0]
+        n_live = 0 if len(ends) == 0 else ends[-1] + 1                     # everything up to the env's last episode end
+        assert live[:, e].sum() == n_live and live[:n_live, e].all()
+        assert len(ends) >= 2 and (np.diff(np.concatenate([[-1], ends])) <= T).all()   # no episode longer than max_steps
+    assert st['num_episodes'] == done.sum() > 2 * E and st['num_steps'] == live.sum() <= 2 * T * E

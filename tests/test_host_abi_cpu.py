@@ -172,6 +172,83 @@ def test_encoder_backward_equals_dense_transpose_product(kind, cfg):
     env.close()
 
 
+@pytest.mark.parametrize("kind,cfg", ENC_CASES)
+def test_encoder_backward_accumulated_over_states(kind, cfg):
+    """ic3_env_encode_backward_accumulate / _finish on the host: three states (snapshots), one expansion = the sum of the
+    three dense products; the work buffer starts as NaN (the `first` call must write, not add)."""
+    from host_abi_util import check, host_lib, p
+    env = _make(kind, cfg)
+    lib = host_lib()
+    H = 8
+    rng = np.random.default_rng(8)
+    n = int(lib.ic3_env_encode_backward_work(env._h, H))
+    work = np.full((n,), np.nan, np.float32)
+    want, wantb = 0.0, 0.0
+    for k in range(3):
+        _play(env, 3 + k, 20 + k)
+        snap = env.snapshot()
+        obs = env.observe().reshape(-1, env.obs_dim).astype(np.float64)
+        wide = rng.standard_normal((env.E * env.N, 2 * H)).astype(np.float32)
+        g = wide[:, H:]                                              # strided rows (ldg = 2H)
+        env.step(np.zeros((env.E, env.N), np.int32), with_obs=False)
+        rc = lib.ic3_env_encode_backward_accumulate(env._h, p(snap), C.c_void_p(wide.ctypes.data + 4 * H), 2 * H, H, p(work),
+                                                    int(k == 0), None)
+        if rc == -38:
+            env.close()
+            pytest.skip("this configuration's first stage has no partial-sums form (the caller keeps the per-state calls)")
+        check(rc)
+        want = want + obs.T @ g.astype(np.float64)
+        wantb = wantb + g.astype(np.float64).sum(0)
+    dwt = np.full((env.obs_dim, H), np.nan, np.float32)
+    db = np.full((H,), np.nan, np.float32)
+    check(lib.ic3_env_encode_backward_finish(env._h, H, p(dwt), p(db), p(work), None))
+    np.testing.assert_allclose(dwt, want, rtol=0, atol=4e-5)
+    np.testing.assert_allclose(db, wantb, rtol=0, atol=4e-5)
+    env.close()
+
+
+@pytest.mark.parametrize("T,E,N,gamma,ratio", [(9, 7, 3, 1.0, 0.0), (12, 30, 10, 0.9, 0.5), (5, 3, 64, 1.0, 1.0)])
+def test_returns_scan_on_the_host(T, E, N, gamma, ratio):
+    """ic3_returns_scan == the loop of /root/reference/trainer.py:162-171 (float64)."""
+    from host_abi_util import check, host_lib, p
+    rng = np.random.default_rng(T)
+    rew = rng.standard_normal((T, E, N)).astype(np.float32)
+    em = (rng.random((T, E)) < 0.8).astype(np.float32)
+    mm = (rng.random((T, E, N)) < 0.8).astype(np.float32)
+    out = np.full((T, E, N), np.nan, np.float32)
+    check(host_lib().ic3_returns_scan(p(rew), p(em), p(mm), gamma, ratio, p(out), T, E, N, None))
+    coop = np.zeros((T, E, N))
+    ncoop = np.zeros((T, E, N))
+    pc = np.zeros((E, N))
+    pn = np.zeros((E, N))
+    for i in reversed(range(T)):
+        coop[i] = rew[i] + gamma * pc * em[i][:, None]
+        ncoop[i] = rew[i] + gamma * pn * em[i][:, None] * mm[i]
+        pc, pn = coop[i], ncoop[i]
+    ref = ratio * coop.mean(2, keepdims=True) + (1 - ratio) * ncoop
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    assert host_lib().ic3_returns_scan(p(rew), p(em), p(mm), gamma, ratio, None, T, E, N, None) == -22
+
+
+def test_comm_masked_mean_add_on_the_host():
+    """ic3_comm_masked_mean_add: the block's output + an addend read through a row stride."""
+    from host_abi_util import check, host_lib, p
+    E, N, H = 5, 7, 16
+    rng = np.random.default_rng(2)
+    h = rng.standard_normal((E, N, H)).astype(np.float32)
+    alive = (rng.random((E, N)) < 0.8).astype(np.int32)
+    gate = (rng.random((E, N)) < 0.6).astype(np.int32)
+    wide = rng.standard_normal((E * N, 2 * H)).astype(np.float32)
+    lib = host_lib()
+    base = np.full((E, N, H), np.nan, np.float32)
+    check(lib.ic3_comm_masked_mean(p(h), 0, p(alive), p(gate), p(base), E, N, H, 1, 1, None))
+    out = np.full((E, N, H), np.nan, np.float32)
+    check(lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), C.c_void_p(wide.ctypes.data + 4 * H), 2 * H, p(out), E, N, H, 1,
+                                       1, None))
+    np.testing.assert_array_equal(out.reshape(E * N, H), wide[:, H:] + base.reshape(E * N, H))
+    assert lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), None, 0, p(out), E, N, H, 1, 1, None) == -22
+
+
 def test_stats_and_state_round_trip():
     env = HostEnv.pp(3, 5, 0, 'mixed', 6, seed=2)                    # (episode_over: mixed mode only, PP:285-286)
     env.reset()

@@ -177,16 +177,18 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
         return out, tr
 
     eager, _ = run(False)
-    graphed, tr = run(True)
+    graphed, tr = run('step')                                   # one graph per step index
     assert len(tr._graphs) == 12
+    whole, tr3 = run(True)                                      # the default: ONE graph for the episode's 12 step launches
+    assert list(tr3._graphs) == ['episode']
     # args.overlap_obs: observation assembled on a second stream from a state snapshot (ic3_env_observe_at)
-    lapped, tr2 = run(True, overlap=True)
-    assert tr2._side is not None
+    lapped, tr2 = run(True, overlap=True)                       # (keeps one graph per step: the obs launch sits between them)
+    assert tr2._side is not None and 'episode' not in tr2._graphs
     raw = tr2.env.env
     torch.cuda.synchronize()
     last_obs = raw._obs.clone()
     assert torch.equal(last_obs, raw.observe())            # the side stream produced the observation of the final state
-    for other in (graphed, lapped):
+    for other in (graphed, whole, lapped):
         for ep, (e, g) in enumerate(zip(eager, other)):
             for i in range(4):
                 for x, y in zip(e[i], g[i]):
@@ -196,8 +198,9 @@ def test_hip_graph_replay_equals_eager(env_name, flags):
                 np.testing.assert_array_equal(e[4][k], g[4][k], err_msg=k)
 
 
+@pytest.mark.parametrize("mode", [True, 'step'], ids=["episode-graph", "step-graphs"])
 @pytest.mark.parametrize("hid", [64, 32])
-def test_graph_replay_follows_weight_updates(hid):
+def test_graph_replay_follows_weight_updates(hid, mode):
     """Replayed step graphs hold the ADDRESSES of the derived weight tensors (packed layouts; for hid 32 the zero-padded
     twin's parameters and ITS packed layouts): after the parameters change in place (optimizer.step, checkpoint load) the
     next episode must play the new weights — begin_episode refreshes the derived tensors in place."""
@@ -230,8 +233,8 @@ def test_graph_replay_follows_weight_updates(hid):
         return out, tr
 
     eager, _ = run(False)
-    graphed, tr = run(True)
-    assert len(tr._graphs) == 12 and getattr(tr.policy_net, 'mega_steps', 0) > 0
+    graphed, tr = run(mode)
+    assert len(tr._graphs) == (12 if mode == 'step' else 1) and getattr(tr.policy_net, 'mega_steps', 0) > 0
     assert not all(torch.equal(x, y) for x, y in zip(eager[2][1], eager[3][1]))     # the update does change the episode
     for ep, (e, g) in enumerate(zip(eager, graphed)):
         for i in range(2):
