@@ -1246,6 +1246,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     }
 }
 
+#include "policy_step_ws.hpp"
+
 // ---- ic3_gate_product_probe: the gate product ALONE (pre-activations without the bias), through the operand layouts, the
 // activation split and the per-accumulator order of matrix instructions of policy_step_kernel's two gate loops — (k ascending;
 // fp32: one v_mfma_f32_32x32x2_f32 per k; split: per 16-k block weight plane outer, then gate, then the activation terms
@@ -1611,6 +1613,57 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, 
     return 0;
 }
 
+// The wave-specialised kernel (policy_step_ws.hpp): one persistent workgroup per CU.  Tile plan: as many FULL tiles as give
+// every workgroup the same number, the envs left over as small tiles of EPTh = ceil(rest / workgroups) envs (<= EPT) that each
+// workgroup plays FIRST.  Zero-store pacing: everything inside the gate loop when it fits (one loop per SIMD at a time here).
+static size_t ps_ws_lds(int H, int tile_words)
+{
+    return ((size_t)2 * 64 * (2 * H + 4) + 2 * (6 * 64 + 4) + 16 + 4 * (size_t)H + 16 * ((size_t)H + 4) + 2 * (size_t)tile_words + 8) *
+           sizeof(float);
+}
+template <int H, int KIND>
+static int launch_step_ws(StepArgs& a, int tile_words, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    static const int grid_env = getenv("IC3_WS_GRID") ? atoi(getenv("IC3_WS_GRID")) : 0;
+    static const int zs_env = getenv("IC3_WS_ZS") ? atoi(getenv("IC3_WS_ZS")) : -1;
+    static const int zepi_env = getenv("IC3_WS_ZEPI") ? atoi(getenv("IC3_WS_ZEPI")) : -1;
+    const int G = grid_env > 0 ? grid_env : device_cus();
+    const int n_all = a.E / a.EPT;
+    a.n_full = n_all / G * G;
+    const int rest = a.E - a.n_full * a.EPT;
+    a.EPTh = rest > 0 ? std::min(a.EPT, (rest + G - 1) / G) : a.EPT;
+    a.ntiles = a.n_full + (rest > 0 ? (rest + a.EPTh - 1) / a.EPTh : 0);
+    {   // pacing: per_wave 1 KiB chunks per matrix wave of a full tile; S = 2 * zs slots per 16-k block in KB16 - 1 blocks
+        const int NWv = H / 32, KB16 = 2 * H / 16;
+        const long long chunks = ((long long)a.EPT * a.N * a.obs_dim / 4 + 63) / 64 + 1;
+        const long long per_wave = (chunks + NWv - 1) / NWv;
+        static const int ZS_SET[] = { 0, 4, 8, 16 };                // (the kernel's loop variants: 0 / 8 / 16 / 32 slots per 16-k block)
+        int zs = 16;
+        for (int cand : ZS_SET)
+            if (2LL * cand * (KB16 - 1) >= per_wave) {
+                zs = cand;
+                break;
+            }
+        if (zs_env >= 0) zs = zs_env >= 16 ? 16 : zs_env >= 8 ? 8 : zs_env >= 4 ? 4 : 0;
+        a.zs = zs;
+        long long left = per_wave - 2LL * zs * (KB16 - 1);
+        a.z0 = a.z3 = a.zc = a.zf = a.zh = 0;
+        a.zepi = zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
+        left -= 32LL * a.zepi;
+        a.zrest = (int)(left > 0 ? left + 1 : 0);
+    }
+    const size_t lds = ps_ws_lds(H, tile_words);
+    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_ws_kernel<H, KIND>), lds));
+    const int grid = std::min(G, a.ntiles);
+    if (ev0 || ev1) {
+        hipExtLaunchKernelGGL((policy_step_ws_kernel<H, KIND>), dim3(grid), dim3(4 * H), lds, s, ev0, ev1, 0, a);
+    } else {
+        hipLaunchKernelGGL((policy_step_ws_kernel<H, KIND>), dim3(grid), dim3(4 * H), lds, s, a);
+    }
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace ic3
 
 using namespace ic3;
@@ -1855,6 +1908,46 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         ev0 = (hipEvent_t)env->ev_start;
         ev1 = (hipEvent_t)env->ev_stop;
         env->ev_start = env->ev_stop = nullptr;
+    }
+    // IC3_PS_WS=1: the wave-specialised schedule (policy_step_ws.hpp) where it applies — same results (A / B switch)
+    static const int ws_on = getenv("IC3_PS_WS") ? atoi(getenv("IC3_PS_WS")) : 0;
+    if (ws_on && a.l_wp3 && fused_obs && !inner && !a.keep_state && !incr && !prefilled && (H == 128 || H == 64) &&
+        ps_ws_lds(H, tile_words) <= 160 * 1024) {
+        StepArgs w = a;
+#ifdef IC3_PS_TRACE
+        // [tile][20] time stamps (s_memrealtime, 100 MHz): 0..8 front phases (helper wave 0), 9 / 10 / 11 gate loop start / end,
+        // epilogue end (matrix wave 0), 12..17 heads / draws / env step / patch wait / patches (helper wave 0); dumped by the
+        // 40th call to $IC3_PS_TRACE_OUT (tools/analyze_trace.py --ws)
+        static unsigned long long* ws_trace = nullptr;
+        static int ws_call = 0;
+        const size_t ws_words = ((size_t)a.E + 64) * 20;
+        w.trace = nullptr;
+        if (getenv("IC3_PS_TRACE_OUT")) {
+            if (!ws_trace) {
+                IC3_HIP(hipMalloc(&ws_trace, ws_words * sizeof(unsigned long long)));
+                IC3_HIP(hipMemset(ws_trace, 0, ws_words * sizeof(unsigned long long)));
+            }
+            w.trace = ws_trace;
+        }
+#endif
+        if (H == 128) rc = pp ? launch_step_ws<128, IC3_ENV_PP>(w, tile_words, s, ev0, ev1) : launch_step_ws<128, IC3_ENV_TJ>(w, tile_words, s, ev0, ev1);
+        else rc = pp ? launch_step_ws<64, IC3_ENV_PP>(w, tile_words, s, ev0, ev1) : launch_step_ws<64, IC3_ENV_TJ>(w, tile_words, s, ev0, ev1);
+#ifdef IC3_PS_TRACE
+        if (w.trace && ++ws_call == 40) {
+            IC3_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hbuf((size_t)w.ntiles * 20);
+            IC3_HIP(hipMemcpy(hbuf.data(), ws_trace, hbuf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(getenv("IC3_PS_TRACE_OUT"), "w")) {
+                for (int t = 0; t < w.ntiles; ++t) {
+                    fprintf(f, "%d", t);
+                    for (int k = 0; k < 20; ++k) fprintf(f, ",%llu", hbuf[(size_t)t * 20 + k]);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+        }
+#endif
+        return rc;
     }
     if (a.l_wp3) {   // gate_split: the gate product on the bf16 matrix cores with exact split products
         if (H == 128)

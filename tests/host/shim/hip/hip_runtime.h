@@ -310,6 +310,9 @@ inline unsigned long long __ballot(int pred)
     w->bar.arrive_and_wait();
     return m;
 }
+// the lanes of a wavefront reach this point together (on the GPU they always do; here they are fibers): what one lane does
+// behind it on behalf of the wave — a release of data all lanes wrote — sees every lane's part
+inline void __builtin_amdgcn_wave_barrier() { ic3_host::tl_wave->bar.arrive_and_wait(); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __shfl(int v, int src) { return (int)ic3_host::exchange(v, src); }
 inline float __shfl(float v, int src)
@@ -627,7 +630,19 @@ inline int __builtin_amdgcn_readfirstlane(int v)
 inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
-inline void __builtin_amdgcn_s_sleep(int) {}
+// a sleeping wave is a wave that SPINS on something another lane will write (policy_step_ws.hpp's role hand-offs through LDS
+// counters): the emulated lane yields to the others; the atomics those hand-offs go through count as progress for the
+// scheduler's deadlock detector (a round in which nobody finishes, completes a barrier or signals is a hang)
+inline void __builtin_amdgcn_s_sleep(int) { ic3_host::yield(); }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+template <class T> inline T ic3_host_atomic_load(T* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+template <class T, class V> inline T ic3_host_fetch_add(T* p, V v)
+{
+    ic3_host::Fibers::get().progressed();
+    return __atomic_fetch_add(p, (T)v, __ATOMIC_SEQ_CST);
+}
+#define __hip_atomic_load(p, order, scope) ic3_host_atomic_load(p)
+#define __hip_atomic_fetch_add(p, v, order, scope) ic3_host_fetch_add(p, v)
 inline void* __builtin_amdgcn_kernarg_segment_ptr() { return const_cast<void*>(ic3_host::tl_kernarg); }
 inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }

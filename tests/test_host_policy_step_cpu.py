@@ -12,6 +12,8 @@ forms is bounds-checked.  What this does NOT see: the hardware's own behaviour (
 GPU suite's."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -71,6 +73,7 @@ def free_run(name, seed=5, offset=300, gate_split=False, use_table=True, E=None,
     nheads = len(heads)
     env = make_env(w, E, seed, offset)
     P = make_params(env.obs_dim, H, heads, seed=seed + 1)
+    gate_split = gate_split or os.environ.get("IC3_HOST_FORCE_SPLIT") == "1"     # (the wave-specialised kernel: split products only)
     pol = HostPolicy(env, P, H, heads, mode_avg=mode_avg, gate_split=gate_split, use_table=use_table)
     tj = w['env'] == 'tj'
     env.reset(0) if tj else env.reset()
@@ -751,5 +754,26 @@ def test_results_do_not_depend_on_the_lane_schedule():
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"),
                             os.path.join(here, "test_host_abi_cpu.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
                            capture_output=True, text=True, env=dict(os.environ, IC3_HOST_SCHED=sched), cwd=os.path.dirname(here))
+        assert r.returncode == 0, sched + r.stdout[-3000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_wave_specialised_schedule_on_the_host():
+    """csrc/policy_step_ws.hpp (IC3_PS_WS=1: matrix waves + helper waves of one persistent workgroup, handing tiles to each other
+    through LDS counters instead of s_barrier) through the stand-in runtime — spinning lanes yield, a hand-off nobody signals
+    aborts as a hang — under the three lane schedules: split-product free runs (TJ-hard: several tiles per workgroup, the small
+    tile first; PP-easy at hid 64 under a shuffled lane order) and an auto-reset stream must pass exactly as on the default kernel."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    runs = [("", "(gate_split_experiment and tj_hard) or auto_reset_stream_restarts"),     # several tiles per workgroup; restarts
+            ("shuffle", "free_run_vs and pp_easy")]                                      # hid 64, another lane order every round
+    for sched, sel in runs:
+        env = dict(os.environ, IC3_PS_WS="1", IC3_HOST_FORCE_SPLIT="1")
+        if sched:
+            env["IC3_HOST_SCHED"] = sched
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"), "-q", "-x", "-p",
+                            "no:cacheprovider", "-k", sel], capture_output=True, text=True, env=env, cwd=os.path.dirname(here))
         assert r.returncode == 0, sched + r.stdout[-3000:] + r.stderr[-2000:]
         assert " passed" in r.stdout and "failed" not in r.stdout

@@ -34,6 +34,59 @@ def clk(path):
         us[ok][last].mean(), cyc[ok][last].mean(), ghz[last].mean()))
 
 
+def ws(path, G=256):
+    """The wave-specialised kernel (policy_step_ws.hpp, IC3_PS_WS=1 on an IC3_PS_TRACE build): per tile the helper waves'
+    front phases F (slots 0..8), the matrix waves' gate loop + epilogue G (9 = A tile there, 10 = loop end, 11 = epilogue end)
+    and the helpers' back phases B (12 = h' there ... 17); tiles of one workgroup are b, b + G, ... behind its small tile."""
+    d = np.loadtxt(path, delimiter=',', dtype=np.int64)
+    t = d[:, 1:19].astype(np.float64) * 0.01
+    ok = t[:, 0] > 0
+    t0 = t[ok, 0].min()
+    t = t - t0
+    ntiles = len(d)
+    print("tiles %d (stamped %d), launch span %.1f us" % (ntiles, ok.sum(), t[ok, 17].max()))
+    F = t[:, 8] - t[:, 0]
+    wait_f = t[:, 9] - t[:, 8]                    # matrix waves pick the tile up this long after the helpers finished it (< 0: they waited)
+    loop = t[:, 10] - t[:, 9]
+    epi = t[:, 11] - t[:, 10]
+    wait_g = t[:, 12] - t[:, 11]                  # helpers start B this long after the epilogue ended
+    B = t[:, 17] - t[:, 12]
+    pw = t[:, 16] - t[:, 15]
+    def row(name, x):
+        x = x[ok]
+        print("   %-46s mean %7.2f us  p10 %7.2f  p50 %7.2f  p90 %7.2f" % (name, x.mean(), np.percentile(x, 10), np.percentile(x, 50), np.percentile(x, 90)))
+    names = ["S0 loads", "S1 desc", "S2 enc + S4 h->LDS", "S3 enc->acc", "-", "S5 comm+Bload", "S6 C product", "S7 inp->LDS"]
+    for k in range(8):
+        row("F: " + names[k], t[:, k + 1] - t[:, k])
+    row("F total (helpers, front phases of a tile)", F)
+    row("A tile done -> matrix waves start (idle if > 0)", wait_f)
+    row("G: gate loop (matrix waves)", loop)
+    row("G: cell epilogue", epi)
+    row("epilogue end -> helpers start B", wait_g)
+    row("B: heads", t[:, 13] - t[:, 12])
+    row("B: draws", t[:, 14] - t[:, 13])
+    row("B: env step", t[:, 15] - t[:, 14])
+    row("B: wait for the tile's zero stores", pw)
+    row("B: patches + barrier", t[:, 17] - t[:, 16])
+    row("B total", B)
+    # per workgroup: the period of its matrix waves (loop start to next loop start) and their idle share
+    per, idle = [], []
+    for b in range(min(G, ntiles)):
+        ids = [i for i in range(b, ntiles, G) if ok[i]]
+        ids.sort(key=lambda i: t[i, 9])
+        for x, y in zip(ids[:-1], ids[1:]):
+            per.append(t[y, 9] - t[x, 9])
+            idle.append(t[y, 9] - t[x, 11])
+    if per:
+        per, idle = np.array(per), np.array(idle)
+        print("matrix-wave period per tile: mean %.2f us (p10 %.2f p90 %.2f); of it idle between epilogue end and the next loop: %.2f us"
+              % (per.mean(), np.percentile(per, 10), np.percentile(per, 90), idle.mean()))
+    fin = np.array([t[[i for i in range(b, ntiles, G) if ok[i]], 17].max() for b in range(min(G, ntiles))])
+    print("workgroup finish: mean %.1f p10 %.1f p90 %.1f max %.1f us;  first gate loop starts at %.1f us (mean)" % (
+        fin.mean(), np.percentile(fin, 10), np.percentile(fin, 90), fin.max(),
+        np.mean([min(t[i, 9] for i in range(b, ntiles, G) if ok[i]) for b in range(min(G, ntiles))])))
+
+
 def main(path, epi=False):
     global NAMES
     if epi:
@@ -81,6 +134,9 @@ def main(path, epi=False):
               (lags.mean(), np.percentile(lags, 10), np.percentile(lags, 50), np.percentile(lags, 90), len(lags)))
 
 
+if __name__ == '__main__' and '--ws' in sys.argv:
+    ws([x for x in sys.argv[1:] if not x.startswith('--')][0])
+    sys.exit(0)
 if __name__ == '__main__':
     if '--clk' in sys.argv[2:]:
         clk(sys.argv[1])
