@@ -46,6 +46,12 @@ WORKLOADS = {
     "tj_medium_commnet_mlp": ("traffic_junction", dict(nagents=10, dim=14, vision=1, max_steps=40, hid_size=128, commnet=True,
                                                        recurrent=False, comm_passes=2, difficulty='medium', add_rate_min=0.05,
                                                        add_rate_max=0.05)),
+    # the reference's non-communicating baselines (models.py:8-97) on the PP-hard env — IC = models.MLP,
+    # IRIC = models.RNN with the LSTM cell — one launch per step through their kernel stand-ins (ic3net_amd/models.py)
+    "pp_hard_ic": ("predator_prey", dict(nagents=10, dim=20, vision=1, max_steps=80, hid_size=128, recurrent=False,
+                                         baseline='mlp', detach_gap=10, mode='mixed')),
+    "pp_hard_iric": ("predator_prey", dict(nagents=10, dim=20, vision=1, max_steps=80, hid_size=128, recurrent=True,
+                                           rnn_type='LSTM', baseline='rnn', detach_gap=10, mode='mixed')),
     "pp_scaled": ("predator_prey", dict(nagents=32, dim=40, vision=2, max_steps=80, hid_size=256, ic3net=True,
                                         recurrent=True, detach_gap=10, mode='mixed')),
 }
@@ -95,7 +101,13 @@ def build_trainer(workload, nenvs, seed, env_id_offset, device, **overrides):
         a.recurrent, a.rnn_type = True, 'LSTM'
     parse_action_args(a)
     torch.manual_seed(seed)               # default PyTorch init, random weights (no checkpoints offline)
-    net = CommNetMLP(a, a.num_inputs).to(torch.device('cuda', device)).float()
+    if getattr(a, 'baseline', None):      # main.py:161-168: MLP / RNN instead of CommNetMLP
+        from ic3net_amd import models
+        a.continuous = False
+        net = (models.RNN if a.baseline == 'rnn' else models.MLP)(a, a.num_inputs)
+    else:
+        net = CommNetMLP(a, a.num_inputs)
+    net = net.to(torch.device('cuda', device)).float()
     return Trainer(a, net, env), a
 
 
@@ -233,6 +245,8 @@ def mfma_roofline(a, nenvs, step_ms, gate_split=False):
     gate = 2.0 * R * (2 * H * 4 * H) if rec else 0.0
     # non-recurrent module (comm.py:220-224): per communication pass one [comm | h] . [C_i | F_i]^T product (2H x H)
     flops = gate + 2.0 * R * (H * H + H * OT) if rec else 2.0 * R * (int(a.comm_passes) * 2 * H * H + H * OT)
+    if getattr(a, 'baseline', None):      # models.py:23-34 / 75-84: affine2 (H x H) or the LSTM cell, + heads — no C layer
+        flops = gate + 2.0 * R * H * OT if rec else 2.0 * R * (H * H + H * OT)
     avg = sum(step_ms) / len(step_ms)
     tf = flops / (avg * 1e-3) / 1e12
     out = {"kernel": "policy_step_kernel" if rec else "commnet_forward_kernel<H, env> (ic3_commnet_step)", "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,

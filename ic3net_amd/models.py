@@ -11,6 +11,91 @@ import torch.nn.functional as F
 from torch import nn
 
 
+class _StandInArgs(object):
+    """The args of a baseline, read live, as the communicating module's constructor and kernels read them: one pass, the
+    communication block switched off (comm_mask_zero: C sees zeros, comm.py:40-41), no gate head."""
+    _FIXED = dict(comm_passes=1, comm_mask_zero=True, hard_attn=False, share_weights=False, comm_init='uniform', commnet=True,
+                  comm_mode='avg', comm_action_one=False)
+
+    def __init__(self, base, recurrent):
+        object.__setattr__(self, '_base', base)
+        object.__setattr__(self, '_rec', bool(recurrent))
+
+    def __getattr__(self, k):
+        if k in _StandInArgs._FIXED:
+            return _StandInArgs._FIXED[k]
+        if k == 'recurrent':
+            return object.__getattribute__(self, '_rec')
+        if k == 'rnn_type':
+            return 'LSTM' if object.__getattribute__(self, '_rec') else 'MLP'
+        return getattr(object.__getattribute__(self, '_base'), k)
+
+    def __setattr__(self, k, v):
+        setattr(object.__getattribute__(self, '_base'), k, v)
+
+
+class _KernelStandIn(object):
+    """The ONE-LAUNCH rollout of a baseline (round 5).  models.MLP is the non-recurrent CommNet module with one pass and the
+    communication block off — h = tanh(x + f(x) + C(0)), x = tanh(encoder(obs)) (comm.py:119-129,220-224 against
+    models.py:23-34: encoder = affine1, f = affine2, C.bias = 0) — and models.RNN with the LSTM cell is the recurrent CommNet
+    policy with the block off — LSTMCell(encoder(obs) + C.bias, (h, c)) (comm.py:209-215 against models.py:75-84).  So a
+    baseline keeps a CommNetMLP of that shape whose parameters are COPIES of its own (C: zeros), refreshed when a parameter's
+    version changes (like the zero-padded twin of comm.CommNetMLP), and its rollout steps run ic3_commnet_step /
+    ic3_policy_step on that stand-in: sparse encoder, layer(s), heads, Philox draws, env.step and the obs rows in one launch.
+    The tanh recurrence of models.RNN (rnn_type 'MLP') has no such kernel and stays a launch chain."""
+
+    def __init__(self, owner, recurrent):
+        self.owner, self.recurrent, self.net, self.key = owner, recurrent, None, None
+
+    def get(self):
+        from .comm import CommNetMLP
+        o = self.owner
+        w = o.affine1.weight
+        if not w.is_cuda or w.dtype != torch.float32 or not getattr(o.args, 'mega_policy', True):
+            return None
+        if self.net is None or self.net.encoder.weight.device != w.device:
+            self.net = CommNetMLP(_StandInArgs(o.args, self.recurrent), o.affine1.in_features).to(device=w.device, dtype=w.dtype)
+            for q in self.net.parameters():
+                q.requires_grad_(False)
+                q.zero_()
+            self.key = None
+        key = tuple((q._version, q.data_ptr()) for q in o.parameters())
+        if key != self.key:
+            with torch.no_grad():
+                n = self.net
+                n.encoder.weight.copy_(o.affine1.weight)
+                n.encoder.bias.copy_(o.affine1.bias)
+                if self.recurrent:
+                    for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                        getattr(n.f_module, k).copy_(getattr(o.lstm_unit, k))
+                else:
+                    n.f_modules[0].weight.copy_(o.affine2.weight)
+                    n.f_modules[0].bias.copy_(o.affine2.bias)
+                for mine, theirs in zip(list(o.heads) + [o.value_head], list(n.heads) + [n.value_head]):
+                    theirs.weight.copy_(mine.weight)
+                    theirs.bias.copy_(mine.bias)
+            self.key = key
+        n = self.net
+        n.obs_encoder, n.obs_table, n.sample_into = o.obs_encoder, getattr(o, 'obs_table', None), getattr(o, 'sample_into', None)
+        return n
+
+    def done(self):
+        """mirror what the Trainer reads off the policy after a call"""
+        for k in ('mega_steps', 'commnet_steps', 'cache_generation'):
+            if k in self.net.__dict__:
+                self.owner.__dict__[k] = self.net.__dict__[k]
+        self.owner.sampled = self.net.sampled
+        self.owner.__dict__['_fc'] = True          # (Trainer.begin_episode: derived weights exist -> refresh them before replays)
+
+    def refresh(self):
+        """Trainer.begin_episode in hipGraph mode: replays never run Python, so the copies and the packed weights derived from
+        them are brought up to date here (in place: the graphs hold their addresses)."""
+        n = self.get()
+        if n is not None:
+            n._fused_cache() if self.recurrent else n._commnet_cache()
+            self.done()
+
+
 class MLP(nn.Module):
     def __init__(self, args, num_inputs):
         super(MLP, self).__init__()
@@ -24,7 +109,27 @@ class MLP(nn.Module):
         self.value_head = nn.Linear(args.hid_size, 1)
         self.tanh = nn.Tanh()
         self.obs_encoder = None          # optional sparse-gather evaluation of affine1 (see comm.CommNetMLP)
+        self.obs_table = None            # envs.encode_table (set by the Trainer like comm.CommNetMLP's)
+        self.sampled = False
         self._wt_cache = (None, None)
+        self.__dict__['_stand_in'] = _KernelStandIn(self, recurrent=False)     # (not a submodule: derived data)
+
+    # ---- the whole iteration trainer.py:61-67 as ONE launch, on the stand-in (see _KernelStandIn) -------------------------
+    def commnet_step_ok(self, env, x):
+        if type(self) is not MLP or torch.is_grad_enabled() or not (torch.is_tensor(x) and x.is_cuda):
+            return False
+        n = self._stand_in.get()
+        return n is not None and n.commnet_step_ok(env, x)
+
+    def step_env_commnet(self, env, x, info, **kw):
+        n = self._stand_in.get()
+        out = n.step_env_commnet(env, x, info, **kw)
+        self._stand_in.done()
+        return out
+
+    def _fused_cache(self):
+        if self.__dict__.get('_stand_in') is not None:
+            self._stand_in.refresh()
 
     def _affine1(self, x):
         if self.obs_encoder is not None and not torch.is_grad_enabled() and self.args.hid_size % 4 == 0:
@@ -105,8 +210,43 @@ class RNN(MLP):
             self._modules.pop('affine2')                 # not part of this variant's state_dict (models.py:64-66)
             self.lstm_unit = nn.LSTMCell(self.hid_size, self.hid_size)
             self._recur = _LSTMRecurrence(self)
+            self.__dict__['_stand_in'] = _KernelStandIn(self, recurrent=True)
+            self.sample_into = None          # (the Trainer's fused-draw protocol: unused here, the step launch draws itself)
         else:
             self._recur = _TanhRecurrence(self)
+            self.__dict__['_stand_in'] = None
+
+    # ---- the LSTM variant's iteration as ONE launch (ic3_policy_step on the stand-in) ------------------------------------------
+    def _kernel(self, x=None):
+        if self._stand_in is None or torch.is_grad_enabled():
+            return None
+        if x is not None and not (torch.is_tensor(x[0]) and x[0].is_cuda):
+            return None
+        return self._stand_in.get()
+
+    def mega_supported(self, env):
+        n = self._kernel()
+        return n is not None and n.mega_supported(env)
+
+    def mega_ok(self, env, x):
+        n = self._kernel(x)
+        return n is not None and n.mega_ok(env, x)
+
+    def record_inplace_ok(self):
+        """The native update's episode record can serve as the step launch's (h, c) buffers only when the stand-in runs at
+        this hidden size itself (64 / 128 / 256), not as a zero-padded twin with wider rows."""
+        from . import ops
+        return ops.padded_hidden(self.hid_size) is None
+
+    def zero_hidden(self, batch_size, device):
+        n = self._kernel()
+        return n.zero_hidden(batch_size, device) if n is not None else self.init_hidden(batch_size)
+
+    def step_env(self, env, x, info, **kw):
+        n = self._stand_in.get()
+        out = n.step_env(env, x, info, **kw)
+        self._stand_in.done()
+        return out
 
     def forward(self, x, info={}):
         obs, state = x

@@ -249,7 +249,9 @@ class Trainer(object):
         """The recorded rollout of a native update reads / writes (h, c) in the episode record (no copies) when every
         step of the episode goes through ic3_policy_step with ONE communication pass."""
         raw = getattr(self.env, 'env', None)
-        return raw is not None and self._mega_expected(raw) and getattr(self.policy_net, 'comm_passes', 1) == 1
+        ok = getattr(self.policy_net, 'record_inplace_ok', None)       # (a baseline whose kernel stand-in runs zero-padded: no)
+        return raw is not None and self._mega_expected(raw) and getattr(self.policy_net, 'comm_passes', 1) == 1 \
+            and (ok is None or ok())
 
     def _mega_expected(self, raw):
         """Will step_episode go through ic3_policy_step?  (no autograd, default sampling, a policy that supports the

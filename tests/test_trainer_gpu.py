@@ -457,6 +457,49 @@ def test_baseline_policies_through_trainer(kind, rnn_type):
     assert np.isfinite(st['action_loss']) and not torch.equal(before, net.affine1.weight)
 
 
+@pytest.mark.parametrize("kind", ["mlp", "lstm"])
+def test_baselines_roll_out_in_one_launch_like_the_launch_chain(kind):
+    """IC / IRIC baselines (models.MLP; models.RNN with the LSTM cell) on the one-launch kernels through their stand-ins
+    (ic3net_amd/models.py: the non-recurrent / recurrent CommNet module with the communication block off): the episode equals
+    the launch chain's (same draws off CDF edges, values / log-probs to 1e-5), the native update's gradients too, and the
+    update moves the baseline's own parameters."""
+    import bench
+    wl = 'pp_hard_ic' if kind == 'mlp' else 'pp_hard_iric'
+
+    def play(mega):
+        tr, a = bench.build_trainer(wl, 24, 3, 0, 0, max_steps=12)
+        a.mega_policy = mega
+        ep, stat = tr.get_episode(0)
+        act = torch.stack([t.action for t in ep]).cpu()
+        val = torch.stack([t.value.reshape(24, 10) for t in ep]).cpu()
+        lp = torch.stack([t.action_out[0] for t in ep]).cpu()
+        rew = torch.stack([t.reward for t in ep]).cpu()
+        return tr, a, act, val, lp, rew
+
+    tr1, a1, act1, val1, lp1, rew1 = play(True)
+    used = getattr(tr1.policy_net, 'commnet_steps' if kind == 'mlp' else 'mega_steps', 0)
+    assert used == 12, "the one-launch path did not run"
+    tr0, a0, act0, val0, lp0, rew0 = play(False)
+    assert getattr(tr0.policy_net, 'commnet_steps', 0) == 0 and getattr(tr0.policy_net, 'mega_steps', 0) == 0
+    # step 0 sees the same state: its outputs agree to rounding; the episodes then agree as long as no draw sits on a CDF edge
+    torch.testing.assert_close(lp1[0], lp0[0], atol=1e-5, rtol=0)
+    torch.testing.assert_close(val1[0], val0[0], atol=1e-5, rtol=0)
+    assert torch.equal(act1, act0) and torch.equal(rew1, rew0)
+    torch.testing.assert_close(lp1, lp0, atol=2e-5, rtol=0)
+    torch.testing.assert_close(val1, val0, atol=2e-5, rtol=0)
+    grads = []
+    for tr, a in ((tr1, a1), (tr0, a0)):
+        a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0.01, value_coeff=0.01, advantages_per_action=False,
+                          batch_size=24 * 12, lrate=0.0)
+        before = tr.policy_net.affine1.weight.detach().clone()
+        st = tr.train_batch(1)
+        assert np.isfinite(st['action_loss'])
+        grads.append({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        g1, g0 = grads[0][k], grads[1][k]
+        assert float((g1 - g0).abs().max()) <= 2e-4 * max(1e-6, float(g0.abs().max())), k
+
+
 def test_enemy_comm_through_trainer():
     """main.py:125-130: with --enemy_comm the policy sees nagents = nfriendly + nenemies; stats gain
     enemy_reward / enemy_comm (trainer.py:73-75,87-88)."""
