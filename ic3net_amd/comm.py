@@ -353,7 +353,7 @@ class CommNetMLP(nn.Module):
 
     def commnet_step_ok(self, env, x):
         """True when step_env_commnet() may replace forward + select_action + env.step for this input (the non-recurrent
-        module, the env's own observation, a handle that is not in auto-reset mode)."""
+        module, the env's own observation)."""
         tw = self._twin_for(x)
         if tw is not None:
             return tw.commnet_step_ok(env, x)

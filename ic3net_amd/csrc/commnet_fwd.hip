@@ -47,6 +47,8 @@ struct CommnetArgs {
     float* obs;                // [E][N][obs_dim] or null: rows of the state acted on
     int32_t* action;           // [nheads][R]
     int obs_dim, G, tile_words;
+    int auto_reset;            // env handle in auto-reset mode: an env with t == 0 starts an episode — nobody is dead yet and
+                               // the gate is 0 (trainer.py:41-46, quirks Q21 / Q22); the module carries no other state
     uint32_t seed, gid0;
     const int32_t* episode;
     const int32_t* tstep;
@@ -95,8 +97,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
     // ---- masks and per-env scale (comm.py:102-107,175-177,194-196) ---------------------------------------------------------
     if (tid < BM) {
         const bool in = tid < rows;
-        const int al = (in && a.alive_in) ? a.alive_in[r0 + tid] : 1;
-        const int cm = (in && a.comm_in) ? a.comm_in[r0 + tid] : 1;
+        int al = (in && a.alive_in) ? a.alive_in[r0 + tid] : 1;
+        int cm = (in && a.comm_in) ? a.comm_in[r0 + tid] : 1;
+        if constexpr (KIND != 0) {
+            if (a.auto_reset && in && a.tstep[e0 + div_small(tid, invN)] == 0) {   // the env starts an episode at this step
+                al = 1;
+                cm = a.comm_in ? 0 : 1;                          // (a gated policy: gate 0; CommNet without a gate head talks)
+            }
+        }
         sm[tid] = in ? (float)(al * cm) : 0.f;
         sal[tid] = al;
     }
@@ -438,7 +446,7 @@ static size_t commnet_step_lds(const ic3_env* env, int H)
 
 extern "C" int ic3_commnet_step_supported(const ic3_env* env, int H)
 {
-    if (!env || !ic3_commnet_forward_supported(H, env->dims.N) || env->auto_max_steps > 0) return 0;
+    if (!env || !ic3_commnet_forward_supported(H, env->dims.N)) return 0;
     const size_t lds = commnet_step_lds(env, H);
     return lds <= 160 * 1024 ? (int)lds : 0;
 }
@@ -458,9 +466,8 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
     if (nheads < 1 || nheads > 4) return fail(-22, "ic3_commnet_step: 1..4 action heads");
     const int lds = ic3_commnet_step_supported(env, H);
     if (!lds)
-        return fail(-38, "ic3_commnet_step: needs hid_size 64/128/256, <= 64 agents per env, an env tile that fits in LDS and a "
-                         "handle that is not in auto-reset mode (use ic3_env_encode + ic3_commnet_forward + ic3_env_sample_actions "
-                         "+ ic3_env_step)");
+        return fail(-38, "ic3_commnet_step: needs hid_size 64/128/256, <= 64 agents per env and an env tile that fits in LDS (use "
+                         "ic3_env_encode + ic3_commnet_forward + ic3_env_sample_actions + ic3_env_step)");
     CommnetArgs a{};
     a.wp = wp;
     a.bias = bias;
@@ -473,6 +480,7 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
     a.N = env->dims.N;
     a.EPT = 64 / a.N;
     a.passes = comm_passes;
+    a.auto_reset = env->auto_max_steps > 0;
     a.mode_avg = mode_avg;
     a.comm_zero = comm_zero;
     a.nheads = nheads;

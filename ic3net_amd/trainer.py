@@ -408,6 +408,9 @@ class Trainer(object):
                         and self.policy_net.commnet_step_ok(raw, state):
                     return self._step_body_commnet(t, observe)
                 self._refresh_skipped_reset_obs(raw, t)
+                if self._auto_reset():
+                    raise NotImplementedError("args.auto_reset needs the one-launch rollout step (ic3_commnet_step: hid_size "
+                                              "64/128/256, no autograd): per-env episode starts are handled inside that launch")
                 action_out, value = self.policy_net(state, info)
             if getattr(self.policy_net, 'sampled', False):                               # drawn by the policy launch
                 self.policy_net.sampled = False

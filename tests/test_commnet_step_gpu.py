@@ -80,6 +80,64 @@ def test_commnet_step_full_episode_vs_fp64_reference_policy(workload, over, E, T
     assert worst < TOL
 
 
+@pytest.mark.parametrize("gated", [True, False], ids=["gated", "commnet"])
+def test_commnet_step_on_an_auto_reset_handle(gated):
+    """Round 5: ic3_commnet_step takes handles in auto-reset mode — an env that finishes (Predator-Prey 'mixed': every predator
+    on the prey; or the step cap) restarts inside the launch, and at an episode's first step nobody is dead and a gated policy's
+    gate is 0 (trainer.py:41-46, quirks Q21 / Q22; the plain CommNet talks from the first step).  One window through the
+    Trainer against the fp64 policy + consecutive oracle episodes per env."""
+    import bench
+    import oracle
+    from oracle import policy_ref
+    seed, offset, E, T = 7, 500, 24, 12
+    over = dict(recurrent=False, comm_passes=2, nagents=2, dim=3, vision=1, hid_size=64, max_steps=T)
+    if not gated:
+        over.update(ic3net=False, commnet=True)
+    tr, a = bench.build_trainer("pp_hard", E, seed, offset, 0, **over)
+    a.auto_reset = True
+    with torch.no_grad():
+        tr.policy_net.heads[0].weight.mul_(3.0)                     # peaked action distributions: episodes do end early
+    tr.begin_episode(0)
+    raw = tr.env.env
+    N, nheads = a.nagents, len(a.naction_heads)
+    params = {k: v.detach().cpu().double().numpy() for k, v in tr.policy_net.state_dict().items()}
+    rec = []
+    for t in range(T):
+        tr.step_episode(t)
+        _, action_out, value, _ = tr._step_out[t]
+        rec.append(dict(logp=[ao.cpu().numpy() for ao in action_out], value=value.reshape(E, N).cpu().numpy(),
+                        act=tr._buf['action'][t].cpu().numpy(), rew=tr._buf['reward'][t].cpu().numpy(),
+                        done=tr._buf['done'][t].cpu().numpy(), obs=raw._obs.cpu().numpy()))
+    assert getattr(tr.policy_net, 'commnet_steps', 0) == T, "the one-launch path did not run"
+    worst, restarts = 0.0, 0
+    for e in range(E):
+        o = oracle.PPOracle(N, a.dim, a.vision, a.mode, seed=seed, env_gid=offset + e)
+        obs = o.reset()
+        gate, tt = np.zeros(N), 0
+        for t in range(T):
+            r = rec[t]
+            np.testing.assert_array_equal(r['obs'][e], obs, err_msg="obs rows env %d slot %d" % (e, t))
+            logp, val, _ = policy_ref.forward(params, obs[None].astype(np.float64), None, None, gate if a.hard_attn else None,
+                                              recurrent=False, comm_passes=a.comm_passes, comm_mode_avg=(a.comm_mode == 'avg'),
+                                              hard_attn=bool(a.hard_attn), nheads=nheads)
+            for hd in range(nheads):
+                worst = max(worst, np.abs(logp[hd][0] - r['logp'][hd][e]).max())
+            worst = max(worst, np.abs(val.reshape(-1) - r['value'][e]).max())
+            assert worst < TOL, (e, t, worst)
+            obs, orew, od = o.step(r['act'][0, e])
+            tt += 1
+            np.testing.assert_array_equal(r['rew'][e], np.asarray(orew).astype(np.float32))
+            end = bool(od) or tt == T
+            assert bool(r['done'][e]) == end, (e, t)
+            if end:
+                restarts += 1
+                obs = o.reset()
+                gate, tt = np.zeros(N), 0
+            elif a.hard_attn:
+                gate = r['act'][nheads - 1, e].astype(np.float64)
+    assert restarts > E // 4, "no episode ended early: the test would not see a restart"
+
+
 def test_commnet_step_refuses_what_it_does_not_cover():
     import bench
     from ic3net_amd import ops
@@ -87,4 +145,4 @@ def test_commnet_step_refuses_what_it_does_not_cover():
     raw = tr.env.env
     assert ops.commnet_step_supported(raw, 128) and not ops.commnet_step_supported(raw, 96)
     raw.set_auto_reset(5)
-    assert not ops.commnet_step_supported(raw, 128)      # (episode starts inside the launch: ic3_policy_step only)
+    assert ops.commnet_step_supported(raw, 128)          # (round 5: episode starts inside the launch are handled here too)
