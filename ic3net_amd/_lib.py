@@ -9,7 +9,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("IC3_ROLLOUT_LIB") or os.path.join(_HERE, "csrc", "libic3rollout.so")   # (override: A/B builds)
 
-ABI_VERSION = 400        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
+ABI_VERSION = 500        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
 ENV_PP, ENV_TJ = 1, 2
 PP_MODES = {"mixed": 0, "cooperative": 1, "competitive": 2}
 TJ_DIFFICULTY = {"easy": 0, "medium": 1, "hard": 2}

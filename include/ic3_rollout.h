@@ -34,7 +34,7 @@ extern "C" {
  * boundary checks itself: ic3_version() returns the library's value, ic3_abi_check() compares the caller's version and
  * struct sizes with the library's, and both structs start with `struct_size` (= sizeof, set by the caller) — an entry
  * point handed a struct of another size refuses it with -EINVAL before reading any other field. */
-#define IC3_VERSION 400 /* 0.4.0 (round 4: struct_size handshake, ic3_obs_prefill) */
+#define IC3_VERSION 500 /* 0.5.0 (round 5: ic3_returns_scan, ic3_comm_masked_mean_add, ic3_env_encode_backward_accumulate / _finish) */
 
 /* 0 when `version` == IC3_VERSION of the library and the two sizes are the library's sizeof(ic3_policy) /
  * sizeof(ic3_episode); -EINVAL (with a message naming the mismatch) otherwise.  A binding calls it once after loading. */

@@ -357,7 +357,7 @@ def trainer_case(name, env_name, T, nenv, nep, seed, greedy=False, closed_form=F
     print(name, 'nsteps', rec['nsteps'].tolist(), 'stat keys', sorted(stats))
 
 
-def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, **flags):
+def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, model=None, **flags):
     """F5b: the reference run_batch + compute_grad (trainer.py:128-225) over nenv*nep taped episodes played one
     after the other in ONE batch (what a single reference process does), fp64.  Records the loss terms and every
     parameter gradient (before the /num_steps of train_batch), plus the weights and the action tape."""
@@ -367,7 +367,12 @@ def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, **flags):
     env = rh.make_env(env_name, a)
     rh.finish_args(a, env)
     torch.manual_seed(seed)
-    net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    if model == 'mlp':        # the reference's IC / IRIC baselines (models.py:8-97; main.py:161-168 builds them like this)
+        net = ref['models'].MLP(a, a.num_inputs)
+    elif model == 'rnn':
+        net = ref['models'].RNN(a, a.num_inputs)
+    else:
+        net = ref['comm'].CommNetMLP(a, a.num_inputs)
     if closed_form:       # BASELINE shapes: weights from the index alone (both sides regenerate them, no 4 MB blobs)
         sd = net.state_dict()
         cw = closed_form_weights({k: tuple(v.shape) for k, v in sd.items()})
@@ -421,6 +426,8 @@ def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, **flags):
     out = dict(tape=tape.astype(np.int32), nsteps=nsteps, cfg=np.array([N, T, nenv, nep, nh, seed], np.int32),
                flags=np.array(repr(sorted(flags.items()))), action_loss=s['action_loss'], value_loss=s['value_loss'],
                entropy=s.get('entropy', 0.0), num_steps=stats['num_steps'])
+    if model:
+        out['model'] = np.array(model)
     if closed_form:
         out['param_names'] = np.array(list(net.state_dict().keys()))
         out['param_shapes'] = np.array([repr(tuple(v.shape)) for v in net.state_dict().values()])
@@ -527,6 +534,19 @@ def grad_stream_case(name, env_name, T, nenv, nwin, seed, closed_form=False, **f
     print(name, 'steps', stats['num_steps'], 'episodes', stats['num_episodes'], 'lengths', lengths, 'losses', s)
 
 
+def grad_baseline_main():
+    """F5b for the non-communicating baselines (round-4 verdict: their native update was only checked against this repo's
+    autograd): the reference's run_batch + compute_grad with models.MLP (IC), models.RNN with the tanh recurrence and with the
+    LSTM cell (IRIC), hid 64."""
+    grad_case('grad_pp_medium_ic_mlp', 'predator_prey', 20, 3, 2, 61, model='mlp', nagents=5, dim=10, vision=1, hid_size=64,
+              recurrent=False, entr=0.01, value_coeff=0.01)
+    grad_case('grad_pp_medium_iric_rnn', 'predator_prey', 20, 3, 1, 62, model='rnn', nagents=5, dim=10, vision=1, hid_size=64,
+              recurrent=True, rnn_type='MLP', detach_gap=8, entr=0.01, value_coeff=0.01, normalize_rewards=True)
+    grad_case('grad_tj_easy_iric_lstm', 'traffic_junction', 20, 3, 2, 63, model='rnn', nagents=5, dim=6, vision=1, hid_size=64,
+              recurrent=True, rnn_type='LSTM', detach_gap=6, add_rate_min=0.3, add_rate_max=0.3, difficulty='easy', entr=0.01,
+              value_coeff=0.01)
+
+
 def grad_stream_main():
     """Collection-mode fixtures (round-4 verdict item 5): a tiny Predator-Prey grid on which sampled policies DO end episodes
     early (cuts inside the windows, a different number of episodes per env, detach points of the env's own step counter), and
@@ -604,6 +624,8 @@ if __name__ == '__main__':
         grad_nonrec_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_fullsize':
         grad_fullsize_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_baseline':
+        grad_baseline_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream':
         grad_stream_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':

@@ -247,7 +247,10 @@ GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_comm
                  # BASELINE shapes (hid 128, 80 steps, detach_gap 10), closed-form weights: configs[1] and configs[3]
                  ("grad_pp_hard_ic3net", "predator_prey"), ("grad_tj_hard_ic3net", "traffic_junction"),
                  # the NON-recurrent module (comm.py:127-129,220-224): CommNet with two passes; gated, shared weights
-                 ("grad_pp_medium_commnet_mlp2", "predator_prey"), ("grad_tj_easy_ic3net_mlp2share", "traffic_junction")]
+                 ("grad_pp_medium_commnet_mlp2", "predator_prey"), ("grad_tj_easy_ic3net_mlp2share", "traffic_junction"),
+                 # the IC / IRIC baselines (models.py:8-97; round 5): models.MLP, models.RNN with the tanh recurrence / the LSTM cell
+                 ("grad_pp_medium_ic_mlp", "predator_prey"), ("grad_pp_medium_iric_rnn", "predator_prey"),
+                 ("grad_tj_easy_iric_lstm", "traffic_junction")]
 
 
 @pytest.mark.parametrize("native", [False, True])
@@ -275,7 +278,13 @@ def test_compute_grad_matches_reference(name, env_name, native):
     if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
         a.recurrent, a.rnn_type = True, 'LSTM'
     parse_action_args(a)
-    net = CommNetMLP(a, a.num_inputs)
+    model = str(fx["model"]) if "model" in fx.files else None
+    if model:                                         # main.py:161-168: the baselines instead of CommNetMLP
+        from ic3net_amd import models
+        a.continuous = False
+        net = (models.RNN if model == 'rnn' else models.MLP)(a, a.num_inputs)
+    else:
+        net = CommNetMLP(a, a.num_inputs)
     if "param_names" in fx.files:                     # full-size fixture: weights from the index alone
         from policy_util import closed_form_weights
         shapes = {str(n): eval(str(sh)) for n, sh in zip(fx["param_names"], fx["param_shapes"])}
