@@ -46,7 +46,7 @@ class Policy(C.Structure):
                 ("comm_zero", C.c_int32), ("enc_wt", C.c_void_p), ("enc_bias", C.c_void_p), ("loc_table", C.c_void_p),
                 ("c_wp", C.c_void_p), ("lstm_wp", C.c_void_p), ("lstm_bias", C.c_void_p), ("head_w", C.c_void_p),
                 ("head_b", C.c_void_p), ("pass_index", C.c_int32), ("inner_pass", C.c_int32), ("gate_split", C.c_int32),
-                ("reserved_", C.c_int32), ("lstm_wp3", C.c_void_p)]
+                ("npasses", C.c_int32), ("lstm_wp3", C.c_void_p), ("c_wp_pass", C.c_void_p * 4), ("enc_bias_pass", C.c_void_p * 4)]
 
     def __init__(self, *a, **kw):             # positional arguments start at the field behind struct_size
         super().__init__(*((0,) + a if a else a), **kw)

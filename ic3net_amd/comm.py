@@ -675,10 +675,15 @@ class CommNetMLP(nn.Module):
         else:                        # the caller's buffer (hipGraph mode: nothing is allocated inside a captured step)
             assert out.is_contiguous() and tuple(out.shape) == (R, OT) and out.dtype == torch.float32
         mz = bool(self.args.comm_mask_zero)
-        for i in range(self.comm_passes - 1):                     # comm.py:179: every pass but the last updates h, c only
-            ops.policy_step_pass(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, i)
-        ops.policy_step(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, out, action, reward, done, alive,
-                        is_completed, obs, pass_index=self.comm_passes - 1)
+        if ops.policy_step_passes_supported(fc, H, self.comm_passes) and getattr(self.args, 'passes_in_launch', True):
+            # comm.py:179-218 as a loop inside ONE launch (round 5): the hidden state stays on chip between the passes
+            ops.policy_step(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, out, action, reward, done, alive,
+                            is_completed, obs, passes=self.comm_passes)
+        else:
+            for i in range(self.comm_passes - 1):                 # comm.py:179: every pass but the last updates h, c only
+                ops.policy_step_pass(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, i)
+            ops.policy_step(env, fc, H, heads, mode_avg, mz, h, c, alive_in, comm_in, out, action, reward, done, alive,
+                            is_completed, obs, pass_index=self.comm_passes - 1)
         self.mega_steps = getattr(self, 'mega_steps', 0) + 1
         return self._split_out(out, batch, n) + ((h, c) if hidden_out is None else tuple(hidden_out),)
 

@@ -195,6 +195,9 @@ struct StepArgs {
                                 // ends behind the LSTM cell (h, c updated; no heads, draws, env.step, obs rows)
     int keep_state;             // not the FIRST pass of the step: h, c hold the previous pass (an env at t == 0 keeps them)
     int tile_words;             // int32 words of one env-descriptor block in LDS
+    int npass;                  // MP instantiation (ic3_policy.npasses >= 2): communication passes played inside the launch
+    const ps_f32x4* c_wp_p[4];  //   packed C_modules[i].weight and encoder.bias + C_modules[i].bias of pass i
+    const ps_f32x4* enc_bias_p[4];
     uint32_t seed, gid0;
     const int32_t* episode;
     const int32_t* tstep;
@@ -321,9 +324,15 @@ __device__ __forceinline__ void reload_args(StepArgs& a)
     for (int i = 0; i < (int)(sizeof(StepArgs) / 4); ++i) dst[i] = kp[i];
 }
 
-template <int H, int KIND, int SPLIT = 0>
+// MP = 1 (round 5): comm_passes > 1 (comm.py:179-218) as a loop INSIDE the launch — masks, positions and window descriptors
+// are built once; every pass gathers the encoder output again (its bias differs per pass: encoder.bias + C_i.bias, and a
+// kept copy would be 32 registers or 32 KB of LDS the kernel does not have), takes h from the h half of the A tile where the
+// previous pass's cell epilogue left it and c from the registers it was computed in, and only the LAST pass stores h', c',
+// issues the obs zero fill and runs the back half.  MP = 0 compiles to exactly the one-pass kernel.
+template <int H, int KIND, int SPLIT = 0, int MP = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(const StepArgs a_in)
 {
+    static_assert(!MP || (SPLIT && KIND != 0), "the in-launch pass loop exists for the split gate product on an env handle");
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
     constexpr int ABL = IC3_PS_ABL;
     IC3_DYNAMIC_LDS(float, smem);
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     ps_f32x4 zv = { 0.f, 0.f, 0.f, 0.f };
     IC3_OPAQUE_VGPR(zv);                                        // keep it in registers (no re-materialisation per store)
     int zlane, zso;                                              // lane offset; running byte offset of this wave's next chunk (SGPR)
-    auto zero_store = [&]() {
+    auto zero_store = [&]() __attribute__((always_inline)) {
 #ifdef IC3_PS_PLAIN_STORES
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, 0);
 #else
@@ -359,12 +368,21 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         zso += NW * 1024;
     };
 
+    for (int pass = 0;; ++pass) {   // (one iteration unless MP)
     // =====================================================================================================================
     // FRONT: masks, descriptors, encoder, comm, C product, gate GEMM
     // =====================================================================================================================
     {
-        const StepArgs& a = a_in;
-        const int tid = threadIdx.x;
+        StepArgs a_re;                                               // MP: the arguments again for every pass (kernarg segment),
+        if constexpr (MP != 0) reload_args(a_re);                    // nothing of them lives across a pass
+        const StepArgs& a = MP ? a_re : a_in;
+        int tid_v = threadIdx.x;
+        if constexpr (MP != 0) IC3_OPAQUE_VGPR(tid_v);               // (per pass: nothing derived from it is hoisted out of the pass loop)
+        const int tid = tid_v;
+        const bool first = !MP || pass == 0, last = !MP || pass + 1 == a.npass;
+        // (the pass's C weights / bias by scalar selects: indexing the arrays with `pass` would put the argument block in scratch)
+        const ps_f32x4* const enc_bias_now = !MP ? a.enc_bias : pass == 0 ? a.enc_bias_p[0] : pass == 1 ? a.enc_bias_p[1] : pass == 2 ? a.enc_bias_p[2] : a.enc_bias_p[3];
+        const ps_f32x4* const c_wp_now = !MP ? a.c_wp : pass == 0 ? a.c_wp_p[0] : pass == 1 ? a.c_wp_p[1] : pass == 2 ? a.c_wp_p[2] : a.c_wp_p[3];
         IC3_TR(0);
         IC3_PRIO_AT(1);
 #ifdef IC3_PS_TRACE
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const float invN = 1.0f / (float)N, inv_nsegE = 1.0f / (float)max(nsegE, 1);   // div_small(): no integer divisions
         // env descriptors of `ne` envs starting at env `eb`, into the LDS block `tl` (two phases around a barrier):
         //   PP: sr[EPT*total] | sc[EPT*total] | tab[EPT*N*WW] (int2);  TJ: EPT x TJTile
-        auto desc_positions = [&](int32_t* tl, int eb, int ne) {
+        auto desc_positions = [&](int32_t* tl, int eb, int ne) __attribute__((always_inline)) {
             if constexpr (KIND == IC3_ENV_PP) {
                 int32_t* psr = tl;
                 int32_t* psc = tl + a.EPT * total;
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         };
-        auto desc_tab = [&](int32_t* tl, int ne) {
+        auto desc_tab = [&](int32_t* tl, int ne) __attribute__((always_inline)) {
             if constexpr (KIND != 0) {
                 int2* pt = reinterpret_cast<int2*>(tl + ((2 * a.EPT * total + 3) & ~3));
                 for (int s = tid; s < ne * nsegE; s += NT) {
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int first = (64 * (g.c_lo + ws) - g.mis) * 16;     // this wave's first full chunk (>= 0)
             const float* obody = a.obs + g.ob0 + g.ohead;
-            zr = make_rsrc(obody, (uint32_t)g.zend);
+            zr = make_rsrc(obody, (uint32_t)(last ? g.zend : 0));
             zlane = lane * 16;
             zso = __builtin_amdgcn_readfirstlane(first);
         }
@@ -463,6 +481,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // load -> wait -> write sequences one after the other, 4.6 us): the h rows first (the big one), then one clamped,
         // unconditional load per thread for each small array, then the positions, and only then the writes.
         ps_f32x4 hv[8];                                              // parked in registers until S4
+        unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
+        int32_t* sr = tile;
+        int32_t* sc = tile + a.EPT * total;
+        int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
+        if (first) {
         {
             // rows are contiguous: float4 number idx of the tile sits at byte 16 * idx; rows >= `rows` read as zeros
             // (descriptor range check)
@@ -485,9 +508,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         const float v_hb = a.head_b[min(tid, a.OT - 1) + tz];
         const float v_lb0 = a.l_bias[tid + tz], v_lb1 = a.l_bias[tid + NT + tz];   // 4H = 2 NT
-        int32_t* sr = tile;
-        int32_t* sc = tile + a.EPT * total;
-        int2* ptab = reinterpret_cast<int2*>(tile + ((2 * a.EPT * total + 3) & ~3));
         desc_positions(tile, e0, nenv);                              // (its LDS writes wait for everything above too)
         if (tid < BM) {                                              // wave 0, all lanes
             // auto-reset: an env whose t == 0 is at the start of an episode (see above); `sact` carries the alive flags
@@ -512,7 +532,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         slb[tid] = v_lb0;
         slb[tid + NT] = v_lb1;
-        if (g.obs_here) {   // (behind this phase's loads: their waits count these stores as younger, they do not wait for them)
+        if (g.obs_here && last) {   // (behind this phase's loads: their waits count these stores as younger, they do not wait for them)
 #pragma unroll 1
             for (int i = 0; i < a.z0; ++i) zero_store();
         }
@@ -523,7 +543,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int j = 0; j < N; ++j) n_alive += sact[el * N + j];
             sscale[el] = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;
         }
-        unsigned long long fmask = 0;                                // rows that start an episode: zero h / c, no masks
         if (autor)
             fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
                     ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
@@ -534,6 +553,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             __syncthreads();
             IC3_TR(2);
         }
+        }   // first
         // encoder weight rows / pre-summed location rows behind buffer descriptors (32-bit gather offsets)
         const BufRows encW = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.Wt), 0,
                                                                  (uint32_t)((size_t)a.obs_dim * H * sizeof(float)), 0x00020000),
@@ -552,20 +572,22 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                     v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
                 } else if constexpr (KIND == IC3_ENV_PP) {
                     v = pp_encode_row_t(sr + el * total, sc + el * total, ptab + el * nsegE, aa, c4, H4, WW,
-                                        a.pp.dim * a.pp.dim + 4, a.pp.dim, encW, a.enc_bias + tz, encL, rmask[row]);
+                                        a.pp.dim * a.pp.dim + 4, a.pp.dim, encW, enc_bias_now + tz, encL, rmask[row]);
                 } else {
-                    v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, a.enc_bias + tz, encL,
+                    v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, enc_bias_now + tz, encL,
                                         rmask[row]);
                 }
             }
             As4[row * LDA4 + c4] = v;
         }
         // ---- S4 (the other half of the tile: no barrier in front): h -> h half ----------------------------------------
+        if (first) {   // (MP, later passes: the h half holds the previous pass's h')
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / H4, c4 = idx - row * H4;
             As4[row * LDA4 + H4 + c4] = (autor && !a.keep_state && ((fmask >> row) & 1)) ? ps_f32x4{ 0.f, 0.f, 0.f, 0.f } : hv[i];
+        }
         }
         __syncthreads();
         IC3_TR(3);
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         }
-        if (g.obs_here) {
+        if (g.obs_here && last) {
 #pragma unroll 1
             for (int i = 0; i < a.z3; ++i) zero_store();
         }
@@ -608,7 +630,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         IC3_TR(4);
         IC3_TR(5);
 
-        if (g.obs_here) {
+        if (g.obs_here && last) {
             // (no load is waited for in the comm phase: the acknowledgements of these run under its LDS work)
 #pragma unroll 1
             for (int i = 0; i < a.zf; ++i) zero_store();
@@ -636,9 +658,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             constexpr int KBC = H / 8, CH = (KBC < 8) ? KBC : 8, NCH = KBC / CH;
             // weights through a buffer descriptor: lane offset in one VGPR, the k part of the address on the scalar ALU
             const __amdgpu_buffer_rsrc_t rcw = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<ps_f32x4*>(a.c_wp), 0, (uint32_t)((size_t)H * H * sizeof(float)), 0x00020000);
+                const_cast<ps_f32x4*>(c_wp_now), 0, (uint32_t)((size_t)H * H * sizeof(float)), 0x00020000);
             const int wlane = (col * 2 + lh) * 16;
-            auto cwp = [&](int k) {
+            auto cwp = [&](int k) __attribute__((always_inline)) {
                 return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rcw, wlane, k * (H * 2 * 16), 0));
             };
             ps_f32x4 cb[2][CH];
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             __syncthreads();
             IC3_TR(6);
             // ---- S6: accC (= enc) += comm . C.weight^T -----------------------------------------------------------------
-            auto cprod = [&](auto two_c) {
+            auto cprod = [&](auto two_c) __attribute__((always_inline)) {
                 constexpr bool TWO = decltype(two_c)::value;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
@@ -668,7 +690,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                             accC[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cb[ch & 1][k][j], accC[0], 0, 0, 0);
                             if constexpr (TWO) accC[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], cb[ch & 1][k][j], accC[1], 0, 0, 0);
                         }
-                        if (g.obs_here && kb < a.zc) zero_store();
+                        if (g.obs_here && last && kb < a.zc) zero_store();
                     }
                 }
             };
@@ -698,7 +720,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const __amdgpu_buffer_rsrc_t rg3 = make_rsrc(a.l_wp3, (uint32_t)((size_t)3 * K * 4 * H * 2));
             const int g3lane = (w * 64 + lane) * 16;
             constexpr int GSTRIDE = NW * 64 * 16;
-            auto wq3 = [&](int pl, int kb, int gt) {
+            auto wq3 = [&](int pl, int kb, int gt) __attribute__((always_inline)) {
                 return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, IC3_PS_WLOAD_AUX);
             };
             ps_u32x4 bq[3][4];
@@ -716,9 +738,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             IC3_TR(8);
             IC3_TRC(0);
             IC3_PRIO_AT(0);
-            const __amdgpu_buffer_rsrc_t rc_old = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
+            // (MP, later passes: the cell state the previous pass's epilogue stored to c_out — read past the vector L1, which
+            //  may still hold the lines as the first pass loaded them)
+            const __amdgpu_buffer_rsrc_t rc_old = make_rsrc((first ? a.c : a.c_out) + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
             const int voff_old = (4 * lh * H + col) * 4;
-            auto block3 = [&](auto two_c, auto s_c, auto refill_c, auto loadc_c, int kb) {
+            auto block3 = [&](auto two_c, auto s_c, auto refill_c, auto loadc_c, int kb) __attribute__((always_inline)) {
                 constexpr bool TWO = decltype(two_c)::value;
                 constexpr int S = decltype(s_c)::value;
                 constexpr bool REFILL = decltype(refill_c)::value;
@@ -747,14 +771,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
                         for (int q = 0; q < 4; ++q) ap[rt][0][q] = ps_hi_pair(xr[rt][q]);
                 }
-                auto products = [&](int pa, int pb, int gt) {
+                auto products = [&](int pa, int pb, int gt) __attribute__((always_inline)) {
                     acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(ps_bf16x8, ap[0][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[0][gt], 0, 0, 0);
                     if constexpr (TWO)
                         acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(ps_bf16x8, ap[1][pa]), __builtin_bit_cast(ps_bf16x8, bq[pb][gt]), acc[1][gt], 0, 0, 0);
                 };
-                auto slot = [&](int i) {                              // (folded after unrolling)
+                auto slot = [&](int i) __attribute__((always_inline)) {                              // (folded after unrolling)
                     if (ps_zslot36(S, i)) {
                         __builtin_amdgcn_sched_barrier(0);
                         zero_store();
@@ -816,15 +840,18 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                             const int idx = 11 * pb + q;
                             if (idx < 32) {
                                 const int rt = idx >> 4, reg = idx & 15;
-                                if (TWO || rt == 0)
-                                    cold[rt][reg] = buf_load_b32(rc_old, voff_old, (32 * rt + (reg & 3) + 8 * (reg >> 2)) * H * 4);
+                                const int so = (32 * rt + (reg & 3) + 8 * (reg >> 2)) * H * 4;
+                                if (TWO || rt == 0) {
+                                    if (first) cold[rt][reg] = buf_load_b32(rc_old, voff_old, so);
+                                    else cold[rt][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc_old, voff_old, so, 17));
+                                }
                             }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            auto gate_loop3 = [&](auto two_c, auto s_c) {
+            auto gate_loop3 = [&](auto two_c, auto s_c) __attribute__((always_inline)) {
                 // (the first block's planes are requested inside the store-slot variant, behind an opaque zero: in front of
                 //  the switch the compiler copies / spills the 12 fragments into every variant's own registers)
                 int zo = 0;
@@ -840,8 +867,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto gate_loop3_s = [&](auto two_c) {
-                switch (g.obs_here ? a.zs : 0) {   // workgroup-uniform; a 16-k block carries twice the slots of an 8-k block
+            auto gate_loop3_s = [&](auto two_c) __attribute__((always_inline)) {
+                switch ((g.obs_here && last) ? a.zs : 0) {   // workgroup-uniform; a 16-k block carries twice the slots of an 8-k block
                 case 1: gate_loop3(two_c, std::integral_constant<int, 2>{}); break;
                 case 2: gate_loop3(two_c, std::integral_constant<int, 4>{}); break;
                 case 3: gate_loop3(two_c, std::integral_constant<int, 6>{}); break;
@@ -970,11 +997,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         reload_args(a);
         int tid = threadIdx.x;
         IC3_OPAQUE_VGPR(tid);
+        const bool first = !MP || pass == 0, last = !MP || pass + 1 == a.npass;
         const TileGeom g = tile_geom<KIND>(a, blockIdx.x);
         const int lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
         const int col = 32 * w + li;
         const int e0 = g.e0, nenv = g.nenv, rows = g.rows;
-        const bool two = g.two, obs_here = g.obs_here;
+        const bool two = g.two, obs_here = g.obs_here && last;
         const size_t r0 = g.r0;
         const int N = a.N;
         const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
@@ -992,14 +1020,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             // c / h rows of the tile through buffer descriptors: one 32-bit lane offset + a constant per element instead
             // of a 64-bit address pair each, and the hardware range check (num_records = the tile's valid rows) stands
             // in for the `row < rows` predicates — an out-of-range store is dropped.
+            // (MP, an inner pass: h' stays in the A tile, its stores are dropped by an empty range; c' goes to c_out — the next
+            //  pass reads it back in its last gate block — instead of occupying 32 registers across that pass)
             const uint32_t nrec = (ABL & 16) ? 0u : (uint32_t)rows * H * 4u;
             const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c_out + r0 * H), 0, nrec, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h_out + r0 * H), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h_out + r0 * H), 0, last ? nrec : 0u, 0x00020000);
             const int voff = (4 * lh * H + col) * 4;
             const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
             // (cold[]: requested in front of the C product; every load this wave issued after them has been waited for
             // in the gate loop and loads return in order, so they have landed)
-            if (autor && !a.keep_state) {
+            if (autor && !a.keep_state && first) {
                 const unsigned long long fmask = (unsigned long long)__builtin_amdgcn_readfirstlane(sfm[0]) |
                                                  ((unsigned long long)__builtin_amdgcn_readfirstlane(sfm[1]) << 32);
 #pragma unroll
@@ -1018,7 +1048,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             // The element loop, one copy per number of zero-store slots per element (workgroup-uniform): with the slot count
             // a compile-time constant the 16 elements of a row tile are ONE basic block, and the scheduler overlaps the
             // transcendental chains (exp -> rcp -> exp -> rcp) of neighbouring elements instead of running them end to end.
-            auto cell = [&](auto ze_c) {
+            auto cell = [&](auto ze_c) __attribute__((always_inline)) {
                 constexpr int ZE = decltype(ze_c)::value;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
@@ -1072,6 +1102,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         __syncthreads();
         IC3_TR(12);
         IC3_PRIO_AT(4);
+        if (MP && !last) continue;          // (uniform) the next communication pass of the step
         if ((ABL & 8) || a.inner) return;   // (uniform)
 
         // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of
@@ -1244,6 +1275,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         IC3_TR(17);
     }
+    break;
+    }   // pass
 }
 
 #include "policy_step_ws.hpp"
@@ -1442,7 +1475,7 @@ static double tiles_cost(const TileCosts& tc, int k_full, int k_half)
     return c + (k_half / 2) * tc.half_pair + (k_half & 1) * tc.lone_half;
 }
 
-template <int H, int KIND, int SPLIT = 0>
+template <int H, int KIND, int SPLIT = 0, int MP = 0>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0 = nullptr,
                        hipEvent_t ev1 = nullptr);
 // words of the small LDS arrays behind the A tile: sm, sscale, sact, rmask [64 each], sfm [4], sep, sts [64 each], shb [16], slb [4H]
@@ -1488,6 +1521,17 @@ static int fill_policy(StepArgs& a, const ic3_policy* p, const char* who)
     a.inner = p->inner_pass != 0;
     a.keep_state = p->pass_index > 0;
     a.l_wp3 = (p->gate_split && p->lstm_wp3) ? p->lstm_wp3 : nullptr;
+    a.npass = 1;
+    if (p->npasses >= 2) {                       // every communication pass inside one launch (ic3_policy_step only)
+        if (p->npasses > 4 || p->pass_index || p->inner_pass)
+            return fail(-38, std::string(who) + ": npasses takes 2..4 passes in one launch, with pass_index = inner_pass = 0");
+        a.npass = p->npasses;
+        for (int i = 0; i < p->npasses; ++i) {
+            if (!p->c_wp_pass[i] || !p->enc_bias_pass[i]) return fail(-22, std::string(who) + ": npasses without the passes' c_wp_pass / enc_bias_pass");
+            a.c_wp_p[i] = reinterpret_cast<const ps_f32x4*>(p->c_wp_pass[i]);
+            a.enc_bias_p[i] = reinterpret_cast<const ps_f32x4*>(p->enc_bias_pass[i]);
+        }
+    }
     return 0;
 }
 
@@ -1597,17 +1641,17 @@ static int plan_tiles(StepArgs& a, int H, const ic3_policy* p, hipStream_t s)
     return a.ntiles;
 }
 
-template <int H, int KIND, int SPLIT>
+template <int H, int KIND, int SPLIT, int MP>
 static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND, SPLIT>), lds));   // per (kernel, device)
+    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_kernel<H, KIND, SPLIT, MP>), lds));   // per (kernel, device)
     // one workgroup per tile, dispatched in tile order (full tiles first, see plan_tiles): the hardware dispatcher
     // balances them over the CUs (a fixed resident set walking a strided tile list was measured slower)
     const int grid = tiles;
     if (ev0 || ev1) {   // timed launch: the dispatch itself stamps the events (no separate record packets around it)
-        hipExtLaunchKernelGGL((policy_step_kernel<H, KIND, SPLIT>), dim3(grid), dim3(2 * H), lds, s, ev0, ev1, 0, a);
+        hipExtLaunchKernelGGL((policy_step_kernel<H, KIND, SPLIT, MP>), dim3(grid), dim3(2 * H), lds, s, ev0, ev1, 0, a);
     } else {
-        hipLaunchKernelGGL((policy_step_kernel<H, KIND, SPLIT>), dim3(grid), dim3(2 * H), lds, s, a);
+        hipLaunchKernelGGL((policy_step_kernel<H, KIND, SPLIT, MP>), dim3(grid), dim3(2 * H), lds, s, a);
     }
     IC3_HIP(hipGetLastError());
     return 0;
@@ -1731,6 +1775,7 @@ extern "C" int ic3_policy_forward(const ic3_policy* p, const float* enc, int E, 
     StepArgs a{};
     int rc = fill_policy(a, p, "ic3_policy_forward");
     if (rc) return rc;
+    if (a.npass > 1) return fail(-38, "ic3_policy_forward: npasses >= 2 is ic3_policy_step's (one call per pass here)");
     a.enc_in = enc;
     a.h = a.h_out = h;
     a.c = a.c_out = c;
@@ -1908,6 +1953,13 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         ev0 = (hipEvent_t)env->ev_start;
         ev1 = (hipEvent_t)env->ev_stop;
         env->ev_start = env->ev_stop = nullptr;
+    }
+    if (a.npass > 1) {   // comm_passes > 1 as a loop inside the launch (MP instantiations: split gate product, hid 64 / 128)
+        if (!a.l_wp3 || (H != 128 && H != 64))
+            return fail(-38, "ic3_policy_step: npasses >= 2 needs gate_split and hid_size 64 / 128 (use one call per pass)");
+        if (H == 128)
+            return pp ? launch_step<128, IC3_ENV_PP, 1, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ, 1, 1>(a, tiles, lds, s, ev0, ev1);
+        return pp ? launch_step<64, IC3_ENV_PP, 1, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<64, IC3_ENV_TJ, 1, 1>(a, tiles, lds, s, ev0, ev1);
     }
     // IC3_PS_WS=1: the wave-specialised schedule (policy_step_ws.hpp) where it applies — same results (A / B switch)
     static const int ws_on = getenv("IC3_PS_WS") ? atoi(getenv("IC3_PS_WS")) : 0;

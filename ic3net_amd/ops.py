@@ -280,12 +280,25 @@ def policy_pack_split(w_ih, w_hh):
     return wp3
 
 
-def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True, pass_index=0, inner=False):
+def policy_step_passes_supported(fc, H, passes):
+    """comm_passes > 1 as a loop INSIDE one ic3_policy_step launch (ic3_policy.npasses): the split gate product, hid 64 / 128,
+    at most 4 passes; otherwise one launch per pass."""
+    return 2 <= passes <= 4 and H in (64, 128) and fc.get('ps_l_wp3') is not None
+
+
+def _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, encoder=True, pass_index=0, inner=False, passes=1):
     """pass_index / inner: comm_passes > 1 — pass i uses C_modules[i] (cache keys '<name>_p<i>' for i > 0), every pass but
-    the last is an `inner` one (h, c only)."""
+    the last is an `inner` one (h, c only).  passes >= 2: all of them in one launch (npasses)."""
     sfx = '' if pass_index == 0 else '_p%d' % pass_index
     pol = _lib.Policy()
     pol.pass_index, pol.inner_pass = int(pass_index), int(bool(inner))
+    if passes >= 2:
+        assert pass_index == 0 and not inner and encoder
+        pol.npasses = int(passes)
+        for i in range(passes):
+            sf = '' if i == 0 else '_p%d' % i
+            pol.c_wp_pass[i] = fc['ps_c_wp' + sf].data_ptr()
+            pol.enc_bias_pass[i] = fc['enc_bias' + sf].data_ptr()
     pol.H, pol.nheads = int(H), len(head_sizes)
     for i, a in enumerate(head_sizes):
         pol.head_sizes[i] = int(a)
@@ -330,7 +343,7 @@ def policy_step_pass(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in
 
 
 def policy_step(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, comm_in, out, action, reward, done,
-                alive=None, is_completed=None, obs=None, pass_index=0):
+                alive=None, is_completed=None, obs=None, pass_index=0, passes=1):
     """One whole rollout iteration (policy forward -> action draws -> env.step) in one launch — ic3_policy_step.
     `fc`: the policy's derived-weight cache (wt, enc_bias, loc_table, ps_c_wp, ps_l_wp, b_cat, w_heads, b_heads);
     h, c (E*N, H) contiguous, updated in place; out (E*N, OT); action (heads, E, N) int32."""
@@ -341,7 +354,7 @@ def policy_step(env, fc, H, head_sizes, mode_avg, comm_zero, h, c, alive_in, com
     assert action.numel() == len(head_sizes) * R and out.shape == (R, sum(head_sizes) + 1)
     for m in (alive_in, comm_in):
         assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
-    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, pass_index=pass_index)
+    pol = _policy_struct(fc, H, head_sizes, mode_avg, comm_zero, pass_index=pass_index, passes=passes)
     import ctypes as C
     check(_lib.lib().ic3_policy_step(env._h, C.byref(pol), ptr(h), ptr(c), ptr(alive_in), ptr(comm_in), ptr(out),
                                      ptr(action), ptr(obs), ptr(reward), ptr(done), ptr(alive), ptr(is_completed), stream()))

@@ -427,8 +427,14 @@ typedef struct {
      * DESIGN.md section 0; what ic3net_amd passes by default).  0: the fp32 matrix instruction.  Honoured by ic3_policy_step
      * and ic3_policy_forward. */
     int32_t gate_split;
-    int32_t reserved_;
+    /* npasses >= 2 (round 5): EVERY communication pass of the step inside ONE ic3_policy_step launch — pass i uses
+     * c_wp_pass[i] / enc_bias_pass[i] (those of C_modules[i], as above); h stays in LDS between the passes (only the last
+     * pass's h' goes to memory), c passes through c_out.  pass_index and inner_pass must be 0; needs gate_split and
+     * hid_size 64 / 128, at most 4 passes (-ENOSYS otherwise: one call per pass as above).  0 or 1: one pass per call. */
+    int32_t npasses;
     const void* lstm_wp3;
+    const float* c_wp_pass[4];
+    const float* enc_bias_pass[4];
 } ic3_policy;
 
 /* The NON-recurrent CommNet module after the encoder (comm.py:127-129,179-205,220-224,228-239), every communication pass

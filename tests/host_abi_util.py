@@ -220,7 +220,7 @@ class HostPolicy(object):
     from a state_dict-shaped dict of float64 arrays (the same dict oracle.policy_ref.forward takes)."""
 
     def __init__(self, env, params, H, head_sizes, mode_avg=True, comm_zero=False, gate_split=False, use_table=True,
-                 pass_index=0, inner=False):
+                 pass_index=0, inner=False, passes=1):
         from ic3net_amd import _lib as binding
         lib = host_lib()
         # (IC3_HOST_FORCE_SPLIT=1: every policy of the process takes the split gate product — the wave-specialised kernel,
@@ -253,6 +253,17 @@ class HostPolicy(object):
             self.l_wp3 = np.zeros((3 * 2 * H * 4 * H,), np.uint16)
             check(lib.ic3_policy_pack_split(p(self.w_ih), p(self.w_hh), p(self.l_wp3), H, None))
             pol.gate_split, pol.lstm_wp3 = 1, self.l_wp3.ctypes.data
+        if passes >= 2:                                         # ic3_policy.npasses: every communication pass in ONE launch
+            pol.npasses = passes
+            self._pass_bufs = []
+            for i in range(passes):
+                eb = f32(params['encoder.bias'] + params['C_modules.%d.bias' % i])
+                cw = f32(params['C_modules.%d.weight' % i])      # (kept: p() of a temporary would dangle)
+                cwp = np.full((H * H,), np.nan, np.float32)
+                scratch = np.full((4 * H * 2 * H,), np.nan, np.float32)
+                check(lib.ic3_policy_pack(p(cw), p(self.w_ih), p(self.w_hh), p(cwp), p(scratch), H, None))
+                self._pass_bufs.append((eb, cwp, cw))
+                pol.enc_bias_pass[i], pol.c_wp_pass[i] = eb.ctypes.data, cwp.ctypes.data
         self.struct = pol
 
     def inner_pass(self, env, h, c, alive_in, comm_in):

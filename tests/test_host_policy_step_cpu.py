@@ -135,6 +135,47 @@ def test_variants_without_location_table_and_with_sum_mode():
     assert free_run("tj_medium", use_table=False, mode_avg=False, T=5, E=4) < TOL
 
 
+@pytest.mark.parametrize("name,passes,auto", [("pp_easy", 2, 0), ("pp_hard", 3, 0), ("tj_medium", 2, 0), ("pp_easy", 2, 4)])
+def test_communication_passes_inside_one_launch(name, passes, auto):
+    """ic3_policy.npasses (round 5): comm_passes > 1 as a loop INSIDE ic3_policy_step — h stays in the A tile, c in registers
+    between the passes — gives exactly what one launch per pass gives (the same split products in the same order), on plain
+    and on auto-reset handles (an env restarted in the launch starts from zeros in the FIRST pass only)."""
+    w = WORKLOADS[name]
+    E, N, H, heads, T = w['E'], w['N'], w['H'], w['heads'], 3
+    res = []
+    for one_launch in (False, True):
+        env = make_env(w, E, 8, 40)
+        P = make_params(env.obs_dim, H, heads, seed=2, comm_passes=passes)
+        if auto:
+            check(env.lib.ic3_env_set_auto_reset(env._h, auto))
+        env.reset(0) if w['env'] == 'tj' else env.reset()
+        if one_launch:
+            pol = HostPolicy(env, P, H, heads, gate_split=True, passes=passes)
+        else:
+            pols = [HostPolicy(env, P, H, heads, gate_split=True, pass_index=i, inner=(i + 1 < passes)) for i in range(passes)]
+        h = np.zeros((E * N, H), np.float32)
+        c = np.zeros((E * N, H), np.float32)
+        gate = np.zeros((E, N), np.int32) if w['hard_attn'] else None
+        alive_in = None
+        rec = []
+        for t in range(T):
+            if one_launch:
+                out, act, obs, rew, done, alive, comp = pol.step(env, h, c, alive_in, gate)
+            else:
+                for q in pols[:-1]:
+                    q.inner_pass(env, h, c, alive_in, gate)
+                out, act, obs, rew, done, alive, comp = pols[-1].step(env, h, c, alive_in, gate)
+            rec.append([x.copy() for x in (out, act, obs, rew, done, h, c)])
+            alive_in = alive if w['env'] == 'tj' else None
+            if w['hard_attn']:
+                gate = np.ascontiguousarray(act[len(heads) - 1])
+        env.close()
+        res.append(rec)
+    for t, (a, b) in enumerate(zip(*res)):
+        for k, (x, y) in enumerate(zip(a, b)):
+            np.testing.assert_array_equal(x, y, err_msg="step %d field %d" % (t, k))
+
+
 def test_two_communication_passes_one_launch_per_pass():
     """comm_passes = 2 on the recurrent policy (comm.py:179-218): pass 0 is an inner pass (ic3_policy.inner_pass: sparse
     encoder, communication block, C_modules[0], LSTMCell — h, c only), pass 1 the ordinary call with C_modules[1]."""
