@@ -245,6 +245,9 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     # gate recompute + cell backward in one launch when the packed gate weights of the rollout kernel exist (hid 64/128/256);
     # its bias partials accumulate over the episode's steps and are reduced once, behind the loop
     fused_gates = fc.get('ps_l_wp') is not None and ops.lstm_gates_backward_supported(H) and R * 4 * H * 4 < 2 ** 32
+    # the input gradient of the gate product inside the same launch (ic3_lstm_gates_backward_dx: split mode, hid 64 / 128)
+    fused_dx = fused_gates and fc.get('ps_l_wp3') is not None and fc.get('ps_l_wp3_bwd') is not None and \
+        bool(getattr(args, 'fused_input_grad', True))
     if fused_gates:
         bias_parts = torch.zeros(((R + 63) // 64, 4 * H), dtype=torch.float32, device=dev)
     else:
@@ -306,7 +309,8 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
             # (the heads' own weight gradient is one pass over the whole episode behind the loop: ic3_heads_grad)
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
-                                    h_prev=h_prev, lstm_wp3=fc.get('ps_l_wp3'))
+                                    h_prev=h_prev, lstm_wp3=fc.get('ps_l_wp3'), lstm_wp3_bwd=fc.get('ps_l_wp3_bwd') if fused_dx else None,
+                                    dxh=dxh if fused_dx else None)
         else:
             if stream is None:
                 acc['w_heads'].addmm_(d.t(), h_t)
@@ -319,7 +323,8 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
             wpart.baddbmm_(xh.view(NB, R // NB, 2 * H).transpose(1, 2), dgates.view(NB, R // NB, 4 * H))
         else:
             acc['w_cat_t'].addmm_(xh.t(), dgates)                         # (2H, R) x (R, 4H)
-        torch.mm(dgates, w_cat_t.t(), out=dxh)                            # (R, 4H) x (4H, 2H) -> [d inp | d h_{t-1}]
+        if not fused_dx:
+            torch.mm(dgates, w_cat_t.t(), out=dxh)                        # (R, 4H) x (4H, 2H) -> [d inp | d h_{t-1}]
         # ---- inp = encoder(obs) + C(comm) (+ both biases)
         if not mask_zero:
             if NBC > 1:

@@ -445,6 +445,8 @@ class CommNetMLP(nn.Module):
                                                     self.f_module.weight_hh))
                     if split:   # the gate product as exact bf16 split products (ruling of round 3's verdict)
                         new['ps_l_wp3'] = ops.policy_pack_split(self.f_module.weight_ih, self.f_module.weight_hh)
+                        if self.hid_size in (64, 128):             # the update half's fused input gradient (bptt)
+                            new['ps_l_wp3_bwd'] = ops.policy_pack_split_bwd(self.f_module.weight_ih, self.f_module.weight_hh)
                     for i in range(1, self.comm_passes):         # comm_passes > 1: what pass i swaps in (C_modules[i])
                         ci = self.C_modules[i]
                         new['enc_bias_p%d' % i] = (self.encoder.bias + ci.bias).contiguous()

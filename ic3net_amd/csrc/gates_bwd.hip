@@ -39,6 +39,10 @@ struct GatesBwdArgs {
     float* dc_prev;        // [R][H] (may be `dc`)
     float* dbias;          // [tiles][4H] column sums of dgates per workgroup, or null
     int ldx, R, accumulate;
+    // ic3_lstm_gates_backward_dx (round 5, SPLIT only): the input gradient dgates . [W_ih | W_hh] of the same tile in the same
+    // launch — wb3 = ic3_policy_pack_split_bwd's planes, dxh [R][2H] = [d inp | d h_prev]; null: dgates only
+    const void* wb3;
+    float* dxh;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gb_rsrc(const void* base, long long bytes)
@@ -249,6 +253,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 
     // ---- the cell's derivative (torch.nn.LSTMCell): c' = f c + i g, h' = o tanh(c') -----------------------------------------
     const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
+    const bool dx = SPLIT != 0 && a.dxh != nullptr;                  // (uniform) the input gradient in this launch too
+    float keep_g[2][16], keep_o[2][16];
+    if (dx) __syncthreads();                                         // every wave is done reading the A tile: it takes d i, d f now
     const long long nrec = (long long)rows * H * 4;
     const __amdgpu_buffer_rsrc_t rdh = gb_rsrc(a.dh + r0 * H, nrec);
     const __amdgpu_buffer_rsrc_t rdc = gb_rsrc(a.dc ? a.dc + r0 * H : a.dh, a.dc ? nrec : 0);   // null: every load reads 0
@@ -281,10 +288,93 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             gb_store1(dg, rdg, goff, lc * 4 * H * 4 + 2 * H * 4);
             gb_store1(dO, rdg, goff, lc * 4 * H * 4 + 3 * H * 4);
             gb_store1(dct * f, rdp, voff, lc * H * 4);
+            if constexpr (SPLIT != 0) {
+                if (dx) {                                            // K-half 0 of dgates (gates i, f) -> the A tile; g, o wait in registers
+                    const int lr = lc + 4 * lh;
+                    As[lr * LDA + col] = di;
+                    As[lr * LDA + H + col] = df;
+                    keep_g[rt][reg] = dg;
+                    keep_o[rt][reg] = dO;
+                }
+            }
             si += di;
             sf += df;
             sg += dg;
             so += dO;
+        }
+    }
+    if constexpr (SPLIT != 0) {
+        if (dx) {
+            // ---- [d inp | d h_prev] = dgates . [W_ih | W_hh]  (64 x 4H . 4H x 2H): the tile's dgates are the A operand from LDS
+            // (fp32, split per wave like the gate loop's), in two K halves through the A tile's 2H columns; the weights: three
+            // bf16 planes in fragment order (ic3_policy_pack_split_bwd), wave w owns output columns [64 w, 64 w + 64).  Nine
+            // exact products per fp32 product, fp32 accumulation — the arithmetic of the gate product.
+            constexpr int KB16B = 4 * H / 16, NCT = 2 * H / 32, KBH = K / 16;
+            const __amdgpu_buffer_rsrc_t rwb = gb_rsrc(a.wb3, (long long)3 * 4 * H * 2 * H * 2);
+            auto wb = [&](int pl, int kg, int ct) __attribute__((always_inline)) {
+                return __builtin_amdgcn_raw_buffer_load_b128(rwb, lane * 16, ((pl * KB16B + kg) * NCT + 2 * w + ct) * 1024, 0);
+            };
+            gb_u32x4 bq2[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bq2[pl][ct] = wb(pl, 0, ct);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.0f;
+            auto blockdx = [&](int kb, int kg) __attribute__((always_inline)) {
+                gb_u32x4 ap[2][3];
+                const gb_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
+                const gb_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
+                gb_split_frag(s0[0], s0[1], ap[0]);
+                gb_split_frag(s1[0], s1[1], ap[1]);
+#pragma unroll
+                for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                        for (int pa = 2; pa >= 0; --pa) {
+                            gb_mfma_bf16(acc[0][ct], ap[0][pa], bq2[pb][ct]);
+                            gb_mfma_bf16(acc[1][ct], ap[1][pa], bq2[pb][ct]);
+                        }
+                        if (kg + 1 < KB16B) bq2[pb][ct] = wb(pb, kg + 1, ct);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            };
+            __syncthreads();                                     // d i, d f of every wave are in the A tile
+#pragma unroll 1
+            for (int kb = 0; kb < KBH; ++kb) blockdx(kb, kb);
+#if IC3_GB_AGPR
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+            __syncthreads();                                     // every wave is done with K-half 0
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    As[lr * LDA + col] = keep_g[rt][reg];
+                    As[lr * LDA + H + col] = keep_o[rt][reg];
+                }
+            __syncthreads();
+#pragma unroll 1
+            for (int kb = 0; kb < KBH; ++kb) blockdx(kb, KBH + kb);
+#if IC3_GB_AGPR
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+            const __amdgpu_buffer_rsrc_t rdx = gb_rsrc(a.dxh + r0 * K, (long long)rows * K * 4);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                        gb_store1(acc[rt][ct][reg], rdx, (lr * K + 64 * w + 32 * ct + li) * 4, 0);
+                    }
         }
     }
     if (a.dbias) {                                               // column sums over the tile's 64 rows: the two lane halves
@@ -313,9 +403,33 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 
 extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
+static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
+                               const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
+                               float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream);
+
 extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias, const float* c_prev,
                                        const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
                                        int accumulate, int R, int H, ic3_stream stream)
+{
+    return gates_backward_impl(xh, ldx, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, accumulate,
+                               nullptr, nullptr, R, H, stream);
+}
+
+extern "C" int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3,
+                                          const void* lstm_wp3_bwd, const float* bias, const float* c_prev, const float* dh,
+                                          const float* dc, float* dgates, float* dc_prev, float* dbias_partials, int accumulate,
+                                          float* dxh, int R, int H, ic3_stream stream)
+{
+    if (!lstm_wp3 || !lstm_wp3_bwd || !dxh)
+        return ic3::fail(-22, "ic3_lstm_gates_backward_dx: needs the split planes of both products (lstm_wp3, lstm_wp3_bwd) and dxh");
+    if (H != 64 && H != 128) return ic3::fail(-38, "ic3_lstm_gates_backward_dx: hid_size 64 / 128");
+    return gates_backward_impl(xh, ldx, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, accumulate,
+                               lstm_wp3_bwd, dxh, R, H, stream);
+}
+
+static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
+                               const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
+                               float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream)
 {
     using namespace ic3;
     if (!xh || !lstm_wp || !bias || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
@@ -324,7 +438,7 @@ extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, 
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
     if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
         return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
-    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate };
+    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh };
     const int tiles = (R + 63) / 64;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;

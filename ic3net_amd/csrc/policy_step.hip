@@ -1432,6 +1432,33 @@ __global__ void policy_pack_split_kernel(const float* __restrict__ w_ih, const f
     }
 }
 
+// The same planes for the BACKWARD of the gate product (ic3_lstm_gates_backward_dx: [d inp | d h] = dgates . [W_ih | W_hh]):
+// Wb[plane][kb16][ct][lane] = 8 x bf16 { W_plane[16 kb16 + 8 lh + i][32 ct + li] }, W = [w_ih | w_hh] (4H x 2H) — k runs over
+// the 4H gate rows, the output column over the 2H inputs
+__global__ void policy_pack_split_bwd_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                             ps_u32x4* __restrict__ Wp, int H)
+{
+    const int NCT = 2 * H / 32, KB16B = 4 * H / 16;
+    const long long per = (long long)KB16B * NCT * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long long rest = i >> 6;
+        const int ct = (int)(rest % NCT), kb = (int)(rest / NCT);
+        const int li = lane & 31, lh = lane >> 5;
+        const int n = 32 * ct + li;
+        unsigned p[3][8];
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * kb + 8 * lh + q;
+            ps_split3(n < H ? w_ih[(size_t)k * H + n] : w_hh[(size_t)k * H + (n - H)], p[0][q], p[1][q], p[2][q]);
+        }
+        for (int pl = 0; pl < 3; ++pl) {
+            ps_u32x4 v;
+            for (int d = 0; d < 4; ++d) v[d] = p[pl][2 * d] | (p[pl][2 * d + 1] << 16);
+            Wp[(size_t)pl * per + i] = v;
+        }
+    }
+}
+
 static int device_cus()
 {
     static int cus[64] = { 0 };   // per device (a process may drive several GPUs)
@@ -1731,6 +1758,16 @@ extern "C" int ic3_policy_pack_split(const float* w_ih, const float* w_hh, void*
         return fail(-22, "ic3_policy_pack_split: H must be a positive multiple of 32");
     hipLaunchKernelGGL(policy_pack_split_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh,
                        reinterpret_cast<ps_u32x4*>(lstm_wp3), H);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ic3_policy_pack_split_bwd(const float* w_ih, const float* w_hh, void* lstm_wp3_bwd, int H, ic3_stream stream)
+{
+    if (!w_ih || !w_hh || !lstm_wp3_bwd || H <= 0 || (H % 32))
+        return fail(-22, "ic3_policy_pack_split_bwd: H must be a positive multiple of 32");
+    hipLaunchKernelGGL(policy_pack_split_bwd_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh,
+                       reinterpret_cast<ps_u32x4*>(lstm_wp3_bwd), H);
     IC3_HIP(hipGetLastError());
     return 0;
 }

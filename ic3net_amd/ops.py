@@ -180,7 +180,7 @@ def lstm_gates_backward_supported(H):
 
 
 def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None, accumulate=False,
-                        h_prev=None, lstm_wp3=None):
+                        h_prev=None, lstm_wp3=None, lstm_wp3_bwd=None, dxh=None):
     """Gate recompute + LSTM cell backward in one launch (ic3_lstm_gates_backward): xh (R,2H) = [inp | h_prev] rows (unit
     column stride; with h_prev (R,H) given the launch fills the h half of xh from it), lstm_wp = policy_step_pack's 'ps_l_wp', bias (4H,) = b_ih + b_hh; c_prev, dh, dc (or None) (R,H) ->
     dgates (R,4H), dc_prev (R,H; may alias dc).  dbias_partials: (ceil(R/64), 4H), written (or added to: `accumulate`)."""
@@ -194,6 +194,16 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
         assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == (tiles, 4 * H)
     if h_prev is not None:
         assert h_prev.is_contiguous() and h_prev.dtype == torch.float32 and tuple(h_prev.shape) == (R, H)
+    if dxh is not None:       # + the input gradient [d inp | d h_prev] = dgates . [W_ih | W_hh] in the same launch
+        assert lstm_wp3 is not None and lstm_wp3_bwd is not None and dxh.is_contiguous() and tuple(dxh.shape) == (R, 2 * H)
+        n = _lib.lib().ic3_lstm_gates_backward_dx(ptr(xh), xh.stride(0), ptr(h_prev) if h_prev is not None else None, ptr(lstm_wp),
+                                                  ptr(lstm_wp3), ptr(lstm_wp3_bwd), ptr(bias), ptr(c_prev), ptr(dh),
+                                                  ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
+                                                  ptr(dbias_partials) if dbias_partials is not None else None,
+                                                  int(bool(accumulate)), ptr(dxh), R, H, stream())
+        if n < 0:
+            check(n)
+        return n
     n = _lib.lib().ic3_lstm_gates_backward(ptr(xh), xh.stride(0), ptr(h_prev) if h_prev is not None else None, ptr(lstm_wp),
                                            ptr(lstm_wp3) if lstm_wp3 is not None else None,   # split gate product
                                            ptr(bias), ptr(c_prev), ptr(dh),
@@ -277,6 +287,16 @@ def policy_pack_split(w_ih, w_hh):
     wp3 = torch.empty((3 * 2 * H * 4 * H,), dtype=torch.bfloat16, device=w_ih.device)
     check(_lib.lib().ic3_policy_pack_split(ptr(w_ih.detach().contiguous().float()), ptr(w_hh.detach().contiguous().float()),
                                            ptr(wp3), H, stream()))
+    return wp3
+
+
+def policy_pack_split_bwd(w_ih, w_hh):
+    """The split planes of [W_ih | W_hh] in the fragment order of the gate product's BACKWARD (ic3_lstm_gates_backward_dx)."""
+    _need_cuda(w_ih, "policy_pack_split_bwd")
+    H = w_ih.shape[1]
+    wp3 = torch.empty((3 * 4 * H * 2 * H,), dtype=torch.bfloat16, device=w_ih.device)
+    check(_lib.lib().ic3_policy_pack_split_bwd(ptr(w_ih.detach().contiguous().float()), ptr(w_hh.detach().contiguous().float()),
+                                               ptr(wp3), H, stream()))
     return wp3
 
 

@@ -326,6 +326,17 @@ int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev /* or NULL *
                             const float* c_prev,
                             const float* dh, const float* dc /* or NULL */, float* dgates, float* dc_prev,
                             float* dbias_partials /* or NULL */, int accumulate, int R, int H, ic3_stream stream);
+/* The same launch + the INPUT gradient of the gate product in it (round 5): dxh [R][2H] = [d inp | d h_prev] = dgates .
+ * [W_ih | W_hh] for the tile the workgroup holds anyway — replaces the (R x 4H) x (4H x 2H) product that followed the call and
+ * its re-read of dgates.  Same arithmetic as the split gate product (nine exact bf16 x bf16 products per fp32 product, fp32
+ * accumulation); lstm_wp3_bwd = ic3_policy_pack_split_bwd's planes (3 * 4H * 2H * 2 bytes).  Needs lstm_wp3 (split mode),
+ * hid_size 64 / 128. */
+int ic3_policy_pack_split_bwd(const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */, void* lstm_wp3_bwd, int H,
+                              ic3_stream stream);
+int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_prev /* or NULL */, const float* lstm_wp, const void* lstm_wp3,
+                               const void* lstm_wp3_bwd, const float* bias, const float* c_prev, const float* dh,
+                               const float* dc /* or NULL */, float* dgates, float* dc_prev, float* dbias_partials /* or NULL */,
+                               int accumulate, float* dxh, int R, int H, ic3_stream stream);
 /* The weight / bias gradient of the heads + value head over a whole episode in one pass (trainer.py:128-225 through
  * comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o] over the M = steps x rows pairs
  * (d [M][OT], h [M][H]: h_t of every step, i.e. the recorded hidden states shifted by one step).  scratch:

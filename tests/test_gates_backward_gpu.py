@@ -97,3 +97,34 @@ def test_gates_backward_rejects_other_sizes():
         ops.lstm_gates_backward(z, torch.zeros(8 * 96 * 96, device='cuda'), torch.zeros(384, device='cuda'),
                                 torch.zeros(8, 96, device='cuda'), torch.zeros(8, 96, device='cuda'), None,
                                 torch.zeros(8, 384, device='cuda'), torch.zeros(8, 96, device='cuda'))
+
+
+@pytest.mark.parametrize("H,R", [(128, 640), (128, 64 * 200 + 37), (64, 150)])
+def test_gates_backward_with_the_input_gradient_in_the_same_launch(H, R):
+    """ic3_lstm_gates_backward_dx (round 5): dgates / dc_prev / bias partials exactly as without it (the same launch), and
+    dxh = dgates . [W_ih | W_hh] against the float64 product at the gate product's own bar (exact bf16 split products)."""
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(3 * H + R)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    w_ih, w_hh, c_w = rn(4 * H, H) / H ** 0.5, rn(4 * H, H) / H ** 0.5, rn(H, H)
+    b = rn(4 * H)
+    xh, h_prev = rn(R, 2 * H), rn(R, H)
+    c_prev, dh, dc = rn(R, H), rn(R, H), rn(R, H)
+    wp = ops.policy_step_pack(c_w, w_ih, w_hh)['ps_l_wp']
+    wp3, wb3 = ops.policy_pack_split(w_ih, w_hh), ops.policy_pack_split_bwd(w_ih, w_hh)
+    tiles = (R + 63) // 64
+    out = []
+    for fused in (False, True):
+        x = xh.clone()
+        dgates = torch.full((R, 4 * H), float('nan'), device='cuda')
+        dcp = torch.full((R, H), float('nan'), device='cuda')
+        parts = torch.zeros((tiles, 4 * H), device='cuda')
+        dxh = torch.full((R, 2 * H), float('nan'), device='cuda') if fused else None
+        ops.lstm_gates_backward(x, wp, b, c_prev, dh, dc, dgates, dcp, parts, True, h_prev=h_prev, lstm_wp3=wp3,
+                                lstm_wp3_bwd=wb3 if fused else None, dxh=dxh)
+        out.append((dgates, dcp, parts, x, dxh))
+    for k in range(4):
+        assert torch.equal(out[0][k], out[1][k]), k
+    ref = out[1][0].double() @ torch.cat([w_ih, w_hh], 1).double()
+    err = float((out[1][4].double() - ref).abs().max())
+    assert err <= 4e-6 * max(1.0, float(ref.abs().max())), err      # (K = 4H terms per sum, twice the gate product's)

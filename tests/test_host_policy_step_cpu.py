@@ -543,6 +543,21 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
                                       0, R, H, None))
     np.testing.assert_array_equal(xh2, wide[:, :2 * H])
     np.testing.assert_array_equal(dg3, dgates)
+    if split and H in (64, 128):
+        # ic3_lstm_gates_backward_dx (round 5): the same outputs + [d inp | d h_prev] = dgates . [W_ih | W_hh] in the launch
+        wb3 = np.zeros(3 * 4 * H * 2 * H, np.uint16)
+        check(lib.ic3_policy_pack_split_bwd(p(w_ih), p(w_hh), p(wb3), H, None))
+        dg5 = np.full((R, 4 * H), np.nan, np.float32)
+        dcp5 = np.full((R, H), np.nan, np.float32)
+        dxh = np.full((R, 2 * H), np.nan, np.float32)
+        check(lib.ic3_lstm_gates_backward_dx(p(xh2), 2 * H, p(h_prev), p(l_wp), p(wp3), p(wb3), p(b), p(c_prev), p(dh), None, p(dg5),
+                                             p(dcp5), None, 0, p(dxh), R, H, None))
+        np.testing.assert_array_equal(dg5, dg3)
+        np.testing.assert_array_equal(dcp5, dcp3)
+        want_dx = dg5.astype(np.float64) @ np.concatenate([w_ih, w_hh], 1).astype(np.float64)
+        assert np.abs(dxh - want_dx).max() <= 6e-6 * max(1.0, np.abs(want_dx).max())
+        assert lib.ic3_lstm_gates_backward_dx(p(xh2), 2 * H, p(h_prev), p(l_wp), None, p(wb3), p(b), p(c_prev), p(dh), None, p(dg5),
+                                              p(dcp5), None, 0, p(dxh), R, H, None) == -22
 
 
 def commnet_weights(lib, P, H, heads, passes):

@@ -59,7 +59,7 @@ evidence)
   timeout 300 $B --steps 40 > /dev/null 2>&1
   timeout 600 python bench.py > $O/bench_pp_hard.json 2> $O/bench_pp_hard.err; summ $O/bench_pp_hard.json "pp_hard (default command)"
   timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_pp_hard_driver_args.json 2>/dev/null; summ $O/bench_pp_hard_driver_args.json "pp_hard --steps 20 --warmup 5"
-  for w in tj_hard tj_medium pp_easy tj_medium_commnet_mlp; do timeout 300 $B --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; summ $O/bench_$w.json $w; done
+  for w in tj_hard tj_medium pp_easy tj_medium_commnet_mlp pp_hard_ic pp_hard_iric; do timeout 300 $B --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; summ $O/bench_$w.json $w; done
   timeout 600 $B --workload pp_scaled --steps 40 > $O/bench_pp_scaled.json 2> $O/bench_pp_scaled.err; summ $O/bench_pp_scaled.json pp_scaled
   timeout 300 $B --gate-split 0 > $O/bench_pp_hard_fp32_instruction.json 2>/dev/null; summ $O/bench_pp_hard_fp32_instruction.json "pp_hard --gate-split 0"
   for w in tj_hard tj_medium; do timeout 300 $B --workload $w --gate-split 0 > $O/bench_${w}_fp32_instruction.json 2>/dev/null; summ $O/bench_${w}_fp32_instruction.json "$w --gate-split 0"; done
@@ -70,7 +70,7 @@ evidence)
   cd /tmp
   S="--no-cpu-baseline --steps 40 --warmup 8"
   R=$GRAFT_REPO_ROOT
-  for w in pp_hard tj_hard tj_medium pp_scaled tj_medium_commnet_mlp; do
+  for w in pp_hard tj_hard tj_medium pp_scaled tj_medium_commnet_mlp pp_hard_ic pp_hard_iric; do
     st="$S"; [ $w == pp_scaled ] && st="--no-cpu-baseline --steps 10 --warmup 4"
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_$w -- python $R/bench.py $st --workload $w > /dev/null 2>&1
     f=$(find $R/$O/kt_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/$O/bench_${w}_kernel_stats.csv
@@ -88,6 +88,14 @@ evidence)
     rm -rf $R/$O/sq_$i
   done
   cd $R; cat $O/sq_counters.csv; grep policy_step $O/pmc_*pp_hard.csv ;;
+train)
+  # the update half: tools/bench_train.py lines (lock-step and collection mode) + the kernel table of one PP-hard update
+  for w in pp_hard tj_hard tj_medium tj_medium_commnet_mlp; do timeout 600 python tools/bench_train.py 8192 4 native $w 2>&1 | grep train_batch; done | tee $O/train_batch.txt
+  timeout 600 python tools/bench_train.py 8192 4 native pp_hard 1 2>&1 | grep train_batch | tee -a $O/train_batch.txt
+  timeout 600 python tools/bench_train.py 8192 4 native pp_hard 0 1 1 2>&1 | grep train_batch | tee -a $O/train_batch.txt
+  timeout 600 python tools/bench_train.py 1024 4 native pp_hard 2>&1 | grep train_batch | tee -a $O/train_batch.txt
+  timeout 600 python tools/bench_train.py 8192 2 native pp_hard_iric 2>&1 | grep train_batch | tee -a $O/train_batch.txt
+  timeout 600 python tools/profile_train_native.py 8192 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn" > $O/train_profile.txt; tail -3 $O/train_profile.txt ;;
 sh)
   bash -c "$*" 2>&1 | grep -v amdgpu.ids | tee -a $O/log.txt | tail -40 ;;
 esac
