@@ -141,7 +141,7 @@ def test_communication_passes_inside_one_launch(name, passes, auto):
     between the passes — gives exactly what one launch per pass gives (the same split products in the same order), on plain
     and on auto-reset handles (an env restarted in the launch starts from zeros in the FIRST pass only)."""
     w = WORKLOADS[name]
-    E, N, H, heads, T = w['E'], w['N'], w['H'], w['heads'], 3
+    E, N, H, heads, T = min(w['E'], 4), w['N'], w['H'], w['heads'], 3
     res = []
     for one_launch in (False, True):
         env = make_env(w, E, 8, 40)
@@ -818,12 +818,13 @@ def test_wave_specialised_schedule_on_the_host():
     """csrc/policy_step_ws.hpp (IC3_PS_WS=1: matrix waves + helper waves of one persistent workgroup, handing tiles to each other
     through LDS counters instead of s_barrier) through the stand-in runtime — spinning lanes yield, a hand-off nobody signals
     aborts as a hang — under the three lane schedules: split-product free runs (TJ-hard: several tiles per workgroup, the small
-    tile first; PP-easy at hid 64 under a shuffled lane order) and an auto-reset stream must pass exactly as on the default kernel."""
+    tile first; PP-easy at hid 64 under a shuffled lane order) must pass exactly as on the default kernel (auto-reset streams
+    under this schedule: tests/test_policy_step_plans_gpu.py)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    runs = [("", "(gate_split_experiment and tj_hard) or auto_reset_stream_restarts"),     # several tiles per workgroup; restarts
+    runs = [("", "gate_split_experiment and tj_hard"),                                    # several tiles per workgroup, small tile first
             ("shuffle", "free_run_vs and pp_easy")]                                      # hid 64, another lane order every round
     for sched, sel in runs:
         env = dict(os.environ, IC3_PS_WS="1", IC3_HOST_FORCE_SPLIT="1")
