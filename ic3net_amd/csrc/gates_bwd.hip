@@ -115,6 +115,17 @@ __device__ __forceinline__ void gb_mfma_bf16(gb_f32x16& acc, gb_u32x4 x, gb_u32x
 #endif
 }
 
+// The split's last VALU results feed the asm MFMAs that follow at once: the hazard recogniser does not see through the asm,
+// and on gfx950 a plane written by v_cvt_pk_bf16_f32 a few cycles before the MFMA that reads it arrived stale when nothing
+// else stalled the wave (round 5: warm launches of the dx phase differed from the cold one in rows 32..63's low plane).
+// The operands tie the wait behind every plane's definition and in front of the products.
+__device__ __forceinline__ void gb_settle(gb_u32x4 (&a)[3], gb_u32x4 (&b)[3])
+{
+#if IC3_GB_AGPR
+    asm volatile("s_nop 15" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+#endif
+}
+
 template <int H, int SPLIT = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kernel(const GatesBwdArgs a)
 {
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
                 const gb_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
                 gb_split_frag(s0[0], s0[1], ap[0]);
                 gb_split_frag(s1[0], s1[1], ap[1]);
+                gb_settle(ap[0], ap[1]);
             }
 #pragma unroll
             for (int pb = 0; pb < 3; ++pb)
@@ -311,8 +323,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             // exact products per fp32 product, fp32 accumulation — the arithmetic of the gate product.
             constexpr int KB16B = 4 * H / 16, NCT = 2 * H / 32, KBH = K / 16;
             const __amdgpu_buffer_rsrc_t rwb = gb_rsrc(a.wb3, (long long)3 * 4 * H * 2 * H * 2);
+            const int wu = __builtin_amdgcn_readfirstlane(w);    // (scalar offset: no waterfall loop around each load)
             auto wb = [&](int pl, int kg, int ct) __attribute__((always_inline)) {
-                return __builtin_amdgcn_raw_buffer_load_b128(rwb, lane * 16, ((pl * KB16B + kg) * NCT + 2 * w + ct) * 1024, 0);
+                return __builtin_amdgcn_raw_buffer_load_b128(rwb, lane * 16, ((pl * KB16B + kg) * NCT + 2 * wu + ct) * 1024, 0);
             };
             gb_u32x4 bq2[3][2];
 #pragma unroll
@@ -331,6 +344,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
                 const gb_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
                 gb_split_frag(s0[0], s0[1], ap[0]);
                 gb_split_frag(s1[0], s1[1], ap[1]);
+                gb_settle(ap[0], ap[1]);
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb)
 #pragma unroll

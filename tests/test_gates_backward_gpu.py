@@ -99,7 +99,7 @@ def test_gates_backward_rejects_other_sizes():
                                 torch.zeros(8, 384, device='cuda'), torch.zeros(8, 96, device='cuda'))
 
 
-@pytest.mark.parametrize("H,R", [(128, 640), (128, 64 * 200 + 37), (64, 150)])
+@pytest.mark.parametrize("H,R", [(128, 640), (128, 64 * 200 + 37), (64, 150), (64, 128)])
 def test_gates_backward_with_the_input_gradient_in_the_same_launch(H, R):
     """ic3_lstm_gates_backward_dx (round 5): dgates / dc_prev / bias partials exactly as without it (the same launch), and
     dxh = dgates . [W_ih | W_hh] against the float64 product at the gate product's own bar (exact bf16 split products)."""
@@ -114,7 +114,7 @@ def test_gates_backward_with_the_input_gradient_in_the_same_launch(H, R):
     wp3, wb3 = ops.policy_pack_split(w_ih, w_hh), ops.policy_pack_split_bwd(w_ih, w_hh)
     tiles = (R + 63) // 64
     out = []
-    for fused in (False, True):
+    for fused in (False, True, True):    # (twice: a cold and a warm launch agree bit for bit — see gb_settle in csrc/gates_bwd.hip)
         x = xh.clone()
         dgates = torch.full((R, 4 * H), float('nan'), device='cuda')
         dcp = torch.full((R, H), float('nan'), device='cuda')
@@ -127,4 +127,5 @@ def test_gates_backward_with_the_input_gradient_in_the_same_launch(H, R):
         assert torch.equal(out[0][k], out[1][k]), k
     ref = out[1][0].double() @ torch.cat([w_ih, w_hh], 1).double()
     err = float((out[1][4].double() - ref).abs().max())
-    assert err <= 4e-6 * max(1.0, float(ref.abs().max())), err      # (K = 4H terms per sum, twice the gate product's)
+    assert err <= 2e-6 * max(1.0, float(ref.abs().max())), err
+    assert torch.equal(out[1][4], out[2][4]) and torch.equal(out[1][0], out[2][0])

@@ -488,7 +488,7 @@ def test_commnet_forward_nonrecurrent_module(H, N, E, passes):
         assert err < 2e-5, (e, err)
 
 
-@pytest.mark.parametrize("H,R,split", [(64, 100, False), (128, 70, False), (128, 70, True), (256, 65, True)])
+@pytest.mark.parametrize("H,R,split", [(64, 100, False), (64, 100, True), (128, 70, False), (128, 70, True), (256, 65, True)])
 def test_gates_backward_recompute_and_cell_derivative(H, R, split):
     """ic3_lstm_gates_backward (gates_bwd.hip): gates = [inp | h_prev] . [W_ih | W_hh]^T + bias re-computed on the matrix cores
     and torch.nn.LSTMCell's derivative applied in the epilogue, against the closed form in float64; bias partials per 64 rows,
