@@ -111,6 +111,10 @@ EXPORTS = {
     "ic3_lstm_cell_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
     "ic3_policy_pack_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_policy_pack_split_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ic3_lstm_gates_backward_given": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_void_p]),
+    "ic3_env_set_record_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_lstm_gates_backward_dx": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_commnet_forward_supported": (C.c_int, [C.c_int, C.c_int]),
     "ic3_commnet_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

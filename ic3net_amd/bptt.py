@@ -80,6 +80,12 @@ class EpisodeRecord(object):
         self.gate = [None] * T
         self.h_last = None
         self.n = 0
+        # (T, R, 4H) the activated gates of every step's LSTM cell and (T, R, 2H) the inp half of its [inp | h] rows, stored by
+        # the step launch itself (ic3_env_set_record_out: Trainer._record_gates) — the backward then skips the gate product and
+        # what leads up to it; gates_n = the steps that stored theirs
+        self.gates = None
+        self.xh = None
+        self.gates_n = 0
         self.stream = None     # collection mode (Trainer._run_batch_streams): per-slot cuts of the recurrence, see backward_episode
 
     def start_from(self, h, c):
@@ -248,6 +254,8 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     # the input gradient of the gate product inside the same launch (ic3_lstm_gates_backward_dx: split mode, hid 64 / 128)
     fused_dx = fused_gates and fc.get('ps_l_wp3') is not None and fc.get('ps_l_wp3_bwd') is not None and \
         bool(getattr(args, 'fused_input_grad', True))
+    # the gates of every step as the rollout recorded them: no gate product in the backward at all
+    given = fused_dx and rec.gates is not None and rec.xh is not None and rec.gates_n == T and rec.gates.shape[2] == 4 * H
     if fused_gates:
         bias_parts = torch.zeros(((R + 63) // 64, 4 * H), dtype=torch.float32, device=dev)
     else:
@@ -291,14 +299,19 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
             alive = torch.where(fr, ones_mask, alive) if alive is not None else None
             gate = torch.where(fr, zeros_mask, gate) if gate is not None else None
         # ---- the forward of step t again: enc + C.bias -> inp, comm, gate pre-activations (comm.py:119,181-215)
-        raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp, loc_table=fc['loc_table'])
-        if not fused_gates:
-            xh[:, H:].copy_(h_prev)                                       # (the fused gate launch fills it)
-        if mask_zero:
-            comm.zero_()                                                  # comm.py:40-41: C sees zeros
+        if given:                                                         # inp as the step launch stored it; comm for C's gradient
+            xh = rec.xh[t]
+            if not mask_zero:
+                ops.comm_masked_mean_raw(h_prev.view(E, N, H), alive, gate, mode_avg, True, out=comm)
         else:
-            ops.comm_masked_mean_raw(h_prev.view(E, N, H), alive, gate, mode_avg, True, out=comm)
-            inp.addmm_(comm.view(R, H), fc['c_wt'])
+            raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=inp, loc_table=fc['loc_table'])
+            if not fused_gates:
+                xh[:, H:].copy_(h_prev)                                   # (the fused gate launch fills it)
+            if mask_zero:
+                comm.zero_()                                              # comm.py:40-41: C sees zeros
+            else:
+                ops.comm_masked_mean_raw(h_prev.view(E, N, H), alive, gate, mode_avg, True, out=comm)
+                inp.addmm_(comm.view(R, H), fc['c_wt'])
         if not fused_gates:
             torch.addmm(fc['b_cat'], xh, w_cat_t, out=gates)              # one K = 2H product, as in the rollout
         # ---- heads (comm.py:228,239) -> LSTM cell
@@ -306,7 +319,10 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         # dL/dh_t = what step t + 1 sent back + the heads' share — in place (addmm with another `out` first copies R x H floats);
         # dh_rec is rewritten with dL/dh_{t-1} at the end of the iteration, after the cell backward has consumed it
         dh = dh_rec.addmm_(d, fc['w_heads'])
-        if fused_gates:                                                   # dc_rec <- dL/dc_{t-1}
+        if given:                                                         # dc_rec <- dL/dc_{t-1}
+            ops.lstm_gates_backward_given(rec.gates[t], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True, xh=xh, h_prev=h_prev,
+                                          lstm_wp3_bwd=fc['ps_l_wp3_bwd'], dxh=dxh)
+        elif fused_gates:
             # (the heads' own weight gradient is one pass over the whole episode behind the loop: ic3_heads_grad)
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
                                     h_prev=h_prev, lstm_wp3=fc.get('ps_l_wp3'), lstm_wp3_bwd=fc.get('ps_l_wp3_bwd') if fused_dx else None,

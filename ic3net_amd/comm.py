@@ -630,7 +630,7 @@ class CommNetMLP(nn.Module):
         return (mb['h'], mb['c'])
 
     def step_env(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, hidden_out=None,
-                 out=None):
+                 out=None, record_out=None):
         """action_out, value, (h, c) = forward(x, info); `action` (heads, E, N) int32 <- select_action (Philox draws
         positioned by the env's own counters); env.step(action[0]) -> reward (E,N) f32, done (E,) i32, alive /
         is_completed (E,N) i32.  trainer.py:49-67 in one launch.  `obs` (E,N,obs_dim), when given, receives the dense
@@ -642,7 +642,7 @@ class CommNetMLP(nn.Module):
             hp, cp, wide = self._twin_hidden(tw, x[1][0], x[1][1], x[0].size(0) * n)
             assert hidden_out is None or wide, "an in-place episode record has the twin's width (Trainer._kernel_net)"
             action_out, value, hc = tw.step_env(env, [x[0], (hp, cp)], info, action, reward, done, alive,
-                                                is_completed, obs, hidden_out, out)
+                                                is_completed, obs, hidden_out, out, record_out)
             self._twin_done(tw)
             return action_out, value, self._twin_state_out(hc, wide)
         x, (hidden_state, cell_state) = x
@@ -661,7 +661,13 @@ class CommNetMLP(nn.Module):
             h, c = hidden_state, cell_state
             assert h.is_contiguous() and c.is_contiguous() and tuple(h.shape) == (R, H) and h.dtype == torch.float32
             env.set_hidden_out(hidden_out[0], hidden_out[1])
+            if record_out is not None:     # + the cell's activated gates and the inp rows into the record (the backward
+                g_out, x_out = record_out  #   skips the gate product and what leads up to it)
+                assert g_out.is_contiguous() and tuple(g_out.shape) == (R, 4 * H) and g_out.dtype == torch.float32
+                assert x_out is None or (x_out.is_contiguous() and tuple(x_out.shape) == (R, 2 * H) and x_out.dtype == torch.float32)
+                env.set_record_out(g_out, x_out)
         else:
+            assert record_out is None, "the gate record comes with the in-place episode record (one pass)"
             hidden_out = None
             if hidden_state.data_ptr() != h.data_ptr():        # fresh hidden state from the caller (t = 0)
                 h.copy_(hidden_state.detach().reshape(R, H))

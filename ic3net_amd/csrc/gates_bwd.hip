@@ -43,6 +43,9 @@ struct GatesBwdArgs {
     // launch — wb3 = ic3_policy_pack_split_bwd's planes, dxh [R][2H] = [d inp | d h_prev]; null: dgates only
     const void* wb3;
     float* dxh;
+    // ic3_lstm_gates_backward_given (round 5, GIVEN instantiation): the ACTIVATED gates i | f | g | o [R][4H] as the rollout's
+    // step launch recorded them (ic3_env_set_gates_out) — no gate product here, only the cell's derivative (+ dx)
+    const float* gates;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gb_rsrc(const void* base, long long bytes)
@@ -126,9 +129,10 @@ __device__ __forceinline__ void gb_settle(gb_u32x4 (&a)[3], gb_u32x4 (&b)[3])
 #endif
 }
 
-template <int H, int SPLIT = 0>
+template <int H, int SPLIT = 0, int GIVEN = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kernel(const GatesBwdArgs a)
 {
+    static_assert(!GIVEN || SPLIT == 1, "recorded gates: the split instantiation (its dx product)");
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, KB = K / 8, K4 = K / 4, RING = 8;
     static_assert(KB % 2 == 0 && KB >= 4, "K / 8 must be even");
     IC3_DYNAMIC_LDS(float, smem);
@@ -141,7 +145,21 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     const int rows = (int)((a.R - r0) < 64 ? (a.R - r0) : 64);
 
     // ---- A tile: 64 rows of [inp | h_prev] -> LDS (all loads issued, then the LDS writes) ------------------------------
-    {
+    if constexpr (GIVEN != 0) {
+        // (recorded gates: nothing of the forward runs again — only the caller's copy of h_prev into the h half of xh, the
+        //  weight-gradient product's operand, is made here)
+        if (a.xh && a.h_prev) {
+            const __amdgpu_buffer_rsrc_t rx = gb_rsrc(a.xh + r0 * a.ldx, ((long long)(rows - 1) * a.ldx + K) * 4);
+            const __amdgpu_buffer_rsrc_t rhp = gb_rsrc(a.h_prev + r0 * H, (long long)rows * H * 4);
+            constexpr int H4 = H / 4, PERH = 64 * H4 / NT;           // float4 per thread (8)
+#pragma unroll
+            for (int i = 0; i < PERH; ++i) {
+                const int idx = tid + i * NT, row = idx / H4, c4 = idx - row * H4;
+                const gb_f32x4 v = gb_load4(rhp, (row * H + 4 * c4) * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gb_u32x4, v), rx, (row * a.ldx + H + 4 * c4) * 4, 0, 0);
+            }
+        }
+    } else {
         const __amdgpu_buffer_rsrc_t rx = gb_rsrc(a.xh + r0 * a.ldx, ((long long)(rows - 1) * a.ldx + K) * 4);
         constexpr int PER = 64 * K4 / NT;                        // float4 per thread (16)
         const __amdgpu_buffer_rsrc_t rhp = gb_rsrc(a.h_prev ? a.h_prev + r0 * H : a.xh, a.h_prev ? (long long)rows * H * 4 : 0);
@@ -182,7 +200,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
-    if constexpr (SPLIT != 0) {
+    if constexpr (GIVEN != 0) {
+    } else if constexpr (SPLIT != 0) {
         constexpr int KB16 = K / 16, NWv = H / 32;
         const __amdgpu_buffer_rsrc_t rg3 = gb_rsrc(a.wq3, (long long)3 * K * 4 * H * 2);
         const int g3lane = (w * 64 + lane) * 16;
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 #endif
 
     // ---- the cell's derivative (torch.nn.LSTMCell): c' = f c + i g, h' = o tanh(c') -----------------------------------------
-    const float bi = slb[col], bf = slb[H + col], bg = slb[2 * H + col], bo = slb[3 * H + col];
+    const float bi = GIVEN ? 0.f : slb[col], bf = GIVEN ? 0.f : slb[H + col], bg = GIVEN ? 0.f : slb[2 * H + col], bo = GIVEN ? 0.f : slb[3 * H + col];
     const bool dx = SPLIT != 0 && a.dxh != nullptr;                  // (uniform) the input gradient in this launch too
     float keep_g[2][16], keep_o[2][16];
     if (dx) __syncthreads();                                         // every wave is done reading the A tile: it takes d i, d f now
@@ -274,22 +293,32 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     const __amdgpu_buffer_rsrc_t rdp = gb_rsrc(a.dc_prev + r0 * H, nrec);
     const __amdgpu_buffer_rsrc_t rdg = gb_rsrc(a.dgates + r0 * 4 * H, 4 * nrec);
     const int goff = (4 * lh * 4 * H + col) * 4;
+    const __amdgpu_buffer_rsrc_t rgin = gb_rsrc(GIVEN ? a.gates + r0 * 4 * H : a.dh, GIVEN ? 4 * nrec : 0);
     float si = 0.f, sf = 0.f, sg = 0.f, so = 0.f;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-        float dhv[16], dcv[16];
+        float dhv[16], dcv[16], gin[GIVEN ? 4 : 1][16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
             dhv[reg] = gb_load1(rdh, voff, lc * H * 4);
             dcv[reg] = gb_load1(rdc, voff, lc * H * 4);
             if constexpr (SPLIT != 0) cold[rt][reg] = gb_load1(rc, voff, lc * H * 4);
+            if constexpr (GIVEN != 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gin[k][reg] = gb_load1(rgin, goff, lc * 4 * H * 4 + k * H * 4);
+            }
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-            const float i = fast_sigmoid(acc[rt][0][reg] + bi), f = fast_sigmoid(acc[rt][1][reg] + bf);
-            const float gt = fast_tanh(acc[rt][2][reg] + bg), o = fast_sigmoid(acc[rt][3][reg] + bo);
+            float i, f, gt, o;
+            if constexpr (GIVEN != 0) {
+                i = gin[0][reg], f = gin[1][reg], gt = gin[2][reg], o = gin[3][reg];
+            } else {
+                i = fast_sigmoid(acc[rt][0][reg] + bi), f = fast_sigmoid(acc[rt][1][reg] + bf);
+                gt = fast_tanh(acc[rt][2][reg] + bg), o = fast_sigmoid(acc[rt][3][reg] + bo);
+            }
             const float c0 = cold[rt][reg];
             const float tc = fast_tanh(f * c0 + i * gt);
             const float dct = dcv[reg] + dhv[reg] * o * (1.0f - tc * tc);
@@ -419,7 +448,8 @@ extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H ==
 
 static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
                                const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
-                               float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream);
+                               float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream,
+                               const float* gates = nullptr);
 
 extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias, const float* c_prev,
                                        const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
@@ -441,21 +471,47 @@ extern "C" int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_pre
                                lstm_wp3_bwd, dxh, R, H, stream);
 }
 
+extern "C" int ic3_lstm_gates_backward_given(const float* gates, float* xh, int ldx, const float* h_prev, const void* lstm_wp3_bwd,
+                                             const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
+                                             float* dbias_partials, int accumulate, float* dxh, int R, int H, ic3_stream stream)
+{
+    if (!gates) return ic3::fail(-22, "ic3_lstm_gates_backward_given: null gates");
+    if ((lstm_wp3_bwd == nullptr) != (dxh == nullptr))
+        return ic3::fail(-22, "ic3_lstm_gates_backward_given: lstm_wp3_bwd and dxh come together");
+    if (H != 64 && H != 128) return ic3::fail(-38, "ic3_lstm_gates_backward_given: hid_size 64 / 128");
+    if ((xh == nullptr) != (h_prev == nullptr))
+        return ic3::fail(-22, "ic3_lstm_gates_backward_given: xh and h_prev come together (the copy into xh's h half) or not at all");
+    return gates_backward_impl(xh, xh ? ldx : 2 * H, h_prev, nullptr, nullptr, nullptr, c_prev, dh, dc, dgates, dc_prev, dbias_partials,
+                               accumulate, lstm_wp3_bwd, dxh, R, H, stream, gates);
+}
+
 static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
                                const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
-                               float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream)
+                               float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream,
+                               const float* gates)
 {
     using namespace ic3;
-    if (!xh || !lstm_wp || !bias || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
+    if ((!gates && (!xh || !lstm_wp || !bias)) || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
         return fail(-22, "ic3_lstm_gates_backward: null argument");
     if (!ic3_lstm_gates_backward_supported(H)) return fail(-38, "ic3_lstm_gates_backward: needs hid_size 64 / 128 / 256");
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
     if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
         return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
-    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh };
+    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh, gates };
     const int tiles = (R + 63) / 64;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    if (gates) {                                                 // (H 64 / 128: checked by the entry point)
+        if (H == 128) {
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<128, 1, 1>), lds));
+            hipLaunchKernelGGL((lstm_gates_bwd_kernel<128, 1, 1>), dim3(tiles), dim3(256), lds, s, a);
+        } else {
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_gates_bwd_kernel<64, 1, 1>), lds));
+            hipLaunchKernelGGL((lstm_gates_bwd_kernel<64, 1, 1>), dim3(tiles), dim3(128), lds, s, a);
+        }
+        IC3_HIP(hipGetLastError());
+        return tiles;
+    }
 #define IC3_GB(h)                                                                                                       \
     case h:                                                                                                             \
         if (lstm_wp3) {                                                                                                 \

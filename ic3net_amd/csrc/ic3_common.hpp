@@ -89,6 +89,7 @@ struct ic3_env {
     int auto_max_steps = 0;    // ic3_env_set_auto_reset: > 0 = finished envs restart inside the step launch
     void *ev_start = nullptr, *ev_stop = nullptr;   // ic3_env_set_step_events: recorded by the next ic3_policy_step launch
     float *h_out = nullptr, *c_out = nullptr;       // ic3_env_set_hidden_out: where the next ic3_policy_step writes h', c'
+    float *gates_out = nullptr, *xh_out = nullptr;  // ic3_env_set_record_out: where the next ic3_policy_step records its cell's gates / inp rows
     // ic3_env_set_incremental_obs (opt-in experiment): per-env record of what ic3_policy_step painted into `painted_obs`
     int32_t* obs_rec = nullptr;
     const float* painted_obs = nullptr;

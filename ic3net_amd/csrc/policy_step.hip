@@ -175,6 +175,8 @@ struct StepArgs {
     float* c;                   // [R][H]
     float* h_out;               // ... and written here (= h, c unless ic3_env_set_hidden_out)
     float* c_out;
+    float* gates_out;           // ic3_env_set_record_out: [R][4H] the activated gates i | f | g | o of this step's LSTM cell, or null
+    float* xh_out;              //   + [R][2H]: the inp half of every row (encoder + C(comm) + biases, the gate product's left operand), or null
     const int32_t* alive_in;    // [R] or null (t = 0: everyone alive, quirk Q21)
     const int32_t* comm_in;     // [R] or null (gate sampled at t-1, quirk Q22)
     float* out;                 // [R][OT] log-probs | value
@@ -734,6 +736,22 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                     As[lr * LDA + col] = accC[rt][reg];
                 }
             }
+            if constexpr (KIND != 0 && MP == 0) {
+                if (a.xh_out) {   // (uniform; ic3_env_set_record_out) the same values -> the inp half of the record's [inp | h] rows
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xh_out + r0 * 2 * H, (ABL & 16) ? 0u : (uint32_t)rows * 2 * H * 4u);
+                    const int xoff = (4 * lh * 2 * H + col) * 4;
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        if (rt == 1 && !two) break;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const float xv = accC[rt][reg];           // (a copy: bit_cast of a vector element reads element 0)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, xv), rx,
+                                                                  xoff + (32 * rt + (reg & 3) + 8 * (reg >> 2)) * 2 * H * 4, 0, IC3_PS_ZSTORE_AUX);
+                        }
+                    }
+                }
+            }
             __syncthreads();
             IC3_TR(8);
             IC3_TRC(0);
@@ -1048,8 +1066,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             // The element loop, one copy per number of zero-store slots per element (workgroup-uniform): with the slot count
             // a compile-time constant the 16 elements of a row tile are ONE basic block, and the scheduler overlaps the
             // transcendental chains (exp -> rcp -> exp -> rcp) of neighbouring elements instead of running them end to end.
-            auto cell = [&](auto ze_c) __attribute__((always_inline)) {
+            // (GS: ic3_env_set_gates_out — the activated gates go to the update half's record, so its backward reads them
+            //  instead of running the gate product again; stores only where armed, 4 x 4 bytes per element)
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+                static_cast<void*>(a.gates_out ? a.gates_out + r0 * 4 * H : a.c_out), 0, a.gates_out ? 4u * nrec : 0u, 0x00020000);
+            const int goff = (4 * lh * 4 * H + col) * 4;
+            auto cell = [&](auto ze_c, auto gs_c) __attribute__((always_inline)) {
                 constexpr int ZE = decltype(ze_c)::value;
+                constexpr bool GS = decltype(gs_c)::value;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     if (rt == 1 && !two) break;          // half tile: rows 32..63 are padding (their h' is never read)
@@ -1060,9 +1084,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         const float gg = acc[rt][2][reg] + bg, go = acc[rt][3][reg] + bo;
                         // (explicit fma: the three copies of this loop must round alike — a*b + c*d left to the compiler
                         //  comes out as fma(a, b, c*d), fma(c, d, a*b) or two products and a sum depending on the schedule)
-                        const float ig = fast_sigmoid(gi) * fast_tanh(gg);
-                        const float c1 = __builtin_fmaf(fast_sigmoid(gf), cold[rt][reg], ig);
-                        const float h1 = fast_sigmoid(go) * fast_tanh(c1);
+                        const float si = fast_sigmoid(gi), tg = fast_tanh(gg), sf = fast_sigmoid(gf), so = fast_sigmoid(go);
+                        const float ig = si * tg;
+                        const float c1 = __builtin_fmaf(sf, cold[rt][reg], ig);
+                        const float h1 = so * fast_tanh(c1);
                         // what the gate loop left of the zero fill goes out between the transcendental work of the cell
                         // (<= 2 x 32 slots, then the rest)
                         if constexpr (ZE > 0) zero_store();
@@ -1070,15 +1095,29 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
+                        if constexpr (GS) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, si), rg, goff + lc * 4 * H * 4, 0, IC3_PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sf), rg, goff + lc * 4 * H * 4 + H * 4, 0, IC3_PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tg), rg, goff + lc * 4 * H * 4 + 2 * H * 4, 0, IC3_PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, so), rg, goff + lc * 4 * H * 4 + 3 * H * 4, 0, IC3_PS_ZSTORE_AUX);
+                        }
                         As[lr * LDA + H + col] = h1;
                         if (rt == 0 && reg == 0) IC3_TRE(0);
                     }
                 }
             };
             const int ze = obs_here ? a.zepi : 0;
-            if (ze <= 0) cell(std::integral_constant<int, 0>{});
-            else if (ze == 1) cell(std::integral_constant<int, 1>{});
-            else cell(std::integral_constant<int, 2>{});
+            bool gs_done = false;
+            if constexpr (SPLIT == 1 && MP == 0 && KIND != 0) {          // (the host arms gates_out for these instantiations only,
+                if (a.gates_out) {                                        //  and leaves the epilogue no zero-store slots then)
+                    cell(std::integral_constant<int, 0>{}, std::true_type{});
+                    gs_done = true;
+                }
+            }
+            if (gs_done) {
+            } else if (ze <= 0) cell(std::integral_constant<int, 0>{}, std::false_type{});
+            else if (ze == 1) cell(std::integral_constant<int, 1>{}, std::false_type{});
+            else cell(std::integral_constant<int, 2>{}, std::false_type{});
             IC3_TRE(1);
             if (tid < a.OT * H4) As4[(tid / H4) * LDA4 + tid % H4] = hw0;
             if (tid + NT < a.OT * H4) As4[((tid + NT) / H4) * LDA4 + (tid + NT) % H4] = hw1;
@@ -1847,7 +1886,9 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     // one-shot outputs armed on the handle (ic3_env_set_hidden_out): consumed by this call whatever becomes of it
     float* const armed_h = env->h_out;
     float* const armed_c = env->c_out;
-    if (!inner) env->h_out = env->c_out = nullptr;
+    float* const armed_g = env->gates_out;                       // (ic3_env_set_record_out: one-shot as well)
+    float* const armed_x = env->xh_out;
+    if (!inner) env->h_out = env->c_out = env->gates_out = env->xh_out = nullptr;
     if (!inner && (!out || !action || !reward || !done)) return fail(-22, "ic3_policy_step: null argument");
     if (inner) obs = nullptr;
     if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");
@@ -1871,6 +1912,12 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     if (!inner && armed_h && armed_c) {                          // (ic3_env_set_hidden_out): the step's LAST launch
         a.h_out = armed_h;
         a.c_out = armed_c;
+    }
+    if (!inner && armed_g) {
+        if (!a.l_wp3 || a.npass > 1 || (H != 64 && H != 128))
+            return fail(-38, "ic3_env_set_record_out: the gate record needs gate_split, one communication pass, hid_size 64 / 128");
+        a.gates_out = armed_g;
+        a.xh_out = armed_x;
     }
     a.alive_in = alive_in;
     a.comm_in = comm_in;
@@ -1963,7 +2010,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         a.zc = take(std::min(zc_env >= 0 ? zc_env : share, H / 8));
         a.zf = take(zf_env >= 0 ? zf_env : share);
         a.zh = take(zh_env >= 0 ? zh_env : 0);
-        a.zepi = (!fused_obs || incr_valid) ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
+        a.zepi = (!fused_obs || incr_valid || a.gates_out) ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
         left -= 32LL * a.zepi;
         a.zrest = (fused_obs && !incr_valid) ? (int)(left > 0 ? left + 1 : 0) : 0;
     }
@@ -2000,7 +2047,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     }
     // IC3_PS_WS=1: the wave-specialised schedule (policy_step_ws.hpp) where it applies — same results (A / B switch)
     static const int ws_on = getenv("IC3_PS_WS") ? atoi(getenv("IC3_PS_WS")) : 0;
-    if (ws_on && a.l_wp3 && fused_obs && !inner && !a.keep_state && !incr && !prefilled && (H == 128 || H == 64) &&
+    if (ws_on && !a.gates_out && a.l_wp3 && fused_obs && !inner && !a.keep_state && !incr && !prefilled && (H == 128 || H == 64) &&
         ps_ws_lds(H, tile_words) <= 160 * 1024) {
         StepArgs w = a;
 #ifdef IC3_PS_TRACE
@@ -2095,6 +2142,15 @@ extern "C" int ic3_gate_product_probe(const float* xh, const float* lstm_wp, con
     if (H == 64) return launch_gate_probe<64>(xh, lstm_wp, lstm_wp3, gates, R, s);
     if (H == 256) return launch_gate_probe<256>(xh, lstm_wp, lstm_wp3, gates, R, s);
     return fail(-38, "ic3_gate_product_probe: hid_size 64 / 128 / 256");
+}
+
+extern "C" int ic3_env_set_record_out(ic3_env* env, float* gates, float* xh)
+{
+    if (!env) return fail(-22, "ic3_env_set_record_out: null handle");
+    if (xh && !gates) return fail(-22, "ic3_env_set_record_out: xh comes with gates");
+    env->gates_out = gates;
+    env->xh_out = xh;
+    return 0;
 }
 
 extern "C" int ic3_env_set_hidden_out(ic3_env* env, float* h_out, float* c_out)

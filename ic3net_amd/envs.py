@@ -291,6 +291,12 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_set_auto_reset(self._h, int(max_steps)))
         self.auto_max_steps = int(max_steps)
 
+    def set_record_out(self, gates, xh=None):
+        """One-shot (ic3_env_set_record_out): the next ic3_policy_step also stores its cell's activated gates (R, 4H) there
+        and, with `xh` (R, 2H), the inp half of its rows."""
+        check(_lib.lib().ic3_env_set_record_out(self._h, ptr(gates) if gates is not None else None,
+                                                ptr(xh) if xh is not None else None))
+
     def set_hidden_out(self, h_out, c_out):
         """One-shot (ic3_env_set_hidden_out): the next ic3_policy_step writes h', c' there instead of in place."""
         check(_lib.lib().ic3_env_set_hidden_out(self._h, ptr(h_out), ptr(c_out)))

@@ -215,6 +215,35 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
     return n
 
 
+def lstm_gates_backward_given(gates, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None, accumulate=False, xh=None,
+                              h_prev=None, lstm_wp3_bwd=None, dxh=None):
+    """The cell's derivative from the RECORDED activated gates (R, 4H) of the step (ic3_lstm_gates_backward_given; the
+    rollout's launch stored them: envs.set_record_out) — no gate product.  xh + h_prev: h_prev is copied into the h half of xh;
+    lstm_wp3_bwd + dxh: [d inp | d h_prev] in the same launch."""
+    _need_cuda(gates, "lstm_gates_backward_given")
+    R, H = c_prev.shape
+    for t in (gates, c_prev, dh, dgates, dc_prev):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    assert tuple(gates.shape) == (R, 4 * H) and tuple(dgates.shape) == (R, 4 * H)
+    tiles = (R + 63) // 64
+    if dbias_partials is not None:
+        assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == (tiles, 4 * H)
+    if xh is not None:
+        assert h_prev is not None and xh.dtype == torch.float32 and xh.stride(1) == 1 and xh.shape == (R, 2 * H)
+        assert h_prev.is_contiguous() and tuple(h_prev.shape) == (R, H)
+    if dxh is not None:
+        assert lstm_wp3_bwd is not None and dxh.is_contiguous() and tuple(dxh.shape) == (R, 2 * H)
+    n = _lib.lib().ic3_lstm_gates_backward_given(ptr(gates), ptr(xh) if xh is not None else None, xh.stride(0) if xh is not None else 0,
+                                                 ptr(h_prev) if xh is not None else None,
+                                                 ptr(lstm_wp3_bwd) if dxh is not None else None, ptr(c_prev), ptr(dh),
+                                                 ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
+                                                 ptr(dbias_partials) if dbias_partials is not None else None,
+                                                 int(bool(accumulate)), ptr(dxh) if dxh is not None else None, R, H, stream())
+    if n < 0:
+        check(n)
+    return n
+
+
 HEADS_GRAD_MAX_OT = 16      # ic3_heads_grad: at most 16 output columns (the heads' actions in total + the value)
 
 

@@ -226,6 +226,9 @@ class Trainer(object):
             knet = self._kernel_net()                             # (a zero-padded twin records its own, wider, state)
             self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size if knet is self.policy_net else knet.hid_size,
                                            raw1.dims.state_words, dev, recurrent=bool(getattr(args, 'recurrent', False)))
+            if self._record_gates(knet, T, E * N):
+                self._rec.gates = torch.empty((T, E * N, 4 * knet.hid_size), dtype=torch.float32, device=dev)
+                self._rec.xh = torch.empty((T, E * N, 2 * knet.hid_size), dtype=torch.float32, device=dev)
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
         if self._use_graph() and self._graphs and getattr(self.policy_net, '_fc', None) is not None:
@@ -244,6 +247,24 @@ class Trainer(object):
         not built for — its zero-padded twin (comm.CommNetMLP.kernel_module)."""
         km = getattr(self.policy_net, 'kernel_module', None)
         return km() if km is not None else self.policy_net
+
+    def _record_gates(self, knet, T, R):
+        """Native update: let every step launch of the recorded rollout store its cell's activated gates in the episode record
+        and the inp rows (ic3_env_set_record_out), so the backward reads them instead of running the gate product again — where the record is
+        the in-place one, the split gate product and its backward planes exist (hid 64 / 128), and T x R x 4H floats are a
+        small part of the device's memory (args.record_gates=False: recompute)."""
+        a = self.args
+        if not getattr(a, 'record_gates', True) or not getattr(a, 'recurrent', False) or not self._rec_inplace() \
+                or not hasattr(knet, '_fused_cache') or bptt._is_baseline(self.policy_net):
+            return False
+        with torch.no_grad():
+            fc = knet._fused_cache()
+        H = knet.hid_size
+        if fc.get('ps_l_wp3') is None or fc.get('ps_l_wp3_bwd') is None or H not in (64, 128) \
+                or not getattr(a, 'fused_input_grad', True):
+            return False
+        total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+        return T * R * 6 * H * 4 <= total // 4
 
     def _rec_inplace(self):
         """The recorded rollout of a native update reads / writes (h, c) in the episode record (no copies) when every
@@ -496,10 +517,14 @@ class Trainer(object):
         if self._rec is not None and self._prev_hid[0].data_ptr() == self._rec.hs[t].data_ptr():
             rec_out = self._rec.slot(t + 1)                        # the launch writes the next slot of the episode record
         out_buf = self._static_out(t, state)
+        extra = {}
+        if rec_out is not None and self._rec.gates is not None:
+            extra['record_out'] = (self._rec.gates[t], self._rec.xh[t])   # + the cell's gates, inp rows (bptt: no gate product later)
+            self._rec.gates_n += 1
         action_out, value, prev_hid = self.policy_net.step_env(
             raw, [state, self._prev_hid], info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
             alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None,
-            hidden_out=rec_out, out=out_buf)
+            hidden_out=rec_out, out=out_buf, **extra)
         if prefill:
             main.wait_stream(side)
             self._pf_ready = (t + 1) & 1

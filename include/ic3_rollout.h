@@ -337,6 +337,15 @@ int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_prev /* or NUL
                                const void* lstm_wp3_bwd, const float* bias, const float* c_prev, const float* dh,
                                const float* dc /* or NULL */, float* dgates, float* dc_prev, float* dbias_partials /* or NULL */,
                                int accumulate, float* dxh, int R, int H, ic3_stream stream);
+/* The cell's derivative from RECORDED gates (round 5): `gates` [R][4H] = the activated i | f | g | o of the step as the
+ * rollout's launch stored them (ic3_env_set_gates_out) — the gate product is not run again (it was the largest item of the
+ * update half: 2 * R * 2H * 4H flop x 9 split products per recorded step).  Same outputs as ic3_lstm_gates_backward_dx; xh /
+ * h_prev (both or neither): the launch copies h_prev into the h half of xh [R][ldx] for the weight-gradient product that
+ * follows; lstm_wp3_bwd / dxh (both or neither): the input gradient in the same launch.  hid_size 64 / 128. */
+int ic3_lstm_gates_backward_given(const float* gates, float* xh /* or NULL */, int ldx, const float* h_prev /* or NULL */,
+                                  const void* lstm_wp3_bwd /* or NULL */, const float* c_prev, const float* dh,
+                                  const float* dc /* or NULL */, float* dgates, float* dc_prev, float* dbias_partials /* or NULL */,
+                                  int accumulate, float* dxh /* or NULL */, int R, int H, ic3_stream stream);
 /* The weight / bias gradient of the heads + value head over a whole episode in one pass (trainer.py:128-225 through
  * comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o] over the M = steps x rows pairs
  * (d [M][OT], h [M][H]: h_t of every step, i.e. the recorded hidden states shifted by one step).  scratch:
@@ -493,6 +502,14 @@ int ic3_gate_product_probe(const float* xh, const float* lstm_wp, const void* ls
  * keeps the state ENTERING every step of an episode (the update half, trainer.py:128-225: backward through time over
  * recorded (h, c)) lets the launch write slot t + 1 of its record directly instead of copying 2 x E*N*H floats per step. */
 int ic3_env_set_hidden_out(ic3_env* env, float* h_out, float* c_out);
+/* One-shot as well: the NEXT ic3_policy_step also stores what the update half's backward would otherwise compute again
+ * (trainer.py:128-225 over a recorded rollout): `gates` [E*N][4H] = the activated gates of its LSTM cell — sigmoid(i) |
+ * sigmoid(f) | tanh(g) | sigmoid(o), exactly the values its cell update used — for ic3_lstm_gates_backward_given; and, when
+ * `xh` is not NULL, the inp half of the rows of xh [E*N][2H] (row stride 2H; inp = encoder(obs) + C(comm) + both biases, the
+ * left operand of the gate product — the h half is not touched: ic3_lstm_gates_backward_given copies h_prev there).
+ * Needs ic3_policy.gate_split, one communication pass per launch, hid_size 64 / 128 (-38 from the step call otherwise);
+ * gates = NULL disarms.  Costs 16 H (+ 4 H) bytes of stores per agent row in the launch; nothing when not armed. */
+int ic3_env_set_record_out(ic3_env* env, float* gates, float* xh /* or NULL */);
 int ic3_policy_step_supported(const ic3_env* env, int H); /* 0, or the LDS bytes per workgroup */
 /* The policy half alone, for callers that bring their own encoder output (a dense observation that is not an env's
  * current state, comm.py:119 evaluated as a GEMM): enc [E*N][H] = encoder(x) + C.bias -> out [E*N][OT] as above, h / c

@@ -129,3 +129,48 @@ def test_gates_backward_with_the_input_gradient_in_the_same_launch(H, R):
     err = float((out[1][4].double() - ref).abs().max())
     assert err <= 2e-6 * max(1.0, float(ref.abs().max())), err
     assert torch.equal(out[1][4], out[2][4]) and torch.equal(out[1][0], out[2][0])
+
+
+@pytest.mark.parametrize("H,R", [(128, 64 * 150 + 37), (64, 150)])
+def test_gates_backward_from_recorded_gates(H, R):
+    """ic3_lstm_gates_backward_given (round 5): the cell's derivative of the activated gates handed in (what the rollout's step
+    launch stored), h_prev copied into the h half of xh, dx in the same launch — against the closed form in float64; and a
+    policy step's recorded gates give the gradient the recomputing launch gives (1e-6)."""
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(5 * H + R)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    w_ih, w_hh, c_w = rn(4 * H, H) / H ** 0.5, rn(4 * H, H) / H ** 0.5, rn(H, H)
+    b = rn(4 * H)
+    xh, h_prev = rn(R, 2 * H), rn(R, H)
+    c_prev, dh, dc = rn(R, H), rn(R, H), rn(R, H)
+    wb3 = ops.policy_pack_split_bwd(w_ih, w_hh)
+    W = torch.cat([w_ih, w_hh], 1).double()
+    xfull = torch.cat([xh[:, :H], h_prev], 1)
+    pre = xfull.double() @ W.t() + b.double()
+    acts = torch.cat([torch.sigmoid(pre[:, :H]), torch.sigmoid(pre[:, H:2 * H]), torch.tanh(pre[:, 2 * H:3 * H]),
+                      torch.sigmoid(pre[:, 3 * H:])], 1).float().contiguous()
+    a = acts.double()
+    i, f, g, o = a[:, :H], a[:, H:2 * H], a[:, 2 * H:3 * H], a[:, 3 * H:]
+    tc = torch.tanh(f * c_prev.double() + i * g)
+    dct = dc.double() + dh.double() * o * (1 - tc * tc)
+    want = torch.cat([dct * g * i * (1 - i), dct * c_prev.double() * f * (1 - f), dct * i * (1 - g * g), dh.double() * tc * o * (1 - o)], 1)
+    tiles = (R + 63) // 64
+    x = xh.clone()
+    dgates = torch.full((R, 4 * H), float('nan'), device='cuda')
+    dcp = torch.full((R, H), float('nan'), device='cuda')
+    parts = torch.zeros((tiles, 4 * H), device='cuda')
+    dxh = torch.full((R, 2 * H), float('nan'), device='cuda')
+    n = ops.lstm_gates_backward_given(acts, c_prev, dh, dc, dgates, dcp, parts, True, xh=x, h_prev=h_prev, lstm_wp3_bwd=wb3, dxh=dxh)
+    assert n == tiles and torch.equal(x, xfull)
+    assert float((dgates.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    assert float((dcp.double() - dct * f).abs().max()) <= 2e-6 * max(1.0, float((dct * f).abs().max()))
+    assert float((parts.double().sum(0) - want.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(want.sum(0).abs().max()))
+    ref = dgates.double() @ W
+    assert float((dxh.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    # the recomputing launch on the same step: its own activations differ from float64's by rounding only
+    wp = ops.policy_step_pack(c_w, w_ih, w_hh)['ps_l_wp']
+    wp3 = ops.policy_pack_split(w_ih, w_hh)
+    dg2, dcp2, dx2 = torch.empty_like(dgates), torch.empty_like(dcp), torch.empty_like(dxh)
+    ops.lstm_gates_backward(xh.clone(), wp, b, c_prev, dh, dc, dg2, dcp2, None, False, h_prev=h_prev, lstm_wp3=wp3, lstm_wp3_bwd=wb3, dxh=dx2)
+    assert float((dg2 - dgates).abs().max()) <= 4e-6 * max(1.0, float(want.abs().max()))
+    assert float((dx2 - dxh).abs().max()) <= 6e-6 * max(1.0, float(ref.abs().max()))

@@ -558,6 +558,33 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
         assert np.abs(dxh - want_dx).max() <= 6e-6 * max(1.0, np.abs(want_dx).max())
         assert lib.ic3_lstm_gates_backward_dx(p(xh2), 2 * H, p(h_prev), p(l_wp), None, p(wb3), p(b), p(c_prev), p(dh), None, p(dg5),
                                               p(dcp5), None, 0, p(dxh), R, H, None) == -22
+        # ic3_lstm_gates_backward_given (round 5): the activated gates handed in (here: float32 roundings of the closed form)
+        # instead of the gate product — the cell's derivative of exactly those values, h_prev copied into xh, dx in the launch
+        acts = f32(np.concatenate([i, f, gg, o], 1))
+        a64 = acts.astype(np.float64)
+        ai, af, ag, ao = a64[:, :H], a64[:, H:2 * H], a64[:, 2 * H:3 * H], a64[:, 3 * H:]
+        tcg = np.tanh(af * c_prev + ai * ag)
+        dct = dc + dh * ao * (1 - tcg * tcg)
+        want_g = np.concatenate([dct * ag * ai * (1 - ai), dct * c_prev * af * (1 - af), dct * ai * (1 - ag * ag), dh * tcg * ao * (1 - ao)], 1)
+        xh6 = np.ascontiguousarray(np.concatenate([wide[:, :H], np.full((R, H), np.nan, np.float32)], 1))
+        dg6, dcp6 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
+        dxh6, parts6 = np.full((R, 2 * H), np.nan, np.float32), np.full((tiles, 4 * H), np.nan, np.float32)
+        n = check(lib.ic3_lstm_gates_backward_given(p(acts), p(xh6), 2 * H, p(h_prev), p(wb3), p(c_prev), p(dh), p(dc), p(dg6), p(dcp6),
+                                                    p(parts6), 0, p(dxh6), R, H, None))
+        assert n == tiles
+        np.testing.assert_array_equal(xh6, wide[:, :2 * H])
+        assert np.abs(dg6 - want_g).max() <= 2e-6 * max(1.0, np.abs(want_g).max())
+        assert np.abs(dcp6 - dct * af).max() <= 2e-6 * max(1.0, np.abs(dct * af).max())
+        np.testing.assert_allclose(parts6.astype(np.float64).sum(0), want_g.sum(0), rtol=1e-5, atol=1e-4)
+        want_dx6 = dg6.astype(np.float64) @ np.concatenate([w_ih, w_hh], 1).astype(np.float64)
+        assert np.abs(dxh6 - want_dx6).max() <= 6e-6 * max(1.0, np.abs(want_dx6).max())
+        dg7, dcp7 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
+        check(lib.ic3_lstm_gates_backward_given(p(acts), None, 0, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0, None,
+                                                R, H, None))                      # (pointwise only: no copy, no dx)
+        np.testing.assert_array_equal(dg7, dg6)
+        np.testing.assert_array_equal(dcp7, dcp6)
+        assert lib.ic3_lstm_gates_backward_given(p(acts), p(xh6), 2 * H, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0,
+                                                 None, R, H, None) == -22
 
 
 def commnet_weights(lib, P, H, heads, passes):
@@ -686,6 +713,54 @@ def test_hidden_out_writes_the_next_slot_and_leaves_the_input_alone():
             assert not np.array_equal(h, h0)
         else:
             res.append((h.copy(), c.copy(), out.copy()))
+        env.close()
+    for x, y in zip(*res):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_gates_out_records_the_cell_s_activated_gates():
+    """ic3_env_set_record_out (round 5): the next ic3_policy_step also stores sigmoid(i) | sigmoid(f) | tanh(g) | sigmoid(o) of its
+    LSTM cell [E*N][4H] — every other output unchanged bit for bit, the new cell / hidden state reproduced from the stored gates
+    exactly (c' = fma(f, c, i g), h' = o tanh(c') up to the kernel's tanh), one-shot; refused (-38) without gate_split."""
+    w = WORKLOADS['pp_easy']
+    E, N, H, heads = 7, w['N'], w['H'], w['heads']
+    res = []
+    for armed in (False, True):
+        env = make_env(w, E, 3, 70)
+        P = make_params(env.obs_dim, H, heads, seed=4)
+        pol = HostPolicy(env, P, H, heads, gate_split=True)
+        env.reset()
+        rng = np.random.default_rng(1)
+        h = (rng.standard_normal((E * N, H)) * 0.3).astype(np.float32)
+        c = (rng.standard_normal((E * N, H)) * 0.3).astype(np.float32)
+        h0, c0 = h.copy(), c.copy()
+        gate = np.ones((E, N), np.int32)
+        gates = np.full((E * N, 4 * H), np.nan, np.float32)
+        xrows = np.full((E * N, 2 * H), np.nan, np.float32)
+        if armed:
+            check(env.lib.ic3_env_set_record_out(env._h, p(gates), p(xrows)))
+        out, act, obs, rew, done, alive, comp = pol.step(env, h, c, None, gate)
+        res.append((h.copy(), c.copy(), out.copy(), act.copy(), obs.copy(), rew.copy()))
+        if armed:
+            assert np.isfinite(gates).all()
+            g64 = gates.astype(np.float64)
+            gi, gf, gg, go = g64[:, :H], g64[:, H:2 * H], g64[:, 2 * H:3 * H], g64[:, 3 * H:]
+            assert (gi > 0).all() and (gi < 1).all() and (np.abs(gg) <= 1).all()
+            c1 = gf * c0 + gi * gg
+            assert np.abs(c1 - c).max() <= 1e-6
+            assert np.abs(go * np.tanh(c1) - h).max() <= 2e-6
+            # the inp half of xh: the gate pre-activations follow from it and the state that entered (float64 product)
+            assert np.isnan(xrows[:, H:]).all() and np.isfinite(xrows[:, :H]).all()
+            pre = np.concatenate([xrows[:, :H], h0], 1).astype(np.float64) @ np.concatenate([pol.w_ih, pol.w_hh], 1).T.astype(np.float64) \
+                + (P['f_module.bias_ih'] + P['f_module.bias_hh'])
+            assert np.abs(1 / (1 + np.exp(-pre[:, :H])) - gi).max() <= 2e-6 and np.abs(np.tanh(pre[:, 2 * H:3 * H]) - gg).max() <= 2e-6
+            keep = gates.copy()
+            pol.step(env, h, c, None, gate)                          # one-shot: this call stores no gates
+            np.testing.assert_array_equal(gates, keep)
+            plain = HostPolicy(env, P, H, heads)                      # the fp32-instruction gate product: no gate record
+            check(env.lib.ic3_env_set_record_out(env._h, p(gates), p(xrows)))
+            with pytest.raises(NotImplementedError):
+                plain.step(env, h, c, None, gate)
         env.close()
     for x, y in zip(*res):
         np.testing.assert_array_equal(x, y)

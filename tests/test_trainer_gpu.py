@@ -776,6 +776,53 @@ def test_native_update_records_the_recurrent_state_in_place():
         assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k
 
 
+@pytest.mark.parametrize("wl,collect", [("pp_hard", False), ("tj_medium", False), ("pp_hard", True)])
+def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect):
+    """Round 5: every step launch of a recorded rollout stores its cell's activated gates in the episode record
+    (ic3_env_set_record_out) and the backward reads them (ic3_lstm_gates_backward_given) instead of running the gate product
+    again: same rollout bit for bit, the recorded gates reproduce the recorded next state, and the gradients equal the
+    recomputing backward's at 1e-5 (args.record_gates=False) — episodes and collection mode."""
+    import bench
+    out = []
+    for record in (True, False):
+        tr, a = bench.build_trainer(wl, 12, 3, 0, 0)
+        a.max_steps, a.batch_size = 10, 12 * 10
+        a.entr, a.value_coeff, a.gamma, a.normalize_rewards, a.advantages_per_action = 0.01, 0.01, 1.0, False, False
+        a.record_gates = record
+        a.auto_reset = collect
+        assert tr._native_update()
+        tr._records = []
+        batch, stats = tr.run_batch(0)
+        recs = tr._records
+        rec = recs[0]
+        assert (rec.gates is not None and rec.gates_n == rec.n) == record
+        if record:
+            H = rec.hs.shape[2]
+            g = rec.gates[:rec.n - 1].double()
+            c1 = g[..., H:2 * H] * rec.cs[:rec.n - 1].double() + g[..., :H] * g[..., 2 * H:3 * H]
+            if not collect:        # (collection mode: an env that starts an episode at slot t had zero state, not the record's)
+                assert float((c1 - rec.cs[1:rec.n].double()).abs().max()) <= 1e-6
+                assert float((g[..., 3 * H:] * torch.tanh(c1) - rec.hs[1:rec.n].double()).abs().max()) <= 2e-6
+                # the recorded inp rows: the gates follow from [inp | h] . [W_ih | W_hh]^T + b
+                knet = tr._kernel_net()
+                fm = knet.f_module
+                W = torch.cat([fm.weight_ih, fm.weight_hh], 1).detach().double()
+                xh = torch.cat([rec.xh[:rec.n - 1, :, :H], rec.hs[:rec.n - 1]], 2).double()
+                pre = xh @ W.t() + (fm.bias_ih + fm.bias_hh).detach().double()
+                assert float((torch.sigmoid(pre[..., :H]) - g[..., :H]).abs().max()) <= 2e-6
+                assert float((torch.tanh(pre[..., 2 * H:3 * H]) - g[..., 2 * H:3 * H]).abs().max()) <= 2e-6
+        tr.optimizer.zero_grad()
+        tr.compute_grad_native(batch, recs)
+        tr._records = None
+        out.append(({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None},
+                    rec.hs[:rec.n].clone(), rec.cs[:rec.n].clone()))
+    # (the backward in collection mode zeroes the rows of fresh envs in the record: compare what both did the same way)
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    for k in out[0][0]:
+        g0, g1 = out[0][0][k], out[1][0][k]
+        assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k
+
+
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
     episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)
