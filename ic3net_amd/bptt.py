@@ -231,6 +231,9 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     if rec.stream is not None:
         assert rec.recurrent and net.comm_passes == 1 and not _is_baseline(net), "collection mode: recurrent policy, one pass"
     if _is_baseline(net):
+        si = standin_for_backward(args, net, rec)
+        if si is not None:
+            return _backward_episode_standin(net, si, raw, rec, d_out, acc)
         return _backward_episode_baseline(args, net, raw, rec, d_out, acc)
     if not rec.recurrent:
         return _backward_episode_commnet(args, net, raw, rec, d_out, acc)
@@ -534,6 +537,53 @@ def _backward_episode_commnet(args, net, raw, rec, d_out, acc):
         acc['enc_bias'].add_(db)
 
 
+def standin_for_backward(args, net, rec=None):
+    """models.RNN with the LSTM cell IS the recurrent CommNet policy with the communication block off (models._KernelStandIn): where
+    that stand-in runs at the baseline's own hidden size with the fused gate launches (hid 64 / 128 / 256), its backward is
+    backward_episode on the stand-in — gate launch with the input gradient, recorded gates when the rollout stored them —
+    instead of the library chain of _backward_episode_baseline.  Returns the stand-in module, or None."""
+    if not (getattr(args, 'recurrent', False) and getattr(args, 'rnn_type', 'MLP') == 'LSTM') or not hasattr(net, 'lstm_unit'):
+        return None
+    if not bool(getattr(args, 'baseline_fused_backward', True)):
+        return None
+    sk = getattr(net, '_stand_in', None)
+    if sk is None or ops.padded_hidden(args.hid_size) is not None or not ops.lstm_gates_backward_supported(args.hid_size):
+        return None
+    if rec is not None and (not rec.recurrent or rec.hs.shape[2] != args.hid_size):
+        return None
+    with torch.no_grad():
+        si = sk.get()
+        if si is None or si._fused_cache().get('ps_l_wp') is None:
+            return None
+    return si
+
+
+def _backward_episode_standin(net, si, raw, rec, d_out, acc):
+    """IRIC (models.RNN, LSTM) through the stand-in's backward; its accumulators are folded into the baseline's by name:
+    encoder = affine1, [W_ih | W_hh] / b_ih + b_hh = lstm_unit's, heads; C (all zeros, never read: comm_mask_zero) has none."""
+    H = si.hid_size
+    acc2 = acc.get('_standin')
+    if acc2 is None:
+        acc2 = acc['_standin'] = new_accumulators(si)
+    out = backward_episode(si.args, si, raw, rec, d_out, acc2)
+    return out
+
+
+def fold_standin(acc):
+    """(behind the last episode of the batch) the stand-in's accumulators -> the baseline's"""
+    acc2 = acc.pop('_standin', None)
+    if acc2 is None:
+        return
+    H = acc['l_b'].shape[0] // 4
+    acc['wt'].add_(acc2['wt'])
+    acc['a1_b'].add_(acc2['enc_bias'])
+    acc['l_w_ih'].add_(acc2['w_cat_t'][:H].t())
+    acc['l_w_hh'].add_(acc2['w_cat_t'][H:].t())
+    acc['l_b'].add_(acc2['b_cat'])
+    acc['w_heads'].add_(acc2['w_heads'])
+    acc['b_heads'].add_(acc2['b_heads'])
+
+
 def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
     """The IC / IRIC baselines of models.py:8-97 (no communication), differentiated by hand over the recorded rollout:
       MLP  (models.py:23-34)   x1 = tanh(affine1(obs));  h = tanh(affine2(x1) + x1)         every step on its own
@@ -646,6 +696,7 @@ def assign_grads(net, acc):
     def put(p, g):
         p.grad = g.reshape(p.shape).contiguous()
     if acc.get('baseline'):                                       # models.MLP / models.RNN
+        fold_standin(acc)
         put(net.affine1.weight, acc['wt'].t())
         put(net.affine1.bias, acc['a1_b'])
         if 'l_b' in acc:

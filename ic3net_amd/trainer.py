@@ -226,7 +226,9 @@ class Trainer(object):
             knet = self._kernel_net()                             # (a zero-padded twin records its own, wider, state)
             self._rec = bptt.EpisodeRecord(T, E * N, args.hid_size if knet is self.policy_net else knet.hid_size,
                                            raw1.dims.state_words, dev, recurrent=bool(getattr(args, 'recurrent', False)))
-            if self._record_gates(knet, T, E * N):
+            with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):   # (the grad mode the episode's steps run in)
+                rec_gates = self._record_gates(knet, T, E * N)
+            if rec_gates:
                 self._rec.gates = torch.empty((T, E * N, 4 * knet.hid_size), dtype=torch.float32, device=dev)
                 self._rec.xh = torch.empty((T, E * N, 2 * knet.hid_size), dtype=torch.float32, device=dev)
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
@@ -251,11 +253,14 @@ class Trainer(object):
     def _record_gates(self, knet, T, R):
         """Native update: let every step launch of the recorded rollout store its cell's activated gates in the episode record
         and the inp rows (ic3_env_set_record_out), so the backward reads them instead of running the gate product again — where the record is
-        the in-place one, the split gate product and its backward planes exist (hid 64 / 128), and T x R x 4H floats are a
-        small part of the device's memory (args.record_gates=False: recompute)."""
+        the in-place one, the split gate product and its backward planes exist (hid 64 / 128), and the records of the batch stay
+        within a third of the device's memory (args.record_gates=False: recompute)."""
         a = self.args
-        if not getattr(a, 'record_gates', True) or not getattr(a, 'recurrent', False) or not self._rec_inplace() \
-                or not hasattr(knet, '_fused_cache') or bptt._is_baseline(self.policy_net):
+        if not getattr(a, 'record_gates', True) or not getattr(a, 'recurrent', False) or not self._rec_inplace():
+            return False
+        if bptt._is_baseline(self.policy_net):                    # IRIC: the stand-in's backward (bptt.standin_for_backward)
+            knet = bptt.standin_for_backward(a, self.policy_net)
+        if knet is None or not hasattr(knet, '_fused_cache'):
             return False
         with torch.no_grad():
             fc = knet._fused_cache()
@@ -264,7 +269,8 @@ class Trainer(object):
                 or not getattr(a, 'fused_input_grad', True):
             return False
         total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-        return T * R * 6 * H * 4 <= total // 4
+        held = sum(4 * (r.gates.numel() + r.xh.numel()) for r in (self._records or []) if r.gates is not None)
+        return held + T * R * 6 * H * 4 <= total // 3     # (all records of the batch being collected: a third of the device at most)
 
     def _rec_inplace(self):
         """The recorded rollout of a native update reads / writes (h, c) in the episode record (no copies) when every

@@ -776,12 +776,13 @@ def test_native_update_records_the_recurrent_state_in_place():
         assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k
 
 
-@pytest.mark.parametrize("wl,collect", [("pp_hard", False), ("tj_medium", False), ("pp_hard", True)])
+@pytest.mark.parametrize("wl,collect", [("pp_hard", False), ("tj_medium", False), ("pp_hard", True), ("pp_hard_iric", False)])
 def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect):
     """Round 5: every step launch of a recorded rollout stores its cell's activated gates in the episode record
     (ic3_env_set_record_out) and the backward reads them (ic3_lstm_gates_backward_given) instead of running the gate product
     again: same rollout bit for bit, the recorded gates reproduce the recorded next state, and the gradients equal the
-    recomputing backward's at 1e-5 (args.record_gates=False) — episodes and collection mode."""
+    recomputing backward's at 1e-5 (args.record_gates=False) — episodes and collection mode; the IRIC baseline (models.RNN
+    with the LSTM cell) takes the same path through its kernel stand-in (bptt.standin_for_backward)."""
     import bench
     out = []
     for record in (True, False):
@@ -805,7 +806,7 @@ def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect):
                 assert float((g[..., 3 * H:] * torch.tanh(c1) - rec.hs[1:rec.n].double()).abs().max()) <= 2e-6
                 # the recorded inp rows: the gates follow from [inp | h] . [W_ih | W_hh]^T + b
                 knet = tr._kernel_net()
-                fm = knet.f_module
+                fm = knet.f_module if hasattr(knet, 'f_module') else knet.lstm_unit     # (IRIC: models.RNN's own cell)
                 W = torch.cat([fm.weight_ih, fm.weight_hh], 1).detach().double()
                 xh = torch.cat([rec.xh[:rec.n - 1, :, :H], rec.hs[:rec.n - 1]], 2).double()
                 pre = xh @ W.t() + (fm.bias_ih + fm.bias_hh).detach().double()
@@ -861,16 +862,18 @@ def test_native_update_is_not_taken_where_it_does_not_apply():
         assert (getattr(tr3.policy_net, 'mega_steps', 0) > 0) == pad     # the one-launch rollout ran for the twin only
 
 
-@pytest.mark.parametrize("kind,rnn_type,env_name", [("mlp", "MLP", "predator_prey"), ("rnn", "MLP", "traffic_junction"),
-                                                    ("rnn", "LSTM", "predator_prey")])
-def test_native_update_of_the_baselines_matches_autograd(kind, rnn_type, env_name):
+@pytest.mark.parametrize("kind,rnn_type,env_name,hid", [("mlp", "MLP", "predator_prey", 32), ("rnn", "MLP", "traffic_junction", 32),
+                                                        ("rnn", "LSTM", "predator_prey", 32),
+                                                        # hid 64: the LSTM baseline's backward runs on its kernel stand-in (fused launches)
+                                                        ("rnn", "LSTM", "predator_prey", 64), ("rnn", "LSTM", "traffic_junction", 64)])
+def test_native_update_of_the_baselines_matches_autograd(kind, rnn_type, env_name, hid):
     """IC / IRIC baselines (models.py:8-97): the graph-free update (bptt._backward_episode_baseline, round 4) against
     loss.backward() through the autograd rollout replaying the same actions — detach_gap cuts inside the episode, entropy
     term and reward normalisation on."""
     from ic3net_amd import bptt, data, models, trainer as trmod
     from ic3net_amd.action_utils import parse_action_args
     T, E = 12, 9
-    flags = dict(nagents=3, dim=5, vision=1, hid_size=32, recurrent=(kind == "rnn"), rnn_type=rnn_type, detach_gap=5,
+    flags = dict(nagents=3, dim=5, vision=1, hid_size=hid, recurrent=(kind == "rnn"), rnn_type=rnn_type, detach_gap=5,
                  mean_ratio=0.5, gamma=0.95, normalize_rewards=True, entr=0.01, value_coeff=0.01)
     if env_name == "traffic_junction":
         flags.update(nagents=5, dim=6, difficulty='easy', add_rate_min=0.4, add_rate_max=0.4)
