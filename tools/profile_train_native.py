@@ -1,5 +1,5 @@
 """Where one native update (Trainer.train_batch, ic3net_amd.bptt) spends its GPU time: kernel table of one update after
-warm-up.  python tools/profile_train_native.py [nenvs]"""
+warm-up.  python tools/profile_train_native.py [nenvs] [workload]"""
 import os
 import sys
 
@@ -9,7 +9,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-tr, a = bench.build_trainer('pp_hard', E, 0, 0, 0)
+WL = sys.argv[2] if len(sys.argv) > 2 else 'pp_hard'
+tr, a = bench.build_trainer(WL, E, 0, 0, 0)
 a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                   batch_size=E * a.max_steps)
 if os.environ.get('TUNE', '1') == '1':
