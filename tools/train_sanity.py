@@ -12,11 +12,12 @@ import bench
 
 def main():
     updates = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    mode = sys.argv[2] if len(sys.argv) > 2 else 'native'        # native: ic3net_amd.bptt (default path) | autograd
+    mode = sys.argv[2] if len(sys.argv) > 2 else 'native'        # native: ic3net_amd.bptt (default path) | native_recompute | autograd
     bench.WORKLOADS['pp_easy_train'] = ('predator_prey', dict(nagents=3, dim=5, vision=0, max_steps=20, hid_size=128,
                                                             ic3net=True, recurrent=True, detach_gap=10, mode='mixed'))
     tr, a = bench.build_trainer('pp_easy_train', 400, 1, 0, 0)
-    a.native_update = mode == 'native'
+    a.native_update = mode != 'autograd'
+    a.record_gates = mode != 'native_recompute'   # (native: the rollout records its gates / inp rows for the backward, round 5)
     print("update path: %s (native supported: %s)" % (mode, tr._native_update()), flush=True)
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=400 * 20, lrate=0.001)
