@@ -776,8 +776,9 @@ def test_native_update_records_the_recurrent_state_in_place():
         assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k
 
 
-@pytest.mark.parametrize("wl,collect", [("pp_hard", False), ("tj_medium", False), ("pp_hard", True), ("pp_hard_iric", False)])
-def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect):
+@pytest.mark.parametrize("wl,collect,hid", [("pp_hard", False, 128), ("tj_medium", False, 128), ("pp_hard", True, 128),
+                                            ("pp_hard_iric", False, 128), ("tj_hard", False, 64), ("pp_easy", False, 32)])
+def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect, hid):
     """Round 5: every step launch of a recorded rollout stores its cell's activated gates in the episode record
     (ic3_env_set_record_out) and the backward reads them (ic3_lstm_gates_backward_given) instead of running the gate product
     again: same rollout bit for bit, the recorded gates reproduce the recorded next state, and the gradients equal the
@@ -786,7 +787,7 @@ def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect):
     import bench
     out = []
     for record in (True, False):
-        tr, a = bench.build_trainer(wl, 12, 3, 0, 0)
+        tr, a = bench.build_trainer(wl, 12, 3, 0, 0, hid_size=hid)    # (hid 32: the zero-padded twin at 64 keeps the record)
         a.max_steps, a.batch_size = 10, 12 * 10
         a.entr, a.value_coeff, a.gamma, a.normalize_rewards, a.advantages_per_action = 0.01, 0.01, 1.0, False, False
         a.record_gates = record
