@@ -57,14 +57,23 @@ __device__ __forceinline__ gb_f32x4 gb_load4(__amdgpu_buffer_rsrc_t r, int voff,
 {
     return __builtin_bit_cast(gb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+template <int AUX = 0>
 __device__ __forceinline__ float gb_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void gb_store1(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, AUX);
 }
+// cache policy of the streams of the GIVEN instantiation (read once / written once per launch, 0.66 GB per PP-hard step, next to
+// 0.8 MB of weight planes every tile re-reads from L2): IC3_GB_NT bit 0 = the loads, bit 1 = the stores non-temporal.
+// A/B inside a PP-hard update (tools/exp/gbnt_ab.sh, profiles/r05/gates_given_nt_ab.txt): 94.7 / 94.2 / 94.0 / 93.5 M
+// agent-steps/s for 0 / 1 / 2 / 3 — nothing to gain, 0 stays
+#ifndef IC3_GB_NT
+#define IC3_GB_NT 0
+#endif
 
 // The accumulators are pinned to AGPRs (tools/exp/ws_probe.hip: an fp32 MFMA stream with AGPR accumulators ran 153
 // instead of 141 TFLOP/s in isolation; this kernel: 266 instead of 280 us per call in tools/exp/microbench_gates_bwd.py,
@@ -301,12 +310,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-            dhv[reg] = gb_load1(rdh, voff, lc * H * 4);
-            dcv[reg] = gb_load1(rdc, voff, lc * H * 4);
-            if constexpr (SPLIT != 0) cold[rt][reg] = gb_load1(rc, voff, lc * H * 4);
+            constexpr int LA = (GIVEN != 0 && (IC3_GB_NT & 1)) ? 2 : 0;
+            dhv[reg] = gb_load1<LA>(rdh, voff, lc * H * 4);
+            dcv[reg] = gb_load1<LA>(rdc, voff, lc * H * 4);
+            if constexpr (SPLIT != 0) cold[rt][reg] = gb_load1<LA>(rc, voff, lc * H * 4);
             if constexpr (GIVEN != 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gin[k][reg] = gb_load1(rgin, goff, lc * 4 * H * 4 + k * H * 4);
+                for (int k = 0; k < 4; ++k) gin[k][reg] = gb_load1<LA>(rgin, goff, lc * 4 * H * 4 + k * H * 4);
             }
         }
 #pragma unroll
@@ -324,11 +334,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             const float dct = dcv[reg] + dhv[reg] * o * (1.0f - tc * tc);
             const float di = dct * gt * i * (1.0f - i), df = dct * c0 * f * (1.0f - f);
             const float dg = dct * i * (1.0f - gt * gt), dO = dhv[reg] * tc * o * (1.0f - o);
-            gb_store1(di, rdg, goff, lc * 4 * H * 4);
-            gb_store1(df, rdg, goff, lc * 4 * H * 4 + H * 4);
-            gb_store1(dg, rdg, goff, lc * 4 * H * 4 + 2 * H * 4);
-            gb_store1(dO, rdg, goff, lc * 4 * H * 4 + 3 * H * 4);
-            gb_store1(dct * f, rdp, voff, lc * H * 4);
+            constexpr int SA = (GIVEN != 0 && (IC3_GB_NT & 2)) ? 2 : 0;
+            gb_store1<SA>(di, rdg, goff, lc * 4 * H * 4);
+            gb_store1<SA>(df, rdg, goff, lc * 4 * H * 4 + H * 4);
+            gb_store1<SA>(dg, rdg, goff, lc * 4 * H * 4 + 2 * H * 4);
+            gb_store1<SA>(dO, rdg, goff, lc * 4 * H * 4 + 3 * H * 4);
+            gb_store1<SA>(dct * f, rdp, voff, lc * H * 4);
             if constexpr (SPLIT != 0) {
                 if (dx) {                                            // K-half 0 of dgates (gates i, f) -> the A tile; g, o wait in registers
                     const int lr = lc + 4 * lh;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                        gb_store1(acc[rt][ct][reg], rdx, (lr * K + 64 * w + 32 * ct + li) * 4, 0);
+                        gb_store1<(GIVEN != 0 && (IC3_GB_NT & 2)) ? 2 : 0>(acc[rt][ct][reg], rdx, (lr * K + 64 * w + 32 * ct + li) * 4, 0);
                     }
         }
     }
