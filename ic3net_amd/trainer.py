@@ -562,8 +562,10 @@ class Trainer(object):
     def _static_out(self, t, state):
         """hipGraph mode: the launch's [log-probs | value] rows of every step index live in one static buffer, so a captured
         step allocates nothing (allocator traffic inside a capture is avoidable risk — it is what moved the failing step of
-        the garbage-collection problem described in step_episode from 53 to 66).  Eager mode: None (a fresh tensor per
-        call, a Transition keeps its action_out)."""
+        the garbage-collection problem described in step_episode from 53 to 66).  The buffer is shared by ALL episodes
+        played in graph mode: action_out / value of a Transition are views of it and are overwritten by the next episode —
+        graph-mode rollouts feed statistics, never an update (_use_graph() is False while records are collected, and
+        compute_grad refuses a no-grad batch).  Eager mode: None (a fresh tensor per call, a Transition keeps its action_out)."""
         if not self._use_graph():
             return None
         args = self.args
