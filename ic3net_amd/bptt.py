@@ -493,48 +493,80 @@ def _backward_episode_commnet(args, net, raw, rec, d_out, acc):
     Cw = [m.weight.detach() for m in net.C_modules]               # (H, H): y = v C^T
     Fw = [m.weight.detach() for m in net.f_modules]
     bias = cn['bias']                                             # (P, H) = C_i.bias + f_i.bias
-    x, enc = z(R, H), z(R, H)
+    enc = z(R, H)
     hs = [z(R, H) for _ in range(P + 1)]
+    x = hs[0]                                                     # h_0 = x = tanh(encoder(obs))
     comm = [z(E, N, H) for _ in range(P)]
     dz, dh, dx, tmp, mixed = z(R, H), z(R, H), z(R, H), z(R, H), z(E, N, H)
     w_heads = cn['w_heads']
+    tanh_bwd = torch.ops.aten.tanh_backward.grad_input            # grad (1 - out^2) in one launch
+    # the H x H weight gradients have K = R: as NB products over row blocks, summed behind the loop, they fill the chip
+    # (as in backward_episode)
+    NB = 32 if R % 32 == 0 and R >= 8192 else 1
+    fpart = [torch.zeros((NB, H, H), dtype=torch.float32, device=dev) for _ in range(P)] if NB > 1 else None
+    cpart = [torch.zeros((NB, H, H), dtype=torch.float32, device=dev) for _ in range(P)] if NB > 1 and not mask_zero else None
+    blk = lambda v: v.view(NB, R // NB, H)
+    enc_acc = None        # None: nothing accumulated yet; True: partial sums hold the steps so far; False: per-step form
     for t in reversed(range(T)):
         alive, gate = rec.alive[t], rec.gate[t]
         # ---- forward of step t again
         raw.encode_at(rec.snaps[t], cn['wt'], cn['enc_bias'], out=enc, loc_table=cn['loc_table'])
         torch.tanh(enc, out=x)
-        hs[0].copy_(x)
         for i in range(P):
             if mask_zero:
                 comm[i].zero_()
             else:
                 ops.comm_masked_mean_raw(hs[i].view(E, N, H), alive, gate, mode_avg, True, out=comm[i])
-            torch.addmm(bias[i], hs[i], Fw[i].t(), out=tmp)       # f_i(h_i) + both biases
-            tmp.addmm_(comm[i].view(R, H), Cw[i].t())             # + C_i(comm_i)
-            torch.add(tmp, x, out=tmp)
+            torch.add(x, bias[i], out=tmp)                        # x + both biases
+            tmp.addmm_(hs[i], Fw[i].t())                          # + f_i(h_i)
+            if not mask_zero:
+                tmp.addmm_(comm[i].view(R, H), Cw[i].t())         # + C_i(comm_i)
             torch.tanh(tmp, out=hs[i + 1])
         # ---- backward: heads, then the passes last to first
         d = d_out[t]
         acc['w_heads'].addmm_(d.t(), hs[P])
         acc['b_heads'].add_(d.sum(0))
         torch.mm(d, w_heads, out=dh)
-        dx.zero_()
         for i in reversed(range(P)):
-            torch.addcmul(dh, dh, hs[i + 1] * hs[i + 1], value=-1.0, out=dz)      # dh (1 - h^2)
-            dx.add_(dz)
-            acc['f_w'][i].addmm_(dz.t(), hs[i])
+            tanh_bwd(dh, hs[i + 1], grad_input=dz)                # dh (1 - h^2)
+            if i == P - 1:
+                dx.copy_(dz)
+            else:
+                dx.add_(dz)
+            if NB > 1:
+                fpart[i].baddbmm_(blk(dz).transpose(1, 2), blk(hs[i]))
+            else:
+                acc['f_w'][i].addmm_(dz.t(), hs[i])
             acc['cf_b'][i].add_(dz.sum(0))
             torch.mm(dz, Fw[i], out=dh)
             if not mask_zero:
-                acc['c_w_p'][i].addmm_(dz.t(), comm[i].view(R, H))
+                if NB > 1:
+                    cpart[i].baddbmm_(blk(dz).transpose(1, 2), blk(comm[i].view(R, H)))
+                else:
+                    acc['c_w_p'][i].addmm_(dz.t(), comm[i].view(R, H))
                 torch.mm(dz, Cw[i], out=tmp)
-                ops.comm_masked_mean_raw(tmp.view(E, N, H), alive, gate, mode_avg, True, out=mixed)
-                dh.add_(mixed.view(R, H))
+                # dh += mix(dz C_i): the mixing matrix is symmetric — the same kernel on the gradient, the addend along
+                ops.comm_masked_mean_raw(tmp.view(E, N, H), alive, gate, mode_avg, True, out=mixed, addend=dh)
+                dh, mixed = mixed.view(R, H), dh.view(E, N, H)
         dx.add_(dh)                                               # h_0 = x
-        torch.addcmul(dx, dx, x * x, value=-1.0, out=tmp)         # through x = tanh(enc)
-        dwt, db = raw.encode_backward(tmp, rec.snaps[t], want_bias=True)
+        tanh_bwd(dx, x, grad_input=tmp)                           # through x = tanh(enc)
+        # encoder: the first stage per step adds to partial sums, the expansion runs once behind the loop (as in backward_episode)
+        if enc_acc is not False:
+            enc_acc = raw.encode_backward_accumulate(tmp, rec.snaps[t], first=(enc_acc is None)) \
+                if hasattr(raw, 'encode_backward_accumulate') else False
+        if enc_acc is False:
+            dwt, db = raw.encode_backward(tmp, rec.snaps[t], want_bias=True)
+            acc['wt'].add_(dwt)
+            acc['enc_bias'].add_(db)
+    if enc_acc:
+        dwt, db = raw.encode_backward_finish(H, want_bias=True)
         acc['wt'].add_(dwt)
         acc['enc_bias'].add_(db)
+    if NB > 1:
+        for i in range(P):
+            acc['f_w'][i].add_(fpart[i].sum(0))
+            if cpart is not None:
+                acc['c_w_p'][i].add_(cpart[i].sum(0))
 
 
 def standin_for_backward(args, net, rec=None):
