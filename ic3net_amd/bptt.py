@@ -648,6 +648,11 @@ def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
     else:
         A2, b2 = net.affine2.weight.detach(), net.affine2.bias.detach()
         x1, hcur = z(R, H), z(R, H)
+    tanh_bwd = torch.ops.aten.tanh_backward.grad_input            # grad (1 - out^2) in one launch
+    NB = 32 if R % 32 == 0 and R >= 8192 else 1                   # affine2's weight gradient (K = R) as row-block products
+    a2part = torch.zeros((NB, H, H), dtype=torch.float32, device=dev) if NB > 1 and not lstm else None
+    blk = lambda v: v.view(NB, R // NB, H)
+    enc_acc = None
     for t in reversed(range(T)):
         d = d_out[t]
         raw.encode_at(rec.snaps[t], wt, b1, out=enc)              # affine1(obs_t)
@@ -659,11 +664,14 @@ def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
             acc['w_heads'].addmm_(d.t(), hcur)
             acc['b_heads'].add_(d.sum(0))
             torch.mm(d, w_heads, out=dh)
-            torch.addcmul(dh, dh, hcur * hcur, value=-1.0, out=dz)                # through the outer tanh
-            acc['a2_w'].addmm_(dz.t(), x1)
+            tanh_bwd(dh, hcur, grad_input=dz)                                     # through the outer tanh
+            if a2part is not None:
+                a2part.baddbmm_(blk(dz).transpose(1, 2), blk(x1))
+            else:
+                acc['a2_w'].addmm_(dz.t(), x1)
             acc['a2_b'].add_(dz.sum(0))
             torch.addmm(dz, dz, A2, out=dh)                                       # d x1 = dz A2 + dz (the skip)
-            torch.addcmul(dh, dh, x1 * x1, value=-1.0, out=dz)                    # through x1 = tanh(enc)
+            tanh_bwd(dh, x1, grad_input=dz)                                       # through x1 = tanh(enc)
         else:
             if (t + 1) % gap == 0:                                # (h_t, c_t) were handed on detached
                 dh_rec.zero_()
@@ -685,13 +693,26 @@ def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
                 torch.mm(dgates, w_ih, out=dz)                    # d enc
                 torch.mm(dgates, w_hh, out=dh_rec)                # dL/dh_{t-1}
             else:                                                 # ---- RNN, tanh recurrence
-                torch.addcmul(dh, dh, h_t * h_t, value=-1.0, out=dz)
-                acc['a2_w'].addmm_(dz.t(), h_prev)
+                tanh_bwd(dh, h_t, grad_input=dz)
+                if a2part is not None:
+                    a2part.baddbmm_(blk(dz).transpose(1, 2), blk(h_prev))
+                else:
+                    acc['a2_w'].addmm_(dz.t(), h_prev)
                 acc['a2_b'].add_(dz.sum(0))
                 torch.mm(dz, A2, out=dh_rec)
-        dwt, db = raw.encode_backward(dz, rec.snaps[t], want_bias=True)
+        if enc_acc is not False:                                  # first stage per step, the expansion once behind the loop
+            enc_acc = raw.encode_backward_accumulate(dz, rec.snaps[t], first=(enc_acc is None)) \
+                if hasattr(raw, 'encode_backward_accumulate') else False
+        if enc_acc is False:
+            dwt, db = raw.encode_backward(dz, rec.snaps[t], want_bias=True)
+            acc['wt'].add_(dwt)
+            acc['a1_b'].add_(db)
+    if enc_acc:
+        dwt, db = raw.encode_backward_finish(H, want_bias=True)
         acc['wt'].add_(dwt)
         acc['a1_b'].add_(db)
+    if a2part is not None:
+        acc['a2_w'].add_(a2part.sum(0))
 
 
 def new_accumulators(net):

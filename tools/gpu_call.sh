@@ -95,6 +95,7 @@ train)
   timeout 600 python tools/bench_train.py 8192 4 native pp_hard 0 1 1 2>&1 | grep train_batch | tee -a $O/train_batch.txt
   timeout 600 python tools/bench_train.py 1024 4 native pp_hard 2>&1 | grep train_batch | tee -a $O/train_batch.txt
   timeout 600 python tools/bench_train.py 8192 2 native pp_hard_iric 2>&1 | grep train_batch | tee -a $O/train_batch.txt
+  timeout 600 python tools/bench_train.py 8192 2 native pp_hard_ic 2>&1 | grep train_batch | tee -a $O/train_batch.txt
   timeout 600 python tools/profile_train_native.py 8192 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn" > $O/train_profile.txt; tail -3 $O/train_profile.txt ;;
 sh)
   bash -c "$*" 2>&1 | grep -v amdgpu.ids | tee -a $O/log.txt | tail -40 ;;
