@@ -105,15 +105,15 @@ EXPORTS = {
     "ic3_tj_get_add_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ic3_env_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     "ic3_comm_masked_mean": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]),
-    "ic3_comm_masked_mean_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    "ic3_comm_masked_mean_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
                                  + [C.c_int] * 5 + [C.c_void_p]),
     "ic3_lstm_cell": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_lstm_cell_backward": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
     "ic3_policy_pack_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_policy_pack_split_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_lstm_gates_backward_given": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                                C.c_void_p]),
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_env_set_record_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_lstm_gates_backward_dx": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_commnet_forward_supported": (C.c_int, [C.c_int, C.c_int]),

@@ -285,8 +285,17 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         keep_rows = stream['keep'].to(torch.float32).repeat_interleave(N, dim=1).unsqueeze(2)   # (T, R, 1)
         ones_mask = torch.ones((E, N), dtype=torch.int32, device=dev)
         zeros_mask = torch.zeros((E, N), dtype=torch.int32, device=dev)
+    # collection mode on recorded gates: the per-row cuts ride inside the launches that touch the rows anyway
+    # (ic3_lstm_gates_backward_given: row_live, row_keep; ic3_comm_masked_mean_add: out_row_scale) — no passes of their own
+    cut_in_kernel = stream is not None and given
+    if cut_in_kernel:
+        keep_flat = keep_rows.squeeze(2).contiguous()                     # (T, R)
+        live_flat = (1.0 - fresh_rows).contiguous()
+        dh_rec.mul_(keep_rows[T - 1])                                     # what the next window handed over, cut at its border
     for t in reversed(range(T)):
-        if stream is not None:
+        if cut_in_kernel:
+            pass
+        elif stream is not None:
             dh_rec.mul_(keep_rows[t])                                     # the cuts of the env's OWN episode / detach points
             dc_rec.mul_(keep_rows[t])
         elif (t + 1) % gap == 0:                                          # trainer.py:56-60: (h_t, c_t) handed on detached
@@ -297,10 +306,15 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         alive, gate = rec.alive[t], rec.gate[t]
         if stream is not None:
             fr = stream['fresh'][t].unsqueeze(1)                          # (E, 1) the env starts an episode at this slot
-            h_prev.mul_((1.0 - fresh_rows[t]).unsqueeze(1))               # in place: the record is not read again
-            c_prev.mul_((1.0 - fresh_rows[t]).unsqueeze(1))
             alive = torch.where(fr, ones_mask, alive) if alive is not None else None
-            gate = torch.where(fr, zeros_mask, gate) if gate is not None else None
+            if cut_in_kernel:
+                # (the state that entered stays in the record; the launch multiplies it by row_live, and the communication
+                #  block must not see it either: the env's agents are gated off — what zero hidden states amount to)
+                gate = torch.where(fr, zeros_mask, gate if gate is not None else ones_mask)
+            else:
+                h_prev.mul_((1.0 - fresh_rows[t]).unsqueeze(1))           # in place: the record is not read again
+                c_prev.mul_((1.0 - fresh_rows[t]).unsqueeze(1))
+                gate = torch.where(fr, zeros_mask, gate) if gate is not None else None
         # ---- the forward of step t again: enc + C.bias -> inp, comm, gate pre-activations (comm.py:119,181-215)
         if given:                                                         # inp as the step launch stored it; comm for C's gradient
             xh = rec.xh[t]
@@ -324,7 +338,9 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         dh = dh_rec.addmm_(d, fc['w_heads'])
         if given:                                                         # dc_rec <- dL/dc_{t-1}
             ops.lstm_gates_backward_given(rec.gates[t], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True, xh=xh, h_prev=h_prev,
-                                          lstm_wp3_bwd=fc['ps_l_wp3_bwd'], dxh=dxh)
+                                          lstm_wp3_bwd=fc['ps_l_wp3_bwd'], dxh=dxh,
+                                          row_live=live_flat[t] if cut_in_kernel else None,
+                                          row_keep=keep_flat[t] if cut_in_kernel else None)
         elif fused_gates:
             # (the heads' own weight gradient is one pass over the whole episode behind the loop: ic3_heads_grad)
             ops.lstm_gates_backward(xh, fc['ps_l_wp'], fc['b_cat'], c_prev, dh, dc_rec, dgates, dc_rec, bias_parts, True,
@@ -352,7 +368,10 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
                 acc['c_w'].addmm_(dinp.t(), comm.view(R, H))
             torch.mm(dinp, fc['c_wt'].t(), out=dcomm)                     # d comm = d inp . C.weight
             # dL/dh_{t-1} (what step t - 1 receives) = d h of the gate product + the communication block's share, one pass
-            ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dh_rec.view(E, N, H), addend=dxh[:, H:])
+            ops.comm_masked_mean_raw(dcomm.view(E, N, H), alive, gate, mode_avg, True, out=dh_rec.view(E, N, H), addend=dxh[:, H:],
+                                     row_scale=keep_flat[t - 1] if cut_in_kernel and t > 0 else None)
+        elif cut_in_kernel and t > 0:
+            torch.mul(dxh[:, H:], keep_rows[t - 1], out=dh_rec)
         else:
             dh_rec.copy_(dxh[:, H:])
         # encoder: the first stage per step adds to partial sums, the expansion into (obs_dim, H) runs once behind the loop

@@ -46,6 +46,12 @@ struct GatesBwdArgs {
     // ic3_lstm_gates_backward_given (round 5, GIVEN instantiation): the ACTIVATED gates i | f | g | o [R][4H] as the rollout's
     // step launch recorded them (ic3_env_set_gates_out) — no gate product here, only the cell's derivative (+ dx)
     const float* gates;
+    // GIVEN, collection mode (trainer.py:227-242 through :128-225): row_live [R] — 0 for the rows of an env that STARTS an episode
+    // at this slot (the state that entered it counts as zero: c_prev and the h_prev copied into xh are multiplied by it);
+    // row_keep [R] — 0 where the gradient arriving from the next slot must not cross (episode end / detach point): dc times it.
+    // null = all ones
+    const float* row_live;
+    const float* row_keep;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gb_rsrc(const void* base, long long bytes)
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 #pragma unroll
             for (int i = 0; i < PERH; ++i) {
                 const int idx = tid + i * NT, row = idx / H4, c4 = idx - row * H4;
-                const gb_f32x4 v = gb_load4(rhp, (row * H + 4 * c4) * 4, 0);
+                gb_f32x4 v = gb_load4(rhp, (row * H + 4 * c4) * 4, 0);
+                if (a.row_live) v *= (row < rows ? a.row_live[r0 + row] : 0.0f);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gb_u32x4, v), rx, (row * a.ldx + H + 4 * c4) * 4, 0, 0);
             }
         }
@@ -303,6 +310,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     const __amdgpu_buffer_rsrc_t rdg = gb_rsrc(a.dgates + r0 * 4 * H, 4 * nrec);
     const int goff = (4 * lh * 4 * H + col) * 4;
     const __amdgpu_buffer_rsrc_t rgin = gb_rsrc(GIVEN ? a.gates + r0 * 4 * H : a.dh, GIVEN ? 4 * nrec : 0);
+    const bool cuts = GIVEN != 0 && (a.row_live != nullptr || a.row_keep != nullptr);
+    const __amdgpu_buffer_rsrc_t rlive = gb_rsrc(a.row_live ? a.row_live + r0 : a.dh, a.row_live ? (long long)rows * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rkeep = gb_rsrc(a.row_keep ? a.row_keep + r0 : a.dh, a.row_keep ? (long long)rows * 4 : 0);
     float si = 0.f, sf = 0.f, sg = 0.f, so = 0.f;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -325,6 +335,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             float i, f, gt, o;
             if constexpr (GIVEN != 0) {
                 i = gin[0][reg], f = gin[1][reg], gt = gin[2][reg], o = gin[3][reg];
+                if (cuts) {                                          // (uniform) collection mode: the slot's per-row cuts
+                    const int lrow = lc + 4 * lh;
+                    if (a.row_live) cold[rt][reg] *= gb_load1(rlive, lrow * 4, 0);
+                    if (a.row_keep) dcv[reg] *= gb_load1(rkeep, lrow * 4, 0);
+                }
             } else {
                 i = fast_sigmoid(acc[rt][0][reg] + bi), f = fast_sigmoid(acc[rt][1][reg] + bf);
                 gt = fast_tanh(acc[rt][2][reg] + bg), o = fast_sigmoid(acc[rt][3][reg] + bo);
@@ -460,7 +475,7 @@ extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H ==
 static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
                                const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
                                float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream,
-                               const float* gates = nullptr);
+                               const float* gates = nullptr, const float* row_live = nullptr, const float* row_keep = nullptr);
 
 extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias, const float* c_prev,
                                        const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
@@ -484,22 +499,24 @@ extern "C" int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_pre
 
 extern "C" int ic3_lstm_gates_backward_given(const float* gates, float* xh, int ldx, const float* h_prev, const void* lstm_wp3_bwd,
                                              const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
-                                             float* dbias_partials, int accumulate, float* dxh, int R, int H, ic3_stream stream)
+                                             float* dbias_partials, int accumulate, float* dxh, const float* row_live,
+                                             const float* row_keep, int R, int H, ic3_stream stream)
 {
     if (!gates) return ic3::fail(-22, "ic3_lstm_gates_backward_given: null gates");
+    if (row_keep && !dc) return ic3::fail(-22, "ic3_lstm_gates_backward_given: row_keep scales dc");
     if ((lstm_wp3_bwd == nullptr) != (dxh == nullptr))
         return ic3::fail(-22, "ic3_lstm_gates_backward_given: lstm_wp3_bwd and dxh come together");
     if (H != 64 && H != 128) return ic3::fail(-38, "ic3_lstm_gates_backward_given: hid_size 64 / 128");
     if ((xh == nullptr) != (h_prev == nullptr))
         return ic3::fail(-22, "ic3_lstm_gates_backward_given: xh and h_prev come together (the copy into xh's h half) or not at all");
     return gates_backward_impl(xh, xh ? ldx : 2 * H, h_prev, nullptr, nullptr, nullptr, c_prev, dh, dc, dgates, dc_prev, dbias_partials,
-                               accumulate, lstm_wp3_bwd, dxh, R, H, stream, gates);
+                               accumulate, lstm_wp3_bwd, dxh, R, H, stream, gates, row_live, row_keep);
 }
 
 static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
                                const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
                                float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream,
-                               const float* gates)
+                               const float* gates, const float* row_live, const float* row_keep)
 {
     using namespace ic3;
     if ((!gates && (!xh || !lstm_wp || !bias)) || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
@@ -508,7 +525,7 @@ static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const fl
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
     if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
         return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
-    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh, gates };
+    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh, gates, row_live, row_keep };
     const int tiles = (R + 63) / 64;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;

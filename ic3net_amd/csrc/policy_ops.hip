@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
                                                                const int32_t* __restrict__ comm_action,
                                                                float* __restrict__ out, int E, int N, int H4,
                                                                int mode_avg, int mask_self,
-                                                               const float* __restrict__ addend = nullptr, int lda = 0)
+                                                               const float* __restrict__ addend = nullptr, int lda = 0,
+                                                               const float* __restrict__ out_scale = nullptr)
 {
     const int per_block = blockDim.x / H4;
     const int e = blockIdx.x * per_block + threadIdx.x / H4;
@@ -42,8 +43,11 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
     auto add = [&](int j) {
         return addend ? *reinterpret_cast<const f32x4*>(addend + ((size_t)e * N + j) * lda + 4 * k) : f32x4{ 0.f, 0.f, 0.f, 0.f };
     };
+    // out_scale [E*N] (with addend only): every output row times its factor — the update half's collection mode drops the
+    // gradient that would cross an episode boundary right where it is produced
+    auto sc = [&](int j) { return out_scale ? out_scale[(size_t)e * N + j] : 1.0f; };
     if (!mask_self) {  // comm_mask_zero: comm.py:40-41 -> all-zero communication
-        for (int j = 0; j < N; ++j) oe[(size_t)j * H4] = add(j);
+        for (int j = 0; j < N; ++j) oe[(size_t)j * H4] = out_scale ? add(j) * sc(j) : add(j);
         return;
     }
     f32x4 S = { 0.f, 0.f, 0.f, 0.f };
@@ -68,7 +72,10 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
             if (i < N) S += mm[i] * hv[i];
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-            if (j < N) oe[(size_t)j * H4] = addend ? add(j) + mm[j] * (S - mm[j] * hv[j]) * scale : mm[j] * (S - mm[j] * hv[j]) * scale;
+            if (j < N) {
+                const f32x4 v = addend ? add(j) + mm[j] * (S - mm[j] * hv[j]) * scale : mm[j] * (S - mm[j] * hv[j]) * scale;
+                oe[(size_t)j * H4] = out_scale ? v * sc(j) : v;
+            }
         return;
     }
     for (int i = 0; i < N; ++i) {
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
         const float m = (float)((alive ? alive[(size_t)e * N + j] : 1) *
                                 (comm_action ? comm_action[(size_t)e * N + j] : 1));
         const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + j) * ldh + 4 * k);
-        oe[(size_t)j * H4] = addend ? add(j) + m * (S - m * hv) * scale : m * (S - m * hv) * scale;
+        const f32x4 v = addend ? add(j) + m * (S - m * hv) * scale : m * (S - m * hv) * scale;
+        oe[(size_t)j * H4] = out_scale ? v * sc(j) : v;
     }
 }
 
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* __restrict
 
 static int comm_masked_mean_launch(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, const float* addend,
                                    int lda, float* out, int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream,
-                                   const char* who)
+                                   const char* who, const float* out_scale = nullptr)
 {
     if (!h || !out || E <= 0 || N <= 0 || H <= 0) return ic3::fail(-22, std::string(who) + ": bad arguments");
     if (ldh <= 0) ldh = H;
@@ -449,15 +457,15 @@ static int comm_masked_mean_launch(const float* h, int ldh, const int32_t* alive
         hipStream_t s = (hipStream_t)stream;
         if (N <= 16)
             hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<16>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
-                               H4, mode_avg, mask_self, addend, lda);
+                               H4, mode_avg, mask_self, addend, lda, out_scale);
         else if (N <= 32)
             hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<32>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
-                               H4, mode_avg, mask_self, addend, lda);
+                               H4, mode_avg, mask_self, addend, lda, out_scale);
         else
             hipLaunchKernelGGL(ic3::comm_masked_mean_kernel<0>, grid, dim3(256), 0, s, h, ldh, alive, comm_action, out, E, N,
-                               H4, mode_avg, mask_self, addend, lda);
+                               H4, mode_avg, mask_self, addend, lda, out_scale);
     } else {
-        if (addend) return ic3::fail(-38, std::string(who) + ": H, ldh and lda must be multiples of 4");
+        if (addend || out_scale) return ic3::fail(-38, std::string(who) + ": H, ldh and lda must be multiples of 4");
         const int threads = H >= 256 ? 256 : ((H + 63) / 64) * 64;
         hipLaunchKernelGGL(ic3::comm_masked_mean_scalar_kernel, dim3(E), dim3(threads), 0, (hipStream_t)stream, h, ldh,
                            alive, comm_action, out, N, H, mode_avg, mask_self);
@@ -474,12 +482,12 @@ extern "C" int ic3_comm_masked_mean(const float* h, int ldh, const int32_t* aliv
 }
 
 extern "C" int ic3_comm_masked_mean_add(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action,
-                                        const float* addend, int lda, float* out, int E, int N, int H, int mode_avg,
-                                        int mask_self, ic3_stream stream)
+                                        const float* addend, int lda, const float* out_row_scale, float* out, int E, int N, int H,
+                                        int mode_avg, int mask_self, ic3_stream stream)
 {
     if (!addend) return ic3::fail(-22, "ic3_comm_masked_mean_add: null addend");
     return comm_masked_mean_launch(h, ldh, alive, comm_action, addend, lda, out, E, N, H, mode_avg, mask_self, stream,
-                                   "ic3_comm_masked_mean_add");
+                                   "ic3_comm_masked_mean_add", out_row_scale);
 }
 
 extern "C" int ic3_lstm_cell(const float* gates, float* c, float* h_out, int ldh, int R, int H, ic3_stream stream)

@@ -64,9 +64,10 @@ def _rows(t, H):
     return t, H
 
 
-def comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self, out=None, addend=None):
+def comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self, out=None, addend=None, row_scale=None):
     """The kernel launch without autograd: h (E,N,H) rows may be a strided column slice; `out` (E,N,H) contiguous.
-    `addend` (E*N,H) / (E,N,H) rows (a strided column slice is fine): out = addend + comm(h) (ic3_comm_masked_mean_add)."""
+    `addend` (E*N,H) / (E,N,H) rows (a strided column slice is fine): out = addend + comm(h) (ic3_comm_masked_mean_add);
+    `row_scale` (E*N,) float32 with it: every output row times its factor."""
     _need_cuda(h, "comm_masked_mean")
     E, N, H = h.shape
     hk, ldh = _rows(h, H)
@@ -74,9 +75,13 @@ def comm_masked_mean_raw(h, alive, comm_action, mode_avg, mask_self, out=None, a
         out = torch.empty((E, N, H), dtype=torch.float32, device=h.device)
     if addend is not None:
         ak, lda = _rows(addend, H)
-        check(_lib.lib().ic3_comm_masked_mean_add(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(ak), lda, ptr(out), E, N, H,
+        if row_scale is not None:
+            assert row_scale.is_contiguous() and row_scale.dtype == torch.float32 and row_scale.numel() == E * N
+        check(_lib.lib().ic3_comm_masked_mean_add(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(ak), lda,
+                                                  ptr(row_scale) if row_scale is not None else None, ptr(out), E, N, H,
                                                   int(mode_avg), int(mask_self), stream()))
         return out
+    assert row_scale is None, "row_scale comes with an addend"
     check(_lib.lib().ic3_comm_masked_mean(ptr(hk), ldh, ptr(alive), ptr(comm_action), ptr(out), E, N, H,
                                           int(mode_avg), int(mask_self), stream()))
     return out
@@ -215,11 +220,19 @@ def lstm_gates_backward(xh, lstm_wp, bias, c_prev, dh, dc, dgates, dc_prev, dbia
     return n
 
 
+def _rowvec(v, R):
+    if v is None:
+        return None
+    assert v.is_contiguous() and v.dtype == torch.float32 and v.numel() == R
+    return ptr(v)
+
+
 def lstm_gates_backward_given(gates, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None, accumulate=False, xh=None,
-                              h_prev=None, lstm_wp3_bwd=None, dxh=None):
+                              h_prev=None, lstm_wp3_bwd=None, dxh=None, row_live=None, row_keep=None):
     """The cell's derivative from the RECORDED activated gates (R, 4H) of the step (ic3_lstm_gates_backward_given; the
     rollout's launch stored them: envs.set_record_out) — no gate product.  xh + h_prev: h_prev is copied into the h half of xh;
-    lstm_wp3_bwd + dxh: [d inp | d h_prev] in the same launch."""
+    lstm_wp3_bwd + dxh: [d inp | d h_prev] in the same launch.  row_live / row_keep (R,) float32 (collection mode): c_prev and
+    the copied h_prev times row_live, dc times row_keep, per row."""
     _need_cuda(gates, "lstm_gates_backward_given")
     R, H = c_prev.shape
     for t in (gates, c_prev, dh, dgates, dc_prev):
@@ -238,7 +251,8 @@ def lstm_gates_backward_given(gates, c_prev, dh, dc, dgates, dc_prev, dbias_part
                                                  ptr(lstm_wp3_bwd) if dxh is not None else None, ptr(c_prev), ptr(dh),
                                                  ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
                                                  ptr(dbias_partials) if dbias_partials is not None else None,
-                                                 int(bool(accumulate)), ptr(dxh) if dxh is not None else None, R, H, stream())
+                                                 int(bool(accumulate)), ptr(dxh) if dxh is not None else None,
+                                                 _rowvec(row_live, R), _rowvec(row_keep, R), R, H, stream())
     if n < 0:
         check(n)
     return n

@@ -294,10 +294,12 @@ int ic3_comm_masked_mean(const float* h, int ldh /* h row stride in floats, 0 = 
                          ic3_stream stream);
 /* The same block with an addend: out = addend + comm(h) — the backward of the communication block is the block itself applied
  * to the gradient (its mixing matrix is symmetric), and what it is added to (dL/dh of the recurrent path) comes along in the
- * same pass.  addend [E*N][H] rows with stride lda floats (0 = H; may be a column slice of a wider buffer).  H, ldh, lda
- * multiples of 4. */
+ * same pass.  addend [E*N][H] rows with stride lda floats (0 = H; may be a column slice of a wider buffer).  out_row_scale
+ * [E*N] or NULL: every output row times its factor (collection mode, trainer.py:227-242 through :128-225: the gradient that
+ * would cross an episode boundary is dropped where it is produced).  H, ldh, lda multiples of 4. */
 int ic3_comm_masked_mean_add(const float* h, int ldh, const int32_t* alive, const int32_t* comm_action, const float* addend,
-                             int lda, float* out, int E, int N, int H, int mode_avg, int mask_self, ic3_stream stream);
+                             int lda, const float* out_row_scale /* or NULL */, float* out, int E, int N, int H, int mode_avg,
+                             int mask_self, ic3_stream stream);
 
 /* Pointwise half of torch.nn.LSTMCell (comm.py:61,215; gate order i,f,g,o): gates [R][4H] already hold
  * W_ih x + b_ih + W_hh h + b_hh (two fp32 MFMA GEMMs, or one over [x | h]).  c [R][H] is updated in place,
@@ -341,11 +343,15 @@ int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_prev /* or NUL
  * rollout's launch stored them (ic3_env_set_gates_out) — the gate product is not run again (it was the largest item of the
  * update half: 2 * R * 2H * 4H flop x 9 split products per recorded step).  Same outputs as ic3_lstm_gates_backward_dx; xh /
  * h_prev (both or neither): the launch copies h_prev into the h half of xh [R][ldx] for the weight-gradient product that
- * follows; lstm_wp3_bwd / dxh (both or neither): the input gradient in the same launch.  hid_size 64 / 128. */
+ * follows; lstm_wp3_bwd / dxh (both or neither): the input gradient in the same launch.  Collection mode (trainer.py:227-242:
+ * a record slot where some envs start an episode, or after which the recurrent gradient must not pass): row_live [R] or NULL —
+ * c_prev and the copied h_prev of a row are multiplied by it (0 = the env starts an episode at this slot: zero state);
+ * row_keep [R] or NULL — dc of a row is multiplied by it (0 = nothing arrives from the next slot).  hid_size 64 / 128. */
 int ic3_lstm_gates_backward_given(const float* gates, float* xh /* or NULL */, int ldx, const float* h_prev /* or NULL */,
                                   const void* lstm_wp3_bwd /* or NULL */, const float* c_prev, const float* dh,
                                   const float* dc /* or NULL */, float* dgates, float* dc_prev, float* dbias_partials /* or NULL */,
-                                  int accumulate, float* dxh /* or NULL */, int R, int H, ic3_stream stream);
+                                  int accumulate, float* dxh /* or NULL */, const float* row_live /* or NULL */,
+                                  const float* row_keep /* or NULL */, int R, int H, ic3_stream stream);
 /* The weight / bias gradient of the heads + value head over a whole episode in one pass (trainer.py:128-225 through
  * comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o] over the M = steps x rows pairs
  * (d [M][OT], h [M][H]: h_t of every step, i.e. the recorded hidden states shifted by one step).  scratch:

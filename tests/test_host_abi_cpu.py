@@ -243,10 +243,18 @@ def test_comm_masked_mean_add_on_the_host():
     base = np.full((E, N, H), np.nan, np.float32)
     check(lib.ic3_comm_masked_mean(p(h), 0, p(alive), p(gate), p(base), E, N, H, 1, 1, None))
     out = np.full((E, N, H), np.nan, np.float32)
-    check(lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), C.c_void_p(wide.ctypes.data + 4 * H), 2 * H, p(out), E, N, H, 1,
+    check(lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), C.c_void_p(wide.ctypes.data + 4 * H), 2 * H, None, p(out), E, N, H, 1,
                                        1, None))
     np.testing.assert_array_equal(out.reshape(E * N, H), wide[:, H:] + base.reshape(E * N, H))
-    assert lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), None, 0, p(out), E, N, H, 1, 1, None) == -22
+    scale = (rng.random(E * N) < 0.7).astype(np.float32)           # per-row factor (collection mode: 0 across an episode boundary)
+    out2 = np.full((E, N, H), np.nan, np.float32)
+    check(lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), C.c_void_p(wide.ctypes.data + 4 * H), 2 * H, p(scale), p(out2), E, N,
+                                       H, 1, 1, None))
+    np.testing.assert_array_equal(out2.reshape(E * N, H), out.reshape(E * N, H) * scale[:, None])
+    check(lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), C.c_void_p(wide.ctypes.data + 4 * H), 2 * H, p(scale), p(out2), E, N,
+                                       H, 1, 0, None))                    # comm_mask_zero: the scaled addend alone
+    np.testing.assert_array_equal(out2.reshape(E * N, H), wide[:, H:] * scale[:, None])
+    assert lib.ic3_comm_masked_mean_add(p(h), 0, p(alive), p(gate), None, 0, None, p(out), E, N, H, 1, 1, None) == -22
 
 
 def test_stats_and_state_round_trip():

@@ -570,7 +570,7 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
         dg6, dcp6 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
         dxh6, parts6 = np.full((R, 2 * H), np.nan, np.float32), np.full((tiles, 4 * H), np.nan, np.float32)
         n = check(lib.ic3_lstm_gates_backward_given(p(acts), p(xh6), 2 * H, p(h_prev), p(wb3), p(c_prev), p(dh), p(dc), p(dg6), p(dcp6),
-                                                    p(parts6), 0, p(dxh6), R, H, None))
+                                                    p(parts6), 0, p(dxh6), None, None, R, H, None))
         assert n == tiles
         np.testing.assert_array_equal(xh6, wide[:, :2 * H])
         assert np.abs(dg6 - want_g).max() <= 2e-6 * max(1.0, np.abs(want_g).max())
@@ -580,11 +580,30 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
         assert np.abs(dxh6 - want_dx6).max() <= 6e-6 * max(1.0, np.abs(want_dx6).max())
         dg7, dcp7 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
         check(lib.ic3_lstm_gates_backward_given(p(acts), None, 0, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0, None,
-                                                R, H, None))                      # (pointwise only: no copy, no dx)
+                                                None, None, R, H, None))          # (pointwise only: no copy, no dx)
         np.testing.assert_array_equal(dg7, dg6)
         np.testing.assert_array_equal(dcp7, dcp6)
         assert lib.ic3_lstm_gates_backward_given(p(acts), p(xh6), 2 * H, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0,
-                                                 None, R, H, None) == -22
+                                                 None, None, None, R, H, None) == -22
+        # collection mode's per-row cuts: the same launch on pre-multiplied inputs
+        live = (rng.random(R) < 0.7).astype(np.float32)
+        keep = (rng.random(R) < 0.6).astype(np.float32)
+        xh8, xh9 = xh6.copy(), xh6.copy()
+        xh8[:, H:] = np.nan
+        xh9[:, H:] = np.nan
+        outs = []
+        for cut in (True, False):
+            cp = c_prev if cut else f32(c_prev * live[:, None])
+            hp = h_prev if cut else f32(h_prev * live[:, None])
+            dcx = dc if cut else f32(dc * keep[:, None])
+            dg8, dcp8 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
+            dx8 = np.full((R, 2 * H), np.nan, np.float32)
+            xx = xh8 if cut else xh9
+            check(lib.ic3_lstm_gates_backward_given(p(acts), p(xx), 2 * H, p(hp), p(wb3), p(cp), p(dh), p(dcx), p(dg8), p(dcp8), None, 0,
+                                                    p(dx8), p(live) if cut else None, p(keep) if cut else None, R, H, None))
+            outs.append((dg8, dcp8, dx8, xx.copy()))
+        for u, v in zip(*outs):
+            np.testing.assert_array_equal(u, v)
 
 
 def commnet_weights(lib, P, H, heads, passes):

@@ -130,6 +130,10 @@ def test_comm_masked_mean_add_is_the_block_plus_the_addend(E, N, H, avg):
         torch.testing.assert_close(out.view(E * N, H), wide[:, H:] + base.view(E * N, H), rtol=1e-6, atol=1e-6)
     out = ops.comm_masked_mean_raw(h, alive, gate, avg, False, addend=wide[:, H:])     # comm_mask_zero: the addend alone
     assert torch.equal(out.view(E * N, H), wide[:, H:])
+    scale = (torch.rand(E * N, device='cuda', generator=g) < 0.7).float()             # per-row factor (collection mode)
+    plain = ops.comm_masked_mean_raw(h, alive, gate, avg, True, addend=wide[:, H:])
+    cut = ops.comm_masked_mean_raw(h, alive, gate, avg, True, addend=wide[:, H:], row_scale=scale)
+    assert torch.equal(cut.view(E * N, H), plain.view(E * N, H) * scale[:, None])
 
 
 @pytest.mark.parametrize("T,E,N,gamma,ratio", [(20, 33, 3, 1.0, 0.0), (40, 17, 10, 0.95, 0.5), (7, 300, 5, 0.9, 1.0),

@@ -813,12 +813,11 @@ def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect, hid):
                 pre = xh @ W.t() + (fm.bias_ih + fm.bias_hh).detach().double()
                 assert float((torch.sigmoid(pre[..., :H]) - g[..., :H]).abs().max()) <= 2e-6
                 assert float((torch.tanh(pre[..., 2 * H:3 * H]) - g[..., 2 * H:3 * H]).abs().max()) <= 2e-6
-        tr.optimizer.zero_grad()
+        hs_rolled, cs_rolled = rec.hs[:rec.n].clone(), rec.cs[:rec.n].clone()    # (the recomputing backward of collection mode
+        tr.optimizer.zero_grad()                                                  #  zeroes the rows of fresh envs in the record)
         tr.compute_grad_native(batch, recs)
         tr._records = None
-        out.append(({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None},
-                    rec.hs[:rec.n].clone(), rec.cs[:rec.n].clone()))
-    # (the backward in collection mode zeroes the rows of fresh envs in the record: compare what both did the same way)
+        out.append(({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None}, hs_rolled, cs_rolled))
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
     for k in out[0][0]:
         g0, g1 = out[0][0][k], out[1][0][k]
