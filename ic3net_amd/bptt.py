@@ -88,6 +88,13 @@ class EpisodeRecord(object):
         self.gates_n = 0
         self.stream = None     # collection mode (Trainer._run_batch_streams): per-slot cuts of the recurrence, see backward_episode
 
+    def release(self):
+        """Drop the record's tensors now (tens of GB with recorded gates): the update is done with them, and whatever still
+        refers to the record object — a reference cycle waiting for the garbage collector — must not keep them alive beside
+        the next update's record."""
+        self.hs = self.cs = self.gates = self.xh = self.snaps = self.h_last = None
+        self.alive, self.gate, self.stream = [], [], None
+
     def start_from(self, h, c):
         """Collection mode: this window continues the streams of the previous one — the state it ended with is the state
         entering slot 0 (an env that starts an episode there is zeroed inside the step launch, and again in the backward)."""

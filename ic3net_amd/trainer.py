@@ -1055,7 +1055,11 @@ class Trainer(object):
             self._records = None
             self._rec = None
         self.optimizer.zero_grad()
-        s = self.compute_grad_native(batch, records) if native else self.compute_grad(batch)
+        try:
+            s = self.compute_grad_native(batch, records) if native else self.compute_grad(batch)
+        finally:
+            for r in (records or []):
+                r.release()
         del records
         merge_stat(s, stat)
         stat = sharding.allreduce_stats(stat)
