@@ -619,12 +619,10 @@ def standin_for_backward(args, net, rec=None):
 def _backward_episode_standin(net, si, raw, rec, d_out, acc):
     """IRIC (models.RNN, LSTM) through the stand-in's backward; its accumulators are folded into the baseline's by name:
     encoder = affine1, [W_ih | W_hh] / b_ih + b_hh = lstm_unit's, heads; C (all zeros, never read: comm_mask_zero) has none."""
-    H = si.hid_size
     acc2 = acc.get('_standin')
     if acc2 is None:
         acc2 = acc['_standin'] = new_accumulators(si)
-    out = backward_episode(si.args, si, raw, rec, d_out, acc2)
-    return out
+    return backward_episode(si.args, si, raw, rec, d_out, acc2)
 
 
 def fold_standin(acc):

@@ -1107,14 +1107,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             };
             const int ze = obs_here ? a.zepi : 0;
-            bool gs_done = false;
-            if constexpr (SPLIT == 1 && MP == 0 && KIND != 0) {          // (the host arms gates_out for these instantiations only,
-                if (a.gates_out) {                                        //  and leaves the epilogue no zero-store slots then)
-                    cell(std::integral_constant<int, 0>{}, std::true_type{});
-                    gs_done = true;
-                }
-            }
-            if (gs_done) {
+            // (the host arms gates_out for the SPLIT, one-pass, env instantiations only, and leaves the epilogue no zero-store
+            //  slots then)
+            constexpr bool GS_BUILT = SPLIT == 1 && MP == 0 && KIND != 0;
+            if (GS_BUILT && a.gates_out) {
+                if constexpr (GS_BUILT) cell(std::integral_constant<int, 0>{}, std::true_type{});
             } else if (ze <= 0) cell(std::integral_constant<int, 0>{}, std::false_type{});
             else if (ze == 1) cell(std::integral_constant<int, 1>{}, std::false_type{});
             else cell(std::integral_constant<int, 2>{}, std::false_type{});
