@@ -130,5 +130,14 @@ out += ["", "**Other files of the round**", "",
         "of one PP-hard update.",
         "* `mp_ab.txt` — comm_passes > 1 inside one launch against one launch per pass (`tools/exp/mp_ab.sh`).",
         "* `tests_gpu_summary.txt` — tail of `pytest -m gpu` on the final code."]
+out.append("""
+**Update half** (`tools/bench_train.py`, `tools/gpu_call.sh train`): `train_batch.txt` (agent-steps/s of whole updates: lock-step and
+collection mode, obs rows on, E = 1024, the baselines), `train_profile*.txt` (kernel table of one update, torch profiler, GEMMs picked
+by TunableOp), `train_batch_pp_hard_kernel_stats.csv` (rocprofv3 --kernel-trace --stats of 5 PP-hard updates with the library's
+default GEMMs: `policy_step_kernel` 224.8 us x 400 — the training rollout incl. the gate / inp record —, `lstm_gates_bwd_kernel<128, 1, 1>`
+213.4 us x 400), `train_sanity.txt` (IC3Net on PP-easy learns on the recorded-gates update), `soak.txt`, `mp_ab.txt` (comm_passes
+inside one launch), and the A/B files of what was tried and not kept: `gates_given_stagger_experiment.txt`, `gates_given_nt_ab.txt`,
+`bptt_side_stream_ab.txt`; `gates_bwd_dx_hazard_check.txt` (the stale-plane hazard of the asm MFMAs: error and run-to-run check after
+the fix); `host_asan.txt` (the product's device code on the host under ASan + UBSan).""")
 open(os.path.join(dst, 'README.md'), 'w').write("\n".join(out) + "\n")
 print("\n".join(out[:20]))
