@@ -196,7 +196,8 @@ __global__ __launch_bounds__(EF_THREADS) void returns_scan_kernel(const float* _
                 __syncthreads();
                 sh[tid] = valid ? coop : 0.0f;
                 __syncthreads();
-                for (int j = 0; j < N; ++j) mean += sh[el * N + j];   // fixed order
+                const int base = valid ? el * N : 0;                  // (the block's spare threads: el * N + j would leave the array)
+                for (int j = 0; j < N; ++j) mean += sh[base + j];     // fixed order
                 mean *= invN;
             }
             if (valid) returns[(size_t)t * EN + en] = mean_ratio * mean + (1.0f - mean_ratio) * ncoop;

@@ -469,8 +469,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         {
             const int ws = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int first = (64 * (g.c_lo + ws) - g.mis) * 16;     // this wave's first full chunk (>= 0)
-            const float* obody = a.obs + g.ob0 + g.ohead;
-            zr = make_rsrc(obody, (uint32_t)(last ? g.zend : 0));
+            const float* obody = a.obs ? a.obs + g.ob0 + g.ohead : nullptr;    // (no obs rows: an empty descriptor, no arithmetic on null)
+            zr = make_rsrc(obody, (uint32_t)((last && a.obs) ? g.zend : 0));
             zlane = lane * 16;
             zso = __builtin_amdgcn_readfirstlane(first);
         }
