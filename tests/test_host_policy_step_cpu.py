@@ -900,12 +900,16 @@ def test_results_do_not_depend_on_the_lane_schedule():
     sel = ("auto_reset or (free_run_vs and (pp_easy or tj_medium)) or two_communication or commnet_forward or "
            "(golden and (pp_easy_mixed or pp_enemycomm_mixed or tj_easy_v1_full or tj_medium_v0)) or encoder_backward or "
            "cell_backward or finalize")
-    for sched in ("reverse", "shuffle"):                       # shuffle: another pseudo-random order in every round
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"),
-                            os.path.join(here, "test_host_abi_cpu.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
-                           capture_output=True, text=True, env=dict(os.environ, IC3_HOST_SCHED=sched), cwd=os.path.dirname(here))
-        assert r.returncode == 0, sched + r.stdout[-3000:] + r.stderr[-2000:]
-        assert " passed" in r.stdout and "failed" not in r.stdout
+    host_lib()                                                 # (built once, here: the two runs below only load it)
+    procs = [(sched, subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"),
+                                       os.path.join(here, "test_host_abi_cpu.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      env=dict(os.environ, IC3_HOST_SCHED=sched), cwd=os.path.dirname(here)))
+             for sched in ("reverse", "shuffle")]              # shuffle: another pseudo-random order in every round; side by side
+    for sched, pr in procs:
+        out, err = pr.communicate()
+        assert pr.returncode == 0, sched + out[-3000:] + err[-2000:]
+        assert " passed" in out and "failed" not in out
 
 
 def test_wave_specialised_schedule_on_the_host():
@@ -920,11 +924,16 @@ def test_wave_specialised_schedule_on_the_host():
     here = os.path.dirname(os.path.abspath(__file__))
     runs = [("", "gate_split_experiment and tj_hard"),                                    # several tiles per workgroup, small tile first
             ("shuffle", "free_run_vs and pp_easy")]                                      # hid 64, another lane order every round
-    for sched, sel in runs:
+    host_lib()
+    procs = []
+    for sched, sel in runs:                                    # side by side
         env = dict(os.environ, IC3_PS_WS="1", IC3_HOST_FORCE_SPLIT="1")
         if sched:
             env["IC3_HOST_SCHED"] = sched
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"), "-q", "-x", "-p",
-                            "no:cacheprovider", "-k", sel], capture_output=True, text=True, env=env, cwd=os.path.dirname(here))
-        assert r.returncode == 0, sched + r.stdout[-3000:] + r.stderr[-2000:]
-        assert " passed" in r.stdout and "failed" not in r.stdout
+        procs.append((sched, subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"), "-q",
+                                               "-x", "-p", "no:cacheprovider", "-k", sel], stdout=subprocess.PIPE,
+                                              stderr=subprocess.PIPE, text=True, env=env, cwd=os.path.dirname(here))))
+    for sched, pr in procs:
+        out, err = pr.communicate()
+        assert pr.returncode == 0, sched + out[-3000:] + err[-2000:]
+        assert " passed" in out and "failed" not in out
