@@ -9,7 +9,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("IC3_ROLLOUT_LIB") or os.path.join(_HERE, "csrc", "libic3rollout.so")   # (override: A/B builds)
 
-ABI_VERSION = 500        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
+ABI_VERSION = 600        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
 ENV_PP, ENV_TJ = 1, 2
 PP_MODES = {"mixed": 0, "cooperative": 1, "competitive": 2}
 TJ_DIFFICULTY = {"easy": 0, "medium": 1, "hard": 2}
@@ -67,6 +67,17 @@ class Episode(C.Structure):
         self.struct_size = C.sizeof(self)
 
 
+class Bptt(C.Structure):
+    """ic3_bptt (include/ic3_rollout.h): one window of the recorded-gates backward through time."""
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("T", "E", "N", "H", "OT", "mode_avg", "comm_zero",
+                                                                        "detach_gap", "enc_first")] + \
+               [("gates", C.c_void_p), ("hs", C.c_void_p), ("cs", C.c_void_p), ("dhead", C.c_void_p), ("snaps", C.c_void_p),
+                ("snap_words", C.c_int64), ("alive", C.POINTER(C.c_void_p)), ("gate", C.POINTER(C.c_void_p)),
+                ("row_live", C.c_void_p), ("row_keep", C.c_void_p), ("lstm_wp3_bwd", C.c_void_p), ("w_heads", C.c_void_p),
+                ("c_weight", C.c_void_p), ("dh", C.c_void_p), ("dc", C.c_void_p), ("dxh", C.c_void_p),
+                ("dbias_partials", C.c_void_p), ("dcw_partials", C.c_void_p), ("enc_work", C.c_void_p)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "ic3_version": (C.c_int, []),
@@ -113,7 +124,14 @@ EXPORTS = {
     "ic3_policy_pack_split_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ic3_lstm_gates_backward_given": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                                C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ic3_comm_backward_partials": (C.c_int, [C.c_int, C.c_int]),
+    "ic3_comm_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]),
+    "ic3_lstm_weight_grad_scratch_floats": (C.c_size_t, [C.c_longlong, C.c_int]),
+    "ic3_lstm_weight_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
+    "ic3_bptt_backward_supported": (C.c_int, [C.c_void_p, C.c_int]),
+    "ic3_bptt_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_set_record_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_lstm_gates_backward_dx": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_commnet_forward_supported": (C.c_int, [C.c_int, C.c_int]),

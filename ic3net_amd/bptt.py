@@ -266,6 +266,10 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         bool(getattr(args, 'fused_input_grad', True))
     # the gates of every step as the rollout recorded them: no gate product in the backward at all
     given = fused_dx and rec.gates is not None and rec.xh is not None and rec.gates_n == T and rec.gates.shape[2] == 4 * H
+    # ... and then the whole window as ONE host call (round 6: ic3_bptt_backward — three launches per step, no library product,
+    # nothing on the host between them; the weight gradient of the window in one launch behind it)
+    if given and bool(getattr(args, 'bptt_native_loop', True)) and d_out.shape[-1] <= 16 and ops.bptt_backward_supported(raw, H):
+        return _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc)
     if fused_gates:
         bias_parts = torch.zeros(((R + 63) // 64, 4 * H), dtype=torch.float32, device=dev)
     else:
@@ -402,6 +406,66 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
         if stream is None:
             _heads_grad_episode(rec, d_out, acc, T, R, H)
     return (dh_rec, dc_rec)       # dL/d(h, c) entering the record's first slot (collection mode: the previous window's carry)
+
+
+def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
+    """backward_episode on recorded gates through ic3_bptt_backward (csrc/bptt_kernels.hip).  Per step, last to first:
+      ic3_lstm_gates_backward_given   cell derivative from the recorded gates, IN PLACE (dgates over the gates), dL/dh_t taking the
+                                      heads' share d_t . W_heads on the way in, [d inp | d h_direct] = dgates . [W_ih | W_hh]
+      ic3_comm_backward               dL/dh_{t-1} = d h_direct + (M d inp) . C,  dC += (M d inp)^T h_{t-1}   (M: the mixing matrix of
+                                      the communication block, symmetric — one mix feeds both products; comm itself is never formed)
+      ic3_env_encode_backward_accumulate   the sparse encoder's stage 1 on the step's snapshot
+    and behind the loop ONE weight-gradient launch over the window's T x R rows (the record's inp rows, the recorded h, the
+    dgates now standing in the gate record), the heads' pass, the encoder's expansion, the partials' sums.  Same cuts as
+    backward_episode (detach points; collection mode: row_live / row_keep / gated-off fresh envs)."""
+    T, R, H = rec.n, rec.hs.shape[1], rec.hs.shape[2]
+    N = net.nagents
+    E = R // N
+    dev = rec.hs.device
+    mode_avg = getattr(args, 'comm_mode', 'avg') == 'avg'
+    mask_zero = bool(args.comm_mask_zero)
+    zeros = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+    dh_rec, dc_rec = zeros(R, H), zeros(R, H)
+    dxh = torch.empty((R, 2 * H), dtype=torch.float32, device=dev)
+    bias_parts = zeros((R + 63) // 64, 4 * H)
+    dcw_parts = None if mask_zero else zeros(ops.comm_backward_partials(E, N), H, H)
+    alive, gate = list(rec.alive[:T]), list(rec.gate[:T])
+    live_flat = keep_flat = None
+    stream = rec.stream
+    gap = int(getattr(args, 'detach_gap', 10000))
+    if stream is not None:
+        if carry is not None:
+            dh_rec.copy_(carry[0])
+            dc_rec.copy_(carry[1])
+        fresh, keep = stream['fresh'], stream['keep']                     # (T, E) bool
+        live_flat = (~fresh).to(torch.float32).repeat_interleave(N, dim=1).contiguous()
+        keep_flat = keep.to(torch.float32).repeat_interleave(N, dim=1).contiguous()
+        ones = torch.ones((E, N), dtype=torch.int32, device=dev)
+        fr = fresh.unsqueeze(2)
+        if any(m is not None for m in alive):                             # an env that starts an episode: nobody is dead (Q21)
+            al = torch.where(fr, ones, torch.stack([m if m is not None else ones for m in alive]))
+            alive = list(al.unbind(0))
+        # ... and its agents are gated off: what the zero state entering the slot amounts to for the communication block (Q22)
+        gt = torch.where(fr, torch.zeros_like(ones), torch.stack([m if m is not None else ones for m in gate]))
+        gate = list(gt.unbind(0))
+        dh_rec.mul_(keep_flat[T - 1].unsqueeze(1))                        # what the next window handed over, cut at its border
+        gap = 0                                                           # (the env's OWN detach points are in `keep`)
+    elif gap > T:
+        gap = 0
+    dhead = d_out if d_out.is_contiguous() else d_out.contiguous()
+    ops.bptt_backward(raw, T, E, N, H, rec.gates, rec.hs, rec.cs, dhead, rec.snaps, alive, gate, fc['ps_l_wp3_bwd'], fc['w_heads'],
+                      None if mask_zero else net.C_modules[0].weight.detach(), dh_rec, dc_rec, dxh, bias_parts, dcw_parts,
+                      mode_avg=mode_avg, comm_zero=mask_zero, detach_gap=gap, row_live=live_flat, row_keep=keep_flat, enc_first=True)
+    work = acc.setdefault('_work', {})
+    ops.lstm_weight_grad(rec.xh[:T], rec.hs[:T], rec.gates[:T], acc['w_cat_t'], row_live=live_flat, accumulate=True, work=work)
+    dwt, db = raw.encode_backward_finish(H, want_bias=True)
+    acc['wt'].add_(dwt)
+    acc['enc_bias'].add_(db)
+    acc['b_cat'].add_(bias_parts.sum(0))
+    if not mask_zero:
+        acc['c_w'].add_(dcw_parts.sum(0))
+    _heads_grad_episode(rec, d_out, acc, T, R, H)
+    return (dh_rec, dc_rec)
 
 
 def _heads_grad_episode(rec, d_out, acc, T, R, H):

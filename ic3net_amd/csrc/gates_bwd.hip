@@ -52,6 +52,13 @@ struct GatesBwdArgs {
     // null = all ones
     const float* row_live;
     const float* row_keep;
+    // GIVEN: the heads' share of dL/dh_t added on the way in (trainer.py:128-225 through comm.py:228,239): dh + dhead . w_heads
+    // with dhead [R][OT] = dL/d[logits of every head | value] of the step and w_heads [OT][H] (heads.k.weight stacked, then
+    // value_head.weight), OT <= 16 — replaces the R x OT x H library product (and its pass over dh) in front of the launch.
+    // null = dh as it is
+    const float* dhead;
+    const float* w_heads;
+    int OT;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gb_rsrc(const void* base, long long bytes)
@@ -63,38 +70,25 @@ __device__ __forceinline__ gb_f32x4 gb_load4(__amdgpu_buffer_rsrc_t r, int voff,
 {
     return __builtin_bit_cast(gb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-template <int AUX = 0>
 __device__ __forceinline__ float gb_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-template <int AUX = 0>
 __device__ __forceinline__ void gb_store1(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
 }
-// cache policy of the streams of the GIVEN instantiation (read once / written once per launch, 0.66 GB per PP-hard step, next to
-// 0.8 MB of weight planes every tile re-reads from L2): IC3_GB_NT bit 0 = the loads, bit 1 = the stores non-temporal.
-// A/B inside a PP-hard update (tools/exp/gbnt_ab.sh, profiles/r05/gates_given_nt_ab.txt): 94.7 / 94.2 / 94.0 / 93.5 M
-// agent-steps/s for 0 / 1 / 2 / 3 — nothing to gain, 0 stays
-#ifndef IC3_GB_NT
-#define IC3_GB_NT 0
-#endif
+// (Cache policy of the GIVEN instantiation's streams, round 5: non-temporal loads / stores measured 94.7 / 94.2 / 94.0 / 93.5 M
+// agent-steps/s for none / loads / stores / both inside a PP-hard update — profiles/r05/gates_given_nt_ab.txt — default policy.)
 
-// The accumulators are pinned to AGPRs (tools/exp/ws_probe.hip: an fp32 MFMA stream with AGPR accumulators ran 153
-// instead of 141 TFLOP/s in isolation; this kernel: 266 instead of 280 us per call in tools/exp/microbench_gates_bwd.py,
-// no spills at 128 AGPR + 128 VGPR).  -DIC3_GB_AGPR=0 is the all-VGPR form.  policy_step_kernel cannot follow: its phases
-// around the loops need more than 128 VGPRs (97 spills with IC3_PS_AGPR=1).
-#ifndef IC3_GB_AGPR
-#define IC3_GB_AGPR 1
-#endif
+// Matrix instructions through the compiler's builtins ONLY.  Rounds 3-5 pinned the accumulators to AGPRs with inline-asm
+// MFMAs (266 instead of 280 us per recompute call); the hazard recogniser cannot see through inline asm, and a split plane
+// written by v_cvt_pk_bf16_f32 a few cycles before the asm MFMA that read it arrived stale on warm launches (round 5: errors
+// of 3e-6 instead of 9e-7, run-to-run differences, held off by s_nop padding).  With the builtins the compiler inserts the
+// wait states itself: safe by construction (round-5 verdict, item 2c; the 5 % are what it costs).
 __device__ __forceinline__ void gb_mfma(gb_f32x16& acc, float x, float y)
 {
-#if IC3_GB_AGPR
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
-#else
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
-#endif
 }
 
 // SPLIT = 1 (the default; the update half's twin of policy_step_kernel's gate_split): the recompute as nine exact
@@ -125,23 +119,8 @@ __device__ __forceinline__ void gb_split_frag(gb_f32x4 x0, gb_f32x4 x1, gb_u32x4
 }
 __device__ __forceinline__ void gb_mfma_bf16(gb_f32x16& acc, gb_u32x4 x, gb_u32x4 y)
 {
-#if IC3_GB_AGPR
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
-#else
     typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gb_bf16x8, x), __builtin_bit_cast(gb_bf16x8, y), acc, 0, 0, 0);
-#endif
-}
-
-// The split's last VALU results feed the asm MFMAs that follow at once: the hazard recogniser does not see through the asm,
-// and on gfx950 a plane written by v_cvt_pk_bf16_f32 a few cycles before the MFMA that reads it arrived stale when nothing
-// else stalled the wave (round 5: warm launches of the dx phase differed from the cold one in rows 32..63's low plane).
-// The operands tie the wait behind every plane's definition and in front of the products.
-__device__ __forceinline__ void gb_settle(gb_u32x4 (&a)[3], gb_u32x4 (&b)[3])
-{
-#if IC3_GB_AGPR
-    asm volatile("s_nop 15" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
-#endif
 }
 
 template <int H, int SPLIT = 0, int GIVEN = 0>
@@ -154,6 +133,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
     float* const As = smem;                                      // [64][LDA]
     gb_f32x4* const As4 = reinterpret_cast<gb_f32x4*>(smem);
     float* const slb = As + 64 * LDA;                            // [4H]
+    float* const sdh = slb + 4 * H;                              // GIVEN: [64][16] the tile's dhead rows, zero beyond OT
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li;
     const long long r0 = (long long)blockIdx.x * 64;
@@ -161,6 +141,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 
     // ---- A tile: 64 rows of [inp | h_prev] -> LDS (all loads issued, then the LDS writes) ------------------------------
     if constexpr (GIVEN != 0) {
+        if (a.dhead) {                                           // (uniform) 64 x 16 floats, 4 per thread at H = 128
+            const __amdgpu_buffer_rsrc_t rdd = gb_rsrc(a.dhead + r0 * a.OT, (long long)rows * a.OT * 4);
+            for (int idx = tid; idx < 64 * 16; idx += NT) {
+                const int row = idx >> 4, o = idx & 15;
+                sdh[idx] = o < a.OT ? gb_load1(rdd, (row * a.OT + o) * 4, 0) : 0.0f;   // (rows past R: dropped loads read 0)
+            }
+        }
         // (recorded gates: nothing of the forward runs again — only the caller's copy of h_prev into the h half of xh, the
         //  weight-gradient product's operand, is made here)
         if (a.xh && a.h_prev) {
@@ -239,7 +226,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
                 const gb_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
                 gb_split_frag(s0[0], s0[1], ap[0]);
                 gb_split_frag(s1[0], s1[1], ap[1]);
-                gb_settle(ap[0], ap[1]);
             }
 #pragma unroll
             for (int pb = 0; pb < 3; ++pb)
@@ -294,15 +280,21 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
         block(s1, std::false_type{}, KB - 1);
         __builtin_amdgcn_sched_barrier(0);
     }
-#if IC3_GB_AGPR
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // (the asm MFMAs are opaque to the hazard recogniser)
-#endif
 
     // ---- the cell's derivative (torch.nn.LSTMCell): c' = f c + i g, h' = o tanh(c') -----------------------------------------
     const float bi = GIVEN ? 0.f : slb[col], bf = GIVEN ? 0.f : slb[H + col], bg = GIVEN ? 0.f : slb[2 * H + col], bo = GIVEN ? 0.f : slb[3 * H + col];
     const bool dx = SPLIT != 0 && a.dxh != nullptr;                  // (uniform) the input gradient in this launch too
     float keep_g[2][16], keep_o[2][16];
-    if (dx) __syncthreads();                                         // every wave is done reading the A tile: it takes d i, d f now
+    const bool heads_in = GIVEN != 0 && a.dhead != nullptr;          // (uniform)
+    if (dx || heads_in) __syncthreads();                             // every wave is done reading the A tile: it takes d i, d f now
+    float wh[16] = {};                                               // w_heads[o][col] of this lane's hidden column
+    if constexpr (GIVEN != 0) {
+        if (heads_in) {
+            const __amdgpu_buffer_rsrc_t rwh = gb_rsrc(a.w_heads, (long long)a.OT * H * 4);
+#pragma unroll
+            for (int o = 0; o < 16; ++o) wh[o] = gb_load1(rwh, (o * H + col) * 4, 0);     // (o >= OT: out of range, 0)
+        }
+    }
     const long long nrec = (long long)rows * H * 4;
     const __amdgpu_buffer_rsrc_t rdh = gb_rsrc(a.dh + r0 * H, nrec);
     const __amdgpu_buffer_rsrc_t rdc = gb_rsrc(a.dc ? a.dc + r0 * H : a.dh, a.dc ? nrec : 0);   // null: every load reads 0
@@ -320,13 +312,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
-            constexpr int LA = (GIVEN != 0 && (IC3_GB_NT & 1)) ? 2 : 0;
-            dhv[reg] = gb_load1<LA>(rdh, voff, lc * H * 4);
-            dcv[reg] = gb_load1<LA>(rdc, voff, lc * H * 4);
-            if constexpr (SPLIT != 0) cold[rt][reg] = gb_load1<LA>(rc, voff, lc * H * 4);
+            dhv[reg] = gb_load1(rdh, voff, lc * H * 4);
+            dcv[reg] = gb_load1(rdc, voff, lc * H * 4);
+            if constexpr (SPLIT != 0) cold[rt][reg] = gb_load1(rc, voff, lc * H * 4);
             if constexpr (GIVEN != 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gin[k][reg] = gb_load1<LA>(rgin, goff, lc * 4 * H * 4 + k * H * 4);
+                for (int k = 0; k < 4; ++k) gin[k][reg] = gb_load1(rgin, goff, lc * 4 * H * 4 + k * H * 4);
             }
         }
 #pragma unroll
@@ -335,6 +326,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             float i, f, gt, o;
             if constexpr (GIVEN != 0) {
                 i = gin[0][reg], f = gin[1][reg], gt = gin[2][reg], o = gin[3][reg];
+                if (heads_in) {                                      // dL/dh_t += dhead[row] . w_heads[:, col]
+                    const gb_f32x4* dr = reinterpret_cast<const gb_f32x4*>(sdh + (lc + 4 * lh) * 16);   // (a broadcast read)
+                    float s = dhv[reg];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (4 * q >= a.OT) break;
+                        const gb_f32x4 dv = dr[q];
+                        s = __builtin_fmaf(dv[0], wh[4 * q], s);
+                        s = __builtin_fmaf(dv[1], wh[4 * q + 1], s);
+                        s = __builtin_fmaf(dv[2], wh[4 * q + 2], s);
+                        s = __builtin_fmaf(dv[3], wh[4 * q + 3], s);
+                    }
+                    dhv[reg] = s;
+                }
                 if (cuts) {                                          // (uniform) collection mode: the slot's per-row cuts
                     const int lrow = lc + 4 * lh;
                     if (a.row_live) cold[rt][reg] *= gb_load1(rlive, lrow * 4, 0);
@@ -345,16 +350,15 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
                 gt = fast_tanh(acc[rt][2][reg] + bg), o = fast_sigmoid(acc[rt][3][reg] + bo);
             }
             const float c0 = cold[rt][reg];
-            const float tc = fast_tanh(f * c0 + i * gt);
+            const float tc = fast_tanh(__builtin_fmaf(f, c0, i * gt));   // (the forward's own rounding: policy_step.hip's cell)
             const float dct = dcv[reg] + dhv[reg] * o * (1.0f - tc * tc);
             const float di = dct * gt * i * (1.0f - i), df = dct * c0 * f * (1.0f - f);
             const float dg = dct * i * (1.0f - gt * gt), dO = dhv[reg] * tc * o * (1.0f - o);
-            constexpr int SA = (GIVEN != 0 && (IC3_GB_NT & 2)) ? 2 : 0;
-            gb_store1<SA>(di, rdg, goff, lc * 4 * H * 4);
-            gb_store1<SA>(df, rdg, goff, lc * 4 * H * 4 + H * 4);
-            gb_store1<SA>(dg, rdg, goff, lc * 4 * H * 4 + 2 * H * 4);
-            gb_store1<SA>(dO, rdg, goff, lc * 4 * H * 4 + 3 * H * 4);
-            gb_store1<SA>(dct * f, rdp, voff, lc * H * 4);
+            gb_store1(di, rdg, goff, lc * 4 * H * 4);
+            gb_store1(df, rdg, goff, lc * 4 * H * 4 + H * 4);
+            gb_store1(dg, rdg, goff, lc * 4 * H * 4 + 2 * H * 4);
+            gb_store1(dO, rdg, goff, lc * 4 * H * 4 + 3 * H * 4);
+            gb_store1(dct * f, rdp, voff, lc * H * 4);
             if constexpr (SPLIT != 0) {
                 if (dx) {                                            // K-half 0 of dgates (gates i, f) -> the A tile; g, o wait in registers
                     const int lr = lc + 4 * lh;
@@ -399,7 +403,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
                 const gb_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
                 gb_split_frag(s0[0], s0[1], ap[0]);
                 gb_split_frag(s1[0], s1[1], ap[1]);
-                gb_settle(ap[0], ap[1]);
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb)
 #pragma unroll
@@ -416,9 +419,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             __syncthreads();                                     // d i, d f of every wave are in the A tile
 #pragma unroll 1
             for (int kb = 0; kb < KBH; ++kb) blockdx(kb, kb);
-#if IC3_GB_AGPR
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
             __syncthreads();                                     // every wave is done with K-half 0
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -431,9 +431,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
             __syncthreads();
 #pragma unroll 1
             for (int kb = 0; kb < KBH; ++kb) blockdx(kb, KBH + kb);
-#if IC3_GB_AGPR
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
             const __amdgpu_buffer_rsrc_t rdx = gb_rsrc(a.dxh + r0 * K, (long long)rows * K * 4);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -442,7 +439,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                        gb_store1<(GIVEN != 0 && (IC3_GB_NT & 2)) ? 2 : 0>(acc[rt][ct][reg], rdx, (lr * K + 64 * w + 32 * ct + li) * 4, 0);
+                        gb_store1(acc[rt][ct][reg], rdx, (lr * K + 64 * w + 32 * ct + li) * 4, 0);
                     }
         }
     }
@@ -475,7 +472,8 @@ extern "C" int ic3_lstm_gates_backward_supported(int H) { return H == 64 || H ==
 static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
                                const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
                                float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream,
-                               const float* gates = nullptr, const float* row_live = nullptr, const float* row_keep = nullptr);
+                               const float* gates = nullptr, const float* row_live = nullptr, const float* row_keep = nullptr,
+                               const float* dhead = nullptr, const float* w_heads = nullptr, int OT = 0);
 
 extern "C" int ic3_lstm_gates_backward(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias, const float* c_prev,
                                        const float* dh, const float* dc, float* dgates, float* dc_prev, float* dbias_partials,
@@ -500,9 +498,12 @@ extern "C" int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_pre
 extern "C" int ic3_lstm_gates_backward_given(const float* gates, float* xh, int ldx, const float* h_prev, const void* lstm_wp3_bwd,
                                              const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
                                              float* dbias_partials, int accumulate, float* dxh, const float* row_live,
-                                             const float* row_keep, int R, int H, ic3_stream stream)
+                                             const float* row_keep, const float* dhead, const float* w_heads, int OT, int R, int H,
+                                             ic3_stream stream)
 {
     if (!gates) return ic3::fail(-22, "ic3_lstm_gates_backward_given: null gates");
+    if ((dhead == nullptr) != (w_heads == nullptr) || (dhead && (OT < 1 || OT > 16)))
+        return ic3::fail(-22, "ic3_lstm_gates_backward_given: dhead [R][OT] and w_heads [OT][H] come together, 1 <= OT <= 16");
     if (row_keep && !dc) return ic3::fail(-22, "ic3_lstm_gates_backward_given: row_keep scales dc");
     if ((lstm_wp3_bwd == nullptr) != (dxh == nullptr))
         return ic3::fail(-22, "ic3_lstm_gates_backward_given: lstm_wp3_bwd and dxh come together");
@@ -510,13 +511,14 @@ extern "C" int ic3_lstm_gates_backward_given(const float* gates, float* xh, int 
     if ((xh == nullptr) != (h_prev == nullptr))
         return ic3::fail(-22, "ic3_lstm_gates_backward_given: xh and h_prev come together (the copy into xh's h half) or not at all");
     return gates_backward_impl(xh, xh ? ldx : 2 * H, h_prev, nullptr, nullptr, nullptr, c_prev, dh, dc, dgates, dc_prev, dbias_partials,
-                               accumulate, lstm_wp3_bwd, dxh, R, H, stream, gates, row_live, row_keep);
+                               accumulate, lstm_wp3_bwd, dxh, R, H, stream, gates, row_live, row_keep, dhead, w_heads, OT);
 }
 
 static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const float* lstm_wp, const void* lstm_wp3, const float* bias,
                                const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
                                float* dbias_partials, int accumulate, const void* wb3, float* dxh, int R, int H, ic3_stream stream,
-                               const float* gates, const float* row_live, const float* row_keep)
+                               const float* gates, const float* row_live, const float* row_keep, const float* dhead,
+                               const float* w_heads, int OT)
 {
     using namespace ic3;
     if ((!gates && (!xh || !lstm_wp || !bias)) || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
@@ -525,9 +527,9 @@ static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const fl
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");
     if ((long long)R * (ldx > 4 * H ? ldx : 4 * H) * 4 >= (1ll << 32))
         return fail(-22, "ic3_lstm_gates_backward: R * 4H floats must stay below 4 GB (32-bit buffer offsets)");
-    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh, gates, row_live, row_keep };
+    const GatesBwdArgs a{ xh, h_prev, lstm_wp, lstm_wp3, bias, c_prev, dh, dc, dgates, dc_prev, dbias_partials, ldx, R, accumulate, wb3, dxh, gates, row_live, row_keep, dhead, w_heads, OT };
     const int tiles = (R + 63) / 64;
-    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H) * sizeof(float);
+    const size_t lds = ((size_t)64 * (2 * H + 4) + 4 * H + (gates ? 64 * 16 : 0)) * sizeof(float);   // (+ the dhead tile)
     hipStream_t s = (hipStream_t)stream;
     if (gates) {                                                 // (H 64 / 128: checked by the entry point)
         if (H == 128) {

@@ -228,11 +228,12 @@ def _rowvec(v, R):
 
 
 def lstm_gates_backward_given(gates, c_prev, dh, dc, dgates, dc_prev, dbias_partials=None, accumulate=False, xh=None,
-                              h_prev=None, lstm_wp3_bwd=None, dxh=None, row_live=None, row_keep=None):
+                              h_prev=None, lstm_wp3_bwd=None, dxh=None, row_live=None, row_keep=None, dhead=None, w_heads=None):
     """The cell's derivative from the RECORDED activated gates (R, 4H) of the step (ic3_lstm_gates_backward_given; the
     rollout's launch stored them: envs.set_record_out) — no gate product.  xh + h_prev: h_prev is copied into the h half of xh;
     lstm_wp3_bwd + dxh: [d inp | d h_prev] in the same launch.  row_live / row_keep (R,) float32 (collection mode): c_prev and
-    the copied h_prev times row_live, dc times row_keep, per row."""
+    the copied h_prev times row_live, dc times row_keep, per row.  dgates may be `gates` itself (in place).  dhead (R, OT) +
+    w_heads (OT, H): dh + dhead @ w_heads is what the cell sees (the heads' share of dL/dh_t, folded in)."""
     _need_cuda(gates, "lstm_gates_backward_given")
     R, H = c_prev.shape
     for t in (gates, c_prev, dh, dgates, dc_prev):
@@ -246,16 +247,128 @@ def lstm_gates_backward_given(gates, c_prev, dh, dc, dgates, dc_prev, dbias_part
         assert h_prev.is_contiguous() and tuple(h_prev.shape) == (R, H)
     if dxh is not None:
         assert lstm_wp3_bwd is not None and dxh.is_contiguous() and tuple(dxh.shape) == (R, 2 * H)
+    OT = 0
+    if dhead is not None:
+        OT = dhead.shape[1]
+        assert w_heads is not None and dhead.is_contiguous() and dhead.dtype == torch.float32 and dhead.shape[0] == R
+        assert w_heads.is_contiguous() and w_heads.dtype == torch.float32 and tuple(w_heads.shape) == (OT, H)
     n = _lib.lib().ic3_lstm_gates_backward_given(ptr(gates), ptr(xh) if xh is not None else None, xh.stride(0) if xh is not None else 0,
                                                  ptr(h_prev) if xh is not None else None,
                                                  ptr(lstm_wp3_bwd) if dxh is not None else None, ptr(c_prev), ptr(dh),
                                                  ptr(dc) if dc is not None else None, ptr(dgates), ptr(dc_prev),
                                                  ptr(dbias_partials) if dbias_partials is not None else None,
                                                  int(bool(accumulate)), ptr(dxh) if dxh is not None else None,
-                                                 _rowvec(row_live, R), _rowvec(row_keep, R), R, H, stream())
+                                                 _rowvec(row_live, R), _rowvec(row_keep, R),
+                                                 ptr(dhead) if dhead is not None else None,
+                                                 ptr(w_heads) if dhead is not None else None, OT, R, H, stream())
     if n < 0:
         check(n)
     return n
+
+
+def comm_backward_partials(E, N):
+    return int(_lib.lib().ic3_comm_backward_partials(int(E), int(N)))
+
+
+def comm_backward(dxh, h_prev, alive, gate, c_weight, dh_out, dcw_partials, E, N, mode_avg=True, comm_zero=False,
+                  out_scale=None, accumulate=True):
+    """ic3_comm_backward: dh_out (R, H) = (dxh[:, H:] + mix(dxh[:, :H]) @ c_weight) * out_scale and dcw_partials (P, H, H)
+    (+)= per-workgroup partial sums of mix(d inp)^T @ h_prev — the communication block's and C's share of one recorded step's
+    backward in one launch.  comm_zero: dh_out = dxh[:, H:] * out_scale."""
+    _need_cuda(dxh, "comm_backward")
+    R, H2 = dxh.shape
+    H = H2 // 2
+    assert R == E * N and dxh.is_contiguous() and dxh.dtype == torch.float32 and dh_out.is_contiguous() and tuple(dh_out.shape) == (R, H)
+    if not comm_zero:
+        assert h_prev.is_contiguous() and tuple(h_prev.shape) == (R, H) and c_weight.is_contiguous() and tuple(c_weight.shape) == (H, H)
+        assert dcw_partials.is_contiguous() and tuple(dcw_partials.shape) == (comm_backward_partials(E, N), H, H)
+        for m in (alive, gate):
+            assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+    n = _lib.lib().ic3_comm_backward(ptr(dxh), 2 * H, ptr(h_prev), ptr(alive), ptr(gate), ptr(c_weight), _rowvec(out_scale, R),
+                                     ptr(dh_out), ptr(dcw_partials), int(bool(accumulate)), E, N, H, int(bool(mode_avg)),
+                                     int(bool(comm_zero)), stream())
+    if n < 0:
+        check(n)
+    return n
+
+
+def lstm_weight_grad(inp, h_prev, dgates, dW, row_live=None, accumulate=True, work=None):
+    """ic3_lstm_weight_grad: dW (2H, 4H) (+)= [inp | h_prev]^T @ dgates over all Q rows of a window of recorded steps in one
+    launch.  inp (Q, >= H) rows with unit column stride (the first H floats count: the record's [inp | h] rows), h_prev (Q, H),
+    dgates (Q, 4H) contiguous; leading dims may be (T, R)."""
+    _need_cuda(dgates, "lstm_weight_grad")
+    H = h_prev.shape[-1]
+    Q = dgates.numel() // (4 * H)
+    inp2 = inp.reshape(Q, inp.shape[-1])
+    assert inp2.stride(1) == 1 and inp2.shape[1] >= H and inp2.dtype == torch.float32
+    assert h_prev.is_contiguous() and h_prev.numel() == Q * H and dgates.is_contiguous() and dgates.dtype == torch.float32
+    assert dW.is_contiguous() and tuple(dW.shape) == (2 * H, 4 * H)
+    if row_live is not None:
+        assert row_live.is_contiguous() and row_live.dtype == torch.float32 and row_live.numel() == Q
+    work = work if work is not None else dict()
+    n = int(_lib.lib().ic3_lstm_weight_grad_scratch_floats(Q, H))
+    if n == 0:
+        raise NotImplementedError("lstm_weight_grad: hid_size 64 / 128")
+    key = ('wgrad', str(dgates.device))
+    if key not in work or work[key].numel() < n:
+        work[key] = torch.empty((n,), dtype=torch.float32, device=dgates.device)
+    check(_lib.lib().ic3_lstm_weight_grad(ptr(inp2), inp2.stride(0), ptr(h_prev), ptr(dgates), ptr(row_live), Q, H, ptr(dW),
+                                          int(bool(accumulate)), ptr(work[key]), stream()))
+
+
+def bptt_backward_supported(env, H):
+    return bool(_lib.lib().ic3_bptt_backward_supported(env._h, int(H)))
+
+
+def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lstm_wp3_bwd, w_heads, c_weight, dh, dc, dxh,
+                  dbias_partials, dcw_partials, mode_avg=True, comm_zero=False, detach_gap=0, row_live=None, row_keep=None,
+                  enc_first=True):
+    """ic3_bptt_backward: the backward through a window of T recorded steps as one host call (gate launch in place on the
+    record, communication backward, encoder backward stage 1 — three launches per step).  alive / gate: lists of T tensors
+    (E, N) int32 or None entries, or None."""
+    import ctypes as C
+    _need_cuda(gates, "bptt_backward")
+    R = E * N
+    OT = dhead.shape[-1]
+    assert gates.is_contiguous() and gates.numel() == T * R * 4 * H and gates.dtype == torch.float32
+    assert hs.is_contiguous() and cs.is_contiguous() and hs.shape[0] >= T and tuple(hs.shape[1:]) == (R, H) == tuple(cs.shape[1:])
+    assert dhead.is_contiguous() and dhead.numel() == T * R * OT and dhead.dtype == torch.float32
+    assert snaps.is_contiguous() and snaps.dtype == torch.int32 and snaps.shape[0] >= T
+    for v in (dh, dc):
+        assert v.is_contiguous() and tuple(v.shape) == (R, H) and v.dtype == torch.float32
+    assert dxh.is_contiguous() and tuple(dxh.shape) == (R, 2 * H)
+    assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == ((R + 63) // 64, 4 * H)
+    if not comm_zero:
+        assert dcw_partials.is_contiguous() and tuple(dcw_partials.shape) == (comm_backward_partials(E, N), H, H)
+        assert c_weight.is_contiguous() and tuple(c_weight.shape) == (H, H)
+    for v in (row_live, row_keep):
+        assert v is None or (v.is_contiguous() and v.dtype == torch.float32 and tuple(v.shape) == (T, R))
+
+    def ptrs(ms):
+        if ms is None or all(m is None for m in ms):
+            return None
+        assert len(ms) >= T
+        for m in ms[:T]:
+            assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+        return (C.c_void_p * T)(*[None if m is None else m.data_ptr() for m in ms[:T]])
+    pa, pg = ptrs(alive), ptrs(gate)
+    b = _lib.Bptt()
+    b.struct_size = C.sizeof(b)
+    b.T, b.E, b.N, b.H, b.OT = T, E, N, H, OT
+    b.mode_avg, b.comm_zero, b.detach_gap, b.enc_first = int(bool(mode_avg)), int(bool(comm_zero)), int(detach_gap), int(bool(enc_first))
+    b.gates, b.hs, b.cs, b.dhead, b.snaps = gates.data_ptr(), hs.data_ptr(), cs.data_ptr(), dhead.data_ptr(), snaps.data_ptr()
+    b.snap_words = snaps.stride(0)
+    b.alive = C.cast(pa, C.POINTER(C.c_void_p)) if pa is not None else None
+    b.gate = C.cast(pg, C.POINTER(C.c_void_p)) if pg is not None else None
+    b.row_live = row_live.data_ptr() if row_live is not None else None
+    b.row_keep = row_keep.data_ptr() if row_keep is not None else None
+    b.lstm_wp3_bwd, b.w_heads = lstm_wp3_bwd.data_ptr(), w_heads.data_ptr()
+    b.c_weight = c_weight.data_ptr() if c_weight is not None else None
+    b.dh, b.dc, b.dxh = dh.data_ptr(), dc.data_ptr(), dxh.data_ptr()
+    b.dbias_partials = dbias_partials.data_ptr()
+    b.dcw_partials = dcw_partials.data_ptr() if dcw_partials is not None else None
+    b.enc_work = env._encb_work(H).data_ptr()
+    check(_lib.lib().ic3_bptt_backward(env._h, C.byref(b), stream()))
 
 
 HEADS_GRAD_MAX_OT = 16      # ic3_heads_grad: at most 16 output columns (the heads' actions in total + the value)

@@ -34,7 +34,7 @@ extern "C" {
  * boundary checks itself: ic3_version() returns the library's value, ic3_abi_check() compares the caller's version and
  * struct sizes with the library's, and both structs start with `struct_size` (= sizeof, set by the caller) — an entry
  * point handed a struct of another size refuses it with -EINVAL before reading any other field. */
-#define IC3_VERSION 500 /* 0.5.0 (round 5: ic3_returns_scan, ic3_comm_masked_mean_add, ic3_env_encode_backward_accumulate / _finish) */
+#define IC3_VERSION 600 /* 0.6.0 (round 6: ic3_comm_backward, ic3_lstm_weight_grad, ic3_bptt_backward; ic3_lstm_gates_backward_given takes the heads' share) */
 
 /* 0 when `version` == IC3_VERSION of the library and the two sizes are the library's sizeof(ic3_policy) /
  * sizeof(ic3_episode); -EINVAL (with a message naming the mismatch) otherwise.  A binding calls it once after loading. */
@@ -346,12 +346,87 @@ int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_prev /* or NUL
  * follows; lstm_wp3_bwd / dxh (both or neither): the input gradient in the same launch.  Collection mode (trainer.py:227-242:
  * a record slot where some envs start an episode, or after which the recurrent gradient must not pass): row_live [R] or NULL —
  * c_prev and the copied h_prev of a row are multiplied by it (0 = the env starts an episode at this slot: zero state);
- * row_keep [R] or NULL — dc of a row is multiplied by it (0 = nothing arrives from the next slot).  hid_size 64 / 128. */
+ * row_keep [R] or NULL — dc of a row is multiplied by it (0 = nothing arrives from the next slot).  hid_size 64 / 128.
+ * Round 6: dgates may BE gates (every lane overwrites exactly what it read: the record turns into the weight-gradient
+ * product's operand in place); dhead [R][OT] / w_heads [OT][H] (both or neither, OT <= 16): the heads' share of dL/dh_t —
+ * dhead . w_heads with dhead = dL/d[logits of every head | value] (comm.py:228,239), w_heads = heads.k.weight stacked, then
+ * value_head.weight — is added to dh on the way in, instead of by an R x OT x H product (and a pass over dh) in front. */
 int ic3_lstm_gates_backward_given(const float* gates, float* xh /* or NULL */, int ldx, const float* h_prev /* or NULL */,
                                   const void* lstm_wp3_bwd /* or NULL */, const float* c_prev, const float* dh,
                                   const float* dc /* or NULL */, float* dgates, float* dc_prev, float* dbias_partials /* or NULL */,
                                   int accumulate, float* dxh /* or NULL */, const float* row_live /* or NULL */,
-                                  const float* row_keep /* or NULL */, int R, int H, ic3_stream stream);
+                                  const float* row_keep /* or NULL */, const float* dhead /* or NULL */,
+                                  const float* w_heads /* or NULL */, int OT, int R, int H, ic3_stream stream);
+
+/* The communication block's and C's share of the backward through one recorded step (trainer.py:128-225 through
+ * comm.py:181-206), one launch.  With M the per-env mixing matrix of ic3_comm_masked_mean (symmetric), comm = M h_prev and
+ * inp = encoder(obs) + comm . C.weight^T:
+ *     dh_out [E*N][H] = (d h_direct + (M d inp) . C.weight) * out_scale        — dL/dh_{t-1}, what step t - 1 receives
+ *     C.weight's gradient += (M d inp)^T . h_prev                               (= d inp^T . comm: the forward's comm is not formed again)
+ * dxh [E*N][ldd]: columns [0, H) = d inp, [H, 2H) = d h_direct (ic3_lstm_gates_backward_given's dxh); alive / gate [E][N] int32 or
+ * NULL as ic3_comm_masked_mean; c_weight [H][H] = C_modules[0].weight as stored; out_scale [E*N] or NULL (collection mode: the
+ * gradient that must not cross an episode boundary or a detach point is dropped where it is produced); dcw_partials
+ * [ic3_comm_backward_partials(E, N)][H][H]: one partial per workgroup, written (accumulate == 0) or added to — their sum over dim 0
+ * is the gradient.  comm_zero != 0 (comm.py:40-41: C sees zeros): dh_out = d h_direct * out_scale, nothing else is read.
+ * Exact fp32 products on the fp32 matrix instruction.  hid_size 64 / 128, <= 64 agents per env.  Returns the number of partials
+ * written (0 with comm_zero), negative errno on error. */
+int ic3_comm_backward_partials(int E, int N);
+int ic3_comm_backward(const float* dxh, int ldd, const float* h_prev, const int32_t* alive /* or NULL */,
+                      const int32_t* gate /* or NULL */, const float* c_weight, const float* out_scale /* or NULL */, float* dh_out,
+                      float* dcw_partials, int accumulate, int E, int N, int H, int mode_avg, int comm_zero, ic3_stream stream);
+
+/* The LSTM cell's weight gradient over a whole WINDOW of recorded steps in one launch (+ a fixed-order reduction): dW [2H][4H]
+ * (+)= [inp | h_prev]^T . dgates over Q = steps x rows pairs — dW = the gradient of [weight_ih | weight_hh]^T of comm.py:61's
+ * LSTMCell (rows [0, H): weight_ih^T, rows [H, 2H): weight_hh^T).  inp [Q][ldi] (the first H floats of a row: the inp half of the
+ * rollout's record, ic3_env_set_record_out), h_prev [Q][H] (slots 0..T-1 of the recorded hidden states — no copy into an
+ * [inp | h] buffer), dgates [Q][4H] (what ic3_lstm_gates_backward_given left in the gate record), row_live [Q] or NULL (collection
+ * mode: h_prev rows times it).  scratch: ic3_lstm_weight_grad_scratch_floats(Q, H) floats.  Exact fp32 products on the fp32 matrix
+ * instruction, split-K over the CUs, slices summed in order (reproducible).  hid_size 64 / 128. */
+size_t ic3_lstm_weight_grad_scratch_floats(long long Q, int H);
+int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_prev, const float* dgates, const float* row_live /* or NULL */,
+                         long long Q, int H, float* dW, int accumulate, float* scratch, ic3_stream stream);
+
+/* The backward through a window of T recorded steps (trainer.py:128-225 over comm.py:134-244, one communication pass, recorded
+ * gates), last step first, as ONE host call — per step: ic3_lstm_gates_backward_given (in place on the gate record, the heads'
+ * share folded in, the input gradient in the same launch) -> ic3_comm_backward -> ic3_env_encode_backward_accumulate on the step's
+ * snapshot; nothing runs on the host between the launches.  Afterwards the caller runs ic3_lstm_weight_grad over the window
+ * (gates now holds dgates), ic3_heads_grad, ic3_env_encode_backward_finish and sums the partials.
+ *   gates [T][R][4H] in: the recorded activated gates, out: dgates;  hs, cs [>= T][R][H] the state ENTERING every step;
+ *   dhead [T][R][OT];  snaps: T snapshots, snap_words int32 apart;  alive / gate: HOST arrays of T device pointers ([E][N] int32,
+ *   entries may be NULL) or NULL;  row_live / row_keep [T][R] or NULL (collection mode, as ic3_lstm_gates_backward_given; the
+ *   communication backward of step t scales its output by row_keep[t - 1]);  detach_gap > 0: dh, dc are zeroed in front of every
+ *   step t with (t + 1) % detach_gap == 0 (trainer.py:56-60, lock-step windows);  dh, dc [R][H] in: dL/d(h, c) arriving at the
+ *   window's last step, out: leaving its first;  dxh [R][2H] scratch;  dbias_partials [ceil(R / 64)][4H] and dcw_partials
+ *   [ic3_comm_backward_partials][H][H] are ADDED to (zero them before the first window);  enc_work as
+ *   ic3_env_encode_backward_accumulate, enc_first != 0: this window starts the accumulation.
+ * ic3_bptt_backward_supported(env, H): 1 when every step can run (hid_size 64 / 128, <= 64 agents, the encoder backward in its
+ * partial-sums form) — the loop overwrites the record as it goes, so ask first. */
+typedef struct ic3_bptt {
+    uint32_t struct_size;   /* sizeof(ic3_bptt) of the caller's header (checked: -EINVAL on mismatch) */
+    int32_t T, E, N, H, OT;
+    int32_t mode_avg, comm_zero, detach_gap, enc_first;
+    float* gates;
+    const float* hs;
+    const float* cs;
+    const float* dhead;
+    const int32_t* snaps;
+    int64_t snap_words;
+    const int32_t* const* alive;
+    const int32_t* const* gate;
+    const float* row_live;
+    const float* row_keep;
+    const void* lstm_wp3_bwd;
+    const float* w_heads;
+    const float* c_weight;
+    float* dh;
+    float* dc;
+    float* dxh;
+    float* dbias_partials;
+    float* dcw_partials;
+    float* enc_work;
+} ic3_bptt;
+int ic3_bptt_backward_supported(const ic3_env* env, int H);
+int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream stream);
 /* The weight / bias gradient of the heads + value head over a whole episode in one pass (trainer.py:128-225 through
  * comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o] over the M = steps x rows pairs
  * (d [M][OT], h [M][H]: h_t of every step, i.e. the recorded hidden states shifted by one step).  scratch:

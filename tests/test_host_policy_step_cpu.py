@@ -570,7 +570,7 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
         dg6, dcp6 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
         dxh6, parts6 = np.full((R, 2 * H), np.nan, np.float32), np.full((tiles, 4 * H), np.nan, np.float32)
         n = check(lib.ic3_lstm_gates_backward_given(p(acts), p(xh6), 2 * H, p(h_prev), p(wb3), p(c_prev), p(dh), p(dc), p(dg6), p(dcp6),
-                                                    p(parts6), 0, p(dxh6), None, None, R, H, None))
+                                                    p(parts6), 0, p(dxh6), None, None, None, None, 0, R, H, None))
         assert n == tiles
         np.testing.assert_array_equal(xh6, wide[:, :2 * H])
         assert np.abs(dg6 - want_g).max() <= 2e-6 * max(1.0, np.abs(want_g).max())
@@ -580,11 +580,11 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
         assert np.abs(dxh6 - want_dx6).max() <= 6e-6 * max(1.0, np.abs(want_dx6).max())
         dg7, dcp7 = np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32)
         check(lib.ic3_lstm_gates_backward_given(p(acts), None, 0, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0, None,
-                                                None, None, R, H, None))          # (pointwise only: no copy, no dx)
+                                                None, None, None, None, 0, R, H, None))   # (pointwise only: no copy, no dx)
         np.testing.assert_array_equal(dg7, dg6)
         np.testing.assert_array_equal(dcp7, dcp6)
         assert lib.ic3_lstm_gates_backward_given(p(acts), p(xh6), 2 * H, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0,
-                                                 None, None, None, R, H, None) == -22
+                                                 None, None, None, None, None, 0, R, H, None) == -22
         # collection mode's per-row cuts: the same launch on pre-multiplied inputs
         live = (rng.random(R) < 0.7).astype(np.float32)
         keep = (rng.random(R) < 0.6).astype(np.float32)
@@ -600,10 +600,103 @@ def test_gates_backward_recompute_and_cell_derivative(H, R, split):
             dx8 = np.full((R, 2 * H), np.nan, np.float32)
             xx = xh8 if cut else xh9
             check(lib.ic3_lstm_gates_backward_given(p(acts), p(xx), 2 * H, p(hp), p(wb3), p(cp), p(dh), p(dcx), p(dg8), p(dcp8), None, 0,
-                                                    p(dx8), p(live) if cut else None, p(keep) if cut else None, R, H, None))
+                                                    p(dx8), p(live) if cut else None, p(keep) if cut else None, None, None, 0, R, H,
+                                                    None))
             outs.append((dg8, dcp8, dx8, xx.copy()))
         for u, v in zip(*outs):
             np.testing.assert_array_equal(u, v)
+        # round 6: the heads' share of dL/dh folded in (dh + dhead . w_heads is what the cell sees), and IN PLACE on the record
+        for OT in (3, 8, 16):
+            dhead, w_heads = f32(rng.standard_normal((R, OT))), f32(rng.standard_normal((OT, H)) / H ** 0.5)
+            dh_full = f32(dh.astype(np.float64) + dhead.astype(np.float64) @ w_heads.astype(np.float64))
+            ref = [np.full((R, 4 * H), np.nan, np.float32), np.full((R, H), np.nan, np.float32), np.full((R, 2 * H), np.nan, np.float32)]
+            check(lib.ic3_lstm_gates_backward_given(p(acts), None, 0, None, p(wb3), p(c_prev), p(dh_full), p(dc), p(ref[0]), p(ref[1]),
+                                                    None, 0, p(ref[2]), None, None, None, None, 0, R, H, None))
+            inplace = acts.copy()
+            got = [inplace, np.full((R, H), np.nan, np.float32), np.full((R, 2 * H), np.nan, np.float32)]
+            check(lib.ic3_lstm_gates_backward_given(p(inplace), None, 0, None, p(wb3), p(c_prev), p(dh), p(dc), p(inplace), p(got[1]),
+                                                    None, 0, p(got[2]), None, None, p(dhead), p(w_heads), OT, R, H, None))
+            for u, v in zip(got, ref):     # (the fold adds its terms one at a time: the last ulp of dh differs from the fp64 sum's rounding)
+                assert np.abs(u - v).max() <= 3e-6 * max(1.0, np.abs(v).max())
+        assert lib.ic3_lstm_gates_backward_given(p(acts), None, 0, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0, None,
+                                                 None, None, p(dhead), None, 3, R, H, None) == -22
+        assert lib.ic3_lstm_gates_backward_given(p(acts), None, 0, None, None, p(c_prev), p(dh), p(dc), p(dg7), p(dcp7), None, 0, None,
+                                                 None, None, p(dhead), p(w_heads), 17, R, H, None) == -22
+
+
+def _mix(x, alive, gate, mode_avg):
+    """comm.py:181-205 in closed form on (E, N, H) float64 (ic3_comm_masked_mean)."""
+    E, N, H = x.shape
+    al = np.ones((E, N)) if alive is None else alive.astype(np.float64)
+    g = al * (np.ones((E, N)) if gate is None else gate.astype(np.float64))
+    S = (g[:, :, None] * x).sum(1, keepdims=True)
+    n_alive = al.sum(1)
+    scale = np.where(n_alive > 1, 1.0 / np.maximum(n_alive - 1, 1), 1.0) if mode_avg else np.ones(E)
+    return g[:, :, None] * (S - g[:, :, None] * x) * scale[:, None, None]
+
+
+@pytest.mark.parametrize("H,N,E,avg,masks", [(128, 10, 13, True, 'both'), (64, 3, 50, True, 'gate'), (128, 20, 7, False, 'alive'),
+                                             (64, 32, 3, True, None), (128, 64, 2, True, 'both'), (64, 1, 5, True, None)])
+def test_comm_backward_one_launch(H, N, E, avg, masks):
+    """ic3_comm_backward (bptt_kernels.hip): dh_out = (d h_direct + (M d inp) . C) * out_scale and the partials of
+    (M d inp)^T . h_prev — against d h_direct + M (d inp . C) and d inp^T . (M h_prev) in float64 (the two forms the Python
+    loop of rounds 3-5 computed: the mixing matrix is symmetric), tiles of 64 / N whole envs, a ragged last tile."""
+    lib = host_lib()
+    rng = np.random.default_rng(H + N + E)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    R = E * N
+    dxh, hp = f32(rng.standard_normal((R, 2 * H))), f32(rng.standard_normal((R, H)))
+    cw = f32(rng.standard_normal((H, H)) / H ** 0.5)
+    alive = (rng.random((E, N)) < 0.8).astype(np.int32) if masks in ('alive', 'both') else None
+    gate = (rng.random((E, N)) < 0.6).astype(np.int32) if masks in ('gate', 'both') else None
+    scale = f32(rng.random(R) < 0.7)
+    dinp, dhd = dxh[:, :H].astype(np.float64), dxh[:, H:].astype(np.float64)
+    want_dh = dhd + _mix((dinp @ cw.astype(np.float64)).reshape(E, N, H), alive, gate, avg).reshape(R, H)
+    want_dc = dinp.T @ _mix(hp.astype(np.float64).reshape(E, N, H), alive, gate, avg).reshape(R, H)
+    nparts = lib.ic3_comm_backward_partials(E, N)
+    assert nparts == min(512, -(-E // (64 // N)))
+    for with_scale in (False, True):
+        dh = np.full((R, H), np.nan, np.float32)
+        parts = np.full((nparts, H, H), np.nan, np.float32)
+        n = check(lib.ic3_comm_backward(p(dxh), 2 * H, p(hp), p(alive), p(gate), p(cw), p(scale) if with_scale else None, p(dh), p(parts),
+                                        0, E, N, H, int(avg), 0, None))
+        assert n == nparts
+        w = want_dh * (scale[:, None] if with_scale else 1.0)
+        assert np.abs(dh - w).max() <= 4e-6 * max(1.0, np.abs(w).max())
+        got = parts.astype(np.float64).sum(0)
+        assert np.abs(got - want_dc).max() <= 1e-5 * max(1.0, np.abs(want_dc).max())
+        before = parts.copy()
+        check(lib.ic3_comm_backward(p(dxh), 2 * H, p(hp), p(alive), p(gate), p(cw), None, p(dh), p(parts), 1, E, N, H, int(avg), 0, None))
+        np.testing.assert_allclose(parts, 2 * before, rtol=1e-6, atol=1e-6)
+    # comm_mask_zero: the gate product's share alone (nothing else is read)
+    dh = np.full((R, H), np.nan, np.float32)
+    assert check(lib.ic3_comm_backward(p(dxh), 2 * H, None, None, None, None, p(scale), p(dh), None, 0, E, N, H, int(avg), 1, None)) == 0
+    np.testing.assert_array_equal(dh, dxh[:, H:] * scale[:, None])
+    assert lib.ic3_comm_backward(p(dxh), 2 * H, p(hp), None, None, p(cw), None, p(dh), None, 0, E, N, H, 1, 0, None) == -22
+
+
+@pytest.mark.parametrize("H,Q,ldi", [(128, 150, 256), (64, 200, 128), (64, 37, 64)])   # (two emulated CUs: a slice per CU at H = 64)
+def test_weight_gradient_of_a_window_in_one_launch(H, Q, ldi):
+    """ic3_lstm_weight_grad: dW (2H, 4H) (+)= [inp | h_prev]^T . dgates over Q rows — inp read from rows of stride ldi (the
+    record's [inp | h] rows), h_prev from its own array, row_live scaling the h rows; written, then accumulated."""
+    lib = host_lib()
+    rng = np.random.default_rng(H + Q)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    inp, h, dg = f32(rng.standard_normal((Q, ldi))), f32(rng.standard_normal((Q, H))), f32(rng.standard_normal((Q, 4 * H)))
+    live = f32(rng.random(Q) < 0.8)
+    n = lib.ic3_lstm_weight_grad_scratch_floats(Q, H)
+    assert n > 0 and lib.ic3_lstm_weight_grad_scratch_floats(Q, 256) == 0
+    scratch = np.full(n, np.nan, np.float32)
+    for lv in (None, live):
+        x = np.concatenate([inp[:, :H].astype(np.float64), h.astype(np.float64) * (1.0 if lv is None else lv[:, None])], 1)
+        want = x.T @ dg.astype(np.float64)
+        dW = np.full((2 * H, 4 * H), np.nan, np.float32)
+        check(lib.ic3_lstm_weight_grad(p(inp), ldi, p(h), p(dg), p(lv), Q, H, p(dW), 0, p(scratch), None))
+        assert np.abs(dW - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        once = dW.copy()
+        check(lib.ic3_lstm_weight_grad(p(inp), ldi, p(h), p(dg), p(lv), Q, H, p(dW), 1, p(scratch), None))
+        np.testing.assert_allclose(dW, 2 * once, rtol=1e-6, atol=1e-6)
+    assert lib.ic3_lstm_weight_grad(p(inp), H - 4, p(h), p(dg), None, Q, H, p(dW), 0, p(scratch), None) == -22
 
 
 def commnet_weights(lib, P, H, heads, passes):
