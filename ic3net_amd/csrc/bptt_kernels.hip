@@ -43,9 +43,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bp_rsrc(const void* base, long
     const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
-__device__ __forceinline__ float bp_load1(__amdgpu_buffer_rsrc_t r, int voff)
+__device__ __forceinline__ float bp_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0)   // (soff: the wave-uniform part)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ bp_f32x4 bp_load4(__amdgpu_buffer_rsrc_t r, int voff)
 {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void bp_mfma(bp_f32x16& acc, float x, float y)
 // owns hidden columns [32 w, 32 w + 32).  Per tile:
 //   0. d inp rows -> LDS, mixed in place: m_j = g_j (S - g_j x_j) scale with g = alive * gate, S = sum_i g_i x_i (the closed
 //      form of ic3_comm_masked_mean, same expression order)
-//   1. P = m . C (64 x H x H), epilogue: dh_out = (d h_direct + P) * out_scale
+//   1. d h_direct + m . C (64 x H x H; d h_direct is loaded INTO the accumulators), epilogue: dh_out = that * out_scale
 //   2. dC[k][n] += sum_rows m[row][k] h_prev[row][n] — accumulators live across the workgroup's tiles, one partial per workgroup
 // HBM per agent row: d inp, d h_direct, h_prev in, dh_out out = 4 H floats (2 KB at H = 128); MFMA: 2 x 2 H^2 flop per row.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -78,12 +78,14 @@ struct CommBwdArgs {
 };
 
 template <int H>
-__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void comm_bwd_kernel(const CommBwdArgs a)
+__global__ __launch_bounds__(2 * H, (H <= 128) ? 3 : 1) void comm_bwd_kernel(const CommBwdArgs a)
 {
-    constexpr int NT = 2 * H, H4 = H / 4, LDA = H + 4, LDA4 = LDA / 4, MB = H / 32;
+    constexpr int NT = 2 * H, H4 = H / 4, LDA = H + 4, LDA4 = LDA / 4, MB = H / 32, PER = 64 * H4 / NT;
     IC3_DYNAMIC_LDS(float, smem);
     float* const Am = smem;                                      // [64][LDA]
     bp_f32x4* const Am4 = reinterpret_cast<bp_f32x4*>(smem);
+    float* const sg = smem + 64 * LDA;                           // [64] alive * gate of the tile's rows
+    float* const sal = sg + 64;                                  // [64] alive
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li;
     const int N = a.N;
@@ -99,49 +101,62 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void comm_bwd_kernel(con
         const int ne = (a.E - e0) < a.ept ? (a.E - e0) : a.ept;
         const int rows = ne * N;
         const long long r0 = (long long)e0 * N;
-        // ---- h_prev of this lane's (row pair, column) for phase 2: requested now ------------------------------------------
+        // ---- every load of the tile is requested here: d inp rows (-> LDS), d h_direct straight into phase 1's accumulators
+        // (P is added on top of it), the masks, h_prev of this lane's (row pair, column) for phase 2.  Rows past the tile read 0.
+        const __amdgpu_buffer_rsrc_t rdi = bp_rsrc(a.dxh + r0 * a.ldd, ((long long)(rows - 1) * a.ldd + H) * 4);
+        const __amdgpu_buffer_rsrc_t rdd = bp_rsrc(a.dxh + r0 * a.ldd + H, ((long long)(rows - 1) * a.ldd + H) * 4);
         const __amdgpu_buffer_rsrc_t rhp = bp_rsrc(a.h_prev + r0 * H, (long long)rows * H * 4);
-        float hpv[32];
+        bp_f32x4 v[PER];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) hpv[s] = bp_load1(rhp, ((2 * s + lh) * H + col) * 4);     // (rows past the tile: 0)
-        // ---- phase 0: d inp rows -> LDS, mixed per env --------------------------------------------------------------------
-        for (int idx = tid; idx < (64 - rows) * H4; idx += NT) {
-            const int row = rows + idx / H4, c4 = idx - (idx / H4) * H4;
-            Am4[row * LDA4 + c4] = bp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * NT, row = idx / H4, c4 = idx - row * H4;
+            v[i] = bp_load4(rdi, (row * a.ldd + 4 * c4) * 4);
         }
+        float mg = 0.f, mal = 0.f;
+        if (tid < 64 && tid < rows) {
+            mal = a.alive ? (float)a.alive[r0 + tid] : 1.0f;                                     // quirk Q21: no mask = everyone
+            mg = mal * (a.gate ? (float)a.gate[r0 + tid] : 1.0f);
+        }
+        bp_f32x16 acc1[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                acc1[rt][reg] = bp_load1(rdd, (4 * lh * a.ldd + col) * 4, (32 * rt + (reg & 3) + 8 * (reg >> 2)) * a.ldd * 4);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) Am4[(tid + i * NT) / H4 * LDA4 + (tid + i * NT) % H4] = v[i];
+        if (tid < 64) {
+            sg[tid] = mg;
+            sal[tid] = mal;
+        }
+        float hpv[32];                                           // (behind the staging registers: in flight during phases 0 and 1)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) hpv[s] = bp_load1(rhp, (lh * H + col) * 4, 2 * s * H * 4);
+        __syncthreads();
+        // ---- phase 0: the rows mixed per env, in place in LDS ------------------------------------------------------------
         for (int item = tid; item < ne * H4; item += NT) {
             const int el = item / H4, c4 = item - el * H4;
-            const size_t m0 = (size_t)(e0 + el) * N;
-            int n_alive = 0;
-            for (int j = 0; j < N; ++j) n_alive += a.alive ? a.alive[m0 + j] : 1;                // comm.py:102-107, quirk Q21
+            float na = 0.f;
+            for (int j = 0; j < N; ++j) na += sal[el * N + j];                                   // comm.py:102-107
+            const int n_alive = (int)na;
             const float scale = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;   // comm.py:194-196, Q23
             bp_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
-            for (int i = 0; i < N; ++i) {
-                const float m = (float)((a.alive ? a.alive[m0 + i] : 1) * (a.gate ? a.gate[m0 + i] : 1));
-                const bp_f32x4 x = *reinterpret_cast<const bp_f32x4*>(a.dxh + (size_t)(r0 + el * N + i) * a.ldd + 4 * c4);
-                Am4[(el * N + i) * LDA4 + c4] = x;
-                S += m * x;
-            }
+            for (int i = 0; i < N; ++i) S += sg[el * N + i] * Am4[(el * N + i) * LDA4 + c4];
             for (int j = 0; j < N; ++j) {
-                const float m = (float)((a.alive ? a.alive[m0 + j] : 1) * (a.gate ? a.gate[m0 + j] : 1));
+                const float m = sg[el * N + j];
                 const bp_f32x4 x = Am4[(el * N + j) * LDA4 + c4];
                 Am4[(el * N + j) * LDA4 + c4] = m * (S - m * x) * scale;
             }
         }
         __syncthreads();
-        // ---- phase 1: P = m . C  (k = 8 kb + 4 lh + j: A fragment and B slot agree) ------------------------------------------
-        bp_f32x16 acc1[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc1[rt][i] = 0.0f;
+        // ---- phase 1: d h_direct + m . C  (k = 8 kb + 4 lh + j: A fragment and B slot agree) ---------------------------------
         float wv[4], wn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wv[j] = bp_load1(rcw, ((4 * lh + j) * H + col) * 4);
+        for (int j = 0; j < 4; ++j) wv[j] = bp_load1(rcw, (4 * lh * H + col) * 4, j * H * 4);
 #pragma unroll 2
         for (int kb = 0; kb < H / 8; ++kb) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wn[j] = bp_load1(rcw, ((8 * (kb + 1) + 4 * lh + j) * H + col) * 4);   // (past the end: 0)
+            for (int j = 0; j < 4; ++j) wn[j] = bp_load1(rcw, (4 * lh * H + col) * 4, (8 * (kb + 1) + j) * H * 4);   // (past the end: 0)
             const bp_f32x4 a0 = Am4[li * LDA4 + 2 * kb + lh];
             const bp_f32x4 a1 = Am4[(32 + li) * LDA4 + 2 * kb + lh];
 #pragma unroll
@@ -153,17 +168,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void comm_bwd_kernel(con
             for (int j = 0; j < 4; ++j) wv[j] = wn[j];
         }
         {
-            const __amdgpu_buffer_rsrc_t rdd = bp_rsrc(a.dxh + r0 * a.ldd + H, ((long long)(rows - 1) * a.ldd + H) * 4);
             const __amdgpu_buffer_rsrc_t rout = bp_rsrc(a.dh_out + r0 * H, (long long)rows * H * 4);
             const __amdgpu_buffer_rsrc_t rsc = bp_rsrc(a.out_scale ? a.out_scale + r0 : a.dh_out, a.out_scale ? (long long)rows * 4 : 0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    float v = bp_load1(rdd, (lr * a.ldd + col) * 4) + acc1[rt][reg];
-                    if (a.out_scale) v *= bp_load1(rsc, lr * 4);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rout, (lr * H + col) * 4, 0, 0);   // (past the tile: dropped)
+                    const int lc = 32 * rt + (reg & 3) + 8 * (reg >> 2);
+                    float o = acc1[rt][reg];
+                    if (a.out_scale) o *= bp_load1(rsc, 4 * lh * 4, lc * 4);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), rout, (4 * lh * H + col) * 4, lc * H * 4, 0);   // (past the tile: dropped)
                 }
         }
         // ---- phase 2: dC[k][n] += sum_rows m[row][k] h_prev[row][n]: A = m^T from LDS, B = the h_prev registers ---------------
@@ -200,15 +214,17 @@ __global__ __launch_bounds__(256) void dh_copy_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // ic3_lstm_weight_grad.  dW[m][n] = sum_q X[q][m] D[q][n], X = [inp | h_prev] (2H columns), D = dgates (4H columns), q over
-// the Q = T x R recorded rows.  Workgroup (ks, ny): K-slice ks of the rows, output columns [256 ny, 256 ny + 256), all 2H output
-// rows; 8 waves as 2 (m) x 4 (n), a wave holds H x 64 of the result in H / 8 x ... accumulator registers (128 at H = 128).
+// the Q = T x R recorded rows.  Workgroup (ks, ny): K-slice ks of the rows, output columns [128 ny, 128 ny + 128), all 2H output
+// rows; 4 waves as 2 (m) x 2 (n), a wave holds H x 64 of the result (128 accumulator registers at H = 128); two workgroups per
+// CU, so that one's staging and barrier sit beside the other's matrix work (a single 8-wave workgroup per CU ran in lock-step:
+// 106 instead of ... TFLOP/s).
 // Both operands are row-major with q outermost — exactly what v_mfma_f32_32x32x2_f32 wants of a K-major pair: lane (i, kk)
 // supplies X[q0 + kk][m(i)] and D[q0 + kk][n(i)], consecutive lanes read consecutive floats, no transposes anywhere.  One
 // ds_read_b128 of X feeds the A operands of four m-blocks (block j takes element j: m = 4 i + j — a permutation of the output
 // rows the epilogue undoes), one ds_read_b64 of D the B operands of two n-blocks: 6 LDS dwords per 8 MFMAs.
 // Staging: KT = 16 rows per stage, global -> registers -> LDS, double-buffered, one barrier per stage.
-// Bound: MFMA (2 Q 2H 4H flop on the fp32 instruction: 1.72 TFLOP for a PP-hard update); HBM reads Q (2H + 4H + 2H) floats (X is
-// read by both column halves), a third of the matrix time at 5 TB/s.
+// Bound: MFMA (2 Q 2H 4H flop on the fp32 instruction: 1.72 TFLOP for a PP-hard update); X is read once per column block
+// (4 H / 128 times, from L2 when the blocks of a slice run together: they are gridDim.x apart, i.e. on one XCD), D once.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct WGradArgs {
     const float* inp;        // [Q][ldi]: the first H floats of a row = inp
@@ -221,15 +237,14 @@ struct WGradArgs {
 };
 
 template <int H>
-__global__ __launch_bounds__(512) void lstm_wgrad_kernel(const WGradArgs a)
+__global__ __launch_bounds__(256, 2) void lstm_wgrad_kernel(const WGradArgs a)
 {
-    constexpr int KT = 16, XW = 2 * H, DW = 256, MB = H / 32, NB = 2;
+    constexpr int KT = 16, XW = 2 * H, DW = 128, MB = H / 32, NB = 2, NT = 256;
     constexpr int X4R = XW / 4, D4R = DW / 4;                    // float4 per staged row
-    constexpr int XPT = KT * X4R / 512, DPT = KT * D4R / 512;    // float4 per thread and stage
-    static_assert(XPT >= 1 && DPT == 2, "staging split");
+    constexpr int XPT = KT * X4R / NT, DPT = KT * D4R / NT;      // float4 per thread and stage (4 / 2 at H = 128)
+    static_assert(XPT >= 1 && DPT == 2 && (NT % X4R) == 0, "staging split");
     IC3_DYNAMIC_LDS(float, smem);
-    // stage b: X at smem + b * SW, D behind it
-    constexpr int SW = KT * (XW + DW);
+    constexpr int SW = KT * (XW + DW);                           // stage b: X at smem + b * SW, D behind it
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int wm = w & 1, wn = w >> 1;
     const int ny = blockIdx.y;
@@ -242,32 +257,37 @@ __global__ __launch_bounds__(512) void lstm_wgrad_kernel(const WGradArgs a)
     const __amdgpu_buffer_rsrc_t rd = bp_rsrc(a.dg + q0 * 4 * H + ny * DW, nq > 0 ? ((nq - 1) * 4 * H + DW) * 4 : 0);
     const __amdgpu_buffer_rsrc_t rl = bp_rsrc(a.row_live ? a.row_live + q0 : a.h, a.row_live ? nq * 4 : 0);
     const int nstages = (int)((nq + KT - 1) / KT);
+    // a thread stages the same (row-in-stage, column chunk) of every stage: X chunk i at row xrow + i * (NT / X4R)
+    const int xrow = tid / X4R, xc4 = tid - xrow * X4R;
+    const bool x_is_h = xc4 >= H / 4;
+    const int xvoff = x_is_h ? (xrow * H + 4 * xc4 - H) * 4 : (xrow * a.ldi + 4 * xc4) * 4;
+    const int xstep = (NT / X4R) * (x_is_h ? H : a.ldi) * 4;    // bytes between two of the thread's chunks
+    const int drow = tid / D4R, dc4 = tid - drow * D4R;
+    const int dvoff = (drow * 4 * H + 4 * dc4) * 4;
 
     bp_f32x4 xr[XPT], dr[DPT];
     auto fetch = [&](int s) {
         const int qb = s * KT;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const int idx = tid + i * 512, row = idx / X4R, c4 = idx - row * X4R;
-            if (c4 < H / 4) xr[i] = bp_load4(ri, ((qb + row) * a.ldi + 4 * c4) * 4);
-            else {
-                xr[i] = bp_load4(rh, ((qb + row) * H + 4 * c4 - H) * 4);
-                if (a.row_live) xr[i] *= bp_load1(rl, (qb + row) * 4);
+            if (x_is_h) {
+                xr[i] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, xvoff + i * xstep, qb * H * 4, 0));
+                if (a.row_live) xr[i] *= bp_load1(rl, (xrow + i * (NT / X4R)) * 4, qb * 4);
+            } else {
+                xr[i] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, xvoff + i * xstep, qb * a.ldi * 4, 0));
             }
         }
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) {
-            const int idx = tid + i * 512, row = idx / D4R, c4 = idx - row * D4R;
-            dr[i] = bp_load4(rd, ((qb + row) * 4 * H + 4 * c4) * 4);
-        }
+        for (int i = 0; i < DPT; ++i)
+            dr[i] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, dvoff + i * (NT / D4R) * 4 * H * 4, qb * 4 * H * 4, 0));
     };
     auto stash = [&](int b) {
         bp_f32x4* X4 = reinterpret_cast<bp_f32x4*>(smem + b * SW);
         bp_f32x4* D4 = reinterpret_cast<bp_f32x4*>(smem + b * SW + KT * XW);
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) X4[tid + i * 512] = xr[i];
+        for (int i = 0; i < XPT; ++i) X4[tid + i * NT] = xr[i];
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) D4[tid + i * 512] = dr[i];
+        for (int i = 0; i < DPT; ++i) D4[tid + i * NT] = dr[i];
     };
     bp_f32x16 acc[MB][NB];
 #pragma unroll
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(512) void lstm_wgrad_kernel(const WGradArgs a)
         __syncthreads();
     }
     // block (mb, nb), register reg, lane (li, lh): output row m = wm H + MB i + mb with i = (reg & 3) + 8 (reg >> 2) + 4 lh,
-    // output column n = 256 ny + 64 wn + 2 li + nb
+    // output column n = 128 ny + 64 wn + 2 li + nb
     float* dst = a.part + (size_t)blockIdx.x * XW * 4 * H;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -378,7 +398,7 @@ extern "C" int ic3_comm_backward(const float* dxh, int ldd, const float* h_prev,
     const CommBwdArgs a{ dxh, h_prev, alive, gate, c_weight, out_scale, dh_out, dcw_partials, ldd, E, N, ept, tiles,
                          mode_avg, accumulate };
     const int grid = ic3_comm_backward_partials(E, N);
-    const size_t lds = (size_t)64 * (H + 4) * sizeof(float);
+    const size_t lds = ((size_t)64 * (H + 4) + 128) * sizeof(float);
     if (H == 128) {
         IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(comm_bwd_kernel<128>), lds));
         hipLaunchKernelGGL((comm_bwd_kernel<128>), dim3(grid), dim3(256), lds, s, a);
@@ -393,8 +413,8 @@ extern "C" int ic3_comm_backward(const float* dxh, int ldd, const float* h_prev,
 // ---- ic3_lstm_weight_grad ----------------------------------------------------------------------------------------------------
 static int wgrad_slices(long long Q, int H)
 {
-    const int ny = 4 * H / 256;
-    int ks = ic3::bp_cus() / ny;
+    const int ny = 4 * H / 128;
+    int ks = 2 * ic3::bp_cus() / ny;                             // two workgroups per CU
     const long long most = (Q + 15) / 16;
     if (ks > most) ks = (int)most;
     return ks < 1 ? 1 : ks;
@@ -420,13 +440,13 @@ extern "C" int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_pr
         return fail(-22, "ic3_lstm_weight_grad: a K slice must stay below 2 GB per operand (32-bit buffer offsets)");
     const WGradArgs a{ inp, h_prev, dgates, row_live, scratch, Q, ldi, (int)per };
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * 16 * (2 * H + 256) * sizeof(float);
+    const size_t lds = (size_t)2 * 16 * (2 * H + 128) * sizeof(float);
     if (H == 128) {
         IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_wgrad_kernel<128>), lds));
-        hipLaunchKernelGGL((lstm_wgrad_kernel<128>), dim3(ks, 2), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((lstm_wgrad_kernel<128>), dim3(ks, 4), dim3(256), lds, s, a);
     } else {
         IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_wgrad_kernel<64>), lds));
-        hipLaunchKernelGGL((lstm_wgrad_kernel<64>), dim3(ks, 1), dim3(512), lds, s, a);
+        hipLaunchKernelGGL((lstm_wgrad_kernel<64>), dim3(ks, 2), dim3(256), lds, s, a);
     }
     IC3_HIP(hipGetLastError());
     const int n = 2 * H * 4 * H;

@@ -618,75 +618,61 @@ namespace ic3 {
 // (trainer.py:128-225 through comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o], m over all
 // M = T * R (step, row) pairs.  Per step this was a K = R library GEMM with an 8 x 128 result (+ two reduction launches);
 // as ONE product its K = 6.5 M (PP-hard) is a shape the library tunes for minutes.  HBM-bound: every h row is read once
-// (M * H * 4 bytes: 3.4 GB per PP-hard update = 0.6 ms).  A workgroup of H threads... 256 threads walk a contiguous range of
-// rows: thread (c, half) keeps OT partial sums of column c for the rows of its half; the d rows of 64 rows go through
-// LDS (broadcast reads).  Partials [grid][OT][H] are reduced by a second small launch in a fixed order (reproducible).
-constexpr int HG_ROWS = 64;
+// (M * H * 4 bytes: 3.4 GB per PP-hard update = 0.6 ms).  Round 6: on the fp32 matrix instruction — v_mfma_f32_32x32x2_f32 with
+// A = d^T (output row = o, the 32 - OT rows beyond the heads are zeros), B = h, K = two rows per instruction: a lane loads ONE
+// float of h (its column of the wave's 32-column block, row by lane half) and one of d per instruction, nothing goes through
+// LDS (rounds 4-5 broadcast the d rows from LDS to one thread per column: 1.78 ms, bound by the LDS instruction issue).  A wave
+// owns a 32-column block; with fewer than four blocks (hid 64) the waves split the rows too.  Partials [parts][17][H] (row 16:
+// the bias sums) are reduced by a second small launch in a fixed order (reproducible).
+typedef float hg_f32x16 __attribute__((ext_vector_type(16)));
 template <int H>
 __global__ __launch_bounds__(256) void heads_grad_kernel(const float* __restrict__ d, const float* __restrict__ h, long long M, int OT,
-                                                         float* __restrict__ partial /* [grid][17][H] */)
+                                                         float* __restrict__ partial /* [grid * NRG][17][H] */)
 {
-    constexpr int HALVES = 256 / H;                              // row lanes per workgroup (H = 64: 4, 128: 2, 256: 1)
-    __shared__ float sd[HG_ROWS * 16];
-    const int c = threadIdx.x % H, half = threadIdx.x / H;
-    float acc[16], bsum[16];
-#pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = bsum[o] = 0.0f;
+    constexpr int CB = H / 32, NRG = CB >= 4 ? 1 : 4 / CB, BPW = CB > 4 ? CB / 4 : 1, U = 8;   // column blocks, row groups, blocks per wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int cb0 = (w % (CB < 4 ? CB : 4)) * BPW, rg = CB >= 4 ? 0 : w / CB;
     const long long per = (M + gridDim.x - 1) / gridDim.x;
-    const long long m0 = (long long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
-    for (long long base = m0; base < m1; base += HG_ROWS) {
-        const int n = (int)((m1 - base) < HG_ROWS ? (m1 - base) : HG_ROWS);
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < HG_ROWS * 16; idx += 256) {
-            const int row = idx >> 4, o = idx & 15;
-            sd[idx] = (row < n && o < OT) ? d[(base + row) * OT + o] : 0.0f;
+    const long long m0 = (long long)blockIdx.x * per;
+    long long nrows = M - m0 < per ? M - m0 : per;
+    if (nrows < 0) nrows = 0;
+    const uint32_t hbytes = (uint32_t)(nrows * H * 4), dbytes = (uint32_t)(nrows * OT * 4);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h + m0 * H), 0, hbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d + m0 * OT), 0, dbytes, 0x00020000);
+    hg_f32x16 acc[BPW];
+#pragma unroll
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.0f;
+    float bsum = 0.0f;
+    const bool has_o = li < OT;
+    const int hv0 = ((2 * rg + lh) * H + 32 * cb0 + li) * 4, dv0 = ((2 * rg + lh) * OT + (has_o ? li : 0)) * 4;
+    for (long long base = 0; base < nrows; base += 2 * NRG * U) {
+        float hv[U][BPW], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = (int)base + 2 * NRG * u;                // rows r + 2 rg + lh of the workgroup's range (past it: 0)
+#pragma unroll
+            for (int b = 0; b < BPW; ++b)
+                hv[u][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, hv0 + 32 * b * 4, r * H * 4, 0));
+            const float dl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, dv0, r * OT * 4, 0));
+            dv[u] = has_o ? dl : 0.0f;                           // (output rows beyond the heads: zeros)
         }
-        __syncthreads();
-        for (int row = half; row < n; row += HALVES) {
-            const float hv = h[(base + row) * H + c];
-            const f32x4* dr = reinterpret_cast<const f32x4*>(sd + row * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 d4 = dr[q];
-                acc[4 * q] += d4[0] * hv;
-                acc[4 * q + 1] += d4[1] * hv;
-                acc[4 * q + 2] += d4[2] * hv;
-                acc[4 * q + 3] += d4[3] * hv;
-                if (c == 0) {
-                    bsum[4 * q] += d4[0];
-                    bsum[4 * q + 1] += d4[1];
-                    bsum[4 * q + 2] += d4[2];
-                    bsum[4 * q + 3] += d4[3];
-                }
-            }
-        }
-    }
-    // fold the row lanes of the workgroup (fixed order), one partial per workgroup
-    __shared__ float fold[256][17];
-    __syncthreads();
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int o = 0; o < 16; ++o) fold[threadIdx.x][o] = acc[o];
-    __syncthreads();
-    if (half == 0) {
-        float* out = partial + (size_t)blockIdx.x * 17 * H;
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            float v = fold[c][o];
-            for (int q = 1; q < HALVES; ++q) v += fold[q * H + c][o];
-            out[o * H + c] = v;
+            for (int b = 0; b < BPW; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], hv[u][b], acc[b], 0, 0, 0);
+            bsum += dv[u];
         }
     }
-    __syncthreads();
-    if (c == 0) {
+    // accumulator register reg, lane (li, lh) <-> o = (reg & 3) + 8 (reg >> 2) + 4 lh, column 32 block + li: o < 16 <-> reg < 8
+    float* out = partial + ((size_t)blockIdx.x * NRG + rg) * 17 * H;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) fold[half][o] = bsum[o];
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        float v = 0.0f;
-        for (int q = 0; q < HALVES; ++q) v += fold[q][threadIdx.x];
-        partial[(size_t)blockIdx.x * 17 * H + 16 * H + threadIdx.x] = v;
-    }
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 8; ++reg) out[((reg & 3) + 8 * (reg >> 2) + 4 * lh) * H + 32 * (cb0 + b) + li] = acc[b][reg];
+    bsum += __shfl_xor(bsum, 32);
+    if (cb0 == 0 && lh == 0 && li < 16) out[16 * H + li] = bsum;      // (li >= OT: 0)
 }
 
 __global__ void heads_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int H, int OT, float* __restrict__ dW,
@@ -716,13 +702,15 @@ extern "C" int ic3_heads_grad(const float* d, const float* h, long long M, int H
     if (!d || !h || !dW || !db || !scratch || M <= 0 || OT < 1 || OT > 16) return fail(-22, "ic3_heads_grad: bad arguments");
     if (H != 64 && H != 128 && H != 256) return fail(-38, "ic3_heads_grad: hid_size 64 / 128 / 256");
     hipStream_t s = (hipStream_t)stream;
-    int grid = (int)std::min<long long>(1024, (M + HG_ROWS - 1) / HG_ROWS);
+    const int nrg = H == 64 ? 2 : 1;                              // (hid 64: two column blocks, the waves split the rows as well)
+    int grid = (int)std::min<long long>(1024 / nrg, (M + 63) / 64);
+    if ((M + grid - 1) / grid * (long long)H * 4 >= (1ll << 31)) return fail(-22, "ic3_heads_grad: too many rows per workgroup");
     if (H == 64) hipLaunchKernelGGL((heads_grad_kernel<64>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
     else if (H == 128) hipLaunchKernelGGL((heads_grad_kernel<128>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
     else hipLaunchKernelGGL((heads_grad_kernel<256>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
     IC3_HIP(hipGetLastError());
     const int n = OT * H + OT;
-    hipLaunchKernelGGL(heads_grad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, grid, H, OT, dW, db);
+    hipLaunchKernelGGL(heads_grad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, grid * nrg, H, OT, dW, db);
     IC3_HIP(hipGetLastError());
     return 0;
 }
