@@ -174,3 +174,100 @@ def test_gates_backward_from_recorded_gates(H, R):
     ops.lstm_gates_backward(xh.clone(), wp, b, c_prev, dh, dc, dg2, dcp2, None, False, h_prev=h_prev, lstm_wp3=wp3, lstm_wp3_bwd=wb3, dxh=dx2)
     assert float((dg2 - dgates).abs().max()) <= 4e-6 * max(1.0, float(want.abs().max()))
     assert float((dx2 - dxh).abs().max()) <= 6e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("H,R,OT", [(128, 64 * 150 + 37, 8), (64, 150, 5), (128, 640, 16)])
+def test_gates_backward_given_in_place_with_the_heads_share(H, R, OT):
+    """Round 6: ic3_lstm_gates_backward_given with dhead / w_heads (dh + dhead . w_heads is what the cell sees) and with
+    dgates written over the gates (in place) = the same launch on a dh that already holds the heads' share, out of place;
+    cold and warm launches agree bit for bit (builtin MFMAs: the compiler places the wait states)."""
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(7 * H + R)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    w_ih, w_hh = rn(4 * H, H) / H ** 0.5, rn(4 * H, H) / H ** 0.5
+    wb3 = ops.policy_pack_split_bwd(w_ih, w_hh)
+    acts = torch.rand((R, 4 * H), device='cuda', generator=gen)
+    acts[:, 2 * H:3 * H] = acts[:, 2 * H:3 * H] * 2 - 1
+    c_prev, dh, dc = rn(R, H), rn(R, H), rn(R, H)
+    dhead, w_heads = rn(R, OT), rn(OT, H) / H ** 0.5
+    dh_full = (dh.double() + dhead.double() @ w_heads.double()).float()
+    tiles = (R + 63) // 64
+    ref = [torch.empty((R, 4 * H), device='cuda'), torch.empty((R, H), device='cuda'), torch.empty((R, 2 * H), device='cuda'),
+           torch.zeros((tiles, 4 * H), device='cuda')]
+    ops.lstm_gates_backward_given(acts, c_prev, dh_full, dc, ref[0], ref[1], ref[3], True, lstm_wp3_bwd=wb3, dxh=ref[2])
+    runs = []
+    for _ in range(3):
+        g = acts.clone()
+        got = [g, torch.empty((R, H), device='cuda'), torch.empty((R, 2 * H), device='cuda'), torch.zeros((tiles, 4 * H), device='cuda')]
+        ops.lstm_gates_backward_given(g, c_prev, dh, dc, g, got[1], got[3], True, lstm_wp3_bwd=wb3, dxh=got[2], dhead=dhead,
+                                      w_heads=w_heads)
+        runs.append(got)
+    for u, v in zip(runs[0], ref):      # (the fold adds its OT terms one at a time in fp32: the last ulp of dh may differ)
+        assert float((u - v).abs().max()) <= 3e-6 * max(1.0, float(v.abs().max()))
+    for k in range(4):
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[1][k], runs[2][k]), k
+
+
+def _mix(x, alive, gate, avg):
+    """comm.py:181-205 in closed form, float64 (E, N, H)"""
+    E, N, H = x.shape
+    al = torch.ones((E, N), device=x.device, dtype=torch.float64) if alive is None else alive.double()
+    g = al * (1.0 if gate is None else gate.double())
+    S = (g.unsqueeze(2) * x).sum(1, keepdim=True)
+    n_alive = al.sum(1)
+    scale = torch.where(n_alive > 1, 1.0 / (n_alive - 1).clamp(min=1), torch.ones_like(n_alive)) if avg else torch.ones_like(n_alive)
+    return g.unsqueeze(2) * (S - g.unsqueeze(2) * x) * scale.view(E, 1, 1)
+
+
+@pytest.mark.parametrize("H,N,E,avg,masks", [(128, 10, 8192, True, 'both'), (128, 20, 1000, True, 'alive'), (64, 3, 5000, False, 'gate'),
+                                             (128, 32, 333, True, None), (64, 64, 17, True, 'both'), (128, 10, 5, True, None)])
+def test_comm_backward_one_launch(H, N, E, avg, masks):
+    """ic3_comm_backward: dh_out = (d h_direct + (M d inp) . C) * out_scale, dC partials = (M d inp)^T . h_prev — against
+    d h_direct + M (d inp . C) and d inp^T . (M h_prev) in float64; launched twice: reproducible."""
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(H + N + E)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    R = E * N
+    dxh, hp, cw = rn(R, 2 * H), rn(R, H), rn(H, H) / H ** 0.5
+    alive = (torch.rand((E, N), device='cuda', generator=gen) < 0.8).to(torch.int32) if masks in ('alive', 'both') else None
+    gate = (torch.rand((E, N), device='cuda', generator=gen) < 0.6).to(torch.int32) if masks in ('gate', 'both') else None
+    scale = (torch.rand(R, device='cuda', generator=gen) < 0.7).float()
+    dinp, dhd = dxh[:, :H].double(), dxh[:, H:].double()
+    want_dh = (dhd + _mix((dinp @ cw.double()).view(E, N, H), alive, gate, avg).view(R, H)) * scale.double().unsqueeze(1)
+    want_dc = dinp.t() @ _mix(hp.double().view(E, N, H), alive, gate, avg).view(R, H)
+    outs = []
+    for _ in range(2):
+        dh = torch.full((R, H), float('nan'), device='cuda')
+        parts = torch.zeros((ops.comm_backward_partials(E, N), H, H), device='cuda')
+        ops.comm_backward(dxh, hp, alive, gate, cw, dh, parts, E, N, mode_avg=avg, out_scale=scale)
+        outs.append((dh, parts))
+    dh, parts = outs[0]
+    assert float((dh.double() - want_dh).abs().max()) <= 2e-6 * max(1.0, float(want_dh.abs().max()))
+    got = parts.double().sum(0)
+    assert float((got - want_dc).abs().max()) <= 2e-6 * (R ** 0.5) * max(1.0, float(hp.abs().max()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dz = torch.empty((R, H), device='cuda')
+    ops.comm_backward(dxh, None, None, None, None, dz, None, E, N, comm_zero=True, out_scale=scale)
+    assert torch.equal(dz, dxh[:, H:] * scale.unsqueeze(1))
+
+
+@pytest.mark.parametrize("H,T,R,live", [(128, 5, 81920, False), (128, 3, 1000, True), (64, 7, 333, True), (128, 1, 17, False),
+                                        (64, 2, 30000, False)])
+def test_weight_gradient_of_a_window_in_one_launch(H, T, R, live):
+    """ic3_lstm_weight_grad over T x R rows (K slices across the CUs) against the float64 product of [inp | h * live]^T . dgates;
+    added on top of what dW holds; reproducible."""
+    from ic3net_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(H + T + R)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
+    xh, hs, dg = rn(T, R, 2 * H), rn(T, R, H), rn(T, R, 4 * H)
+    lv = (torch.rand((T, R), device='cuda', generator=gen) < 0.8).float() if live else None
+    x = torch.cat([xh[:, :, :H].double(), hs.double() * (lv.double().unsqueeze(2) if live else 1.0)], 2).view(T * R, 2 * H)
+    want = 1.0 + x.t() @ dg.double().view(T * R, 4 * H)
+    outs = []
+    for _ in range(2):
+        dW = torch.ones((2 * H, 4 * H), device='cuda')
+        ops.lstm_weight_grad(xh, hs, dg, dW, row_live=lv)
+        outs.append(dW)
+    tol = 2e-6 * (T * R) ** 0.5 * 16
+    assert float((outs[0].double() - want).abs().max()) <= tol
+    assert torch.equal(outs[0], outs[1])

@@ -824,6 +824,39 @@ def test_native_update_reads_the_gates_the_rollout_recorded(wl, collect, hid):
         assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())), k
 
 
+@pytest.mark.parametrize("wl,collect,hid", [("pp_hard", False, 128), ("tj_hard", False, 128), ("pp_hard", True, 128),
+                                            ("tj_medium", True, 64), ("pp_hard_iric", False, 128), ("pp_easy", False, 32)])
+def test_backward_window_as_one_host_call_equals_the_per_step_loop(wl, collect, hid):
+    """Round 6: ic3_bptt_backward (the whole window in one host call: gate launch in place with the heads' share folded in,
+    ic3_comm_backward, encoder stage 1; the weight gradient of the window in one launch) against the per-step Python loop of
+    round 5 on the same recorded gates (args.bptt_native_loop=False: library products, two masked means per step) — the same
+    rollout bit for bit, gradients at 1e-5 of each tensor's scale (fp32 sums in another order; measured <= 3.2e-6)."""
+    import bench
+    out = []
+    for loop in (True, False):
+        tr, a = bench.build_trainer(wl, 12, 3, 0, 0, hid_size=hid)
+        a.max_steps, a.batch_size = 10, 12 * 10 * (3 if collect else 1)
+        a.detach_gap = 4
+        a.entr, a.value_coeff, a.gamma, a.normalize_rewards, a.advantages_per_action = 0.01, 0.01, 0.9, False, False
+        a.bptt_native_loop = loop
+        a.auto_reset = collect
+        assert tr._native_update()
+        tr._records = []
+        batch, stats = tr.run_batch(0)
+        recs = tr._records
+        assert recs[0].gates is not None and recs[0].gates_n == recs[0].n
+        hs_rolled = torch.cat([r.hs[:r.n] for r in recs]).clone()
+        tr.optimizer.zero_grad()
+        tr.compute_grad_native(batch, recs)
+        tr._records = None
+        out.append(({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None}, hs_rolled))
+    assert torch.equal(out[0][1], out[1][1])
+    assert out[0][0].keys() == out[1][0].keys()
+    for k in out[0][0]:
+        g0, g1 = out[0][0][k], out[1][0][k]
+        assert float((g0 - g1).abs().max()) <= 1e-5 * max(1e-3, float(g1.abs().max())), (k, float((g0 - g1).abs().max()), float(g1.abs().max()))
+
+
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
     episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)
