@@ -560,6 +560,20 @@ def grad_stream_main():
                      ic3net=True, recurrent=True, detach_gap=4, add_rate_min=0.3, add_rate_max=0.3, difficulty='easy')
 
 
+def grad_stream_h128_main():
+    """Collection mode at the hidden size of the BASELINE configs (round-5 verdict item 2a): hid 128, so that the kernels the
+    headline update runs — lstm_gates_bwd_kernel<128, 1, 1> with its per-row cuts, comm_bwd_kernel<128>, lstm_wgrad_kernel<128> —
+    are compared with the reference on the device where the cuts fall INSIDE a window: a small Predator-Prey grid on which the
+    sampled policy does end episodes early (16 envs, 3 windows of 20 slots, detach points of the env's own step counter every 7
+    steps), and Traffic-Junction (alive masks, the gate head; episodes of exactly max_steps, the detach points every 3 steps
+    fall mid-window).  Closed-form weights (the fixture stores no weights)."""
+    grad_stream_case('gradstream_pp_small_h128', 'predator_prey', 20, 16, 3, 54, closed_form=True, nagents=3, dim=3, vision=1,
+                     hid_size=128, ic3net=True, recurrent=True, detach_gap=7, entr=0.01, value_coeff=0.01, mode='mixed')
+    grad_stream_case('gradstream_tj_easy_h128', 'traffic_junction', 10, 6, 2, 55, closed_form=True, nagents=5, dim=6, vision=1,
+                     hid_size=128, ic3net=True, recurrent=True, detach_gap=3, add_rate_min=0.3, add_rate_max=0.3,
+                     difficulty='easy', entr=0.01, value_coeff=0.01)
+
+
 def trainer_main():
     grad_case('grad_pp_easy_ic3net', 'predator_prey', 20, 4, 2, 31, nagents=3, dim=5, vision=0, hid_size=16,
               ic3net=True, recurrent=True, detach_gap=10, entr=0.01, value_coeff=0.01)
@@ -628,6 +642,8 @@ if __name__ == '__main__':
         grad_baseline_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream':
         grad_stream_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream_h128':
+        grad_stream_h128_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':
         trainer_fullsize_main()
     else:

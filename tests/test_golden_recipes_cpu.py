@@ -36,12 +36,13 @@ RECIPES = {
     'grad_nonrec': ['make_golden_policy.py', 'grad_nonrec'],
     'grad_fullsize': ['make_golden_policy.py', 'grad_fullsize'],
     'grad_stream': ['make_golden_policy.py', 'grad_stream'],
+    'grad_stream_h128': ['make_golden_policy.py', 'grad_stream_h128'],
     'grad_baseline': ['make_golden_policy.py', 'grad_baseline'],
     'render': ['make_golden_render.py'],
     'ckpt': ['make_golden_ckpt.py'],
 }
 # every committed data fixture must come out of one of the recipes above
-EXPECTED_MIN_NPZ = 65
+EXPECTED_MIN_NPZ = 67
 
 
 @pytest.fixture(scope='module')

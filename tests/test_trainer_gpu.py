@@ -4,6 +4,8 @@ import argparse
 import ast
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -318,19 +320,63 @@ def test_compute_grad_matches_reference(name, env_name, native):
     finally:
         trmod.select_action = orig
         tr._records = None
-    for k in ("action_loss", "value_loss", "entropy"):
-        np.testing.assert_allclose(s[k], float(fx[k]), rtol=2e-4, atol=1e-3, err_msg=k)
+    _check_against_reference(name + ("/native" if native else "/autograd"), fx, s, net)
+
+
+def _check_against_reference(label, fx, s, net):
+    """Losses and every parameter gradient against the reference's (fp64), each at <= 4 x the error MEASURED for the fixture
+    (profiles/r06/grad_errors.txt, written by this function under IC3_GRAD_ERRORS=<file>; round-5 verdict item 2b: the blanket
+    3e-4 of rounds 3-5 would have passed an error 100 x the stale-plane defect's).  Gradients: max |g - g_ref| over the tensor,
+    relative to the tensor's max |g_ref|; losses: relative."""
+    loss_err = max(abs(s[k] - float(fx[k])) / max(abs(float(fx[k])), 1.0) for k in ("action_loss", "value_loss", "entropy"))
+    worst, worst_name = 0.0, None
     for pname, p in net.named_parameters():
         g = fx["g:" + pname]
         if g.size == 0:
             assert p.grad is None, pname            # unused hidd_encoder (quirk Q18)
             continue
         scale = max(np.abs(g).max(), 1e-6)
-        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=3e-4, err_msg=pname)
+        err = float(np.abs(p.grad.cpu().numpy().astype(np.float64) - g).max() / scale)
+        if err >= worst:
+            worst, worst_name = err, pname
+    out = os.environ.get("IC3_GRAD_ERRORS")
+    if out:
+        with open(out, "a") as f:
+            f.write("%-44s gradients %.3e (%s)   losses %.3e\n" % (label, worst, worst_name, loss_err))
+    fixture = label.split("/")[0]
+    gtol, ltol = GRAD_TOL.get(fixture, GRAD_TOL_DEFAULT)
+    assert loss_err <= ltol, (label, "losses", loss_err, ltol)
+    assert worst <= gtol, (label, worst_name, worst, gtol)
+
+
+# (gradient, loss) bars per fixture = 4 x the worst error measured over the paths that run it (profiles/r06/grad_errors.txt),
+# floored at 4e-6 / 2e-6 — fp32 on the GPU against the reference's fp64.  A fixture without an entry fails: measure it first.
+GRAD_TOL_DEFAULT = (0.0, 0.0)
+GRAD_TOL = {
+    "grad_pp_easy_ic3net":             (5.6e-06, 2.0e-06),
+    "grad_pp_hard_ic3net":             (4.3e-05, 4.2e-06),
+    "grad_pp_medium_commnet_mlp2":     (4.0e-06, 2.0e-06),
+    "grad_pp_medium_commnet_norm":     (4.0e-06, 1.0e-04),
+    "grad_pp_medium_ic_mlp":           (4.0e-06, 2.0e-06),
+    "grad_pp_medium_iric_rnn":         (4.0e-06, 1.1e-04),
+    "grad_tj_easy_ic3net":             (4.0e-06, 2.0e-06),
+    "grad_tj_easy_ic3net_mlp2share":   (4.0e-06, 2.0e-06),
+    "grad_tj_easy_iric_lstm":          (4.0e-06, 2.0e-06),
+    "grad_tj_hard_ic3net":             (7.0e-05, 2.0e-06),
+    "grad_tj_medium_perhead":          (4.0e-06, 2.0e-06),
+    "gradstream_pp_small_h128":        (7.0e-06, 2.0e-06),
+    "gradstream_pp_tiny_commnet":      (4.0e-06, 6.5e-06),
+    "gradstream_pp_tiny_ic3net":       (4.0e-06, 2.0e-06),
+    "gradstream_tj_easy_h128":         (3.8e-05, 2.0e-06),
+    "gradstream_tj_easy_ic3net":       (5.3e-06, 2.0e-06),
+}
 
 
 STREAM_FIXTURES = [("gradstream_pp_tiny_ic3net", "predator_prey"), ("gradstream_pp_tiny_commnet", "predator_prey"),
-                   ("gradstream_tj_easy_ic3net", "traffic_junction")]
+                   ("gradstream_tj_easy_ic3net", "traffic_junction"),
+                   # hid 128 (round 6): the kernels of the BASELINE updates with cuts INSIDE the windows — 10 of 48 Predator-Prey
+                   # episodes end early, 7 of 16 streams run out of phase with the windows; TJ: detach points every 3 steps
+                   ("gradstream_pp_small_h128", "predator_prey"), ("gradstream_tj_easy_h128", "traffic_junction")]
 
 
 @pytest.mark.parametrize("name,env_name", STREAM_FIXTURES)
@@ -362,7 +408,12 @@ def test_collection_mode_grad_matches_reference(name, env_name):
         a.recurrent, a.rnn_type = True, 'LSTM'
     parse_action_args(a)
     net = CommNetMLP(a, a.num_inputs)
-    net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
+    if "param_names" in fx.files:                     # hid-128 fixtures: weights from the index alone
+        from policy_util import closed_form_weights
+        shapes = {str(n): eval(str(sh)) for n, sh in zip(fx["param_names"], fx["param_shapes"])}
+        net.load_state_dict({k: torch.from_numpy(v).float() for k, v in closed_form_weights(shapes).items()})
+    else:
+        net.load_state_dict({k[2:]: torch.from_numpy(fx[k]).float() for k in fx.files if k.startswith("w:")})
     net = net.cuda()
     tr = trmod.Trainer(a, net, env)
     a.batch_size = nenv * T * nwin                      # slots: exactly nwin windows
@@ -387,15 +438,7 @@ def test_collection_mode_grad_matches_reference(name, env_name):
         s = tr.compute_grad_native(batch, tr._records)
     finally:
         tr._records = None
-    for k in ("action_loss", "value_loss", "entropy"):
-        np.testing.assert_allclose(s[k], float(fx[k]), rtol=2e-4, atol=1e-3, err_msg=k)
-    for pname, p in net.named_parameters():
-        g = fx["g:" + pname]
-        if g.size == 0:
-            assert p.grad is None, pname
-            continue
-        scale = max(np.abs(g).max(), 1e-6)
-        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, g / scale, rtol=0, atol=3e-4, err_msg=pname)
+    _check_against_reference(name + "/collection", fx, s, net)
 
 
 def test_collection_mode_train_batch_runs_at_a_baseline_shape():
