@@ -75,7 +75,8 @@ class Bptt(C.Structure):
                 ("snap_words", C.c_int64), ("alive", C.POINTER(C.c_void_p)), ("gate", C.POINTER(C.c_void_p)),
                 ("row_live", C.c_void_p), ("row_keep", C.c_void_p), ("lstm_wp3_bwd", C.c_void_p), ("w_heads", C.c_void_p),
                 ("c_weight", C.c_void_p), ("dh", C.c_void_p), ("dc", C.c_void_p), ("dxh", C.c_void_p),
-                ("dbias_partials", C.c_void_p), ("dcw_partials", C.c_void_p), ("enc_work", C.c_void_p)]
+                ("dbias_partials", C.c_void_p), ("dcw_partials", C.c_void_p), ("enc_work", C.c_void_p),
+                ("gate_events", C.POINTER(C.c_void_p))]
 
 
 EXPORTS = {

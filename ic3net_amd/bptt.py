@@ -455,7 +455,8 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
     dhead = d_out if d_out.is_contiguous() else d_out.contiguous()
     ops.bptt_backward(raw, T, E, N, H, rec.gates, rec.hs, rec.cs, dhead, rec.snaps, alive, gate, fc['ps_l_wp3_bwd'], fc['w_heads'],
                       None if mask_zero else net.C_modules[0].weight.detach(), dh_rec, dc_rec, dxh, bias_parts, dcw_parts,
-                      mode_avg=mode_avg, comm_zero=mask_zero, detach_gap=gap, row_live=live_flat, row_keep=keep_flat, enc_first=True)
+                      mode_avg=mode_avg, comm_zero=mask_zero, detach_gap=gap, row_live=live_flat, row_keep=keep_flat, enc_first=True,
+                      gate_events=getattr(raw, 'gate_timer', None))     # (bench.py --mode train: HIP events around the gate launches)
     work = acc.setdefault('_work', {})
     ops.lstm_weight_grad(rec.xh[:T], rec.hs[:T], rec.gates[:T], acc['w_cat_t'], row_live=live_flat, accumulate=True, work=work)
     dwt, db = raw.encode_backward_finish(H, want_bias=True)

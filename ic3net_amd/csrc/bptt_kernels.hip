@@ -499,12 +499,14 @@ extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream str
             IC3_HIP(hipMemsetAsync(b->dc, 0, (size_t)R * H * sizeof(float), s));
         }
         float* g = b->gates + (size_t)t * R * 4 * H;
+        if (b->gate_events) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t], s));
         int rc = ic3_lstm_gates_backward_given(g, nullptr, 0, nullptr, b->lstm_wp3_bwd, b->cs + (size_t)t * R * H, b->dh, b->dc, g,
                                                b->dc, b->dbias_partials, 1, b->dxh,
                                                b->row_live ? b->row_live + (size_t)t * R : nullptr,
                                                b->row_keep ? b->row_keep + (size_t)t * R : nullptr,
                                                b->dhead + (size_t)t * R * b->OT, b->w_heads, b->OT, (int)R, H, stream);
         if (rc < 0) return rc;
+        if (b->gate_events) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t + 1], s));
         const float* out_scale = (b->row_keep && t > 0) ? b->row_keep + (size_t)(t - 1) * R : nullptr;
         rc = ic3_comm_backward(b->dxh, 2 * H, b->hs + (size_t)t * R * H, b->alive ? b->alive[t] : nullptr,
                                b->gate ? b->gate[t] : nullptr, b->c_weight, out_scale, b->dh, b->dcw_partials, 1, E, N, H,
@@ -515,6 +517,5 @@ extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream str
         if (rc < 0) return rc;
         enc_first = 0;
     }
-    (void)s;
     return 0;
 }

@@ -322,10 +322,11 @@ def bptt_backward_supported(env, H):
 
 def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lstm_wp3_bwd, w_heads, c_weight, dh, dc, dxh,
                   dbias_partials, dcw_partials, mode_avg=True, comm_zero=False, detach_gap=0, row_live=None, row_keep=None,
-                  enc_first=True):
+                  enc_first=True, gate_events=None):
     """ic3_bptt_backward: the backward through a window of T recorded steps as one host call (gate launch in place on the
     record, communication backward, encoder backward stage 1 — three launches per step).  alive / gate: lists of T tensors
-    (E, N) int32 or None entries, or None."""
+    (E, N) int32 or None entries, or None.  gate_events: a list that receives (start, stop, t) DispatchEvent triples stamped
+    around every step's gate launch (measurement: bench.py --mode train)."""
     import ctypes as C
     _need_cuda(gates, "bptt_backward")
     R = E * N
@@ -368,7 +369,15 @@ def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lst
     b.dbias_partials = dbias_partials.data_ptr()
     b.dcw_partials = dcw_partials.data_ptr() if dcw_partials is not None else None
     b.enc_work = env._encb_work(H).data_ptr()
+    evs = None
+    if gate_events is not None:
+        from .envs import DispatchEvent
+        evs = [DispatchEvent() for _ in range(2 * T)]
+        arr = (C.c_void_p * (2 * T))(*[e.handle.value for e in evs])
+        b.gate_events = C.cast(arr, C.POINTER(C.c_void_p))
     check(_lib.lib().ic3_bptt_backward(env._h, C.byref(b), stream()))
+    if evs is not None:
+        gate_events.extend((evs[2 * t], evs[2 * t + 1], t) for t in range(T))
 
 
 HEADS_GRAD_MAX_OT = 16      # ic3_heads_grad: at most 16 output columns (the heads' actions in total + the value)

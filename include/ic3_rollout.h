@@ -398,7 +398,7 @@ int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_prev, const f
  *   step t with (t + 1) % detach_gap == 0 (trainer.py:56-60, lock-step windows);  dh, dc [R][H] in: dL/d(h, c) arriving at the
  *   window's last step, out: leaving its first;  dxh [R][2H] scratch;  dbias_partials [ceil(R / 64)][4H] and dcw_partials
  *   [ic3_comm_backward_partials][H][H] are ADDED to (zero them before the first window);  enc_work as
- *   ic3_env_encode_backward_accumulate, enc_first != 0: this window starts the accumulation.
+ *   ic3_env_encode_backward_accumulate, enc_first != 0: this window starts the accumulation;  gate_events: see the struct.
  * ic3_bptt_backward_supported(env, H): 1 when every step can run (hid_size 64 / 128, <= 64 agents, the encoder backward in its
  * partial-sums form) — the loop overwrites the record as it goes, so ask first. */
 typedef struct ic3_bptt {
@@ -424,6 +424,8 @@ typedef struct ic3_bptt {
     float* dbias_partials;
     float* dcw_partials;
     float* enc_work;
+    void** gate_events;     /* measurement support: NULL, or 2 T events (ic3_event_create) — [2t] / [2t + 1] are recorded on the
+                               stream in front of / behind step t's gate launch (read them with ic3_event_elapsed_ms) */
 } ic3_bptt;
 int ic3_bptt_backward_supported(const ic3_env* env, int H);
 int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream stream);
