@@ -39,9 +39,21 @@ _FLAGS = [
     ('share_weights', 'flag', False),
 ]
 # engine flags (new)
-_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', int, 1), ('tune_gemm', 'flag', False),
+def _hip_graph_mode(v):
+    """--hip_graph [0 | 1 | episode | step]: 1 / episode (the default; also a bare `--hip_graph`): rollouts that feed no update
+    (evaluation, --display off) replay ONE hipGraph per episode; step: one graph per step index; 0: eager launches."""
+    v = str(v).lower()
+    if v in ('0', 'false', 'off', 'eager'):
+        return False
+    if v in ('1', 'true', 'on', 'episode'):
+        return True
+    if v == 'step':
+        return 'step'
+    raise argparse.ArgumentTypeError("--hip_graph takes 0, 1, episode or step (got %r)" % v)
+
+
+_ENGINE_FLAGS = [('nenvs', int, 32), ('device', int, -1), ('hip_graph', 'hip_graph', True), ('tune_gemm', 'flag', False),
                  ('dist_backend', str, 'nccl')]     # 'nccl' = RCCL over xGMI; 'gloo' for several ranks on one GPU (tests)
-# hip_graph 1 (default): rollouts that feed no update (evaluation, --display off) replay ONE hipGraph per episode; 0 = eager
 
 
 def build_parser(argv):
@@ -49,6 +61,8 @@ def build_parser(argv):
     for name, typ, default in _FLAGS + _ENGINE_FLAGS:
         if typ == 'flag':
             parser.add_argument('--' + name, action='store_true', default=default)
+        elif typ == 'hip_graph':
+            parser.add_argument('--' + name, type=_hip_graph_mode, nargs='?', const=True, default=default)
         else:
             parser.add_argument('--' + name, type=typ, default=default)
     init_args_for_env(parser, argv)                 # main.py:112: the env adds its own flag group

@@ -205,8 +205,7 @@ class Trainer(object):
         lstm = bool(getattr(args, 'recurrent', False)) and getattr(args, 'rnn_type', '') == 'LSTM'
         if not cont:
             self._info = dict()
-            # trainer.py:41; an LSTM policy replaces it by init_hidden() at t = 0 (trainer.py:50-51), so not allocated then
-            self._prev_hid = None if lstm else torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)
+            self._prev_hid = None                                  # (set below, once the episode's buffers exist)
         self._nsteps = 0
         # Episode buffers [T, ...]: the env / sampling kernels write step t's outputs straight into slice t, so the
         # hot loop launches no bookkeeping kernels; masks and statistics are derived once in end_episode().
@@ -219,6 +218,18 @@ class Trainer(object):
                                 ones=torch.ones((E, N), dtype=torch.int32, device=dev),
                                 zeros=torch.zeros((E, N), dtype=torch.int32, device=dev))
         self._buf = self._static
+        if not cont and not lstm:
+            # trainer.py:41; an LSTM policy replaces it by init_hidden() at t = 0 (trainer.py:50-51), so not allocated then.
+            # Graph mode: step 0's captured launches READ this tensor on every replay — it lives in the static buffers and is
+            # zeroed here, in front of the replay (a fresh torch.zeros per episode would leave the graph reading a freed block)
+            if self._use_graph():
+                ph = self._static.get('prev_hid')
+                if ph is None or tuple(ph.shape) != (E, args.nagents, args.hid_size):
+                    ph = self._static['prev_hid'] = torch.empty((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)
+                ph.zero_()
+                self._prev_hid = ph
+            else:
+                self._prev_hid = torch.zeros((E, args.nagents, args.hid_size), dtype=torch.float32, device=dev)
         self._step_out = [(None, None, None, None)] * T          # (state, action_out, value, next_state) per step
         self._rec = None
         if self._records is not None:                              # native update: what the backward pass needs later
@@ -229,8 +240,11 @@ class Trainer(object):
             with torch.set_grad_enabled(bool(getattr(args, 'rollout_grad', False))):   # (the grad mode the episode's steps run in)
                 rec_gates = self._record_gates(knet, T, E * N)
             if rec_gates:
-                self._rec.gates = torch.empty((T, E * N, 4 * knet.hid_size), dtype=torch.float32, device=dev)
-                self._rec.xh = torch.empty((T, E * N, 2 * knet.hid_size), dtype=torch.float32, device=dev)
+                try:
+                    self._rec.gates = torch.empty((T, E * N, 4 * knet.hid_size), dtype=torch.float32, device=dev)
+                    self._rec.xh = torch.empty((T, E * N, 2 * knet.hid_size), dtype=torch.float32, device=dev)
+                except torch.cuda.OutOfMemoryError:                # (the budget above is an estimate: recompute instead)
+                    self._rec.gates = self._rec.xh = None
         self._ones_comm = self._static['ones'] if args.comm_action_one else None
         self._zeros_comm = self._static['zeros']
         if self._use_graph() and self._graphs and getattr(self.policy_net, '_fc', None) is not None:
@@ -268,9 +282,12 @@ class Trainer(object):
         if fc.get('ps_l_wp3') is None or fc.get('ps_l_wp3_bwd') is None or H not in (64, 128) \
                 or not getattr(a, 'fused_input_grad', True):
             return False
-        total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-        held = sum(4 * (r.gates.numel() + r.xh.numel()) for r in (self._records or []) if r.gates is not None)
-        return held + T * R * 6 * H * 4 <= total // 3     # (all records of the batch being collected: a third of the device at most)
+        # what this episode's gate / inp records need against what the device can still give: free memory + the blocks torch's
+        # allocator holds unused, half of it at most (the backward's own buffers, the graph pools and other ranks on the device
+        # need room too); an allocation that fails anyway falls back to the recomputing backward (begin_episode)
+        free, _total = torch.cuda.mem_get_info()
+        cached = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+        return T * R * 6 * H * 4 <= (free + max(cached, 0)) // 2
 
     def _rec_inplace(self):
         """The recorded rollout of a native update reads / writes (h, c) in the episode record (no copies) when every
@@ -300,8 +317,12 @@ class Trainer(object):
 
     def _use_graph(self):
         a = self.args
+        # (collection windows — run_batch under args.auto_reset — step eagerly on fresh buffers: their masks / Transitions are
+        #  read after later windows have played, and a step-0 graph captured in a window that starts the streams must not be
+        #  replayed in one that continues them)
         return bool(getattr(a, 'hip_graph', False)) and not getattr(a, 'store_states', False) \
             and not getattr(a, 'rollout_grad', False) and self._records is None and self.clock.env is not None \
+            and getattr(self, '_stream', None) is None \
             and not getattr(self, '_should_display', False) \
             and getattr(self.clock.env, 'step_timer', None) is None      # event-timed launches stay eager
 

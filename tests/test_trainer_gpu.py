@@ -995,3 +995,57 @@ def test_native_update_of_the_baselines_matches_autograd(kind, rnn_type, env_nam
     for k in g1:
         scale = max(float(g2[k].abs().max()), 1e-6)
         np.testing.assert_allclose(g1[k].cpu().numpy() / scale, g2[k].cpu().numpy() / scale, rtol=0, atol=5e-4, err_msg=k)
+
+
+def test_hip_graph_replay_of_the_tanh_rnn_baseline():
+    """Round-5 advisor finding: models.RNN with the tanh recurrence (rnn_type 'MLP') under args.hip_graph — step 0's captured
+    launches read the initial hidden state on every replay, so it lives in the Trainer's static buffers (zeroed in front of each
+    replay) instead of being a fresh torch.zeros per episode; episodes are identical to the eager run in both graph modes, also
+    with allocator traffic between the episodes."""
+    import bench
+    out = {}
+    for mode in (False, True, 'step'):
+        tr, a = bench.build_trainer('pp_hard_iric', 16, 5, 0, 0, rnn_type='MLP', max_steps=8, hid_size=64)
+        a.hip_graph = mode
+        eps = []
+        junk = []
+        for ep in range(5):
+            episode, stat = tr.get_episode(ep)
+            eps.append(([t.action.clone() for t in episode], [t.reward.clone() for t in episode], [t.value.clone() for t in episode]))
+            junk.append(torch.full((16 * 10 * 64 * (ep + 1),), float('nan'), device='cuda'))   # (a freed block would be reused here)
+            if ep % 2:
+                junk.clear()
+        out[mode] = eps
+        if mode:
+            assert tr._graphs, "the rollout did not go through a graph"
+    for mode in (True, 'step'):
+        for ep, (e, g) in enumerate(zip(out[False], out[mode])):
+            for i in range(3):
+                for x, y in zip(e[i], g[i]):
+                    assert torch.equal(x, y), (mode, ep, i)
+
+
+@pytest.mark.parametrize("wl", ["pp_easy", "tj_medium"])
+def test_collection_mode_run_batch_is_the_same_under_hip_graph(wl):
+    """Round-5 advisor finding: run_batch in collection mode (args.auto_reset) with args.hip_graph on and no records (a direct
+    run_batch call): the windows step eagerly on buffers of their own (Trainer._use_graph), so the batch — actions, rewards,
+    masks, statistics — equals the one collected with hip_graph off, window after window."""
+    import bench
+    res = []
+    for graph in (False, True):
+        tr, a = bench.build_trainer(wl, 24, 7, 0, 0, max_steps=10, hid_size=64)
+        a.auto_reset = True
+        a.hip_graph = graph
+        a.batch_size = 3 * 24 * 10                      # three windows
+        tr.get_episode(0)                               # (graph mode: an episode played, so that captures would be taken)
+        tr.get_episode(0)
+        batch, stats = tr.run_batch(0)
+        res.append(([x.clone() for x in batch.action], [x.clone() for x in batch.reward], [m['live'].clone() for m in batch.misc],
+                    [m['alive_mask'].clone() for m in batch.misc], [x.clone() for x in batch.episode_mask],
+                    {k: np.asarray(v).copy() for k, v in stats.items()}))
+    for i in range(5):
+        assert len(res[0][i]) == len(res[1][i]) == 30
+        for x, y in zip(res[0][i], res[1][i]):
+            assert torch.equal(x, y), i
+    for k in res[0][5]:
+        np.testing.assert_array_equal(res[0][5][k], res[1][5][k], err_msg=k)
