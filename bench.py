@@ -390,10 +390,6 @@ def main():
                    help='EXPERIMENT (labelled in the output, never the headline): ic3_policy_step maintains the obs rows '
                         'incrementally (clears what the previous step painted, paints the new entries) instead of '
                         'zero-filling them every step; the rows are bit-identical, the HBM traffic is not')
-    p.add_argument('--prefill-obs', type=int, default=int(os.environ.get('IC3_BENCH_PREFILL_OBS', '0')),
-                   help='1: the zero background of the obs rows is written by ic3_obs_prefill on a second stream, one step '
-                        'ahead on the other of two obs buffers (the policy launch then only patches); 0: zero stores '
-                        'issued from inside the policy launch')
     p.add_argument('--rccl', type=int, default=int(os.environ.get('IC3_BENCH_RCCL', '0')),
                    help='1: bring up the RCCL process group even for one rank (world_size 1) so that the timing barrier '
                         'and the MAX / SUM reductions of the N > 1 path run on device tensors over RCCL')
@@ -464,7 +460,6 @@ def main():
     a.auto_reset = bool(o.auto_reset)
     a.incremental_obs = bool(o.incremental_obs)
     a.gate_split = bool(o.gate_split)
-    a.prefill_obs = bool(o.prefill_obs)
     T = a.max_steps
     raw_env = trainer.env.env
     live_done = [0.0]                         # live env-steps of the episodes that ENDED so far (stat['num_steps'])
@@ -552,7 +547,6 @@ def main():
         raw_env.step_timer = []               # the launch of every step is event-timed and issued eagerly
         raw_env.dispatch_events = bool(o.dispatch_events)   # events stamped by the dispatch, not recorded around it
         raw_env.step_timer_every = o.time_every if o.time_every > 0 else min(4, max(1, o.steps // 8))
-        raw_env.fill_timer = []               # ... and the fill launch on the second stream (args.prefill_obs)
     gc.disable()                              # (like timeit: no collector pause in the warm-up + timed steps)
     t_in_ep = run(o.warmup, 0)                # W untimed warm-up steps, in the measured configuration
 
@@ -562,8 +556,6 @@ def main():
         raw_env.obs_timer = []
         if raw_env.step_timer is not None:
             raw_env.step_timer = []
-        if getattr(raw_env, 'fill_timer', None) is not None:
-            raw_env.fill_timer = []
         live0 = live_done[0] + raw_env.device_stats().live_env_steps  # (synchronises) finished episodes + the running one
         barrier()
         torch.cuda.synchronize()
@@ -577,7 +569,6 @@ def main():
         obs_ms = [s_.elapsed_time(e_) for s_, e_ in raw_env.obs_timer]
         step_all = [(s_.elapsed_time(e_), t_) for s_, e_, t_ in (raw_env.step_timer or [])]
         live = live_done[0] + raw_env.device_stats().live_env_steps - live0
-        fill_ms[:] = [s_.elapsed_time(e_) for s_, e_, _t in (getattr(raw_env, 'fill_timer', None) or [])]
         return t_in_ep, dt, host_dt, obs_ms, step_all, live
 
     # One 6 ms sample (the driver's 20 steps) can be hit by a clock ramp or a host hiccup.  The region is therefore
@@ -585,7 +576,6 @@ def main():
     # (GPU-bound loop: wall = launches + a few us of gaps per step).  A region whose two clocks disagree by more than
     # 10 % is measured again (at most 3 attempts, each EXACTLY o.steps steps); the attempt count is reported.
     attempts = []
-    fill_ms = []
     for attempt in range(3):
         t_in_ep, dt, host_dt, obs_ms, step_all, live_steps = timed_region(t_in_ep)
         # (every N-th step launch is event-timed: the launches of the region = their mean x the steps)
@@ -605,7 +595,7 @@ def main():
     gc.enable()
     # the store stream alone, same run: the stand-alone obs-assembly kernel on the same rows (rank 0, default configuration)
     store_ref_ms = []
-    if rank == 0 and step_all and not o.no_dense_obs and not o.incremental_obs and not o.prefill_obs:
+    if rank == 0 and step_all and not o.no_dense_obs and not o.incremental_obs:
         raw_env.obs_timer = []
         for _ in range(12):
             raw_env.observe_timed()
@@ -614,7 +604,7 @@ def main():
     # What SHIPS: Trainer.get_episode in its default execution mode — the episode's max_steps launches as ONE hipGraph, the
     # per-episode statistics read included — timed over whole episodes (>= the steps of the region above), every rank.
     ep_graph = None
-    if o.episode_graph and mega_live and not (o.prefill_obs or o.overlap_obs or o.incremental_obs):
+    if o.episode_graph and mega_live and not (o.overlap_obs or o.incremental_obs):
         raw_env.obs_timer = None
         raw_env.step_timer = None
         a.hip_graph = True
@@ -675,10 +665,7 @@ def main():
         state_bytes = mfma_roofline(a, o.nenvs, step_ms or [1.0])["hbm_bytes_per_launch_algorithmic"]
         per_step_obs = len(obs_ms) >= max(1, o.steps // 2)
         roof_note = None
-        if fused_obs and fill_ms:
-            hbm_kernel = "obs_fill_kernel (zero background of the obs rows, second stream, beside policy_step_kernel)"
-            hbm_bytes, hbm_ms = obs_bytes, fill_ms
-        elif fused_obs and o.incremental_obs:
+        if fused_obs and o.incremental_obs:
             hbm_kernel, hbm_bytes, hbm_ms = "policy_step_kernel", None, step_ms
             roof_note = "EXPERIMENT --incremental-obs: the launch does not rewrite the rows, so no fraction is formed over them"
         elif fused_obs:
@@ -698,7 +685,7 @@ def main():
         achieved = hbm_bytes / (avg_ms * 1e-3) / 1e9 if (hbm_ms and hbm_bytes) else None
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'obs_traffic.json')
-        if os.path.exists(tf) and hbm_kernel and not o.incremental_obs and not fill_ms:
+        if os.path.exists(tf) and hbm_kernel and not o.incremental_obs:
             try:
                 tab = json.load(open(tf))
                 key = o.workload + ('_fused' if fused_obs else '')
@@ -717,7 +704,7 @@ def main():
                               "applied"} if traffic is not None else None,
             "bytes_per_launch": hbm_bytes, "obs_bytes_per_launch": obs_bytes if not o.no_dense_obs else 0,
             "avg_launch_ms": round(avg_ms, 4), "launches": len(hbm_ms), "note": roof_note}
-        if roofline is not None and fused_obs and achieved is not None and not fill_ms and not o.incremental_obs and store_ref_ms:
+        if roofline is not None and fused_obs and achieved is not None and not o.incremental_obs and store_ref_ms:
             # context next to `frac` (which stays algorithmic bytes / the 8 TB/s spec peak), MEASURED IN THIS RUN: the stand-alone
             # obs-assembly kernel (ic3_env_observe: nothing but the same obs rows, zeros + non-zero entries) event-timed right
             # behind the timed region — the store stream this chip takes when nothing else runs beside it.
@@ -753,8 +740,6 @@ def main():
                        "auto_reset": bool(o.auto_reset),
                        "obs_rows": ("EXPERIMENT: maintained incrementally (not rewritten every step) - not the headline "
                                     "configuration" if o.incremental_obs else
-                                    "rewritten every step (EXPERIMENT --prefill-obs: zeros by ic3_obs_prefill on a second "
-                                    "stream, non-zero entries by the policy launch)" if (o.prefill_obs and fill_ms) else
                                     "rewritten every step"),
                        "gemm": ("hand-written MFMA; gate product [inp|h].[W_ih|W_hh]^T: every fp32 operand split exactly into 3 "
                                 "bf16 terms, all 9 cross products on v_mfma_f32_32x32x16_bf16 (each product exact in fp32), fp32 "
@@ -768,7 +753,6 @@ def main():
             "roofline": roofline, "roofline_note": roof_note if roofline is None else None,
             "cpu_baseline": cpu,
             "roofline_mfma": mfma_roofline(a, o.nenvs, step_ms, bool(mega_live and o.gate_split)) if step_ms else None,
-            "fill_launch_ms": round(sum(fill_ms) / len(fill_ms), 4) if fill_ms else None,
             "host_enqueue_ms_per_step": round(host_dt / o.steps * 1e3, 4),
             "ms_per_step_ranks": [round(x, 4) for x in rank_ms],
             "collectives": backend,

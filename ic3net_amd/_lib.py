@@ -161,8 +161,6 @@ EXPORTS = {
     "ic3_policy_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_policy_forward": (C.c_int, [C.POINTER(Policy), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "ic3_policy_step": (C.c_int, [C.c_void_p, C.POINTER(Policy)] + [C.c_void_p] * 12),
-    "ic3_obs_prefill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "ic3_obs_set_prefilled": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ic3_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ic3_event_destroy": (C.c_int, [C.c_void_p]),
     "ic3_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

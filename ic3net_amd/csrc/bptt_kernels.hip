@@ -141,11 +141,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 3 : 1) void comm_bwd_kernel(con
             const int n_alive = (int)na;
             const float scale = (a.mode_avg && n_alive > 1) ? 1.0f / (float)(n_alive - 1) : 1.0f;   // comm.py:194-196, Q23
             bp_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
-            for (int i = 0; i < N; ++i) S += sg[el * N + i] * Am4[(el * N + i) * LDA4 + c4];
+            for (int i = 0; i < N; ++i) S = mask_fma4(sg[el * N + i], Am4[(el * N + i) * LDA4 + c4], S);   // (ic3_common.hpp: not packed)
             for (int j = 0; j < N; ++j) {
                 const float m = sg[el * N + j];
                 const bp_f32x4 x = Am4[(el * N + j) * LDA4 + c4];
-                Am4[(el * N + j) * LDA4 + c4] = m * (S - m * x) * scale;
+                Am4[(el * N + j) * LDA4 + c4] = comm_out4(m, S, x, scale);
             }
         }
         __syncthreads();

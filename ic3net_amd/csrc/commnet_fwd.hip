@@ -213,10 +213,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                 const float scl = sscale[el];
                 cn_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
                 if (!a.comm_zero)
-                    for (int i = 0; i < N; ++i) S += sm[el * N + i] * hp[i * LDA4];
+                    for (int i = 0; i < N; ++i) S = mask_fma4(sm[el * N + i], hp[i * LDA4], S);   // (one component per instruction: ic3_common.hpp)
                 for (int j = 0; j < N; ++j) {
                     const float m = a.comm_zero ? 0.f : sm[el * N + j];
-                    As4[(el * N + j) * LDA4 + c4] = m * (S - m * hp[j * LDA4]) * scl;
+                    As4[(el * N + j) * LDA4 + c4] = comm_out4(m, S, hp[j * LDA4], scl);
                 }
             }
             for (int idx = rows * H4 + tid; idx < BM * H4; idx += NT) {

@@ -94,12 +94,9 @@ struct ic3_env {
     int32_t* obs_rec = nullptr;
     const float* painted_obs = nullptr;
     bool painted_valid = false;
-    int fill_nap = 0;                       // ic3_obs_prefill: sleep quanta between two stores of a fill wave (pacing)
-    const float* prefilled_obs = nullptr;   // ic3_obs_prefill: this buffer holds zero rows — the next ic3_policy_step on it only patches
     void touch_obs(const float* obs)        // another writer of that buffer
     {
         if (obs && obs == painted_obs) painted_valid = false;
-        if (obs && obs == prefilled_obs) prefilled_obs = nullptr;
     }
     // Traffic-Junction constant tables (device + host copies)
     int32_t* d_grid = nullptr;       // [h*w] road ids
@@ -156,6 +153,43 @@ __device__ __forceinline__ float fast_tanh(float x)
 {
     // (an explicit fma: which of mul + sub / fma the compiler picks must not depend on the code around the call)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)), 1.0f);
+}
+#endif
+
+// The communication block's masked sums (comm.py:181-205 in closed form: S = sum_i m_i h_i, out_j = m_j (S - m_j h_j) scale) on
+// ONE-COMPONENT instructions.  Written on float4 values (`S += m * x`) hipcc packs the arithmetic into v_pk_fma_f32 / v_pk_mul_f32
+// with op_sel broadcasting the mask out of the destination pair of a ds_read2_b32 — and on gfx950 that sequence came out WRONG
+// now and then: lanes 48..63 of the wave took a stale multiplier in the low half of one packed FMA, i.e. one agent's row was
+// missing from (or doubled in) S for the hidden columns >= 64 of the second env of a wave (round 6: ~1 % of the TJ-medium
+// E = 8192 launches of policy_step_kernel<128, TJ, split>, one env per launch off by ~1e-3 — found through a test that failed one
+// suite run in five; tools/exp/flake_probe2.py, profiles/r06/packed_fma_hazard.txt).  The same loop on v_fma_f32, one component
+// at a time behind opaque-register fences so that the SLP vectoriser cannot re-pack it: 0 differing runs in 40 (packed: 40 in 40).
+// Same rounding as the packed form (a fused multiply-add per term).
+#if defined(__HIPCC__)
+typedef float ic3_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ic3_f32x4 mask_fma4(float m, ic3_f32x4 x, ic3_f32x4 s)          // s + m x
+{
+    float s0 = __builtin_fmaf(m, x[0], s[0]);
+    IC3_OPAQUE_VGPR(s0);
+    float s1 = __builtin_fmaf(m, x[1], s[1]);
+    IC3_OPAQUE_VGPR(s1);
+    float s2 = __builtin_fmaf(m, x[2], s[2]);
+    IC3_OPAQUE_VGPR(s2);
+    float s3 = __builtin_fmaf(m, x[3], s[3]);
+    IC3_OPAQUE_VGPR(s3);
+    return ic3_f32x4{ s0, s1, s2, s3 };
+}
+__device__ __forceinline__ ic3_f32x4 comm_out4(float m, ic3_f32x4 S, ic3_f32x4 x, float scale)   // m (S - m x) scale
+{
+    float o0 = (m * __builtin_fmaf(-m, x[0], S[0])) * scale;
+    IC3_OPAQUE_VGPR(o0);
+    float o1 = (m * __builtin_fmaf(-m, x[1], S[1])) * scale;
+    IC3_OPAQUE_VGPR(o1);
+    float o2 = (m * __builtin_fmaf(-m, x[2], S[2])) * scale;
+    IC3_OPAQUE_VGPR(o2);
+    float o3 = (m * __builtin_fmaf(-m, x[3], S[3])) * scale;
+    IC3_OPAQUE_VGPR(o3);
+    return ic3_f32x4{ o0, o1, o2, o3 };
 }
 #endif
 

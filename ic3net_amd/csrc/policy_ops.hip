@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i)
-            if (i < N) S += mm[i] * hv[i];
+            if (i < N) S = mask_fma4(mm[i], hv[i], S);            // (one component per instruction: ic3_common.hpp)
 #pragma unroll
         for (int j = 0; j < NR; ++j)
             if (j < N) {
-                const f32x4 v = addend ? add(j) + mm[j] * (S - mm[j] * hv[j]) * scale : mm[j] * (S - mm[j] * hv[j]) * scale;
+                const f32x4 v = addend ? add(j) + comm_out4(mm[j], S, hv[j], scale) : comm_out4(mm[j], S, hv[j], scale);
                 oe[(size_t)j * H4] = out_scale ? v * sc(j) : v;
             }
         return;
@@ -81,13 +81,13 @@ __global__ __launch_bounds__(256) void comm_masked_mean_kernel(const float* __re
     for (int i = 0; i < N; ++i) {
         const int m = (alive ? alive[(size_t)e * N + i] : 1) * (comm_action ? comm_action[(size_t)e * N + i] : 1);
         const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + i) * ldh + 4 * k);
-        S += (float)m * hv;
+        S = mask_fma4((float)m, hv, S);
     }
     for (int j = 0; j < N; ++j) {
         const float m = (float)((alive ? alive[(size_t)e * N + j] : 1) *
                                 (comm_action ? comm_action[(size_t)e * N + j] : 1));
         const f32x4 hv = *reinterpret_cast<const f32x4*>(h + ((size_t)e * N + j) * ldh + 4 * k);
-        const f32x4 v = addend ? add(j) + m * (S - m * hv) * scale : m * (S - m * hv) * scale;
+        const f32x4 v = addend ? add(j) + comm_out4(m, S, hv, scale) : comm_out4(m, S, hv, scale);
         oe[(size_t)j * H4] = out_scale ? v * sc(j) : v;
     }
 }

@@ -31,125 +31,23 @@
 
 #include "env_device.hpp"
 #include "ic3_common.hpp"
+#include "ps_common.hpp"
 
 namespace ic3 {
 
-typedef float ps_f32x4 __attribute__((ext_vector_type(4)));
-typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
-typedef int ps_i32x4 __attribute__((ext_vector_type(4)));
-
-// v_mfma_f32_32x32x2_f32, optionally with the accumulator pinned to AGPRs (IC3_PS_AGPR=1): hipcc picks the all-VGPR
-// form when the registers fit, which streams ~6 % slower in isolation (144 vs 153 TFLOP/s, tools/exp/ws_probe.hip).
-// The asm is opaque to the hazard recogniser: whoever reads the accumulator afterwards calls mfma_settle() first.
-// -DIC3_PS_TRACE: wave 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries into a device buffer;
-// the 40th ic3_policy_step call of the process dumps it to $IC3_PS_TRACE_OUT (tools/build_variant.sh trace -DIC3_PS_TRACE)
-// -DIC3_PS_TRACE_EPI (with IC3_PS_TRACE): slots 12..14 are three stamps INSIDE the cell epilogue (old cell state there and
-// first element done; element loop done; head weights in LDS + the remaining zero stores issued), slot 15 its closing
-// barrier; the heads / draws / env step stamps are dropped (tools/analyze_trace.py --epi).
-// -DIC3_PS_TRACE_CLK (with IC3_PS_TRACE): slots 13 / 14 hold s_memtime (SHADER clock cycles) at the start / end of the gate
-// loop instead of the heads / draws stamps — with the 100 MHz stamps of slots 8 / 9 that is the clock the loop ran at
-// (tools/analyze_trace.py --clk).
-#ifdef IC3_PS_TRACE
-#ifdef IC3_PS_TRACE_CLK
-__device__ constexpr int ps_trace_slot(int k) { return (k == 13 || k == 14) ? -1 : k; }
-#define IC3_TRE(j) do { } while (0)
-#define IC3_TRC(j) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 20 + 13 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
-#elif defined(IC3_PS_TRACE_EPI)
-__device__ constexpr int ps_trace_slot(int k) { return k == 12 ? 15 : (k >= 13 && k <= 15) ? -1 : k; }
-#define IC3_TRE(j) IC3_TR_RAW(12 + (j))
-#define IC3_TRC(j) do { } while (0)
-#else
-__device__ constexpr int ps_trace_slot(int k) { return k; }
-#define IC3_TRE(j) do { } while (0)
-#define IC3_TRC(j) do { } while (0)
-#endif
-#define IC3_TR_RAW(k)                                                                                   \
-    do {                                                                                                \
-        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 20 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#define IC3_TR(k)                                                                                       \
-    do {                                                                                                \
-        if constexpr (ps_trace_slot(k) >= 0) IC3_TR_RAW(ps_trace_slot(k));                              \
-    } while (0)
-#else
-#define IC3_TR(k) do { } while (0)
-#define IC3_TRE(j) do { } while (0)
-#define IC3_TRC(j) do { } while (0)
-#endif
+// Matrix instructions through the compiler's builtins only (an AGPR-pinned inline-asm form was measured in rounds 2-3: net
+// slower here — the phases around the loops need more than 128 VGPRs — and opaque to the hazard recogniser).
+//
 // Wave priority: 3 in the phases in front of the gate loop (short dependent chains of loads, LDS exchanges and barriers
 // whose every instruction is on the tile's critical path), 0 from the gate loop on — the co-resident workgroup's MFMA
-// stream gives up an issue slot now and then, the phases stop queueing behind it (measured on one box, round 4:
-// TJ-hard +2.3 %, TJ-medium +1.7 %, PP-hard +0.6 %; also raising the epilogue or the phases behind it: no further gain;
-// the reverse: -1.5 %).  IC3_PS_PRIO_MASK (variant builds): 1 = front, 2 = cell epilogue, 4 = behind the epilogue.
-#ifndef IC3_PS_PRIO_MASK
-#define IC3_PS_PRIO_MASK 1
-#endif
-#define IC3_PRIO_AT(bit) __builtin_amdgcn_s_setprio(((IC3_PS_PRIO_MASK) & (bit)) ? 3 : 0)
-#ifndef IC3_PS_WLOAD_AUX
-#define IC3_PS_WLOAD_AUX 0    // cache policy of the split loop's weight fragment loads (variant builds: 2 = nt, 16 = sc1, 17 = sc0 sc1)
-#endif
-#ifndef IC3_PS_ZSTORE_AUX
-#define IC3_PS_ZSTORE_AUX 2   // cache policy of the obs zero stores: nt (variant builds: 3 = sc0 nt, 18 = sc1 nt, 19 = sc0 sc1 nt)
-#endif
-#ifndef IC3_PS_ENC_UNROLL
-#define IC3_PS_ENC_UNROLL 2   // rows of the sparse encoder gather in flight per thread
-#endif
-#ifndef IC3_PS_AGPR
-#define IC3_PS_AGPR 0   // the 128/128 VGPR/AGPR split spills (round 2: net slower, 0.57 vs 0.52 ms; round 3: the compiler keeps
-                        // the old cell state in scratch across the gate loop, 97 spills; with it requested inside a common
-                        // loop tail instead — commit 864dc03, profiles/r03/agpr_gate_loop.txt — 1 spill, -6 % without obs
-                        // rows, +1.5 % with them) — gates_bwd.hip, which has no phases around its loop, does use AGPRs
-#endif
-// Timing ablations are COMPILE-TIME only (tools/build_variant.sh abl1 -DIC3_PS_ABL=1 ...): a set bit removes a phase and
-// makes the results wrong, so no environment variable of the shipped library can do it.  Bits: 1 gate MFMA loop,
-// 2 C product, 4 encoder gather, 8 heads / draws / env step, 16 epilogue HBM traffic, 32 obs patch pass, 64 zero
-// stores issued but dropped.
-#ifndef IC3_PS_ABL
-#define IC3_PS_ABL 0
-#endif
-#ifndef IC3_PS_RING
-#define IC3_PS_RING 8   // float4 slots of the gate GEMM's B-operand ring (4: one K block, 8: two)
-#endif
-__device__ __forceinline__ void mfma_acc(ps_f32x16& acc, float x, float y)
-{
-#if IC3_PS_AGPR
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
-#else
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
-#endif
-}
-__device__ __forceinline__ void mfma_settle()
-{
-#if IC3_PS_AGPR
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-}
-
-// ---- vector-memory bookkeeping --------------------------------------------------------------------------------------
-// A wave has ONE counter (vmcnt) for its outstanding loads AND stores, they complete in issue order, and s_waitcnt
-// takes an immediate.  Round 2 issued the obs zero stores as inline asm behind a run-time count: invisible to the
-// compiler, whose `s_waitcnt vmcnt(n)` in front of each MFMA group therefore counted only the weight loads — with
-// stores in between, "at most n operations outstanding" turned into "the zero stores issued a moment ago have been
-// acknowledged" (the gate loop ran 12 % over its MFMA time, every load behind the loop first drained the store queue).
-// Now every vector-memory operation of the kernel is a compiler-visible builtin and the zero stores are issued
-// UNCONDITIONALLY — the hardware range check of their buffer descriptor drops the ones past the tile's slice
-// (tools/exp/buf_probe.hip: VGPR and SGPR offsets both take part in the check) — so the number of operations between
-// any load and its first use is a compile-time property of the program and the compiler's waits are exact.
-// (A first version kept inline-asm loads with hand-written waits tied to their registers by "+v" operands: the compiler
-// is free to COPY such a register in front of the wait, and did — stale weights whenever the L2 was cold.)
-typedef unsigned int ps_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ ps_f32x4 buf_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    return __builtin_bit_cast(ps_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ float buf_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
+// stream gives up an issue slot now and then, the phases stop queueing behind it (round 4, one box: TJ-hard +2.3 %,
+// TJ-medium +1.7 %, PP-hard +0.6 %; also raising the epilogue or the phases behind it: no further gain; the reverse: -1.5 %).
+// PRIO_AT(1) = front phases, (2) = cell epilogue, (4) = behind the epilogue.
+#define IC3_PRIO_AT(bit) __builtin_amdgcn_s_setprio(((bit) & 1) ? 3 : 0)
+// Cache policy of the split loop's weight fragment loads (default) and of the obs zero stores (nt: the rows are read by nobody
+// on this chip before they fall out of L2; sc0 / sc1 variants and plain stores were measured in rounds 3-4: profiles/r03,
+// profiles/r04/ab_runs.txt); float4 slots of the fp32 gate loop's B-operand ring (8 = two K blocks).
+constexpr int PS_WLOAD_AUX = 0, PS_ZSTORE_AUX = 2, PS_RING = 8;
 
 struct StepArgs {
     // policy (ic3_policy)
@@ -164,7 +62,6 @@ struct StepArgs {
     const float* head_b;        // [OT]
     int OT, nheads, a0, a1, a2, a3;
     int mode_avg, comm_zero;
-    unsigned long long* trace;  // IC3_PS_TRACE builds: [tiles][20] phase time stamps
     // pacing of the obs zero fill (speed only — every store slot past the tile's slice is dropped by the hardware):
     int zs;                     // stores per K block of the gate loop (one of ZS_SET; a block = 32 MFMAs of a full tile)
     int zf, zepi, zh;           // stores in front of the comm phase; per element of the cell epilogue (0..2); in front of the heads
@@ -184,8 +81,6 @@ struct StepArgs {
     float* obs;                 // [E][N][obs_dim] or null: next_state rows, stored from inside this kernel
     int32_t* obs_rec;           // incremental mode (ic3_env_set_incremental_obs): what the rows of `obs` hold painted, per env
     int obs_incr;               // 1: `obs` still holds exactly what obs_rec describes -> clear those entries, no zero fill
-    int obs_prefilled;          // 1: ic3_obs_prefill zero-filled `obs` (a launch of its own, ordered in front by the caller):
-                                //    this launch only patches the non-zero entries in
     int obs_dim;                // floats per observation row
     int ntiles;                 // workgroups = tiles: n_full tiles of EPT envs, then half tiles of EPTh envs
     int n_full, EPTh;
@@ -212,67 +107,6 @@ struct StepArgs {
 constexpr bool ps_zslot(int S, int i) { return S > 0 && ((i + 1) * S / 16) > (i * S / 16); }
 // the same for the split-product loop (SPLIT = 1): 36 slots per 16-k block (one behind every pair of bf16 MFMAs)
 constexpr bool ps_zslot36(int S, int i) { return S > 0 && ((i + 1) * S / 36) > (i * S / 36); }
-
-// ---- ic3_policy.gate_split (the default since round 4; DESIGN.md section 0, tools/exp/bf16x9_probe.hip): the gate
-// product with every fp32 operand split EXACTLY into three bf16 terms (x = x1 + x2 + x3, round-to-nearest-even splits,
-// exact residuals) and all nine cross products on v_mfma_f32_32x32x16_bf16 — each product exact in fp32, fp32
-// accumulation.  Weights: pre-split planes in fragment order (ic3_policy_pack_split); activations: the fp32 A tile stays
-// in LDS as it is and every wave splits the 8 values of its row per 16 k-steps in registers.
-typedef __bf16 ps_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned ps_bf16_rne(float x)
-{
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void ps_split3(float x, unsigned& x1, unsigned& x2, unsigned& x3)
-{
-    x1 = ps_bf16_rne(x);
-    const float r1 = x - __builtin_bit_cast(float, x1 << 16);
-    x2 = ps_bf16_rne(r1);
-    const float r2 = r1 - __builtin_bit_cast(float, x2 << 16);
-    x3 = ps_bf16_rne(r2);
-}
-// 8 consecutive fp32 of one row -> the three bf16 A fragments of a 32x32x16 MFMA.  Pairwise through v_cvt_pk_bf16_f32
-// (round-to-nearest-even in hardware, the pair comes out packed): 9 vector instructions per pair.
-typedef float ps_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 ps_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void ps_split_pair(ps_f32x2 x, unsigned& p1, unsigned& p2, unsigned& p3)
-{
-    const ps_bf16x2 h1 = __builtin_convertvector(x, ps_bf16x2);
-    const ps_f32x2 r1 = x - __builtin_convertvector(h1, ps_f32x2);
-    const ps_bf16x2 h2 = __builtin_convertvector(r1, ps_bf16x2);
-    const ps_f32x2 r2 = r1 - __builtin_convertvector(h2, ps_f32x2);
-    const ps_bf16x2 h3 = __builtin_convertvector(r2, ps_bf16x2);
-    p1 = __builtin_bit_cast(unsigned, h1);
-    p2 = __builtin_bit_cast(unsigned, h2);
-    p3 = __builtin_bit_cast(unsigned, h3);
-}
-// The same split in stages, for the gate loop's software pipeline: the most significant plane of a pair, then
-// `r -= float(h)` and the next plane of what is left (ps_split_pair = ps_hi_pair, ps_next_pair, ps_next_pair).
-__device__ __forceinline__ unsigned ps_hi_pair(ps_f32x2 x)
-{
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, ps_bf16x2));
-}
-__device__ __forceinline__ unsigned ps_next_pair(ps_f32x2& r, unsigned h)
-{
-#ifdef IC3_PS_SCALAR_SUB   // variant build: two v_sub_f32 instead of one v_pk_add_f32 (needs -fno-slp-vectorize to stay that way)
-    r[0] = r[0] - __builtin_bit_cast(float, h << 16);
-    r[1] = r[1] - __builtin_bit_cast(float, h & 0xffff0000u);
-#else
-    r = r - __builtin_convertvector(__builtin_bit_cast(ps_bf16x2, h), ps_f32x2);
-#endif
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(r, ps_bf16x2));
-}
-__device__ __forceinline__ void ps_split_frag(ps_f32x4 x0, ps_f32x4 x1, ps_u32x4 (&out)[3])
-{
-    unsigned p[3][4];
-    ps_split_pair(ps_f32x2{ x0[0], x0[1] }, p[0][0], p[1][0], p[2][0]);
-    ps_split_pair(ps_f32x2{ x0[2], x0[3] }, p[0][1], p[1][1], p[2][1]);
-    ps_split_pair(ps_f32x2{ x1[0], x1[1] }, p[0][2], p[1][2], p[2][2]);
-    ps_split_pair(ps_f32x2{ x1[2], x1[3] }, p[0][3], p[1][3], p[2][3]);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) out[pl] = ps_u32x4{ p[pl][0], p[pl][1], p[pl][2], p[pl][3] };
-}
 
 // Geometry of one tile, derived from the kernel arguments and the tile index only — the phases behind the gate loop
 // derive it AGAIN from a re-read copy of the arguments instead of keeping ~40 scalars (and the 40 argument pointers)
@@ -307,8 +141,7 @@ __device__ __forceinline__ TileGeom tile_geom(const StepArgs& a, int tile_id)
     g.c_lo = g.mis ? 1 : 0;
     g.c_hi = (g.mis + g.onb) >> 6;
     g.zend = g.obs_here ? max(0, (64 * g.c_hi - g.mis) * 16) : 0;   // bytes of the body up to the last full chunk
-    if (IC3_PS_ABL & 64) g.zend = 0;   // ablation: every zero store is issued and dropped by the range check (no HBM traffic)
-    if (a.obs_incr || a.obs_prefilled) g.zend = 0;   // incremental / prefilled rows: nothing to zero-fill here (the host
+    if (a.obs_incr) g.zend = 0;                      // incremental rows: nothing to zero-fill here (the host
                                                      // also sets every slot count to 0)
     return g;
 }
@@ -336,7 +169,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 {
     static_assert(!MP || (SPLIT && KIND != 0), "the in-launch pass loop exists for the split gate product on an env handle");
     constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, H4 = H / 4;
-    constexpr int ABL = IC3_PS_ABL;
     IC3_DYNAMIC_LDS(float, smem);
     float* const As = smem;                                      // [BM][LDA]: cols [0,H) enc / comm / inp, [H,2H) h / h'
     ps_f32x4* const As4 = reinterpret_cast<ps_f32x4*>(smem);
@@ -362,11 +194,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
     IC3_OPAQUE_VGPR(zv);                                        // keep it in registers (no re-materialisation per store)
     int zlane, zso;                                              // lane offset; running byte offset of this wave's next chunk (SGPR)
     auto zero_store = [&]() __attribute__((always_inline)) {
-#ifdef IC3_PS_PLAIN_STORES
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, 0);
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, IC3_PS_ZSTORE_AUX);
-#endif
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ps_u32x4, zv), zr, zlane, zso, PS_ZSTORE_AUX);
         zso += NW * 1024;
     };
 
@@ -385,14 +213,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // (the pass's C weights / bias by scalar selects: indexing the arrays with `pass` would put the argument block in scratch)
         const ps_f32x4* const enc_bias_now = !MP ? a.enc_bias : pass == 0 ? a.enc_bias_p[0] : pass == 1 ? a.enc_bias_p[1] : pass == 2 ? a.enc_bias_p[2] : a.enc_bias_p[3];
         const ps_f32x4* const c_wp_now = !MP ? a.c_wp : pass == 0 ? a.c_wp_p[0] : pass == 1 ? a.c_wp_p[1] : pass == 2 ? a.c_wp_p[2] : a.c_wp_p[3];
-        IC3_TR(0);
         IC3_PRIO_AT(1);
-#ifdef IC3_PS_TRACE
-        if (a.trace && tid == 0) {
-            a.trace[(size_t)blockIdx.x * 20 + 18] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-            a.trace[(size_t)blockIdx.x * 20 + 19] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
-        }
-#endif
         // (Two experiments on the co-residency of the two workgroups of a CU were measured in round 3 and removed again:
         //  a start stagger of the second resident, and a per-CU lock that lets one gate loop run at a time — the loops
         //  did take turns, 36 us instead of 76, and the phases around them stretched by exactly what the loops gained:
@@ -539,7 +360,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int i = 0; i < a.z0; ++i) zero_store();
         }
         __syncthreads();
-        IC3_TR(1);
         for (int el = tid; el < nenv; el += NT) {                    // per-env 1 / (n_alive - 1) (comm.py:194-196), read at S5
             int n_alive = 0;
             for (int j = 0; j < N; ++j) n_alive += sact[el * N + j];
@@ -553,7 +373,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         if constexpr (KIND != 0) {
             desc_tab(tile, nenv);
             __syncthreads();
-            IC3_TR(2);
         }
         }   // first
         // encoder weight rows / pre-summed location rows behind buffer descriptors (32-bit gather offsets)
@@ -563,12 +382,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         const BufRows encL = { __builtin_amdgcn_make_buffer_rsrc(const_cast<ps_f32x4*>(a.loc_table), 0, 0x7fffffffu, 0x00020000),
                                a.loc_table != nullptr };
         // ---- S2: encoder(obs) + C.bias as a sparse gather (comm.py:51,119; pp/tj_encode_kernel) -> inp half ----------
-#pragma unroll IC3_PS_ENC_UNROLL
+#pragma unroll 2
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / H4, c4 = idx - row * H4;
             ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
-            if (row < rows && !(ABL & 4)) {
+            if (row < rows) {
                 const int el = div_small(row, invN), aa = row - el * N;
                 if constexpr (KIND == 0) {
                     v = *reinterpret_cast<const ps_f32x4*>(a.enc_in + (r0 + row) * H + 4 * c4);
@@ -592,7 +411,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         }
         }
         __syncthreads();
-        IC3_TR(3);
 
         // ---- S3: the encoder output moves into the accumulators of the C product (MFMA C/D layout:
         //      col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ------------------------------------------------
@@ -612,7 +430,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
         // zero stores (one counter, in order).  Rows >= `rows` read as zeros (range check).  32 registers held through
         // the loop.
         if constexpr (!SPLIT) {
-            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.c + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.c + r0 * H, (uint32_t)rows * H * 4u);
             const int voff = (4 * lh * H + col) * 4;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -629,8 +447,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             for (int i = 0; i < a.z3; ++i) zero_store();
         }
         __syncthreads();   // every wave has its share of the encoder output
-        IC3_TR(4);
-        IC3_TR(5);
 
         if (g.obs_here && last) {
             // (no load is waited for in the comm phase: the acknowledgements of these run under its LDS work)
@@ -644,11 +460,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 for (int el = tid / H4; el < nenv; el += NT / H4) {
                     const ps_f32x4* hp = As4 + (el * N) * LDA4 + H4 + c4;
                     const float scl = sscale[el];
+                    // (one component per instruction: mask_fma4 / comm_out4 in ic3_common.hpp — the packed form of this loop was
+                    //  measured wrong on gfx950 now and then)
                     ps_f32x4 S = { 0.f, 0.f, 0.f, 0.f };
-                    for (int i = 0; i < N; ++i) S += sm[el * N + i] * hp[i * LDA4];
+                    for (int i = 0; i < N; ++i) S = mask_fma4(sm[el * N + i], hp[i * LDA4], S);
                     for (int j = 0; j < N; ++j) {
                         const float m = sm[el * N + j];
-                        As4[(el * N + j) * LDA4 + c4] = m * (S - m * hp[j * LDA4]) * scl;
+                        As4[(el * N + j) * LDA4 + c4] = comm_out4(m, S, hp[j * LDA4], scl);
                     }
                 }
                 for (int idx = rows * H4 + tid; idx < BM * H4; idx += NT) {
@@ -669,7 +487,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
             for (int k = 0; k < CH; ++k) cb[0][k] = cwp(k);
             __syncthreads();
-            IC3_TR(6);
             // ---- S6: accC (= enc) += comm . C.weight^T -----------------------------------------------------------------
             auto cprod = [&](auto two_c) __attribute__((always_inline)) {
                 constexpr bool TWO = decltype(two_c)::value;
@@ -696,13 +513,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                     }
                 }
             };
-            if (!(ABL & 2)) {
-                if (two) cprod(std::true_type{});
-                else cprod(std::false_type{});
-            }
-            mfma_settle();
+            if (two) cprod(std::true_type{});
+            else cprod(std::false_type{});
             __syncthreads();   // every wave has read the comm tile
-            IC3_TR(7);
         }
 
 #pragma unroll
@@ -723,7 +536,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             const int g3lane = (w * 64 + lane) * 16;
             constexpr int GSTRIDE = NW * 64 * 16;
             auto wq3 = [&](int pl, int kb, int gt) __attribute__((always_inline)) {
-                return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, IC3_PS_WLOAD_AUX);
+                return __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16 + kb) * 4 + gt) * GSTRIDE, PS_WLOAD_AUX);
             };
             ps_u32x4 bq[3][4];
             // ---- S7: inp = enc + C.bias + C(comm) -> inp half --------------------------------------------------------
@@ -738,7 +551,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
             if constexpr (KIND != 0 && MP == 0) {
                 if (a.xh_out) {   // (uniform; ic3_env_set_record_out) the same values -> the inp half of the record's [inp | h] rows
-                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xh_out + r0 * 2 * H, (ABL & 16) ? 0u : (uint32_t)rows * 2 * H * 4u);
+                    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xh_out + r0 * 2 * H, (uint32_t)rows * 2 * H * 4u);
                     const int xoff = (4 * lh * 2 * H + col) * 4;
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
@@ -747,18 +560,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         for (int reg = 0; reg < 16; ++reg) {
                             const float xv = accC[rt][reg];           // (a copy: bit_cast of a vector element reads element 0)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, xv), rx,
-                                                                  xoff + (32 * rt + (reg & 3) + 8 * (reg >> 2)) * 2 * H * 4, 0, IC3_PS_ZSTORE_AUX);
+                                                                  xoff + (32 * rt + (reg & 3) + 8 * (reg >> 2)) * 2 * H * 4, 0, PS_ZSTORE_AUX);
                         }
                     }
                 }
             }
             __syncthreads();
-            IC3_TR(8);
-            IC3_TRC(0);
             IC3_PRIO_AT(0);
             // (MP, later passes: the cell state the previous pass's epilogue stored to c_out — read past the vector L1, which
             //  may still hold the lines as the first pass loaded them)
-            const __amdgpu_buffer_rsrc_t rc_old = make_rsrc((first ? a.c : a.c_out) + r0 * H, (ABL & 16) ? 0u : (uint32_t)rows * H * 4u);
+            const __amdgpu_buffer_rsrc_t rc_old = make_rsrc((first ? a.c : a.c_out) + r0 * H, (uint32_t)rows * H * 4u);
             const int voff_old = (4 * lh * H + col) * 4;
             auto block3 = [&](auto two_c, auto s_c, auto refill_c, auto loadc_c, int kb) __attribute__((always_inline)) {
                 constexpr bool TWO = decltype(two_c)::value;
@@ -824,20 +635,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
 #pragma unroll
                 for (int pb = 0; pb < 3; ++pb) {
                     if (pb > 0) {
-#ifdef IC3_PS_PAIRFRAG   // variant build: two fragments at a time — an accumulator comes round every fourth MFMA, not every second
-#pragma unroll
-                        for (int gt = 0; gt < 4; gt += 2) {
-#pragma unroll
-                            for (int pa = 2; pa >= 0; --pa) {
-                                products(pa, pb, gt);
-                                slot((pb * 4 + gt) * 3 + 2 * (2 - pa));
-                                products(pa, pb, gt + 1);
-                                slot((pb * 4 + gt) * 3 + 2 * (2 - pa) + 1);
-                            }
-                            if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt), bq[pb][gt + 1] = wq3(pb, kb + 1, gt + 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-#else
 #pragma unroll
                         for (int gt = 0; gt < 4; ++gt) {
                             // the six products of ONE weight fragment back to back (three activation terms, least
@@ -850,7 +647,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                             if constexpr (REFILL) bq[pb][gt] = wq3(pb, kb + 1, gt);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-#endif
                     }
                     if constexpr (LOADC) {                            // 11 + 11 + 10 old cell states behind the three plane groups
 #pragma unroll
@@ -878,11 +674,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                     for (int gt = 0; gt < 4; ++gt)
-                        bq[pl][gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16) * 4 + gt) * GSTRIDE + zo, IC3_PS_WLOAD_AUX);
-                if (!(ABL & 1)) {
+                        bq[pl][gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pl * KB16) * 4 + gt) * GSTRIDE + zo, PS_WLOAD_AUX);
 #pragma unroll 1
-                    for (int kb = 0; kb < KB16 - 1; ++kb) block3(two_c, s_c, std::true_type{}, std::false_type{}, kb);
-                }
+                for (int kb = 0; kb < KB16 - 1; ++kb) block3(two_c, s_c, std::true_type{}, std::false_type{}, kb);
                 __builtin_amdgcn_sched_barrier(0);
             };
             auto gate_loop3_s = [&](auto two_c) __attribute__((always_inline)) {
@@ -900,19 +694,19 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 case 16: gate_loop3(two_c, std::integral_constant<int, 32>{}); break;
                 default: gate_loop3(two_c, std::integral_constant<int, 0>{}); break;
                 }
-                if (!(ABL & 1))   // the last block: common code, no store slots, requests the old cell state
-                    block3(two_c, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, KB16 - 1);
+                // the last block: common code, no store slots, requests the old cell state
+                block3(two_c, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, KB16 - 1);
                 __builtin_amdgcn_sched_barrier(0);
             };
             if (two) gate_loop3_s(std::true_type{});
             else gate_loop3_s(std::false_type{});
         } else {
             // gate weights in the layout Wq[k][c] = float4 (W[c][k], W[H+c][k], W[2H+c][k], W[3H+c][k]) of ic3_policy_pack:
-            // ONE 16-byte load per lane feeds a k-step of all four gates.  The operand ring is IC3_PS_RING float4 deep (8 = two
+            // ONE 16-byte load per lane feeds a k-step of all four gates.  The operand ring is PS_RING float4 deep (8 = two
             // K blocks = 32 registers, what round 2 held as two buffers of four float4 per gate); a slot is refilled right
             // behind the 8 MFMAs that read it, RING - 1 k sub-steps (56 MFMAs) ahead of its next use — with the obs zero stores
             // in flight the L2 answers slower than an idle one, a ring of 4 (24 MFMAs ahead) ran the gate loop 5 % slower.
-            constexpr int RING = IC3_PS_RING;
+            constexpr int RING = PS_RING;
             static_assert(RING == 4 || RING == 8, "operand ring: one or two K blocks");
             const __amdgpu_buffer_rsrc_t rgw = make_rsrc(a.l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
             const int glane = (4 * lh * H + col) * 16;               // k = 8 kb + 4 lh + j (must match the A fragments)
@@ -932,8 +726,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
             __syncthreads();
-            IC3_TR(8);
-            IC3_TRC(0);
             IC3_PRIO_AT(0);
 
             // ---- S8: gates = [inp | h] . [W_ih | W_hh]^T (comm.py:215, torch.nn.LSTMCell; the bias joins in the epilogue) --
@@ -968,15 +760,13 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 static_assert(KB % 2 == 0 && KB >= 4, "K/8 must be even");
                 constexpr std::integral_constant<int, 0> s0{};
                 constexpr std::integral_constant<int, RING == 8 ? 4 : 0> s1{};
-                if (!(ABL & 1)) {
     #pragma unroll 1
-                    for (int kb = 0; kb < KB - 2; kb += 2) {
-                        block(two_c, s_c, s0, std::true_type{}, kb);
-                        block(two_c, s_c, s1, std::true_type{}, kb + 1);
-                    }
-                    block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2);
-                    block(two_c, s_c, s1, std::false_type{}, KB - 1);
+                for (int kb = 0; kb < KB - 2; kb += 2) {
+                    block(two_c, s_c, s0, std::true_type{}, kb);
+                    block(two_c, s_c, s1, std::true_type{}, kb + 1);
                 }
+                block(two_c, s_c, s0, std::integral_constant<bool, RING == 4>{}, KB - 2);
+                block(two_c, s_c, s1, std::false_type{}, KB - 1);
                 __builtin_amdgcn_sched_barrier(0);
             };
             auto gate_loop_s = [&](auto two_c) {
@@ -998,11 +788,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             if (two) gate_loop_s(std::true_type{});
             else gate_loop_s(std::false_type{});
         }
-        IC3_TRC(1);
-        IC3_TR(9);
         IC3_PRIO_AT(2);
-        mfma_settle();
-        IC3_TR(10);
     }
 
     // =====================================================================================================================
@@ -1040,7 +826,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             // in for the `row < rows` predicates — an out-of-range store is dropped.
             // (MP, an inner pass: h' stays in the A tile, its stores are dropped by an empty range; c' goes to c_out — the next
             //  pass reads it back in its last gate block — instead of occupying 32 registers across that pass)
-            const uint32_t nrec = (ABL & 16) ? 0u : (uint32_t)rows * H * 4u;
+            const uint32_t nrec = (uint32_t)rows * H * 4u;
             const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.c_out + r0 * H), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(static_cast<void*>(a.h_out + r0 * H), 0, last ? nrec : 0u, 0x00020000);
             const int voff = (4 * lh * H + col) * 4;
@@ -1057,7 +843,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         if ((fmask >> (32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh)) & 1) cold[rt][reg] = 0.0f;
             }
             __syncthreads();   // every wave is done with the A tile
-            IC3_TR(11);
             // head / value weights -> rows [0, OT) of the inp half: requested now, written to LDS behind the element loop
             // (the compiler's wait there allows the >= 32 stores issued meanwhile to stay in flight)
             const __amdgpu_buffer_rsrc_t rhw = make_rsrc(a.head_w, (uint32_t)(a.OT * H * sizeof(float)));
@@ -1096,13 +881,12 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c1), rc, voff + lc * H * 4, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h1), rh, voff + lc * H * 4, 0, 0);
                         if constexpr (GS) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, si), rg, goff + lc * 4 * H * 4, 0, IC3_PS_ZSTORE_AUX);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sf), rg, goff + lc * 4 * H * 4 + H * 4, 0, IC3_PS_ZSTORE_AUX);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tg), rg, goff + lc * 4 * H * 4 + 2 * H * 4, 0, IC3_PS_ZSTORE_AUX);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, so), rg, goff + lc * 4 * H * 4 + 3 * H * 4, 0, IC3_PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, si), rg, goff + lc * 4 * H * 4, 0, PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sf), rg, goff + lc * 4 * H * 4 + H * 4, 0, PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tg), rg, goff + lc * 4 * H * 4 + 2 * H * 4, 0, PS_ZSTORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, so), rg, goff + lc * 4 * H * 4 + 3 * H * 4, 0, PS_ZSTORE_AUX);
                         }
                         As[lr * LDA + H + col] = h1;
-                        if (rt == 0 && reg == 0) IC3_TRE(0);
                     }
                 }
             };
@@ -1115,10 +899,9 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             } else if (ze <= 0) cell(std::integral_constant<int, 0>{}, std::false_type{});
             else if (ze == 1) cell(std::integral_constant<int, 1>{}, std::false_type{});
             else cell(std::integral_constant<int, 2>{}, std::false_type{});
-            IC3_TRE(1);
             if (tid < a.OT * H4) As4[(tid / H4) * LDA4 + tid % H4] = hw0;
             if (tid + NT < a.OT * H4) As4[((tid + NT) / H4) * LDA4 + (tid + NT) % H4] = hw1;
-            if (obs_here && !a.obs_incr && !a.obs_prefilled) {
+            if (obs_here && !a.obs_incr) {
 #pragma unroll 1
                 for (int i = 0; i < a.zrest; ++i) zero_store();     // obs-dominated shapes
                 // ragged chunks: chunk 0 when the body starts inside it, chunk c_hi when the body ends inside it; the
@@ -1133,13 +916,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 if (tid < g.ohead) a.obs[g.ob0 + tid] = 0.f;
                 if (tid < otail) a.obs[g.ob0 + g.ohead + 4 * (long long)g.onb + tid] = 0.f;
             }
-            IC3_TRE(2);
         }
         __syncthreads();
-        IC3_TR(12);
         IC3_PRIO_AT(4);
         if (MP && !last) continue;          // (uniform) the next communication pass of the step
-        if ((ABL & 8) || a.inner) return;   // (uniform)
+        if (a.inner) return;   // (uniform)
 
         // ---- S10: heads + value head (comm.py:228,239) as a 64 x 16 x H product on v_mfma_f32_16x16x4_f32: row tile of
         //      16 rows per wave, the OT <= 16 output columns are the weight rows [0, 16) of the inp half (rows >= OT hold
@@ -1175,7 +956,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
         __syncthreads();
-        IC3_TR(13);
 
         // ---- S11: log_softmax per head + the action draws (action_utils.py:32-36; same arithmetic and Philox counters
         //      as lstm_cell_heads_kernel / sample_actions_env_kernel), one task per (row, head) + one per row for the value
@@ -1221,7 +1001,6 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
             }
         }
         __syncthreads();
-        IC3_TR(14);
 
         // ---- S12: env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) ------------------------
         if constexpr (KIND != 0) {
@@ -1237,13 +1016,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         }
-        IC3_TR(15);
-        if (obs_here && !(ABL & 32)) {
+        if (obs_here) {
             // every zero store of this workgroup has completed (own stores: vmcnt(0); the others': barrier) before the
             // first non-zero entry goes out to the same lines
             IC3_WAIT_VMEM();
             __syncthreads();
-            IC3_TR(16);
             float* orow0 = a.obs + g.ob0;
             // Incremental rows (opt-in experiment, ic3_env_set_incremental_obs): the caller's buffer still holds what the
             // previous call painted; its descriptors were recorded per env (PP: the window table, TJ: alive flags + window
@@ -1309,191 +1086,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void policy_step_kernel(
                 }
             }
         }
-        IC3_TR(17);
     }
     break;
     }   // pass
 }
 
-#include "policy_step_ws.hpp"
-
-// ---- ic3_gate_product_probe: the gate product ALONE (pre-activations without the bias), through the operand layouts, the
-// activation split and the per-accumulator order of matrix instructions of policy_step_kernel's two gate loops — (k ascending;
-// fp32: one v_mfma_f32_32x32x2_f32 per k; split: per 16-k block weight plane outer, then gate, then the activation terms
-// least significant first) — without their prefetch rings and store slots.  What the arithmetic of the two modes IS can be
-// measured with it on operands no rollout produces (edge magnitudes, tests/test_gate_split_gpu.py).
-template <int H, int SPLIT>
-__global__ __launch_bounds__(2 * H) void gate_product_probe_kernel(const float* __restrict__ xh, const ps_f32x4* l_wp, const void* l_wp3,
-                                                                   float* __restrict__ gates, int R)
-{
-    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, BM = 64, NT = 2 * H, NW = H / 32, KB = K / 8, KB16 = K / 16;
-    IC3_DYNAMIC_LDS(float, smem);
-    ps_f32x4* const As4 = reinterpret_cast<ps_f32x4*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5, col = 32 * w + li;
-    const size_t r0 = (size_t)blockIdx.x * BM;
-    for (int idx = tid; idx < BM * (K / 4); idx += NT) {
-        const int row = idx / (K / 4), c4 = idx - row * (K / 4);
-        ps_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
-        if (r0 + row < (size_t)R) v = *reinterpret_cast<const ps_f32x4*>(xh + (r0 + row) * K + 4 * c4);
-        As4[row * LDA4 + c4] = v;
-    }
-    __syncthreads();
-    ps_f32x16 acc[2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rt][gt][i] = 0.0f;
-    if constexpr (SPLIT != 0) {
-        const __amdgpu_buffer_rsrc_t rg3 = make_rsrc(l_wp3, (uint32_t)((size_t)3 * K * 4 * H * 2));
-        const int g3lane = (w * 64 + lane) * 16;
-        constexpr int GSTRIDE = NW * 64 * 16;
-#pragma unroll 1
-        for (int kb = 0; kb < KB16; ++kb) {
-            ps_u32x4 ap[2][3];
-            const ps_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
-            ps_split_frag(s0[0], s0[1], ap[0]);
-            const ps_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
-            ps_split_frag(s1[0], s1[1], ap[1]);
-            // (product order of block3: weight plane group 0 pass by pass, most significant activation plane first; groups
-            //  1 and 2 fragment by fragment, least significant activation plane first)
-            ps_u32x4 bq0[4];
-#pragma unroll
-            for (int gt = 0; gt < 4; ++gt)
-                bq0[gt] = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, (kb * 4 + gt) * GSTRIDE, 0);
-#pragma unroll
-            for (int pa = 0; pa < 3; ++pa)
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-                        acc[rt][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(ps_bf16x8, ap[rt][pa]), __builtin_bit_cast(ps_bf16x8, bq0[gt]), acc[rt][gt], 0, 0, 0);
-#pragma unroll
-            for (int pb = 1; pb < 3; ++pb)
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    const ps_u32x4 bq = __builtin_amdgcn_raw_buffer_load_b128(rg3, g3lane, ((pb * KB16 + kb) * 4 + gt) * GSTRIDE, 0);
-#pragma unroll
-                    for (int pa = 2; pa >= 0; --pa)
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt)
-                            acc[rt][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(ps_bf16x8, ap[rt][pa]), __builtin_bit_cast(ps_bf16x8, bq), acc[rt][gt], 0, 0, 0);
-                }
-        }
-    } else {
-        const __amdgpu_buffer_rsrc_t rgw = make_rsrc(l_wp, (uint32_t)((size_t)K * 4 * H * sizeof(float)));
-        const int glane = (4 * lh * H + col) * 16;
-#pragma unroll 1
-        for (int kb = 0; kb < KB; ++kb) {
-            const ps_f32x4 a0 = As4[li * LDA4 + 2 * kb + lh], a1 = As4[(32 + li) * LDA4 + 2 * kb + lh];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const ps_f32x4 wk = buf_load_b128(rgw, glane, (8 * kb + j) * (H * 16));
-#pragma unroll
-                for (int gt = 0; gt < 4; ++gt) {
-                    acc[0][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], wk[gt], acc[0][gt], 0, 0, 0);
-                    acc[1][gt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], wk[gt], acc[1][gt], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int gt = 0; gt < 4; ++gt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const size_t row = r0 + 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (row < (size_t)R) gates[row * 4 * H + (size_t)gt * H + col] = acc[rt][gt][reg];
-            }
-}
-
-// Wp[kb][col][hh][j] = W[col][8 kb + 4 hh + j], W = [Wa | Wb] (C x (Ka + Kb)) row-major halves
-__global__ void policy_pack_kernel(const float* __restrict__ Wa, const float* __restrict__ Wb, float* __restrict__ Wp,
-                                   int C, int Ka, int Kb)
-{
-    const int Kt = Ka + Kb;
-    const long long n = (long long)C * Kt;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 3), hh = (int)((i >> 2) & 1);
-        const long long rest = i >> 3;
-        const int colx = (int)(rest % C), kb = (int)(rest / C);
-        const int k = 8 * kb + 4 * hh + j;
-        Wp[i] = k < Ka ? Wa[(size_t)colx * Ka + k] : Wb[(size_t)colx * Kb + (k - Ka)];
-    }
-}
-
-// Wq[k][c] = float4 (W[c][k], W[H + c][k], W[2H + c][k], W[3H + c][k]), W = [w_ih | w_hh] (4H x 2H): the gate GEMM's B
-// operand, one k-step of all four gates of a hidden column per 16-byte load
-__global__ void policy_pack_gates_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, float* __restrict__ Wq, int H)
-{
-    const long long n = (long long)8 * H * H;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int gt = (int)(i & 3);
-        const long long rest = i >> 2;
-        const int c = (int)(rest % H), k = (int)(rest / H);
-        const size_t row = (size_t)gt * H + c;
-        Wq[i] = k < H ? w_ih[row * H + k] : w_hh[row * H + (k - H)];
-    }
-}
-
-// gate_split: Wp[plane][kb16][gate][wave][lane] = 8 x bf16 { W_plane[gate * H + 32 wave + li][16 kb16 + 8 lh + i] },
-// W = [w_ih | w_hh] (4H x 2H), the three planes an exact split of every weight
-__global__ void policy_pack_split_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
-                                         ps_u32x4* __restrict__ Wp, int H)
-{
-    const int NWv = H / 32, KB16 = 2 * H / 16;
-    const long long per = (long long)KB16 * 4 * NWv * 64;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
-        const int lane = (int)(i & 63);
-        long long rest = i >> 6;
-        const int wv = (int)(rest % NWv);
-        rest /= NWv;
-        const int gt = (int)(rest & 3), kb = (int)(rest >> 2);
-        const int li = lane & 31, lh = lane >> 5;
-        const size_t row = (size_t)gt * H + 32 * wv + li;
-        unsigned p[3][8];
-        for (int q = 0; q < 8; ++q) {
-            const int k = 16 * kb + 8 * lh + q;
-            ps_split3(k < H ? w_ih[row * H + k] : w_hh[row * H + (k - H)], p[0][q], p[1][q], p[2][q]);
-        }
-        for (int pl = 0; pl < 3; ++pl) {
-            ps_u32x4 v;
-            for (int d = 0; d < 4; ++d) v[d] = p[pl][2 * d] | (p[pl][2 * d + 1] << 16);
-            Wp[(size_t)pl * per + i] = v;
-        }
-    }
-}
-
-// The same planes for the BACKWARD of the gate product (ic3_lstm_gates_backward_dx: [d inp | d h] = dgates . [W_ih | W_hh]):
-// Wb[plane][kb16][ct][lane] = 8 x bf16 { W_plane[16 kb16 + 8 lh + i][32 ct + li] }, W = [w_ih | w_hh] (4H x 2H) — k runs over
-// the 4H gate rows, the output column over the 2H inputs
-__global__ void policy_pack_split_bwd_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
-                                             ps_u32x4* __restrict__ Wp, int H)
-{
-    const int NCT = 2 * H / 32, KB16B = 4 * H / 16;
-    const long long per = (long long)KB16B * NCT * 64;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
-        const int lane = (int)(i & 63);
-        const long long rest = i >> 6;
-        const int ct = (int)(rest % NCT), kb = (int)(rest / NCT);
-        const int li = lane & 31, lh = lane >> 5;
-        const int n = 32 * ct + li;
-        unsigned p[3][8];
-        for (int q = 0; q < 8; ++q) {
-            const int k = 16 * kb + 8 * lh + q;
-            ps_split3(n < H ? w_ih[(size_t)k * H + n] : w_hh[(size_t)k * H + (n - H)], p[0][q], p[1][q], p[2][q]);
-        }
-        for (int pl = 0; pl < 3; ++pl) {
-            ps_u32x4 v;
-            for (int d = 0; d < 4; ++d) v[d] = p[pl][2 * d] | (p[pl][2 * d + 1] << 16);
-            Wp[(size_t)pl * per + i] = v;
-        }
-    }
-}
 
 static int device_cus()
 {
@@ -1720,93 +1317,10 @@ static int launch_step(const StepArgs& a, int tiles, size_t lds, hipStream_t s, 
     return 0;
 }
 
-// The wave-specialised kernel (policy_step_ws.hpp): one persistent workgroup per CU.  Tile plan: as many FULL tiles as give
-// every workgroup the same number, the envs left over as small tiles of EPTh = ceil(rest / workgroups) envs (<= EPT) that each
-// workgroup plays FIRST.  Zero-store pacing: everything inside the gate loop when it fits (one loop per SIMD at a time here).
-static size_t ps_ws_lds(int H, int tile_words)
-{
-    return ((size_t)2 * 64 * (2 * H + 4) + 2 * (6 * 64 + 4) + 16 + 4 * (size_t)H + 16 * ((size_t)H + 4) + 2 * (size_t)tile_words + 8) *
-           sizeof(float);
-}
-template <int H, int KIND>
-static int launch_step_ws(StepArgs& a, int tile_words, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
-{
-    static const int grid_env = getenv("IC3_WS_GRID") ? atoi(getenv("IC3_WS_GRID")) : 0;
-    static const int zs_env = getenv("IC3_WS_ZS") ? atoi(getenv("IC3_WS_ZS")) : -1;
-    static const int zepi_env = getenv("IC3_WS_ZEPI") ? atoi(getenv("IC3_WS_ZEPI")) : -1;
-    const int G = grid_env > 0 ? grid_env : device_cus();
-    const int n_all = a.E / a.EPT;
-    a.n_full = n_all / G * G;
-    const int rest = a.E - a.n_full * a.EPT;
-    a.EPTh = rest > 0 ? std::min(a.EPT, (rest + G - 1) / G) : a.EPT;
-    a.ntiles = a.n_full + (rest > 0 ? (rest + a.EPTh - 1) / a.EPTh : 0);
-    {   // pacing: per_wave 1 KiB chunks per matrix wave of a full tile; S = 2 * zs slots per 16-k block in KB16 - 1 blocks
-        const int NWv = H / 32, KB16 = 2 * H / 16;
-        const long long chunks = ((long long)a.EPT * a.N * a.obs_dim / 4 + 63) / 64 + 1;
-        const long long per_wave = (chunks + NWv - 1) / NWv;
-        static const int ZS_SET[] = { 0, 4, 8, 16 };                // (the kernel's loop variants: 0 / 8 / 16 / 32 slots per 16-k block)
-        int zs = 16;
-        for (int cand : ZS_SET)
-            if (2LL * cand * (KB16 - 1) >= per_wave) {
-                zs = cand;
-                break;
-            }
-        if (zs_env >= 0) zs = zs_env >= 16 ? 16 : zs_env >= 8 ? 8 : zs_env >= 4 ? 4 : 0;
-        a.zs = zs;
-        long long left = per_wave - 2LL * zs * (KB16 - 1);
-        a.z0 = a.z3 = a.zc = a.zf = a.zh = 0;
-        a.zepi = zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
-        left -= 32LL * a.zepi;
-        a.zrest = (int)(left > 0 ? left + 1 : 0);
-    }
-    const size_t lds = ps_ws_lds(H, tile_words);
-    IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&policy_step_ws_kernel<H, KIND>), lds));
-    const int grid = std::min(G, a.ntiles);
-    if (ev0 || ev1) {
-        hipExtLaunchKernelGGL((policy_step_ws_kernel<H, KIND>), dim3(grid), dim3(4 * H), lds, s, ev0, ev1, 0, a);
-    } else {
-        hipLaunchKernelGGL((policy_step_ws_kernel<H, KIND>), dim3(grid), dim3(4 * H), lds, s, a);
-    }
-    IC3_HIP(hipGetLastError());
-    return 0;
-}
-
 }  // namespace ic3
 
 using namespace ic3;
 
-extern "C" int ic3_policy_pack(const float* c_weight, const float* w_ih, const float* w_hh, float* c_wp, float* lstm_wp,
-                               int H, ic3_stream stream)
-{
-    if (!c_weight || !w_ih || !w_hh || !c_wp || !lstm_wp || H <= 0 || (H & 31))
-        return fail(-22, "ic3_policy_pack: H must be a positive multiple of 32");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(policy_pack_kernel, dim3(64), dim3(256), 0, s, c_weight, (const float*)nullptr, c_wp, H, H, 0);
-    hipLaunchKernelGGL(policy_pack_gates_kernel, dim3(256), dim3(256), 0, s, w_ih, w_hh, lstm_wp, H);
-    IC3_HIP(hipGetLastError());
-    return 0;
-}
-
-
-extern "C" int ic3_policy_pack_split(const float* w_ih, const float* w_hh, void* lstm_wp3, int H, ic3_stream stream)
-{
-    if (!w_ih || !w_hh || !lstm_wp3 || H <= 0 || (H % 32))
-        return fail(-22, "ic3_policy_pack_split: H must be a positive multiple of 32");
-    hipLaunchKernelGGL(policy_pack_split_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh,
-                       reinterpret_cast<ps_u32x4*>(lstm_wp3), H);
-    IC3_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int ic3_policy_pack_split_bwd(const float* w_ih, const float* w_hh, void* lstm_wp3_bwd, int H, ic3_stream stream)
-{
-    if (!w_ih || !w_hh || !lstm_wp3_bwd || H <= 0 || (H % 32))
-        return fail(-22, "ic3_policy_pack_split_bwd: H must be a positive multiple of 32");
-    hipLaunchKernelGGL(policy_pack_split_bwd_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_ih, w_hh,
-                       reinterpret_cast<ps_u32x4*>(lstm_wp3_bwd), H);
-    IC3_HIP(hipGetLastError());
-    return 0;
-}
 
 // LDS bytes of one workgroup (0 = unsupported shape); *tile_words_out = int32 words of one env-descriptor block
 static int policy_step_lds(const ic3_env* env, int H, int with_obs, int* tile_words_out)
@@ -1891,11 +1405,10 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     if (env->resets == 0) return fail(-22, "ic3_policy_step: reset() has not been called");
     if (!p->enc_wt || !p->enc_bias) return fail(-22, "ic3_policy_step: incomplete ic3_policy (encoder)");
     const int H = p->H;
-    // next_state rows are stored from inside the kernel when their descriptors fit in LDS next to the tile's own
-    // (IC3_PS_OBS=0: always as a separate ic3_env_observe launch after the kernel)
-    static const int obs_inside = getenv("IC3_PS_OBS") ? atoi(getenv("IC3_PS_OBS")) : 1;   // (same rows either way)
+    // next_state rows are stored from inside the kernel when their descriptors fit in LDS next to the tile's own (otherwise
+    // ic3_env_observe runs as a launch of its own in front of the kernel: same rows)
     int tile_words = 0;
-    int lds = (obs && obs_inside) ? policy_step_lds(env, H, 1, &tile_words) : 0;
+    int lds = obs ? policy_step_lds(env, H, 1, &tile_words) : 0;
     const bool fused_obs = lds != 0;
     if (!lds) lds = policy_step_lds(env, H, 0, &tile_words);
     if (!lds)
@@ -1941,13 +1454,9 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     const int tiles = plan_tiles(a, H, p, (hipStream_t)stream);
     // incremental obs rows (opt-in): the buffer must be the one the previous call painted, untouched since
     const bool incr = fused_obs && env->obs_rec != nullptr;
-    // rows zero-filled by ic3_obs_prefill (a launch of its own, beside the previous step): patches only.  One use per fill.
-    const bool prefilled = fused_obs && !incr && env->prefilled_obs == obs;
-    if (obs && env->prefilled_obs == obs) env->prefilled_obs = nullptr;
-    const bool incr_valid = (incr && env->painted_valid && env->painted_obs == obs) || prefilled;   // (no zero fill in the launch)
+    const bool incr_valid = incr && env->painted_valid && env->painted_obs == obs;   // (no zero fill in the launch)
     a.obs_rec = incr ? env->obs_rec : nullptr;
-    a.obs_incr = (incr_valid && !prefilled) ? 1 : 0;
-    a.obs_prefilled = prefilled ? 1 : 0;
+    a.obs_incr = incr_valid ? 1 : 0;
     if (incr) {
         env->painted_obs = obs;
         env->painted_valid = true;
@@ -1959,16 +1468,9 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
     {   // pacing of the obs zero fill (speed only: a slot past a wave's last chunk is dropped by the hardware).
         // A wave of a full tile owns `per_wave` 1 KiB chunks.  Stores issued back to back are exposed at the HBM write
         // rate; stores between MFMAs ride in their shadows until the rate all CUs ask for exceeds what HBM takes.
-        // IC3_PS_ZS / ZF / ZEPI / ZH override the split (stores per K block of the gate loop; in front of the comm
-        // phase; per element of the cell epilogue; in front of the heads), IC3_PS_ZFRAC the share of the gate loop.
-        static const int zs_env = getenv("IC3_PS_ZS") ? atoi(getenv("IC3_PS_ZS")) : -1;
-        static const int zf_env = getenv("IC3_PS_ZF") ? atoi(getenv("IC3_PS_ZF")) : -1;
-        static const int zh_env = getenv("IC3_PS_ZH") ? atoi(getenv("IC3_PS_ZH")) : -1;
-        static const int zepi_env = getenv("IC3_PS_ZEPI") ? atoi(getenv("IC3_PS_ZEPI")) : -1;
-        static const int zfrac = getenv("IC3_PS_ZFRAC") ? atoi(getenv("IC3_PS_ZFRAC")) : 70;
-        static const int z0_env = getenv("IC3_PS_Z0") ? atoi(getenv("IC3_PS_Z0")) : -1;
-        static const int z3_env = getenv("IC3_PS_Z3") ? atoi(getenv("IC3_PS_Z3")) : -1;
-        static const int zc_env = getenv("IC3_PS_ZC") ? atoi(getenv("IC3_PS_ZC")) : -1;
+        // The split below (stores per K block of the gate loop; inside the C product; in front of the comm phase; per element
+        // of the cell epilogue) is the outcome of the sweeps of rounds 3-4 (profiles/r03/pacing_sweep.txt, profiles/r04).
+        constexpr int zfrac = 70;                                // share of a large slice that goes out inside the gate loop (%)
         const int NWv = H / 32, KBv = 2 * H / 8;
         const long long chunks = ((long long)a.EPT * a.N * a.obs_dim / 4 + 63) / 64 + 1;   // 1 KiB chunks of a full tile
         const long long per_wave = (chunks + NWv - 1) / NWv;
@@ -1984,8 +1486,7 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
             const double want = small ? (double)((per_wave + KBv - 1) / KBv) : (double)per_wave * zfrac / 100.0 / KBv;
             double best = 1e30;
             for (int cand : ZS_SET) {
-                if (zs_env >= 0 && cand != zs_env) continue;
-                if (zs_env < 0 && cand == 1) continue;             // (2 slots per unrolled pair of K blocks: the compiler's
+                if (cand == 1) continue;                           // (2 slots per unrolled pair of K blocks: the compiler's
                                                                    //  vmcnt comes out one short of exact for that variant)
                 const double d = want > cand ? want - cand : cand - want;
                 if (d < best) {
@@ -2001,13 +1502,13 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
             left -= n;
             return n;
         };
-        a.z0 = take(z0_env >= 0 ? z0_env : 0);
-        a.z3 = take(z3_env >= 0 ? z3_env : 0);
+        a.z0 = take(0);
+        a.z3 = take(0);
         const int share = small ? 0 : (int)((per_wave * 7 + 50) / 100);
-        a.zc = take(std::min(zc_env >= 0 ? zc_env : share, H / 8));
-        a.zf = take(zf_env >= 0 ? zf_env : share);
-        a.zh = take(zh_env >= 0 ? zh_env : 0);
-        a.zepi = (!fused_obs || incr_valid || a.gates_out) ? 0 : zepi_env >= 0 ? std::min(zepi_env, 2) : left > 32 ? 2 : left > 0 ? 1 : 0;
+        a.zc = take(std::min(share, H / 8));
+        a.zf = take(share);
+        a.zh = take(0);
+        a.zepi = (!fused_obs || incr_valid || a.gates_out) ? 0 : left > 32 ? 2 : left > 0 ? 1 : 0;
         left -= 32LL * a.zepi;
         a.zrest = (fused_obs && !incr_valid) ? (int)(left > 0 ? left + 1 : 0) : 0;
     }
@@ -2017,18 +1518,6 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         rc = ic3_env_observe(env, obs, stream);
         if (rc) return rc;
     }
-#ifdef IC3_PS_TRACE
-    static unsigned long long* trace_buf = nullptr;
-    static int trace_call = 0, trace_tiles = 0;
-    if (getenv("IC3_PS_TRACE_OUT")) {
-        if (!trace_buf) {
-            trace_tiles = tiles;
-            IC3_HIP(hipMalloc(&trace_buf, (size_t)tiles * 20 * sizeof(unsigned long long)));
-            IC3_HIP(hipMemset(trace_buf, 0, (size_t)tiles * 20 * sizeof(unsigned long long)));
-        }
-        if (tiles == trace_tiles) a.trace = trace_buf;
-    }
-#endif
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (!inner) {                                                // one-shot (ic3_env_set_step_events): the step's LAST launch
         ev0 = (hipEvent_t)env->ev_start;
@@ -2041,46 +1530,6 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         if (H == 128)
             return pp ? launch_step<128, IC3_ENV_PP, 1, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<128, IC3_ENV_TJ, 1, 1>(a, tiles, lds, s, ev0, ev1);
         return pp ? launch_step<64, IC3_ENV_PP, 1, 1>(a, tiles, lds, s, ev0, ev1) : launch_step<64, IC3_ENV_TJ, 1, 1>(a, tiles, lds, s, ev0, ev1);
-    }
-    // IC3_PS_WS=1: the wave-specialised schedule (policy_step_ws.hpp) where it applies — same results (A / B switch)
-    static const int ws_on = getenv("IC3_PS_WS") ? atoi(getenv("IC3_PS_WS")) : 0;
-    if (ws_on && !a.gates_out && a.l_wp3 && fused_obs && !inner && !a.keep_state && !incr && !prefilled && (H == 128 || H == 64) &&
-        ps_ws_lds(H, tile_words) <= 160 * 1024) {
-        StepArgs w = a;
-#ifdef IC3_PS_TRACE
-        // [tile][20] time stamps (s_memrealtime, 100 MHz): 0..8 front phases (helper wave 0), 9 / 10 / 11 gate loop start / end,
-        // epilogue end (matrix wave 0), 12..17 heads / draws / env step / patch wait / patches (helper wave 0); dumped by the
-        // 40th call to $IC3_PS_TRACE_OUT (tools/analyze_trace.py --ws)
-        static unsigned long long* ws_trace = nullptr;
-        static int ws_call = 0;
-        const size_t ws_words = ((size_t)a.E + 64) * 20;
-        w.trace = nullptr;
-        if (getenv("IC3_PS_TRACE_OUT")) {
-            if (!ws_trace) {
-                IC3_HIP(hipMalloc(&ws_trace, ws_words * sizeof(unsigned long long)));
-                IC3_HIP(hipMemset(ws_trace, 0, ws_words * sizeof(unsigned long long)));
-            }
-            w.trace = ws_trace;
-        }
-#endif
-        if (H == 128) rc = pp ? launch_step_ws<128, IC3_ENV_PP>(w, tile_words, s, ev0, ev1) : launch_step_ws<128, IC3_ENV_TJ>(w, tile_words, s, ev0, ev1);
-        else rc = pp ? launch_step_ws<64, IC3_ENV_PP>(w, tile_words, s, ev0, ev1) : launch_step_ws<64, IC3_ENV_TJ>(w, tile_words, s, ev0, ev1);
-#ifdef IC3_PS_TRACE
-        if (w.trace && ++ws_call == 40) {
-            IC3_HIP(hipStreamSynchronize(s));
-            std::vector<unsigned long long> hbuf((size_t)w.ntiles * 20);
-            IC3_HIP(hipMemcpy(hbuf.data(), ws_trace, hbuf.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            if (FILE* f = fopen(getenv("IC3_PS_TRACE_OUT"), "w")) {
-                for (int t = 0; t < w.ntiles; ++t) {
-                    fprintf(f, "%d", t);
-                    for (int k = 0; k < 20; ++k) fprintf(f, ",%llu", hbuf[(size_t)t * 20 + k]);
-                    fprintf(f, "\n");
-                }
-                fclose(f);
-            }
-        }
-#endif
-        return rc;
     }
     if (a.l_wp3) {   // gate_split: the gate product on the bf16 matrix cores with exact split products
         if (H == 128)
@@ -2095,51 +1544,9 @@ extern "C" int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, floa
         rc = pp ? launch_step<64, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<64, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
     else
         rc = pp ? launch_step<256, IC3_ENV_PP>(a, tiles, lds, s, ev0, ev1) : launch_step<256, IC3_ENV_TJ>(a, tiles, lds, s, ev0, ev1);
-#ifdef IC3_PS_TRACE
-    if (a.trace && ++trace_call == 40) {
-        IC3_HIP(hipStreamSynchronize(s));
-        std::vector<unsigned long long> h((size_t)trace_tiles * 20);
-        IC3_HIP(hipMemcpy(h.data(), trace_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(getenv("IC3_PS_TRACE_OUT"), "w")) {
-            for (int t = 0; t < trace_tiles; ++t) {
-                fprintf(f, "%d", t);
-                for (int k = 0; k < 20; ++k) fprintf(f, ",%llu", h[(size_t)t * 20 + k]);
-                fprintf(f, "\n");
-            }
-            fclose(f);
-        }
-    }
-#endif
     return rc;
 }
 
-template <int H>
-static int launch_gate_probe(const float* xh, const float* lstm_wp, const void* lstm_wp3, float* gates, int R, hipStream_t s)
-{
-    const size_t lds = (size_t)64 * (2 * H + 4) * sizeof(float);
-    const dim3 grid((R + 63) / 64), block(2 * H);
-    if (lstm_wp3) {
-        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&gate_product_probe_kernel<H, 1>), lds));
-        hipLaunchKernelGGL((gate_product_probe_kernel<H, 1>), grid, block, lds, s, xh, (const ps_f32x4*)nullptr, lstm_wp3, gates, R);
-    } else {
-        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(&gate_product_probe_kernel<H, 0>), lds));
-        hipLaunchKernelGGL((gate_product_probe_kernel<H, 0>), grid, block, lds, s, xh, reinterpret_cast<const ps_f32x4*>(lstm_wp),
-                           (const void*)nullptr, gates, R);
-    }
-    IC3_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int ic3_gate_product_probe(const float* xh, const float* lstm_wp, const void* lstm_wp3, float* gates, int R, int H,
-                                      ic3_stream stream)
-{
-    if (!xh || !gates || (!lstm_wp && !lstm_wp3) || R <= 0) return fail(-22, "ic3_gate_product_probe: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    if (H == 128) return launch_gate_probe<128>(xh, lstm_wp, lstm_wp3, gates, R, s);
-    if (H == 64) return launch_gate_probe<64>(xh, lstm_wp, lstm_wp3, gates, R, s);
-    if (H == 256) return launch_gate_probe<256>(xh, lstm_wp, lstm_wp3, gates, R, s);
-    return fail(-38, "ic3_gate_product_probe: hid_size 64 / 128 / 256");
-}
 
 extern "C" int ic3_env_set_record_out(ic3_env* env, float* gates, float* xh)
 {

@@ -163,29 +163,6 @@ class _BatchedEnv(object):
         check(_lib.lib().ic3_env_encode(self._h, ptr(weight_t), ptr(bias), ptr(loc_table), ptr(out), ldo, H, stream()))
         return out
 
-    def obs_pair(self):
-        """Two observation buffers for the prefilled rollout (Trainer, args.prefill_obs): step t's launch patches
-        pair[t & 1] while ic3_obs_prefill zero-fills pair[(t + 1) & 1] on a second stream.  pair[0] is the env's own
-        buffer; `self._obs` names whichever one holds the latest observation."""
-        pair = getattr(self, '_obs_pair', None)
-        if pair is None:
-            with torch.cuda.device(self.device):
-                first = self._obs
-                pair = self._obs_pair = [first, torch.empty_like(first)]
-        return pair
-
-    def prefill(self, obs, cuda_stream=None):
-        """ic3_obs_prefill: zero-fill `obs` on `cuda_stream` (a torch stream; default: the current one) and mark it, so
-        that the next ic3_policy_step on it only patches the non-zero entries in."""
-        self._require()
-        h = C.c_void_p(cuda_stream.cuda_stream) if cuda_stream is not None else stream()
-        check(_lib.lib().ic3_obs_prefill(self._h, ptr(obs), h))
-
-    def mark_prefilled(self, obs):
-        """ic3_obs_set_prefilled: state (without a launch) which buffer holds zero rows (None: none does)."""
-        self._require()
-        check(_lib.lib().ic3_obs_set_prefilled(self._h, ptr(obs)))
-
     def set_incremental_obs(self, on=True):
         """EXPERIMENT (ic3_env_set_incremental_obs): ic3_policy_step maintains the rows of the obs buffer it is handed
         (clear what the previous call painted, paint the new entries) instead of zero-filling them every step.  The

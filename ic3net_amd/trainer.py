@@ -127,7 +127,7 @@ class Trainer(object):
         if not mode or mode == 'step' or not self._use_graph() or self._episodes_played == 0 or check_every:
             return False
         raw = self.env.env
-        return not self._prefill_obs() and not self._overlap_obs() and getattr(raw, 'obs_timer', None) is None
+        return not self._overlap_obs() and getattr(raw, 'obs_timer', None) is None
 
     def _play_episode_graph(self):
         T = self.args.max_steps
@@ -339,7 +339,6 @@ class Trainer(object):
             in_graph_obs = self._dense_obs() and (not self._obs_outside_graph(raw, t) or
                                                   (self._mega_now() and self._fused_obs()))
             saved = (self._state, self._info, self._prev_hid)
-            pf_before = getattr(self, '_pf_ready', None)
             graph = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
@@ -365,28 +364,14 @@ class Trainer(object):
                     gc.enable()
             self._graph_gen = getattr(self.policy_net, 'cache_generation', 0)
             g = self._graphs[t] = dict(graph=graph, obs_inside=in_graph_obs, inputs=saved,
-                                       outputs=(self._state, self._info, self._prev_hid, self._step_out[t]),
-                                       # prefilled rollout: the captured launch only PATCHES pair[t & 1] when the fill of
-                                       # the previous step had zeroed it; the buffer the step leaves the observation in
-                                       pf_expect=(self._mega_now() and in_graph_obs and self._fused_obs()
-                                                  and self._prefill_obs() and pf_before == (t & 1)),
-                                       pf_used=(self._mega_now() and in_graph_obs and self._fused_obs()
-                                                and self._prefill_obs()),
-                                       obs_buf=raw._obs)
-            self._pf_ready = pf_before                             # (the capture did not execute)
+                                       outputs=(self._state, self._info, self._prev_hid, self._step_out[t]))
             # capture does not execute: fall through to a replay so that step t actually runs
         if g['obs_inside'] and self._obs_outside_graph(raw, t) and not (self._mega_now() and self._fused_obs()):
             # timing was switched on after capture: re-capture without the obs launch
             del self._graphs[t]
             return self.step_episode(t)
         self.clock.t = t
-        if g.get('pf_expect') and getattr(self, '_pf_ready', None) != (t & 1):
-            raw.prefill(raw.obs_pair()[t & 1])     # irregular step order (an abandoned episode): zero it on this stream
         g['graph'].replay()
-        if g.get('pf_used'):
-            self._pf_ready = (t + 1) & 1
-            self._pf_dirty = True
-            raw._obs = g['obs_buf']
         if not g['obs_inside'] and self._dense_obs():
             if self._overlap_obs():
                 self._observe_on_side_stream(raw)
@@ -518,28 +503,6 @@ class Trainer(object):
         # stream (args.overlap_obs) — ic3_policy_step falls back to a separate obs launch by itself when the obs
         # descriptors of a tile do not fit in LDS
         fused = observe and self._fused_obs()
-        prefill = fused and self._prefill_obs()
-        if prefill:
-            # two observation buffers: this step's launch writes pair[t & 1] — only its non-zero entries when the fill
-            # launch of the previous step left it zeroed (the library keeps track) — while ic3_obs_prefill zero-fills
-            # pair[(t + 1) & 1] on a second stream BESIDE it (fork here, join behind the launch)
-            pair = raw.obs_pair()
-            main = torch.cuda.current_stream()
-            side = self._fill_stream(main)
-            raw._obs = pair[t & 1]
-            if getattr(self, '_pf_dirty', False):                  # graph replays since the last eager launch: tell the
-                ready = getattr(self, '_pf_ready', None)           # handle which buffer they left zero-filled
-                raw.mark_prefilled(pair[ready] if ready is not None else None)
-                self._pf_dirty = False
-            side.wait_stream(main)                                # (the launch that last patched the other buffer)
-            ft = getattr(raw, 'fill_timer', None)
-            if ft is not None:
-                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                f0.record(side)
-            raw.prefill(pair[(t + 1) & 1], side)
-            if ft is not None:
-                f1.record(side)
-                ft.append((f0, f1, t))
         rec_out = None
         if self._rec is not None and self._prev_hid[0].data_ptr() == self._rec.hs[t].data_ptr():
             rec_out = self._rec.slot(t + 1)                        # the launch writes the next slot of the episode record
@@ -552,9 +515,6 @@ class Trainer(object):
             raw, [state, self._prev_hid], info, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
             alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if fused else None,
             hidden_out=rec_out, out=out_buf, **extra)
-        if prefill:
-            main.wait_stream(side)
-            self._pf_ready = (t + 1) & 1
         self._mega_last = True
         if timer is not None:
             if not stamped:
@@ -651,19 +611,6 @@ class Trainer(object):
         stand-alone obs launch behind the step."""
         return bool(getattr(self.args, 'fused_obs', True)) and not self._overlap_obs() \
             and not getattr(self.args, 'store_states', False)
-
-    def _prefill_obs(self):
-        """args.prefill_obs (off by default): the zero background of the obs rows comes from ic3_obs_prefill on a second
-        stream, one step ahead, instead of from zero stores inside the policy launch.  Not combined with the incremental
-        rows experiment."""
-        return bool(getattr(self.args, 'prefill_obs', False)) and not getattr(self.args, 'incremental_obs', False) \
-            and hasattr(self.env.env, 'obs_pair')
-
-    def _fill_stream(self, main):
-        side = getattr(self, '_fill_side', None)
-        if side is None or side.device != main.device:
-            side = self._fill_side = torch.cuda.Stream(device=main.device)
-        return side
 
     def _overlap_obs(self):
         """args.overlap_obs is only honoured when nothing on the rollout path reads the dense observation (the sparse

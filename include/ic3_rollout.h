@@ -603,20 +603,6 @@ int ic3_policy_step(ic3_env* env, const ic3_policy* p, float* h, float* c, const
                     const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward, int32_t* done,
                     int32_t* alive, int32_t* is_completed, ic3_stream stream);
 
-/* The zero background of the dense observation rows as a launch of its own: zero-fills obs [E][N][obs_dim] on `stream`
- * and marks the buffer — the NEXT ic3_policy_step that is handed this buffer only patches the non-zero entries of the
- * rows in (instead of zero-filling its tiles' slices from inside the matrix work) and clears the mark.  Meant to run on a
- * second stream BESIDE the policy launch of the previous step, on the other one of two obs buffers (the reference
- * allocates a fresh observation every step: predator_prey_env.py:188-190, env_wrappers.py:88-100); the caller orders the
- * fill in front of the ic3_policy_step that consumes it (event / stream wait).  Every row is still rewritten every step.
- * Any other writer of the buffer through this handle (ic3_env_observe, ic3_env_step with obs) drops the mark.
- * obs must be 16-byte aligned (-EINVAL otherwise). */
-int ic3_obs_prefill(ic3_env* env, float* obs, ic3_stream stream);
-/* The mark by itself (host state of the handle, no launch): `obs` holds zero rows — or, with NULL, no buffer does.  For a
- * caller that replays captured launches (hipGraph): the handle only sees the calls made while capturing, so before it
- * issues ic3_policy_step eagerly again the caller states what its replays left behind. */
-int ic3_obs_set_prefilled(ic3_env* env, const float* obs);
-
 /* Synthetic uniform actions in [0, naction) for env-only benchmarks (DOMAIN_BENCH). */
 int ic3_random_actions(int32_t* action, int naction, uint32_t seed, uint32_t env_id_offset, uint32_t episode,
                        uint32_t t, int E, int N, ic3_stream stream);

@@ -223,8 +223,7 @@ class HostPolicy(object):
                  pass_index=0, inner=False, passes=1):
         from ic3net_amd import _lib as binding
         lib = host_lib()
-        # (IC3_HOST_FORCE_SPLIT=1: every policy of the process takes the split gate product — the wave-specialised kernel,
-        #  IC3_PS_WS=1, exists for it only: tests/test_host_policy_step_cpu.py::test_wave_specialised_schedule_on_the_host)
+        # (IC3_HOST_FORCE_SPLIT=1: every policy of the process takes the split gate product)
         gate_split = gate_split or os.environ.get('IC3_HOST_FORCE_SPLIT') == '1'
         f32 = lambda a: np.ascontiguousarray(a, np.float32)
         self.H, self.heads = H, [int(a) for a in head_sizes]

@@ -278,86 +278,6 @@ def test_incremental_obs_rows_are_the_same_rows():
             np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("name", ["pp_hard", "tj_hard", "tj_medium"])
-def test_prefilled_obs_rows_are_the_same_rows(name):
-    """ic3_obs_prefill + ic3_policy_step (patches only) on two alternating buffers — the product's default rollout — against
-    the launch that zero-fills its rows itself: rows and every other output bit-identical, step after step.  The buffers
-    start as NaN, so a row the fill launch missed or a stale entry would show."""
-    w = WORKLOADS[name]
-    E, N, H, heads = 5, w['N'], w['H'], w['heads']
-    tj = w['env'] == 'tj'
-    outs = []
-    for prefill in (0, 1):
-        env = make_env(w, E, 3, 70)
-        P = make_params(env.obs_dim, H, heads, seed=4)
-        pol = HostPolicy(env, P, H, heads)
-        env.reset(0) if tj else env.reset()
-        h = np.zeros((E * N, H), np.float32)
-        c = np.zeros((E * N, H), np.float32)
-        gate = np.zeros((E, N), np.int32) if w['hard_attn'] else None
-        alive_in = None
-        pair = [np.full((E, N, env.obs_dim), np.nan, np.float32) for _ in range(2)]
-        rows = []
-        for t in range(5):
-            obs = pair[t & 1] if prefill else pair[0]
-            out = np.full((E * N, pol.OT), np.nan, np.float32)
-            act = np.full((len(heads), E, N), -1, np.int32)
-            rew, done = np.zeros((E, N), np.float32), np.zeros((E,), np.int32)
-            alive, comp = np.zeros((E, N), np.int32), np.zeros((E, N), np.int32)
-            if prefill:
-                check(env.lib.ic3_obs_prefill(env._h, p(pair[(t + 1) & 1]), None))     # (beside this step on the GPU)
-            check(env.lib.ic3_policy_step(env._h, C.byref(pol.struct), p(h), p(c), p(alive_in), p(gate), p(out), p(act), p(obs), p(rew), p(done),
-                                          p(alive), p(comp), None))
-            rows.append((obs.copy(), out.copy(), act.copy(), rew.copy()))
-            alive_in = alive if tj else None
-            if w['hard_attn']:
-                gate = np.ascontiguousarray(act[len(heads) - 1])
-        outs.append(rows)
-        env.close()
-    for a, b in zip(*outs):
-        for x, y in zip(a, b):
-            np.testing.assert_array_equal(x, y)
-
-
-def test_prefill_mark_is_dropped_by_other_writers_and_used_once():
-    """The mark ic3_obs_prefill leaves is per buffer and single-use: a second ic3_policy_step on the same buffer, or one
-    behind ic3_env_observe on it, rewrites whole rows (a NaN planted in a zero position must be gone)."""
-    w = WORKLOADS['pp_hard']
-    E, N, H, heads = 3, w['N'], w['H'], w['heads']
-    env = make_env(w, E, 3, 70)
-    P = make_params(env.obs_dim, H, heads, seed=4)
-    pol = HostPolicy(env, P, H, heads)
-    env.reset()
-    h = np.zeros((E * N, H), np.float32)
-    c = np.zeros((E * N, H), np.float32)
-    gate = np.zeros((E, N), np.int32)
-    obs = np.zeros((E, N, env.obs_dim), np.float32)
-
-    def step():
-        out = np.zeros((E * N, pol.OT), np.float32)
-        act = np.zeros((2, E, N), np.int32)
-        rew, done = np.zeros((E, N), np.float32), np.zeros((E,), np.int32)
-        check(env.lib.ic3_policy_step(env._h, C.byref(pol.struct), p(h), p(c), None, p(gate), p(out), p(act), p(obs), p(rew),
-                                      p(done), None, None, None))
-    check(env.lib.ic3_obs_prefill(env._h, p(obs), None))
-    step()                                   # consumes the mark (patches only)
-    assert np.isfinite(obs).all()
-    obs[:] = np.nan                          # the caller scribbles: the NEXT step must not trust the buffer
-    step()
-    assert np.isfinite(obs).all()
-    check(env.lib.ic3_obs_prefill(env._h, p(obs), None))
-    check(env.lib.ic3_env_observe(env._h, p(obs), None))     # another writer drops the mark
-    obs[:] = np.nan
-    step()
-    assert np.isfinite(obs).all()
-    check(env.lib.ic3_obs_set_prefilled(env._h, p(obs)))      # the explicit mark: the caller vouches for the zeros
-    obs[:] = 0
-    step()
-    assert np.isfinite(obs).all()
-    assert env.lib.ic3_obs_prefill(env._h, C.c_void_p(p(obs).value + 4), None) == -22     # not 16-byte aligned
-    env.close()
-
-
 def test_auto_reset_stream_restarts_policy_and_env_inside_the_launch():
     """ic3_env_set_auto_reset: an env whose episode ends (episode_over, or the step cap) starts its next episode inside the
     same ic3_policy_step launch, and the launch treats an env at t = 0 as an episode start (h = c = 0, no alive mask, gate 0:
@@ -999,33 +919,6 @@ def test_results_do_not_depend_on_the_lane_schedule():
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                       env=dict(os.environ, IC3_HOST_SCHED=sched), cwd=os.path.dirname(here)))
              for sched in ("reverse", "shuffle")]              # shuffle: another pseudo-random order in every round; side by side
-    for sched, pr in procs:
-        out, err = pr.communicate()
-        assert pr.returncode == 0, sched + out[-3000:] + err[-2000:]
-        assert " passed" in out and "failed" not in out
-
-
-def test_wave_specialised_schedule_on_the_host():
-    """csrc/policy_step_ws.hpp (IC3_PS_WS=1: matrix waves + helper waves of one persistent workgroup, handing tiles to each other
-    through LDS counters instead of s_barrier) through the stand-in runtime — spinning lanes yield, a hand-off nobody signals
-    aborts as a hang — under the three lane schedules: split-product free runs (TJ-hard: several tiles per workgroup, the small
-    tile first; PP-easy at hid 64 under a shuffled lane order) must pass exactly as on the default kernel (auto-reset streams
-    under this schedule: tests/test_policy_step_plans_gpu.py)."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    runs = [("", "gate_split_experiment and tj_hard"),                                    # several tiles per workgroup, small tile first
-            ("shuffle", "free_run_vs and pp_easy")]                                      # hid 64, another lane order every round
-    host_lib()
-    procs = []
-    for sched, sel in runs:                                    # side by side
-        env = dict(os.environ, IC3_PS_WS="1", IC3_HOST_FORCE_SPLIT="1")
-        if sched:
-            env["IC3_HOST_SCHED"] = sched
-        procs.append((sched, subprocess.Popen([sys.executable, "-m", "pytest", os.path.join(here, "test_host_policy_step_cpu.py"), "-q",
-                                               "-x", "-p", "no:cacheprovider", "-k", sel], stdout=subprocess.PIPE,
-                                              stderr=subprocess.PIPE, text=True, env=env, cwd=os.path.dirname(here))))
     for sched, pr in procs:
         out, err = pr.communicate()
         assert pr.returncode == 0, sched + out[-3000:] + err[-2000:]

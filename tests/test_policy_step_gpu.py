@@ -327,10 +327,10 @@ def test_trainer_takes_the_one_launch_path_and_graph_replay_is_identical(workloa
 
 
 def test_result_changing_environment_knobs_are_gone():
-    """Round 2 read IC3_PS_DEBUG / ZMODE / SKEW / WGS with getenv on the hot entry point ("results are wrong when set").
-    They are compile-time switches of variant builds now (tools/build_variant.sh): the shipped library produces the same
-    bits with and without them in the environment; the remaining variables (IC3_PS_ZS / ZF / ZFRAC / HALF ...) only move
-    work around inside the launch."""
+    """Round 2 read IC3_PS_DEBUG / ZMODE / SKEW / WGS with getenv on the hot entry point ("results are wrong when set");
+    rounds 3-5 kept the pacing overrides IC3_PS_ZS / ZF / ZFRAC / ... for sweeps.  Round 6 removed them all: the library
+    reads ONE variable, IC3_PS_HALF (the tile plan, a test hook: same results either way), and produces the same bits with
+    or without any of the old names in the environment."""
     import subprocess
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -19,7 +19,7 @@ try:
     r=d.get('roofline') or {}; m=d.get('roofline_mfma') or {}; t=d.get('timing') or {}
     print("%-44s %.4f ms/step %7.1f M/s | launch %.4f (min %s med %s) fill %s | hbm %.3f mfma %.3f | ok=%s" % (
         sys.argv[2], d['ms_per_step'], d['value']/1e6, (m or r).get('avg_launch_ms',0), t.get('launch_ms_min'),
-        t.get('launch_ms_median'), d.get('fill_launch_ms'), r.get('frac',0) or 0, m.get('frac',0) or 0, t.get('consistent')))
+        t.get('launch_ms_median'), None, r.get('frac',0) or 0, m.get('frac',0) or 0, t.get('consistent')))
 except Exception as e:
     print(sys.argv[2], 'FAILED', e)
     try: print(open(sys.argv[1][:-5]+'.err').read()[-1500:])
