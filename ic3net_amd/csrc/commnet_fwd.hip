@@ -58,12 +58,8 @@ struct CommnetArgs {
 };
 
 // Wave priority (policy_step.hip: the phases around a matrix product are dependent chains on the tile's critical path, the
-// product is throughput work): 3 outside the [comm | h] product, 0 inside.  -DIC3_CN_NO_PRIO: variant build without it.
-#ifdef IC3_CN_NO_PRIO
-#define CN_PRIO(p) do { } while (0)
-#else
+// product is throughput work): 3 outside the [comm | h] product, 0 inside.
 #define CN_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#endif
 
 template <int H, int KIND = 0>
 __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_kernel(const CommnetArgs a)

@@ -33,15 +33,13 @@ __device__ __forceinline__ void enc_bwd_accumulate(const float* __restrict__ g, 
         const encb_f32x4 v = reinterpret_cast<const encb_f32x4*>(g + (row0 + a) * (size_t)ldg)[c4];
         reinterpret_cast<encb_f32x4*>(gl)[idx] = v;
         const int p = pos(a);
-#ifndef IC3_ENCB_NOATOMIC   // (timing experiment, round 3: PP-hard E = 8192 takes 212 us per call with these atomics, 81 us without)
-        if (p >= 0) {
+        if (p >= 0) {      // (round 3: PP-hard E = 8192 takes 212 us per call with these atomics, 81 us without: see enc_bwd_rows below)
             float* dst = P + (size_t)p * H + 4 * c4;
             if (v.x != 0.f) atomicAdd(dst + 0, v.x);
             if (v.y != 0.f) atomicAdd(dst + 1, v.y);
             if (v.z != 0.f) atomicAdd(dst + 2, v.z);
             if (v.w != 0.f) atomicAdd(dst + 3, v.w);
         }
-#endif
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < (nslots + 1) * H; idx += blockDim.x) {
@@ -186,17 +184,13 @@ __device__ __forceinline__ void enc_bwd_rows(const float* __restrict__ g, int ld
             const int lr = order[i];
             const int el = lr / rows_env, a = lr - el * rows_env;
             const size_t row = (size_t)(eb + el) * rows_env + a;
-#ifndef IC3_ENCB_ABL   // timing ablations (compile-time only: tools/build_variant.sh x -DIC3_ENCB_ABL=.. pp_kernels)
-#define IC3_ENCB_ABL 0
-#endif
-            encb_f32x4 v = { 1.f, 1.f, 1.f, 1.f };
-            if (!(IC3_ENCB_ABL & 4)) v = *reinterpret_cast<const encb_f32x4*>(g + row * ldg + col0 + 4 * c4);
+            const encb_f32x4 v = *reinterpret_cast<const encb_f32x4*>(g + row * ldg + col0 + 4 * c4);
             db += v;
             const int pos = row_fn(row, ent + el * total, a, [&](int k, float wgt) { racc[k] += wgt * v; });
-            if (!(IC3_ENCB_ABL & 2) && pos >= 0) Pl4[pos * C4 + c4] += v;     // this lane owns bin pos % RL
+            if (pos >= 0) Pl4[pos * C4 + c4] += v;     // this lane owns bin pos % RL
         }
         // the other entities inside the windows
-        const int npairs = (IC3_ENCB_ABL & 1) ? 0 : nrows * total;
+        const int npairs = nrows * total;
         for (int p0 = 0; p0 < npairs; p0 += ENCB_HITS) {
             if (threadIdx.x == 0) nhit[0] = 0;
             __syncthreads();
