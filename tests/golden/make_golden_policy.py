@@ -607,6 +607,14 @@ def grad_fullsize_main():
               difficulty='hard', entr=0.01, value_coeff=0.01)
 
 
+def grad_scaled_main():
+    """F5b at the hidden size / agent count of config 5 (round-5 verdict item 4): 32 agents, hid 256, vision 2, closed-form
+    weights — on a 12 x 12 grid and 8 steps, so that encoder.weight's gradient (hid x obs_dim) stays a small fixture; the native
+    update at hid 256 is the recomputing backward (ic3_lstm_gates_backward<256>, the kernel config 5 runs)."""
+    grad_case('grad_pp_scaled_h256_ic3net', 'predator_prey', 8, 2, 1, 45, closed_form=True, nagents=32, dim=12, vision=2,
+              hid_size=256, ic3net=True, recurrent=True, detach_gap=3, entr=0.01, value_coeff=0.01)
+
+
 def grad_nonrec_main():
     """F5b for the NON-recurrent module (comm.py:127-129,220-224): the reference's compute_grad with
     recurrent = False — CommNet with two communication passes, and the gated (IC3Net-style) module with shared weights."""
@@ -636,6 +644,8 @@ if __name__ == '__main__':
         trainer_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_nonrec':
         grad_nonrec_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_scaled':
+        grad_scaled_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_fullsize':
         grad_fullsize_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_baseline':

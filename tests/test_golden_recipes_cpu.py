@@ -35,6 +35,7 @@ RECIPES = {
     'trainer': ['make_golden_policy.py', 'trainer'],          # (runs trainer_fullsize too)
     'grad_nonrec': ['make_golden_policy.py', 'grad_nonrec'],
     'grad_fullsize': ['make_golden_policy.py', 'grad_fullsize'],
+    'grad_scaled': ['make_golden_policy.py', 'grad_scaled'],
     'grad_stream': ['make_golden_policy.py', 'grad_stream'],
     'grad_stream_h128': ['make_golden_policy.py', 'grad_stream_h128'],
     'grad_baseline': ['make_golden_policy.py', 'grad_baseline'],
@@ -42,7 +43,7 @@ RECIPES = {
     'ckpt': ['make_golden_ckpt.py'],
 }
 # every committed data fixture must come out of one of the recipes above
-EXPECTED_MIN_NPZ = 67
+EXPECTED_MIN_NPZ = 68
 
 
 @pytest.fixture(scope='module')

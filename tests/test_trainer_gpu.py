@@ -248,6 +248,8 @@ GRAD_FIXTURES = [("grad_pp_easy_ic3net", "predator_prey"), ("grad_pp_medium_comm
                  ("grad_tj_easy_ic3net", "traffic_junction"), ("grad_tj_medium_perhead", "traffic_junction"),
                  # BASELINE shapes (hid 128, 80 steps, detach_gap 10), closed-form weights: configs[1] and configs[3]
                  ("grad_pp_hard_ic3net", "predator_prey"), ("grad_tj_hard_ic3net", "traffic_junction"),
+                 # config 5's hidden size and agent count (hid 256, 32 agents, vision 2): the recomputing backward at <256>
+                 ("grad_pp_scaled_h256_ic3net", "predator_prey"),
                  # the NON-recurrent module (comm.py:127-129,220-224): CommNet with two passes; gated, shared weights
                  ("grad_pp_medium_commnet_mlp2", "predator_prey"), ("grad_tj_easy_ic3net_mlp2share", "traffic_junction"),
                  # the IC / IRIC baselines (models.py:8-97; round 5): models.MLP, models.RNN with the tanh recurrence / the LSTM cell
@@ -355,6 +357,7 @@ GRAD_TOL_DEFAULT = (0.0, 0.0)
 GRAD_TOL = {
     "grad_pp_easy_ic3net":             (5.6e-06, 2.0e-06),
     "grad_pp_hard_ic3net":             (4.3e-05, 4.2e-06),
+    "grad_pp_scaled_h256_ic3net":      (8.6e-06, 2.0e-06),
     "grad_pp_medium_commnet_mlp2":     (4.0e-06, 2.0e-06),
     "grad_pp_medium_commnet_norm":     (4.0e-06, 1.0e-04),
     "grad_pp_medium_ic_mlp":           (4.0e-06, 2.0e-06),
