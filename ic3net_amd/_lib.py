@@ -130,7 +130,7 @@ EXPORTS = {
     "ic3_comm_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]),
     "ic3_lstm_weight_grad_scratch_floats": (C.c_size_t, [C.c_longlong, C.c_int]),
     "ic3_lstm_weight_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p,
-                                       C.c_int, C.c_void_p, C.c_void_p]),
+                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ic3_bptt_backward_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_bptt_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_set_record_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

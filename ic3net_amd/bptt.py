@@ -458,7 +458,8 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
                       mode_avg=mode_avg, comm_zero=mask_zero, detach_gap=gap, row_live=live_flat, row_keep=keep_flat, enc_first=True,
                       gate_events=getattr(raw, 'gate_timer', None))     # (bench.py --mode train: HIP events around the gate launches)
     work = acc.setdefault('_work', {})
-    ops.lstm_weight_grad(rec.xh[:T], rec.hs[:T], rec.gates[:T], acc['w_cat_t'], row_live=live_flat, accumulate=True, work=work)
+    ops.lstm_weight_grad(rec.xh[:T], rec.hs[:T], rec.gates[:T], acc['w_cat_t'], row_live=live_flat, accumulate=True, work=work,
+                         split=bool(getattr(args, 'gate_split', True)))
     dwt, db = raw.encode_backward_finish(H, want_bias=True)
     acc['wt'].add_(dwt)
     acc['enc_bias'].add_(db)

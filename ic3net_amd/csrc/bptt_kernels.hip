@@ -25,6 +25,7 @@
 
 #include "enc_bwd.hpp"
 #include "ic3_common.hpp"
+#include "ps_common.hpp"
 
 extern "C" int ic3_lstm_gates_backward_given(const float* gates, float* xh, int ldx, const float* h_prev, const void* lstm_wp3_bwd,
                                              const float* c_prev, const float* dh, const float* dc, float* dgates, float* dc_prev,
@@ -341,6 +342,148 @@ __global__ __launch_bounds__(256, 2) void lstm_wgrad_kernel(const WGradArgs a)
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same product as EXACT bf16 split products (split != 0; the arithmetic of the rollout's gate product):
+// every fp32 operand x = x1 + x2 + x3 (three bf16 terms, round-to-nearest-even, exact residuals), all nine cross products on
+// v_mfma_f32_32x32x16_bf16 (a bf16 x bf16 product is exact in fp32), fp32 accumulation.  Here BOTH operands are activations, and
+// the matrix instruction wants 8 consecutive k = rows q per lane at a fixed column — the transposed access of row-major data:
+//   * a thread stages 8 consecutive rows of ONE column (8 four-byte loads, coalesced across the lanes: consecutive columns),
+//     splits them in registers (ps_split_frag: 36 vector instructions per 8 values) and writes three 16-byte fragments — each
+//     element of X and D is split ONCE per workgroup, not once per wave that multiplies with it;
+//   * LDS holds the planes in fragment order, [plane][k half][column] x 16 bytes: a wave's A / B fragment is one conflict-free
+//     ds_read_b128, 18 of them (4 + 2 fragments x 3 planes) per 72 MFMAs of a 16-row step.
+// Same grid, tile (2H x 128 per workgroup, H x 64 per wave), K slices and reduction as the fp32 form above.  Issue bound: 9 x 32
+// cycles per 32 x 32 x 16 block against 8 x 64 on the fp32 instruction (1.78 x), minus the split that does not hide under the MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256, 2) void lstm_wgrad_split_kernel(const WGradArgs a)
+{
+    constexpr int KT = 16, XW = 2 * H, DW = 128, MB = H / 32, NB = 2, NT = 256;
+    constexpr int NGX = 2 * XW / NT;                             // 8-row groups of X per thread and stage (2 at H = 128, 1 at H = 64)
+    constexpr int SQ = 3 * 2 * (XW + DW);                        // 16-byte fragments per stage: [plane][k half][column]
+    typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+    IC3_DYNAMIC_LDS(float, smem);
+    ps_u32x4* const frag = reinterpret_cast<ps_u32x4*>(smem);    // stage b at frag + b * SQ: X planes, then D planes
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int wm = w & 1, wn = w >> 1;
+    const int ny = blockIdx.y;
+    const long long q0 = (long long)blockIdx.x * a.rows_per_wg;
+    long long nq = a.Q - q0;
+    if (nq > a.rows_per_wg) nq = a.rows_per_wg;
+    if (nq < 0) nq = 0;
+    const __amdgpu_buffer_rsrc_t ri = bp_rsrc(a.inp + q0 * a.ldi, nq > 0 ? ((nq - 1) * a.ldi + H) * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rh = bp_rsrc(a.h + q0 * H, nq * H * 4);
+    const __amdgpu_buffer_rsrc_t rd = bp_rsrc(a.dg + q0 * 4 * H + ny * DW, nq > 0 ? ((nq - 1) * 4 * H + DW) * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rl = bp_rsrc(a.row_live ? a.row_live + q0 : a.h, a.row_live ? nq * 4 : 0);
+    const int nstages = (int)((nq + KT - 1) / KT);
+    // X group g = tid + i NT: column g % XW, rows 8 (g / XW) .. + 7 of the stage; the D group: column tid % DW, k half tid / DW.
+    // Lane part of every address in ONE VGPR (column + the group's k half), the stage / row part on the scalar ALU — an soffset
+    // that depends on a VGPR, however uniform, costs a waterfall loop per load.  Which side of [inp | h] a wave stages is
+    // wave-uniform (64 consecutive columns): a scalar branch.
+    const int dcol = tid % DW, dkg = tid / DW;
+    int xoff[NGX], loff[NGX];
+    bool x_is_h[NGX];
+#pragma unroll
+    for (int i = 0; i < NGX; ++i) {
+        const int g = tid + i * NT, c = g % XW, kg = g / XW;
+        x_is_h[i] = __builtin_amdgcn_readfirstlane((int)(c >= H)) != 0;
+        xoff[i] = x_is_h[i] ? ((c - H) + 8 * kg * H) * 4 : (c + 8 * kg * a.ldi) * 4;
+        loff[i] = 8 * kg * 4;
+    }
+    const int doff = (dcol + 8 * dkg * 4 * H) * 4;
+    float xv[NGX][8], dv[8];
+    auto fetch = [&](int s) {
+        const int qb = s * KT;
+#pragma unroll
+        for (int i = 0; i < NGX; ++i) {
+            if (x_is_h[i]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[i][j] = bp_load1(rh, xoff[i], (qb + j) * H * 4);
+                if (a.row_live) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[i][j] *= bp_load1(rl, loff[i], (qb + j) * 4);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[i][j] = bp_load1(ri, xoff[i], (qb + j) * a.ldi * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = bp_load1(rd, doff, (qb + j) * 4 * H * 4);
+    };
+    auto stash = [&](int b) {
+        ps_u32x4* f = frag + b * SQ;
+        ps_u32x4 pl[3];
+#pragma unroll
+        for (int i = 0; i < NGX; ++i) {
+            const int g = tid + i * NT, c = g % XW, kg = g / XW;
+            ps_split_frag(ps_f32x4{ xv[i][0], xv[i][1], xv[i][2], xv[i][3] }, ps_f32x4{ xv[i][4], xv[i][5], xv[i][6], xv[i][7] }, pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[(p * 2 + kg) * XW + c] = pl[p];
+        }
+        ps_split_frag(ps_f32x4{ dv[0], dv[1], dv[2], dv[3] }, ps_f32x4{ dv[4], dv[5], dv[6], dv[7] }, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[3 * 2 * XW + (p * 2 + dkg) * DW + dcol] = pl[p];
+    };
+    bp_f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.0f;
+    // Pipeline: at the top of iteration s the registers hold stage s + 1 (requested a whole iteration ago) and LDS buffer s & 1
+    // holds stage s.  The iteration is ONE basic block — the split + stash of stage s + 1 and the 72 products of stage s
+    // (independent work: different LDS buffers; the compiler interleaves them), then the loads of stage s + 2 — so that the vector
+    // work rides in the issue slots the matrix instructions leave (measured: 6.8 ms with the stash behind a branch and waterfall
+    // loops around the loads, 5.8 ms like this, for 3.3 M rows at H = 128; the fp32 form takes 6.4 ms).  Everything is unconditional: stages past the slice read zeros (range check) and
+    // stash them into a buffer nobody multiplies.
+    fetch(0);
+    stash(0);
+    fetch(1);
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < nstages; ++s) {
+        const ps_u32x4* fx = frag + (s & 1) * SQ;
+        const ps_u32x4* fd = fx + 3 * 2 * XW;
+        ps_u32x4 bf[3][NB];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bf[p][nb] = fd[(p * 2 + lh) * DW + 64 * wn + 32 * nb + li];
+        stash((s + 1) & 1);                                      // (in front of the products in program order: the scheduler
+                                                                 //  starts the vector work while the first fragments arrive)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            ps_u32x4 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = fx[(p * 2 + lh) * XW + wm * H + 32 * mb + li];
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int pa = 2; pa >= 0; --pa)                  // (least significant term first)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, af[pa]),
+                                                                              __builtin_bit_cast(wg_bf16x8, bf[pb][nb]), acc[mb][nb], 0, 0, 0);
+        }
+        fetch(s + 2);
+        __syncthreads();
+    }
+    // block (mb, nb), register reg, lane (li, lh): output row m = wm H + 32 mb + (reg & 3) + 8 (reg >> 2) + 4 lh, column
+    // n = 128 ny + 64 wn + 32 nb + li
+    float* dst = a.part + (size_t)blockIdx.x * XW * 4 * H;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = wm * H + 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                dst[(size_t)m * 4 * H + DW * ny + 64 * wn + 32 * nb + li] = acc[mb][nb][reg];
+            }
+}
+
 // dW += the K slices' partials, summed in slice order (reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ dW,
                                                            int accumulate)
@@ -427,7 +570,7 @@ extern "C" size_t ic3_lstm_weight_grad_scratch_floats(long long Q, int H)
 }
 
 extern "C" int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_prev, const float* dgates, const float* row_live,
-                                    long long Q, int H, float* dW, int accumulate, float* scratch, ic3_stream stream)
+                                    long long Q, int H, float* dW, int accumulate, int split, float* scratch, ic3_stream stream)
 {
     using namespace ic3;
     if (!inp || !h_prev || !dgates || !dW || !scratch || Q <= 0) return fail(-22, "ic3_lstm_weight_grad: null argument");
@@ -440,6 +583,21 @@ extern "C" int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_pr
         return fail(-22, "ic3_lstm_weight_grad: a K slice must stay below 2 GB per operand (32-bit buffer offsets)");
     const WGradArgs a{ inp, h_prev, dgates, row_live, scratch, Q, ldi, (int)per };
     hipStream_t s = (hipStream_t)stream;
+    if (split) {                                                 // exact bf16 split products (the rollout's arithmetic)
+        const size_t lds3 = (size_t)2 * 3 * 2 * (2 * H + 128) * 16;
+        if (H == 128) {
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_wgrad_split_kernel<128>), lds3));
+            hipLaunchKernelGGL((lstm_wgrad_split_kernel<128>), dim3(ks, 4), dim3(256), lds3, s, a);
+        } else {
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_wgrad_split_kernel<64>), lds3));
+            hipLaunchKernelGGL((lstm_wgrad_split_kernel<64>), dim3(ks, 2), dim3(256), lds3, s, a);
+        }
+        IC3_HIP(hipGetLastError());
+        const int n3 = 2 * H * 4 * H;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n3 + 255) / 256), dim3(256), 0, s, scratch, ks, n3, dW, accumulate);
+        IC3_HIP(hipGetLastError());
+        return ks;
+    }
     const size_t lds = (size_t)2 * 16 * (2 * H + 128) * sizeof(float);
     if (H == 128) {
         IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lstm_wgrad_kernel<128>), lds));

@@ -292,10 +292,11 @@ def comm_backward(dxh, h_prev, alive, gate, c_weight, dh_out, dcw_partials, E, N
     return n
 
 
-def lstm_weight_grad(inp, h_prev, dgates, dW, row_live=None, accumulate=True, work=None):
+def lstm_weight_grad(inp, h_prev, dgates, dW, row_live=None, accumulate=True, work=None, split=True):
     """ic3_lstm_weight_grad: dW (2H, 4H) (+)= [inp | h_prev]^T @ dgates over all Q rows of a window of recorded steps in one
     launch.  inp (Q, >= H) rows with unit column stride (the first H floats count: the record's [inp | h] rows), h_prev (Q, H),
-    dgates (Q, 4H) contiguous; leading dims may be (T, R)."""
+    dgates (Q, 4H) contiguous; leading dims may be (T, R).  split (default): exact bf16 split products on the bf16 matrix cores
+    (the rollout's gate_split arithmetic); False: the fp32 matrix instruction."""
     _need_cuda(dgates, "lstm_weight_grad")
     H = h_prev.shape[-1]
     Q = dgates.numel() // (4 * H)
@@ -313,7 +314,7 @@ def lstm_weight_grad(inp, h_prev, dgates, dW, row_live=None, accumulate=True, wo
     if key not in work or work[key].numel() < n:
         work[key] = torch.empty((n,), dtype=torch.float32, device=dgates.device)
     check(_lib.lib().ic3_lstm_weight_grad(ptr(inp2), inp2.stride(0), ptr(h_prev), ptr(dgates), ptr(row_live), Q, H, ptr(dW),
-                                          int(bool(accumulate)), ptr(work[key]), stream()))
+                                          int(bool(accumulate)), int(bool(split)), ptr(work[key]), stream()))
 
 
 def bptt_backward_supported(env, H):

@@ -380,11 +380,13 @@ int ic3_comm_backward(const float* dxh, int ldd, const float* h_prev, const int3
  * LSTMCell (rows [0, H): weight_ih^T, rows [H, 2H): weight_hh^T).  inp [Q][ldi] (the first H floats of a row: the inp half of the
  * rollout's record, ic3_env_set_record_out), h_prev [Q][H] (slots 0..T-1 of the recorded hidden states — no copy into an
  * [inp | h] buffer), dgates [Q][4H] (what ic3_lstm_gates_backward_given left in the gate record), row_live [Q] or NULL (collection
- * mode: h_prev rows times it).  scratch: ic3_lstm_weight_grad_scratch_floats(Q, H) floats.  Exact fp32 products on the fp32 matrix
- * instruction, split-K over the CUs, slices summed in order (reproducible).  hid_size 64 / 128. */
+ * mode: h_prev rows times it).  scratch: ic3_lstm_weight_grad_scratch_floats(Q, H) floats.  split != 0 (what ic3net_amd passes
+ * with args.gate_split, the default): every fp32 operand split exactly into three bf16 terms, all nine cross products on the bf16
+ * matrix cores, fp32 accumulation — the arithmetic of the rollout's gate product (ic3_policy.gate_split); split == 0: the fp32 matrix
+ * instruction.  Exact products either way, split-K over the CUs, slices summed in order (reproducible).  hid_size 64 / 128. */
 size_t ic3_lstm_weight_grad_scratch_floats(long long Q, int H);
 int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_prev, const float* dgates, const float* row_live /* or NULL */,
-                         long long Q, int H, float* dW, int accumulate, float* scratch, ic3_stream stream);
+                         long long Q, int H, float* dW, int accumulate, int split, float* scratch, ic3_stream stream);
 
 /* The backward through a window of T recorded steps (trainer.py:128-225 over comm.py:134-244, one communication pass, recorded
  * gates), last step first, as ONE host call — per step: ic3_lstm_gates_backward_given (in place on the gate record, the heads'

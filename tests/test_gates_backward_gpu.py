@@ -251,11 +251,13 @@ def test_comm_backward_one_launch(H, N, E, avg, masks):
     assert torch.equal(dz, dxh[:, H:] * scale.unsqueeze(1))
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["bf16x9", "fp32"])
 @pytest.mark.parametrize("H,T,R,live", [(128, 5, 81920, False), (128, 3, 1000, True), (64, 7, 333, True), (128, 1, 17, False),
                                         (64, 2, 30000, False)])
-def test_weight_gradient_of_a_window_in_one_launch(H, T, R, live):
+def test_weight_gradient_of_a_window_in_one_launch(H, T, R, live, split):
     """ic3_lstm_weight_grad over T x R rows (K slices across the CUs) against the float64 product of [inp | h * live]^T . dgates;
-    added on top of what dW holds; reproducible."""
+    added on top of what dW holds; reproducible.  Both arithmetic modes: nine exact bf16 x bf16 products per fp32 product (the
+    default, the rollout's gate_split arithmetic) and the fp32 matrix instruction."""
     from ic3net_amd import ops
     gen = torch.Generator(device='cuda').manual_seed(H + T + R)
     rn = lambda *s: torch.randn(*s, device='cuda', generator=gen)
@@ -266,7 +268,7 @@ def test_weight_gradient_of_a_window_in_one_launch(H, T, R, live):
     outs = []
     for _ in range(2):
         dW = torch.ones((2 * H, 4 * H), device='cuda')
-        ops.lstm_weight_grad(xh, hs, dg, dW, row_live=lv)
+        ops.lstm_weight_grad(xh, hs, dg, dW, row_live=lv, split=split)
         outs.append(dW)
     tol = 2e-6 * (T * R) ** 0.5 * 16
     assert float((outs[0].double() - want).abs().max()) <= tol

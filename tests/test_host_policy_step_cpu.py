@@ -607,16 +607,16 @@ def test_weight_gradient_of_a_window_in_one_launch(H, Q, ldi):
     n = lib.ic3_lstm_weight_grad_scratch_floats(Q, H)
     assert n > 0 and lib.ic3_lstm_weight_grad_scratch_floats(Q, 256) == 0
     scratch = np.full(n, np.nan, np.float32)
-    for lv in (None, live):
+    for lv, split in ((None, 0), (live, 0), (None, 1), (live, 1)):    # split: nine exact bf16 x bf16 products per fp32 product
         x = np.concatenate([inp[:, :H].astype(np.float64), h.astype(np.float64) * (1.0 if lv is None else lv[:, None])], 1)
         want = x.T @ dg.astype(np.float64)
         dW = np.full((2 * H, 4 * H), np.nan, np.float32)
-        check(lib.ic3_lstm_weight_grad(p(inp), ldi, p(h), p(dg), p(lv), Q, H, p(dW), 0, p(scratch), None))
+        check(lib.ic3_lstm_weight_grad(p(inp), ldi, p(h), p(dg), p(lv), Q, H, p(dW), 0, split, p(scratch), None))
         assert np.abs(dW - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
         once = dW.copy()
-        check(lib.ic3_lstm_weight_grad(p(inp), ldi, p(h), p(dg), p(lv), Q, H, p(dW), 1, p(scratch), None))
+        check(lib.ic3_lstm_weight_grad(p(inp), ldi, p(h), p(dg), p(lv), Q, H, p(dW), 1, split, p(scratch), None))
         np.testing.assert_allclose(dW, 2 * once, rtol=1e-6, atol=1e-6)
-    assert lib.ic3_lstm_weight_grad(p(inp), H - 4, p(h), p(dg), None, Q, H, p(dW), 0, p(scratch), None) == -22
+    assert lib.ic3_lstm_weight_grad(p(inp), H - 4, p(h), p(dg), None, Q, H, p(dW), 0, 0, p(scratch), None) == -22
 
 
 def commnet_weights(lib, P, H, heads, passes):

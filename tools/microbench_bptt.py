@@ -62,7 +62,9 @@ def main():
     xh, hs, dg = g(T, R, 2 * H), g(T, R, H), g(T, R, 4 * H)
     dW = torch.zeros((2 * H, 4 * H), device=dev)
     work = {}
-    timeit("ic3_lstm_weight_grad (T %d: Q = %d rows)" % (T, Q), lambda: ops.lstm_weight_grad(xh, hs, dg, dW, work=work), n=5,
+    timeit("ic3_lstm_weight_grad, bf16 x 9 (T %d: Q = %d rows)" % (T, Q), lambda: ops.lstm_weight_grad(xh, hs, dg, dW, work=work), n=5,
+           flop=2 * Q * 2 * H * 4 * H, nbytes=Q * (4 * H * 4 + 2 * H * 4))
+    timeit("ic3_lstm_weight_grad, fp32 instruction", lambda: ops.lstm_weight_grad(xh, hs, dg, dW, work=work, split=False), n=5,
            flop=2 * Q * 2 * H * 4 * H, nbytes=Q * (4 * H * 4 + 2 * H * 4))
     wpart = torch.zeros((8, 2 * H, 4 * H), device=dev)
     xcat = torch.cat([xh[0][:, :H], hs[0]], 1).contiguous()
