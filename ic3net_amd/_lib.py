@@ -9,7 +9,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("IC3_ROLLOUT_LIB") or os.path.join(_HERE, "csrc", "libic3rollout.so")   # (override: A/B builds)
 
-ABI_VERSION = 600        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
+ABI_VERSION = 601        # IC3_VERSION of include/ic3_rollout.h this binding was written against (checked at load)
 ENV_PP, ENV_TJ = 1, 2
 PP_MODES = {"mixed": 0, "cooperative": 1, "competitive": 2}
 TJ_DIFFICULTY = {"easy": 0, "medium": 1, "hard": 2}
@@ -76,7 +76,7 @@ class Bptt(C.Structure):
                 ("row_live", C.c_void_p), ("row_keep", C.c_void_p), ("lstm_wp3_bwd", C.c_void_p), ("w_heads", C.c_void_p),
                 ("c_weight", C.c_void_p), ("dh", C.c_void_p), ("dc", C.c_void_p), ("dxh", C.c_void_p),
                 ("dbias_partials", C.c_void_p), ("dcw_partials", C.c_void_p), ("enc_work", C.c_void_p),
-                ("gate_events", C.POINTER(C.c_void_p))]
+                ("dxh_step", C.c_int64), ("gate_events", C.POINTER(C.c_void_p))]
 
 
 EXPORTS = {
@@ -107,6 +107,10 @@ EXPORTS = {
     "ic3_env_encode_backward_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                      C.c_void_p]),
     "ic3_env_encode_backward_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ic3_env_encode_backward_window_work": (C.c_int64, [C.c_void_p, C.c_int]),
+    "ic3_env_encode_backward_window": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                                 C.c_void_p, C.c_int, C.c_void_p]),
+    "ic3_env_encode_backward_window_finish": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ic3_env_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ic3_env_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

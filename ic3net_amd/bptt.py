@@ -414,7 +414,8 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
                                       heads' share d_t . W_heads on the way in, [d inp | d h_direct] = dgates . [W_ih | W_hh]
       ic3_comm_backward               dL/dh_{t-1} = d h_direct + (M d inp) . C,  dC += (M d inp)^T h_{t-1}   (M: the mixing matrix of
                                       the communication block, symmetric — one mix feeds both products; comm itself is never formed)
-      ic3_env_encode_backward_accumulate   the sparse encoder's stage 1 on the step's snapshot
+      ic3_env_encode_backward_accumulate   the sparse encoder's stage 1 on the step's snapshot — or, with the steps' input gradients
+                                      kept in a ring, ONE ic3_env_encode_backward_window launch over all of them behind the loop
     and behind the loop ONE weight-gradient launch over the window's T x R rows (the record's inp rows, the recorded h, the
     dgates now standing in the gate record), the heads' pass, the encoder's expansion, the partials' sums.  Same cuts as
     backward_episode (detach points; collection mode: row_live / row_keep / gated-off fresh envs)."""
@@ -426,7 +427,11 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
     mask_zero = bool(args.comm_mask_zero)
     zeros = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
     dh_rec, dc_rec = zeros(R, H), zeros(R, H)
-    dxh = torch.empty((R, 2 * H), dtype=torch.float32, device=dev)
+    # the per-step input gradients: a ring of T of them when the encoder's backward has its window form (one launch over all the
+    # window's states behind the loop instead of one per step) and the memory is there, else one buffer
+    ring = bool(getattr(args, 'enc_window', True)) and raw.encode_window_work(H) is not None and \
+        _ring_fits(dev, T * R * 2 * H * 4)
+    dxh = torch.empty((T, R, 2 * H) if ring else (R, 2 * H), dtype=torch.float32, device=dev)
     bias_parts = zeros((R + 63) // 64, 4 * H)
     dcw_parts = None if mask_zero else zeros(ops.comm_backward_partials(E, N), H, H)
     alive, gate = list(rec.alive[:T]), list(rec.gate[:T])
@@ -460,7 +465,7 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
     work = acc.setdefault('_work', {})
     ops.lstm_weight_grad(rec.xh[:T], rec.hs[:T], rec.gates[:T], acc['w_cat_t'], row_live=live_flat, accumulate=True, work=work,
                          split=bool(getattr(args, 'gate_split', True)))
-    dwt, db = raw.encode_backward_finish(H, want_bias=True)
+    dwt, db = raw.encode_backward_window_finish(H, want_bias=True) if ring else raw.encode_backward_finish(H, want_bias=True)
     acc['wt'].add_(dwt)
     acc['enc_bias'].add_(db)
     acc['b_cat'].add_(bias_parts.sum(0))
@@ -468,6 +473,15 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
         acc['c_w'].add_(dcw_parts.sum(0))
     _heads_grad_episode(rec, d_out, acc, T, R, H)
     return (dh_rec, dc_rec)
+
+
+def _ring_fits(dev, nbytes):
+    """Room for the ring of per-step input gradients: a quarter of what the device has free (+ what the caching allocator holds)."""
+    if dev.type != 'cuda':
+        return True
+    free, _ = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return nbytes <= (free + cached) // 4
 
 
 def _heads_grad_episode(rec, d_out, acc, T, R, H):

@@ -648,6 +648,8 @@ extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream str
         !b->dbias_partials || !b->enc_work)
         return fail(-22, "ic3_bptt_backward: null argument");
     if (!b->comm_zero && (!b->c_weight || !b->dcw_partials)) return fail(-22, "ic3_bptt_backward: C.weight and its partials");
+    if (b->dxh_step && (b->dxh_step < (long long)E * N * 2 * H || ic3_env_encode_backward_window_work(env, H) <= 0))
+        return fail(-22, "ic3_bptt_backward: dxh_step >= E * N * 2 * hid_size, on a configuration with ic3_env_encode_backward_window");
     const long long R = (long long)E * N;
     hipStream_t s = (hipStream_t)stream;
     int enc_first = b->enc_first;
@@ -657,23 +659,28 @@ extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream str
             IC3_HIP(hipMemsetAsync(b->dc, 0, (size_t)R * H * sizeof(float), s));
         }
         float* g = b->gates + (size_t)t * R * 4 * H;
+        float* dxh = b->dxh + (size_t)t * (size_t)b->dxh_step;
         if (b->gate_events) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t], s));
         int rc = ic3_lstm_gates_backward_given(g, nullptr, 0, nullptr, b->lstm_wp3_bwd, b->cs + (size_t)t * R * H, b->dh, b->dc, g,
-                                               b->dc, b->dbias_partials, 1, b->dxh,
+                                               b->dc, b->dbias_partials, 1, dxh,
                                                b->row_live ? b->row_live + (size_t)t * R : nullptr,
                                                b->row_keep ? b->row_keep + (size_t)t * R : nullptr,
                                                b->dhead + (size_t)t * R * b->OT, b->w_heads, b->OT, (int)R, H, stream);
         if (rc < 0) return rc;
         if (b->gate_events) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t + 1], s));
         const float* out_scale = (b->row_keep && t > 0) ? b->row_keep + (size_t)(t - 1) * R : nullptr;
-        rc = ic3_comm_backward(b->dxh, 2 * H, b->hs + (size_t)t * R * H, b->alive ? b->alive[t] : nullptr,
+        rc = ic3_comm_backward(dxh, 2 * H, b->hs + (size_t)t * R * H, b->alive ? b->alive[t] : nullptr,
                                b->gate ? b->gate[t] : nullptr, b->c_weight, out_scale, b->dh, b->dcw_partials, 1, E, N, H,
                                b->mode_avg, b->comm_zero, stream);
         if (rc < 0) return rc;
-        rc = ic3_env_encode_backward_accumulate(env, b->snaps + (size_t)t * b->snap_words, b->dxh, 2 * H, H, b->enc_work, enc_first,
+        if (b->dxh_step) continue;                               // (the encoder's first stage: once, behind the loop)
+        rc = ic3_env_encode_backward_accumulate(env, b->snaps + (size_t)t * b->snap_words, dxh, 2 * H, H, b->enc_work, enc_first,
                                                 stream);
         if (rc < 0) return rc;
         enc_first = 0;
     }
+    if (b->dxh_step)
+        return ic3_env_encode_backward_window(env, b->snaps, b->snap_words, T, b->dxh, 2 * H, b->dxh_step, H, b->enc_work, enc_first,
+                                              stream);
     return 0;
 }

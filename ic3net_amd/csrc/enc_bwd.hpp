@@ -16,6 +16,8 @@
 
 #include <cstdint>
 
+#include "ps_common.hpp"
+
 namespace ic3 {
 
 typedef float encb_f32x4 __attribute__((ext_vector_type(4)));
@@ -233,6 +235,276 @@ __device__ __forceinline__ void enc_bwd_rows(const float* __restrict__ g, int ld
         encb_f32x4* dst = reinterpret_cast<encb_f32x4*>(Dg + (size_t)s * H + 4 * k);
         *dst = accumulate ? *dst + reinterpret_cast<const encb_f32x4*>(Dl)[i] : reinterpret_cast<const encb_f32x4*>(Dl)[i];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stage 1, third form (round 6): a whole WINDOW of T recorded states in one launch, on the matrix cores.
+//   out[m][h] = sum over the Q = T * R rows q of  A[m][q] * g[q][h],     m < npos:  A = [pos(q) == m]   (a one-hot column)
+//                                                                         m = npos + slot:  A = the slot's weight in row q
+//                                                                         m = npos + nslots:  A = 1      (the bias)
+// is a product with K = Q.  The one-hot entries are exact in bf16 and are MADE in registers from the rows' positions (packed
+// 16-bit arithmetic, 3 instructions per pair of rows: no table of A anywhere); g is split exactly into three bf16 terms
+// (ps_split_frag), so a 32-position block costs 3 v_mfma_f32_32x32x16_bf16 per 16 rows; the slot weights (counts at PP, arbitrary
+// header scalars at TJ) sit in an LDS table [slot][row of the batch] that the workgroup fills per batch of ENCW_RB rows — the
+// row itself, then every (row, other entity) pair that falls into the row's window, the entities' positions staged in LDS — and
+// are split the same way: 9 products for their block (3 where the weights are small counts: Spec::slots_exact_bf16).  The one-hot
+// fragments are the same for every wave of the workgroup (the waves differ in their columns of g): per batch each is made once
+// and parked in LDS (8 KB per position block), the product loop reads it back with one ds_read_b128 (with the 12 vector
+// instructions per fragment inside the loop, 156 per K step at 13 blocks, the loop was issue-bound at 2.6 x its matrix time).  A wave owns 32 columns of g (its B fragment: 8 rows x 1 column per lane,
+// straight from global memory, one K step ahead) and MBP position blocks + 1 slot block of `out` in registers for the WHOLE row
+// range of its workgroup (gridDim.z slices the blocks: slice z holds position blocks [z MBP, (z + 1) MBP) and slot block z); the
+// partials are written once per launch in the layout of the second form (Ppart[row group][pos][H], Dpart[row group][slot][H])
+// for the same expand stage.
+// Against the second form per step (84 us per state at PP-hard E = 8192: an LDS counting sort per batch, one partial read-modify-
+// write per launch): 80 states in one launch, no sort, no LDS accumulators.  Needs the rows' g of ALL the window's steps at
+// once: ic3_bptt.dxh_step (a ring of per-step input gradients instead of one buffer).
+// Spec (per env kind; all methods const, device):  total, rows_env;  word(st, e, i) = packed (row | col << 16) of entity i;
+// live(st, row);  pos(word);  self(st, row, a, word, emit(slot, weight));  pair(word_a, word_p, a, p) = slot or -1.
+constexpr int ENCW_RB = 128;             // rows per batch of the slot table (8 K steps)
+constexpr int ENCW_LDW = ENCW_RB + 4;    // floats per slot row of the table
+struct EncWinPlan {
+    int MBP = 0;       // position blocks per wave (template argument: 3, 7 or 13); 0 = not supported
+    int nsl = 0;       // slices of the M dimension (gridDim.z)
+    int ncs = 0;       // column slices of <= 128 columns (gridDim.y)
+    int nw = 0;        // waves per workgroup = columns of a slice / 32
+    int nrg = 0;       // row groups (gridDim.x) = partials
+    int nstage = 0;    // staged entity words per batch
+    int lds = 0;       // bytes
+    int PB = 0, SB = 0;
+};
+inline EncWinPlan enc_win_plan(long long R, int rows_env, int total, int H, int npos, int nslots, int cus)
+{
+    EncWinPlan p;
+    if (H < 32 || (H & 31) || R <= 0 || npos <= 0 || npos >= 0xffff || rows_env <= 0 || total < rows_env) return p;
+    p.PB = (npos + 31) / 32;
+    p.SB = (nslots + 1 + 31) / 32;
+    const int mbp = p.PB <= 3 ? 3 : (p.PB <= 7 ? 7 : 13);
+    p.nsl = (p.PB + mbp - 1) / mbp;
+    if (p.nsl < p.SB) p.nsl = p.SB;
+    p.ncs = (H + 127) / 128;
+    if (H % p.ncs || (H / p.ncs) % 32) return p;
+    p.nw = H / p.ncs / 32;
+    p.nstage = (ENCW_RB / rows_env + 2) * total;
+    p.lds = ENCW_RB * 2 + 32 * ENCW_LDW * 4 + (ENCW_RB / 16) * mbp * 64 * 16 + p.nstage * 4;
+    if (p.lds > 150 * 1024 || p.nstage > 4 * 64 * p.nw) return p;
+    const int wg_per_cu = (mbp == 13 ? 1 : (mbp == 7 ? 2 : 4)) * (4 / p.nw > 0 ? 4 / p.nw : 1);
+    long long nrg = (long long)cus * wg_per_cu / ((long long)p.ncs * p.nsl);
+    const long long nbat = (R + ENCW_RB - 1) / ENCW_RB;          // (of ONE state: the partial count does not depend on T)
+    if (nrg > nbat) nrg = nbat;
+    if (nrg < 1) nrg = 1;
+    p.nrg = (int)nrg;
+    p.MBP = mbp;
+    return p;
+}
+struct EncWinArgs {
+    const int32_t* snaps;      // state of step t at snaps + t * snap_words
+    long long snap_words;
+    const float* g;            // g of (t, row) at g + t * g_step + row * ldg
+    long long g_step;
+    int ldg, T, E, R, H, npos, nslots, PB, SB, accumulate, nstage;
+    int bat_per_wg;            // batches of ENCW_RB rows per row group
+    float* Ppart;
+    float* Dpart;
+};
+
+typedef unsigned short encw_u16x2 __attribute__((ext_vector_type(2)));
+// the two 16-bit positions of `pk` against position m (both halves of mm): 0x3F80 (bf16 1.0) where equal, 0 elsewhere
+__device__ __forceinline__ unsigned encw_onehot_pair(unsigned pk, unsigned mm)
+{
+    const encw_u16x2 d = __builtin_bit_cast(encw_u16x2, pk) - __builtin_bit_cast(encw_u16x2, mm);
+    const encw_u16x2 z = __builtin_elementwise_min(d, encw_u16x2{ 1, 1 });              // 0 where equal, 1 elsewhere
+    const encw_u16x2 r = z * encw_u16x2{ 0xC080, 0xC080 } + encw_u16x2{ 0x3F80, 0x3F80 };   // 0x3F80 - 0x3F80 z (mod 2^16)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+template <int MBP, class Spec>
+__device__ __forceinline__ void enc_bwd_window(const EncWinArgs& a, const Spec& sp, unsigned char* sm)
+{
+    typedef __bf16 encw_bf16x8 __attribute__((ext_vector_type(8)));
+    constexpr int NKS = ENCW_RB / 16;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, w = tid >> 6, nw = NT >> 6, li = lane & 31, lh = lane >> 5;
+    unsigned short* posw = reinterpret_cast<unsigned short*>(sm);                      // [ENCW_RB]
+    float* Wt = reinterpret_cast<float*>(sm + ENCW_RB * 2);                            // [32][ENCW_LDW]: this slice's slot block
+    ps_u32x4* afr = reinterpret_cast<ps_u32x4*>(Wt + 32 * ENCW_LDW);                   // [NKS][MBP][64] one-hot A fragments
+    unsigned* ent = reinterpret_cast<unsigned*>(afr + NKS * MBP * 64);                 // [nstage] entity words of the batch's envs
+    const int gb0 = blockIdx.z * MBP;                                                  // first position block of this M slice
+    const bool has_pos = gb0 < a.PB, has_slots = (int)blockIdx.z < a.SB;               // (uniform)
+    const int s0 = blockIdx.z * 32;                                                    // first slot of this slice's slot block
+    const int col = blockIdx.y * (32 * nw) + 32 * w + li;
+    const int Q = a.T * a.R;
+    const int qb = (int)min((long long)blockIdx.x * a.bat_per_wg * ENCW_RB, (long long)Q);
+    const int qe = (int)min((long long)qb + (long long)a.bat_per_wg * ENCW_RB, (long long)Q);
+    ps_f32x16 accp[MBP], accs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accs[i] = 0.f;
+#pragma unroll
+    for (int b = 0; b < MBP; ++b) accp[b] = accs;
+    // The lane's 8 rows of a K step, q = kq + 8 lh + j, column `col`: buffer loads off a descriptor whose base is the K step's
+    // first row and whose size ends at the range's last row (rows past it read 0: no branch, no select) — scalar bookkeeping
+    // (kq, kt, kr), loop-invariant lane offsets.  A K step that straddles two states whose rows are not contiguous
+    // (wrap != 0; the ring of ic3_bptt is contiguous) reads the second state's rows off a second descriptor.
+    const long long wrap = a.g_step - (long long)a.R * a.ldg;
+    int kq = qb, kt = qb / a.R, kr = qb - kt * a.R;              // (uniform)
+    int voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) voff[j] = ((8 * lh + j) * a.ldg + col) * 4;
+    auto fetch = [&](float (&v)[8]) {
+        const int nv = min(16, qe - kq);                          // rows of this K step inside the range (<= 0: none)
+        const float* base = a.g + (size_t)kt * a.g_step + (size_t)kr * a.ldg;
+        const bool cross = wrap != 0 && kr + 16 > a.R;            // (uniform)
+        const int nA = cross ? min(nv, a.R - kr) : nv;
+        const __amdgpu_buffer_rsrc_t rA = make_rsrc(base, nA > 0 ? (uint32_t)nA * a.ldg * 4u : 0u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = buf_load_b32(rA, voff[j], 0);
+        if (cross && nv > nA) {                                   // rows nA.. of the K step: the next state's first rows
+            const float* b2 = a.g + (size_t)(kt + 1) * a.g_step - (size_t)nA * a.ldg;
+            const __amdgpu_buffer_rsrc_t rB = make_rsrc(b2, (uint32_t)nv * a.ldg * 4u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = buf_load_b32(rB, voff[j], 0);
+                if (8 * lh + j >= nA) v[j] = x;
+            }
+        }
+        kq += 16;
+        kr += 16;
+        while (kr >= a.R) { kr -= a.R; ++kt; }
+    };
+    // the entity words of a batch's envs (flat env fe = q / rows_env = t E + e), one batch ahead in registers
+    unsigned ew[4];                                                // (nstage <= 4 * NT: enc_win_plan)
+    auto stage_fetch = [&](int q0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * NT;
+            unsigned v = 0u;
+            if (idx < a.nstage && q0 < qe) {
+                const int fe = q0 / sp.rows_env + idx / sp.total, i = idx % sp.total;
+                const int t = fe / a.E, e = fe - t * a.E;
+                if (t < a.T) v = sp.word(a.snaps + (size_t)t * a.snap_words, e, i);
+            }
+            ew[k] = v;
+        }
+    };
+    float gv[8];
+    fetch(gv);
+    stage_fetch(qb);
+    for (int q0 = qb; q0 < qe; q0 += ENCW_RB) {
+        __syncthreads();                                          // the previous batch's readers
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + k * NT < a.nstage) ent[tid + k * NT] = ew[k];
+        if (has_slots)
+            for (int i = tid; i < 32 * (ENCW_LDW / 4); i += NT) reinterpret_cast<ps_f32x4*>(Wt)[i] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        __syncthreads();
+        stage_fetch(q0 + ENCW_RB);                                // the next batch's words: in flight under this batch's products
+        const int fe0 = q0 / sp.rows_env;
+        for (int lr = tid; lr < ENCW_RB; lr += NT) {
+            const int q = q0 + lr;
+            unsigned short pw = 0xffff;
+            if (q < qe) {
+                const int fe = q / sp.rows_env, ag = q - fe * sp.rows_env, t = fe / a.E, r = q - t * a.R;
+                const int32_t* st = a.snaps + (size_t)t * a.snap_words;
+                const unsigned wa = ent[(fe - fe0) * sp.total + ag];
+                const bool lv = sp.live(st, (size_t)r);
+                if (lv) pw = (unsigned short)sp.pos(wa);
+                if (has_slots) {
+                    if ((unsigned)(a.nslots - s0) < 32u) Wt[(a.nslots - s0) * ENCW_LDW + lr] = 1.0f;   // the bias row: every row
+                    if (lv)
+                        sp.self(st, (size_t)r, ag, wa, [&](int slot, float wgt) {
+                            if ((unsigned)(slot - s0) < 32u) atomicAdd(&Wt[(slot - s0) * ENCW_LDW + lr], wgt);
+                        });
+                }
+            }
+            posw[lr] = pw;
+        }
+        __syncthreads();
+        if (has_pos)                                              // the batch's one-hot fragments, each made ONCE per workgroup
+            for (int ks = w; ks < NKS; ks += nw) {
+                const ps_u32x4 pk = *reinterpret_cast<const ps_u32x4*>(posw + ks * 16 + lh * 8);
+#pragma unroll
+                for (int b = 0; b < MBP; ++b) {
+                    const unsigned m = (unsigned)((gb0 + b) * 32 + li), mm = m | (m << 16);
+                    afr[(ks * MBP + b) * 64 + lane] = ps_u32x4{ encw_onehot_pair(pk[0], mm), encw_onehot_pair(pk[1], mm),
+                                                                encw_onehot_pair(pk[2], mm), encw_onehot_pair(pk[3], mm) };
+                }
+            }
+        if (has_slots) {
+            const int npairs = ENCW_RB * sp.total;
+            for (int idx = tid; idx < npairs; idx += NT) {
+                const int lr = idx / sp.total, p = idx - lr * sp.total;
+                const int q = q0 + lr;
+                if (q >= qe) continue;
+                const int fe = q / sp.rows_env, ag = q - fe * sp.rows_env;
+                if (p == ag) continue;
+                if (!sp.live_always) {
+                    const int t = fe / a.E;
+                    if (!sp.live(a.snaps + (size_t)t * a.snap_words, (size_t)(q - t * a.R))) continue;
+                }
+                const unsigned* ee = ent + (fe - fe0) * sp.total;
+                const int slot = sp.pair(ee[ag], ee[p], ag, p);
+                if ((unsigned)(slot - s0) < 32u) atomicAdd(&Wt[(slot - s0) * ENCW_LDW + lr], 1.0f);
+            }
+        }
+        __syncthreads();
+        const int nks = (min(qe - q0, ENCW_RB) + 15) / 16;
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            ps_u32x4 bf[3];
+            ps_split_frag(ps_f32x4{ gv[0], gv[1], gv[2], gv[3] }, ps_f32x4{ gv[4], gv[5], gv[6], gv[7] }, bf);
+            fetch(gv);                                            // the next K step's rows (past the range: zeros)
+            if (has_pos) {
+                ps_u32x4 af[MBP];
+#pragma unroll
+                for (int b = 0; b < MBP; ++b) af[b] = afr[(ks * MBP + b) * 64 + lane];
+#pragma unroll
+                for (int p = 2; p >= 0; --p)                      // (least significant term first; consecutive products independent)
+#pragma unroll
+                    for (int b = 0; b < MBP; ++b)
+                        accp[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(encw_bf16x8, af[b]),
+                                                                          __builtin_bit_cast(encw_bf16x8, bf[p]), accp[b], 0, 0, 0);
+            }
+            if (has_slots) {
+                const float* wr = Wt + li * ENCW_LDW + ks * 16 + lh * 8;
+                const ps_f32x4 w0 = *reinterpret_cast<const ps_f32x4*>(wr), w1 = *reinterpret_cast<const ps_f32x4*>(wr + 4);
+                if (sp.slots_exact_bf16) {                        // small integer counts: one bf16 term holds them
+                    const ps_u32x4 af = { ps_hi_pair(ps_f32x2{ w0[0], w0[1] }), ps_hi_pair(ps_f32x2{ w0[2], w0[3] }),
+                                          ps_hi_pair(ps_f32x2{ w1[0], w1[1] }), ps_hi_pair(ps_f32x2{ w1[2], w1[3] }) };
+#pragma unroll
+                    for (int pb = 2; pb >= 0; --pb)
+                        accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(encw_bf16x8, af),
+                                                                       __builtin_bit_cast(encw_bf16x8, bf[pb]), accs, 0, 0, 0);
+                } else {
+                    ps_u32x4 af[3];
+                    ps_split_frag(w0, w1, af);
+#pragma unroll
+                    for (int pb = 2; pb >= 0; --pb)
+#pragma unroll
+                        for (int pa = 2; pa >= 0; --pa)
+                            accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(encw_bf16x8, af[pa]),
+                                                                           __builtin_bit_cast(encw_bf16x8, bf[pb]), accs, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // block b, register reg, lane (li, lh): output row m = 32 block + (reg & 3) + 8 (reg >> 2) + 4 lh, column `col`
+    float* Pg = a.Ppart + (size_t)blockIdx.x * a.npos * a.H;
+    float* Dg = a.Dpart + (size_t)blockIdx.x * (a.nslots + 1) * a.H;
+#pragma unroll
+    for (int b = 0; b < MBP; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = 32 * (gb0 + b) + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (m >= a.npos) continue;
+            float* dst = Pg + (size_t)m * a.H + col;
+            *dst = a.accumulate ? *dst + accp[b][reg] : accp[b][reg];
+        }
+    if (has_slots)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = s0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (m > a.nslots) continue;
+            float* dst = Dg + (size_t)m * a.H + col;
+            *dst = a.accumulate ? *dst + accs[reg] : accs[reg];
+        }
 }
 
 // sum over partials [k0, k1) of P (the per-env form has one, atomically accumulated)

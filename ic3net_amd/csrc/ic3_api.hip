@@ -464,6 +464,31 @@ int ic3_env_encode_backward_finish(ic3_env* env, int H, float* dWt, float* dbias
                                    : tj_encode_bwd(env, nullptr, nullptr, H, H, dWt, dbias, work, (hipStream_t)stream, 3);
 }
 
+int64_t ic3_env_encode_backward_window_work(const ic3_env* env, int H)
+{
+    if (!env || H <= 0) return fail(-22, "ic3_env_encode_backward_window_work: null handle or hid_size <= 0");
+    return env->kind == IC3_ENV_PP ? pp_encode_bwd_window_work(env, H) : tj_encode_bwd_window_work(env, H);
+}
+
+int ic3_env_encode_backward_window(ic3_env* env, const int32_t* snaps, int64_t snap_words, int T, const float* grad_out, int ldg,
+                                   int64_t step_stride, int H, float* work, int first, ic3_stream stream)
+{
+    if (!env || !snaps || !grad_out || !work) return fail(-22, "ic3_env_encode_backward_window: null argument");
+    if (ldg <= 0) ldg = H;
+    if (T <= 0 || H <= 0 || ldg < H || snap_words < env->dims.state_words || step_stride < 0)
+        return fail(-22, "ic3_env_encode_backward_window: T > 0, ldg >= H, snap_words >= dims.state_words, step_stride >= 0");
+    return env->kind == IC3_ENV_PP
+               ? pp_encode_bwd_window(env, snaps, snap_words, T, grad_out, ldg, step_stride, H, work, first, (hipStream_t)stream)
+               : tj_encode_bwd_window(env, snaps, snap_words, T, grad_out, ldg, step_stride, H, work, first, (hipStream_t)stream);
+}
+
+int ic3_env_encode_backward_window_finish(ic3_env* env, int H, float* dWt, float* dbias, float* work, ic3_stream stream)
+{
+    if (!env || !dWt || !work || H <= 0) return fail(-22, "ic3_env_encode_backward_window_finish: null argument");
+    return env->kind == IC3_ENV_PP ? pp_encode_bwd_window_finish(env, H, dWt, dbias, work, (hipStream_t)stream)
+                                   : tj_encode_bwd_window_finish(env, H, dWt, dbias, work, (hipStream_t)stream);
+}
+
 int ic3_env_step(ic3_env* env, const int32_t* actions, float* obs, float* reward, int32_t* done, int32_t* alive,
                  int32_t* is_completed, ic3_stream stream)
 {

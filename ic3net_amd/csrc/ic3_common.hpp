@@ -217,6 +217,16 @@ int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
                   hipStream_t s, int mode = 0);
 int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, int H, float* dWt, float* dbias, float* work,
                   hipStream_t s, int mode = 0);
+// window form: stage 1 over T recorded states in one launch, and its expand stage
+int enc_bwd_cus();
+int64_t pp_encode_bwd_window_work(const ic3_env* env, int H);
+int64_t tj_encode_bwd_window_work(const ic3_env* env, int H);
+int pp_encode_bwd_window(ic3_env* env, const int32_t* snaps, long long snap_words, int T, const float* g, int ldg, long long g_step,
+                         int H, float* work, int first, hipStream_t s);
+int tj_encode_bwd_window(ic3_env* env, const int32_t* snaps, long long snap_words, int T, const float* g, int ldg, long long g_step,
+                         int H, float* work, int first, hipStream_t s);
+int pp_encode_bwd_window_finish(ic3_env* env, int H, float* dWt, float* dbias, float* work, hipStream_t s);
+int tj_encode_bwd_window_finish(ic3_env* env, int H, float* dWt, float* dbias, float* work, hipStream_t s);
 // tj_tables.cpp (host)
 int tj_build_tables(int dim, int vision, int difficulty, int* h, int* w, int* base, int* npath, int* narrival,
                     int* routes_per_arrival, std::vector<int32_t>& grid, std::vector<int32_t>& route_off,

@@ -675,19 +675,26 @@ __global__ __launch_bounds__(256) void heads_grad_kernel(const float* __restrict
     if (cb0 == 0 && lh == 0 && li < 16) out[16 * H + li] = bsum;      // (li >= OT: 0)
 }
 
-__global__ void heads_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int H, int OT, float* __restrict__ dW,
-                                         float* __restrict__ db)
+// dW / db += the workgroups' partials.  16 outputs x 16 shares of the partials per workgroup (a thread walking all <= 1024
+// partials 8.7 KB apart is a latency chain: 417 us at hid 128 — round 6), the shares folded in share order: reproducible.
+__global__ __launch_bounds__(256) void heads_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int H, int OT,
+                                                                float* __restrict__ dW, float* __restrict__ db)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < OT * H) {
-        float v = 0.0f;
-        for (int p = 0; p < nparts; ++p) v += partial[(size_t)p * 17 * H + i];
-        dW[i] += v;
-    } else if (i < OT * H + OT) {
-        const int o = i - OT * H;
-        float v = 0.0f;
-        for (int p = 0; p < nparts; ++p) v += partial[(size_t)p * 17 * H + 16 * H + o];
-        db[o] += v;
+    __shared__ float sh[16][17];
+    const int ol = threadIdx.x & 15, share = threadIdx.x >> 4, i = blockIdx.x * 16 + ol, n = OT * H + OT;
+    const int per = (nparts + 15) / 16, p0 = share * per, p1 = min(nparts, p0 + per);
+    const int off = i < OT * H ? i : 16 * H + (i - OT * H);
+    float v = 0.0f;
+    if (i < n)
+        for (int p = p0; p < p1; ++p) v += partial[(size_t)p * 17 * H + off];
+    sh[share][ol] = v;
+    __syncthreads();
+    if (share == 0 && i < n) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][ol];
+        if (i < OT * H) dW[i] += t;
+        else db[i - OT * H] += t;
     }
 }
 
@@ -710,7 +717,7 @@ extern "C" int ic3_heads_grad(const float* d, const float* h, long long M, int H
     else hipLaunchKernelGGL((heads_grad_kernel<256>), dim3(grid), dim3(256), 0, s, d, h, M, OT, scratch);
     IC3_HIP(hipGetLastError());
     const int n = OT * H + OT;
-    hipLaunchKernelGGL(heads_grad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, scratch, grid * nrg, H, OT, dW, db);
+    hipLaunchKernelGGL(heads_grad_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, s, scratch, grid * nrg, H, OT, dW, db);
     IC3_HIP(hipGetLastError());
     return 0;
 }

@@ -280,6 +280,39 @@ __global__ __launch_bounds__(256) void pp_encode_bwd_rows_kernel(const int32_t* 
         [&](int k) { return k == 0 ? 2 * centre : (k == 1 ? 2 * centre + 1 : -1); }, accumulate);
 }
 
+// Stage 1, window form (enc_bwd.hpp: a window of recorded states in one launch, position sums as one-hot products).
+struct PPEncSpec {
+    long long off_r, off_c;              // loc_r / loc_c inside a snapshot, in words
+    int N, total, rows_env, dim, v;
+    __device__ unsigned word(const int32_t* st, int e, int i) const
+    {
+        const size_t k = (size_t)e * total + i;
+        return (unsigned)st[off_r + k] | ((unsigned)st[off_c + k] << 16);
+    }
+    static constexpr bool live_always = true;
+    static constexpr bool slots_exact_bf16 = true;     // entity counts
+    __device__ bool live(const int32_t*, size_t) const { return true; }
+    __device__ int pos(unsigned w) const { return (int)(w & 0xffff) * dim + (int)(w >> 16); }
+    template <class Emit>
+    __device__ void self(const int32_t*, size_t, int a, unsigned, Emit emit) const
+    {
+        const int W = 2 * v + 1;
+        emit(2 * (v * W + v) + (a < N ? 0 : 1), 1.0f);           // the observer itself, in its window's centre cell
+    }
+    __device__ int pair(unsigned wa, unsigned wp, int, int p) const   // PP:191-195: another entity standing inside the window
+    {
+        const int W = 2 * v + 1;
+        const int dy = (int)(wp & 0xffff) - (int)(wa & 0xffff) + v, dx = (int)(wp >> 16) - (int)(wa >> 16) + v;
+        return ((unsigned)dy < (unsigned)W && (unsigned)dx < (unsigned)W) ? 2 * (dy * W + dx) + (p >= N ? 1 : 0) : -1;
+    }
+};
+template <int MBP>
+__global__ __launch_bounds__(256) void pp_encode_bwd_window_kernel(const EncWinArgs a, const PPEncSpec sp)
+{
+    IC3_DYNAMIC_LDS(unsigned char, sm);
+    enc_bwd_window<MBP>(a, sp, sm);
+}
+
 // Stage 2 for PP: dWt (zeroed by the caller) += P through the id map, class columns and dbias from the partials.
 // P = the sum of `np` partials of npos * H floats each.
 __global__ __launch_bounds__(256) void pp_encode_bwd_expand_kernel(const float* __restrict__ P, int np,
@@ -383,6 +416,68 @@ int pp_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
     hipLaunchKernelGGL(pp_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, np, Dpart, nwg, dWt, dbias, c.dim,
                        c.vision, H);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+int enc_bwd_cus()
+{
+    static int cus[64] = {};      // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+static EncWinPlan pp_win_plan(const ic3_env* env, int H)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int W = 2 * c.vision + 1;
+    return enc_win_plan((long long)c.E * env->dims.N, env->dims.N, c.N + c.nprey, H, c.dim * c.dim, 2 * W * W, enc_bwd_cus());
+}
+int64_t pp_encode_bwd_window_work(const ic3_env* env, int H)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int W = 2 * c.vision + 1;
+    const EncWinPlan pl = pp_win_plan(env, H);
+    return pl.MBP ? (int64_t)pl.nrg * (c.dim * c.dim + 2 * W * W + 1) * H : 0;
+}
+// g of (t, row) at g + t * g_step + row * ldg, the state of step t at snaps + t * snap_words; first != 0 writes the partials in
+// `work`, 0 adds to them.  finish: the expand stage over those partials.
+int pp_encode_bwd_window(ic3_env* env, const int32_t* snaps, long long snap_words, int T, const float* g, int ldg, long long g_step,
+                         int H, float* work, int first, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int W = 2 * c.vision + 1, npos = c.dim * c.dim, nslots = 2 * W * W, R = c.E * env->dims.N;
+    const EncWinPlan pl = pp_win_plan(env, H);
+    if (!pl.MBP || (long long)T * R >= (1ll << 31) - 2 * ENCW_RB) return fail(-38, "ic3_env_encode_backward_window: hid_size a multiple of 32 (and of 128 above 128), T * E * N < 2^31");
+    const long long nbat = ((long long)T * R + ENCW_RB - 1) / ENCW_RB;
+    EncWinArgs a = { snaps, snap_words, g, g_step, ldg, T, c.E, R, H, npos, nslots, pl.PB, pl.SB, first ? 0 : 1, pl.nstage,
+                     (int)((nbat + pl.nrg - 1) / pl.nrg), work, work + (size_t)pl.nrg * npos * H };
+    const PPEncSpec sp = { env->f("loc_r") - env->state, env->f("loc_c") - env->state, c.N, c.N + c.nprey, env->dims.N, c.dim, c.vision };
+    const dim3 grid(pl.nrg, pl.ncs, pl.nsl), block(64 * pl.nw);
+    auto go = [&](auto kernel) {
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (size_t)pl.lds));
+        hipLaunchKernelGGL(kernel, grid, block, pl.lds, s, a, sp);
+        IC3_HIP(hipGetLastError());
+        return 0;
+    };
+    return pl.MBP == 3 ? go(pp_encode_bwd_window_kernel<3>) : (pl.MBP == 7 ? go(pp_encode_bwd_window_kernel<7>) : go(pp_encode_bwd_window_kernel<13>));
+}
+int pp_encode_bwd_window_finish(ic3_env* env, int H, float* dWt, float* dbias, float* work, hipStream_t s)
+{
+    const ic3_pp_cfg& c = env->pp;
+    const int W = 2 * c.vision + 1, npos = c.dim * c.dim;
+    const EncWinPlan pl = pp_win_plan(env, H);
+    if (!pl.MBP) return fail(-38, "ic3_env_encode_backward_window_finish: this configuration has no window form");
+    IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)env->dims.obs_dim * H * sizeof(float), s));
+    if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
+    const long long items = enc_bwd_pfold_threads((long long)npos * H) + encode_bwd_items_b(pl.nrg, 2 * W * W + 1, H);
+    const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
+    hipLaunchKernelGGL(pp_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, work, pl.nrg, work + (size_t)pl.nrg * npos * H, pl.nrg,
+                       dWt, dbias, c.dim, c.vision, H);
     IC3_HIP(hipGetLastError());
     return 0;
 }

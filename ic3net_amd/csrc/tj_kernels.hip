@@ -436,6 +436,45 @@ __global__ __launch_bounds__(256) void tj_encode_bwd_rows_kernel(const int32_t* 
         [&](int k) { return k < hdr ? k : (k == 4 ? hdr + centre : -1); }, accumulate);
 }
 
+// Stage 1, window form (enc_bwd.hpp).
+struct TJEncSpec {
+    long long off_alive, off_r, off_c, off_act, off_route;   // inside a snapshot, in words
+    int total, rows_env, h, w, v, npath, hdr;
+    __device__ unsigned word(const int32_t* st, int e, int i) const
+    {
+        const size_t k = (size_t)e * total + i;
+        return (unsigned)st[off_r + k] | ((unsigned)st[off_c + k] << 16);
+    }
+    static constexpr bool live_always = false;
+    static constexpr bool slots_exact_bf16 = false;     // the header scalars are arbitrary fp32
+    __device__ bool live(const int32_t* st, size_t row) const { return st[off_alive + row] != 0; }
+    __device__ int pos(unsigned wd) const { return (int)(wd & 0xffff) * w + (int)(wd >> 16); }
+    template <class Emit>
+    __device__ void self(const int32_t* st, size_t row, int, unsigned wd, Emit emit) const
+    {
+        const int r = (int)(wd & 0xffff), c = (int)(wd >> 16), W = 2 * v + 1;
+        emit(0, (float)((double)st[off_act + row] / 1.0));                       // same expressions as the forward
+        emit(1, (float)((double)st[off_route + row] / (double)(npath - 1)));
+        if (hdr == 4) {
+            emit(2, (float)((double)r / (double)(h - 1)));
+            emit(3, (float)((double)c / (double)(w - 1)));
+        }
+        emit(hdr + v * W + v, 1.0f);                             // the car itself, in its window's centre cell
+    }
+    __device__ int pair(unsigned wa, unsigned wp, int, int) const   // another car slot standing inside a live car's window
+    {
+        const int W = 2 * v + 1;
+        const int dy = (int)(wp & 0xffff) - (int)(wa & 0xffff) + v, dx = (int)(wp >> 16) - (int)(wa >> 16) + v;
+        return ((unsigned)dy < (unsigned)W && (unsigned)dx < (unsigned)W) ? hdr + dy * W + dx : -1;
+    }
+};
+template <int MBP>
+__global__ __launch_bounds__(256) void tj_encode_bwd_window_kernel(const EncWinArgs a, const TJEncSpec sp)
+{
+    IC3_DYNAMIC_LDS(unsigned char, sm);
+    enc_bwd_window<MBP>(a, sp, sm);
+}
+
 __global__ __launch_bounds__(256) void tj_encode_bwd_expand_kernel(const float* __restrict__ P, int np,
                                                                    const float* __restrict__ Dpart, int nwg,
                                                                    const int32_t* __restrict__ grid,
@@ -536,6 +575,59 @@ int tj_encode_bwd(ic3_env* env, const int32_t* snap, const float* g, int ldg, in
     const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
     hipLaunchKernelGGL(tj_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, P, np, Dpart, nwg, env->d_grid, dWt, dbias,
                        d.grid_h, d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, H, hdr);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
+
+static EncWinPlan tj_win_plan(const ic3_env* env, int H)
+{
+    const ic3_dims& d = env->dims;
+    const int hdr = env->tj.vocab_type ? 4 : 2;
+    return enc_win_plan((long long)env->tj.E * env->tj.N, env->tj.N, env->tj.N, H, d.grid_h * d.grid_w, hdr + d.window * d.window, enc_bwd_cus());
+}
+int64_t tj_encode_bwd_window_work(const ic3_env* env, int H)
+{
+    const ic3_dims& d = env->dims;
+    const int hdr = env->tj.vocab_type ? 4 : 2;
+    const EncWinPlan pl = tj_win_plan(env, H);
+    return pl.MBP ? (int64_t)pl.nrg * (d.grid_h * d.grid_w + hdr + d.window * d.window + 1) * H : 0;
+}
+int tj_encode_bwd_window(ic3_env* env, const int32_t* snaps, long long snap_words, int T, const float* g, int ldg, long long g_step,
+                         int H, float* work, int first, hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const ic3_dims& d = env->dims;
+    const int hdr = c.vocab_type ? 4 : 2, npos = d.grid_h * d.grid_w, nslots = hdr + d.window * d.window, R = c.E * c.N;
+    const EncWinPlan pl = tj_win_plan(env, H);
+    if (!pl.MBP || (long long)T * R >= (1ll << 31) - 2 * ENCW_RB) return fail(-38, "ic3_env_encode_backward_window: hid_size a multiple of 32 (and of 128 above 128), T * E * N < 2^31");
+    const long long nbat = ((long long)T * R + ENCW_RB - 1) / ENCW_RB;
+    EncWinArgs a = { snaps, snap_words, g, g_step, ldg, T, c.E, R, H, npos, nslots, pl.PB, pl.SB, first ? 0 : 1, pl.nstage,
+                     (int)((nbat + pl.nrg - 1) / pl.nrg), work, work + (size_t)pl.nrg * npos * H };
+    auto off = [&](const char* name) { return (long long)(env->f(name) - env->state); };
+    const TJEncSpec sp = { off("alive"), off("loc_r"), off("loc_c"), off("last_act"), off("route_id"), c.N, c.N, d.grid_h, d.grid_w,
+                           c.vision, d.npath, hdr };
+    const dim3 grid(pl.nrg, pl.ncs, pl.nsl), block(64 * pl.nw);
+    auto go = [&](auto kernel) {
+        IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (size_t)pl.lds));
+        hipLaunchKernelGGL(kernel, grid, block, pl.lds, s, a, sp);
+        IC3_HIP(hipGetLastError());
+        return 0;
+    };
+    return pl.MBP == 3 ? go(tj_encode_bwd_window_kernel<3>) : (pl.MBP == 7 ? go(tj_encode_bwd_window_kernel<7>) : go(tj_encode_bwd_window_kernel<13>));
+}
+int tj_encode_bwd_window_finish(ic3_env* env, int H, float* dWt, float* dbias, float* work, hipStream_t s)
+{
+    const ic3_tj_cfg& c = env->tj;
+    const ic3_dims& d = env->dims;
+    const int hdr = c.vocab_type ? 4 : 2, npos = d.grid_h * d.grid_w, WW = d.window * d.window;
+    const EncWinPlan pl = tj_win_plan(env, H);
+    if (!pl.MBP) return fail(-38, "ic3_env_encode_backward_window_finish: this configuration has no window form");
+    IC3_HIP(hipMemsetAsync(dWt, 0, (size_t)d.obs_dim * H * sizeof(float), s));
+    if (dbias) IC3_HIP(hipMemsetAsync(dbias, 0, (size_t)H * sizeof(float), s));
+    const long long items = enc_bwd_pfold_threads((long long)npos * H) + encode_bwd_items_b(pl.nrg, hdr + WW + 1, H);
+    const int blocks = (int)std::min<long long>((items + 255) / 256, 4096);
+    hipLaunchKernelGGL(tj_encode_bwd_expand_kernel, dim3(blocks), dim3(256), 0, s, work, pl.nrg, work + (size_t)pl.nrg * npos * H, pl.nrg,
+                       env->d_grid, dWt, dbias, d.grid_h, d.grid_w, c.vision, d.vocab, d.vocab - 3, d.vocab - 1, H, hdr);
     IC3_HIP(hipGetLastError());
     return 0;
 }

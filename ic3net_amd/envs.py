@@ -261,6 +261,41 @@ class _BatchedEnv(object):
                                                         ptr(self._encb_work(H)), stream()))
         return dwt, dbias
 
+    def encode_window_work(self, H):
+        """Scratch of the window form of the encoder backward (ic3_env_encode_backward_window), or None when this configuration
+        has none."""
+        self._require()
+        key = ('encw', H)
+        if not hasattr(self, '_scratch'):
+            self._scratch = {}
+        if key not in self._scratch:
+            n = _lib.lib().ic3_env_encode_backward_window_work(self._h, H)
+            if n < 0:
+                check(int(n))
+            self._scratch[key] = torch.empty((n,), dtype=torch.float32, device=self.device) if n > 0 else None
+        return self._scratch[key]
+
+    def encode_backward_window(self, grad_out, snaps, H, first=True):
+        """Stage 1 of the encoder backward over a window of states in one launch: grad_out (T, E*N, >= H) float32 with unit inner
+        stride (the rows' first H floats), snaps (T, state_words) int32."""
+        self._require()
+        T = grad_out.shape[0]
+        if grad_out.dtype != torch.float32 or grad_out.dim() != 3 or grad_out.stride(2) != 1 or grad_out.shape[2] < H or \
+                grad_out.shape[1] != self.nenvs * self.nagents_env or snaps.shape[0] < T or snaps.dtype != torch.int32:
+            raise ValueError("encode_backward_window: grad_out float32 (T, E*N, >= H) with unit inner stride, snaps int32 (>= T, words)")
+        check(_lib.lib().ic3_env_encode_backward_window(self._h, ptr(snaps), snaps.stride(0), T, ptr(grad_out), grad_out.stride(1),
+                                                        grad_out.stride(0), H, ptr(self.encode_window_work(H)), int(bool(first)),
+                                                        stream()))
+
+    def encode_backward_window_finish(self, H, want_bias=True):
+        """(dWt (obs_dim, H), dbias (H,)) of what the window form accumulated."""
+        self._require()
+        dwt = torch.empty((self.obs_dim, H), dtype=torch.float32, device=self.device)
+        dbias = torch.empty((H,), dtype=torch.float32, device=self.device) if want_bias else None
+        check(_lib.lib().ic3_env_encode_backward_window_finish(self._h, H, ptr(dwt), ptr(dbias) if want_bias else None,
+                                                               ptr(self.encode_window_work(H)), stream()))
+        return dwt, dbias
+
     def set_auto_reset(self, max_steps):
         """max_steps > 0: an env whose episode ends (episode_over, or max_steps steps played) starts its next episode
         inside the same step launch (ic3_env_set_auto_reset); 0: lock-step episodes (finished envs freeze)."""

@@ -338,7 +338,7 @@ def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lst
     assert snaps.is_contiguous() and snaps.dtype == torch.int32 and snaps.shape[0] >= T
     for v in (dh, dc):
         assert v.is_contiguous() and tuple(v.shape) == (R, H) and v.dtype == torch.float32
-    assert dxh.is_contiguous() and tuple(dxh.shape) == (R, 2 * H)
+    assert dxh.is_contiguous() and tuple(dxh.shape) in ((R, 2 * H), (T, R, 2 * H))      # one buffer, or a ring of T (dxh_step)
     assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == ((R + 63) // 64, 4 * H)
     if not comm_zero:
         assert dcw_partials.is_contiguous() and tuple(dcw_partials.shape) == (comm_backward_partials(E, N), H, H)
@@ -369,7 +369,11 @@ def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lst
     b.dh, b.dc, b.dxh = dh.data_ptr(), dc.data_ptr(), dxh.data_ptr()
     b.dbias_partials = dbias_partials.data_ptr()
     b.dcw_partials = dcw_partials.data_ptr() if dcw_partials is not None else None
-    b.enc_work = env._encb_work(H).data_ptr()
+    if dxh.dim() == 3:                     # a ring of per-step input gradients: the encoder's first stage once, over the window
+        b.dxh_step = dxh.stride(0)
+        b.enc_work = env.encode_window_work(H).data_ptr()
+    else:
+        b.enc_work = env._encb_work(H).data_ptr()
     evs = None
     if gate_events is not None:
         from .envs import DispatchEvent

@@ -34,7 +34,7 @@ extern "C" {
  * boundary checks itself: ic3_version() returns the library's value, ic3_abi_check() compares the caller's version and
  * struct sizes with the library's, and both structs start with `struct_size` (= sizeof, set by the caller) — an entry
  * point handed a struct of another size refuses it with -EINVAL before reading any other field. */
-#define IC3_VERSION 600 /* 0.6.0 (round 6: ic3_comm_backward, ic3_lstm_weight_grad, ic3_bptt_backward; ic3_lstm_gates_backward_given takes the heads' share) */
+#define IC3_VERSION 601 /* 0.6.0 (round 6: ic3_comm_backward, ic3_lstm_weight_grad, ic3_bptt_backward; ic3_lstm_gates_backward_given takes the heads' share) */
 
 /* 0 when `version` == IC3_VERSION of the library and the two sizes are the library's sizeof(ic3_policy) /
  * sizeof(ic3_episode); -EINVAL (with a message naming the mismatch) otherwise.  A binding calls it once after loading. */
@@ -202,6 +202,20 @@ int ic3_env_encode_backward(ic3_env* env, const int32_t* snap, const float* grad
 int ic3_env_encode_backward_accumulate(ic3_env* env, const int32_t* snap, const float* grad_out, int ldg, int H, float* work,
                                        int first, ic3_stream stream);
 int ic3_env_encode_backward_finish(ic3_env* env, int H, float* dWt, float* dbias /* or NULL */, float* work, ic3_stream stream);
+
+/* The first stage over a WINDOW of T recorded states in ONE launch, on the matrix cores (enc_bwd.hpp, third form): the state of
+ * step t at snaps + t * snap_words, its grad_out rows at grad_out + t * step_stride + row * ldg floats (ic3_bptt.dxh_step keeps
+ * the per-step input gradients of a backward pass for this).  The position sums are one-hot x grad_out products — the one-hot
+ * entries made in registers, grad_out split exactly into three bf16 terms, fp32 accumulation — and the shared columns' weights a
+ * per-batch LDS table, split the same way.  `first` != 0 writes the partials in `work`
+ * (ic3_env_encode_backward_window_work(env, H) floats; 0 = this configuration has no window form: hid_size a multiple of 32, and
+ * of 128 above 128), otherwise adds to them; _window_finish expands them into dWt / dbias like _finish does for the per-step form
+ * (the two forms' partials have different shapes: finish with the one that accumulated).  Reproducible run to run (no atomics in
+ * stage 1; the expand stage's fp32 atomics as above). */
+int64_t ic3_env_encode_backward_window_work(const ic3_env* env, int H);
+int ic3_env_encode_backward_window(ic3_env* env, const int32_t* snaps, int64_t snap_words, int T, const float* grad_out, int ldg,
+                                   int64_t step_stride, int H, float* work, int first, ic3_stream stream);
+int ic3_env_encode_backward_window_finish(ic3_env* env, int H, float* dWt, float* dbias /* or NULL */, float* work, ic3_stream stream);
 
 /* Synchronising: returns -EINVAL if any step since the last check saw an out-of-range action. */
 int ic3_env_check(ic3_env* env, ic3_stream stream);
@@ -398,7 +412,7 @@ int ic3_lstm_weight_grad(const float* inp, int ldi, const float* h_prev, const f
  *   entries may be NULL) or NULL;  row_live / row_keep [T][R] or NULL (collection mode, as ic3_lstm_gates_backward_given; the
  *   communication backward of step t scales its output by row_keep[t - 1]);  detach_gap > 0: dh, dc are zeroed in front of every
  *   step t with (t + 1) % detach_gap == 0 (trainer.py:56-60, lock-step windows);  dh, dc [R][H] in: dL/d(h, c) arriving at the
- *   window's last step, out: leaving its first;  dxh [R][2H] scratch;  dbias_partials [ceil(R / 64)][4H] and dcw_partials
+ *   window's last step, out: leaving its first;  dxh [R][2H] scratch (or a ring of T of them: dxh_step);  dbias_partials [ceil(R / 64)][4H] and dcw_partials
  *   [ic3_comm_backward_partials][H][H] are ADDED to (zero them before the first window);  enc_work as
  *   ic3_env_encode_backward_accumulate, enc_first != 0: this window starts the accumulation;  gate_events: see the struct.
  * ic3_bptt_backward_supported(env, H): 1 when every step can run (hid_size 64 / 128, <= 64 agents, the encoder backward in its
@@ -426,6 +440,10 @@ typedef struct ic3_bptt {
     float* dbias_partials;
     float* dcw_partials;
     float* enc_work;
+    int64_t dxh_step;       /* 0: dxh is one [R][2H] buffer and every step runs ic3_env_encode_backward_accumulate on it;  > 0: dxh is
+                               a ring, step t's input gradients at dxh + t * dxh_step floats (>= R * 2H), and the encoder's first
+                               stage runs ONCE behind the loop over all T of them (ic3_env_encode_backward_window: enc_work of
+                               ic3_env_encode_backward_window_work floats, finish with ic3_env_encode_backward_window_finish) */
     void** gate_events;     /* measurement support: NULL, or 2 T events (ic3_event_create) — [2t] / [2t + 1] are recorded on the
                                stream in front of / behind step t's gate launch (read them with ic3_event_elapsed_ms) */
 } ic3_bptt;

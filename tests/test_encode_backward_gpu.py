@@ -90,6 +90,35 @@ def test_encode_backward_accumulated_over_states_equals_the_sum(kind, c):
     torch.testing.assert_close(db.double(), refb, atol=4e-6 * max(1.0, (3 * R) ** 0.5), rtol=0)
 
 
+@pytest.mark.parametrize("kind,c", CASES)
+def test_encode_backward_over_a_window_of_states_in_one_launch(kind, c):
+    """ic3_env_encode_backward_window / _window_finish: stage 1 over T recorded states in ONE launch on the matrix cores (one-hot x
+    gradient products, the gradient split exactly into three bf16 terms) = the sum of the per-state dense fp64 products; rows read
+    out of a (T, R, 2H) ring as ic3_bptt_backward leaves them; two windows (the second adds)."""
+    env, nact = build(kind, c, seed=3)
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    H, R, T = c['H'], env.nenvs * env.nagents_env, 4
+    assert env.encode_window_work(H) is not None
+    ref = None
+    refb = torch.zeros(H, dtype=torch.float64, device='cuda')
+    for win in range(2):
+        snaps = torch.empty((T, env.dims.state_words), dtype=torch.int32, device='cuda')
+        ring = torch.randn(T, R, 2 * H, device='cuda', generator=gen)
+        for t in range(T):
+            play(env, nact, 2 + t, gen)
+            snaps[t].copy_(env.snapshot())
+            obs = env.observe().reshape(R, -1).double()
+            r = obs.t() @ ring[t, :, :H].double()
+            ref = r if ref is None else ref + r
+            refb += ring[t, :, :H].double().sum(0)
+        play(env, nact, 1, gen)
+        env.encode_backward_window(ring, snaps, H, first=(win == 0))
+    dwt, db = env.encode_backward_window_finish(H)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((dwt.double() - ref).abs().max()) <= 4e-6 * scale
+    torch.testing.assert_close(db.double(), refb, atol=4e-6 * max(1.0, (2 * T * R) ** 0.5), rtol=0)
+
+
 def test_snapshot_is_the_state_of_the_forward():
     env, nact = build("pp", CASES[0][1])
     gen = torch.Generator(device='cuda').manual_seed(5)

@@ -207,6 +207,44 @@ def test_encoder_backward_accumulated_over_states(kind, cfg):
     env.close()
 
 
+@pytest.mark.parametrize("kind,cfg", ENC_CASES)
+def test_encoder_backward_over_a_window_of_states_in_one_launch(kind, cfg):
+    """ic3_env_encode_backward_window / _window_finish on the host: the first stage over T recorded states in ONE launch (position
+    sums as one-hot x gradient products, the shared columns' weights from a per-batch table) = the sum of the dense products
+    obs_t^T @ g_t; called twice (first = 1, then 0: a second window adds), on strided rows of a [T][R][2H] ring; the work buffer
+    starts as NaN."""
+    from host_abi_util import check, host_lib, p
+    env = _make(kind, cfg)
+    lib = host_lib()
+    H, T = 32, 3
+    rng = np.random.default_rng(9)
+    n = int(lib.ic3_env_encode_backward_window_work(env._h, H))
+    assert n > 0
+    assert int(lib.ic3_env_encode_backward_window_work(env._h, 24)) == 0       # hid_size must be a multiple of 32
+    work = np.full((n,), np.nan, np.float32)
+    R = env.E * env.N
+    want, wantb = 0.0, 0.0
+    for win in range(2):
+        snaps, ring = [], rng.standard_normal((T, R, 2 * H)).astype(np.float32)
+        for k in range(T):
+            _play(env, 2 + k, 30 + 7 * win + k)
+            snaps.append(env.snapshot())
+            obs = env.observe().reshape(-1, env.obs_dim).astype(np.float64)
+            g = ring[k, :, :H]
+            want = want + obs.T @ g.astype(np.float64)
+            wantb = wantb + g.astype(np.float64).sum(0)
+        snaps = np.ascontiguousarray(np.stack(snaps))
+        env.step(np.zeros((env.E, env.N), np.int32), with_obs=False)        # the live state moves on: the snapshots count
+        check(lib.ic3_env_encode_backward_window(env._h, p(snaps), snaps.shape[1], T, p(ring), 2 * H, R * 2 * H, H, p(work),
+                                                 int(win == 0), None))
+    dwt = np.full((env.obs_dim, H), np.nan, np.float32)
+    db = np.full((H,), np.nan, np.float32)
+    check(lib.ic3_env_encode_backward_window_finish(env._h, H, p(dwt), p(db), p(work), None))
+    np.testing.assert_allclose(dwt, want, rtol=0, atol=4e-5)
+    np.testing.assert_allclose(db, wantb, rtol=0, atol=4e-5)
+    env.close()
+
+
 @pytest.mark.parametrize("T,E,N,gamma,ratio", [(9, 7, 3, 1.0, 0.0), (12, 30, 10, 0.9, 0.5), (5, 3, 64, 1.0, 1.0)])
 def test_returns_scan_on_the_host(T, E, N, gamma, ratio):
     """ic3_returns_scan == the loop of /root/reference/trainer.py:162-171 (float64)."""
