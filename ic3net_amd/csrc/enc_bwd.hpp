@@ -242,15 +242,16 @@ __device__ __forceinline__ void enc_bwd_rows(const float* __restrict__ g, int ld
 //   out[m][h] = sum over the Q = T * R rows q of  A[m][q] * g[q][h],     m < npos:  A = [pos(q) == m]   (a one-hot column)
 //                                                                         m = npos + slot:  A = the slot's weight in row q
 //                                                                         m = npos + nslots:  A = 1      (the bias)
-// is a product with K = Q.  The one-hot entries are exact in bf16 and are MADE in registers from the rows' positions (packed
-// 16-bit arithmetic, 3 instructions per pair of rows: no table of A anywhere); g is split exactly into three bf16 terms
+// is a product with K = Q.  The one-hot entries are exact in bf16; g is split exactly into three bf16 terms
 // (ps_split_frag), so a 32-position block costs 3 v_mfma_f32_32x32x16_bf16 per 16 rows; the slot weights (counts at PP, arbitrary
 // header scalars at TJ) sit in an LDS table [slot][row of the batch] that the workgroup fills per batch of ENCW_RB rows — the
 // row itself, then every (row, other entity) pair that falls into the row's window, the entities' positions staged in LDS — and
 // are split the same way: 9 products for their block (3 where the weights are small counts: Spec::slots_exact_bf16).  The one-hot
-// fragments are the same for every wave of the workgroup (the waves differ in their columns of g): per batch each is made once
-// and parked in LDS (8 KB per position block), the product loop reads it back with one ds_read_b128 (with the 12 vector
-// instructions per fragment inside the loop, 156 per K step at 13 blocks, the loop was issue-bound at 2.6 x its matrix time).  A wave owns 32 columns of g (its B fragment: 8 rows x 1 column per lane,
+// fragments are the same for every wave of the workgroup (the waves differ in their columns of g) and all but empty: they live
+// in LDS (8 KB per position block), a row's owner sets its one entry and clears it behind the products, the product loop reads a
+// fragment with one ds_read_b128.  (Made in registers inside the loop — 3 packed 16-bit instructions per pair of rows, 156 per
+// K step at 13 blocks — the loop was issue-bound at 2.6 x its matrix time; made per batch by compares, the batch preparation
+// took as long as the batch's products.)  A wave owns 32 columns of g (its B fragment: 8 rows x 1 column per lane,
 // straight from global memory, one K step ahead) and MBP position blocks + 1 slot block of `out` in registers for the WHOLE row
 // range of its workgroup (gridDim.z slices the blocks: slice z holds position blocks [z MBP, (z + 1) MBP) and slot block z); the
 // partials are written once per launch in the layout of the second form (Ppart[row group][pos][H], Dpart[row group][slot][H])
@@ -285,7 +286,7 @@ inline EncWinPlan enc_win_plan(long long R, int rows_env, int total, int H, int 
     if (H % p.ncs || (H / p.ncs) % 32) return p;
     p.nw = H / p.ncs / 32;
     p.nstage = (ENCW_RB / rows_env + 2) * total;
-    p.lds = ENCW_RB * 2 + 32 * ENCW_LDW * 4 + (ENCW_RB / 16) * mbp * 64 * 16 + p.nstage * 4;
+    p.lds = 32 * ENCW_LDW * 4 + (ENCW_RB / 16) * mbp * 64 * 16 + p.nstage * 4;
     if (p.lds > 150 * 1024 || p.nstage > 4 * 64 * p.nw) return p;
     const int wg_per_cu = (mbp == 13 ? 1 : (mbp == 7 ? 2 : 4)) * (4 / p.nw > 0 ? 4 / p.nw : 1);
     long long nrg = (long long)cus * wg_per_cu / ((long long)p.ncs * p.nsl);
@@ -307,14 +308,13 @@ struct EncWinArgs {
     float* Dpart;
 };
 
-typedef unsigned short encw_u16x2 __attribute__((ext_vector_type(2)));
-// the two 16-bit positions of `pk` against position m (both halves of mm): 0x3F80 (bf16 1.0) where equal, 0 elsewhere
-__device__ __forceinline__ unsigned encw_onehot_pair(unsigned pk, unsigned mm)
+// x / d for x < 2^31 through m = floor((2^32 - 1) / d): the estimate is the quotient or one below it
+__host__ __device__ inline unsigned encw_magic(int d) { return (unsigned)(0xffffffffull / (unsigned)d); }
+__device__ __forceinline__ int encw_div(int x, int d, unsigned m)
 {
-    const encw_u16x2 d = __builtin_bit_cast(encw_u16x2, pk) - __builtin_bit_cast(encw_u16x2, mm);
-    const encw_u16x2 z = __builtin_elementwise_min(d, encw_u16x2{ 1, 1 });              // 0 where equal, 1 elsewhere
-    const encw_u16x2 r = z * encw_u16x2{ 0xC080, 0xC080 } + encw_u16x2{ 0x3F80, 0x3F80 };   // 0x3F80 - 0x3F80 z (mod 2^16)
-    return __builtin_bit_cast(unsigned, r);
+    int qd = (int)__umulhi((unsigned)x, m);
+    if (x - qd * d >= d) ++qd;
+    return qd;
 }
 
 template <int MBP, class Spec>
@@ -323,8 +323,7 @@ __device__ __forceinline__ void enc_bwd_window(const EncWinArgs& a, const Spec& 
     typedef __bf16 encw_bf16x8 __attribute__((ext_vector_type(8)));
     constexpr int NKS = ENCW_RB / 16;
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, w = tid >> 6, nw = NT >> 6, li = lane & 31, lh = lane >> 5;
-    unsigned short* posw = reinterpret_cast<unsigned short*>(sm);                      // [ENCW_RB]
-    float* Wt = reinterpret_cast<float*>(sm + ENCW_RB * 2);                            // [32][ENCW_LDW]: this slice's slot block
+    float* Wt = reinterpret_cast<float*>(sm);                                          // [32][ENCW_LDW]: this slice's slot block
     ps_u32x4* afr = reinterpret_cast<ps_u32x4*>(Wt + 32 * ENCW_LDW);                   // [NKS][MBP][64] one-hot A fragments
     unsigned* ent = reinterpret_cast<unsigned*>(afr + NKS * MBP * 64);                 // [nstage] entity words of the batch's envs
     const int gb0 = blockIdx.z * MBP;                                                  // first position block of this M slice
@@ -334,6 +333,7 @@ __device__ __forceinline__ void enc_bwd_window(const EncWinArgs& a, const Spec& 
     const int Q = a.T * a.R;
     const int qb = (int)min((long long)blockIdx.x * a.bat_per_wg * ENCW_RB, (long long)Q);
     const int qe = (int)min((long long)qb + (long long)a.bat_per_wg * ENCW_RB, (long long)Q);
+    const unsigned m_rows = encw_magic(sp.rows_env), m_E = encw_magic(a.E);
     ps_f32x16 accp[MBP], accs;
 #pragma unroll
     for (int i = 0; i < 16; ++i) accs[i] = 0.f;
@@ -372,23 +372,38 @@ __device__ __forceinline__ void enc_bwd_window(const EncWinArgs& a, const Spec& 
     // the entity words of a batch's envs (flat env fe = q / rows_env = t E + e), one batch ahead in registers
     unsigned ew[4];                                                // (nstage <= 4 * NT: enc_win_plan)
     auto stage_fetch = [&](int q0) {
+        const int fe0 = encw_div(q0, sp.rows_env, m_rows);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = tid + k * NT;
             unsigned v = 0u;
             if (idx < a.nstage && q0 < qe) {
-                const int fe = q0 / sp.rows_env + idx / sp.total, i = idx % sp.total;
-                const int t = fe / a.E, e = fe - t * a.E;
+                const int de = idx / sp.total, i = idx - de * sp.total, fe = fe0 + de;
+                const int t = encw_div(fe, a.E, m_E), e = fe - t * a.E;
                 if (t < a.T) v = sp.word(a.snaps + (size_t)t * a.snap_words, e, i);
             }
             ew[k] = v;
         }
     };
-    float gv[8];
-    fetch(gv);
+    float g0[8], g1[8], g2[8], g3[8];                              // the next FOUR K steps' rows: 8 KB per wave in flight
+    fetch(g0);
+    fetch(g1);
+    fetch(g2);
+    fetch(g3);
     stage_fetch(qb);
+    // The one-hot fragments: LDS holds the batch's NKS x MBP of them, all zero but for ONE bf16 1.0 per row (at block pos / 32,
+    // lane pos % 32 + 32 (k / 8), element k % 8 of the row's K step) — the thread that owns a row sets it and clears it again
+    // behind the products, so the table is zeroed once per launch and a batch costs two 2-byte stores per row.
+    for (int i = tid; i < NKS * MBP * 64; i += NT) afr[i] = ps_u32x4{ 0u, 0u, 0u, 0u };
+    int mark[ENCW_RB / 64];                                        // byte offset of this thread's mark per row it owns, or -1
+#pragma unroll
+    for (int k = 0; k < ENCW_RB / 64; ++k) mark[k] = -1;
+    unsigned short* const afh = reinterpret_cast<unsigned short*>(afr);
     for (int q0 = qb; q0 < qe; q0 += ENCW_RB) {
         __syncthreads();                                          // the previous batch's readers
+#pragma unroll
+        for (int k = 0; k < ENCW_RB / 64; ++k)
+            if (mark[k] >= 0) afh[mark[k]] = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (tid + k * NT < a.nstage) ent[tid + k * NT] = ew[k];
@@ -396,61 +411,55 @@ __device__ __forceinline__ void enc_bwd_window(const EncWinArgs& a, const Spec& 
             for (int i = tid; i < 32 * (ENCW_LDW / 4); i += NT) reinterpret_cast<ps_f32x4*>(Wt)[i] = ps_f32x4{ 0.f, 0.f, 0.f, 0.f };
         __syncthreads();
         stage_fetch(q0 + ENCW_RB);                                // the next batch's words: in flight under this batch's products
-        const int fe0 = q0 / sp.rows_env;
-        for (int lr = tid; lr < ENCW_RB; lr += NT) {
-            const int q = q0 + lr;
-            unsigned short pw = 0xffff;
-            if (q < qe) {
-                const int fe = q / sp.rows_env, ag = q - fe * sp.rows_env, t = fe / a.E, r = q - t * a.R;
-                const int32_t* st = a.snaps + (size_t)t * a.snap_words;
-                const unsigned wa = ent[(fe - fe0) * sp.total + ag];
-                const bool lv = sp.live(st, (size_t)r);
-                if (lv) pw = (unsigned short)sp.pos(wa);
-                if (has_slots) {
-                    if ((unsigned)(a.nslots - s0) < 32u) Wt[(a.nslots - s0) * ENCW_LDW + lr] = 1.0f;   // the bias row: every row
-                    if (lv)
-                        sp.self(st, (size_t)r, ag, wa, [&](int slot, float wgt) {
-                            if ((unsigned)(slot - s0) < 32u) atomicAdd(&Wt[(slot - s0) * ENCW_LDW + lr], wgt);
-                        });
-                }
-            }
-            posw[lr] = pw;
-        }
-        __syncthreads();
-        if (has_pos)                                              // the batch's one-hot fragments, each made ONCE per workgroup
-            for (int ks = w; ks < NKS; ks += nw) {
-                const ps_u32x4 pk = *reinterpret_cast<const ps_u32x4*>(posw + ks * 16 + lh * 8);
+        const int fe0 = encw_div(q0, sp.rows_env, m_rows);
 #pragma unroll
-                for (int b = 0; b < MBP; ++b) {
-                    const unsigned m = (unsigned)((gb0 + b) * 32 + li), mm = m | (m << 16);
-                    afr[(ks * MBP + b) * 64 + lane] = ps_u32x4{ encw_onehot_pair(pk[0], mm), encw_onehot_pair(pk[1], mm),
-                                                                encw_onehot_pair(pk[2], mm), encw_onehot_pair(pk[3], mm) };
+        for (int k = 0; k < ENCW_RB / 64; ++k) {                  // rows lr = tid + k NT (NT >= 64)
+            const int lr = tid + k * NT, q = q0 + lr;
+            mark[k] = -1;
+            if (lr >= ENCW_RB || q >= qe) continue;
+            const int fe = encw_div(q, sp.rows_env, m_rows), ag = q - fe * sp.rows_env, t = encw_div(fe, a.E, m_E), r = q - t * a.R;
+            const int32_t* st = a.snaps + (size_t)t * a.snap_words;
+            const unsigned wa = ent[(fe - fe0) * sp.total + ag];
+            const bool lv = sp.live(st, (size_t)r);
+            if (lv && has_pos) {
+                const int pos = sp.pos(wa), gb = (pos >> 5) - gb0;
+                if ((unsigned)gb < (unsigned)MBP) {
+                    mark[k] = ((((lr >> 4) * MBP + gb) * 64 + (pos & 31) + 32 * ((lr >> 3) & 1)) * 8 + (lr & 7));
+                    afh[mark[k]] = 0x3F80;
                 }
             }
-        if (has_slots) {
-            const int npairs = ENCW_RB * sp.total;
-            for (int idx = tid; idx < npairs; idx += NT) {
-                const int lr = idx / sp.total, p = idx - lr * sp.total;
-                const int q = q0 + lr;
+            if (has_slots) {
+                if ((unsigned)(a.nslots - s0) < 32u) Wt[(a.nslots - s0) * ENCW_LDW + lr] = 1.0f;       // the bias row: every row
+                if (lv)
+                    sp.self(st, (size_t)r, ag, wa, [&](int slot, float wgt) {
+                        if ((unsigned)(slot - s0) < 32u) atomicAdd(&Wt[(slot - s0) * ENCW_LDW + lr], wgt);
+                    });
+            }
+        }
+        if (has_slots) {                                          // the other entities: row lr = it % RB against p = it / RB, + PG, ...
+            const int PG = NT >= ENCW_RB ? NT / ENCW_RB : 1;
+            for (int it = tid; it < ENCW_RB * PG; it += NT) {
+                const int lr = it & (ENCW_RB - 1), pg = it / ENCW_RB, q = q0 + lr;
                 if (q >= qe) continue;
-                const int fe = q / sp.rows_env, ag = q - fe * sp.rows_env;
-                if (p == ag) continue;
+                const int fe = encw_div(q, sp.rows_env, m_rows), ag = q - fe * sp.rows_env;
                 if (!sp.live_always) {
-                    const int t = fe / a.E;
+                    const int t = encw_div(fe, a.E, m_E);
                     if (!sp.live(a.snaps + (size_t)t * a.snap_words, (size_t)(q - t * a.R))) continue;
                 }
                 const unsigned* ee = ent + (fe - fe0) * sp.total;
-                const int slot = sp.pair(ee[ag], ee[p], ag, p);
-                if ((unsigned)(slot - s0) < 32u) atomicAdd(&Wt[(slot - s0) * ENCW_LDW + lr], 1.0f);
+                const unsigned wa = ee[ag];
+                for (int p = pg; p < sp.total; p += PG) {
+                    const int slot = sp.pair(wa, ee[p], ag, p);
+                    if (p != ag && (unsigned)(slot - s0) < 32u) atomicAdd(&Wt[(slot - s0) * ENCW_LDW + lr], 1.0f);
+                }
             }
         }
         __syncthreads();
         const int nks = (min(qe - q0, ENCW_RB) + 15) / 16;
-#pragma unroll 1
-        for (int ks = 0; ks < nks; ++ks) {
+        auto kstep = [&](float (&gv_)[8], int ks) {
             ps_u32x4 bf[3];
-            ps_split_frag(ps_f32x4{ gv[0], gv[1], gv[2], gv[3] }, ps_f32x4{ gv[4], gv[5], gv[6], gv[7] }, bf);
-            fetch(gv);                                            // the next K step's rows (past the range: zeros)
+            ps_split_frag(ps_f32x4{ gv_[0], gv_[1], gv_[2], gv_[3] }, ps_f32x4{ gv_[4], gv_[5], gv_[6], gv_[7] }, bf);
+            fetch(gv_);                                           // the rows of the K step four ahead (past the range: zeros)
             if (has_pos) {
                 ps_u32x4 af[MBP];
 #pragma unroll
@@ -483,6 +492,13 @@ __device__ __forceinline__ void enc_bwd_window(const EncWinArgs& a, const Spec& 
                                                                            __builtin_bit_cast(encw_bf16x8, bf[pb]), accs, 0, 0, 0);
                 }
             }
+        };
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ks += 4) {
+            kstep(g0, ks);
+            if (ks + 1 < nks) kstep(g1, ks + 1);
+            if (ks + 2 < nks) kstep(g2, ks + 2);
+            if (ks + 3 < nks) kstep(g3, ks + 3);
         }
     }
     // block b, register reg, lane (li, lh): output row m = 32 block + (reg & 3) + 8 (reg >> 2) + 4 lh, column `col`
