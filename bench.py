@@ -293,8 +293,19 @@ def train_mode(o, trainer, a, raw_env, rank, world, use_dist, backend, red_dev, 
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.enable()
+    gate_ms_chain = [s_.elapsed_time(e_) for s_, e_, _t in raw_env.gate_timer]
+    # In the timed updates the backward's launches run as TWO concurrent chains of envs (ic3_bptt.two_chains): the events there
+    # bracket the first chain's gate launch while the second chain's kernels share the GPU.  The kernel ALONE: two more updates
+    # behind the timed region with the backward as one chain, every gate launch of them event-timed.
+    two = bool(getattr(a, 'bptt_two_chains', True))
+    a.bptt_two_chains = False
+    raw_env.gate_timer = []
+    for u in range(2):
+        trainer.train_batch(o.warmup + o.steps + u)
+    torch.cuda.synchronize()
     gate_ms = [s_.elapsed_time(e_) for s_, e_, _t in raw_env.gate_timer]
     raw_env.gate_timer = None
+    a.bptt_two_chains = two
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -315,7 +326,17 @@ def train_mode(o, trainer, a, raw_env, rank, world, use_dist, backend, red_dev, 
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "traffic": None, "bytes_per_launch": nbytes, "avg_launch_ms": round(avg, 4), "launches": len(gate_ms),
                     "launch_ms_min": round(min(gate_ms), 4), "launch_ms_max": round(max(gate_ms), 4),
-                    "timed": "HIP events recorded on the launch stream around every gate launch of the timed updates"}
+                    "timed": "HIP events recorded on the launch stream around every gate launch of two updates behind the timed "
+                             "region, the backward as ONE chain of launches (the kernel alone on the GPU)"}
+        if two and gate_ms_chain:
+            from ic3net_amd import ops as _ops
+            E1 = _ops.first_chain_envs(E, N)
+            if E1 < E:
+                avg1 = sum(gate_ms_chain) / len(gate_ms_chain)
+                roofline["in_the_timed_updates"] = {
+                    "what": "the first chain's gate launch (envs [0, %d)) while the second chain's launches share the GPU" % E1,
+                    "bytes_per_launch": nbytes * E1 // E, "avg_launch_ms": round(avg1, 4), "launches": len(gate_ms_chain),
+                    "GBps": round(nbytes * E1 / E / (avg1 * 1e-3) / 1e9, 1)}
         flops = 2.0 * R * 4 * H * 2 * H
         mf = {"kernel": "lstm_gates_bwd_kernel (its input-gradient product)", "bound": "mfma",
               "achieved": round(flops / (avg * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -334,8 +355,9 @@ def train_mode(o, trainer, a, raw_env, rank, world, use_dist, backend, red_dev, 
                    "envs_per_gpu": E, "agents": N, "env_steps_per_update": int(steps / o.steps) if o.steps else 0,
                    "parallelism": "env-shard x%d, gradient all-reduce at update time" % world,
                    "update": ("no-grad one-launch rollout recording (h, c), gates, inp; explicit backward through time: "
-                              "ic3_bptt_backward (3 hand-written launches per step, one host call per window) + "
-                              "ic3_lstm_weight_grad per window — no library GEMM" if native else "autograd"),
+                              "ic3_bptt_backward (2 hand-written launches per step and chain of envs, two chains on two streams, "
+                              "one host call per window) + ic3_env_encode_backward_window + ic3_lstm_weight_grad per window — "
+                              "no library GEMM" if native else "autograd"),
                    "auto_reset": bool(o.auto_reset)},
         "roofline": roofline, "roofline_mfma": mf, "cpu_baseline": cpu,
         "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "collectives": backend,

@@ -76,7 +76,7 @@ class Bptt(C.Structure):
                 ("row_live", C.c_void_p), ("row_keep", C.c_void_p), ("lstm_wp3_bwd", C.c_void_p), ("w_heads", C.c_void_p),
                 ("c_weight", C.c_void_p), ("dh", C.c_void_p), ("dc", C.c_void_p), ("dxh", C.c_void_p),
                 ("dbias_partials", C.c_void_p), ("dcw_partials", C.c_void_p), ("enc_work", C.c_void_p),
-                ("dxh_step", C.c_int64), ("gate_events", C.POINTER(C.c_void_p))]
+                ("dxh_step", C.c_int64), ("two_chains", C.c_int32), ("gate_events", C.POINTER(C.c_void_p))]
 
 
 EXPORTS = {
@@ -135,6 +135,7 @@ EXPORTS = {
     "ic3_lstm_weight_grad_scratch_floats": (C.c_size_t, [C.c_longlong, C.c_int]),
     "ic3_lstm_weight_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ic3_bptt_first_chain_envs": (C.c_int, [C.c_int, C.c_int]),
     "ic3_bptt_backward_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_bptt_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_env_set_record_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -433,7 +433,9 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
         _ring_fits(dev, T * R * 2 * H * 4)
     dxh = torch.empty((T, R, 2 * H) if ring else (R, 2 * H), dtype=torch.float32, device=dev)
     bias_parts = zeros((R + 63) // 64, 4 * H)
-    dcw_parts = None if mask_zero else zeros(ops.comm_backward_partials(E, N), H, H)
+    # two chains of launches (envs [0, E1) and [E1, E) on two streams): one fills the ragged last round of the other's launches
+    two = ring and bool(getattr(args, 'bptt_two_chains', True)) and ops.first_chain_envs(E, N) < E
+    dcw_parts = None if mask_zero else zeros(ops.bptt_dcw_partials(E, N, two), H, H)
     alive, gate = list(rec.alive[:T]), list(rec.gate[:T])
     live_flat = keep_flat = None
     stream = rec.stream
@@ -461,7 +463,8 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
     ops.bptt_backward(raw, T, E, N, H, rec.gates, rec.hs, rec.cs, dhead, rec.snaps, alive, gate, fc['ps_l_wp3_bwd'], fc['w_heads'],
                       None if mask_zero else net.C_modules[0].weight.detach(), dh_rec, dc_rec, dxh, bias_parts, dcw_parts,
                       mode_avg=mode_avg, comm_zero=mask_zero, detach_gap=gap, row_live=live_flat, row_keep=keep_flat, enc_first=True,
-                      gate_events=getattr(raw, 'gate_timer', None))     # (bench.py --mode train: HIP events around the gate launches)
+                      gate_events=getattr(raw, 'gate_timer', None),     # (bench.py --mode train: HIP events around the gate launches)
+                      two_chains=two)
     work = acc.setdefault('_work', {})
     ops.lstm_weight_grad(rec.xh[:T], rec.hs[:T], rec.gates[:T], acc['w_cat_t'], row_live=live_flat, accumulate=True, work=work,
                          split=bool(getattr(args, 'gate_split', True)))

@@ -632,6 +632,36 @@ extern "C" int ic3_bptt_backward_supported(const ic3_env* env, int H)
     return pl.csplit ? 1 : 0;     // (the sparse encoder's backward in its partial-sums form: ic3_env_encode_backward_accumulate)
 }
 
+namespace ic3 {
+// the second chain's stream + the fork / join events, per device
+struct BpttSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static BpttSide* bptt_side()
+{
+    static BpttSide side[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    BpttSide& sd = side[dev];
+    if (!sd.stream) {
+        if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    return &sd;
+}
+}  // namespace ic3
+
+// envs [0, E1) run on the caller's stream, [E1, E) on the library's second stream (ic3_bptt.two_chains): E1 * N a multiple of 64,
+// so that the gate launch's row tiles — and with them its bias partials — do not straddle the border
+extern "C" int ic3_bptt_first_chain_envs(int E, int N)
+{
+    if (E < 128 || N <= 0) return E;
+    return (E / 2) & ~63;
+}
+
 extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream stream)
 {
     using namespace ic3;
@@ -652,32 +682,58 @@ extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream str
         return fail(-22, "ic3_bptt_backward: dxh_step >= E * N * 2 * hid_size, on a configuration with ic3_env_encode_backward_window");
     const long long R = (long long)E * N;
     hipStream_t s = (hipStream_t)stream;
+    // Two chains: the steps of envs [0, E1) and [E1, E) are independent until the weight gradients are summed, so with
+    // two_chains their launches go to two streams and the GPU fills the ragged last round of one chain's launch (1280 row tiles
+    // on 512 workgroup slots = 2.5 rounds at PP-hard E = 8192) with the other chain's workgroups.  Needs what ties the chains
+    // together to be per step or behind the loop: the ring of input gradients (the encoder's stage 1 behind the loop).
+    const int E1 = (b->two_chains && b->dxh_step) ? ic3_bptt_first_chain_envs(E, N) : E;
+    const int nch = E1 < E ? 2 : 1;
+    BpttSide* side = nch == 2 ? bptt_side() : nullptr;
+    if (nch == 2 && !side) return fail(-12, "ic3_bptt_backward: no second stream");
+    if (nch == 2) {
+        IC3_HIP(hipEventRecord(side->fork, s));
+        IC3_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+    }
     int enc_first = b->enc_first;
     for (int t = T - 1; t >= 0; --t) {
-        if (b->detach_gap > 0 && (t + 1) % b->detach_gap == 0) {      // trainer.py:56-60: (h_t, c_t) were handed on detached
-            IC3_HIP(hipMemsetAsync(b->dh, 0, (size_t)R * H * sizeof(float), s));
-            IC3_HIP(hipMemsetAsync(b->dc, 0, (size_t)R * H * sizeof(float), s));
+        for (int ch = 0; ch < nch; ++ch) {
+            const int e0 = ch ? E1 : 0, Ec = ch ? E - E1 : E1;
+            const size_t r0 = (size_t)e0 * N, Rc = (size_t)Ec * N;
+            hipStream_t sc = ch ? side->stream : s;
+            ic3_stream scv = (ic3_stream)sc;
+            float* dh = b->dh + r0 * H;
+            float* dc = b->dc + r0 * H;
+            if (b->detach_gap > 0 && (t + 1) % b->detach_gap == 0) {  // trainer.py:56-60: (h_t, c_t) were handed on detached
+                IC3_HIP(hipMemsetAsync(dh, 0, Rc * H * sizeof(float), sc));
+                IC3_HIP(hipMemsetAsync(dc, 0, Rc * H * sizeof(float), sc));
+            }
+            float* g = b->gates + ((size_t)t * R + r0) * 4 * H;
+            float* dxh = b->dxh + (size_t)t * (size_t)b->dxh_step + r0 * 2 * H;
+            if (b->gate_events && ch == 0) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t], sc));
+            int rc = ic3_lstm_gates_backward_given(g, nullptr, 0, nullptr, b->lstm_wp3_bwd, b->cs + ((size_t)t * R + r0) * H, dh, dc, g,
+                                                   dc, b->dbias_partials + (r0 / 64) * 4 * H, 1, dxh,
+                                                   b->row_live ? b->row_live + (size_t)t * R + r0 : nullptr,
+                                                   b->row_keep ? b->row_keep + (size_t)t * R + r0 : nullptr,
+                                                   b->dhead + ((size_t)t * R + r0) * b->OT, b->w_heads, b->OT, (int)Rc, H, scv);
+            if (rc < 0) return rc;
+            if (b->gate_events && ch == 0) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t + 1], sc));
+            const float* out_scale = (b->row_keep && t > 0) ? b->row_keep + (size_t)(t - 1) * R + r0 : nullptr;
+            float* dcw = b->dcw_partials;
+            if (dcw && ch) dcw += (size_t)ic3_comm_backward_partials(E1, N) * H * H;
+            rc = ic3_comm_backward(dxh, 2 * H, b->hs + ((size_t)t * R + r0) * H, (b->alive && b->alive[t]) ? b->alive[t] + r0 : nullptr,
+                                   (b->gate && b->gate[t]) ? b->gate[t] + r0 : nullptr, b->c_weight, out_scale, dh, dcw, 1, Ec, N, H,
+                                   b->mode_avg, b->comm_zero, scv);
+            if (rc < 0) return rc;
         }
-        float* g = b->gates + (size_t)t * R * 4 * H;
-        float* dxh = b->dxh + (size_t)t * (size_t)b->dxh_step;
-        if (b->gate_events) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t], s));
-        int rc = ic3_lstm_gates_backward_given(g, nullptr, 0, nullptr, b->lstm_wp3_bwd, b->cs + (size_t)t * R * H, b->dh, b->dc, g,
-                                               b->dc, b->dbias_partials, 1, dxh,
-                                               b->row_live ? b->row_live + (size_t)t * R : nullptr,
-                                               b->row_keep ? b->row_keep + (size_t)t * R : nullptr,
-                                               b->dhead + (size_t)t * R * b->OT, b->w_heads, b->OT, (int)R, H, stream);
-        if (rc < 0) return rc;
-        if (b->gate_events) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t + 1], s));
-        const float* out_scale = (b->row_keep && t > 0) ? b->row_keep + (size_t)(t - 1) * R : nullptr;
-        rc = ic3_comm_backward(dxh, 2 * H, b->hs + (size_t)t * R * H, b->alive ? b->alive[t] : nullptr,
-                               b->gate ? b->gate[t] : nullptr, b->c_weight, out_scale, b->dh, b->dcw_partials, 1, E, N, H,
-                               b->mode_avg, b->comm_zero, stream);
-        if (rc < 0) return rc;
         if (b->dxh_step) continue;                               // (the encoder's first stage: once, behind the loop)
-        rc = ic3_env_encode_backward_accumulate(env, b->snaps + (size_t)t * b->snap_words, dxh, 2 * H, H, b->enc_work, enc_first,
-                                                stream);
+        int rc = ic3_env_encode_backward_accumulate(env, b->snaps + (size_t)t * b->snap_words, b->dxh, 2 * H, H, b->enc_work,
+                                                    enc_first, stream);
         if (rc < 0) return rc;
         enc_first = 0;
+    }
+    if (nch == 2) {
+        IC3_HIP(hipEventRecord(side->join, side->stream));
+        IC3_HIP(hipStreamWaitEvent(s, side->join, 0));
     }
     if (b->dxh_step)
         return ic3_env_encode_backward_window(env, b->snaps, b->snap_words, T, b->dxh, 2 * H, b->dxh_step, H, b->enc_work, enc_first,

@@ -317,13 +317,24 @@ def lstm_weight_grad(inp, h_prev, dgates, dW, row_live=None, accumulate=True, wo
                                           int(bool(accumulate)), int(bool(split)), ptr(work[key]), stream()))
 
 
+def first_chain_envs(E, N):
+    """ic3_bptt_first_chain_envs: with ic3_bptt.two_chains, envs [0, E1) run on the caller's stream and [E1, E) on a second one."""
+    return int(_lib.lib().ic3_bptt_first_chain_envs(int(E), int(N)))
+
+
+def bptt_dcw_partials(E, N, two_chains):
+    """Slots of ic3_bptt.dcw_partials."""
+    E1 = first_chain_envs(E, N) if two_chains else E
+    return comm_backward_partials(E1, N) + (comm_backward_partials(E - E1, N) if E1 < E else 0)
+
+
 def bptt_backward_supported(env, H):
     return bool(_lib.lib().ic3_bptt_backward_supported(env._h, int(H)))
 
 
 def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lstm_wp3_bwd, w_heads, c_weight, dh, dc, dxh,
                   dbias_partials, dcw_partials, mode_avg=True, comm_zero=False, detach_gap=0, row_live=None, row_keep=None,
-                  enc_first=True, gate_events=None):
+                  enc_first=True, gate_events=None, two_chains=False):
     """ic3_bptt_backward: the backward through a window of T recorded steps as one host call (gate launch in place on the
     record, communication backward, encoder backward stage 1 — three launches per step).  alive / gate: lists of T tensors
     (E, N) int32 or None entries, or None.  gate_events: a list that receives (start, stop, t) DispatchEvent triples stamped
@@ -340,8 +351,9 @@ def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lst
         assert v.is_contiguous() and tuple(v.shape) == (R, H) and v.dtype == torch.float32
     assert dxh.is_contiguous() and tuple(dxh.shape) in ((R, 2 * H), (T, R, 2 * H))      # one buffer, or a ring of T (dxh_step)
     assert dbias_partials.is_contiguous() and tuple(dbias_partials.shape) == ((R + 63) // 64, 4 * H)
+    two_chains = bool(two_chains) and dxh.dim() == 3 and first_chain_envs(E, N) < E
     if not comm_zero:
-        assert dcw_partials.is_contiguous() and tuple(dcw_partials.shape) == (comm_backward_partials(E, N), H, H)
+        assert dcw_partials.is_contiguous() and tuple(dcw_partials.shape) == (bptt_dcw_partials(E, N, two_chains), H, H)
         assert c_weight.is_contiguous() and tuple(c_weight.shape) == (H, H)
     for v in (row_live, row_keep):
         assert v is None or (v.is_contiguous() and v.dtype == torch.float32 and tuple(v.shape) == (T, R))
@@ -369,6 +381,7 @@ def bptt_backward(env, T, E, N, H, gates, hs, cs, dhead, snaps, alive, gate, lst
     b.dh, b.dc, b.dxh = dh.data_ptr(), dc.data_ptr(), dxh.data_ptr()
     b.dbias_partials = dbias_partials.data_ptr()
     b.dcw_partials = dcw_partials.data_ptr() if dcw_partials is not None else None
+    b.two_chains = int(two_chains)
     if dxh.dim() == 3:                     # a ring of per-step input gradients: the encoder's first stage once, over the window
         b.dxh_step = dxh.stride(0)
         b.enc_work = env.encode_window_work(H).data_ptr()

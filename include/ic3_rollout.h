@@ -444,10 +444,15 @@ typedef struct ic3_bptt {
                                a ring, step t's input gradients at dxh + t * dxh_step floats (>= R * 2H), and the encoder's first
                                stage runs ONCE behind the loop over all T of them (ic3_env_encode_backward_window: enc_work of
                                ic3_env_encode_backward_window_work floats, finish with ic3_env_encode_backward_window_finish) */
+    int32_t two_chains;     /* != 0 (with dxh_step): the steps of envs [0, E1) and [E1, E), E1 = ic3_bptt_first_chain_envs(E, N), are
+                               launched on two streams — the caller's and one the library owns, forked / joined with events — so that
+                               one chain's workgroups fill the ragged last round of the other's launches.  dcw_partials then holds
+                               ic3_comm_backward_partials(E1, N) + ic3_comm_backward_partials(E - E1, N) slots */
     void** gate_events;     /* measurement support: NULL, or 2 T events (ic3_event_create) — [2t] / [2t + 1] are recorded on the
                                stream in front of / behind step t's gate launch (read them with ic3_event_elapsed_ms) */
 } ic3_bptt;
 int ic3_bptt_backward_supported(const ic3_env* env, int H);
+int ic3_bptt_first_chain_envs(int E, int N);
 int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream stream);
 /* The weight / bias gradient of the heads + value head over a whole episode in one pass (trainer.py:128-225 through
  * comm.py:228,239): dW [OT][H] += sum_m d[m][o] h[m][c], db [OT] += sum_m d[m][o] over the M = steps x rows pairs

@@ -451,6 +451,11 @@ typedef ic3_host_event* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new ic3_host_event{ std::chrono::steady_clock::now() }; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+// (the host "device" runs every launch to completion inside the call: streams and waits are no-ops)
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
 {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();

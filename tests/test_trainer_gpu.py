@@ -903,6 +903,41 @@ def test_backward_window_as_one_host_call_equals_the_per_step_loop(wl, collect, 
         assert float((g0 - g1).abs().max()) <= 1e-5 * max(1e-3, float(g1.abs().max())), (k, float((g0 - g1).abs().max()), float(g1.abs().max()))
 
 
+@pytest.mark.parametrize("wl,collect,hid", [("pp_hard", False, 128), ("tj_medium", True, 64), ("pp_easy", True, 128),
+                                            ("tj_hard", False, 128)])
+def test_backward_as_two_chains_and_with_the_encoder_window_form(wl, collect, hid):
+    """Round 6, later: ic3_bptt.two_chains (envs [0, E1) and [E1, E) launched on two streams) and ic3_bptt.dxh_step (the per-step
+    input gradients kept in a ring, the encoder's first stage ONCE over the window: ic3_env_encode_backward_window) against the
+    single chain with the encoder's per-step accumulate, on 192 envs (E1 = 64): the chains touch disjoint rows, so only the order
+    of the partial sums changes — 1e-5 of each gradient's scale (measured <= 2e-6)."""
+    import bench
+    from ic3net_amd import ops
+    assert ops.first_chain_envs(192, 10) == 64 and ops.first_chain_envs(100, 10) == 100
+    out = []
+    for two, win in ((False, False), (True, True), (False, True)):
+        tr, a = bench.build_trainer(wl, 192, 3, 0, 0, hid_size=hid)
+        a.max_steps, a.batch_size = 9, 192 * 9 * (2 if collect else 1)
+        a.detach_gap = 4
+        a.entr, a.value_coeff, a.gamma, a.normalize_rewards, a.advantages_per_action = 0.01, 0.01, 0.9, False, False
+        a.bptt_two_chains, a.enc_window = two, win
+        a.auto_reset = collect
+        assert tr._native_update()
+        tr._records = []
+        batch, stats = tr.run_batch(0)
+        recs = tr._records
+        tr.optimizer.zero_grad()
+        tr.compute_grad_native(batch, recs)
+        tr._records = None
+        torch.cuda.synchronize()
+        out.append({k: p.grad.clone() for k, p in tr.policy_net.named_parameters() if p.grad is not None})
+    for o in out[1:]:
+        assert o.keys() == out[0].keys()
+        for k in o:
+            g0, g1 = o[k], out[0][k]
+            err = float((g0 - g1).abs().max())
+            assert err <= 1e-5 * max(1e-3, float(g1.abs().max())), (k, err, float(g1.abs().max()))
+
+
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
     episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)

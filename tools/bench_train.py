@@ -23,7 +23,9 @@ def main():
     a.train_dense_obs = bool(dense) and len(sys.argv) > 5     # (default since round 5: the training rollout assembles no obs rows)
     a.gate_split = bool(split)
     a.auto_reset = bool(coll)
-    a.native_update = mode == 'native' 
+    a.native_update = mode == 'native'
+    a.bptt_two_chains = os.environ.get('TWO_CHAINS', '1') == '1'     # A/B: the backward's launches as two concurrent chains of envs
+    a.enc_window = os.environ.get('ENC_WINDOW', '1') == '1'           # A/B: the encoder backward's stage 1 once per window
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=E * a.max_steps)
     tune = os.environ.get('TUNE', '1') == '1'
