@@ -230,22 +230,20 @@ def backward_episode(args, net, raw, rec, d_out, acc, carry=None):
     fused weight cache).
 
     Collection mode (`rec.stream`, Trainer._run_batch_streams: the record is a WINDOW of consecutive slots of E streams of
-    episodes; recurrent policy, one communication pass): `fresh[t]` marks the envs that start an episode at slot t — their
+    episodes; every policy family — the non-recurrent ones have no state to cut, only the masks of a starting env): `fresh[t]` marks the envs that start an episode at slot t — their
     rows of (h, c) entering the slot are zero, nobody is dead and the gate is 0 (trainer.py:38-51, quirks Q21 / Q22), as
     the step launch had it — and `keep[t]` the envs whose state leaving slot t reaches slot t + 1 with its gradient (no
     episode end, not a detach point of the env's own step count: trainer.py:56-60); `carry` = (dL/dh, dL/dc) arriving at
     the window's last slot from the next window, and the pair leaving the window's first slot is returned."""
-    if rec.stream is not None:
-        assert rec.recurrent and net.comm_passes == 1 and not _is_baseline(net), "collection mode: recurrent policy, one pass"
     if _is_baseline(net):
         si = standin_for_backward(args, net, rec)
         if si is not None:
-            return _backward_episode_standin(net, si, raw, rec, d_out, acc)
-        return _backward_episode_baseline(args, net, raw, rec, d_out, acc)
+            return _backward_episode_standin(net, si, raw, rec, d_out, acc, carry)
+        return _backward_episode_baseline(args, net, raw, rec, d_out, acc, carry)
     if not rec.recurrent:
         return _backward_episode_commnet(args, net, raw, rec, d_out, acc)
     if net.comm_passes > 1:
-        return _backward_episode_multipass(args, net, raw, rec, d_out, acc)
+        return _backward_episode_multipass(args, net, raw, rec, d_out, acc, carry)
     fc = net._fused_cache()
     T, R, H = rec.n, rec.hs.shape[1], rec.hs.shape[2]
     N = net.nagents
@@ -487,6 +485,48 @@ def _ring_fits(dev, nbytes):
     return nbytes <= (free + cached) // 4
 
 
+class _Cuts(object):
+    """Collection mode (rec.stream) for the per-step Python loops: the masks of an env that STARTS an episode at slot t (nobody
+    is dead, the gate is 0: trainer.py:38-51, quirks Q21 / Q22), the rows of its entering state (zero), and what of the
+    gradient of the recurrent state crosses from slot t + 1 back to slot t (`keep`: no episode end, no detach point of the env's
+    own step counter)."""
+
+    def __init__(self, rec, E, N, dev):
+        st = rec.stream
+        self.on = st is not None
+        if not self.on:
+            return
+        self.fresh = st['fresh']
+        self.live_rows = (~st['fresh']).to(torch.float32).repeat_interleave(N, dim=1).unsqueeze(2)   # (T, R, 1)
+        self.keep_rows = st['keep'].to(torch.float32).repeat_interleave(N, dim=1).unsqueeze(2)
+        self.ones = torch.ones((E, N), dtype=torch.int32, device=dev)
+        self.zeros = torch.zeros((E, N), dtype=torch.int32, device=dev)
+
+    def masks(self, t, alive, gate):
+        if not self.on:
+            return alive, gate
+        fr = self.fresh[t].unsqueeze(1)
+        return (torch.where(fr, self.ones, alive) if alive is not None else None,
+                torch.where(fr, self.zeros, gate) if gate is not None else None)
+
+    def entering(self, t, h, c=None):
+        """(h, c) entering slot t with the rows of starting envs zeroed (in place: the record is not read again)"""
+        if self.on:
+            h.mul_(self.live_rows[t])
+            if c is not None:
+                c.mul_(self.live_rows[t])
+        return h, c
+
+    def cut(self, t, gap, *grads):
+        """the gradient of the state LEAVING slot t: lock-step — zero at the episode's detach points; collection — times keep"""
+        if self.on:
+            for g in grads:
+                g.mul_(self.keep_rows[t])
+        elif (t + 1) % gap == 0:
+            for g in grads:
+                g.zero_()
+
+
 def _heads_grad_episode(rec, d_out, acc, T, R, H):
     """heads + value head over a whole record: dW += sum_t d_t^T h_t, db += sum_t sum_rows d_t — h_t of step t is the state
     ENTERING step t + 1 (slot t + 1 of the record).  ONE pass (ic3_heads_grad) for up to 16 output columns, a library product
@@ -505,7 +545,7 @@ def _heads_grad_episode(rec, d_out, acc, T, R, H):
         grad(d_out[T - 1], rec.h_last)
 
 
-def _backward_episode_multipass(args, net, raw, rec, d_out, acc):
+def _backward_episode_multipass(args, net, raw, rec, d_out, acc, carry=None):
     """comm_passes > 1 (comm.py:179-218): the step's passes are re-evaluated forward from the (h, c) that entered the step
     — pass i: comm_i = mix(h_i), inp_i = enc + C_i(comm_i), (h_{i+1}, c_{i+1}) = LSTMCell(inp_i, (h_i, c_i)), every pass's
     [inp | h], comm and c kept for the duration of the step — and then differentiated last pass first; the encoder sees
@@ -532,16 +572,21 @@ def _backward_episode_multipass(args, net, raw, rec, d_out, acc):
     dh_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     dc_rec = torch.zeros((R, H), dtype=torch.float32, device=dev)
     gap = int(getattr(args, 'detach_gap', 10000))
+    cuts = _Cuts(rec, E, N, dev)
+    if cuts.on and carry is not None:
+        dh_rec.copy_(carry[0])
+        dc_rec.copy_(carry[1])
+    if cuts.on:                                                   # (reads h_t of every slot: before the starting envs' rows are zeroed)
+        heads_first = [(rec.hs[t + 1] if t + 1 < T else rec.h_last).clone() for t in range(T)]
     for t in reversed(range(T)):
-        if (t + 1) % gap == 0:
-            dh_rec.zero_()
-            dc_rec.zero_()
-        h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
-        alive, gate = rec.alive[t], rec.gate[t]
+        cuts.cut(t, gap, dh_rec, dc_rec)
+        h_t = heads_first[t] if cuts.on else (rec.hs[t + 1] if t + 1 < T else rec.h_last)
+        alive, gate = cuts.masks(t, rec.alive[t], rec.gate[t])
         # ---- forward: enc (+ encoder.bias + C_0.bias), then the passes
         raw.encode_at(rec.snaps[t], fc['wt'], fc['enc_bias'], out=enc, loc_table=fc['loc_table'])
-        xh[0][:, H:].copy_(rec.hs[t])
-        cs[0].copy_(rec.cs[t])
+        h_in, c_in = cuts.entering(t, rec.hs[t], rec.cs[t])
+        xh[0][:, H:].copy_(h_in)
+        cs[0].copy_(c_in)
         for i in range(P):
             inp_i = xh[i][:, :H]
             torch.add(enc, dbias[i], out=inp_i) if i else inp_i.copy_(enc)
@@ -580,6 +625,7 @@ def _backward_episode_multipass(args, net, raw, rec, d_out, acc):
         dwt, db = raw.encode_backward(denc, rec.snaps[t], want_bias=True)
         acc['wt'].add_(dwt)
         acc['enc_bias'].add_(db)
+    return (dh_rec, dc_rec)
 
 
 def _backward_episode_commnet(args, net, raw, rec, d_out, acc):
@@ -616,8 +662,9 @@ def _backward_episode_commnet(args, net, raw, rec, d_out, acc):
     cpart = [torch.zeros((NB, H, H), dtype=torch.float32, device=dev) for _ in range(P)] if NB > 1 and not mask_zero else None
     blk = lambda v: v.view(NB, R // NB, H)
     enc_acc = None        # None: nothing accumulated yet; True: partial sums hold the steps so far; False: per-step form
+    cuts = _Cuts(rec, E, N, dev)      # collection mode: no state crosses a step — only the masks of an env that starts an episode
     for t in reversed(range(T)):
-        alive, gate = rec.alive[t], rec.gate[t]
+        alive, gate = cuts.masks(t, rec.alive[t], rec.gate[t])
         # ---- forward of step t again
         raw.encode_at(rec.snaps[t], cn['wt'], cn['enc_bias'], out=enc, loc_table=cn['loc_table'])
         torch.tanh(enc, out=x)
@@ -699,13 +746,13 @@ def standin_for_backward(args, net, rec=None):
     return si
 
 
-def _backward_episode_standin(net, si, raw, rec, d_out, acc):
+def _backward_episode_standin(net, si, raw, rec, d_out, acc, carry=None):
     """IRIC (models.RNN, LSTM) through the stand-in's backward; its accumulators are folded into the baseline's by name:
     encoder = affine1, [W_ih | W_hh] / b_ih + b_hh = lstm_unit's, heads; C (all zeros, never read: comm_mask_zero) has none."""
     acc2 = acc.get('_standin')
     if acc2 is None:
         acc2 = acc['_standin'] = new_accumulators(si)
-    return backward_episode(si.args, si, raw, rec, d_out, acc2)
+    return backward_episode(si.args, si, raw, rec, d_out, acc2, carry=carry)
 
 
 def fold_standin(acc):
@@ -723,7 +770,7 @@ def fold_standin(acc):
     acc['b_heads'].add_(acc2['b_heads'])
 
 
-def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
+def _backward_episode_baseline(args, net, raw, rec, d_out, acc, carry=None):
     """The IC / IRIC baselines of models.py:8-97 (no communication), differentiated by hand over the recorded rollout:
       MLP  (models.py:23-34)   x1 = tanh(affine1(obs));  h = tanh(affine2(x1) + x1)         every step on its own
       RNN  (models.py:68-92)   rnn_type 'MLP':  h_t = tanh(affine2(h_{t-1}) + affine1(obs))
@@ -760,6 +807,13 @@ def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
     a2part = torch.zeros((NB, H, H), dtype=torch.float32, device=dev) if NB > 1 and not lstm else None
     blk = lambda v: v.view(NB, R // NB, H)
     enc_acc = None
+    cuts = _Cuts(rec, R // net.args.nagents, net.args.nagents, dev)
+    if cuts.on and recurrent:
+        if carry is not None:
+            dh_rec.copy_(carry[0])
+            if lstm:
+                dc_rec.copy_(carry[1])
+        heads_first = [(rec.hs[t + 1] if t + 1 < T else rec.h_last).clone() for t in range(T)]   # (before rows are zeroed)
     for t in reversed(range(T)):
         d = d_out[t]
         raw.encode_at(rec.snaps[t], wt, b1, out=enc)              # affine1(obs_t)
@@ -780,19 +834,16 @@ def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
             torch.addmm(dz, dz, A2, out=dh)                                       # d x1 = dz A2 + dz (the skip)
             tanh_bwd(dh, x1, grad_input=dz)                                       # through x1 = tanh(enc)
         else:
-            if (t + 1) % gap == 0:                                # (h_t, c_t) were handed on detached
-                dh_rec.zero_()
-                if lstm:
-                    dc_rec.zero_()
-            h_prev = rec.hs[t]
-            h_t = rec.hs[t + 1] if t + 1 < T else rec.h_last
+            cuts.cut(t, gap, *((dh_rec, dc_rec) if lstm else (dh_rec,)))     # (h_t, c_t) were handed on detached / the episode ended
+            h_prev, c_prev = cuts.entering(t, rec.hs[t], rec.cs[t] if lstm else None)
+            h_t = heads_first[t] if cuts.on else (rec.hs[t + 1] if t + 1 < T else rec.h_last)
             acc['w_heads'].addmm_(d.t(), h_t)
             acc['b_heads'].add_(d.sum(0))
             torch.addmm(dh_rec, d, w_heads, out=dh)
             if lstm:                                              # ---- RNN, LSTM cell
                 torch.addmm(b_cat, enc, w_ih.t(), out=gates)
                 gates.addmm_(h_prev, w_hh.t())
-                p_ = ops.lstm_cell_backward(gates, rec.cs[t], dh, dc_rec, dgates, dc_rec, parts)   # dc_rec <- dL/dc_{t-1}
+                p_ = ops.lstm_cell_backward(gates, c_prev, dh, dc_rec, dgates, dc_rec, parts)   # dc_rec <- dL/dc_{t-1}
                 torch.sum(p_, 0, out=bsum)
                 acc['l_b'].add_(bsum)
                 acc['l_w_ih'].addmm_(dgates.t(), enc)
@@ -820,6 +871,8 @@ def _backward_episode_baseline(args, net, raw, rec, d_out, acc):
         acc['a1_b'].add_(db)
     if a2part is not None:
         acc['a2_w'].add_(a2part.sum(0))
+    if recurrent:
+        return (dh_rec, dc_rec if lstm else dh_rec)
 
 
 def new_accumulators(net):

@@ -962,12 +962,27 @@ class Trainer(object):
         if not bptt.supported(self.args if knet is self.policy_net else knet.args, knet, raw):
             return False
         if self._auto_reset():
-            # collection mode: episode cuts inside the windows — handled by bptt.backward_episode for the recurrent policy
-            # with one communication pass on the one-launch rollout (the launch restarts finished envs itself); other
-            # policies keep the explicit NotImplementedError of _step_body
-            return bool(getattr(self.args, 'recurrent', False)) and getattr(knet, 'comm_passes', 1) == 1 \
-                and not bptt._is_baseline(knet) and self._mega_expected(raw)
+            # collection mode: episode cuts inside the windows — bptt.backward_episode handles them for every family; the
+            # ROLLOUT must be a one-launch step (the launch restarts finished envs itself): ic3_policy_step for the recurrent
+            # LSTM policies (CommNet / IC3Net with any number of passes, IRIC through its stand-in), ic3_commnet_step for the
+            # non-recurrent ones (CommNet, IC through its stand-in).  The tanh-recurrence RNN has no such launch.
+            with torch.no_grad():                                  # (the native update's rollout runs without autograd)
+                if getattr(self.args, 'recurrent', False):
+                    return getattr(self.args, 'rnn_type', '') == 'LSTM' and self._mega_expected(raw)
+                return self._commnet_expected(raw)
         return True
+
+    def _commnet_expected(self, raw):
+        """Will step_episode go through ic3_commnet_step?  (the non-recurrent twin of _mega_expected)"""
+        a = self.args
+        if getattr(a, 'rollout_grad', False) or a.recurrent or self.clock.env is not raw or getattr(a, 'store_states', False) \
+                or select_action is not _select_action_default:
+            return False
+        net = self.policy_net
+        if getattr(net, 'commnet_step_ok', None) is None or not hasattr(raw, '_h'):
+            return False
+        H = getattr(self._kernel_net(), 'hid_size', a.hid_size)
+        return bool(ops.commnet_step_supported(raw, H)) and getattr(net.obs_encoder, '__self__', None) is raw
 
     def compute_grad_native(self, batch, records):
         """compute_grad() without an autograd graph: losses and dL/d(logits, value) from the batch, then

@@ -442,7 +442,7 @@ def grad_case(name, env_name, T, nenv, nep, seed, closed_form=False, model=None,
     print(name, 'steps', stats['num_steps'], 'losses', s)
 
 
-def grad_stream_case(name, env_name, T, nenv, nwin, seed, closed_form=False, **flags):
+def grad_stream_case(name, env_name, T, nenv, nwin, seed, closed_form=False, model=None, **flags):
     """F5c — collection mode: the reference's run_batch + compute_grad (trainer.py:227-242,128-225) over, per env, the
     consecutive WHOLE episodes that fit in nwin * T slots (`while: get_episode()` of one reference process per env, the batch
     their concatenation) — what one auto-reset rollout of nwin windows holds here, the unfinished tail of every stream
@@ -456,7 +456,12 @@ def grad_stream_case(name, env_name, T, nenv, nwin, seed, closed_form=False, **f
     env = rh.make_env(env_name, a)
     rh.finish_args(a, env)
     torch.manual_seed(seed)
-    net = ref['comm'].CommNetMLP(a, a.num_inputs)
+    if model == 'mlp':        # the reference's IC / IRIC baselines (models.py:8-97; main.py:161-168 builds them like this)
+        net = ref['models'].MLP(a, a.num_inputs)
+    elif model == 'rnn':
+        net = ref['models'].RNN(a, a.num_inputs)
+    else:
+        net = ref['comm'].CommNetMLP(a, a.num_inputs)
     if closed_form:
         sd = net.state_dict()
         cw = closed_form_weights({k: tuple(v.shape) for k, v in sd.items()})
@@ -521,6 +526,8 @@ def grad_stream_case(name, env_name, T, nenv, nwin, seed, closed_form=False, **f
                ep_len=ep_len, actions=acts, action_loss=s['action_loss'], value_loss=s['value_loss'],
                entropy=s.get('entropy', 0.0), num_steps=stats['num_steps'], num_episodes=stats['num_episodes'],
                reward=np.asarray(stats['reward'], np.float64), success=float(stats.get('success', 0)))
+    if model:
+        out['model'] = np.array(model)
     if closed_form:
         out['param_names'] = np.array(list(net.state_dict().keys()))
         out['param_shapes'] = np.array([repr(tuple(v.shape)) for v in net.state_dict().values()])
@@ -572,6 +579,26 @@ def grad_stream_h128_main():
     grad_stream_case('gradstream_tj_easy_h128', 'traffic_junction', 10, 6, 2, 55, closed_form=True, nagents=5, dim=6, vision=1,
                      hid_size=128, ic3net=True, recurrent=True, detach_gap=3, add_rate_min=0.3, add_rate_max=0.3,
                      difficulty='easy', entr=0.01, value_coeff=0.01)
+
+
+def grad_stream_families_main():
+    """Collection mode for the other policy families (round-5 verdict item 6), hid 64 (a size their one-launch rollouts run at),
+    closed-form weights: the NON-recurrent CommNet module with two communication passes, the gated non-recurrent module on
+    Traffic-Junction, the IC baseline (models.MLP) and the IRIC baseline with the LSTM cell (models.RNN) — on the tiny
+    Predator-Prey grid where sampled policies end episodes early, and Traffic-Junction (alive masks)."""
+    grad_stream_case('gradstream_pp_tiny_commnet_mlp2', 'predator_prey', 12, 6, 3, 67, closed_form=True, nagents=2, dim=3, vision=1,
+                     hid_size=64, commnet=True, recurrent=False, comm_passes=2, entr=0.01, value_coeff=0.01, mode='mixed')
+    grad_stream_case('gradstream_tj_easy_ic3net_mlp', 'traffic_junction', 10, 4, 2, 57, closed_form=True, nagents=5, dim=6, vision=1,
+                     hid_size=64, ic3net=True, recurrent=False, add_rate_min=0.3, add_rate_max=0.3, difficulty='easy', entr=0.01,
+                     value_coeff=0.01)
+    grad_stream_case('gradstream_pp_tiny_ic_mlp', 'predator_prey', 12, 6, 3, 58, closed_form=True, model='mlp', nagents=2, dim=3,
+                     vision=1, hid_size=64, recurrent=False, entr=0.01, value_coeff=0.01, mode='mixed')
+    grad_stream_case('gradstream_pp_tiny_iric_lstm', 'predator_prey', 12, 6, 3, 59, closed_form=True, model='rnn', nagents=2, dim=3,
+                     vision=1, hid_size=64, recurrent=True, rnn_type='LSTM', detach_gap=5, entr=0.01, value_coeff=0.01,
+                     mode='mixed')
+    grad_stream_case('gradstream_pp_tiny_ic3net_p2', 'predator_prey', 12, 6, 3, 60, closed_form=True, nagents=2, dim=3, vision=1,
+                     hid_size=64, ic3net=True, recurrent=True, comm_passes=2, detach_gap=5, entr=0.01, value_coeff=0.01,
+                     mode='mixed')
 
 
 def trainer_main():
@@ -652,6 +679,8 @@ if __name__ == '__main__':
         grad_baseline_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream':
         grad_stream_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream_families':
+        grad_stream_families_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'grad_stream_h128':
         grad_stream_h128_main()
     elif len(sys.argv) > 1 and sys.argv[1] == 'trainer_fullsize':

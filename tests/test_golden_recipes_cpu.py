@@ -38,12 +38,13 @@ RECIPES = {
     'grad_scaled': ['make_golden_policy.py', 'grad_scaled'],
     'grad_stream': ['make_golden_policy.py', 'grad_stream'],
     'grad_stream_h128': ['make_golden_policy.py', 'grad_stream_h128'],
+    'grad_stream_families': ['make_golden_policy.py', 'grad_stream_families'],
     'grad_baseline': ['make_golden_policy.py', 'grad_baseline'],
     'render': ['make_golden_render.py'],
     'ckpt': ['make_golden_ckpt.py'],
 }
 # every committed data fixture must come out of one of the recipes above
-EXPECTED_MIN_NPZ = 68
+EXPECTED_MIN_NPZ = 73
 
 
 @pytest.fixture(scope='module')

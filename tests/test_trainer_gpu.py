@@ -368,6 +368,11 @@ GRAD_TOL = {
     "grad_tj_hard_ic3net":             (7.0e-05, 2.0e-06),
     "grad_tj_medium_perhead":          (4.0e-06, 2.0e-06),
     "gradstream_pp_small_h128":        (7.0e-06, 2.0e-06),
+    "gradstream_pp_tiny_commnet_mlp2": (6.1e-06, 2.0e-06),
+    "gradstream_pp_tiny_ic3net_p2":    (2.3e-05, 2.0e-06),
+    "gradstream_pp_tiny_ic_mlp":       (4.0e-06, 2.0e-06),
+    "gradstream_pp_tiny_iric_lstm":    (6.0e-06, 2.0e-06),
+    "gradstream_tj_easy_ic3net_mlp":   (9.3e-06, 2.0e-06),
     "gradstream_pp_tiny_commnet":      (4.0e-06, 6.5e-06),
     "gradstream_pp_tiny_ic3net":       (4.0e-06, 2.0e-06),
     "gradstream_tj_easy_h128":         (3.8e-05, 2.0e-06),
@@ -379,7 +384,12 @@ STREAM_FIXTURES = [("gradstream_pp_tiny_ic3net", "predator_prey"), ("gradstream_
                    ("gradstream_tj_easy_ic3net", "traffic_junction"),
                    # hid 128 (round 6): the kernels of the BASELINE updates with cuts INSIDE the windows — 10 of 48 Predator-Prey
                    # episodes end early, 7 of 16 streams run out of phase with the windows; TJ: detach points every 3 steps
-                   ("gradstream_pp_small_h128", "predator_prey"), ("gradstream_tj_easy_h128", "traffic_junction")]
+                   ("gradstream_pp_small_h128", "predator_prey"), ("gradstream_tj_easy_h128", "traffic_junction"),
+                   # the other policy families in collection mode (round-5 verdict item 6), hid 64: the non-recurrent CommNet
+                   # module (two passes; gated on TJ), IC (models.MLP), IRIC (models.RNN, LSTM cell), IC3Net with two passes
+                   ("gradstream_pp_tiny_commnet_mlp2", "predator_prey"), ("gradstream_tj_easy_ic3net_mlp", "traffic_junction"),
+                   ("gradstream_pp_tiny_ic_mlp", "predator_prey"), ("gradstream_pp_tiny_iric_lstm", "predator_prey"),
+                   ("gradstream_pp_tiny_ic3net_p2", "predator_prey")]
 
 
 @pytest.mark.parametrize("name,env_name", STREAM_FIXTURES)
@@ -410,7 +420,13 @@ def test_collection_mode_grad_matches_reference(name, env_name):
     if a.commnet and (a.recurrent or a.rnn_type == 'LSTM'):
         a.recurrent, a.rnn_type = True, 'LSTM'
     parse_action_args(a)
-    net = CommNetMLP(a, a.num_inputs)
+    model = str(fx["model"]) if "model" in fx.files else None
+    if model:                                         # main.py:161-168: the baselines instead of CommNetMLP
+        from ic3net_amd import models
+        a.continuous = False
+        net = (models.RNN if model == 'rnn' else models.MLP)(a, a.num_inputs)
+    else:
+        net = CommNetMLP(a, a.num_inputs)
     if "param_names" in fx.files:                     # hid-128 fixtures: weights from the index alone
         from policy_util import closed_form_weights
         shapes = {str(n): eval(str(sh)) for n, sh in zip(fx["param_names"], fx["param_shapes"])}
@@ -941,8 +957,9 @@ def test_backward_as_two_chains_and_with_the_encoder_window_form(wl, collect, hi
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
     episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)
-    for the recurrent policy with one communication pass; a policy with several passes per step has no such backward and
-    train_batch must not take the native path (the autograd rollout then raises its explicit NotImplementedError); and hid
+    for every policy family whose rollout step is ONE launch (round 6; the launch restarts finished envs itself); the tanh-recurrence
+    RNN baseline has no such launch and train_batch must not take the native path (the rollout then raises its explicit
+    NotImplementedError); and hid
     sizes ic3_lstm_cell_backward does not take (H / 4 not a power of two <= 64) keep the autograd update instead of failing
     inside it."""
     import bench
@@ -954,10 +971,14 @@ def test_native_update_is_not_taken_where_it_does_not_apply():
     trp, ap = bench.build_trainer('pp_hard', 8, 1, 0, 0, comm_passes=2)
     assert trp._native_update()
     ap.auto_reset = True
-    assert not trp._native_update()
-    ap.batch_size = 8 * ap.max_steps
+    assert trp._native_update()          # (round 6: every family with a one-launch rollout step — test_collection_mode_grad_...)
+    trr, ar = bench.build_trainer('pp_hard_iric', 8, 1, 0, 0, rnn_type='MLP')     # the tanh-recurrence RNN has no such launch
+    assert trr._native_update()
+    ar.auto_reset = True
+    assert not trr._native_update()
+    ar.batch_size = 8 * ar.max_steps
     with pytest.raises(NotImplementedError):
-        trp.train_batch(0)
+        trr.train_batch(0)
     for hid, ok in ((96, False), (100, False), (128, True), (32, True)):
         tr2, a2 = bench.build_trainer('pp_easy', 8, 1, 0, 0, hid_size=hid)
         assert bptt.supported(a2, tr2.policy_net, tr2.env.env) == ok, hid
