@@ -142,10 +142,11 @@ EXPORTS = {
     "ic3_lstm_gates_backward_dx": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ic3_commnet_forward_supported": (C.c_int, [C.c_int, C.c_int]),
     "ic3_commnet_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "ic3_commnet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 +
+    "ic3_commnet_pack_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ic3_commnet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 +
                             [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "ic3_commnet_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
-    "ic3_commnet_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int] +
+    "ic3_commnet_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int] +
                          [C.c_void_p] * 10),
     "ic3_lstm_gates_backward_supported": (C.c_int, [C.c_int]),
     "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -316,13 +316,16 @@ class CommNetMLP(nn.Module):
         ps = [self.encoder.weight, self.encoder.bias, self.value_head.weight, self.value_head.bias] + \
             [q for m in list(self.C_modules) + list(self.f_modules) for q in (m.weight, m.bias)] + \
             [q for hd in self.heads for q in (hd.weight, hd.bias)]
-        key = tuple((q._version, q.data_ptr()) for q in ps)
+        key = tuple((q._version, q.data_ptr()) for q in ps) + (bool(getattr(self.args, 'gate_split', True)),)
         if getattr(self, '_cn_key', None) != key:
             with torch.no_grad():
                 wt = self.encoder.weight.t().contiguous()
                 wp, bias = ops.commnet_pack([m.weight for m in self.C_modules], [m.weight for m in self.f_modules],
                                             [m.bias for m in self.C_modules], [m.bias for m in self.f_modules])
-                self._cn = dict(wt=wt, enc_bias=self.encoder.bias.detach().contiguous(), wp=wp, bias=bias,
+                # args.gate_split (the default): the [comm | h] . [C_i | F_i]^T product as exact bf16 split products too
+                wp3 = ops.commnet_pack_split([m.weight for m in self.C_modules], [m.weight for m in self.f_modules]) \
+                    if getattr(self.args, 'gate_split', True) else None
+                self._cn = dict(wt=wt, enc_bias=self.encoder.bias.detach().contiguous(), wp=wp, wp3=wp3, bias=bias,
                                 loc_table=self.obs_table(wt) if self.obs_table is not None else None,
                                 w_heads=torch.cat([hd.weight for hd in self.heads] + [self.value_head.weight], 0).contiguous(),
                                 b_heads=torch.cat([hd.bias for hd in self.heads] + [self.value_head.bias], 0).contiguous())
@@ -345,7 +348,8 @@ class CommNetMLP(nn.Module):
         else:
             torch.addmm(cn['enc_bias'], x.reshape(R, -1), cn['wt'], out=buf)             # dense encoder GEMM
         out = ops.commnet_forward(buf, batch, n, cn['wp'], cn['bias'], cn['w_heads'], cn['b_heads'],
-                                  self.args.naction_heads, mode_avg, bool(self.args.comm_mask_zero), alive, comm_action)
+                                  self.args.naction_heads, mode_avg, bool(self.args.comm_mask_zero), alive, comm_action,
+                                  wp3=cn.get('wp3'))
         self.commnet_forwards = getattr(self, 'commnet_forwards', 0) + 1
         self.sampled = False
         action, value = self._split_out(out, batch, n)

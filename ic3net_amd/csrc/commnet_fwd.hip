@@ -23,6 +23,7 @@
 
 #include "env_device.hpp"
 #include "ic3_common.hpp"
+#include "ps_common.hpp"
 
 namespace ic3 {
 
@@ -47,6 +48,7 @@ struct CommnetArgs {
     float* obs;                // [E][N][obs_dim] or null: rows of the state acted on
     int32_t* action;           // [nheads][R]
     int obs_dim, G, tile_words;
+    const void* wp3;           // or null: per pass three exact bf16 planes of [C_i | F_i] in fragment order (ic3_commnet_pack_split)
     int auto_reset;            // env handle in auto-reset mode: an env with t == 0 starts an episode — nobody is dead yet and
                                // the gate is 0 (trainer.py:41-46, quirks Q21 / Q22); the module carries no other state
     uint32_t seed, gid0;
@@ -227,6 +229,46 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
+        if (a.wp3) {
+            // the product as nine exact bf16 x bf16 products per fp32 product (policy_step_kernel's gate_split):
+            // the weights' three planes in fragment order, Wp3[pass][plane][kb16][wave][lane] x 16 bytes, one 16-k block ahead in
+            // registers; the activations split per wave from the fp32 LDS tile (ps_split_frag).  9 x 32 cycles per 16 k against
+            // 8 x 64 on the fp32 instruction.
+            typedef __bf16 cn_bf16x8 __attribute__((ext_vector_type(8)));
+            constexpr int KB16 = K / 16, NWv = H / 32;
+            const __amdgpu_buffer_rsrc_t rw = make_rsrc(reinterpret_cast<const ps_u32x4*>(a.wp3) + (size_t)pass * 3 * KB16 * NWv * 64,
+                                                        (uint32_t)(3 * KB16 * NWv * 64 * 16));
+            const int wu = __builtin_amdgcn_readfirstlane(w);
+            auto wb = [&](int pl, int kb) __attribute__((always_inline)) {
+                return __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, ((pl * KB16 + kb) * NWv + wu) * 1024, 0);
+            };
+            const int kb0 = a.comm_zero ? KB16 / 2 : 0;          // (comm_mask_zero / the IC stand-in: the comm half is all zeros)
+            ps_u32x4 bq[3], bn[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[pl] = wb(pl, kb0);
+            CN_PRIO(0);
+#pragma unroll 2
+            for (int kb = kb0; kb < KB16; ++kb) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bn[pl] = wb(pl, kb + 1);                      // (past the end: zeros, never used)
+                ps_u32x4 ap[2][3];
+                const cn_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
+                const cn_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
+                ps_split_frag(s0[0], s0[1], ap[0]);
+                ps_split_frag(s1[0], s1[1], ap[1]);
+#pragma unroll
+                for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+                    for (int pa = 2; pa >= 0; --pa) {                                        // (least significant term first)
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8, ap[0][pa]),
+                                                                         __builtin_bit_cast(cn_bf16x8, bq[pb]), acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8, ap[1][pa]),
+                                                                         __builtin_bit_cast(cn_bf16x8, bq[pb]), acc[1], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bq[pl] = bn[pl];
+            }
+        } else {
         const cn_f32x4* wp = reinterpret_cast<const cn_f32x4*>(a.wp) + (size_t)pass * (K * H / 4) + col * 2 + lh;
         constexpr int CH = 8;
         static_assert(KB % CH == 0, "2H / 8 is a multiple of 8");
@@ -255,6 +297,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                     }
                 }
             }
+        }
         }
         CN_PRIO(3);
         __syncthreads();                                         // every wave has read the old h
@@ -355,7 +398,42 @@ __global__ void commnet_pack_kernel(const float* __restrict__ Cw, const float* _
     }
 }
 
+// gate_split's planes for [C | F] (H x 2H): Wp3[plane][kb16][wave][lane] = 8 x bf16 { W_plane[32 wave + li][16 kb16 + 8 lh + i] },
+// the three planes an exact split of every weight (ps_split3)
+__global__ void commnet_pack_split_kernel(const float* __restrict__ Cw, const float* __restrict__ Fw, ps_u32x4* __restrict__ Wp, int H)
+{
+    const int NWv = H / 32, KB16 = 2 * H / 16;
+    const long long per = (long long)KB16 * NWv * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long long rest = i >> 6;
+        const int wv = (int)(rest % NWv), kb = (int)(rest / NWv);
+        const int li = lane & 31, lh = lane >> 5;
+        const size_t row = (size_t)32 * wv + li;
+        unsigned p[3][8];
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * kb + 8 * lh + q;
+            ps_split3(k < H ? Cw[row * H + k] : Fw[row * H + (k - H)], p[0][q], p[1][q], p[2][q]);
+        }
+        for (int pl = 0; pl < 3; ++pl) {
+            ps_u32x4 v;
+            for (int d = 0; d < 4; ++d) v[d] = p[pl][2 * d] | (p[pl][2 * d + 1] << 16);
+            Wp[(size_t)pl * per + i] = v;
+        }
+    }
+}
+
 }  // namespace ic3
+
+extern "C" int ic3_commnet_pack_split(const float* C_weight, const float* f_weight, void* wp3, int H, ic3_stream stream)
+{
+    using namespace ic3;
+    if (!C_weight || !f_weight || !wp3 || H <= 0 || (H & 31)) return fail(-22, "ic3_commnet_pack_split: hid_size a positive multiple of 32");
+    hipLaunchKernelGGL(commnet_pack_split_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, C_weight, f_weight,
+                       reinterpret_cast<ps_u32x4*>(wp3), H);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int ic3_commnet_forward_supported(int H, int N) { return (H == 64 || H == 128 || H == 256) && N >= 1 && N <= 64; }
 
@@ -368,7 +446,8 @@ extern "C" int ic3_commnet_pack(const float* C_weight, const float* f_weight, fl
     return 0;
 }
 
-extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, const float* wp, const float* bias,
+extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, const float* wp, const void* wp3,
+                                   const float* bias,
                                    const float* head_w, const float* head_b, const int32_t* head_sizes, int nheads,
                                    int mode_avg, int comm_zero, const int32_t* alive_in, const int32_t* comm_in, float* out,
                                    float* h_out, ic3_stream stream)
@@ -382,6 +461,7 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
     CommnetArgs a{};
     a.enc = enc;
     a.wp = wp;
+    a.wp3 = wp3;
     a.bias = bias;
     a.head_w = head_w;
     a.head_b = head_b;
@@ -448,8 +528,8 @@ extern "C" int ic3_commnet_step_supported(const ic3_env* env, int H)
 }
 
 extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* enc_bias, const float* loc_table, int H,
-                                int comm_passes, const float* wp, const float* bias, const float* head_w, const float* head_b,
-                                const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
+                                int comm_passes, const float* wp, const void* wp3, const float* bias, const float* head_w,
+                                const float* head_b, const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
                                 const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward, int32_t* done,
                                 int32_t* alive, int32_t* is_completed, ic3_stream stream)
 {
@@ -466,6 +546,7 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
                          "ic3_env_encode + ic3_commnet_forward + ic3_env_sample_actions + ic3_env_step)");
     CommnetArgs a{};
     a.wp = wp;
+    a.wp3 = wp3;
     a.bias = bias;
     a.head_w = head_w;
     a.head_b = head_b;

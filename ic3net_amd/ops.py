@@ -135,8 +135,21 @@ def commnet_pack(c_weights, f_weights, c_biases, f_biases):
     return wp, bias
 
 
+def commnet_pack_split(c_weights, f_weights):
+    """Per-pass [C_i | F_i] as three exact bf16 planes in MFMA fragment order (ic3_commnet_pack_split): (P, 3 * H * H) float32
+    words, or None when hid_size is not a multiple of 32."""
+    H, P, dev = c_weights[0].shape[0], len(c_weights), c_weights[0].device
+    if H % 32:
+        return None
+    wp3 = torch.empty((P, 3 * H * H), dtype=torch.float32, device=dev)
+    for i in range(P):
+        check(_lib.lib().ic3_commnet_pack_split(ptr(c_weights[i].detach().contiguous().float()),
+                                                ptr(f_weights[i].detach().contiguous().float()), ptr(wp3[i]), H, stream()))
+    return wp3
+
+
 def commnet_forward(enc, E, N, wp, bias, head_w, head_b, head_sizes, mode_avg, comm_zero, alive_in, comm_in, out=None,
-                    h_out=None):
+                    h_out=None, wp3=None):
     """The non-recurrent CommNet module after the encoder, every communication pass in one launch (ic3_commnet_forward):
     enc (E*N, H) = encoder(obs) incl. bias -> out (E*N, OT) = [log-probs of every head | value]."""
     import ctypes as C
@@ -149,7 +162,8 @@ def commnet_forward(enc, E, N, wp, bias, head_w, head_b, head_sizes, mode_avg, c
     if out is None:
         out = torch.empty((R, OT), dtype=torch.float32, device=enc.device)
     sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
-    check(_lib.lib().ic3_commnet_forward(ptr(enc), E, N, H, wp.shape[0], ptr(wp), ptr(bias), ptr(head_w), ptr(head_b), sizes,
+    assert wp3 is None or (wp3.is_contiguous() and tuple(wp3.shape) == (wp.shape[0], 3 * H * H))
+    check(_lib.lib().ic3_commnet_forward(ptr(enc), E, N, H, wp.shape[0], ptr(wp), ptr(wp3), ptr(bias), ptr(head_w), ptr(head_b), sizes,
                                          len(head_sizes), int(bool(mode_avg)), int(bool(comm_zero)), ptr(alive_in),
                                          ptr(comm_in), ptr(out), ptr(h_out), stream()))
     return out
@@ -163,7 +177,7 @@ def commnet_step(env, cn, H, head_sizes, mode_avg, comm_zero, alive_in, comm_in,
                  is_completed=None, obs=None):
     """One whole rollout iteration of the NON-recurrent module (sparse encoder -> communication passes -> heads -> draws ->
     env.step, + the dense obs rows of the state acted on) in one launch — ic3_commnet_step.  `cn`: the module's derived
-    weights (wt, enc_bias, loc_table, wp, bias, w_heads, b_heads)."""
+    weights (wt, enc_bias, loc_table, wp, bias, w_heads, b_heads; wp3 = the split planes or None: the fp32 instruction)."""
     import ctypes as C
     _need_cuda(out, "commnet_step")
     R = out.shape[0]
@@ -173,7 +187,8 @@ def commnet_step(env, cn, H, head_sizes, mode_avg, comm_zero, alive_in, comm_in,
         assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
     sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
     check(_lib.lib().ic3_commnet_step(env._h, ptr(cn['wt']), ptr(cn['enc_bias']), ptr(cn['loc_table']), int(H),
-                                      cn['wp'].shape[0], ptr(cn['wp']), ptr(cn['bias']), ptr(cn['w_heads']), ptr(cn['b_heads']),
+                                      cn['wp'].shape[0], ptr(cn['wp']), ptr(cn.get('wp3')), ptr(cn['bias']), ptr(cn['w_heads']),
+                                      ptr(cn['b_heads']),
                                       sizes, len(head_sizes), int(bool(mode_avg)), int(bool(comm_zero)), ptr(alive_in),
                                       ptr(comm_in), ptr(out), ptr(action), ptr(obs), ptr(reward), ptr(done), ptr(alive),
                                       ptr(is_completed), stream()))

@@ -571,11 +571,18 @@ typedef struct {
  * (ic3_env_encode or a dense GEMM); wp = comm_passes blocks of 2*H*H floats, block i = ic3_commnet_pack(C_modules[i].weight,
  * f_modules[i].weight); bias [comm_passes][H] = C_i.bias + f_i.bias; head_w / head_b / head_sizes as ic3_policy_heads;
  * alive_in / comm_in as ic3_policy_step (NULL = everyone alive / talking); h_out [E*N][H] or NULL receives the final
- * hidden state.  hid_size 64 / 128 / 256, <= 64 agents per env (ic3_commnet_forward_supported), else -ENOSYS. */
+ * hidden state.  hid_size 64 / 128 / 256, <= 64 agents per env (ic3_commnet_forward_supported), else -ENOSYS.
+ * wp3 != NULL (comm_passes blocks of 3 * 2*H*H bf16 = 3*H*H floats, block i = ic3_commnet_pack_split of the same weights; what
+ * ic3net_amd passes with args.gate_split, the default): the product [comm | h] . [C_i | F_i]^T with every fp32 operand split exactly
+ * into three bf16 terms, all nine cross products on the bf16 matrix cores, fp32 accumulation — the arithmetic of
+ * ic3_policy.gate_split; NULL: the fp32 matrix instruction on wp. */
 int ic3_commnet_forward_supported(int H, int N);
 int ic3_commnet_pack(const float* C_weight /* [H][H] */, const float* f_weight /* [H][H] */, float* wp /* [2*H*H] */, int H,
                      ic3_stream stream);
-int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, const float* wp, const float* bias,
+int ic3_commnet_pack_split(const float* C_weight /* [H][H] */, const float* f_weight /* [H][H] */, void* wp3 /* 3 * 2*H*H * 2 bytes */,
+                           int H, ic3_stream stream);
+int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, const float* wp, const void* wp3 /* or NULL */,
+                        const float* bias,
                         const float* head_w, const float* head_b, const int32_t* head_sizes, int nheads, int mode_avg,
                         int comm_zero, const int32_t* alive_in, const int32_t* comm_in, float* out, float* h_out /* or NULL */,
                         ic3_stream stream);
@@ -583,15 +590,15 @@ int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, 
 /* The whole rollout iteration of trainer.py:43-108 for the NON-recurrent module as ONE launch — what ic3_policy_step is for
  * the recurrent policy: the sparse encoder on the env's integer state (enc_wt [obs_dim][H] = encoder.weight^T, enc_bias [H] =
  * encoder.bias, loc_table = ic3_env_encode_table(enc_wt) or NULL), ic3_commnet_forward's passes / heads / log_softmax (same
- * wp / bias / head_* arguments), the action draws of every head (action [nheads][E][N], Philox counters of
+ * wp / wp3 / bias / head_* arguments), the action draws of every head (action [nheads][E][N], Philox counters of
  * ic3_env_sample_actions), env.step with head 0 (reward / done / alive / is_completed as ic3_env_step) and, when obs != NULL,
  * the dense observation rows [E][N][obs_dim] of the state this call ACTS ON (bit-identical to ic3_env_observe before the
  * call).  -ENOSYS when ic3_commnet_step_supported(env, H) == 0 (hid_size not 64/128/256, > 64 agents, a tile that does
  * not fit in LDS, or a handle in auto-reset mode). */
 int ic3_commnet_step_supported(const ic3_env* env, int H);
 int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* enc_bias, const float* loc_table /* or NULL */, int H,
-                     int comm_passes, const float* wp, const float* bias, const float* head_w, const float* head_b,
-                     const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
+                     int comm_passes, const float* wp, const void* wp3 /* or NULL */, const float* bias, const float* head_w,
+                     const float* head_b, const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
                      const int32_t* comm_in, float* out, int32_t* action, float* obs /* or NULL */, float* reward, int32_t* done,
                      int32_t* alive, int32_t* is_completed, ic3_stream stream);
 

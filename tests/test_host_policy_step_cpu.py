@@ -369,10 +369,12 @@ def test_results_do_not_depend_on_the_tile_plan():
     assert crcs[0] == crcs[1], crcs
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x9"])
 @pytest.mark.parametrize("H,N,E,passes", [(64, 3, 9, 1), (128, 10, 5, 2), (256, 5, 3, 3)])
-def test_commnet_forward_nonrecurrent_module(H, N, E, passes):
+def test_commnet_forward_nonrecurrent_module(H, N, E, passes, split):
     """ic3_commnet_forward: the non-recurrent CommNet module behind the encoder, every communication pass in one launch
-    (comm.py:127-129,179-205,220-224,228-239), against oracle.policy_ref with recurrent = False."""
+    (comm.py:127-129,179-205,220-224,228-239), against oracle.policy_ref with recurrent = False; the [comm | h] product on the
+    fp32 matrix instruction (wp3 = NULL) and as exact bf16 split products (ic3_commnet_pack_split)."""
     from oracle import policy_ref
     lib = host_lib()
     heads = [2]
@@ -387,6 +389,12 @@ def test_commnet_forward_nonrecurrent_module(H, N, E, passes):
     for i in range(passes):
         cw, fw = f32(P['C_modules.%d.weight' % i]), f32(P['f_modules.%d.weight' % i])
         check(lib.ic3_commnet_pack(p(cw), p(fw), C.c_void_p(wp.ctypes.data + i * 2 * H * H * 4), H, None))
+    wp3 = None
+    if split:
+        wp3 = np.full((passes, 3 * H * H), np.nan, np.float32)
+        for i in range(passes):
+            cw, fw = f32(P['C_modules.%d.weight' % i]), f32(P['f_modules.%d.weight' % i])
+            check(lib.ic3_commnet_pack_split(p(cw), p(fw), C.c_void_p(wp3.ctypes.data + i * 3 * H * H * 4), H, None))
     bias = f32(np.stack([P['C_modules.%d.bias' % i] + P['f_modules.%d.bias' % i] for i in range(passes)]))
     head_w = f32(np.concatenate([P['heads.0.weight'], P['value_head.weight']], 0))
     head_b = f32(np.concatenate([P['heads.0.bias'], P['value_head.bias']], 0))
@@ -397,8 +405,8 @@ def test_commnet_forward_nonrecurrent_module(H, N, E, passes):
     out = np.full((E * N, 3), np.nan, np.float32)
     h_out = np.full((E * N, H), np.nan, np.float32)
     sizes = np.array(heads, np.int32)
-    check(lib.ic3_commnet_forward(p(enc), E, N, H, passes, p(wp), p(bias), p(head_w), p(head_b), p(sizes), 1, 1, 0, p(alive), None,
-                                  p(out), p(h_out), None))
+    check(lib.ic3_commnet_forward(p(enc), E, N, H, passes, p(wp), p(wp3) if split else None, p(bias), p(head_w), p(head_b), p(sizes),
+                                  1, 1, 0, p(alive), None, p(out), p(h_out), None))
     for e in range(E):
         logp, val, hh = policy_ref.forward(P, x[e][None], None, alive[e].astype(np.float64), None, recurrent=False,
                                            comm_passes=passes, hard_attn=False, nheads=1)
@@ -629,7 +637,12 @@ def commnet_weights(lib, P, H, heads, passes):
     bias = f32(np.stack([P['C_modules.%d.bias' % i] + P['f_modules.%d.bias' % i] for i in range(passes)]))
     head_w = f32(np.concatenate([P['heads.%d.weight' % k] for k in range(len(heads))] + [P['value_head.weight']], 0))
     head_b = f32(np.concatenate([P['heads.%d.bias' % k] for k in range(len(heads))] + [P['value_head.bias']], 0))
-    return dict(wp=wp, bias=bias, head_w=head_w, head_b=head_b, wt=f32(P['encoder.weight'].T), enc_bias=f32(P['encoder.bias']))
+    wp3 = np.full((passes, 3 * H * H), np.nan, np.float32)       # the same weights as three exact bf16 planes
+    for i in range(passes):
+        cw, fw = f32(P['C_modules.%d.weight' % i]), f32(P['f_modules.%d.weight' % i])
+        check(lib.ic3_commnet_pack_split(p(cw), p(fw), C.c_void_p(wp3.ctypes.data + i * 3 * H * H * 4), H, None))
+    return dict(wp=wp, wp3=wp3, bias=bias, head_w=head_w, head_b=head_b, wt=f32(P['encoder.weight'].T),
+                enc_bias=f32(P['encoder.bias']))
 
 
 @pytest.mark.parametrize("name,passes,use_table", [("pp_easy", 1, True), ("pp_hard", 2, True), ("tj_medium", 2, False),
@@ -669,7 +682,8 @@ def test_commnet_step_free_run_vs_fp64_reference_policy(name, passes, use_table)
         obs = np.full((E, N, env.obs_dim), np.nan, np.float32)
         rew, done = np.zeros((E, N), np.float32), np.zeros((E,), np.int32)
         alive, comp = np.zeros((E, N), np.int32), np.zeros((E, N), np.int32)
-        check(lib.ic3_commnet_step(env._h, p(cw['wt']), p(cw['enc_bias']), p(table), H, passes, p(cw['wp']), p(cw['bias']),
+        check(lib.ic3_commnet_step(env._h, p(cw['wt']), p(cw['enc_bias']), p(table), H, passes, p(cw['wp']),
+                                   p(cw['wp3']) if passes > 1 else None, p(cw['bias']),
                                    p(cw['head_w']), p(cw['head_b']), p(sizes), nheads, 1, 0, p(alive_in), p(gate), p(out), p(act),
                                    p(obs), p(rew), p(done), p(alive), p(comp), None))
         rec.append(dict(out=out.reshape(E, N, -1).copy(), act=act, obs=obs, rew=rew, alive=alive))
