@@ -54,6 +54,8 @@ def main():
     tr, a = bench.build_trainer(wl, E, 1, 0, 0)
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False, lrate=0.001,
                       batch_size=E * a.max_steps)
+    a.bptt_two_chains = os.environ.get('TWO_CHAINS', '1') == '1'
+    a.enc_window = os.environ.get('ENC_WINDOW', '1') == '1'
     tr.optimizer = torch.optim.RMSprop(tr.policy_net.parameters(), lr=a.lrate, alpha=0.97, eps=1e-6)
     for u in range(pre):                                   # (lock-step updates: the policy learns to end its episodes early)
         st = tr.train_batch(u // 10)
