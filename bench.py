@@ -52,6 +52,8 @@ WORKLOADS = {
                                          baseline='mlp', detach_gap=10, mode='mixed')),
     "pp_hard_iric": ("predator_prey", dict(nagents=10, dim=20, vision=1, max_steps=80, hid_size=128, recurrent=True,
                                            rnn_type='LSTM', baseline='rnn', detach_gap=10, mode='mixed')),
+    "pp_hard_iric_tanh": ("predator_prey", dict(nagents=10, dim=20, vision=1, max_steps=80, hid_size=128, recurrent=True,
+                                                rnn_type='MLP', baseline='rnn', detach_gap=10, mode='mixed')),
     "pp_scaled": ("predator_prey", dict(nagents=32, dim=40, vision=2, max_steps=80, hid_size=256, ic3net=True,
                                         recurrent=True, detach_gap=10, mode='mixed')),
 }
@@ -241,7 +243,7 @@ def mfma_roofline(a, nenvs, step_ms, gate_split=False):
     9 x the gate product's flops against the dense bf16 peak."""
     R, H = nenvs * a.nagents, a.hid_size
     OT = sum(int(x) for x in a.naction_heads) + 1
-    rec = bool(getattr(a, 'recurrent', True))
+    rec = bool(getattr(a, 'recurrent', True)) and getattr(a, 'rnn_type', 'LSTM') == 'LSTM'
     gate = 2.0 * R * (2 * H * 4 * H) if rec else 0.0
     # non-recurrent module (comm.py:220-224): per communication pass one [comm | h] . [C_i | F_i]^T product (2H x H)
     flops = gate + 2.0 * R * (H * H + H * OT) if rec else 2.0 * R * (int(a.comm_passes) * 2 * H * H + H * OT)
@@ -691,7 +693,8 @@ def main():
             hbm_kernel, hbm_bytes, hbm_ms = "policy_step_kernel", None, step_ms
             roof_note = "EXPERIMENT --incremental-obs: the launch does not rewrite the rows, so no fraction is formed over them"
         elif fused_obs:
-            hbm_kernel = ("policy_step_kernel" if a.recurrent else "commnet_forward_kernel<H, env>") + \
+            lstm_pol = bool(a.recurrent) and getattr(a, 'rnn_type', 'LSTM') == 'LSTM'      # (the tanh-recurrence RNN runs ic3_commnet_step)
+            hbm_kernel = ("policy_step_kernel" if lstm_pol else "commnet_forward_kernel<H, env>") + \
                 " (policy + draws + env.step + obs assembly in one launch)"
             hbm_bytes, hbm_ms = obs_bytes + state_bytes, step_ms
         elif step_ms and o.no_dense_obs:
@@ -731,7 +734,7 @@ def main():
             # obs-assembly kernel (ic3_env_observe: nothing but the same obs rows, zeros + non-zero entries) event-timed right
             # behind the timed region — the store stream this chip takes when nothing else runs beside it.
             R_ = o.nenvs * N
-            written = obs_bytes + R_ * ((2 * a.hid_size if a.recurrent else 0) + sum(int(x) for x in a.naction_heads) + 1
+            written = obs_bytes + R_ * ((2 * a.hid_size if lstm_pol else (a.hid_size if a.recurrent else 0)) + sum(int(x) for x in a.naction_heads) + 1
                                         + 2 * len(a.naction_heads) + 1) * 4
             ref_ms = sum(store_ref_ms) / len(store_ref_ms)
             ref_gbs = obs_bytes / (ref_ms * 1e-3) / 1e9
@@ -757,7 +760,7 @@ def main():
                                   "eager, event-timed: policy+step launch, obs launch" if step_ms else
                                   "hipGraph replay" if o.graph else "eager"),
                        "dense_obs": not o.no_dense_obs, "overlap_obs": bool(o.overlap_obs),
-                       "policy": ("one launch per step (%s)" % ("ic3_policy_step" if a.recurrent else "ic3_commnet_step"))
+                       "policy": ("one launch per step (%s)" % ("ic3_policy_step" if (a.recurrent and getattr(a, 'rnn_type', 'LSTM') == 'LSTM') else "ic3_commnet_step"))
                        if mega_live else "launch chain",
                        "auto_reset": bool(o.auto_reset),
                        "obs_rows": ("EXPERIMENT: maintained incrementally (not rewritten every step) - not the headline "

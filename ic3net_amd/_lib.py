@@ -147,7 +147,7 @@ EXPORTS = {
                             [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "ic3_commnet_step_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "ic3_commnet_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int] +
-                         [C.c_void_p] * 10),
+                         [C.c_void_p] * 12),
     "ic3_lstm_gates_backward_supported": (C.c_int, [C.c_int]),
     "ic3_lstm_gates_backward": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_heads_grad_scratch_floats": (C.c_size_t, [C.c_int]),

@@ -369,12 +369,15 @@ class CommNetMLP(nn.Module):
             return False
         return ops.commnet_step_supported(env, self.hid_size)
 
-    def step_env_commnet(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, out=None):
+    def step_env_commnet(self, env, x, info, action, reward, done, alive=None, is_completed=None, obs=None, out=None, h_in=None,
+                         h_out=None):
         """trainer.py:61-67 for the non-recurrent module in ONE launch (ic3_commnet_step): action_out, value =
         forward(x, info); `action` (heads, E, N) int32 <- the draws; env.step(action[0]) -> reward / done / alive /
-        is_completed; `obs`, when given, receives the dense observation of the state this call acts on."""
+        is_completed; `obs`, when given, receives the dense observation of the state this call acts on.  h_in / h_out (E*N, H):
+        the tanh recurrence of models.RNN on this module as its stand-in (one pass, communication off: ic3_commnet_step's h_in)."""
         tw = self._twin_for(x)
         if tw is not None:
+            assert h_in is None, "the tanh recurrence runs at the kernels' own hidden sizes"
             r = tw.step_env_commnet(env, x, info, action, reward, done, alive, is_completed, obs, out)
             self._twin_done(tw)
             return r
@@ -389,7 +392,7 @@ class CommNetMLP(nn.Module):
         if out is None:
             out = torch.empty((R, sum(heads) + 1), dtype=torch.float32, device=dev)
         ops.commnet_step(env, cn, H, heads, mode_avg, bool(self.args.comm_mask_zero), alive_in, comm_in, out, action, reward,
-                         done, alive, is_completed, obs)
+                         done, alive, is_completed, obs, h_in=h_in, h_out=h_out)
         self.commnet_steps = getattr(self, 'commnet_steps', 0) + 1
         action_out, value = self._split_out(out, batch, n)
         return action_out, value.reshape(batch, n, 1)

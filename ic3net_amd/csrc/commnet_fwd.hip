@@ -39,7 +39,9 @@ struct CommnetArgs {
     const int32_t* alive_in;   // [R] or null
     const int32_t* comm_in;    // [R] or null
     float* out;                // [R][OT]
-    float* h_out;              // [R][H] or null: the final hidden state (tests)
+    float* h_out;              // [R][H] or null: the final hidden state (tests; the tanh recurrence: h_t)
+    const float* h_in;         // [R][H] or null.  Non-null = the tanh RECURRENCE of models.RNN (models.py:68-92, rnn_type 'MLP'):
+                               // h_t = tanh(affine1(obs) + affine2(h_{t-1})): x = enc WITHOUT the tanh, h_0 = h_in (one pass, comm off)
     int E, N, EPT, passes, mode_avg, comm_zero, nheads, OT, a0, a1, a2, a3;
     // ic3_commnet_step (KIND != 0): the env side of the iteration
     const cn_f32x4* Wt;        // encoder.weight^T [obs_dim][H/4]
@@ -171,8 +173,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                 } else {
                     v = tj_encode_row_t(tj_tile_at(tile + el * tjw, N), a.tj, aa, c4, H4, encW, a.enc_bias, encL, rmask[row]);
                 }
+                if (!a.h_in) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
+                    for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
+                }
             }
             As4[row * LDA4 + H4 + c4] = v;
         }
@@ -183,8 +187,10 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
         cn_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
         if (row < rows) {
             v = *reinterpret_cast<const cn_f32x4*>(a.enc + (r0 + row) * H + 4 * c4);
+            if (!a.h_in) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
+                for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
+            }
         }
         As4[row * LDA4 + H4 + c4] = v;
     }
@@ -201,6 +207,20 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) xr[rt][reg] = As[(32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDA + H + col];
     __syncthreads();
+    if (a.h_in) {
+        // the tanh recurrence: h_0 = the state that entered the step (zero for an env that starts an episode here: auto-reset)
+        for (int idx = tid; idx < BM * H4; idx += NT) {
+            const int row = idx / H4, c4 = idx - row * H4;
+            cn_f32x4 v = { 0.f, 0.f, 0.f, 0.f };
+            if (row < rows) {
+                bool fresh = false;
+                if constexpr (KIND != 0) fresh = a.auto_reset && a.tstep[e0 + div_small(row, invN)] == 0;
+                if (!fresh) v = *reinterpret_cast<const cn_f32x4*>(a.h_in + (r0 + row) * H + 4 * c4);
+            }
+            As4[row * LDA4 + H4 + c4] = v;
+        }
+        __syncthreads();
+    }
 
     for (int pass = 0; pass < a.passes; ++pass) {
         // ---- comm_j = m_j (S_e - m_j h_j) scale_e (closed form of comm.py:181-205) -> comm half -----------------------------
@@ -530,11 +550,13 @@ extern "C" int ic3_commnet_step_supported(const ic3_env* env, int H)
 extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* enc_bias, const float* loc_table, int H,
                                 int comm_passes, const float* wp, const void* wp3, const float* bias, const float* head_w,
                                 const float* head_b, const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
-                                const int32_t* comm_in, float* out, int32_t* action, float* obs, float* reward, int32_t* done,
-                                int32_t* alive, int32_t* is_completed, ic3_stream stream)
+                                const int32_t* comm_in, const float* h_in, float* h_out, float* out, int32_t* action, float* obs,
+                                float* reward, int32_t* done, int32_t* alive, int32_t* is_completed, ic3_stream stream)
 {
     using namespace ic3;
     ic3::Range range_("ic3_commnet_step");
+    if (h_in && (!h_out || h_out == h_in || comm_passes != 1 || !comm_zero))
+        return fail(-22, "ic3_commnet_step: the tanh recurrence (h_in) takes one pass with the communication block off and h_out != h_in");
     if (!env || !enc_wt || !enc_bias || !wp || !bias || !head_w || !head_b || !head_sizes || !out || !action || !reward || !done ||
         comm_passes < 1)
         return fail(-22, "ic3_commnet_step: bad arguments");
@@ -553,6 +575,8 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
     a.alive_in = alive_in;
     a.comm_in = comm_in;
     a.out = out;
+    a.h_in = h_in;
+    a.h_out = h_out;
     a.E = env->dims.E;
     a.N = env->dims.N;
     a.EPT = 64 / a.N;

@@ -214,11 +214,43 @@ class RNN(MLP):
             self.sample_into = None          # (the Trainer's fused-draw protocol: unused here, the step launch draws itself)
         else:
             self._recur = _TanhRecurrence(self)
-            self.__dict__['_stand_in'] = None
+            # round 6: h_t = tanh(affine1(obs) + affine2(h_{t-1})) is the non-recurrent stand-in's layer with x = enc (no tanh) and
+            # h_0 = h_{t-1} (ic3_commnet_step's h_in): the whole iteration as one launch too
+            self.__dict__['_stand_in'] = _KernelStandIn(self, recurrent=False)
+
+    # ---- the tanh variant's iteration as ONE launch (ic3_commnet_step with h_in on the stand-in) -----------------------------
+    def commnet_step_ok(self, env, x):                       # (MLP's: not for a recurrent policy)
+        return False
+
+    def rnn_step_supported(self, env):
+        from . import ops
+        if self.args.rnn_type == 'LSTM' or torch.is_grad_enabled() or ops.padded_hidden(self.hid_size) is not None:
+            return False
+        n = self._stand_in.get()
+        return n is not None and hasattr(env, '_h') and getattr(self.obs_encoder, '__self__', None) is env \
+            and self.nagents == env.nagents_env and ops.commnet_step_supported(env, self.hid_size)
+
+    def rnn_step_ok(self, env, x):
+        """True when step_env_rnn() may replace forward + select_action + env.step for this input: the env's own observation, a
+        contiguous float32 (E, N, H) state on the device, hid_size 64 / 128 / 256."""
+        if not self.rnn_step_supported(env):
+            return False
+        obs, h = x
+        if not (torch.is_tensor(obs) and obs.is_cuda and torch.is_tensor(h) and h.is_cuda and h.dtype == torch.float32
+                and h.is_contiguous() and h.numel() == obs.shape[0] * self.nagents * self.hid_size):
+            return False
+        return self._stand_in.get().commnet_step_ok(env, obs)
+
+    def step_env_rnn(self, env, x, info, h_out, **kw):
+        """trainer.py:61-67 for models.RNN with the tanh recurrence in ONE launch: (action_out, value, h_t), h_t in `h_out`."""
+        n = self._stand_in.get()
+        action_out, value = n.step_env_commnet(env, x[0], info, h_in=x[1], h_out=h_out, **kw)
+        self._stand_in.done()
+        return action_out, value, h_out
 
     # ---- the LSTM variant's iteration as ONE launch (ic3_policy_step on the stand-in) ------------------------------------------
     def _kernel(self, x=None):
-        if self._stand_in is None or torch.is_grad_enabled():
+        if self._stand_in is None or self.args.rnn_type != 'LSTM' or torch.is_grad_enabled():
             return None
         if x is not None and not (torch.is_tensor(x[0]) and x[0].is_cuda):
             return None

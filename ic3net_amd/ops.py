@@ -174,7 +174,7 @@ def commnet_step_supported(env, H):
 
 
 def commnet_step(env, cn, H, head_sizes, mode_avg, comm_zero, alive_in, comm_in, out, action, reward, done, alive=None,
-                 is_completed=None, obs=None):
+                 is_completed=None, obs=None, h_in=None, h_out=None):
     """One whole rollout iteration of the NON-recurrent module (sparse encoder -> communication passes -> heads -> draws ->
     env.step, + the dense obs rows of the state acted on) in one launch — ic3_commnet_step.  `cn`: the module's derived
     weights (wt, enc_bias, loc_table, wp, bias, w_heads, b_heads; wp3 = the split planes or None: the fp32 instruction)."""
@@ -185,13 +185,15 @@ def commnet_step(env, cn, H, head_sizes, mode_avg, comm_zero, alive_in, comm_in,
     assert action.numel() == len(head_sizes) * R and out.shape[1] == sum(int(a) for a in head_sizes) + 1
     for m in (alive_in, comm_in):
         assert m is None or (m.dtype == torch.int32 and m.is_contiguous() and m.numel() == R)
+    for v in (h_in, h_out):
+        assert v is None or (v.dtype == torch.float32 and v.is_contiguous() and v.numel() == R * int(H))
     sizes = (C.c_int32 * len(head_sizes))(*[int(a) for a in head_sizes])
     check(_lib.lib().ic3_commnet_step(env._h, ptr(cn['wt']), ptr(cn['enc_bias']), ptr(cn['loc_table']), int(H),
                                       cn['wp'].shape[0], ptr(cn['wp']), ptr(cn.get('wp3')), ptr(cn['bias']), ptr(cn['w_heads']),
                                       ptr(cn['b_heads']),
                                       sizes, len(head_sizes), int(bool(mode_avg)), int(bool(comm_zero)), ptr(alive_in),
-                                      ptr(comm_in), ptr(out), ptr(action), ptr(obs), ptr(reward), ptr(done), ptr(alive),
-                                      ptr(is_completed), stream()))
+                                      ptr(comm_in), ptr(h_in), ptr(h_out), ptr(out), ptr(action), ptr(obs), ptr(reward), ptr(done),
+                                      ptr(alive), ptr(is_completed), stream()))
     return out
 
 

@@ -415,6 +415,11 @@ class Trainer(object):
                 if fuse_draw and self.clock.env is raw and getattr(self.policy_net, 'mega_ok', None) is not None \
                         and self.policy_net.mega_ok(raw, [state, self._prev_hid]):
                     return self._step_body_mega(t, observe)
+                if not torch.is_grad_enabled() and self.clock.env is raw and self.clock.env is not None and not store \
+                        and select_action is _select_action_default and args.rnn_type != 'LSTM' \
+                        and getattr(self.policy_net, 'rnn_step_ok', None) is not None \
+                        and self.policy_net.rnn_step_ok(raw, [state, self._prev_hid]):
+                    return self._step_body_rnn(t, observe)         # models.RNN, tanh recurrence: one launch too (round 6)
                 self._refresh_skipped_reset_obs(raw, t)
                 if self._auto_reset():
                     raise NotImplementedError("args.auto_reset needs the one-launch rollout step (ic3_policy_step: "
@@ -594,6 +599,52 @@ class Trainer(object):
         self._state = next_state
         self._info = info
         self._nsteps = t + 1
+
+    def _step_body_rnn(self, t, observe):
+        """The iteration of _step_body for models.RNN with the tanh recurrence (models.py:68-92, rnn_type 'MLP') through
+        RNN.step_env_rnn (ic3_commnet_step with h_in): sparse encoder, h_t = tanh(affine1(obs) + affine2(h_{t-1})), heads, the draws,
+        env.step and the dense obs rows of the state acted on are ONE launch.  h_t goes to one of two persistent buffers
+        (the one the entering state does not live in: the same sequence of addresses in every episode, so a captured step reads /
+        writes the same ones on every replay)."""
+        args, buf, state, info = self.args, self._buf, self._state, self._info
+        raw = self.env.env
+        timer = self._step_timer(raw)
+        if timer is not None:
+            from .envs import DispatchEvent
+            e0, e1 = DispatchEvent(), DispatchEvent()
+            raw.set_step_events(e0, e1)
+            timer.append((e0, e1, t))
+        E, N, H = state.shape[0], args.nagents, args.hid_size
+        pp = self._static.get('rnn_h')
+        if pp is None or tuple(pp.shape) != (2, E, N, H):
+            pp = self._static['rnn_h'] = torch.empty((2, E, N, H), dtype=torch.float32, device=state.device)
+        h_out = pp[1] if self._prev_hid.data_ptr() == pp[0].data_ptr() else pp[0]
+        action_out, value, h_t = self.policy_net.step_env_rnn(
+            raw, [state, self._prev_hid], info, h_out, action=buf['action'][t], reward=buf['reward'][t], done=buf['done'][t],
+            alive=buf['alive'][t], is_completed=buf['is_completed'][t], obs=raw._obs if observe else None,
+            out=self._static_out(t, state))
+        self._mega_last = True                                     # (the reset obs launch may be skipped: step 0 writes the rows)
+        self._prev_hid = h_t                                       # no autograd here: detach_gap is moot
+        next_state = self.env._flatten_obs(raw._obs) if hasattr(self.env, '_flatten_obs') else raw._obs
+        if raw.dims.kind == 2:                                     # TJ:244-247
+            info = {'alive_mask': buf['alive'][t], 'is_completed': buf['is_completed'][t]}
+        else:
+            info = {'alive_mask_device': buf['alive'][t]}
+        if getattr(self, '_should_display', False):                # trainer.py:101-102
+            self.env.display()
+        self._step_out[t] = (None, action_out, value, None)
+        self._state = next_state
+        self._info = info
+        self._nsteps = t + 1
+
+    def _rnn_expected(self, raw):
+        """Will step_episode go through ic3_commnet_step with h_in?  (models.RNN, tanh recurrence)"""
+        a = self.args
+        if getattr(a, 'rollout_grad', False) or not a.recurrent or a.rnn_type == 'LSTM' or self.clock.env is not raw \
+                or getattr(a, 'store_states', False) or select_action is not _select_action_default:
+            return False
+        ok = getattr(self.policy_net, 'rnn_step_supported', None)
+        return bool(ok(raw)) if ok is not None else False
 
     def _mega_now(self):
         """this episode (or, before its first step, the previous one) runs on the one-launch path"""
@@ -965,10 +1016,10 @@ class Trainer(object):
             # collection mode: episode cuts inside the windows — bptt.backward_episode handles them for every family; the
             # ROLLOUT must be a one-launch step (the launch restarts finished envs itself): ic3_policy_step for the recurrent
             # LSTM policies (CommNet / IC3Net with any number of passes, IRIC through its stand-in), ic3_commnet_step for the
-            # non-recurrent ones (CommNet, IC through its stand-in).  The tanh-recurrence RNN has no such launch.
+            # non-recurrent ones (CommNet, IC through its stand-in) and — with h_in — the tanh-recurrence RNN.
             with torch.no_grad():                                  # (the native update's rollout runs without autograd)
                 if getattr(self.args, 'recurrent', False):
-                    return getattr(self.args, 'rnn_type', '') == 'LSTM' and self._mega_expected(raw)
+                    return self._mega_expected(raw) if getattr(self.args, 'rnn_type', '') == 'LSTM' else self._rnn_expected(raw)
                 return self._commnet_expected(raw)
         return True
 

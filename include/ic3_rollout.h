@@ -594,13 +594,18 @@ int ic3_commnet_forward(const float* enc, int E, int N, int H, int comm_passes, 
  * ic3_env_sample_actions), env.step with head 0 (reward / done / alive / is_completed as ic3_env_step) and, when obs != NULL,
  * the dense observation rows [E][N][obs_dim] of the state this call ACTS ON (bit-identical to ic3_env_observe before the
  * call).  -ENOSYS when ic3_commnet_step_supported(env, H) == 0 (hid_size not 64/128/256, > 64 agents, a tile that does
- * not fit in LDS, or a handle in auto-reset mode). */
+ * not fit in LDS).  Handles in auto-reset mode are taken (an env that starts an episode: nobody dead, gate 0).
+ * h_in != NULL (round 6): the tanh RECURRENCE of the IRIC baseline (models.py:68-92, rnn_type 'MLP') as the same launch —
+ * h_t = tanh(affine1(obs) + affine2(h_{t-1})): enc_wt / enc_bias = affine1, block 0 of wp / wp3 = pack(zeros, affine2.weight), bias =
+ * affine2.bias, one pass, comm_zero != 0; h_in [E*N][H] the state entering the step (rows of an env that starts an episode are read
+ * as zero in auto-reset mode), h_out [E*N][H] (!= h_in) receives h_t.  h_in == NULL: h_out, when given, receives the module's final
+ * hidden state. */
 int ic3_commnet_step_supported(const ic3_env* env, int H);
 int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* enc_bias, const float* loc_table /* or NULL */, int H,
                      int comm_passes, const float* wp, const void* wp3 /* or NULL */, const float* bias, const float* head_w,
                      const float* head_b, const int32_t* head_sizes, int nheads, int mode_avg, int comm_zero, const int32_t* alive_in,
-                     const int32_t* comm_in, float* out, int32_t* action, float* obs /* or NULL */, float* reward, int32_t* done,
-                     int32_t* alive, int32_t* is_completed, ic3_stream stream);
+                     const int32_t* comm_in, const float* h_in /* or NULL */, float* h_out /* or NULL */, float* out, int32_t* action,
+                     float* obs /* or NULL */, float* reward, int32_t* done, int32_t* alive, int32_t* is_completed, ic3_stream stream);
 
 int ic3_policy_pack(const float* C_weight /* [H][H] */, const float* w_ih /* [4H][H] */, const float* w_hh /* [4H][H] */,
                     float* c_wp /* H*H */, float* lstm_wp /* 4H*2H */, int H, ic3_stream stream);

@@ -584,7 +584,8 @@ def grad_stream_h128_main():
 def grad_stream_families_main():
     """Collection mode for the other policy families (round-5 verdict item 6), hid 64 (a size their one-launch rollouts run at),
     closed-form weights: the NON-recurrent CommNet module with two communication passes, the gated non-recurrent module on
-    Traffic-Junction, the IC baseline (models.MLP) and the IRIC baseline with the LSTM cell (models.RNN) — on the tiny
+    Traffic-Junction, the IC baseline (models.MLP) and the IRIC baseline with the LSTM cell and with the tanh recurrence
+    (models.RNN) — on the tiny
     Predator-Prey grid where sampled policies end episodes early, and Traffic-Junction (alive masks)."""
     grad_stream_case('gradstream_pp_tiny_commnet_mlp2', 'predator_prey', 12, 6, 3, 67, closed_form=True, nagents=2, dim=3, vision=1,
                      hid_size=64, commnet=True, recurrent=False, comm_passes=2, entr=0.01, value_coeff=0.01, mode='mixed')
@@ -596,6 +597,8 @@ def grad_stream_families_main():
     grad_stream_case('gradstream_pp_tiny_iric_lstm', 'predator_prey', 12, 6, 3, 59, closed_form=True, model='rnn', nagents=2, dim=3,
                      vision=1, hid_size=64, recurrent=True, rnn_type='LSTM', detach_gap=5, entr=0.01, value_coeff=0.01,
                      mode='mixed')
+    grad_stream_case('gradstream_pp_tiny_iric_rnn', 'predator_prey', 12, 6, 3, 64, closed_form=True, model='rnn', nagents=2, dim=3,
+                     vision=1, hid_size=64, recurrent=True, rnn_type='MLP', detach_gap=5, entr=0.01, value_coeff=0.01, mode='mixed')
     grad_stream_case('gradstream_pp_tiny_ic3net_p2', 'predator_prey', 12, 6, 3, 60, closed_form=True, nagents=2, dim=3, vision=1,
                      hid_size=64, ic3net=True, recurrent=True, comm_passes=2, detach_gap=5, entr=0.01, value_coeff=0.01,
                      mode='mixed')

@@ -44,7 +44,7 @@ RECIPES = {
     'ckpt': ['make_golden_ckpt.py'],
 }
 # every committed data fixture must come out of one of the recipes above
-EXPECTED_MIN_NPZ = 73
+EXPECTED_MIN_NPZ = 74
 
 
 @pytest.fixture(scope='module')

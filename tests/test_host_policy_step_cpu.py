@@ -684,8 +684,8 @@ def test_commnet_step_free_run_vs_fp64_reference_policy(name, passes, use_table)
         alive, comp = np.zeros((E, N), np.int32), np.zeros((E, N), np.int32)
         check(lib.ic3_commnet_step(env._h, p(cw['wt']), p(cw['enc_bias']), p(table), H, passes, p(cw['wp']),
                                    p(cw['wp3']) if passes > 1 else None, p(cw['bias']),
-                                   p(cw['head_w']), p(cw['head_b']), p(sizes), nheads, 1, 0, p(alive_in), p(gate), p(out), p(act),
-                                   p(obs), p(rew), p(done), p(alive), p(comp), None))
+                                   p(cw['head_w']), p(cw['head_b']), p(sizes), nheads, 1, 0, p(alive_in), p(gate), None, None, p(out),
+                                   p(act), p(obs), p(rew), p(done), p(alive), p(comp), None))
         rec.append(dict(out=out.reshape(E, N, -1).copy(), act=act, obs=obs, rew=rew, alive=alive))
         alive_in = alive if tj else None
         if w['hard_attn']:
@@ -713,6 +713,69 @@ def test_commnet_step_free_run_vs_fp64_reference_policy(name, passes, use_table)
                 alive = o.alive.astype(np.float64)
             if w['hard_attn']:
                 g = r['act'][nheads - 1, e].astype(np.float64)
+    env.close()
+
+
+@pytest.mark.parametrize("name,split,auto", [("pp_easy", False, False), ("pp_hard", True, True), ("tj_medium", True, False)])
+def test_commnet_step_as_the_tanh_recurrence_of_the_iric_baseline(name, split, auto):
+    """ic3_commnet_step with h_in (round 6): models.RNN with the tanh recurrence (models.py:68-92) as ONE launch per step —
+    h_t = tanh(affine1(obs) + affine2(h_{t-1})), heads on h_t — free-running against float64 numpy driven by the oracle env on the
+    kernel's own actions; h_t ping-pongs between two buffers; in auto-reset mode an env that starts an episode reads h = 0
+    (its entering rows are poisoned with a large value to prove it); a call with h_out == h_in, two passes or the communication
+    block on is refused."""
+    lib = host_lib()
+    w = WORKLOADS[name]
+    E, T = min(w['E'], 4), 5
+    N, H, heads = w['N'], w['H'], w['heads'][:1]
+    tj = w['env'] == 'tj'
+    env = make_env(w, E, 5, 300)
+    P = make_params(env.obs_dim, H, heads, seed=9, comm_passes=1)
+    rng = np.random.default_rng(H)
+    A2 = (rng.standard_normal((H, H)) * 0.1).astype(np.float32).astype(np.float64)
+    b2 = (rng.standard_normal(H) * 0.1).astype(np.float32).astype(np.float64)
+    P['C_modules.0.weight'], P['C_modules.0.bias'] = np.zeros((H, H)), np.zeros(H)
+    P['f_modules.0.weight'], P['f_modules.0.bias'] = A2, b2
+    cw = commnet_weights(lib, P, H, heads, 1)
+    if auto:
+        check(lib.ic3_env_set_auto_reset(env._h, 3))          # episodes of 3 steps: restarts inside the launches
+    env.reset(0) if tj else env.reset()
+    sizes = np.array(heads, np.int32)
+    OT = sum(heads) + 1
+    hbuf = np.zeros((2, E * N, H), np.float32)
+    alive_in = None
+    W1, b1 = P['encoder.weight'], P['encoder.bias']
+    Wh = np.concatenate([P['heads.0.weight'], P['value_head.weight']], 0)
+    bh = np.concatenate([P['heads.0.bias'], P['value_head.bias']], 0)
+    h_ref = np.zeros((E * N, H))
+    worst = 0.0
+    for t in range(T):
+        out = np.full((E * N, OT), np.nan, np.float32)
+        act = np.full((1, E, N), -1, np.int32)
+        obs = np.full((E, N, env.obs_dim), np.nan, np.float32)
+        rew, done = np.zeros((E, N), np.float32), np.zeros((E,), np.int32)
+        alive, comp = np.zeros((E, N), np.int32), np.zeros((E, N), np.int32)
+        h_in, h_out = hbuf[t & 1], hbuf[(t + 1) & 1]
+        fresh = auto and t % 3 == 0 and t > 0
+        if fresh:
+            h_in[:] = 1e3                                      # what the launch must NOT read
+            h_ref[:] = 0.0
+        args = [env._h, p(cw['wt']), p(cw['enc_bias']), None, H, 1, p(cw['wp']), p(cw['wp3']) if split else None, p(cw['bias']),
+                p(cw['head_w']), p(cw['head_b']), p(sizes), 1, 1, 1, p(alive_in), None]
+        tail = [p(out), p(act), p(obs), p(rew), p(done), p(alive), p(comp), None]
+        if t == 0:
+            assert lib.ic3_commnet_step(*(args + [p(h_in), p(h_in)] + tail)) == -22          # h_out == h_in
+            assert lib.ic3_commnet_step(*(args[:14] + [0] + args[15:] + [p(h_in), p(h_out)] + tail)) == -22   # communication on
+        check(lib.ic3_commnet_step(*(args + [p(h_in), p(h_out)] + tail)))
+        x = obs.reshape(E * N, -1).astype(np.float64) @ W1.T + b1
+        h_ref = np.tanh(x + h_ref @ A2.T + b2)
+        z = h_ref @ Wh.T + bh
+        A = heads[0]
+        zl = z[:, :A] - z[:, :A].max(1, keepdims=True)
+        logp = zl - np.log(np.exp(zl).sum(1, keepdims=True))
+        worst = max(worst, np.abs(h_out - h_ref).max(), np.abs(out[:, :A] - logp).max(), np.abs(out[:, A] - z[:, A]).max())
+        assert worst < TOL, (name, t, worst)
+        h_ref = h_out.astype(np.float64)                       # (free run: follow the kernel's own state)
+        alive_in = alive if tj else None
     env.close()
 
 

@@ -372,6 +372,7 @@ GRAD_TOL = {
     "gradstream_pp_tiny_ic3net_p2":    (2.3e-05, 2.0e-06),
     "gradstream_pp_tiny_ic_mlp":       (4.0e-06, 2.0e-06),
     "gradstream_pp_tiny_iric_lstm":    (6.0e-06, 2.0e-06),
+    "gradstream_pp_tiny_iric_rnn":     (4.0e-06, 2.0e-06),
     "gradstream_tj_easy_ic3net_mlp":   (9.3e-06, 2.0e-06),
     "gradstream_pp_tiny_commnet":      (4.0e-06, 6.5e-06),
     "gradstream_pp_tiny_ic3net":       (4.0e-06, 2.0e-06),
@@ -389,7 +390,9 @@ STREAM_FIXTURES = [("gradstream_pp_tiny_ic3net", "predator_prey"), ("gradstream_
                    # module (two passes; gated on TJ), IC (models.MLP), IRIC (models.RNN, LSTM cell), IC3Net with two passes
                    ("gradstream_pp_tiny_commnet_mlp2", "predator_prey"), ("gradstream_tj_easy_ic3net_mlp", "traffic_junction"),
                    ("gradstream_pp_tiny_ic_mlp", "predator_prey"), ("gradstream_pp_tiny_iric_lstm", "predator_prey"),
-                   ("gradstream_pp_tiny_ic3net_p2", "predator_prey")]
+                   ("gradstream_pp_tiny_ic3net_p2", "predator_prey"),
+                   # IRIC with the tanh recurrence: its rollout step is one launch too (ic3_commnet_step with h_in, round 6)
+                   ("gradstream_pp_tiny_iric_rnn", "predator_prey")]
 
 
 @pytest.mark.parametrize("name,env_name", STREAM_FIXTURES)
@@ -528,14 +531,15 @@ def test_baseline_policies_through_trainer(kind, rnn_type):
     assert np.isfinite(st['action_loss']) and not torch.equal(before, net.affine1.weight)
 
 
-@pytest.mark.parametrize("kind", ["mlp", "lstm"])
+@pytest.mark.parametrize("kind", ["mlp", "lstm", "tanh"])
 def test_baselines_roll_out_in_one_launch_like_the_launch_chain(kind):
-    """IC / IRIC baselines (models.MLP; models.RNN with the LSTM cell) on the one-launch kernels through their stand-ins
+    """IC / IRIC baselines (models.MLP; models.RNN with the LSTM cell; round 6: models.RNN with the tanh recurrence, through
+    ic3_commnet_step's h_in) on the one-launch kernels through their stand-ins
     (ic3net_amd/models.py: the non-recurrent / recurrent CommNet module with the communication block off): the episode equals
     the launch chain's (same draws off CDF edges, values / log-probs to 1e-5), the native update's gradients too, and the
     update moves the baseline's own parameters."""
     import bench
-    wl = 'pp_hard_ic' if kind == 'mlp' else 'pp_hard_iric'
+    wl = {'mlp': 'pp_hard_ic', 'lstm': 'pp_hard_iric', 'tanh': 'pp_hard_iric_tanh'}[kind]
 
     def play(mega):
         tr, a = bench.build_trainer(wl, 24, 3, 0, 0, max_steps=12)
@@ -548,7 +552,7 @@ def test_baselines_roll_out_in_one_launch_like_the_launch_chain(kind):
         return tr, a, act, val, lp, rew
 
     tr1, a1, act1, val1, lp1, rew1 = play(True)
-    used = getattr(tr1.policy_net, 'commnet_steps' if kind == 'mlp' else 'mega_steps', 0)
+    used = getattr(tr1.policy_net, 'mega_steps' if kind == 'lstm' else 'commnet_steps', 0)
     assert used == 12, "the one-launch path did not run"
     tr0, a0, act0, val0, lp0, rew0 = play(False)
     assert getattr(tr0.policy_net, 'commnet_steps', 0) == 0 and getattr(tr0.policy_net, 'mega_steps', 0) == 0
@@ -957,9 +961,9 @@ def test_backward_as_two_chains_and_with_the_encoder_window_form(wl, collect, hi
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
     episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)
-    for every policy family whose rollout step is ONE launch (round 6; the launch restarts finished envs itself); the tanh-recurrence
-    RNN baseline has no such launch and train_batch must not take the native path (the rollout then raises its explicit
-    NotImplementedError); and hid
+    for every policy family whose rollout step is ONE launch (round 6; the launch restarts finished envs itself); a tanh-recurrence
+    RNN baseline at a hidden size the kernels do not take has no such launch and train_batch must not take the native path (the
+    rollout then raises its explicit NotImplementedError); and hid
     sizes ic3_lstm_cell_backward does not take (H / 4 not a power of two <= 64) keep the autograd update instead of failing
     inside it."""
     import bench
@@ -972,7 +976,10 @@ def test_native_update_is_not_taken_where_it_does_not_apply():
     assert trp._native_update()
     ap.auto_reset = True
     assert trp._native_update()          # (round 6: every family with a one-launch rollout step — test_collection_mode_grad_...)
-    trr, ar = bench.build_trainer('pp_hard_iric', 8, 1, 0, 0, rnn_type='MLP')     # the tanh-recurrence RNN has no such launch
+    trk, ak = bench.build_trainer('pp_hard_iric', 8, 1, 0, 0, rnn_type='MLP')     # the tanh-recurrence RNN: one launch too (round 6, later)
+    ak.auto_reset = True
+    assert trk._native_update()
+    trr, ar = bench.build_trainer('pp_hard_iric', 8, 1, 0, 0, rnn_type='MLP', hid_size=96)   # ... at the kernels' own sizes only
     assert trr._native_update()
     ar.auto_reset = True
     assert not trr._native_update()
