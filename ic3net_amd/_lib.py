@@ -173,6 +173,9 @@ EXPORTS = {
     "ic3_env_set_step_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ic3_episode_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ic3_episode_finalize": (C.c_int, [C.POINTER(Episode), C.c_void_p]),
+    "ic3_loss_gradients_partials": (C.c_int, [C.c_longlong, C.c_longlong]),
+    "ic3_loss_gradients": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ic3_returns_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]),
     "ic3_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

@@ -87,12 +87,16 @@ class EpisodeRecord(object):
         self.xh = None
         self.gates_n = 0
         self.stream = None     # collection mode (Trainer._run_batch_streams): per-slot cuts of the recurrence, see backward_episode
+        # (T, R, OT) the [log-probs | value] rows of every step, written by the one-launch steps themselves (Trainer hands slice t
+        # as their `out`); out_n = the steps that did
+        self.out = None
+        self.out_n = 0
 
     def release(self):
         """Drop the record's tensors now (tens of GB with recorded gates): the update is done with them, and whatever still
         refers to the record object — a reference cycle waiting for the garbage collector — must not keep them alive beside
         the next update's record."""
-        self.hs = self.cs = self.gates = self.xh = self.snaps = self.h_last = None
+        self.hs = self.cs = self.gates = self.xh = self.snaps = self.h_last = self.out = None
         self.alive, self.gate, self.stream = [], [], None
 
     def start_from(self, h, c):
@@ -176,14 +180,45 @@ def _returns(args, rewards, episode_masks, episode_mini_masks):
     return args.mean_ratio * coop_returns.mean(dim=2, keepdim=True) + (1 - args.mean_ratio) * ncoop_returns
 
 
-def loss_gradients(args, batch):
+def _recorded_out(records, T):
+    """The (T, R, OT) rows the step launches of the batch's episodes wrote, when every step wrote into its record's buffer
+    (Trainer: EpisodeRecord.out) — no stack of T x heads views then."""
+    if not records or any(getattr(r, 'out', None) is None or r.out_n != r.n for r in records) or sum(r.n for r in records) != T:
+        return None
+    return records[0].out[:records[0].n] if len(records) == 1 else torch.cat([r.out[:r.n] for r in records])
+
+
+def loss_gradients(args, batch, records=None):
     """trainer.py:128-218 up to the losses: returns (stat, d_out) with d_out (T, R, OT) = dL/d[logits of every head |
-    value] of every transition (the log-softmax is folded in: gradients w.r.t. its INPUT)."""
+    value] of every transition (the log-softmax is folded in: gradients w.r.t. its INPUT).  On the device, with the step
+    launches' rows at hand (`records`) and at most four heads: ONE launch (ic3_loss_gradients) behind the return scan; the tensor
+    program below is the same arithmetic (tests/test_trainer_gpu.py compares them)."""
     n = args.nagents
     rewards = torch.stack(batch.reward)                                   # (T, E, N)
     T, E = rewards.shape[0], rewards.shape[1]
     episode_masks = torch.stack(batch.episode_mask)
     episode_mini_masks = torch.stack(batch.episode_mini_mask)
+    out_rows = _recorded_out(records, T) if (rewards.is_cuda and bool(getattr(args, 'fused_loss', True))) else None
+    if out_rows is not None and len(batch.action_out[0]) <= 4 and rewards.dtype == torch.float32:
+        actions = torch.stack(batch.action).reshape(T, -1, E * n)             # (T, heads, R) int32
+        alive_masks = torch.stack([m['alive_mask'] for m in batch.misc]).reshape(T, E * n)
+        live = torch.stack([m['live'] for m in batch.misc])                   # (T, E)
+        returns = _returns(args, rewards, episode_masks, episode_mini_masks).reshape(T, E * n)
+        shift, scale = 0.0, 1.0
+        if args.normalize_rewards:                                        # trainer.py:176-177 (live entries only)
+            lv = live.unsqueeze(2).expand(T, E, n).reshape(T, E * n)
+            adv = returns - out_rows[:, :, -1]
+            cnt = lv.sum()
+            mean = (adv * lv).sum() / cnt
+            var = (((adv - mean) ** 2) * lv).sum() / (cnt - 1)
+            shift, scale = float(mean), float(1.0 / var.sqrt())
+        if actions.dtype != torch.int32:
+            actions = actions.int()
+        d_out, sums = ops.loss_gradients(out_rows, actions.contiguous(), returns.contiguous(), alive_masks.contiguous(),
+                                         live.contiguous(), [int(a) for a in args.naction_heads], float(args.entr),
+                                         float(args.value_coeff), shift, scale)
+        sums = sums.tolist()
+        return dict(action_loss=sums[0], value_loss=sums[1], entropy=sums[2]), d_out
     actions = torch.stack(batch.action).permute(0, 2, 3, 1).long()        # (T, E, N, heads)
     values = torch.stack([v.reshape(E, n) for v in batch.value])          # (T, E, N)
     nheads = len(batch.action_out[0])

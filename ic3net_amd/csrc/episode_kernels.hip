@@ -205,11 +205,131 @@ __global__ __launch_bounds__(EF_THREADS) void returns_scan_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ic3_loss_gradients — compute_grad's losses and what they hand back to the policy's outputs (/root/reference/trainer.py:173-218),
+// one thread per transition row (slot t, agent row r), in ONE launch instead of ~40 elementwise / gather / scatter / reduce
+// launches:  adv = (returns - value - shift) * scale  (normalize_rewards: shift / scale from the caller, else 0 / 1);
+//   action_loss = sum -adv * (sum_k logp_k[a_k]) * alive        value_loss = sum (value - returns)^2 * alive
+//   entropy     = sum_k sum_o -logp_k[o] exp(logp_k[o]) * live  (no alive mask there, trainer.py:211-218)
+//   d_out[k][o] = dlp_o - exp(logp_o) * sum_o' dlp_o',  dlp_o = [o == a_k] (-adv * alive) + entr * live * exp(logp_o) (logp_o + 1)
+//   d_out[value] = 2 * value_coeff * (value - returns) * alive          (the log-softmax folded in: gradients w.r.t. its INPUT)
+// The three sums: per-workgroup partials in double (fixed order inside a workgroup), summed by the caller.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LossGradArgs {
+    const float* out;        // [T][R][OT] = [log-probs of every head | value]
+    const int32_t* action;   // [T][nheads][R]
+    const float* returns;    // [T][R]
+    const float* alive;      // [T][R]  (already times live)
+    const float* live;       // [T][E]
+    float* d_out;            // [T][R][OT]
+    double* sums;            // [gridDim.x][3]
+    long long M;             // T * R
+    int R, N, OT, nheads, a0, a1, a2, a3;
+    float shift, scale, entr, value_coeff;
+};
+__global__ __launch_bounds__(256) void loss_gradients_kernel(const LossGradArgs a)
+{
+    __shared__ double red[3][4];
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    double s_act = 0.0, s_val = 0.0, s_ent = 0.0;
+    if (m < a.M) {
+        const long long t = m / a.R;
+        const int r = (int)(m - t * a.R), e = r / a.N;
+        const float* o = a.out + m * a.OT;
+        float* d = a.d_out + m * a.OT;
+        const float value = o[a.OT - 1], ret = a.returns[m], al = a.alive[m], lv = a.live[t * (a.R / a.N) + e];
+        const float adv = (ret - value - a.shift) * a.scale;
+        const float w = -adv * al;
+        const int sizes[4] = { a.a0, a.a1, a.a2, a.a3 };
+        int off = 0;
+        float lp_sum = 0.f;
+        for (int k = 0; k < a.nheads; ++k) {
+            const int A = sizes[k], act = a.action[(t * a.nheads + k) * a.R + r];
+            float dsum = 0.f, ent = 0.f;
+            for (int j = 0; j < A; ++j) {                         // (A <= 15: the row's logits are read twice, from L1)
+                const float lp = o[off + j], p = expf(lp);
+                float dl = (j == act) ? w : 0.f;
+                if (a.entr > 0.f) dl += a.entr * lv * p * (lp + 1.0f);
+                dsum += dl;
+                ent -= lp * p;
+            }
+            for (int j = 0; j < A; ++j) {
+                const float lp = o[off + j], p = expf(lp);
+                float dl = (j == act) ? w : 0.f;
+                if (a.entr > 0.f) dl += a.entr * lv * p * (lp + 1.0f);
+                d[off + j] = dl - p * dsum;
+            }
+            lp_sum += o[off + act];
+            s_ent += (double)(ent * lv);
+            off += A;
+        }
+        d[a.OT - 1] = 2.0f * a.value_coeff * (value - ret) * al;
+        s_act = (double)(-adv * lp_sum * al);
+        s_val = (double)((value - ret) * (value - ret) * al);
+    }
+    // workgroup sums: lanes by shuffles, the four waves through LDS, in a fixed order
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        s_act += __shfl_xor(s_act, sh);
+        s_val += __shfl_xor(s_val, sh);
+        s_ent += __shfl_xor(s_ent, sh);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wv] = s_act;
+        red[1][wv] = s_val;
+        red[2][wv] = s_ent;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        a.sums[(size_t)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 }  // namespace ic3
 
 using namespace ic3;
 
 extern "C" {
+
+int ic3_loss_gradients_partials(long long T, long long R) { return (T <= 0 || R <= 0) ? 0 : (int)((T * R + 255) / 256); }
+
+int ic3_loss_gradients(const float* out, const int32_t* action, const float* returns, const float* alive_mask, const float* live,
+                       const int32_t* head_sizes, int nheads, float adv_shift, float adv_scale, float entr, float value_coeff,
+                       float* d_out, double* sums, int T, int E, int N, ic3_stream stream)
+{
+    Range range("ic3_loss_gradients");
+    if (!out || !action || !returns || !alive_mask || !live || !head_sizes || !d_out || !sums) return fail(-22, "ic3_loss_gradients: null argument");
+    if (T <= 0 || E <= 0 || N <= 0 || nheads < 1 || nheads > 4) return fail(-22, "ic3_loss_gradients: T, E, N > 0, 1..4 heads");
+    LossGradArgs a{};
+    int sz[4] = { 0, 0, 0, 0 };
+    a.OT = 1;
+    for (int k = 0; k < nheads; ++k) {
+        sz[k] = head_sizes[k];
+        if (sz[k] < 1) return fail(-22, "ic3_loss_gradients: empty action head");
+        a.OT += sz[k];
+    }
+    a.out = out;
+    a.action = action;
+    a.returns = returns;
+    a.alive = alive_mask;
+    a.live = live;
+    a.d_out = d_out;
+    a.sums = sums;
+    a.R = E * N;
+    a.N = N;
+    a.M = (long long)T * a.R;
+    a.nheads = nheads;
+    a.a0 = sz[0];
+    a.a1 = sz[1];
+    a.a2 = sz[2];
+    a.a3 = sz[3];
+    a.shift = adv_shift;
+    a.scale = adv_scale;
+    a.entr = entr;
+    a.value_coeff = value_coeff;
+    hipLaunchKernelGGL(loss_gradients_kernel, dim3(ic3_loss_gradients_partials(T, a.R)), dim3(256), 0, (hipStream_t)stream, a);
+    IC3_HIP(hipGetLastError());
+    return 0;
+}
 
 int ic3_returns_scan(const float* reward, const float* episode_mask, const float* episode_mini_mask, float gamma, float mean_ratio,
                      float* returns, int T, int E, int N, ic3_stream stream)

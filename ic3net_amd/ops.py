@@ -633,6 +633,29 @@ def returns_scan(rewards, episode_masks, episode_mini_masks, gamma, mean_ratio):
     return out
 
 
+def loss_gradients(out, action, returns, alive_mask, live, head_sizes, entr, value_coeff, adv_shift=0.0, adv_scale=1.0):
+    """compute_grad's losses and dL/d[logits | value] of every transition in one launch (ic3_loss_gradients): out (T, R, OT) the
+    step launches' rows, action (T, heads, R) int32, returns / alive_mask (T, R), live (T, E).  Returns (d_out (T, R, OT),
+    (action_loss, value_loss, entropy) as a float64 tensor of 3 on the device)."""
+    import ctypes as C
+    _need_cuda(out, "loss_gradients")
+    T, R, OT = out.shape
+    E = live.shape[1]
+    N = R // E
+    nh = len(head_sizes)
+    assert OT == sum(int(a) for a in head_sizes) + 1 and tuple(action.shape) == (T, nh, R) and action.dtype == torch.int32
+    for v in (out, action, returns, alive_mask, live):
+        assert v.is_contiguous()
+    assert returns.numel() == T * R == alive_mask.numel() and live.numel() == T * E and E * N == R
+    d_out = torch.empty_like(out)
+    sums = torch.empty((int(_lib.lib().ic3_loss_gradients_partials(T, R)), 3), dtype=torch.float64, device=out.device)
+    sizes = (C.c_int32 * nh)(*[int(a) for a in head_sizes])
+    check(_lib.lib().ic3_loss_gradients(ptr(out), ptr(action), ptr(returns), ptr(alive_mask), ptr(live), sizes, nh,
+                                        float(adv_shift), float(adv_scale), float(entr), float(value_coeff), ptr(d_out), ptr(sums),
+                                        T, E, N, stream()))
+    return d_out, sums.sum(0)
+
+
 def lstm_cell_heads_ok(H):
     """ic3_lstm_cell_heads needs H/4 to be a power of two <= 64."""
     return H % 4 == 0 and H // 4 <= 64 and (H // 4) & (H // 4 - 1) == 0

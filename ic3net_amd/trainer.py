@@ -552,6 +552,16 @@ class Trainer(object):
         played in graph mode: action_out / value of a Transition are views of it and are overwritten by the next episode —
         graph-mode rollouts feed statistics, never an update (_use_graph() is False while records are collected, and
         compute_grad refuses a no-grad batch).  Eager mode: None (a fresh tensor per call, a Transition keeps its action_out)."""
+        if self._rec is not None and not self._use_graph():
+            # native update: the rows of every step of the episode in ONE buffer of its record — compute_grad's losses then read
+            # them in place (ic3_loss_gradients) instead of stacking T x heads views
+            rec = self._rec
+            OT = sum(int(o) for o in self.args.naction_heads) + 1
+            if rec.out is None:
+                rec.out = torch.empty((self.args.max_steps, state.shape[0] * self.args.nagents, OT), dtype=torch.float32,
+                                      device=state.device)
+            rec.out_n += 1
+            return rec.out[t]
         if not self._use_graph():
             return None
         args = self.args
@@ -1038,7 +1048,7 @@ class Trainer(object):
     def compute_grad_native(self, batch, records):
         """compute_grad() without an autograd graph: losses and dL/d(logits, value) from the batch, then
         bptt.backward_episode over every recorded episode; fills p.grad like loss.backward() would."""
-        stat, d_out = bptt.loss_gradients(self.args, batch)
+        stat, d_out = bptt.loss_gradients(self.args, batch, records)
         knet = self._kernel_net()
         kargs = self.args if knet is self.policy_net else knet.args
         acc = bptt.new_accumulators(knet)

@@ -295,6 +295,17 @@ int ic3_episode_finalize(const ic3_episode* ep, ic3_stream stream);
  *   coop[t] = reward[t] + gamma * coop[t+1] * episode_mask[t];   ncoop[t] = reward[t] + gamma * ncoop[t+1] * episode_mask[t] *
  *   episode_mini_mask[t];   returns[t][e][n] = mean_ratio * mean_n coop[t][e][:] + (1 - mean_ratio) * ncoop[t][e][n]
  * reward, episode_mini_mask, returns [T][E][N] f32; episode_mask [T][E] f32.  N <= 256. */
+/* compute_grad's losses and the gradients they hand back to the policy's outputs (trainer.py:173-218) in ONE launch (round 6):
+ * out [T][E*N][OT] = the rows the step launches wrote ([log-probs of every head | value]), action [T][nheads][E*N], returns
+ * [T][E*N] (ic3_returns_scan's), alive_mask [T][E*N] (already times live), live [T][E]; advantages = (returns - value - adv_shift) *
+ * adv_scale (normalize_rewards: the caller's mean and 1 / std over the live entries; else 0 and 1).  d_out [T][E*N][OT] receives
+ * dL/d[logits of every head | value] with the log-softmax folded in (gradients w.r.t. its input), L = action_loss + value_coeff *
+ * value_loss - entr * entropy; sums [ic3_loss_gradients_partials(T, E*N)][3] doubles = per-workgroup partial sums of (action_loss,
+ * value_loss, entropy): the caller adds them up. */
+int ic3_loss_gradients_partials(long long T, long long R);
+int ic3_loss_gradients(const float* out, const int32_t* action, const float* returns, const float* alive_mask, const float* live,
+                       const int32_t* head_sizes, int nheads, float adv_shift, float adv_scale, float entr, float value_coeff,
+                       float* d_out, double* sums, int T, int E, int N, ic3_stream stream);
 int ic3_returns_scan(const float* reward, const float* episode_mask, const float* episode_mini_mask, float gamma, float mean_ratio,
                      float* returns, int T, int E, int N, ic3_stream stream);
 

@@ -323,6 +323,8 @@ inline float __shfl(float v, int src)
     std::memcpy(&v, &i, 4);
     return v;
 }
+inline double __shfl(double v, int src);          // (defined below: visible to the templates' overload resolution)
+inline unsigned __shfl(unsigned v, int src);
 template <class T>
 inline T __shfl_xor(T v, int m) { return __shfl(v, ic3_host::tl_lane ^ m); }
 // DPP row operations of group_sum<G> (quad_perm / row_half_mirror / row_mirror): the lane each control reads from

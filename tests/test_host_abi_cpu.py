@@ -245,6 +245,63 @@ def test_encoder_backward_over_a_window_of_states_in_one_launch(kind, cfg):
     env.close()
 
 
+@pytest.mark.parametrize("T,E,N,heads,entr,norm", [(7, 9, 3, [5, 2], 0.01, False), (11, 30, 10, [5], 0.0, True), (3, 2, 20, [2, 2, 3], 0.1, False)])
+def test_loss_gradients_in_one_launch_on_the_host(T, E, N, heads, entr, norm):
+    """ic3_loss_gradients == the losses of /root/reference/trainer.py:173-218 and their gradients w.r.t. [logits | value] (float64
+    numpy, the log-softmax folded in): rows of (slot, agent), 257+ rows so that several workgroups' partials are summed."""
+    from host_abi_util import check, host_lib, p
+    lib = host_lib()
+    rng = np.random.default_rng(T * 100 + E)
+    R, OT, nh = E * N, sum(heads) + 1, len(heads)
+    logits = rng.standard_normal((T, R, OT))
+    out = np.empty((T, R, OT), np.float32)
+    off = 0
+    for A in heads:
+        z = logits[:, :, off:off + A]
+        out[:, :, off:off + A] = z - np.log(np.exp(z).sum(2, keepdims=True))
+        off += A
+    out[:, :, off] = logits[:, :, off]
+    action = np.stack([rng.integers(0, A, size=(T, R)) for A in heads], 1).astype(np.int32)        # (T, heads, R)
+    returns = rng.standard_normal((T, R)).astype(np.float32)
+    live = (rng.random((T, E)) < 0.8).astype(np.float32)
+    alive = ((rng.random((T, R)) < 0.9) * np.repeat(live, N, axis=1)).astype(np.float32)
+    vc = 0.03
+    o64, ret, al, lv = out.astype(np.float64), returns.astype(np.float64), alive.astype(np.float64), np.repeat(live, N, axis=1).astype(np.float64)
+    adv = ret - o64[:, :, -1]
+    shift, scale = 0.0, 1.0
+    if norm:
+        cnt = lv.sum()
+        shift = float((adv * lv).sum() / cnt)
+        scale = float(1.0 / np.sqrt((((adv - shift) ** 2) * lv).sum() / (cnt - 1)))
+    adv = (adv - shift) * scale
+    want = np.zeros((T, R, OT))
+    act_loss = ent = 0.0
+    off = 0
+    for k, A in enumerate(heads):
+        lp = o64[:, :, off:off + A]
+        onehot = np.eye(A)[action[:, k]]
+        dlp = onehot * (-adv * al)[:, :, None] + entr * lv[:, :, None] * np.exp(lp) * (lp + 1.0) * (entr > 0)
+        want[:, :, off:off + A] = dlp - np.exp(lp) * dlp.sum(2, keepdims=True)
+        act_loss += (-adv * (lp * onehot).sum(2) * al).sum()
+        ent -= (lp * np.exp(lp) * lv[:, :, None]).sum()
+        off += A
+    want[:, :, off] = 2.0 * vc * (o64[:, :, -1] - ret) * al
+    val_loss = (((o64[:, :, -1] - ret) ** 2) * al).sum()
+    nparts = int(lib.ic3_loss_gradients_partials(T, R))
+    assert nparts == (T * R + 255) // 256
+    d_out = np.full((T, R, OT), np.nan, np.float32)
+    sums = np.full((nparts, 3), np.nan, np.float64)
+    sizes = np.array(heads, np.int32)
+    check(lib.ic3_loss_gradients(p(out), p(action), p(returns), p(alive), p(live), p(sizes), nh, C.c_float(shift), C.c_float(scale),
+                                 C.c_float(entr), C.c_float(vc), p(d_out), p(sums), T, E, N, None))
+    np.testing.assert_allclose(d_out, want, rtol=0, atol=2e-6 * max(1.0, np.abs(want).max()))
+    got = sums.sum(0)
+    for g, w_ in zip(got, (act_loss, val_loss, ent)):
+        assert abs(g - w_) <= 2e-6 * max(1.0, abs(w_)), (got, act_loss, val_loss, ent)
+    assert lib.ic3_loss_gradients(p(out), p(action), p(returns), p(alive), p(live), p(sizes), 5, C.c_float(0), C.c_float(1),
+                                  C.c_float(0), C.c_float(vc), p(d_out), p(sums), T, E, N, None) == -22      # at most four heads
+
+
 @pytest.mark.parametrize("T,E,N,gamma,ratio", [(9, 7, 3, 1.0, 0.0), (12, 30, 10, 0.9, 0.5), (5, 3, 64, 1.0, 1.0)])
 def test_returns_scan_on_the_host(T, E, N, gamma, ratio):
     """ic3_returns_scan == the loop of /root/reference/trainer.py:162-171 (float64)."""

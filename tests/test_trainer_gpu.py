@@ -958,6 +958,34 @@ def test_backward_as_two_chains_and_with_the_encoder_window_form(wl, collect, hi
             assert err <= 1e-5 * max(1e-3, float(g1.abs().max())), (k, err, float(g1.abs().max()))
 
 
+@pytest.mark.parametrize("wl,norm,entr", [("pp_hard", False, 0.0), ("tj_medium", True, 0.01), ("pp_hard_ic", False, 0.01)])
+def test_losses_and_their_gradients_in_one_launch_equal_the_tensor_program(wl, norm, entr):
+    """ic3_loss_gradients (round 6: compute_grad's losses, trainer.py:173-218, and dL/d[logits | value] of every transition in ONE
+    launch on the rows the step launches wrote into the episode record) against the tensor program it replaces
+    (args.fused_loss = False) on the same batch: the three losses to 1e-6 relative, d_out to 1e-6 of its scale."""
+    import bench
+    from ic3net_amd import bptt
+    tr, a = bench.build_trainer(wl, 40, 3, 0, 0, max_steps=12)
+    a.__dict__.update(gamma=0.95, normalize_rewards=norm, entr=entr, value_coeff=0.02, advantages_per_action=False,
+                      batch_size=40 * 12)
+    assert tr._native_update()
+    tr._records = []
+    try:
+        batch, stats = tr.run_batch(0)
+        recs = tr._records
+        assert recs[0].out is not None and recs[0].out_n == recs[0].n == 12
+        with torch.no_grad():
+            s1, d1 = bptt.loss_gradients(a, batch, recs)
+            a.fused_loss = False
+            s0, d0 = bptt.loss_gradients(a, batch, recs)
+    finally:
+        tr._records = None
+    for k in ("action_loss", "value_loss", "entropy"):
+        assert abs(s1[k] - s0[k]) <= 1e-6 * max(1.0, abs(s0[k])), (k, s1[k], s0[k])
+    assert d1.shape == d0.shape
+    assert float((d1 - d0).abs().max()) <= 1e-6 * max(1.0, float(d0.abs().max()))
+
+
 def test_native_update_is_not_taken_where_it_does_not_apply():
     """Round-3 advisor findings: with args.auto_reset the recorded (h, c) / masks of a restarted env belong to the previous
     episode — since round 5 the explicit backward CUTS there (collection mode, test_collection_mode_grad_matches_reference)

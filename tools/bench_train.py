@@ -25,6 +25,7 @@ def main():
     a.auto_reset = bool(coll)
     a.native_update = mode == 'native'
     a.bptt_two_chains = os.environ.get('TWO_CHAINS', '1') == '1'     # A/B: the backward's launches as two concurrent chains of envs
+    a.fused_loss = os.environ.get('FUSED_LOSS', '1') == '1'           # A/B: compute_grad's losses + their gradients as one launch
     a.enc_window = os.environ.get('ENC_WINDOW', '1') == '1'           # A/B: the encoder backward's stage 1 once per window
     a.__dict__.update(gamma=1.0, normalize_rewards=False, entr=0, value_coeff=0.01, advantages_per_action=False,
                       batch_size=E * a.max_steps)
