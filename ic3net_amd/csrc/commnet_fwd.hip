@@ -65,13 +65,18 @@ struct CommnetArgs {
 // product is throughput work): 3 outside the [comm | h] product, 0 inside.
 #define CN_PRIO(p) __builtin_amdgcn_s_setprio(p)
 
-template <int H, int KIND = 0>
-__global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_kernel(const CommnetArgs a)
+// NARROW (round 6): one pass with the communication block off and split products — the IC baseline's stand-in and the tanh
+// recurrence — keeps only the h half of the A tile (33.8 instead of 66.5 KB at H = 128; the heads' weights in a region of their
+// own): THREE workgroups per CU instead of two, so that the obs stores of one tile overlap the matrix work / dependent chains of
+// two others (the kernel has no in-stream store pacing: a tile's stores and its products do not overlap inside a workgroup).
+template <int H, int KIND = 0, bool NARROW = false>
+__global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void commnet_forward_kernel(const CommnetArgs a)
 {
     CN_PRIO(3);
-    constexpr int K = 2 * H, LDA = K + 4, LDA4 = LDA / 4, NT = 2 * H, H4 = H / 4, KB = K / 8, BM = 64;
+    constexpr int K = 2 * H, LDA = (NARROW ? H : K) + 4, LDA4 = LDA / 4, NT = 2 * H, H4 = H / 4, KB = K / 8, BM = 64;
+    constexpr int HO = NARROW ? 0 : H, HO4 = HO / 4;             // column of the h half inside the tile
     IC3_DYNAMIC_LDS(float, smem);
-    float* const As = smem;                                      // [BM][LDA]: cols [0,H) comm, [H,2H) h
+    float* const As = smem;                                      // [BM][LDA]: cols [0,H) comm, [H,2H) h  (NARROW: h alone)
     cn_f32x4* const As4 = reinterpret_cast<cn_f32x4*>(smem);
     float* const sm = As + BM * LDA;                             // [BM] m_j = alive_j * comm_action_j
     float* const sscale = sm + BM;                               // [BM] per-env 1 / (n_alive - 1)
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                     for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
                 }
             }
-            As4[row * LDA4 + H4 + c4] = v;
+            As4[row * LDA4 + HO4 + c4] = v;
         }
     } else {
     // ---- x = tanh(enc) -> h half (comm.py:127-129) ---------------------------------------------------------------------------
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                 for (int q = 0; q < 4; ++q) v[q] = fast_tanh(v[q]);
             }
         }
-        As4[row * LDA4 + H4 + c4] = v;
+        As4[row * LDA4 + HO4 + c4] = v;
     }
     }
     __syncthreads();
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) xr[rt][reg] = As[(32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDA + H + col];
+        for (int reg = 0; reg < 16; ++reg) xr[rt][reg] = As[(32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * LDA + HO + col];
     __syncthreads();
     if (a.h_in) {
         // the tanh recurrence: h_0 = the state that entered the step (zero for an env that starts an episode here: auto-reset)
@@ -217,14 +222,14 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
                 if constexpr (KIND != 0) fresh = a.auto_reset && a.tstep[e0 + div_small(row, invN)] == 0;
                 if (!fresh) v = *reinterpret_cast<const cn_f32x4*>(a.h_in + (r0 + row) * H + 4 * c4);
             }
-            As4[row * LDA4 + H4 + c4] = v;
+            As4[row * LDA4 + HO4 + c4] = v;
         }
         __syncthreads();
     }
 
     for (int pass = 0; pass < a.passes; ++pass) {
         // ---- comm_j = m_j (S_e - m_j h_j) scale_e (closed form of comm.py:181-205) -> comm half -----------------------------
-        {
+        if constexpr (!NARROW) {
             const int c4 = tid % H4;
             for (int el = tid / H4; el < nenv; el += NT / H4) {
                 const cn_f32x4* hp = As4 + (el * N) * LDA4 + H4 + c4;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][i] = 0.0f;
-        if (a.wp3) {
+        if (NARROW || a.wp3) {
             // the product as nine exact bf16 x bf16 products per fp32 product (policy_step_kernel's gate_split):
             // the weights' three planes in fragment order, Wp3[pass][plane][kb16][wave][lane] x 16 bytes, one 16-k block ahead in
             // registers; the activations split per wave from the fp32 LDS tile (ps_split_frag).  9 x 32 cycles per 16 k against
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
             auto wb = [&](int pl, int kb) __attribute__((always_inline)) {
                 return __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, ((pl * KB16 + kb) * NWv + wu) * 1024, 0);
             };
-            const int kb0 = a.comm_zero ? KB16 / 2 : 0;          // (comm_mask_zero / the IC stand-in: the comm half is all zeros)
+            const int kb0 = (NARROW || a.comm_zero) ? KB16 / 2 : 0;   // (comm_mask_zero / the IC stand-in: the comm half is all zeros)
+            constexpr int AOFF = NARROW ? H4 : 0;                // (NARROW: the tile starts at k = H)
             ps_u32x4 bq[3], bn[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bq[pl] = wb(pl, kb0);
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bn[pl] = wb(pl, kb + 1);                      // (past the end: zeros, never used)
                 ps_u32x4 ap[2][3];
-                const cn_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh;
-                const cn_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh;
+                const cn_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh - AOFF;
+                const cn_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh - AOFF;
                 ps_split_frag(s0[0], s0[1], ap[0]);
                 ps_split_frag(s1[0], s1[1], ap[1]);
 #pragma unroll
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bq[pl] = bn[pl];
             }
-        } else {
+        } else if constexpr (!NARROW) {
         const cn_f32x4* wp = reinterpret_cast<const cn_f32x4*>(a.wp) + (size_t)pass * (K * H / 4) + col * 2 + lh;
         constexpr int CH = 8;
         static_assert(KB % CH == 0, "2H / 8 is a multiple of 8");
@@ -328,25 +334,28 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void commnet_forward_ker
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int lr = 32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                As[lr * LDA + H + col] = fast_tanh(xr[rt][reg] + acc[rt][reg] + b);
+                As[lr * LDA + HO + col] = fast_tanh(xr[rt][reg] + acc[rt][reg] + b);
             }
         __syncthreads();
     }
 
     // ---- heads + value head (comm.py:228,239): weights -> rows [0, OT) of the comm half, logits -> zl ------------------------
-    for (int i = tid; i < a.OT * H4; i += NT)
-        As4[(i / H4) * LDA4 + i % H4] = reinterpret_cast<const cn_f32x4*>(a.head_w)[i];
+    cn_f32x4* const hw4 = reinterpret_cast<cn_f32x4*>(tile + a.tile_words);          // NARROW: [16][H] the heads' weights
+    for (int i = tid; i < a.OT * H4; i += NT) {
+        if constexpr (NARROW) hw4[i] = reinterpret_cast<const cn_f32x4*>(a.head_w)[i];
+        else As4[(i / H4) * LDA4 + i % H4] = reinterpret_cast<const cn_f32x4*>(a.head_w)[i];
+    }
     if (a.h_out) {
         for (int idx = tid; idx < rows * H4; idx += NT) {
             const int row = idx / H4, c4 = idx - row * H4;
-            *reinterpret_cast<cn_f32x4*>(a.h_out + (r0 + row) * H + 4 * c4) = As4[row * LDA4 + H4 + c4];
+            *reinterpret_cast<cn_f32x4*>(a.h_out + (r0 + row) * H + 4 * c4) = As4[row * LDA4 + HO4 + c4];
         }
     }
     __syncthreads();
     for (int task = tid; task < rows * a.OT; task += NT) {
         const int row = task / a.OT, o = task - row * a.OT;
-        const cn_f32x4* hp = As4 + row * LDA4 + H4;
-        const cn_f32x4* wo = As4 + o * LDA4;
+        const cn_f32x4* hp = As4 + row * LDA4 + HO4;
+        const cn_f32x4* wo = NARROW ? hw4 + o * H4 : As4 + o * LDA4;
         cn_f32x4 s = { 0.f, 0.f, 0.f, 0.f };
         for (int k = 0; k < H4; ++k) s += hp[k] * wo[k];
         zl[row * 16 + o] = (s[0] + s[1]) + (s[2] + s[3]) + a.head_b[o];
@@ -535,9 +544,10 @@ static size_t commnet_step_tile_words(const ic3_env* env)
     return (w + 3) & ~(size_t)3;
 }
 
-static size_t commnet_step_lds(const ic3_env* env, int H)
+static size_t commnet_step_lds(const ic3_env* env, int H, bool narrow = false)
 {
-    return ((size_t)64 * (2 * H + 4) + 3 * 64 + 64 * 16 + 4 * 64 + commnet_step_tile_words(env)) * sizeof(float);
+    return ((size_t)64 * ((narrow ? H : 2 * H) + 4) + 3 * 64 + 64 * 16 + 4 * 64 + commnet_step_tile_words(env) + (narrow ? 16 * H : 0)) *
+           sizeof(float);
 }
 
 extern "C" int ic3_commnet_step_supported(const ic3_env* env, int H)
@@ -625,9 +635,18 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
     // one-shot (ic3_env_set_step_events): the dispatch itself stamps the caller's events
     hipEvent_t ev0 = (hipEvent_t)env->ev_start, ev1 = (hipEvent_t)env->ev_stop;
     env->ev_start = env->ev_stop = nullptr;
+    // one pass, communication off, split products: the narrow tile (three workgroups per CU)
+    const bool narrow = wp3 && comm_zero && comm_passes == 1;
+    const size_t ldsn = commnet_step_lds(env, H, true);
 #define IC3_CS(h)                                                                                                          \
     case h:                                                                                                                \
-        if (pp) {                                                                                                          \
+        if (narrow && pp) {                                                                                                \
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h, IC3_ENV_PP, true>), ldsn)); \
+            hipExtLaunchKernelGGL((commnet_forward_kernel<h, IC3_ENV_PP, true>), dim3(tiles), dim3(2 * h), ldsn, s, ev0, ev1, 0, a); \
+        } else if (narrow) {                                                                                               \
+            IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h, IC3_ENV_TJ, true>), ldsn)); \
+            hipExtLaunchKernelGGL((commnet_forward_kernel<h, IC3_ENV_TJ, true>), dim3(tiles), dim3(2 * h), ldsn, s, ev0, ev1, 0, a); \
+        } else if (pp) {                                                                                                   \
             IC3_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(commnet_forward_kernel<h, IC3_ENV_PP>), lds));        \
             hipExtLaunchKernelGGL((commnet_forward_kernel<h, IC3_ENV_PP>), dim3(tiles), dim3(2 * h), lds, s, ev0, ev1, 0, a); \
         } else {                                                                                                           \
