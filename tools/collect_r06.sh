@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o train -
   python tools/bench_train.py 8192 3 native pp_scaled 2>&1 | tail -1
   TWO_CHAINS=0 python tools/bench_train.py 8192 6 native pp_hard 2>&1 | tail -1
   TWO_CHAINS=0 ENC_WINDOW=0 python tools/bench_train.py 8192 6 native pp_hard 2>&1 | tail -1 ) > $O/train_batch.txt 2>&1
-( for w in tj_medium_commnet_mlp pp_hard_ic pp_hard_iric tj_hard tj_medium pp_scaled; do python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1; done ) > $O/bench_other_workloads.jsonl
+( for w in tj_medium_commnet_mlp pp_hard_ic pp_hard_iric pp_hard_iric_tanh tj_hard tj_medium pp_scaled; do python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1; done ) > $O/bench_other_workloads.jsonl
 python tools/microbench_bptt.py > $O/microbench_bptt.txt 2>&1
 python tools/bench_collection.py > $O/collection.txt 2>&1
 ls $O $O/prof_rollout $O/prof_train
