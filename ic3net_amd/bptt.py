@@ -493,6 +493,17 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
     elif gap > T:
         gap = 0
     dhead = d_out if d_out.is_contiguous() else d_out.contiguous()
+    # the heads' weight gradient reads only d_out and the recorded h: it runs on a second stream BESIDE the chain (no LDS, a few
+    # waves per CU: it fits next to the chain's workgroups and rides their idle issue slots instead of taking 0.7 ms of its own)
+    side = None
+    if dev.type == 'cuda' and bool(getattr(args, 'heads_grad_beside', True)) and not torch.cuda.is_current_stream_capturing():
+        main = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.get(dev.index)
+        if side is None:
+            side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _heads_grad_episode(rec, d_out, acc, T, R, H)
     ops.bptt_backward(raw, T, E, N, H, rec.gates, rec.hs, rec.cs, dhead, rec.snaps, alive, gate, fc['ps_l_wp3_bwd'], fc['w_heads'],
                       None if mask_zero else net.C_modules[0].weight.detach(), dh_rec, dc_rec, dxh, bias_parts, dcw_parts,
                       mode_avg=mode_avg, comm_zero=mask_zero, detach_gap=gap, row_live=live_flat, row_keep=keep_flat, enc_first=True,
@@ -507,8 +518,14 @@ def _backward_window_native(args, net, raw, rec, d_out, acc, carry, fc):
     acc['b_cat'].add_(bias_parts.sum(0))
     if not mask_zero:
         acc['c_w'].add_(dcw_parts.sum(0))
-    _heads_grad_episode(rec, d_out, acc, T, R, H)
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+    else:
+        _heads_grad_episode(rec, d_out, acc, T, R, H)
     return (dh_rec, dc_rec)
+
+
+_SIDE_STREAMS = {}     # per device: the stream the heads' gradient runs on beside the backward's chain
 
 
 def _ring_fits(dev, nbytes):

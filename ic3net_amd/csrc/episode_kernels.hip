@@ -215,6 +215,7 @@ __global__ __launch_bounds__(EF_THREADS) void returns_scan_kernel(const float* _
 //   d_out[value] = 2 * value_coeff * (value - returns) * alive          (the log-softmax folded in: gradients w.r.t. its INPUT)
 // The three sums: per-workgroup partials in double (fixed order inside a workgroup), summed by the caller.
 // ---------------------------------------------------------------------------------------------------------------------------
+typedef float lg_f32x4 __attribute__((ext_vector_type(4)));
 struct LossGradArgs {
     const float* out;        // [T][R][OT] = [log-probs of every head | value]
     const int32_t* action;   // [T][nheads][R]
@@ -235,8 +236,25 @@ __global__ __launch_bounds__(256) void loss_gradients_kernel(const LossGradArgs 
     if (m < a.M) {
         const long long t = m / a.R;
         const int r = (int)(m - t * a.R), e = r / a.N;
-        const float* o = a.out + m * a.OT;
-        float* d = a.d_out + m * a.OT;
+        // the row in registers (OT <= 16): 16-byte loads / stores when the row is a whole number of them
+        float o[16], d[16];
+        const float* og = a.out + m * a.OT;
+        float* dg = a.d_out + m * a.OT;
+        const bool vec = (a.OT & 3) == 0;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * q < a.OT) {
+                    const lg_f32x4 v = reinterpret_cast<const lg_f32x4*>(og)[q];
+                    o[4 * q] = v[0], o[4 * q + 1] = v[1], o[4 * q + 2] = v[2], o[4 * q + 3] = v[3];
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < a.OT) o[q] = og[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d[q] = 0.f;
         const float value = o[a.OT - 1], ret = a.returns[m], al = a.alive[m], lv = a.live[t * (a.R / a.N) + e];
         const float adv = (ret - value - a.shift) * a.scale;
         const float w = -adv * al;
@@ -264,6 +282,15 @@ __global__ __launch_bounds__(256) void loss_gradients_kernel(const LossGradArgs 
             off += A;
         }
         d[a.OT - 1] = 2.0f * a.value_coeff * (value - ret) * al;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * q < a.OT) reinterpret_cast<lg_f32x4*>(dg)[q] = lg_f32x4{ d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3] };
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < a.OT) dg[q] = d[q];
+        }
         s_act = (double)(-adv * lp_sum * al);
         s_val = (double)((value - ret) * (value - ret) * al);
     }
