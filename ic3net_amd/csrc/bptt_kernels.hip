@@ -703,14 +703,14 @@ extern "C" int ic3_bptt_backward(ic3_env* env, const ic3_bptt* b, ic3_stream str
             ic3_stream scv = (ic3_stream)sc;
             float* dh = b->dh + r0 * H;
             float* dc = b->dc + r0 * H;
-            if (b->detach_gap > 0 && (t + 1) % b->detach_gap == 0) {  // trainer.py:56-60: (h_t, c_t) were handed on detached
-                IC3_HIP(hipMemsetAsync(dh, 0, Rc * H * sizeof(float), sc));
-                IC3_HIP(hipMemsetAsync(dc, 0, Rc * H * sizeof(float), sc));
-            }
+            // trainer.py:56-60: (h_t, c_t) were handed on detached — the gate launch reads zeros for dL/d(h_t, c_t) (null inputs: an
+            // empty descriptor instead of two memsets and their reads)
+            const bool detached = b->detach_gap > 0 && (t + 1) % b->detach_gap == 0;
             float* g = b->gates + ((size_t)t * R + r0) * 4 * H;
             float* dxh = b->dxh + (size_t)t * (size_t)b->dxh_step + r0 * 2 * H;
             if (b->gate_events && ch == 0) IC3_HIP(hipEventRecord((hipEvent_t)b->gate_events[2 * t], sc));
-            int rc = ic3_lstm_gates_backward_given(g, nullptr, 0, nullptr, b->lstm_wp3_bwd, b->cs + ((size_t)t * R + r0) * H, dh, dc, g,
+            int rc = ic3_lstm_gates_backward_given(g, nullptr, 0, nullptr, b->lstm_wp3_bwd, b->cs + ((size_t)t * R + r0) * H,
+                                                   detached ? nullptr : dh, detached ? nullptr : dc, g,
                                                    dc, b->dbias_partials + (r0 / 64) * 4 * H, 1, dxh,
                                                    b->row_live ? b->row_live + (size_t)t * R + r0 : nullptr,
                                                    b->row_keep ? b->row_keep + (size_t)t * R + r0 : nullptr,

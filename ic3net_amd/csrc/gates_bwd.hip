@@ -296,15 +296,16 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? 2 : 1) void lstm_gates_bwd_kern
         }
     }
     const long long nrec = (long long)rows * H * 4;
-    const __amdgpu_buffer_rsrc_t rdh = gb_rsrc(a.dh + r0 * H, nrec);
-    const __amdgpu_buffer_rsrc_t rdc = gb_rsrc(a.dc ? a.dc + r0 * H : a.dh, a.dc ? nrec : 0);   // null: every load reads 0
+    // (dh / dc null: every load reads 0 through an empty descriptor — a detach point of the recurrence costs no memset and no read)
+    const __amdgpu_buffer_rsrc_t rdh = gb_rsrc(a.dh ? a.dh + r0 * H : a.c_prev, a.dh ? nrec : 0);
+    const __amdgpu_buffer_rsrc_t rdc = gb_rsrc(a.dc ? a.dc + r0 * H : a.c_prev, a.dc ? nrec : 0);
     const __amdgpu_buffer_rsrc_t rdp = gb_rsrc(a.dc_prev + r0 * H, nrec);
     const __amdgpu_buffer_rsrc_t rdg = gb_rsrc(a.dgates + r0 * 4 * H, 4 * nrec);
     const int goff = (4 * lh * 4 * H + col) * 4;
-    const __amdgpu_buffer_rsrc_t rgin = gb_rsrc(GIVEN ? a.gates + r0 * 4 * H : a.dh, GIVEN ? 4 * nrec : 0);
+    const __amdgpu_buffer_rsrc_t rgin = gb_rsrc(GIVEN ? a.gates + r0 * 4 * H : a.c_prev, GIVEN ? 4 * nrec : 0);
     const bool cuts = GIVEN != 0 && (a.row_live != nullptr || a.row_keep != nullptr);
-    const __amdgpu_buffer_rsrc_t rlive = gb_rsrc(a.row_live ? a.row_live + r0 : a.dh, a.row_live ? (long long)rows * 4 : 0);
-    const __amdgpu_buffer_rsrc_t rkeep = gb_rsrc(a.row_keep ? a.row_keep + r0 : a.dh, a.row_keep ? (long long)rows * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rlive = gb_rsrc(a.row_live ? a.row_live + r0 : a.c_prev, a.row_live ? (long long)rows * 4 : 0);
+    const __amdgpu_buffer_rsrc_t rkeep = gb_rsrc(a.row_keep ? a.row_keep + r0 : a.c_prev, a.row_keep ? (long long)rows * 4 : 0);
     float si = 0.f, sf = 0.f, sg = 0.f, so = 0.f;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -521,7 +522,7 @@ static int gates_backward_impl(float* xh, int ldx, const float* h_prev, const fl
                                const float* w_heads, int OT)
 {
     using namespace ic3;
-    if ((!gates && (!xh || !lstm_wp || !bias)) || !c_prev || !dh || !dgates || !dc_prev || R <= 0)
+    if ((!gates && (!xh || !lstm_wp || !bias)) || !c_prev || (!dh && !gates) || !dgates || !dc_prev || R <= 0)
         return fail(-22, "ic3_lstm_gates_backward: null argument");
     if (!ic3_lstm_gates_backward_supported(H)) return fail(-38, "ic3_lstm_gates_backward: needs hid_size 64 / 128 / 256");
     if (ldx < 2 * H || (ldx & 3)) return fail(-22, "ic3_lstm_gates_backward: ldx must be a multiple of 4, >= 2 * hid_size");

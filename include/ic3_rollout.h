@@ -375,7 +375,9 @@ int ic3_lstm_gates_backward_dx(float* xh, int ldx, const float* h_prev /* or NUL
  * Round 6: dgates may BE gates (every lane overwrites exactly what it read: the record turns into the weight-gradient
  * product's operand in place); dhead [R][OT] / w_heads [OT][H] (both or neither, OT <= 16): the heads' share of dL/dh_t —
  * dhead . w_heads with dhead = dL/d[logits of every head | value] (comm.py:228,239), w_heads = heads.k.weight stacked, then
- * value_head.weight — is added to dh on the way in, instead of by an R x OT x H product (and a pass over dh) in front. */
+ * value_head.weight — is added to dh on the way in, instead of by an R x OT x H product (and a pass over dh) in front; dh and / or
+ * dc may be NULL = zeros (a detach point of the recurrence, trainer.py:56-60: nothing arrives from the next step — no memset, no
+ * read). */
 int ic3_lstm_gates_backward_given(const float* gates, float* xh /* or NULL */, int ldx, const float* h_prev /* or NULL */,
                                   const void* lstm_wp3_bwd /* or NULL */, const float* c_prev, const float* dh,
                                   const float* dc /* or NULL */, float* dgates, float* dc_prev, float* dbias_partials /* or NULL */,
