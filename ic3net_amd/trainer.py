@@ -182,8 +182,10 @@ class Trainer(object):
             # the reset obs launch is only skipped when the coming episode will take the one-launch path again (its
             # first step writes the rows of the reset state itself): the previous episode did, and nothing that decides
             # it has changed since
+            # ... or nothing reads the rows at all (the training rollout of the native update: args.dense_obs off, the sparse
+            # encoder reads the integer state)
             raw0.skip_reset_obs = bool(getattr(self, '_mega_last', False) and self._mega_expected(raw0)
-                                       and self._fused_obs() and self._dense_obs())
+                                       and (not self._dense_obs() or self._fused_obs()))
         self._mega_prev = bool(getattr(self, '_mega_last', False))     # (zero_hidden hands the launch its own buffers)
         self._mega_last = False
         cont = self._stream_continues()
