@@ -156,14 +156,33 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
         }
         __syncthreads();
         // ---- the dense observation rows of the state this step acts on (trainer.py:49), every element stored once ------------
-        if (a.obs) {
-            if constexpr (KIND == IC3_ENV_PP) {
+        // Round 6, TJ: the tile's contiguous chunk of the obs tensor (~96-98 % zeros) is ZERO-FILLED here with 16-byte stores — no
+        // per-element evaluation (it was a quarter of this kernel's vector instructions, profiles/r06/pmc_commnet.txt) — and the few
+        // non-zero entries are patched in behind the draws, after every wave has seen its zero stores complete (as
+        // policy_step_kernel and tj_obs_fill_kernel do; bit-identical to ic3_env_observe).
+        if constexpr (KIND == IC3_ENV_PP) {
+            // (PP rows — 145 KB per env — keep the run-based store, every element evaluated and stored once: with the zero fill the
+            //  wait for a tile's 872 KB of stores in front of the patches holds the workgroup's CU slot; IC launch 0.294 against 0.261 ms)
+            if (a.obs) {
                 const int vocab = a.pp.dim * a.pp.dim + 4;
                 if ((vocab & 3) == 0) pp_obs_store_run(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
                 else pp_obs_store_run_scalar(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
-            } else {
-                tj_obs_store_run(tile, tjw, a.tj, a.obs, e0, nenv, tid, NT, 0, 1);
             }
+        } else if (a.obs) {
+            const long long b0 = (long long)e0 * N * a.obs_dim;  // first float of the tile's chunk
+            const long long L = (long long)nenv * N * a.obs_dim;
+            float* out = a.obs + b0;
+            const int head = (int)((4 - (b0 & 3)) & 3);
+            const long long nb = (L - head) >> 2;
+            const int tail = (int)((L - head) & 3);
+            if (tid < head) out[tid] = 0.0f;
+            if (tid < tail) out[head + 4 * nb + tid] = 0.0f;
+            cn_f32x4* out4 = reinterpret_cast<cn_f32x4*>(out + head);
+            const cn_f32x4 z4 = { 0.f, 0.f, 0.f, 0.f };
+            const int o = (int)(((b0 + head) >> 2) & 63);        // 1 KiB-aligned wave stores
+            long long j = tid - o;
+            if (j < 0) j += NT;
+            for (; j < nb; j += NT) __builtin_nontemporal_store(z4, out4 + j);
         }
         // ---- x = tanh(encoder(obs)) as a sparse gather (comm.py:119,127-129) -> h half ------------------------------------------
         const PtrRows encW = { a.Wt }, encL = { a.loc_table };
@@ -398,6 +417,19 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
         }
     }
     if constexpr (KIND != 0) {
+        // ---- the non-zero entries of the tile's obs rows, on top of the zero fill issued at the start ---------------------------
+        if constexpr (KIND == IC3_ENV_TJ) {
+            if (a.obs) {
+                IC3_WAIT_VMEM();                                 // this wave's zero stores ...
+                __syncthreads();                                 // ... and every other wave's have completed
+                float* orow0 = a.obs + (size_t)e0 * N * a.obs_dim;
+                const float inv_q = 1.0f / (float)(nsegE + N);
+                for (int sg = tid; sg < nenv * (nsegE + N); sg += NT) {
+                    const int el = div_small(sg, inv_q), q = sg - el * (nsegE + N);
+                    tj_obs_patch(tj_tile_at(tile + el * tjw, N), a.tj, orow0 + (size_t)el * N * a.obs_dim, a.obs_dim, WW, q);
+                }
+            }
+        }
         // ---- env.step for the tile's envs with the env-action head (env_wrappers.py:76-77) -------------------------------------
         __syncthreads();
         const int lgG = __builtin_ctz(a.G);
