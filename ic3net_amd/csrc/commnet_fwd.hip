@@ -567,6 +567,39 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
     return 0;
 }
 
+// Envs per tile of the NARROW Predator-Prey launch (the IC baseline's stand-in, the tanh recurrence).  That launch is bound by its
+// obs stores (6 % of the matrix peak): a tile costs its bytes (~ its envs) plus a fixed part (descriptors, the weights' fragments,
+// the dependent chain behind the product — measured ~0.15 of one env's stores), and the launch lasts as long as the CU with the most
+// tiles: the dispatcher deals the workgroups round-robin, so a tile count that is no multiple of the CU count leaves some CUs one
+// tile more than the others (8192 envs of 10 agents: 1366 tiles of 6 envs = 5.3 per CU against 2048 tiles of 4 envs = 8 per CU;
+// 0.254-0.260 -> 0.241-0.247 ms per launch on the same box).  Half of that imbalance is charged: late tiles on emptier CUs run faster.  Results do not depend
+// on the tile size (rows are independent; the draws are keyed per env).  profiles/r06/commnet_ept_sweep.txt: six env counts x
+// five tile sizes against this choice.
+static int plan_store_bound_ept(int E, int ept_max)
+{
+    static int cu_count[64] = { 0 };   // per device (a process may drive several GPUs)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (!cu_count[dev]) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cu_count[dev] = prop.multiProcessorCount;
+        }
+        if (cu_count[dev]) cus = cu_count[dev];
+    }
+    int best = ept_max;
+    double best_cost = 0.0;
+    for (int ept = ept_max; ept >= 1 && ept >= ept_max / 3; --ept) {
+        const int tiles = (E + ept - 1) / ept;
+        const double per_cu = (double)tiles / cus, worst = (double)((tiles + cus - 1) / cus);
+        const double cost = 0.5 * (per_cu + worst) * (ept + 0.15);
+        if (ept == ept_max || cost < best_cost - 1e-9) {
+            best = ept;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 static size_t commnet_step_tile_words(const ic3_env* env)
 {
     const int N = env->dims.N, EPT = 64 / N, WW = env->dims.window * env->dims.window;
@@ -662,7 +695,6 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
         a.gid0 = env->tj.env_id_offset;
     }
     env->touch_obs(obs);
-    const int tiles = (a.E + a.EPT - 1) / a.EPT;
     hipStream_t s = (hipStream_t)stream;
     // one-shot (ic3_env_set_step_events): the dispatch itself stamps the caller's events
     hipEvent_t ev0 = (hipEvent_t)env->ev_start, ev1 = (hipEvent_t)env->ev_stop;
@@ -670,6 +702,8 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
     // one pass, communication off, split products: the narrow tile (three workgroups per CU)
     const bool narrow = wp3 && comm_zero && comm_passes == 1;
     const size_t ldsn = commnet_step_lds(env, H, true);
+    if (narrow && pp && obs) a.EPT = plan_store_bound_ept(a.E, a.EPT);
+    const int tiles = (a.E + a.EPT - 1) / a.EPT;
 #define IC3_CS(h)                                                                                                          \
     case h:                                                                                                                \
         if (narrow && pp) {                                                                                                \

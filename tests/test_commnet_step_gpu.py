@@ -146,3 +146,28 @@ def test_commnet_step_refuses_what_it_does_not_cover():
     assert ops.commnet_step_supported(raw, 128) and not ops.commnet_step_supported(raw, 96)
     raw.set_auto_reset(5)
     assert ops.commnet_step_supported(raw, 128)          # (round 5: episode starts inside the launch are handled here too)
+
+
+@pytest.mark.parametrize("wl", ["pp_hard_ic", "pp_hard_iric_tanh"])
+def test_narrow_launch_does_not_depend_on_its_tile_plan(wl):
+    """The narrow Predator-Prey launch picks its envs per tile from the env count (plan_store_bound_ept in csrc/commnet_fwd.hip:
+    2 / 3 / 6 / 4 envs per tile at the counts below).  An env's trajectory is keyed by (seed, env id) alone: the first 24 envs of
+    every run — obs rows, log-probs, values, draws, rewards — are the same bits whatever tile they sat in."""
+    import bench
+    runs = []
+    for E in (24, 600, 1536, 2048):
+        tr, a = bench.build_trainer(wl, E, 3, 40, 0, max_steps=6)
+        tr.begin_episode(0)
+        rec = []
+        for t in range(6):
+            tr.step_episode(t)
+            _, action_out, value, _ = tr._step_out[t]
+            rec.append((action_out[0].reshape(E, 10, -1)[:24].clone(), value.reshape(E, 10)[:24].clone(),
+                        tr._buf['action'][t][:, :24].clone(), tr._buf['reward'][t][:24].clone(),
+                        tr.env.env._obs[:24].clone()))
+        assert getattr(tr.policy_net, 'commnet_steps', 0) == 6, "the one-launch path did not run"
+        runs.append(rec)
+    for other in runs[1:]:
+        for t in range(6):
+            for x, y in zip(runs[0][t], other[t]):
+                assert torch.equal(x, y), t
