@@ -18,6 +18,7 @@
 // (action_utils.py:32-36, the counters of ic3_env_sample_actions) -> env.step (pp/tj_step_lanes: the device functions the
 // stand-alone step kernels and policy_step_kernel run).  Five launches per step before (encode, this kernel's policy part,
 // draws, step, obs).
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -43,6 +44,7 @@ struct CommnetArgs {
     const float* h_in;         // [R][H] or null.  Non-null = the tanh RECURRENCE of models.RNN (models.py:68-92, rnn_type 'MLP'):
                                // h_t = tanh(affine1(obs) + affine2(h_{t-1})): x = enc WITHOUT the tanh, h_0 = h_in (one pass, comm off)
     int E, N, EPT, passes, mode_avg, comm_zero, nheads, OT, a0, a1, a2, a3;
+    int n_full, EPTs;          // tiles [0, n_full) hold EPT envs, the tiles behind them EPTs envs (<= 32 rows: one 32-row MFMA tile)
     // ic3_commnet_step (KIND != 0): the env side of the iteration
     const cn_f32x4* Wt;        // encoder.weight^T [obs_dim][H/4]
     const cn_f32x4* enc_bias;  // encoder.bias [H/4]
@@ -89,7 +91,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
     int32_t* const tile = sts + BM;                              // env descriptors of the tile's envs
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int col = 32 * w + li, N = a.N;
-    const int e0 = blockIdx.x * a.EPT, nenv = min(a.EPT, a.E - e0), rows = nenv * N;
+    const int bid = blockIdx.x;
+    const bool short_tile = bid >= a.n_full;                      // (plan_commnet_tiles: full tiles first, short ones behind)
+    const int e0 = short_tile ? a.n_full * a.EPT + (bid - a.n_full) * a.EPTs : bid * a.EPT;
+    const int nenv = min(short_tile ? a.EPTs : a.EPT, a.E - e0), rows = nenv * N;
+    const bool two = rows > 32;                                  // the second 32-row MFMA tile holds rows (workgroup-uniform)
     const size_t r0 = (size_t)e0 * N;
     const int WW = (KIND == 0) ? 0 : (KIND == IC3_ENV_PP) ? (2 * a.pp.v + 1) * (2 * a.pp.v + 1) : (2 * a.tj.v + 1) * (2 * a.tj.v + 1);
     const int total = a.pp.Np + a.pp.nprey;
@@ -288,31 +294,39 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
             };
             const int kb0 = (NARROW || a.comm_zero) ? KB16 / 2 : 0;   // (comm_mask_zero / the IC stand-in: the comm half is all zeros)
             constexpr int AOFF = NARROW ? H4 : 0;                // (NARROW: the tile starts at k = H)
-            ps_u32x4 bq[3], bn[3];
+            // the loop in two copies, chosen once per tile: a short tile (rows <= 32, plan_commnet_tiles) runs the first 32-row MFMA
+            // tile only — a branch inside the loop cost the full tiles 5 % (profiles/r06/commnet_ept_sweep.txt)
+            auto product = [&](auto two_c) __attribute__((always_inline)) {
+                constexpr bool TWO = decltype(two_c)::value;
+                ps_u32x4 bq[3], bn[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bq[pl] = wb(pl, kb0);
-            CN_PRIO(0);
+                for (int pl = 0; pl < 3; ++pl) bq[pl] = wb(pl, kb0);
+                CN_PRIO(0);
 #pragma unroll 2
-            for (int kb = kb0; kb < KB16; ++kb) {
+                for (int kb = kb0; kb < KB16; ++kb) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bn[pl] = wb(pl, kb + 1);                      // (past the end: zeros, never used)
-                ps_u32x4 ap[2][3];
-                const cn_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh - AOFF;
-                const cn_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh - AOFF;
-                ps_split_frag(s0[0], s0[1], ap[0]);
-                ps_split_frag(s1[0], s1[1], ap[1]);
+                    for (int pl = 0; pl < 3; ++pl) bn[pl] = wb(pl, kb + 1);                  // (past the end: zeros, never used)
+                    ps_u32x4 ap[2][3];
+                    const cn_f32x4* s0 = As4 + li * LDA4 + 4 * kb + 2 * lh - AOFF;
+                    const cn_f32x4* s1 = As4 + (32 + li) * LDA4 + 4 * kb + 2 * lh - AOFF;
+                    ps_split_frag(s0[0], s0[1], ap[0]);
+                    if constexpr (TWO) ps_split_frag(s1[0], s1[1], ap[1]);
 #pragma unroll
-                for (int pb = 0; pb < 3; ++pb)
+                    for (int pb = 0; pb < 3; ++pb)
 #pragma unroll
-                    for (int pa = 2; pa >= 0; --pa) {                                        // (least significant term first)
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8, ap[0][pa]),
-                                                                         __builtin_bit_cast(cn_bf16x8, bq[pb]), acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8, ap[1][pa]),
-                                                                         __builtin_bit_cast(cn_bf16x8, bq[pb]), acc[1], 0, 0, 0);
-                    }
+                        for (int pa = 2; pa >= 0; --pa) {                                    // (least significant term first)
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8, ap[0][pa]),
+                                                                             __builtin_bit_cast(cn_bf16x8, bq[pb]), acc[0], 0, 0, 0);
+                            if constexpr (TWO)
+                                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cn_bf16x8, ap[1][pa]),
+                                                                                 __builtin_bit_cast(cn_bf16x8, bq[pb]), acc[1], 0, 0, 0);
+                        }
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bq[pl] = bn[pl];
-            }
+                    for (int pl = 0; pl < 3; ++pl) bq[pl] = bn[pl];
+                }
+            };
+            if (two) product(std::true_type{});
+            else product(std::false_type{});
         } else if constexpr (!NARROW) {
         const cn_f32x4* wp = reinterpret_cast<const cn_f32x4*>(a.wp) + (size_t)pass * (K * H / 4) + col * 2 + lh;
         constexpr int CH = 8;
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], cb[half][k][j], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], cb[half][k][j], acc[1], 0, 0, 0);
+                        if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], cb[half][k][j], acc[1], 0, 0, 0);
                     }
                 }
             }
@@ -550,6 +564,8 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
     a.a2 = sz[2];
     a.a3 = sz[3];
     const int tiles = (E + a.EPT - 1) / a.EPT;
+    a.n_full = tiles;
+    a.EPTs = a.EPT;
     const size_t lds = ((size_t)64 * (2 * H + 4) + 3 * 64 + 64 * 16 + 4 * 64) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define IC3_CN(h)                                                                                                 \
@@ -575,17 +591,21 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
 // 0.254-0.260 -> 0.241-0.247 ms per launch on the same box).  Half of that imbalance is charged: late tiles on emptier CUs run faster.  Results do not depend
 // on the tile size (rows are independent; the draws are keyed per env).  profiles/r06/commnet_ept_sweep.txt: six env counts x
 // five tile sizes against this choice.
-static int plan_store_bound_ept(int E, int ept_max)
+static int commnet_cus()
 {
     static int cu_count[64] = { 0 };   // per device (a process may drive several GPUs)
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        if (!cu_count[dev]) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cu_count[dev] = prop.multiProcessorCount;
-        }
-        if (cu_count[dev]) cus = cu_count[dev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cu_count[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cu_count[dev] = prop.multiProcessorCount;
     }
+    return cu_count[dev] ? cu_count[dev] : 256;
+}
+
+static int plan_store_bound_ept(int E, int ept_max)
+{
+    const int cus = commnet_cus();
     int best = ept_max;
     double best_cost = 0.0;
     for (int ept = ept_max; ept >= 1 && ept >= ept_max / 3; --ept) {
@@ -598,6 +618,31 @@ static int plan_store_bound_ept(int E, int ept_max)
         }
     }
     return best;
+}
+
+// Tiles of the launches that are bound by their vector / matrix work (every instantiation but the narrow Predator-Prey one): a.EPT
+// = 64 / N envs fill the 64-row tile, and a tile count that is no multiple of the CU count leaves some CUs a whole tile more than the
+// others (8192 envs of 10 agents: 1366 tiles = 5.3 per CU; E = 7680 / 8192 / 9216 cost 0.137 / 0.152 / 0.156 ms on TJ-medium).  As
+// policy_step_kernel's plan B: as many FULL tiles as give every CU the same number, the rest as SHORT tiles of 32 / N envs (one
+// 32-row MFMA tile: half the matrix work and half the rows' vector work — measured 0.5 of a full tile) dispatched
+// behind them; taken when at least one round of full tiles remains and the CU with the most work ends earlier.  Results do not
+// depend on the plan (GPU test).  Returns the number of workgroups.
+static int plan_commnet_tiles(ic3::CommnetArgs& a)
+{
+    const int n_all = (a.E + a.EPT - 1) / a.EPT;
+    a.n_full = n_all;
+    a.EPTs = a.EPT;
+    const int cus = commnet_cus(), epts = 32 / a.N;
+    if (epts < 1) return n_all;
+    const int n_full = (a.E / a.EPT) / cus * cus;
+    if (n_full < cus) return n_all;
+    const int n_short = (a.E - n_full * a.EPT + epts - 1) / epts;
+    if (n_full / cus + 0.5 * ((n_short + cus - 1) / cus) < (double)((n_all + cus - 1) / cus) - 1e-9) {
+        a.n_full = n_full;
+        a.EPTs = epts;
+        return n_full + n_short;
+    }
+    return n_all;
 }
 
 static size_t commnet_step_tile_words(const ic3_env* env)
@@ -702,8 +747,15 @@ extern "C" int ic3_commnet_step(ic3_env* env, const float* enc_wt, const float* 
     // one pass, communication off, split products: the narrow tile (three workgroups per CU)
     const bool narrow = wp3 && comm_zero && comm_passes == 1;
     const size_t ldsn = commnet_step_lds(env, H, true);
-    if (narrow && pp && obs) a.EPT = plan_store_bound_ept(a.E, a.EPT);
-    const int tiles = (a.E + a.EPT - 1) / a.EPT;
+    int tiles;
+    if (narrow && pp && obs) {
+        a.EPT = plan_store_bound_ept(a.E, a.EPT);
+        tiles = (a.E + a.EPT - 1) / a.EPT;
+        a.n_full = tiles;
+        a.EPTs = a.EPT;
+    } else {
+        tiles = plan_commnet_tiles(a);
+    }
 #define IC3_CS(h)                                                                                                          \
     case h:                                                                                                                \
         if (narrow && pp) {                                                                                                \
