@@ -583,14 +583,7 @@ extern "C" int ic3_commnet_forward(const float* enc, int E, int N, int H, int co
     return 0;
 }
 
-// Envs per tile of the NARROW Predator-Prey launch (the IC baseline's stand-in, the tanh recurrence).  That launch is bound by its
-// obs stores (6 % of the matrix peak): a tile costs its bytes (~ its envs) plus a fixed part (descriptors, the weights' fragments,
-// the dependent chain behind the product — measured ~0.15 of one env's stores), and the launch lasts as long as the CU with the most
-// tiles: the dispatcher deals the workgroups round-robin, so a tile count that is no multiple of the CU count leaves some CUs one
-// tile more than the others (8192 envs of 10 agents: 1366 tiles of 6 envs = 5.3 per CU against 2048 tiles of 4 envs = 8 per CU;
-// 0.254-0.260 -> 0.241-0.247 ms per launch on the same box).  Half of that imbalance is charged: late tiles on emptier CUs run faster.  Results do not depend
-// on the tile size (rows are independent; the draws are keyed per env).  profiles/r06/commnet_ept_sweep.txt: six env counts x
-// five tile sizes against this choice.
+// CUs of the current device (the tile plans below)
 static int commnet_cus()
 {
     static int cu_count[64] = { 0 };   // per device (a process may drive several GPUs)
@@ -603,6 +596,14 @@ static int commnet_cus()
     return cu_count[dev] ? cu_count[dev] : 256;
 }
 
+// Envs per tile of the NARROW Predator-Prey launch (the IC baseline's stand-in, the tanh recurrence).  That launch is bound by its
+// obs stores (6 % of the matrix peak): a tile costs its bytes (~ its envs) plus a fixed part (descriptors, the weights' fragments,
+// the dependent chain behind the product — measured ~0.15 of one env's stores), and the launch lasts as long as the CU with the most
+// tiles: the dispatcher deals the workgroups round-robin, so a tile count that is no multiple of the CU count leaves some CUs one
+// tile more than the others (8192 envs of 10 agents: 1366 tiles of 6 envs = 5.3 per CU against 2048 tiles of 4 envs = 8 per CU;
+// 0.254-0.260 -> 0.241-0.247 ms per launch on the same box).  Half of that imbalance is charged: late tiles on emptier CUs run faster.  Results do not depend
+// on the tile size (rows are independent; the draws are keyed per env).  profiles/r06/commnet_ept_sweep.txt: six env counts x
+// five tile sizes against this choice.
 static int plan_store_bound_ept(int E, int ept_max)
 {
     const int cus = commnet_cus();
