@@ -171,7 +171,11 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
             //  wait for a tile's 872 KB of stores in front of the patches holds the workgroup's CU slot; IC launch 0.294 against 0.261 ms)
             if (a.obs) {
                 const int vocab = a.pp.dim * a.pp.dim + 4;
-                if ((vocab & 3) == 0) pp_obs_store_run(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
+                // the tanh recurrence streams h_in / h_out (84 MB per launch) next to the rows: with plain stores the rows wash them out of
+                // the L2 (0.275 against 0.254 ms per PP-hard launch); without that traffic plain stores are the faster ones (IC: 0.245
+                // against 0.259 ms) — same-box A/B, profiles/r06/commnet_ept_sweep.txt
+                if ((vocab & 3) == 0 && a.h_in) pp_obs_store_run<true>(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
+                else if ((vocab & 3) == 0) pp_obs_store_run<false>(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
                 else pp_obs_store_run_scalar(ptab, a.obs, e0, nenv, nsegE, vocab, tid, NT, 0, 1);
             }
         } else if (a.obs) {
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(2 * H, (H <= 128) ? (NARROW ? 3 : 2) : 1) void comm
             const int o = (int)(((b0 + head) >> 2) & 63);        // 1 KiB-aligned wave stores
             long long j = tid - o;
             if (j < 0) j += NT;
-            for (; j < nb; j += NT) __builtin_nontemporal_store(z4, out4 + j);
+            for (; j < nb; j += NT) out4[j] = z4;   // (plain stores: the rows are small — 21 KB per env — and the patches then meet their lines
+                                                    //  in the L2; non-temporal: 0.146 against 0.143 ms per TJ-medium launch)
         }
         // ---- x = tanh(encoder(obs)) as a sparse gather (comm.py:119,127-129) -> h half ------------------------------------------
         const PtrRows encW = { a.Wt }, encL = { a.loc_table };

@@ -590,6 +590,8 @@ __device__ __forceinline__ dv_f32x4 tj_encode_row(const TJTile& t, const TJState
 // ------------------------------------------------------------------------------------------------
 // PP, vocab % 4 == 0: every float4 lies inside one window cell; lane -> float4 map shifted so that wave stores are
 // 1 KiB-aligned in the global address space (see pp_obs_kernel).
+// NTS: non-temporal stores (the caller streams other data through the L2 next to the rows — commnet_fwd.hip)
+template <bool NTS = false>
 __device__ __forceinline__ void pp_obs_store_run(const int2* tab, float* __restrict__ obs, long long e0, int nenv,
                                                  int nsegE, int vocab, int t, int nthr, int part, int nparts)
 {
@@ -620,7 +622,8 @@ __device__ __forceinline__ void pp_obs_store_run(const int2* tab, float* __restr
             z.z += (float)(d.y >> 16);
             z.w += (float)(d.y & 0xffff);
         }
-        out[g] = z;
+        if constexpr (NTS) __builtin_nontemporal_store(z, out + g);
+        else out[g] = z;
     }
 }
 
