@@ -173,9 +173,9 @@ def test_narrow_launch_does_not_depend_on_its_tile_plan(wl):
                 assert torch.equal(x, y), t
 
 
-def _play_first_steps(wl, E, offset, T, sl):
+def _play_first_steps(wl, E, offset, T, sl, **over):
     import bench
-    tr, a = bench.build_trainer(wl, E, 3, offset, 0, max_steps=T)
+    tr, a = bench.build_trainer(wl, E, 3, offset, 0, max_steps=T, **over)
     tr.begin_episode(0)
     N = a.nagents
     rec = []
@@ -188,18 +188,20 @@ def _play_first_steps(wl, E, offset, T, sl):
     return rec
 
 
-@pytest.mark.parametrize("wl", ["tj_medium_commnet_mlp", "pp_hard_iric_tanh"])
-def test_full_and_short_tiles_give_the_same_bits(wl):
+@pytest.mark.parametrize("wl,over", [("tj_medium_commnet_mlp", dict()), ("pp_hard_iric_tanh", dict()),
+                                     ("tj_medium_commnet_mlp", dict(hid_size=64)), ("tj_medium_commnet_mlp", dict(hid_size=256))],
+                         ids=["tj_commnet", "pp_tanh", "tj_commnet_h64", "tj_commnet_h256"])
+def test_full_and_short_tiles_give_the_same_bits(wl, over):
     """plan_commnet_tiles (csrc/commnet_fwd.hip): at 2048 envs of 10 agents the launch runs 256 full tiles of 6 envs and 171 short
     tiles of 3 envs (one 32-row MFMA tile) behind them; at 24 envs full tiles only.  Envs [0, 24) of the big launch sit in full
     tiles, envs [2024, 2048) in short ones: both equal the same env ids played by a 24-env launch, bit for bit.  (The narrow
     Predator-Prey launch with obs rows takes its own plan — test_narrow_launch_does_not_depend_on_its_tile_plan; without this
     plan's short tiles the second comparison still pins the env-id keying.)"""
     T = 6
-    big_lo = _play_first_steps(wl, 2048, 40, T, slice(0, 24))
-    big_hi = _play_first_steps(wl, 2048, 40, T, slice(2024, 2048))
-    small_lo = _play_first_steps(wl, 24, 40, T, slice(0, 24))
-    small_hi = _play_first_steps(wl, 24, 40 + 2024, T, slice(0, 24))
+    big_lo = _play_first_steps(wl, 2048, 40, T, slice(0, 24), **over)
+    big_hi = _play_first_steps(wl, 2048, 40, T, slice(2024, 2048), **over)
+    small_lo = _play_first_steps(wl, 24, 40, T, slice(0, 24), **over)
+    small_hi = _play_first_steps(wl, 24, 40 + 2024, T, slice(0, 24), **over)
     for big, small in ((big_lo, small_lo), (big_hi, small_hi)):
         for t in range(T):
             for x, y in zip(big[t], small[t]):
