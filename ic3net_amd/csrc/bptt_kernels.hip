@@ -514,7 +514,12 @@ extern "C" int ic3_comm_backward_partials(int E, int N)
 {
     if (E <= 0 || N <= 0 || N > 64) return 0;
     const int ept = 64 / N, tiles = (E + ept - 1) / ept;
-    return tiles < 512 ? tiles : 512;     // (two workgroups per CU; 768 / 1024 slots measured: 109 M against 111 M agent-steps/s per PP-hard update)
+    constexpr int cap = 512;
+    // at most 512 workgroups (two per CU; 768 / 1024 slots measured: 109 M against 111 M agent-steps/s per PP-hard update), every one
+    // the same number of tiles: the launch lasts as long as the workgroup with the most tiles either way, and every workgroup fewer
+    // is 2 x H x H x 4 bytes of partial sums less to add to (a chain of 4096 envs of 10 agents: 683 tiles as 342 x 2, not 171 x 2 + 341 x 1)
+    const int rounds = (tiles + cap - 1) / cap;
+    return (tiles + rounds - 1) / rounds;
 }
 
 extern "C" int ic3_comm_backward(const float* dxh, int ldd, const float* h_prev, const int32_t* alive, const int32_t* gate,
